@@ -1,0 +1,238 @@
+"""ctypes binding of include/dxtex_amd.h. One-to-one with the C ABI; numpy arrays carry host pixels,
+integers carry device pointers (e.g. ``torch.Tensor.data_ptr()``)."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import formats as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libdxtex_amd.so")
+
+
+def _load():
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the MI355X path)")
+    try:
+        # Share PyTorch's HIP runtime when PyTorch is in the process (same SONAME libamdhip64.so.7), so that
+        # torch device pointers and streams are valid in this library.
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
+    return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
+class Image(ctypes.Structure):
+    """Mirrors ``dxtex_image`` / ``DirectX::Image`` (DirectXTex.h:437-445)."""
+    _fields_ = [("width", ctypes.c_size_t), ("height", ctypes.c_size_t), ("format", ctypes.c_int32),
+                ("rowPitch", ctypes.c_size_t), ("slicePitch", ctypes.c_size_t), ("pixels", ctypes.c_void_p)]
+
+
+_lib = _load()
+_P = ctypes.POINTER
+_ctx_p = ctypes.c_void_p
+
+_SIGS = {
+    "dxtex_ctx_create": (ctypes.c_int32, [ctypes.c_int, _P(_ctx_p)]),
+    "dxtex_ctx_destroy": (None, [_ctx_p]),
+    "dxtex_ctx_set_stream": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p]),
+    "dxtex_ctx_get_stream": (ctypes.c_void_p, [_ctx_p]),
+    "dxtex_ctx_synchronize": (ctypes.c_int32, [_ctx_p]),
+    "dxtex_ctx_last_error": (ctypes.c_char_p, [_ctx_p]),
+    "dxtex_ctx_last_kernel_ms": (ctypes.c_float, [_ctx_p]),
+    "dxtex_is_compressed": (ctypes.c_int, [ctypes.c_int32]),
+    "dxtex_bits_per_pixel": (ctypes.c_size_t, [ctypes.c_int32]),
+    "dxtex_compute_pitch": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, _P(ctypes.c_size_t), _P(ctypes.c_size_t)]),
+    "dxtex_compress": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
+    "dxtex_compress_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
+    "dxtex_compress_many_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_size_t, ctypes.c_uint32, ctypes.c_float]),
+    "dxtex_decompress": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image)]),
+    "dxtex_decompress_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image)]),
+    "dxtex_encode_blocks": (ctypes.c_int32, [_ctx_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "dxtex_decode_blocks": (ctypes.c_int32, [_ctx_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "dxtex_generate_mips": (ctypes.c_int32, [_ctx_p, _P(Image), ctypes.c_size_t, ctypes.c_uint32]),
+    "dxtex_generate_mips_device": (ctypes.c_int32, [_ctx_p, _P(Image), ctypes.c_size_t, ctypes.c_uint32]),
+    "dxtex_convert": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
+    "dxtex_convert_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
+    "dxtex_resize": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32]),
+    "dxtex_resize_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32]),
+    "dxtex_compute_mse_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), _P(ctypes.c_double)]),
+    "dxtex_device_alloc": (ctypes.c_int32, [_ctx_p, ctypes.c_size_t, _P(ctypes.c_void_p)]),
+    "dxtex_device_free": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p]),
+    "dxtex_memcpy_h2d": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "dxtex_memcpy_d2h": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(_lib, _name)     # AttributeError here == the .so does not export what the header declares
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+class DxtexError(RuntimeError):
+    def __init__(self, hr, msg=""):
+        self.hresult = hr
+        super().__init__(f"HRESULT 0x{hr & 0xFFFFFFFF:08X} {msg}".strip())
+
+
+def compute_pitch(fmt, width, height):
+    rp, sp = ctypes.c_size_t(), ctypes.c_size_t()
+    hr = _lib.dxtex_compute_pitch(fmt, width, height, ctypes.byref(rp), ctypes.byref(sp))
+    if hr != 0:
+        raise DxtexError(hr, "compute_pitch")
+    return rp.value, sp.value
+
+
+def is_compressed(fmt):
+    return bool(_lib.dxtex_is_compressed(fmt))
+
+
+def bits_per_pixel(fmt):
+    return int(_lib.dxtex_bits_per_pixel(fmt))
+
+
+def _host_image(arr, width, height, fmt, row_pitch=None):
+    """numpy buffer -> dxtex_image (host pointer). `arr` must be C-contiguous."""
+    assert arr.flags["C_CONTIGUOUS"]
+    rp, sp = compute_pitch(fmt, width, height)
+    if row_pitch is not None:
+        rows = sp // rp
+        rp, sp = row_pitch, row_pitch * rows
+    assert arr.nbytes >= sp, (arr.nbytes, sp)
+    return Image(width, height, fmt, rp, sp, arr.ctypes.data)
+
+
+def device_image(ptr, width, height, fmt, row_pitch=None):
+    rp, sp = compute_pitch(fmt, width, height)
+    if row_pitch is not None:
+        rows = sp // rp
+        rp, sp = row_pitch, row_pitch * rows
+    return Image(width, height, fmt, rp, sp, ptr)
+
+
+class Context:
+    """One context per GPU (``dxtex_ctx``)."""
+
+    def __init__(self, device=0):
+        self._h = _ctx_p()
+        hr = _lib.dxtex_ctx_create(device, ctypes.byref(self._h))
+        if hr != 0:
+            raise DxtexError(hr, "dxtex_ctx_create: no usable gfx950 device (this library has no CPU path)")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            _lib.dxtex_ctx_destroy(self._h)
+            self._h = _ctx_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, hr, what):
+        if hr != 0:
+            raise DxtexError(hr, f"{what}: {_lib.dxtex_ctx_last_error(self._h).decode()}")
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._check(_lib.dxtex_ctx_set_stream(self._h, stream_ptr), "set_stream")
+
+    def stream(self):
+        return _lib.dxtex_ctx_get_stream(self._h)
+
+    def synchronize(self):
+        self._check(_lib.dxtex_ctx_synchronize(self._h), "synchronize")
+
+    def last_kernel_ms(self):
+        return float(_lib.dxtex_ctx_last_kernel_ms(self._h))
+
+    # -- Compress -----------------------------------------------------------------------------------
+    def compress(self, pixels, width, height, src_format, dst_format, flags=0, threshold=0.5, src_row_pitch=None):
+        """Host image (numpy, any dtype, C-contiguous rows) -> numpy uint8 BC payload (tight pitch)."""
+        pixels = np.ascontiguousarray(pixels)
+        src = _host_image(pixels, width, height, src_format, src_row_pitch)
+        rp, sp = compute_pitch(dst_format, width, height)
+        out = np.zeros(sp, np.uint8)
+        dst = Image(width, height, dst_format, rp, sp, out.ctypes.data)
+        self._check(_lib.dxtex_compress(self._h, ctypes.byref(src), ctypes.byref(dst), flags, threshold), "compress")
+        return out
+
+    def compress_device(self, src_ptr, width, height, src_format, dst_ptr, dst_format, flags=0, threshold=0.5, src_row_pitch=None):
+        src = device_image(src_ptr, width, height, src_format, src_row_pitch)
+        dst = device_image(dst_ptr, width, height, dst_format)
+        self._check(_lib.dxtex_compress_device(self._h, ctypes.byref(src), ctypes.byref(dst), flags, threshold), "compress_device")
+
+    def compress_many_device(self, srcs, dsts, flags=0, threshold=0.5):
+        n = len(srcs)
+        a = (Image * n)(*srcs)
+        b = (Image * n)(*dsts)
+        self._check(_lib.dxtex_compress_many_device(self._h, a, b, n, flags, threshold), "compress_many_device")
+
+    def encode_blocks(self, bc_format, rgba, flags=0, threshold=0.5):
+        rgba = np.ascontiguousarray(rgba, np.float32).reshape(-1, 16, 4)
+        n = rgba.shape[0]
+        out = np.zeros((n, F.BC_BLOCK_BYTES[bc_format]), np.uint8)
+        self._check(_lib.dxtex_encode_blocks(self._h, bc_format, flags, threshold, rgba.ctypes.data, n, out.ctypes.data), "encode_blocks")
+        return out
+
+    def decode_blocks(self, bc_format, blocks):
+        blocks = np.ascontiguousarray(blocks, np.uint8).reshape(-1, F.BC_BLOCK_BYTES[bc_format])
+        n = blocks.shape[0]
+        out = np.zeros((n, 16, 4), np.float32)
+        self._check(_lib.dxtex_decode_blocks(self._h, bc_format, blocks.ctypes.data, n, out.ctypes.data), "decode_blocks")
+        return out
+
+    def decompress(self, payload, width, height, bc_format, dst_format):
+        payload = np.ascontiguousarray(payload, np.uint8)
+        src = _host_image(payload, width, height, bc_format)
+        rp, sp = compute_pitch(dst_format, width, height)
+        out = np.zeros(sp, np.uint8)
+        dst = Image(width, height, dst_format, rp, sp, out.ctypes.data)
+        self._check(_lib.dxtex_decompress(self._h, ctypes.byref(src), ctypes.byref(dst)), "decompress")
+        return out
+
+    # -- GenerateMipMaps / Convert / Resize ---------------------------------------------------------
+    def generate_mips(self, level0, width, height, fmt, nlevels, filter_flags):
+        """Returns [level0, level1, ...] as numpy uint8 buffers with tight pitch."""
+        levels, bufs = [], []
+        w, h = width, height
+        for i in range(nlevels):
+            rp, sp = compute_pitch(fmt, w, h)
+            buf = np.zeros(sp, np.uint8)
+            if i == 0:
+                src = np.ascontiguousarray(level0).view(np.uint8).reshape(-1)
+                buf[:] = src[:sp]
+            bufs.append(buf)
+            levels.append(Image(w, h, fmt, rp, sp, buf.ctypes.data))
+            w, h = max(1, w >> 1), max(1, h >> 1)
+        arr = (Image * nlevels)(*levels)
+        self._check(_lib.dxtex_generate_mips(self._h, arr, nlevels, filter_flags), "generate_mips")
+        return bufs
+
+    def convert(self, pixels, width, height, src_format, dst_format, filter_flags=0, threshold=0.5):
+        pixels = np.ascontiguousarray(pixels)
+        src = _host_image(pixels, width, height, src_format)
+        rp, sp = compute_pitch(dst_format, width, height)
+        out = np.zeros(sp, np.uint8)
+        dst = Image(width, height, dst_format, rp, sp, out.ctypes.data)
+        self._check(_lib.dxtex_convert(self._h, ctypes.byref(src), ctypes.byref(dst), filter_flags, threshold), "convert")
+        return out
+
+    def resize(self, pixels, width, height, fmt, new_width, new_height, filter_flags=0):
+        pixels = np.ascontiguousarray(pixels)
+        src = _host_image(pixels, width, height, fmt)
+        rp, sp = compute_pitch(fmt, new_width, new_height)
+        out = np.zeros(sp, np.uint8)
+        dst = Image(new_width, new_height, fmt, rp, sp, out.ctypes.data)
+        self._check(_lib.dxtex_resize(self._h, ctypes.byref(src), ctypes.byref(dst), filter_flags), "resize")
+        return out

@@ -1,0 +1,745 @@
+// BC1 / BC2 / BC3 / BC4 / BC5 encoders for gfx950: one 4x4 block per lane.
+//
+// Every lane gathers its own tile with four coalesced 16-byte row loads (lane = block, so a wave reads
+// 1 KiB contiguous per tile row), runs the whole endpoint fit in registers and stores one 8- or 16-byte
+// block; consecutive lanes store consecutive blocks. No LDS, no cross-lane traffic.
+//
+// The arithmetic restates, operation for operation in IEEE fp32 without FMA contraction, what the
+// reference CPU encoders compute, so the output is bit-identical to them:
+//   BC1 colour block  : BC.cpp:370-685 (EncodeBC1) + BC.cpp:65-314 (OptimizeRGB) + :44-61 (Encode565)
+//   BC1 entry / alpha : BC.cpp:738-795   BC2: BC.cpp:828-895   BC3: BC.cpp:944-1141
+//   alpha endpoint fit: BC.h:187-311 (OptimizeAlpha<bRange>)
+//   BC4/BC5           : BC4BC5.cpp:183-293 (FindEndPoints*), :325-377 (FindClosest*), :419-562 (entry points)
+// This translation unit must be compiled with -ffp-contract=off (see csrc/Makefile).
+#include "dxtex_device.h"
+
+namespace dxtex
+{
+namespace
+{
+// Floyd-Steinberg taps inside the 4x4 tile: right 7/16, down-left 3/16, down 5/16, down-right 1/16
+// (BC.cpp:451-481). `i` is a compile-time constant after unrolling.
+template<int N>
+__device__ __forceinline__ void diffuse(float (&err)[N], int i, float d)
+{
+    if (3 != (i & 3)) err[i + 1] += d * (7.0f / 16.0f);
+    if (i < 12)
+    {
+        if (i & 3) err[i + 3] += d * (3.0f / 16.0f);
+        err[i + 4] += d * (5.0f / 16.0f);
+        if (3 != (i & 3)) err[i + 5] += d * (1.0f / 16.0f);
+    }
+}
+
+__device__ __forceinline__ uint32_t encode565(float r, float g, float b)
+{
+    r = (r < 0.0f) ? 0.0f : (r > 1.0f) ? 1.0f : r;
+    g = (g < 0.0f) ? 0.0f : (g > 1.0f) ? 1.0f : g;
+    b = (b < 0.0f) ? 0.0f : (b > 1.0f) ? 1.0f : b;
+    return (uint32_t(int32_t(r * 31.0f + 0.5f)) << 11) | (uint32_t(int32_t(g * 63.0f + 0.5f)) << 5) | uint32_t(int32_t(b * 31.0f + 0.5f));
+}
+
+__device__ __forceinline__ void decode565(uint32_t w, float& r, float& g, float& b)
+{
+    r = float((w >> 11) & 31) * (1.0f / 31.0f);
+    g = float((w >> 5) & 63) * (1.0f / 63.0f);
+    b = float(w & 31) * (1.0f / 31.0f);
+}
+
+// Interpolation coefficient tables of the Newton fits, selected without indexing memory.
+__device__ __forceinline__ float coefC(uint32_t i, uint32_t cSteps)
+{
+    if (cSteps == 3) return (i == 0) ? 1.0f : (i == 1) ? 0.5f : 0.0f;
+    return (i == 0) ? 1.0f : (i == 1) ? (2.0f / 3.0f) : (i == 2) ? (1.0f / 3.0f) : 0.0f;
+}
+__device__ __forceinline__ float coefD(uint32_t i, uint32_t cSteps)
+{
+    if (cSteps == 3) return (i == 0) ? 0.0f : (i == 1) ? 0.5f : 1.0f;
+    return (i == 0) ? 0.0f : (i == 1) ? (1.0f / 3.0f) : (i == 2) ? (2.0f / 3.0f) : 1.0f;
+}
+
+// 6-D Newton endpoint fit over 16 points (BC.cpp:65-314).
+__device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const float (&pg)[16], const float (&pb)[16],
+                               uint32_t cSteps, bool uniform,
+                               float& oXr, float& oXg, float& oXb, float& oYr, float& oYg, float& oYb)
+{
+    constexpr float fEpsilon = (0.25f / 64.0f) * (0.25f / 64.0f);
+
+    float Xr = uniform ? 1.0f : (0.2125f / 0.7154f);
+    float Xg = 1.0f;
+    float Xb = uniform ? 1.0f : (0.0721f / 0.7154f);
+    float Yr = 0.0f, Yg = 0.0f, Yb = 0.0f;
+
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        if (pr[i] < Xr) Xr = pr[i];
+        if (pg[i] < Xg) Xg = pg[i];
+        if (pb[i] < Xb) Xb = pb[i];
+        if (pr[i] > Yr) Yr = pr[i];
+        if (pg[i] > Yg) Yg = pg[i];
+        if (pb[i] > Yb) Yb = pb[i];
+    }
+
+    const float ABr = Yr - Xr, ABg = Yg - Xg, ABb = Yb - Xb;
+    const float fAB = ABr * ABr + ABg * ABg + ABb * ABb;
+
+    if (fAB < 1.175494351e-38f)   // FLT_MIN: single colour block
+    {
+        oXr = Xr; oXg = Xg; oXb = Xb; oYr = Yr; oYg = Yg; oYb = Yb;
+        return;
+    }
+
+    const float fABInv = 1.0f / fAB;
+    float Dr = ABr * fABInv, Dg = ABg * fABInv, Db = ABb * fABInv;
+    const float Mr = (Xr + Yr) * 0.5f, Mg = (Xg + Yg) * 0.5f, Mb = (Xb + Yb) * 0.5f;
+
+    float fDir0 = 0.0f, fDir1 = 0.0f, fDir2 = 0.0f, fDir3 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        const float Pr = (pr[i] - Mr) * Dr;
+        const float Pg = (pg[i] - Mg) * Dg;
+        const float Pb = (pb[i] - Mb) * Db;
+        float f;
+        f = Pr + Pg + Pb; fDir0 += f * f;
+        f = Pr + Pg - Pb; fDir1 += f * f;
+        f = Pr - Pg + Pb; fDir2 += f * f;
+        f = Pr - Pg - Pb; fDir3 += f * f;
+    }
+
+    float fDirMax = fDir0; uint32_t iDirMax = 0;
+    if (fDir1 > fDirMax) { fDirMax = fDir1; iDirMax = 1; }
+    if (fDir2 > fDirMax) { fDirMax = fDir2; iDirMax = 2; }
+    if (fDir3 > fDirMax) { fDirMax = fDir3; iDirMax = 3; }
+
+    if (iDirMax & 2) { const float f = Xg; Xg = Yg; Yg = f; }
+    if (iDirMax & 1) { const float f = Xb; Xb = Yb; Yb = f; }
+
+    if (fAB < 1.0f / 4096.0f)   // two colour block
+    {
+        oXr = Xr; oXg = Xg; oXb = Xb; oYr = Yr; oYg = Yg; oYb = Yb;
+        return;
+    }
+
+    const float fSteps = float(cSteps - 1);
+
+    for (int iter = 0; iter < 8; ++iter)
+    {
+        Dr = Yr - Xr; Dg = Yg - Xg; Db = Yb - Xb;
+        const float fLen = Dr * Dr + Dg * Dg + Db * Db;
+        if (fLen < (1.0f / 4096.0f))
+            break;
+
+        const float fScale = fSteps / fLen;
+        Dr *= fScale; Dg *= fScale; Db *= fScale;
+
+        float d2X = 0.0f, d2Y = 0.0f;
+        float dXr = 0.0f, dXg = 0.0f, dXb = 0.0f, dYr = 0.0f, dYg = 0.0f, dYb = 0.0f;
+
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+        {
+            const float fDot = (pr[i] - Xr) * Dr + (pg[i] - Xg) * Dg + (pb[i] - Xb) * Db;
+
+            uint32_t iStep;
+            if (fDot <= 0.0f) iStep = 0;
+            else if (fDot >= fSteps) iStep = cSteps - 1;
+            else iStep = uint32_t(fDot + 0.5f);
+
+            const float c = coefC(iStep, cSteps), d = coefD(iStep, cSteps);
+            // pSteps[iStep] = X * pC[iStep] + Y * pD[iStep], evaluated where it is used
+            const float diffR = (Xr * c + Yr * d) - pr[i];
+            const float diffG = (Xg * c + Yg * d) - pg[i];
+            const float diffB = (Xb * c + Yb * d) - pb[i];
+
+            const float fC = c * (1.0f / 8.0f);
+            const float fD = d * (1.0f / 8.0f);
+
+            d2X += fC * c;
+            dXr += fC * diffR; dXg += fC * diffG; dXb += fC * diffB;
+            d2Y += fD * d;
+            dYr += fD * diffR; dYg += fD * diffG; dYb += fD * diffB;
+        }
+
+        if (d2X > 0.0f)
+        {
+            const float f = -1.0f / d2X;
+            Xr += dXr * f; Xg += dXg * f; Xb += dXb * f;
+        }
+        if (d2Y > 0.0f)
+        {
+            const float f = -1.0f / d2Y;
+            Yr += dYr * f; Yg += dYg * f; Yb += dYb * f;
+        }
+
+        if ((dXr * dXr < fEpsilon) && (dXg * dXg < fEpsilon) && (dXb * dXb < fEpsilon) &&
+            (dYr * dYr < fEpsilon) && (dYg * dYg < fEpsilon) && (dYb * dYb < fEpsilon))
+            break;
+    }
+
+    oXr = Xr; oXg = Xg; oXb = Xb; oYr = Yr; oYg = Yg; oYb = Yb;
+}
+
+// BC1 colour block (BC.cpp:370-685). pa is only read when bColorKey is set.
+template<bool DITHER>
+__device__ __forceinline__ uint2 encode_bc1_color(const float (&sr)[16], const float (&sg)[16], const float (&sb)[16], const float (&pa)[16],
+                                  bool bColorKey, float threshold, uint32_t flags)
+{
+    const bool uniform = (flags & BCF_UNIFORM) != 0;
+    constexpr float LumR = 0.2125f / 0.7154f, LumB = 0.0721f / 0.7154f;
+    constexpr float LumInvR = 0.7154f / 0.2125f, LumInvB = 0.7154f / 0.0721f;
+
+    uint32_t uSteps = 4;
+    if (bColorKey)
+    {
+        uint32_t uColorKey = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (pa[i] < threshold) uColorKey++;
+
+        if (uColorKey == 16)
+            return make_uint2(0xffff0000u, 0xffffffffu);   // rgb[0] = 0x0000, rgb[1] = 0xffff
+
+        uSteps = (uColorKey > 0) ? 3u : 4u;
+    }
+
+    // Quantise to the 565 grid (optionally error-diffused), then weight by luminance.
+    float cr[16], cg[16], cb[16];
+    float er[DITHER ? 16 : 1], eg[DITHER ? 16 : 1], eb[DITHER ? 16 : 1];
+    if constexpr (DITHER)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { er[i] = 0.0f; eg[i] = 0.0f; eb[i] = 0.0f; }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        float r = sr[i], g = sg[i], b = sb[i];
+        if constexpr (DITHER) { r += er[i]; g += eg[i]; b += eb[i]; }
+
+        cr[i] = float(int32_t(r * 31.0f + 0.5f)) * (1.0f / 31.0f);
+        cg[i] = float(int32_t(g * 63.0f + 0.5f)) * (1.0f / 63.0f);
+        cb[i] = float(int32_t(b * 31.0f + 0.5f)) * (1.0f / 31.0f);
+
+        if constexpr (DITHER)
+        {
+            // Color[i].a == 1.0f in the default build, so Diff = 1.0f * (Clr - Color)
+            diffuse(er, i, 1.0f * (r - cr[i]));
+            diffuse(eg, i, 1.0f * (g - cg[i]));
+            diffuse(eb, i, 1.0f * (b - cb[i]));
+        }
+
+        if (!uniform) { cr[i] *= LumR; cg[i] *= 1.0f; cb[i] *= LumB; }
+    }
+
+    float Ar, Ag, Ab, Br, Bg, Bb;
+    optimize_rgb16(cr, cg, cb, uSteps, uniform, Ar, Ag, Ab, Br, Bg, Bb);
+
+    float Cr, Cg, Cb, Dr, Dg, Db;
+    if (uniform) { Cr = Ar; Cg = Ag; Cb = Ab; Dr = Br; Dg = Bg; Db = Bb; }
+    else
+    {
+        Cr = Ar * LumInvR; Cg = Ag * 1.0f; Cb = Ab * LumInvB;
+        Dr = Br * LumInvR; Dg = Bg * 1.0f; Db = Bb * LumInvB;
+    }
+
+    const uint32_t wA = encode565(Cr, Cg, Cb);
+    const uint32_t wB = encode565(Dr, Dg, Db);
+
+    if ((uSteps == 4) && (wA == wB))
+        return make_uint2(wA | (wB << 16), 0u);
+
+    decode565(wA, Cr, Cg, Cb);
+    decode565(wB, Dr, Dg, Db);
+
+    if (uniform) { Ar = Cr; Ag = Cg; Ab = Cb; Br = Dr; Bg = Dg; Bb = Db; }
+    else
+    {
+        Ar = Cr * LumR; Ag = Cg * 1.0f; Ab = Cb * LumB;
+        Br = Dr * LumR; Bg = Dg * 1.0f; Bb = Db * LumB;
+    }
+
+    // Endpoint order decides 3- vs 4-colour decoding.
+    float S0r, S0g, S0b, S1r, S1g, S1b;
+    uint32_t rgb0, rgb1;
+    if ((3 == uSteps) == (wA <= wB))
+    {
+        rgb0 = wA; rgb1 = wB;
+        S0r = Ar; S0g = Ag; S0b = Ab; S1r = Br; S1g = Bg; S1b = Bb;
+    }
+    else
+    {
+        rgb0 = wB; rgb1 = wA;
+        S0r = Br; S0g = Bg; S0b = Bb; S1r = Ar; S1g = Ag; S1b = Ab;
+    }
+
+    // Step[2], Step[3] (only needed to feed the dither error)
+    float S2r, S2g, S2b, S3r = 0.0f, S3g = 0.0f, S3b = 0.0f;
+    if (3 == uSteps)
+    {
+        S2r = S0r + 0.5f * (S1r - S0r); S2g = S0g + 0.5f * (S1g - S0g); S2b = S0b + 0.5f * (S1b - S0b);
+    }
+    else
+    {
+        S2r = S0r + (1.0f / 3.0f) * (S1r - S0r); S2g = S0g + (1.0f / 3.0f) * (S1g - S0g); S2b = S0b + (1.0f / 3.0f) * (S1b - S0b);
+        S3r = S0r + (2.0f / 3.0f) * (S1r - S0r); S3g = S0g + (2.0f / 3.0f) * (S1g - S0g); S3b = S0b + (2.0f / 3.0f) * (S1b - S0b);
+    }
+
+    float dirR = S1r - S0r, dirG = S1g - S0g, dirB = S1b - S0b;
+    const float fSteps = float(uSteps - 1);
+    const float fScale = (wA != wB) ? (fSteps / (dirR * dirR + dirG * dirG + dirB * dirB)) : 0.0f;
+    dirR *= fScale; dirG *= fScale; dirB *= fScale;
+
+    uint32_t dw = 0;
+    if constexpr (DITHER)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { er[i] = 0.0f; eg[i] = 0.0f; eb[i] = 0.0f; }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        if ((3 == uSteps) && (pa[i] < threshold))
+        {
+            dw = (3u << 30) | (dw >> 2);
+        }
+        else
+        {
+            float r, g, b;
+            if (uniform) { r = sr[i]; g = sg[i]; b = sb[i]; }
+            else { r = sr[i] * LumR; g = sg[i] * 1.0f; b = sb[i] * LumB; }
+
+            if constexpr (DITHER) { r += er[i]; g += eg[i]; b += eb[i]; }
+
+            const float fDot = (r - S0r) * dirR + (g - S0g) * dirG + (b - S0b) * dirB;
+
+            uint32_t iStep;
+            if (fDot <= 0.0f) iStep = 0;
+            else if (fDot >= fSteps) iStep = 1;
+            else
+            {
+                const uint32_t k = uint32_t(fDot + 0.5f);
+                // pSteps3 = {0,2,1}; pSteps4 = {0,2,3,1}
+                iStep = (3 == uSteps) ? ((k == 0) ? 0u : (k == 1) ? 2u : 1u)
+                                      : ((k == 0) ? 0u : (k == 1) ? 2u : (k == 2) ? 3u : 1u);
+            }
+
+            dw = (iStep << 30) | (dw >> 2);
+
+            if constexpr (DITHER)
+            {
+                const float qr = (iStep == 0) ? S0r : (iStep == 1) ? S1r : (iStep == 2) ? S2r : S3r;
+                const float qg = (iStep == 0) ? S0g : (iStep == 1) ? S1g : (iStep == 2) ? S2g : S3g;
+                const float qb = (iStep == 0) ? S0b : (iStep == 1) ? S1b : (iStep == 2) ? S2b : S3b;
+                diffuse(er, i, 1.0f * (r - qr));
+                diffuse(eg, i, 1.0f * (g - qg));
+                diffuse(eb, i, 1.0f * (b - qb));
+            }
+        }
+    }
+
+    return make_uint2(rgb0 | (rgb1 << 16), dw);
+}
+
+// 1-D Newton endpoint fit for BC3 alpha / BC4 / BC5 (BC.h:187-311).
+template<bool bRange>
+__device__ __forceinline__ void optimize_alpha(float& outX, float& outY, const float (&p)[16], uint32_t cSteps)
+{
+    constexpr float MAX_VALUE = 1.0f;
+    constexpr float MIN_VALUE = bRange ? -1.0f : 0.0f;
+
+    float fX = MAX_VALUE, fY = MIN_VALUE;
+
+    if (8 == cSteps)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+        {
+            if (p[i] < fX) fX = p[i];
+            if (p[i] > fY) fY = p[i];
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+        {
+            if (p[i] < fX && p[i] > MIN_VALUE) fX = p[i];
+            if (p[i] > fY && p[i] < MAX_VALUE) fY = p[i];
+        }
+        if (fX == fY) fY = MAX_VALUE;
+    }
+
+    const float fSteps = float(cSteps - 1);
+    const bool six = (6 == cSteps);
+
+    for (int iter = 0; iter < 8; ++iter)
+    {
+        if ((fY - fX) < (1.0f / 256.0f))
+            break;
+
+        const float fScale = fSteps / (fY - fX);
+
+        float dX = 0.0f, dY = 0.0f, d2X = 0.0f, d2Y = 0.0f;
+
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+        {
+            const float fDot = (p[i] - fX) * fScale;
+
+            uint32_t iStep;
+            if (fDot <= 0.0f)
+                iStep = (six && (p[i] <= (fX + MIN_VALUE) * 0.5f)) ? 6u : 0u;
+            else if (fDot >= fSteps)
+                iStep = (six && (p[i] >= (fY + MAX_VALUE) * 0.5f)) ? 7u : (cSteps - 1);
+            else
+                iStep = uint32_t(fDot + 0.5f);
+
+            if (iStep < cSteps)
+            {
+                // pC6[i] = (5-i)/5, pD6[i] = i/5; pC8[i] = (7-i)/7, pD8[i] = i/7 (constant-folded divisions)
+                const float c = six ? (float(5 - int(iStep)) / 5.0f) : (float(7 - int(iStep)) / 7.0f);
+                const float d = six ? (float(iStep) / 5.0f) : (float(iStep) / 7.0f);
+                const float fDiff = (c * fX + d * fY) - p[i];
+
+                dX += c * fDiff;
+                d2X += c * c;
+                dY += d * fDiff;
+                d2Y += d * d;
+            }
+        }
+
+        if (d2X > 0.0f) fX -= dX / d2X;
+        if (d2Y > 0.0f) fY -= dY / d2Y;
+
+        if (fX > fY) { const float f = fX; fX = fY; fY = f; }
+
+        if ((dX * dX < (1.0f / 64.0f)) && (dY * dY < (1.0f / 64.0f)))
+            break;
+    }
+
+    outX = (fX < MIN_VALUE) ? MIN_VALUE : (fX > MAX_VALUE) ? MAX_VALUE : fX;
+    outY = (fY < MIN_VALUE) ? MIN_VALUE : (fY > MAX_VALUE) ? MAX_VALUE : fY;
+}
+
+// BC3 alpha block (BC.cpp:957-1140). Returns the 8 bytes {alpha0, alpha1, 48 index bits}.
+__device__ __forceinline__ uint2 encode_bc3_alpha(const float (&pa)[16], uint32_t flags)
+{
+    const bool dither = (flags & BCF_DITHER_A) != 0;
+
+    float fAlpha[16], fError[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fError[i] = 0.0f;
+
+    float fMinAlpha = pa[0], fMaxAlpha = pa[0];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        float fAlph = pa[i];
+        if (dither) fAlph += fError[i];
+
+        fAlpha[i] = float(int32_t(fAlph * 255.0f + 0.5f)) * (1.0f / 255.0f);
+
+        if (fAlpha[i] < fMinAlpha) fMinAlpha = fAlpha[i];
+        else if (fAlpha[i] > fMaxAlpha) fMaxAlpha = fAlpha[i];
+
+        if (dither) diffuse(fError, i, fAlph - fAlpha[i]);
+    }
+
+    if (1.0f == fMinAlpha)
+        return make_uint2(0x0000ffffu, 0u);
+
+    const uint32_t uSteps = ((0.0f == fMinAlpha) || (1.0f == fMaxAlpha)) ? 6u : 8u;
+
+    float fAlphaA, fAlphaB;
+    optimize_alpha<false>(fAlphaA, fAlphaB, fAlpha, uSteps);
+
+    const uint32_t bAlphaA = uint32_t(int32_t(fAlphaA * 255.0f + 0.5f)) & 0xFF;
+    const uint32_t bAlphaB = uint32_t(int32_t(fAlphaB * 255.0f + 0.5f)) & 0xFF;
+
+    fAlphaA = float(bAlphaA) * (1.0f / 255.0f);
+    fAlphaB = float(bAlphaB) * (1.0f / 255.0f);
+
+    if ((8 == uSteps) && (bAlphaA == bAlphaB))
+        return make_uint2(bAlphaA | (bAlphaB << 8), 0u);
+
+    float fStep[8];
+    uint32_t a0, a1;
+    if (6 == uSteps)
+    {
+        a0 = bAlphaA; a1 = bAlphaB;
+        fStep[0] = fAlphaA; fStep[1] = fAlphaB;
+#pragma unroll
+        for (int i = 1; i < 5; ++i)
+            fStep[i + 1] = (fStep[0] * float(5 - i) + fStep[1] * float(i)) * (1.0f / 5.0f);
+        fStep[6] = 0.0f; fStep[7] = 1.0f;
+    }
+    else
+    {
+        a0 = bAlphaB; a1 = bAlphaA;
+        fStep[0] = fAlphaB; fStep[1] = fAlphaA;
+#pragma unroll
+        for (int i = 1; i < 7; ++i)
+            fStep[i + 1] = (fStep[0] * float(7 - i) + fStep[1] * float(i)) * (1.0f / 7.0f);
+    }
+
+    const float fSteps = float(uSteps - 1);
+    const float fScale = (fStep[0] != fStep[1]) ? (fSteps / (fStep[1] - fStep[0])) : 0.0f;
+
+    if (dither)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fError[i] = 0.0f;
+    }
+
+    uint64_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        float fAlph = pa[i];
+        if (dither) fAlph += fError[i];
+        const float fDot = (fAlph - fStep[0]) * fScale;
+
+        uint32_t iStep;
+        if (fDot <= 0.0f)
+            iStep = ((6 == uSteps) && (fAlph <= fStep[0] * 0.5f)) ? 6u : 0u;
+        else if (fDot >= fSteps)
+            iStep = ((6 == uSteps) && (fAlph >= (fStep[1] + 1.0f) * 0.5f)) ? 7u : 1u;
+        else
+        {
+            // pSteps6 = {0,2,3,4,5,1}; pSteps8 = {0,2,3,4,5,6,7,1}
+            const uint32_t k = uint32_t(fDot + 0.5f);
+            iStep = (k == 0) ? 0u : (k == uSteps - 1) ? 1u : (k + 1);
+        }
+
+        bits |= uint64_t(iStep) << (3 * i);
+
+        if (dither)
+        {
+            float q = fStep[0];
+#pragma unroll
+            for (int s = 1; s < 8; ++s) q = (iStep == uint32_t(s)) ? fStep[s] : q;
+            diffuse(fError, i, fAlph - q);
+        }
+    }
+
+    const uint64_t blk = uint64_t(a0) | (uint64_t(a1) << 8) | (bits << 16);
+    return make_uint2(uint32_t(blk), uint32_t(blk >> 32));
+}
+
+// BC2 explicit 4-bit alpha (BC.cpp:841-883).
+__device__ __forceinline__ uint2 encode_bc2_alpha(const float (&pa)[16], uint32_t flags)
+{
+    const bool dither = (flags & BCF_DITHER_A) != 0;
+    float fError[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fError[i] = 0.0f;
+
+    uint64_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        float fAlph = pa[i];
+        if (dither) fAlph += fError[i];
+        const uint32_t u = uint32_t(fAlph * 15.0f + 0.5f);
+        bits |= uint64_t(u & 0xF) << (4 * i);
+        if (dither) diffuse(fError, i, fAlph - float(u) * (1.0f / 15.0f));
+    }
+    return make_uint2(uint32_t(bits), uint32_t(bits >> 32));
+}
+
+// BC4 channel block. SNORM selects BC4S/BC5S (BC4BC5.cpp:183-293, :325-377).
+template<bool SNORM>
+__device__ __forceinline__ uint2 encode_bc4_channel(const float (&t)[16])
+{
+    constexpr float MIN_NORM = SNORM ? -1.0f : 0.0f;
+    constexpr float MAX_NORM = 1.0f;
+
+    float fBlockMax = t[0], fBlockMin = t[0];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        if (t[i] < fBlockMin) fBlockMin = t[i];
+        else if (t[i] > fBlockMax) fBlockMax = t[i];
+    }
+
+    const bool bUsing4BlockCodec = (MIN_NORM == fBlockMin || MAX_NORM == fBlockMax);
+
+    float fStart, fEnd;
+    optimize_alpha<SNORM>(fStart, fEnd, t, bUsing4BlockCodec ? 6u : 8u);
+
+    int32_t iStart, iEnd;
+    if (SNORM)
+    {
+        // FloatToSNorm (BC4BC5.cpp:158-179); inputs are already clamped to [-1, 1] by optimize_alpha
+        float a = fStart, b = fEnd;
+        if (a != a) a = 0.0f; else if (a > 1.0f) a = 1.0f; else if (a < -1.0f) a = -1.0f;
+        if (b != b) b = 0.0f; else if (b > 1.0f) b = 1.0f; else if (b < -1.0f) b = -1.0f;
+        a = a * 127.0f; b = b * 127.0f;
+        a = (a >= 0.0f) ? (a + 0.5f) : (a - 0.5f);
+        b = (b >= 0.0f) ? (b + 0.5f) : (b - 0.5f);
+        iStart = int32_t(a); iEnd = int32_t(b);
+    }
+    else
+    {
+        iStart = int32_t(fStart * 255.0f) & 0xFF;   // truncating, BC4BC5.cpp:219-220
+        iEnd = int32_t(fEnd * 255.0f) & 0xFF;
+    }
+
+    int32_t e0, e1;
+    if (!bUsing4BlockCodec) { e0 = iEnd; e1 = iStart; }
+    else { e0 = iStart; e1 = iEnd; }
+
+    // Decode the 8 representable values exactly as DecodeFromIndex does (BC4BC5.cpp:47-69 / :103-128).
+    float grad[8];
+    float f0, f1;
+    if (SNORM)
+    {
+        const int32_t s0 = (e0 == -128) ? -127 : e0;
+        const int32_t s1 = (e1 == -128) ? -127 : e1;
+        f0 = float(s0) / 127.0f; f1 = float(s1) / 127.0f;
+    }
+    else
+    {
+        f0 = float(e0) / 255.0f; f1 = float(e1) / 255.0f;
+    }
+    grad[0] = f0; grad[1] = f1;
+    if (e0 > e1)
+    {
+#pragma unroll
+        for (int i = 1; i < 7; ++i)
+            grad[i + 1] = (f0 * float(7 - i) + f1 * float(i)) / 7.0f;
+    }
+    else
+    {
+#pragma unroll
+        for (int i = 1; i < 5; ++i)
+            grad[i + 1] = (f0 * float(5 - i) + f1 * float(i)) / 5.0f;
+        grad[6] = MIN_NORM;
+        grad[7] = 1.0f;
+    }
+
+    uint64_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        uint32_t uBest = 0;
+        float fBestDelta = 100000.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+        {
+            const float fCur = fabsf(grad[k] - t[i]);
+            if (fCur < fBestDelta) { uBest = uint32_t(k); fBestDelta = fCur; }
+        }
+        bits |= uint64_t(uBest) << (3 * i);
+    }
+
+    const uint64_t blk = uint64_t(uint32_t(e0) & 0xFF) | (uint64_t(uint32_t(e1) & 0xFF) << 8) | (bits << 16);
+    return make_uint2(uint32_t(blk), uint32_t(blk >> 32));
+}
+
+// BC1 entry: optional alpha error diffusion to {0,1} before colour keying (BC.cpp:744-784).
+__device__ __forceinline__ void bc1_dither_alpha(float (&pa)[16])
+{
+    float fError[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fError[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        const float fAlph = pa[i] + fError[i];
+        const float q = float(int32_t(pa[i] + fError[i] + 0.5f));
+        pa[i] = q;
+        diffuse(fError, i, fAlph - q);
+    }
+}
+
+struct EncodeArgs
+{
+    SrcView src;
+    uint8_t* dst;
+    uint64_t dstRowPitch;   // bytes per row of blocks
+    uint32_t nbw, nbh;      // blocks per row / column
+    int dstFormat;
+    uint32_t flags;
+    float threshold;
+};
+
+// KIND: 1..3 = BC1..BC3, 4/5 = BC4/BC5 unsigned, 6/7 = BC4/BC5 signed. One instantiation per format keeps
+// each kernel's register footprint to what that codec needs.
+template<int KIND, bool DITHER>
+__global__ void __launch_bounds__(256) bc15_encode_kernel(EncodeArgs a)
+{
+    const uint32_t nb = blockIdx.x * 256u + threadIdx.x;
+    if (nb >= a.nbw * a.nbh) return;
+    const uint32_t by = nb / a.nbw, bx = nb - by * a.nbw;
+
+    Tile t;
+    load_tile(a.src, bx, by, t);
+    uint8_t* out = a.dst + uint64_t(by) * a.dstRowPitch;
+
+    if constexpr (KIND == 1)
+    {
+        if (a.flags & BCF_DITHER_A) bc1_dither_alpha(t.a);
+        reinterpret_cast<uint2*>(out)[bx] = encode_bc1_color<DITHER>(t.r, t.g, t.b, t.a, true, a.threshold, a.flags);
+    }
+    else if constexpr (KIND == 2)
+    {
+        const uint2 al = encode_bc2_alpha(t.a, a.flags);
+        const uint2 c = encode_bc1_color<DITHER>(t.r, t.g, t.b, t.a, false, 0.0f, a.flags);
+        reinterpret_cast<uint4*>(out)[bx] = make_uint4(al.x, al.y, c.x, c.y);
+    }
+    else if constexpr (KIND == 3)
+    {
+        const uint2 al = encode_bc3_alpha(t.a, a.flags);
+        const uint2 c = encode_bc1_color<DITHER>(t.r, t.g, t.b, t.a, false, 0.0f, a.flags);
+        reinterpret_cast<uint4*>(out)[bx] = make_uint4(al.x, al.y, c.x, c.y);
+    }
+    else if constexpr (KIND == 4)
+        reinterpret_cast<uint2*>(out)[bx] = encode_bc4_channel<false>(t.r);
+    else if constexpr (KIND == 6)
+        reinterpret_cast<uint2*>(out)[bx] = encode_bc4_channel<true>(t.r);
+    else if constexpr (KIND == 5)
+    {
+        const uint2 u = encode_bc4_channel<false>(t.r), v = encode_bc4_channel<false>(t.g);
+        reinterpret_cast<uint4*>(out)[bx] = make_uint4(u.x, u.y, v.x, v.y);
+    }
+    else
+    {
+        const uint2 u = encode_bc4_channel<true>(t.r), v = encode_bc4_channel<true>(t.g);
+        reinterpret_cast<uint4*>(out)[bx] = make_uint4(u.x, u.y, v.x, v.y);
+    }
+}
+} // namespace
+
+hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, int dstFormat,
+                              uint32_t flags, float threshold, hipStream_t stream)
+{
+    EncodeArgs a;
+    a.src = src; a.dst = dst; a.dstRowPitch = dstRowPitch;
+    a.nbw = (src.width + 3) / 4; a.nbh = (src.height + 3) / 4;
+    a.dstFormat = dstFormat; a.flags = flags; a.threshold = threshold;
+    const uint64_t nblocks = uint64_t(a.nbw) * a.nbh;
+    if (!nblocks) return hipSuccess;
+    const dim3 grid(uint32_t((nblocks + 255) / 256)), block(256);
+    const bool dither = (flags & BCF_DITHER_RGB) != 0;
+#define DXTEX_LAUNCH(KIND) do { if (dither) hipLaunchKernelGGL((bc15_encode_kernel<KIND, true>), grid, block, 0, stream, a); \
+                                else hipLaunchKernelGGL((bc15_encode_kernel<KIND, false>), grid, block, 0, stream, a); } while (0)
+    switch (dstFormat)
+    {
+    case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: DXTEX_LAUNCH(1); break;
+    case FMT_BC2_UNORM: case FMT_BC2_UNORM_SRGB: DXTEX_LAUNCH(2); break;
+    case FMT_BC3_UNORM: case FMT_BC3_UNORM_SRGB: DXTEX_LAUNCH(3); break;
+    case FMT_BC4_UNORM: hipLaunchKernelGGL((bc15_encode_kernel<4, false>), grid, block, 0, stream, a); break;
+    case FMT_BC5_UNORM: hipLaunchKernelGGL((bc15_encode_kernel<5, false>), grid, block, 0, stream, a); break;
+    case FMT_BC4_SNORM: hipLaunchKernelGGL((bc15_encode_kernel<6, false>), grid, block, 0, stream, a); break;
+    case FMT_BC5_SNORM: hipLaunchKernelGGL((bc15_encode_kernel<7, false>), grid, block, 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef DXTEX_LAUNCH
+    return hipGetLastError();
+}
+} // namespace dxtex

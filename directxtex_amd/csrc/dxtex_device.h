@@ -1,0 +1,238 @@
+// Device-side helpers shared by the HIP kernels: DXGI format ids, HRESULT values, and the 4x4 tile
+// loader that plays the role of the reference's LoadScanline + partial-block replication +
+// ConvertScanline (DirectXTexCompress.cpp:291-343, DirectXTexConvert.cpp:779-1619, :3080-3854).
+// gfx950 only. Compile with -ffp-contract=off: BC1-BC5 parity is bit-exact fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace dxtex
+{
+// Public DXGI numbering (only the formats this library understands).
+enum : int
+{
+    FMT_UNKNOWN = 0,
+    FMT_R32G32B32A32_FLOAT = 2,
+    FMT_R16G16B16A16_FLOAT = 10,
+    FMT_R16G16B16A16_UNORM = 11,
+    FMT_R32G32_FLOAT = 16,
+    FMT_R8G8B8A8_UNORM = 28,
+    FMT_R8G8B8A8_UNORM_SRGB = 29,
+    FMT_R8G8B8A8_SNORM = 31,
+    FMT_R16G16_FLOAT = 34,
+    FMT_R16G16_UNORM = 35,
+    FMT_R32_FLOAT = 41,
+    FMT_R8G8_UNORM = 49,
+    FMT_R8G8_SNORM = 51,
+    FMT_R16_FLOAT = 54,
+    FMT_R16_UNORM = 56,
+    FMT_R8_UNORM = 61,
+    FMT_R8_SNORM = 63,
+    FMT_A8_UNORM = 65,
+    FMT_BC1_UNORM = 71, FMT_BC1_UNORM_SRGB = 72,
+    FMT_BC2_UNORM = 74, FMT_BC2_UNORM_SRGB = 75,
+    FMT_BC3_UNORM = 77, FMT_BC3_UNORM_SRGB = 78,
+    FMT_BC4_UNORM = 80, FMT_BC4_SNORM = 81,
+    FMT_BC5_UNORM = 83, FMT_BC5_SNORM = 84,
+    FMT_B8G8R8A8_UNORM = 87, FMT_B8G8R8X8_UNORM = 88,
+    FMT_B8G8R8A8_UNORM_SRGB = 91, FMT_B8G8R8X8_UNORM_SRGB = 93,
+    FMT_BC6H_UF16 = 95, FMT_BC6H_SF16 = 96,
+    FMT_BC7_UNORM = 98, FMT_BC7_UNORM_SRGB = 99,
+};
+
+// BC_FLAGS == TEX_COMPRESS_FLAGS bit-for-bit (BC.h:30-48, DirectXTex.h:887-917).
+enum : uint32_t
+{
+    BCF_DITHER_RGB = 0x10000,
+    BCF_DITHER_A = 0x20000,
+    BCF_UNIFORM = 0x40000,
+    BCF_USE_3SUBSETS = 0x80000,
+    BCF_BC7_QUICK = 0x100000,
+};
+
+// What ConvertScanline does to a loaded tile on the compress path (DirectXTexConvert.cpp:3080-3854
+// restricted to the in/out pairs Compress can produce; sRGB one-sided conversions are rejected on
+// the host). Chosen on the host from (srcFormat, dstFormat).
+enum : int
+{
+    TCV_NONE = 0,
+    TCV_SATURATE = 1,        // FLOAT -> UNORM  (:3481-3486)
+    TCV_CLAMP_SNORM = 2,     // FLOAT -> SNORM  (:3521-3526)
+    TCV_UNORM_TO_SNORM = 3,  // UNORM -> SNORM  v*2 + -1, unfused (:3495-3501)
+    TCV_SNORM_TO_UNORM = 4,  // SNORM -> UNORM  v*0.5 + 0.5 (:3457-3463)
+};
+enum : int
+{
+    TSW_NONE = 0,
+    TSW_R_TO_RGB = 1,        // R format -> RGB format: (x,x,x,w) (:3670-3680)
+    TSW_R_TO_RG = 2,         // R format -> RG format:  (x,x,z,w) (:3683-3693)
+    TSW_A_TO_RGB = 3,        // A format -> !A: splat w (:3657-3666)
+};
+
+struct SrcView
+{
+    const uint8_t* pixels;
+    uint32_t width, height;
+    uint64_t rowPitch;
+    int format;
+    int tcv;      // TCV_*
+    int tsw;      // TSW_*
+};
+
+struct Texel { float r, g, b, a; };
+
+// One texel, LoadScanline semantics for the supported formats.
+__device__ __forceinline__ Texel load_texel(const uint8_t* row, uint32_t x, int format)
+{
+    Texel t;
+    switch (format)
+    {
+    case FMT_R8G8B8A8_UNORM:
+    case FMT_R8G8B8A8_UNORM_SRGB:
+    {
+        // XMLoadUByteN4 (DirectXTexConvert.cpp:909-911): float(byte) * (1/255)
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.r = float(v & 0xFF) * (1.0f / 255.0f);
+        t.g = float((v >> 8) & 0xFF) * (1.0f / 255.0f);
+        t.b = float((v >> 16) & 0xFF) * (1.0f / 255.0f);
+        t.a = float(v >> 24) * (1.0f / 255.0f);
+        break;
+    }
+    case FMT_B8G8R8A8_UNORM:
+    case FMT_B8G8R8A8_UNORM_SRGB:
+    case FMT_B8G8R8X8_UNORM:
+    case FMT_B8G8R8X8_UNORM_SRGB:
+    {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.b = float(v & 0xFF) * (1.0f / 255.0f);
+        t.g = float((v >> 8) & 0xFF) * (1.0f / 255.0f);
+        t.r = float((v >> 16) & 0xFF) * (1.0f / 255.0f);
+        t.a = (format == FMT_B8G8R8X8_UNORM || format == FMT_B8G8R8X8_UNORM_SRGB) ? 1.0f : float(v >> 24) * (1.0f / 255.0f);
+        break;
+    }
+    case FMT_R16G16B16A16_FLOAT:
+    {
+        const uint2 v = reinterpret_cast<const uint2*>(row)[x];
+        t.r = __half2float(__ushort_as_half(uint16_t(v.x & 0xFFFF)));
+        t.g = __half2float(__ushort_as_half(uint16_t(v.x >> 16)));
+        t.b = __half2float(__ushort_as_half(uint16_t(v.y & 0xFFFF)));
+        t.a = __half2float(__ushort_as_half(uint16_t(v.y >> 16)));
+        break;
+    }
+    case FMT_R32G32B32A32_FLOAT:
+    {
+        const float4 v = reinterpret_cast<const float4*>(row)[x];
+        t.r = v.x; t.g = v.y; t.b = v.z; t.a = v.w;
+        break;
+    }
+    case FMT_R8_UNORM:
+        // true division here, unlike the packed loads (DirectXTexConvert.cpp:1113)
+        t.r = float(row[x]) / 255.0f; t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;
+        break;
+    case FMT_R8G8_UNORM:
+    {
+        const uint16_t v = reinterpret_cast<const uint16_t*>(row)[x];
+        t.r = float(v & 0xFF) * (1.0f / 255.0f); t.g = float(v >> 8) * (1.0f / 255.0f); t.b = 0.0f; t.a = 1.0f;
+        break;
+    }
+    case FMT_R8_SNORM:
+        t.r = float(int8_t(row[x])) / 127.0f; t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;   // :1139, no clamp
+        break;
+    case FMT_R32_FLOAT:
+        t.r = reinterpret_cast<const float*>(row)[x]; t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;
+        break;
+    case FMT_R16_FLOAT:
+        t.r = __half2float(__ushort_as_half(reinterpret_cast<const uint16_t*>(row)[x])); t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;
+        break;
+    case FMT_A8_UNORM:
+        t.r = 0.0f; t.g = 0.0f; t.b = 0.0f; t.a = float(row[x]) / 255.0f;   // :1165
+        break;
+    default:
+        t.r = t.g = t.b = 0.0f; t.a = 1.0f;
+        break;
+    }
+    return t;
+}
+
+__device__ __forceinline__ float tcv1(float v, int tcv)
+{
+    switch (tcv)
+    {
+    case TCV_SATURATE: { float m = (v > 0.0f) ? v : 0.0f; return (m < 1.0f) ? m : 1.0f; }   // maxps then minps
+    case TCV_CLAMP_SNORM: { float m = (v > -1.0f) ? v : -1.0f; return (m < 1.0f) ? m : 1.0f; }
+    case TCV_UNORM_TO_SNORM: return v * 2.0f + -1.0f;
+    case TCV_SNORM_TO_UNORM: return v * 0.5f + 0.5f;
+    default: return v;
+    }
+}
+
+__device__ __forceinline__ Texel convert_texel(Texel t, int tcv, int tsw)
+{
+    if (tcv != TCV_NONE)
+    {
+        t.r = tcv1(t.r, tcv); t.g = tcv1(t.g, tcv); t.b = tcv1(t.b, tcv); t.a = tcv1(t.a, tcv);
+    }
+    switch (tsw)
+    {
+    case TSW_R_TO_RGB: t.g = t.r; t.b = t.r; break;
+    case TSW_R_TO_RG: t.g = t.r; break;
+    case TSW_A_TO_RGB: t.r = t.a; t.g = t.a; t.b = t.a; break;
+    default: break;
+    }
+    return t;
+}
+
+// Gathers block (bx, by) as 16 texels, row-major temp[y*4+x], replicating partial blocks exactly like
+// the reference (uSrc = {0,0,0,1}: column/row s >= extent copies column/row uSrc[s], applied in
+// increasing s so a 1-wide block replicates column 0 everywhere; DirectXTexCompress.cpp:315-341).
+struct Tile { float r[16], g[16], b[16], a[16]; };
+
+__device__ __forceinline__ uint32_t replicate_src(uint32_t s, uint32_t extent)
+{
+    if (s < extent) return s;
+    return (s == 3 && extent > 1) ? 1u : 0u;
+}
+
+__device__ __forceinline__ void load_tile(const SrcView& src, uint32_t bx, uint32_t by, Tile& t)
+{
+    const uint32_t x0 = bx * 4, y0 = by * 4;
+    const uint32_t pw = min(4u, src.width - x0);
+    const uint32_t ph = min(4u, src.height - y0);
+    const int format = src.format;
+#pragma unroll
+    for (uint32_t y = 0; y < 4; ++y)
+    {
+        const uint32_t sy = y0 + replicate_src(y, ph);
+        const uint8_t* row = src.pixels + uint64_t(sy) * src.rowPitch;
+        if (pw == 4 && (format == FMT_R8G8B8A8_UNORM || format == FMT_R8G8B8A8_UNORM_SRGB))
+        {
+            // fast path: one 16-byte load per tile row, coalesced across the wave (lane = block)
+            const uint4 v = *reinterpret_cast<const uint4*>(row + uint64_t(x0) * 4);
+            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (uint32_t x = 0; x < 4; ++x)
+            {
+                Texel px;
+                px.r = float(w[x] & 0xFF) * (1.0f / 255.0f);
+                px.g = float((w[x] >> 8) & 0xFF) * (1.0f / 255.0f);
+                px.b = float((w[x] >> 16) & 0xFF) * (1.0f / 255.0f);
+                px.a = float(w[x] >> 24) * (1.0f / 255.0f);
+                px = convert_texel(px, src.tcv, src.tsw);
+                t.r[y * 4 + x] = px.r; t.g[y * 4 + x] = px.g; t.b[y * 4 + x] = px.b; t.a[y * 4 + x] = px.a;
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (uint32_t x = 0; x < 4; ++x)
+            {
+                const uint32_t sx = x0 + replicate_src(x, pw);
+                Texel px = convert_texel(load_texel(row, sx, format), src.tcv, src.tsw);
+                t.r[y * 4 + x] = px.r; t.g[y * 4 + x] = px.g; t.b[y * 4 + x] = px.b; t.a[y * 4 + x] = px.a;
+            }
+        }
+    }
+}
+
+} // namespace dxtex

@@ -1,0 +1,62 @@
+// Host-side format tables for the formats this library handles (DirectXTexUtil.cpp:340-1186 semantics).
+#pragma once
+#include "dxtex_device.h"
+#include <stddef.h>
+
+namespace dxtex
+{
+enum FmtClass : uint32_t
+{
+    FC_UNORM = 1, FC_SNORM = 2, FC_FLOAT = 4, FC_BC = 8,
+    FC_R = 0x10, FC_G = 0x20, FC_B = 0x40, FC_A = 0x80, FC_SRGB = 0x100,
+};
+
+struct FmtInfo { int format; uint32_t bpp; uint32_t cls; };
+
+inline const FmtInfo* format_info(int format)
+{
+    static const FmtInfo table[] = {
+        { FMT_R32G32B32A32_FLOAT, 128, FC_FLOAT | FC_R | FC_G | FC_B | FC_A },
+        { FMT_R16G16B16A16_FLOAT, 64, FC_FLOAT | FC_R | FC_G | FC_B | FC_A },
+        { FMT_R8G8B8A8_UNORM, 32, FC_UNORM | FC_R | FC_G | FC_B | FC_A },
+        { FMT_R8G8B8A8_UNORM_SRGB, 32, FC_UNORM | FC_R | FC_G | FC_B | FC_A | FC_SRGB },
+        { FMT_B8G8R8A8_UNORM, 32, FC_UNORM | FC_R | FC_G | FC_B | FC_A },
+        { FMT_B8G8R8A8_UNORM_SRGB, 32, FC_UNORM | FC_R | FC_G | FC_B | FC_A | FC_SRGB },
+        { FMT_B8G8R8X8_UNORM, 32, FC_UNORM | FC_R | FC_G | FC_B },
+        { FMT_B8G8R8X8_UNORM_SRGB, 32, FC_UNORM | FC_R | FC_G | FC_B | FC_SRGB },
+        { FMT_R8G8_UNORM, 16, FC_UNORM | FC_R | FC_G },
+        { FMT_R8_UNORM, 8, FC_UNORM | FC_R },
+        { FMT_R8_SNORM, 8, FC_SNORM | FC_R },
+        { FMT_A8_UNORM, 8, FC_UNORM | FC_A },
+        { FMT_R32_FLOAT, 32, FC_FLOAT | FC_R },
+        { FMT_R16_FLOAT, 16, FC_FLOAT | FC_R },
+        { FMT_BC1_UNORM, 4, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A },
+        { FMT_BC1_UNORM_SRGB, 4, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_SRGB },
+        { FMT_BC2_UNORM, 8, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A },
+        { FMT_BC2_UNORM_SRGB, 8, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_SRGB },
+        { FMT_BC3_UNORM, 8, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A },
+        { FMT_BC3_UNORM_SRGB, 8, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_SRGB },
+        { FMT_BC4_UNORM, 4, FC_UNORM | FC_BC | FC_R },
+        { FMT_BC4_SNORM, 4, FC_SNORM | FC_BC | FC_R },
+        { FMT_BC5_UNORM, 8, FC_UNORM | FC_BC | FC_R | FC_G },
+        { FMT_BC5_SNORM, 8, FC_SNORM | FC_BC | FC_R | FC_G },
+        { FMT_BC6H_UF16, 8, FC_FLOAT | FC_BC | FC_R | FC_G | FC_B | FC_A },
+        { FMT_BC6H_SF16, 8, FC_FLOAT | FC_BC | FC_R | FC_G | FC_B | FC_A },
+        { FMT_BC7_UNORM, 8, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A },
+        { FMT_BC7_UNORM_SRGB, 8, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_SRGB },
+    };
+    for (const FmtInfo& f : table)
+        if (f.format == format) return &f;
+    return nullptr;
+}
+
+inline bool is_bc(int format) { const FmtInfo* f = format_info(format); return f && (f->cls & FC_BC); }
+inline size_t bc_block_bytes(int format)
+{
+    switch (format)
+    {
+    case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: case FMT_BC4_UNORM: case FMT_BC4_SNORM: return 8;
+    default: return is_bc(format) ? 16 : 0;
+    }
+}
+} // namespace dxtex

@@ -1,0 +1,167 @@
+/*
+ * dxtex_amd.h - C ABI of the MI355X-native DirectXTex hot path (libdxtex_amd.so).
+ *
+ * Drop-in boundary: these entry points are what a maintainer of microsoft/DirectXTex would bind in place
+ * of the library's own GPU plugin (GPUCompressBC, DirectXTex/BCDirectCompute.h:15-68) and of the CPU
+ * loops behind Compress / Decompress / GenerateMipMaps / Convert / Resize. Plain pointers and sizes only;
+ * every function returns an HRESULT with the reference's values (DirectXTexP.h:210-234).
+ *
+ *   reference interface                                         replaced by
+ *   ----------------------------------------------------------  -----------------------------------------
+ *   GPUCompressBC::Initialize(ID3D11Device*)   BCDirectCompute.h:26   dxtex_ctx_create
+ *   GPUCompressBC::Prepare(w,h,flags,fmt,aw)   BCDirectCompute.h:28   (folded into compress: no per-size state)
+ *   GPUCompressBC::Compress(src,dst)           BCDirectCompute.h:30   dxtex_compress / dxtex_compress_device
+ *   CompressBC / CompressBC_Parallel           DirectXTexCompress.cpp:72-372   dxtex_compress
+ *   DecompressBC                               DirectXTexCompress.cpp:425-535  dxtex_decompress
+ *   BC_ENCODE / BC_DECODE fn-ptr hooks         BC.h:318-343           dxtex_encode_blocks / dxtex_decode_blocks
+ *   Generate2DMips{Point,Box,Linear,Cubic,Triangle}Filter  DirectXTexMipmaps.cpp:907-1602  dxtex_generate_mips
+ *   ConvertCustom                              DirectXTexConvert.cpp:4804-4913 dxtex_convert
+ *   Resize*Filter                              DirectXTexResize.cpp:255-803    dxtex_resize
+ *
+ * Threading: a context is bound to one GPU and one HIP stream; use one context per GPU (or per host
+ * thread). Contexts share nothing. No function retains caller pointers past its return, except the
+ * *_device variants, which are asynchronous on the context's stream.
+ */
+#ifndef DXTEX_AMD_H
+#define DXTEX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t dxtex_hresult;
+
+#define DXTEX_S_OK                 ((dxtex_hresult)0)
+#define DXTEX_E_FAIL               ((dxtex_hresult)0x80004005)
+#define DXTEX_E_INVALIDARG         ((dxtex_hresult)0x80070057)
+#define DXTEX_E_OUTOFMEMORY        ((dxtex_hresult)0x8007000E)
+#define DXTEX_E_POINTER            ((dxtex_hresult)0x80004003)
+#define DXTEX_E_ABORT              ((dxtex_hresult)0x80004004)
+#define DXTEX_E_NOTIMPL            ((dxtex_hresult)0x80004001)
+#define DXTEX_E_UNEXPECTED         ((dxtex_hresult)0x8000FFFF)
+#define DXTEX_E_NOT_SUPPORTED      ((dxtex_hresult)0x80070032)  /* HRESULT_FROM_WIN32(ERROR_NOT_SUPPORTED) */
+#define DXTEX_E_ARITHMETIC_OVERFLOW ((dxtex_hresult)0x80070216)
+
+/* TEX_COMPRESS_FLAGS, bit-for-bit (DirectXTex.h:887-917). */
+#define DXTEX_COMPRESS_DEFAULT          0u
+#define DXTEX_COMPRESS_RGB_DITHER       0x10000u
+#define DXTEX_COMPRESS_A_DITHER         0x20000u
+#define DXTEX_COMPRESS_DITHER           0x30000u
+#define DXTEX_COMPRESS_UNIFORM          0x40000u
+#define DXTEX_COMPRESS_BC7_USE_3SUBSETS 0x80000u
+#define DXTEX_COMPRESS_BC7_QUICK        0x100000u
+#define DXTEX_COMPRESS_SRGB_IN          0x1000000u
+#define DXTEX_COMPRESS_SRGB_OUT         0x2000000u
+#define DXTEX_COMPRESS_PARALLEL         0x10000000u
+
+/* TEX_FILTER_FLAGS subset (DirectXTex.h:741-793). */
+#define DXTEX_FILTER_DEFAULT   0u
+#define DXTEX_FILTER_WRAP_U    0x1u
+#define DXTEX_FILTER_WRAP_V    0x2u
+#define DXTEX_FILTER_MIRROR_U  0x10u
+#define DXTEX_FILTER_MIRROR_V  0x20u
+#define DXTEX_FILTER_POINT     0x100000u
+#define DXTEX_FILTER_LINEAR    0x200000u
+#define DXTEX_FILTER_CUBIC     0x300000u
+#define DXTEX_FILTER_BOX       0x400000u
+#define DXTEX_FILTER_TRIANGLE  0x500000u
+#define DXTEX_FILTER_MODE_MASK 0xF00000u
+
+/* Mirrors DirectX::Image (DirectXTex.h:437-445); `format` is a DXGI_FORMAT value. */
+typedef struct dxtex_image
+{
+    size_t   width;
+    size_t   height;
+    int32_t  format;
+    size_t   rowPitch;
+    size_t   slicePitch;
+    uint8_t* pixels;
+} dxtex_image;
+
+typedef struct dxtex_ctx dxtex_ctx;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+
+/* Binds a context to HIP device `device` and creates its stream. Fails with DXTEX_E_FAIL when no
+ * gfx950-capable device is visible: there is no CPU fallback anywhere in this library. */
+dxtex_hresult dxtex_ctx_create(int device, dxtex_ctx** out);
+void          dxtex_ctx_destroy(dxtex_ctx* ctx);
+/* Run subsequent work on a caller-owned hipStream_t (e.g. the current PyTorch stream); NULL restores
+ * the context's own stream. */
+dxtex_hresult dxtex_ctx_set_stream(dxtex_ctx* ctx, void* hip_stream);
+void*         dxtex_ctx_get_stream(dxtex_ctx* ctx);
+dxtex_hresult dxtex_ctx_synchronize(dxtex_ctx* ctx);
+/* Human-readable description of the last failure on this context (never NULL). */
+const char*   dxtex_ctx_last_error(dxtex_ctx* ctx);
+/* Device time in milliseconds of the kernels launched by the most recent call on this context
+ * (hipEvent pair on the context's stream, transfers excluded); -1 if nothing was timed. */
+float         dxtex_ctx_last_kernel_ms(dxtex_ctx* ctx);
+
+/* ---- format utilities (DirectXTexUtil.cpp:340-1186) ------------------------------------------- */
+
+int           dxtex_is_compressed(int32_t format);
+size_t        dxtex_bits_per_pixel(int32_t format);
+/* ComputePitch (DirectXTexUtil.cpp:961-1186) with CP_FLAGS_NONE. */
+dxtex_hresult dxtex_compute_pitch(int32_t format, size_t width, size_t height, size_t* rowPitch, size_t* slicePitch);
+
+/* ---- Compress / Decompress -------------------------------------------------------------------- */
+
+/* Host images in, host image out: H2D copy, kernels, D2H copy, synchronous. `dst` must already describe
+ * a BC image of the same width/height (ScratchImage::Initialize2D layout). Error behaviour follows
+ * CompressBC (DirectXTexCompress.cpp:72-205): E_POINTER for null pixels, HRESULT_E_NOT_SUPPORTED for an
+ * unsupported source/destination format, E_INVALIDARG for a compressed source. */
+dxtex_hresult dxtex_compress(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst,
+                             uint32_t compress_flags, float threshold);
+
+/* Same, but `src->pixels` / `dst->pixels` are device pointers on the context's GPU; asynchronous on the
+ * context's stream. This is the entry point the benchmark times (inputs resident in HBM). */
+dxtex_hresult dxtex_compress_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst,
+                                    uint32_t compress_flags, float threshold);
+
+/* Batch of `count` independent images (texture array / atlas pages) on device memory; one stream-ordered
+ * submission. */
+dxtex_hresult dxtex_compress_many_device(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts,
+                                         size_t count, uint32_t compress_flags, float threshold);
+
+/* BC -> uncompressed (R8G8B8A8_UNORM, R16G16B16A16_FLOAT, R32G32B32A32_FLOAT, R8_UNORM/SNORM, R8G8_*).
+ * Host and device variants as above. */
+dxtex_hresult dxtex_decompress(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst);
+dxtex_hresult dxtex_decompress_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst);
+
+/* Block-level hooks with the reference's BC_ENCODE / BC_DECODE shape (BC.h:318-343): `rgba` holds
+ * nblocks x 16 texels x 4 floats (row-major 4x4 tiles) in host memory, `bc` nblocks x 8|16 bytes.
+ * `threshold` is only read for BC1. */
+dxtex_hresult dxtex_encode_blocks(dxtex_ctx* ctx, int32_t bc_format, uint32_t bc_flags, float threshold,
+                                  const float* rgba, size_t nblocks, uint8_t* bc);
+dxtex_hresult dxtex_decode_blocks(dxtex_ctx* ctx, int32_t bc_format, const uint8_t* bc, size_t nblocks, float* rgba);
+
+/* ---- GenerateMipMaps / Convert / Resize -------------------------------------------------------- */
+
+/* Fills levels[1..nlevels-1] from levels[0] (each level from the previous *stored* level,
+ * DirectXTexMipmaps.cpp:1036-1037). All levels share levels[0].format. `filter` = TEX_FILTER_FLAGS. */
+dxtex_hresult dxtex_generate_mips(dxtex_ctx* ctx, const dxtex_image* levels, size_t nlevels, uint32_t filter);
+dxtex_hresult dxtex_generate_mips_device(dxtex_ctx* ctx, const dxtex_image* levels, size_t nlevels, uint32_t filter);
+
+dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float threshold);
+dxtex_hresult dxtex_convert_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float threshold);
+
+dxtex_hresult dxtex_resize(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter);
+dxtex_hresult dxtex_resize_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter);
+
+/* ComputeMSE (DirectXTexMisc.cpp:27-176) for two same-size images on the device: per-channel MSE in
+ * mse[4] over [0,1] floats. Used for PSNR reporting without a D2H round trip. */
+dxtex_hresult dxtex_compute_mse_device(dxtex_ctx* ctx, const dxtex_image* a, const dxtex_image* b, double mse[4]);
+
+/* ---- device memory helpers (so non-HIP hosts can stay resident in HBM) -------------------------- */
+dxtex_hresult dxtex_device_alloc(dxtex_ctx* ctx, size_t bytes, void** out);
+dxtex_hresult dxtex_device_free(dxtex_ctx* ctx, void* p);
+dxtex_hresult dxtex_memcpy_h2d(dxtex_ctx* ctx, void* dst, const void* src, size_t bytes);
+dxtex_hresult dxtex_memcpy_d2h(dxtex_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DXTEX_AMD_H */

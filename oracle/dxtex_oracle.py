@@ -1,0 +1,201 @@
+"""TEST INFRASTRUCTURE ONLY. CPU oracle for Compress / Decompress (see oracle/__init__.py).
+
+Parity status: the block codecs are the reference itself (oracle/_ref). The scanline conventions that
+live in DirectXMath (XMLoadUByteN4 = float(b) * (1/255.f), XMLoadHalf4 exact, ...) are restated from
+its published behaviour - DirectXMath is not vendored in /root/reference and no reference test pins
+them: PARITY UNPINNED at that boundary.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REF_PATH = os.path.join(_HERE, "_ref", "libdxtex_ref.so")
+
+BC_BLOCK_BYTES = {71: 8, 72: 8, 80: 8, 81: 8, 74: 16, 75: 16, 77: 16, 78: 16, 83: 16, 84: 16, 95: 16, 96: 16, 98: 16, 99: 16}
+
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(_REF_PATH)
+
+
+def _load_ref():
+    global _ref
+    if _ref is None:
+        if not have_ref():
+            raise RuntimeError(f"{_REF_PATH} missing: run `make -C oracle ref` where /root/reference exists")
+        lib = ctypes.CDLL(_REF_PATH)
+        lib.dxtex_ref_encode_blocks.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p,
+                                                ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+        lib.dxtex_ref_encode_blocks.restype = ctypes.c_int
+        lib.dxtex_ref_decode_blocks.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        lib.dxtex_ref_decode_blocks.restype = ctypes.c_int
+        lib.dxtex_ref_num_threads.restype = ctypes.c_int
+        _ref = lib
+    return _ref
+
+
+def ref_num_threads():
+    return int(_load_ref().dxtex_ref_num_threads())
+
+
+def ref_encode_blocks(bc_format, rgba, flags=0, threshold=0.5, threads=0):
+    """D3DXEncodeBC* of the reference (BC.h:332-343) on (n,16,4) float32 tiles -> (n, 8|16) uint8."""
+    rgba = np.ascontiguousarray(rgba, np.float32).reshape(-1, 16, 4)
+    n = rgba.shape[0]
+    out = np.zeros((n, BC_BLOCK_BYTES[bc_format]), np.uint8)
+    rc = _load_ref().dxtex_ref_encode_blocks(bc_format, flags & 0x1F0000, threshold, rgba.ctypes.data, n, out.ctypes.data, threads)
+    assert rc == 0
+    return out
+
+
+def ref_decode_blocks(bc_format, blocks):
+    """D3DXDecodeBC* of the reference (BC.h:321-330): (n, 8|16) uint8 -> (n,16,4) float32."""
+    blocks = np.ascontiguousarray(blocks, np.uint8).reshape(-1, BC_BLOCK_BYTES[bc_format])
+    n = blocks.shape[0]
+    out = np.zeros((n, 16, 4), np.float32)
+    rc = _load_ref().dxtex_ref_decode_blocks(bc_format, blocks.ctypes.data, n, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+# ---- LoadScanline restatement (DirectXTexConvert.cpp:779-1619) -----------------------------------------
+
+_F = np.float32
+
+
+def load_image(pixels, width, height, fmt, row_pitch=None):
+    """-> (H, W, 4) float32, exactly what LoadScanline puts in the XMVECTOR row buffer."""
+    raw = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
+    bpp = {2: 16, 10: 8, 28: 4, 29: 4, 87: 4, 88: 4, 91: 4, 93: 4, 49: 2, 61: 1, 63: 1, 65: 1, 41: 4, 54: 2}[fmt]
+    rp = row_pitch or width * bpp
+    rows = np.stack([raw[y * rp: y * rp + width * bpp] for y in range(height)])
+    out = np.zeros((height, width, 4), np.float32)
+    out[..., 3] = 1.0
+    if fmt in (28, 29):        # R8G8B8A8_UNORM: XMLoadUByteN4, :909-911
+        out[:] = rows.reshape(height, width, 4).astype(np.float32) * _F(1.0 / 255.0)
+    elif fmt in (87, 91):      # B8G8R8A8: XMLoadUByteN4 + swizzle<2,1,0,3>, :1260-1273
+        v = rows.reshape(height, width, 4).astype(np.float32) * _F(1.0 / 255.0)
+        out[:] = v[..., [2, 1, 0, 3]]
+    elif fmt in (88, 93):      # B8G8R8X8: alpha forced to 1, :1275-1289
+        v = rows.reshape(height, width, 4).astype(np.float32) * _F(1.0 / 255.0)
+        out[..., :3] = v[..., [2, 1, 0]]
+    elif fmt == 10:            # R16G16B16A16_FLOAT: XMLoadHalf4 (exact), :820-821
+        out[:] = rows.view(np.float16).reshape(height, width, 4).astype(np.float32)
+    elif fmt == 2:             # R32G32B32A32_FLOAT: memcpy, :798-803
+        out[:] = rows.view(np.float32).reshape(height, width, 4)
+    elif fmt == 61:            # R8_UNORM: float(b) / 255.f (true division), :1106-1117
+        out[..., 0] = rows.reshape(height, width).astype(np.float32) / _F(255.0)
+        out[..., 1:3] = 0
+    elif fmt == 63:            # R8_SNORM: float(b) / 127.f, :1132-1143
+        out[..., 0] = rows.view(np.int8).reshape(height, width).astype(np.float32) / _F(127.0)
+        out[..., 1:3] = 0
+    elif fmt == 65:            # A8_UNORM: (0,0,0,a/255.f), :1158-1169
+        out[..., :3] = 0
+        out[..., 3] = rows.reshape(height, width).astype(np.float32) / _F(255.0)
+    elif fmt == 49:            # R8G8_UNORM: XMLoadUByteN2 -> (x,y,0,1), :1028-1029
+        v = rows.reshape(height, width, 2).astype(np.float32) * _F(1.0 / 255.0)
+        out[..., :2] = v
+        out[..., 2] = 0
+    elif fmt == 41:            # R32_FLOAT
+        out[..., 0] = rows.view(np.float32).reshape(height, width)
+        out[..., 1:3] = 0
+    elif fmt == 54:            # R16_FLOAT: XMConvertHalfToFloat, :1040-1051
+        out[..., 0] = rows.view(np.float16).reshape(height, width).astype(np.float32)
+        out[..., 1:3] = 0
+    else:
+        raise NotImplementedError(fmt)
+    return out
+
+
+_UNORM_SRC = {28, 29, 87, 88, 91, 93, 49, 61, 65}
+_FLOAT_SRC = {2, 10, 41, 54}
+_SNORM_SRC = {63}
+_R_ONLY_SRC = {61, 63, 41, 54}
+
+
+def convert_tiles(tiles, src_fmt, dst_fmt):
+    """ConvertScanline on the compress path (DirectXTexConvert.cpp:3080-3854; branches at :3453-3530 and
+    :3650-3695). tiles: (..., 4) float32, returns a new array."""
+    t = tiles.astype(np.float32, copy=True)
+    out_unorm = dst_fmt in (71, 72, 74, 75, 77, 78, 80, 83, 98, 99)
+    out_snorm = dst_fmt in (81, 84)
+    if out_unorm:
+        if src_fmt in _SNORM_SRC:
+            t = t * _F(0.5) + _F(0.5)
+        elif src_fmt in _FLOAT_SRC:
+            t = np.minimum(np.maximum(t, _F(0)), _F(1))           # XMVectorSaturate
+    elif out_snorm:
+        if src_fmt in _UNORM_SRC:
+            t = t * _F(2.0) + _F(-1.0)                             # XMVectorMultiplyAdd(v, 2, -1), unfused
+        elif src_fmt in _FLOAT_SRC:
+            t = np.minimum(np.maximum(t, _F(-1)), _F(1))
+    out_rgb = dst_fmt in (71, 72, 74, 75, 77, 78, 95, 96, 98, 99)
+    out_rg = dst_fmt in (83, 84)
+    out_has_a = out_rgb
+    if src_fmt == 65 and not out_has_a:
+        t[..., 0] = t[..., 3]; t[..., 1] = t[..., 3]; t[..., 2] = t[..., 3]   # splat W, :3657-3666
+    elif src_fmt in _R_ONLY_SRC:
+        if out_rgb:
+            t[..., 1] = t[..., 0]; t[..., 2] = t[..., 0]                      # :3670-3680
+        elif out_rg:
+            t[..., 1] = t[..., 0]                                            # :3683-3693
+    return t
+
+
+def gather_tiles(img):
+    """(H, W, 4) float32 -> (nbh*nbw, 16, 4) tiles temp[y*4+x], replicating partial blocks with
+    uSrc = {0,0,0,1} exactly as CompressBC does (DirectXTexCompress.cpp:315-341)."""
+    h, w = img.shape[:2]
+    nbw, nbh = (w + 3) // 4, (h + 3) // 4
+
+    def src_index(n, extent_total):
+        idx = np.zeros((n, 4), np.int64)
+        for b in range(n):
+            ext = min(4, extent_total - b * 4)
+            for s in range(4):
+                if s < ext:
+                    k = s
+                else:
+                    k = 1 if (s == 3 and ext > 1) else 0
+                idx[b, s] = b * 4 + k
+        return idx
+
+    xi = src_index(nbw, w)      # (nbw, 4)
+    yi = src_index(nbh, h)      # (nbh, 4)
+    t = img[yi[:, None, :, None], xi[None, :, None, :]]     # (nbh, nbw, 4y, 4x, 4)
+    return np.ascontiguousarray(t.reshape(nbh * nbw, 16, 4))
+
+
+def compress_image(pixels, width, height, src_fmt, dst_fmt, flags=0, threshold=0.5, row_pitch=None, threads=0):
+    """Oracle for DirectX::Compress on one image: CompressBC (DirectXTexCompress.cpp:72-205) with the
+    reference's block encoders. Returns the tight-pitch BC payload as uint8."""
+    if ((src_fmt in (29, 91, 93)) or bool(flags & 0x1000000)) != ((dst_fmt in (72, 75, 78, 99)) or bool(flags & 0x2000000)):
+        raise NotImplementedError("one-sided sRGB")
+    img = load_image(pixels, width, height, src_fmt, row_pitch)
+    tiles = convert_tiles(gather_tiles(img), src_fmt, dst_fmt)
+    return ref_encode_blocks(dst_fmt, tiles, flags, threshold, threads).reshape(-1)
+
+
+def decode_image(payload, width, height, bc_fmt):
+    """BC payload -> (H, W, 4) float32 via the reference decoders (DecompressBC, DirectXTexCompress.cpp:425-535)."""
+    nbw, nbh = (width + 3) // 4, (height + 3) // 4
+    t = ref_decode_blocks(bc_fmt, payload).reshape(nbh, nbw, 4, 4, 4)
+    img = t.transpose(0, 2, 1, 3, 4).reshape(nbh * 4, nbw * 4, 4)
+    return img[:height, :width]
+
+
+def compute_mse(a, b):
+    """ComputeMSE (DirectXTexMisc.cpp:27-176): per-channel sum of squared differences / (w*h), on floats."""
+    d = a.astype(np.float64) - b.astype(np.float64)
+    return (d * d).reshape(-1, a.shape[-1]).mean(axis=0)
+
+
+def psnr_rgb(a, b):
+    """texdiag's PSNR: 10*log10(3 / (mseR + mseG + mseB)) (Texdiag/texdiag.cpp:3531-3532)."""
+    m = compute_mse(a, b)
+    s = float(m[0] + m[1] + m[2])
+    return float("inf") if s == 0 else 10.0 * np.log10(3.0 / s)

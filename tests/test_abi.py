@@ -1,0 +1,48 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/dxtex_amd.h declares (no
+compute calls without a GPU), pitch arithmetic matches ComputePitch (DirectXTexUtil.cpp:961-1186)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dxtex_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dxtex_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    import ctypes
+    import directxtex_amd as dx
+    lib = ctypes.CDLL(dx.library_path())
+    names = _declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dxtex_amd.h but not exported"
+    from directxtex_amd import capi
+    assert set(capi.EXPORTED_SYMBOLS) == set(names)
+
+
+def test_compute_pitch():
+    import directxtex_amd as dx
+    assert dx.compute_pitch(dx.DXGI_FORMAT_BC1_UNORM, 256, 256) == (512, 512 * 64)
+    assert dx.compute_pitch(dx.DXGI_FORMAT_BC7_UNORM, 4096, 4096) == (16384, 16384 * 1024)
+    assert dx.compute_pitch(dx.DXGI_FORMAT_BC3_UNORM, 1, 1) == (16, 16)
+    assert dx.compute_pitch(dx.DXGI_FORMAT_BC4_UNORM, 5, 7) == (16, 32)
+    assert dx.compute_pitch(dx.DXGI_FORMAT_R8G8B8A8_UNORM, 13, 3) == (52, 156)
+    assert dx.compute_pitch(dx.DXGI_FORMAT_R16G16B16A16_FLOAT, 4096, 2) == (32768, 65536)
+    assert dx.is_compressed(dx.DXGI_FORMAT_BC6H_UF16) and not dx.is_compressed(dx.DXGI_FORMAT_R8_UNORM)
+    assert dx.bits_per_pixel(dx.DXGI_FORMAT_R32G32B32A32_FLOAT) == 128
+
+
+def test_no_context_without_gpu():
+    """Without a gfx950 device the library must refuse to create a context - never fall back to CPU."""
+    import torch
+    import directxtex_amd as dx
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(dx.DxtexError):
+        dx.Context(0)

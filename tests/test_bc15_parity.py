@@ -1,0 +1,117 @@
+"""BC1-BC5: the HIP encoders must be byte-identical to the reference CPU encoders
+(D3DXEncodeBC1..BC5, BC.cpp / BC4BC5.cpp) - through the C ABI, on seeded synthetic inputs that cover
+partial blocks, colour-key alpha, flat / two-colour blocks, the 6-step alpha modes and every flag."""
+import numpy as np
+import pytest
+
+import directxtex_amd as dx
+from directxtex_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+BC15 = [dx.DXGI_FORMAT_BC1_UNORM, dx.DXGI_FORMAT_BC2_UNORM, dx.DXGI_FORMAT_BC3_UNORM, dx.DXGI_FORMAT_BC4_UNORM,
+        dx.DXGI_FORMAT_BC4_SNORM, dx.DXGI_FORMAT_BC5_UNORM, dx.DXGI_FORMAT_BC5_SNORM]
+FLAGSETS = [0, dx.TEX_COMPRESS_UNIFORM, dx.TEX_COMPRESS_RGB_DITHER, dx.TEX_COMPRESS_A_DITHER,
+            dx.TEX_COMPRESS_DITHER | dx.TEX_COMPRESS_UNIFORM]
+
+
+def _mismatch(a, b, bb):
+    a = a.reshape(-1, bb); b = b.reshape(-1, bb)
+    bad = np.nonzero((a != b).any(axis=1))[0]
+    return bad
+
+
+@pytest.mark.parametrize("fmt", BC15)
+@pytest.mark.parametrize("alpha", ["opaque", "random", "binary", "smooth"])
+def test_image_bit_exact(ctx, oracle, fmt, alpha):
+    w, h = 256, 256           # BASELINE config 1 size
+    img = synth.rgba8(w, h, seed=1, alpha=alpha)
+    got = ctx.compress(img, w, h, dx.DXGI_FORMAT_R8G8B8A8_UNORM, fmt, 0, 0.5)
+    ref = oracle.compress_image(img, w, h, dx.DXGI_FORMAT_R8G8B8A8_UNORM, fmt, 0, 0.5)
+    bad = _mismatch(got, ref, dx.BC_BLOCK_BYTES[fmt])
+    assert bad.size == 0, f"{bad.size} of {ref.size // dx.BC_BLOCK_BYTES[fmt]} blocks differ, first {bad[:8]}"
+
+
+@pytest.mark.parametrize("fmt", [dx.DXGI_FORMAT_BC1_UNORM, dx.DXGI_FORMAT_BC2_UNORM, dx.DXGI_FORMAT_BC3_UNORM])
+@pytest.mark.parametrize("flags", FLAGSETS)
+@pytest.mark.parametrize("threshold", [0.5, 0.0, 1.0])
+def test_flags_bit_exact(ctx, oracle, fmt, flags, threshold):
+    w, h = 128, 96
+    img = synth.rgba8(w, h, seed=5, alpha="smooth")
+    got = ctx.compress(img, w, h, dx.DXGI_FORMAT_R8G8B8A8_UNORM, fmt, flags, threshold)
+    ref = oracle.compress_image(img, w, h, dx.DXGI_FORMAT_R8G8B8A8_UNORM, fmt, flags, threshold)
+    bad = _mismatch(got, ref, dx.BC_BLOCK_BYTES[fmt])
+    assert bad.size == 0, f"{bad.size} blocks differ, first {bad[:8]}"
+
+
+@pytest.mark.parametrize("fmt", BC15)
+@pytest.mark.parametrize("size", [(1, 1), (2, 3), (3, 2), (5, 7), (13, 4), (4, 13), (67, 45)])
+def test_partial_blocks(ctx, oracle, fmt, size):
+    w, h = size
+    img = synth.rgba8(w, h, seed=9, alpha="random")
+    got = ctx.compress(img, w, h, dx.DXGI_FORMAT_R8G8B8A8_UNORM, fmt, 0, 0.5)
+    ref = oracle.compress_image(img, w, h, dx.DXGI_FORMAT_R8G8B8A8_UNORM, fmt, 0, 0.5)
+    assert np.array_equal(got, ref)
+
+
+def _special_tiles():
+    rng = np.random.default_rng(1234)
+    tiles = []
+    # single colour, two colours, alpha extremes (trigger the 6-step alpha / 4-block BC4 codec), ramps
+    for v in (0.0, 1.0, 0.5, 100 / 255.0):
+        t = np.full((16, 4), v, np.float32); tiles.append(t)
+    t = np.zeros((16, 4), np.float32); t[:8] = 1.0; tiles.append(t)
+    t = np.tile(np.linspace(0, 1, 16, dtype=np.float32)[:, None], (1, 4)); tiles.append(t)
+    t = t.copy(); t[0, 3] = 0.0; t[5, 3] = 1.0; tiles.append(t)
+    for _ in range(400):
+        base = rng.random((1, 4), dtype=np.float32)
+        spread = rng.choice([0.0, 0.004, 0.02, 0.1, 0.5, 1.0])
+        t = np.clip(base + spread * (rng.random((16, 4), dtype=np.float32) - 0.5), 0, 1)
+        q = rng.integers(0, 3)
+        if q == 0:
+            t = np.round(t * 255) / 255
+        elif q == 1:
+            t[rng.integers(0, 16, 3), 3] = rng.choice([0.0, 1.0])
+        tiles.append(t.astype(np.float32))
+    return np.stack(tiles)
+
+
+@pytest.mark.parametrize("fmt", BC15)
+@pytest.mark.parametrize("flags", [0, dx.TEX_COMPRESS_DITHER])
+def test_block_hook_bit_exact(ctx, oracle, fmt, flags):
+    """BC_ENCODE-shaped hook (BC.h:318-343): raw float tiles in, blocks out."""
+    tiles = _special_tiles()
+    if fmt in (dx.DXGI_FORMAT_BC4_SNORM, dx.DXGI_FORMAT_BC5_SNORM):
+        tiles = tiles * np.float32(2) - np.float32(1)
+    got = ctx.encode_blocks(fmt, tiles, flags, 0.5)
+    ref = oracle.ref_encode_blocks(fmt, tiles, flags, 0.5)
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of {len(tiles)} blocks differ, first {bad[:8]}"
+
+
+@pytest.mark.parametrize("src", ["f32", "f16", "bgra", "r8"])
+def test_source_formats(ctx, oracle, src):
+    w, h = 64, 52
+    img8 = synth.rgba8(w, h, seed=3, alpha="smooth")
+    if src == "f32":
+        pix, sfmt = (img8.astype(np.float32) / np.float32(255) * np.float32(1.2) - np.float32(0.1)), dx.DXGI_FORMAT_R32G32B32A32_FLOAT
+    elif src == "f16":
+        pix, sfmt = (img8.astype(np.float32) / np.float32(255)).astype(np.float16), dx.DXGI_FORMAT_R16G16B16A16_FLOAT
+    elif src == "bgra":
+        pix, sfmt = img8, dx.DXGI_FORMAT_B8G8R8A8_UNORM
+    else:
+        pix, sfmt = np.ascontiguousarray(img8[..., 0]), dx.DXGI_FORMAT_R8_UNORM
+    for fmt in (dx.DXGI_FORMAT_BC1_UNORM, dx.DXGI_FORMAT_BC3_UNORM, dx.DXGI_FORMAT_BC4_UNORM, dx.DXGI_FORMAT_BC5_SNORM):
+        got = ctx.compress(pix, w, h, sfmt, fmt, 0, 0.5)
+        ref = oracle.compress_image(pix, w, h, sfmt, fmt, 0, 0.5)
+        assert np.array_equal(got, ref), (src, fmt)
+
+
+def test_errors(ctx):
+    img = synth.rgba8(16, 16, 1)
+    with pytest.raises(dx.DxtexError) as e:
+        ctx.compress(img, 16, 16, dx.DXGI_FORMAT_R8G8B8A8_UNORM_SRGB, dx.DXGI_FORMAT_BC1_UNORM)   # one-sided sRGB
+    assert e.value.hresult == dx.HRESULT_E_NOT_SUPPORTED
+    with pytest.raises(dx.DxtexError) as e:
+        ctx.compress(np.zeros(128, np.uint8), 16, 16, dx.DXGI_FORMAT_BC1_UNORM, dx.DXGI_FORMAT_BC3_UNORM)  # compressed source
+    assert e.value.hresult == dx.E_INVALIDARG
