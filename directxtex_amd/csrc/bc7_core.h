@@ -1,0 +1,849 @@
+// BC7 encoder core for gfx950: everything one "task" (one region of one candidate shape, or one
+// single-subset candidate) computes in a single lane. The kernels in bc7_encode.hip spread the tasks of
+// a block over the lanes of a wavefront and reduce the results with cross-lane operations.
+//
+// What is computed is exactly the search of the reference CPU encoder (D3DX_BC7::Encode,
+// BC6HBC7.cpp:2783-2889, with RoughMSE :3492-3597, Refine :3399-3463, FixEndpointPBits :3311-3396,
+// AssignIndices :3139-3218, OptimizeEndPoints/OptimizeOne :3113-3136/:3045-3110, PerturbOne :2926-2966,
+// Exhaustive :2971-3042, MapColors :3466-3489, ComputeError :1559-1635, EmitBlock :3221-3308), including
+// its quirks, so the emitted blocks are byte-identical. How it is computed is not:
+//   * errors are exact integers, so they are carried as int32 instead of fp32 sums; |p - q|^2 is expanded
+//     to |p|^2 + |q|^2 - 2 p.q and evaluated with v_dot4_u32_u8 on packed RGBA bytes;
+//   * MapColors' "running total exceeded the best so far" early-out only ever turns a losing candidate
+//     into FLT_MAX, so it is dropped: a candidate wins iff its exact total is smaller;
+//   * palettes are interpolated two channels at a time in 16-bit halves of a 32-bit lane register;
+//   * the float Newton seed (OptimizeRGB/OptimizeRGBA, :1198-1555) is shared by every mode that uses the
+//     same partition, since it does not depend on the mode.
+// Only the seed uses floating point; it must round like the reference (compile with -ffp-contract=off).
+#pragma once
+#include <stdint.h>
+#include <type_traits>
+
+#if defined(DXTEX_HOST_DEBUG)
+#define DXTEX_HD __host__ __device__ inline
+#else
+#define DXTEX_HD __device__ __forceinline__
+#endif
+
+namespace dxtex
+{
+namespace bc7
+{
+// ---- per-mode constants (BC6HBC7.cpp:1106-1124) ---------------------------------------------------
+template<int MODE> struct ModeInfo;
+#define DXTEX_BC7_MODE(M, NS_, PARTBITS_, PB_, ROTBITS_, IMBITS_, IB_, IB2_, CP_, AP_, CPP_, APP_) \
+    template<> struct ModeInfo<M> { enum : int { NS = NS_, PARTBITS = PARTBITS_, PB = PB_, ROTBITS = ROTBITS_, IMBITS = IMBITS_, \
+        IB = IB_, IB2 = IB2_, CP = CP_, AP = AP_, CPP = CPP_, APP = APP_ }; }
+// PB: 0 = no p-bits, 1 = one per endpoint, 2 = one shared per subset
+DXTEX_BC7_MODE(0, 3, 4, 1, 0, 0, 3, 0, 4, 0, 5, 0);
+DXTEX_BC7_MODE(1, 2, 6, 2, 0, 0, 3, 0, 6, 0, 7, 0);
+DXTEX_BC7_MODE(2, 3, 6, 0, 0, 0, 2, 0, 5, 0, 5, 0);
+DXTEX_BC7_MODE(3, 2, 6, 1, 0, 0, 2, 0, 7, 0, 8, 0);
+DXTEX_BC7_MODE(4, 1, 0, 0, 2, 1, 2, 3, 5, 6, 5, 6);
+DXTEX_BC7_MODE(5, 1, 0, 0, 2, 0, 2, 2, 7, 8, 7, 8);
+DXTEX_BC7_MODE(6, 1, 0, 1, 0, 0, 4, 0, 7, 7, 8, 8);
+DXTEX_BC7_MODE(7, 2, 6, 1, 0, 0, 2, 0, 5, 5, 6, 6);
+#undef DXTEX_BC7_MODE
+
+DXTEX_HD constexpr int weight(int bits, int i)
+{
+    // g_aWeights2/3/4 (BC6HBC7.cpp:327-329)
+    return bits == 2 ? (i == 0 ? 0 : i == 1 ? 21 : i == 2 ? 43 : 64)
+         : bits == 3 ? (i == 0 ? 0 : i == 1 ? 9 : i == 2 ? 18 : i == 3 ? 27 : i == 4 ? 37 : i == 5 ? 46 : i == 6 ? 55 : 64)
+         : (i == 0 ? 0 : i == 1 ? 4 : i == 2 ? 9 : i == 3 ? 13 : i == 4 ? 17 : i == 5 ? 21 : i == 6 ? 26 : i == 7 ? 30
+            : i == 8 ? 34 : i == 9 ? 38 : i == 10 ? 43 : i == 11 ? 47 : i == 12 ? 51 : i == 13 ? 55 : i == 14 ? 60 : 64);
+}
+
+DXTEX_HD uint32_t udot4(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, 0u, false);
+#else
+    return (a & 0xFF) * (b & 0xFF) + ((a >> 8) & 0xFF) * ((b >> 8) & 0xFF) + ((a >> 16) & 0xFF) * ((b >> 16) & 0xFF) + (a >> 24) * (b >> 24);
+#endif
+}
+
+DXTEX_HD uint32_t byte_of(uint32_t v, int ch) { return (v >> (8 * ch)) & 0xFFu; }
+DXTEX_HD uint32_t with_byte(uint32_t v, int ch, uint32_t b) { return (v & ~(0xFFu << (8 * ch))) | (b << (8 * ch)); }
+
+// swap channel (rot-1) with alpha: the BC7 rotation (BC6HBC7.cpp:2837-2843)
+DXTEX_HD uint32_t rotate_pixel(uint32_t p, uint32_t rot)
+{
+    if (rot == 0) return p;
+    const int sh = 8 * int(rot - 1);
+    const uint32_t c = (p >> sh) & 0xFFu, a = p >> 24;
+    return (p & ~((0xFFu << sh) | 0xFF000000u)) | (a << sh) | (c << 24);
+}
+
+// D3DX_BC7::Unquantize for one component at compile-time precision (:826-831). PREC == 0 -> 255.
+template<int PREC>
+DXTEX_HD uint32_t unq1(uint32_t c)
+{
+    if (PREC == 0) return 255u;
+    if (PREC == 8) return c;
+    const uint32_t s = (c << (8 - PREC)) & 0xFFu;
+    return s | (s >> PREC);
+}
+
+template<int MODE>
+DXTEX_HD uint32_t unquantize(uint32_t ep)
+{
+    typedef ModeInfo<MODE> MI;
+    const uint32_t r = unq1<MI::CPP>(ep & 0xFF), g = unq1<MI::CPP>((ep >> 8) & 0xFF), b = unq1<MI::CPP>((ep >> 16) & 0xFF), a = unq1<MI::APP>(ep >> 24);
+    return r | (g << 8) | (b << 16) | (a << 24);
+}
+
+// One palette entry, two channels per 16-bit half (LDRColorA::Interpolate, :384-416):
+// (c0 * (64 - w) + c1 * w + 32) >> 6 for each of the four bytes.
+DXTEX_HD uint32_t lerp_bytes(uint32_t a, uint32_t b, int w)
+{
+    const uint32_t arb = a & 0x00FF00FFu, aga = (a >> 8) & 0x00FF00FFu;
+    const uint32_t brb = b & 0x00FF00FFu, bga = (b >> 8) & 0x00FF00FFu;
+    const uint32_t rb = ((arb * uint32_t(64 - w) + brb * uint32_t(w) + 0x00200020u) >> 6) & 0x00FF00FFu;
+    const uint32_t ga = ((aga * uint32_t(64 - w) + bga * uint32_t(w) + 0x00200020u) >> 6) & 0x00FF00FFu;
+    return rb | (ga << 8);
+}
+
+// The first local minimum along the palette, as ComputeError's early-breaking linear scan finds it
+// (:1581-1595): keep going while the value does not increase. `t[i]` are errors up to a per-pixel constant.
+template<int N>
+DXTEX_HD int ascent_min(const int (&t)[N])
+{
+    int best = t[0];
+    bool done = false;
+#pragma unroll
+    for (int i = 1; i < N; ++i)
+    {
+        done = done || (t[i] > best);
+        best = done ? best : t[i];
+    }
+    return best;
+}
+
+template<int N>
+DXTEX_HD int ascent_min_idx(const int (&t)[N], uint32_t& idx)
+{
+    int best = t[0];
+    bool done = false;
+    idx = 0;
+#pragma unroll
+    for (int i = 1; i < N; ++i)
+    {
+        done = done || (t[i] > best);
+        if (!done && t[i] < best) { best = t[i]; idx = uint32_t(i); }
+    }
+    return best;
+}
+
+// ---- the pixels one task sees ------------------------------------------------------------------------
+// Region: a subset of a block whose packed RGBA8 texels live in LDS (`pix`); `order` lists the texel
+// positions of the subset, 4 bits each, in increasing position order; `np` of them are valid. Used by the
+// multi-subset modes, where the subset size differs from lane to lane.
+struct Region
+{
+    enum : bool { kStatic = false };
+    const uint32_t* pix;
+    uint64_t order;
+    int np;
+    int p2sum;       // sum over the region of |p|^2 (all four channels)
+
+    DXTEX_HD int count() const { return np; }
+    DXTEX_HD uint32_t pos(int k) const { return uint32_t(order >> (4 * k)) & 15u; }
+    DXTEX_HD uint32_t fetch(int k) const { return pix[pos(k)]; }
+};
+
+DXTEX_HD void region_init(Region& r, const uint32_t* pix, uint32_t mask16)
+{
+    r.pix = pix; r.order = 0; r.np = 0; r.p2sum = 0;
+    for (uint32_t i = 0; i < 16; ++i)
+        if ((mask16 >> i) & 1u)
+        {
+            r.order |= uint64_t(i) << (4 * r.np);
+            const uint32_t p = pix[i];
+            r.p2sum += int(udot4(p, p));
+            ++r.np;
+        }
+}
+
+// Block16: all 16 texels of a block held in the lane's registers (already rotated); used by the
+// single-subset modes 4, 5, 6 where every task sees the whole block.
+struct Block16
+{
+    enum : bool { kStatic = true };
+    uint32_t px[16];
+    int p2sum;
+    DXTEX_HD int count() const { return 16; }
+    DXTEX_HD uint32_t pos(int k) const { return uint32_t(k); }
+    DXTEX_HD uint32_t fetch(int k) const { return px[k]; }
+};
+
+template<class PIX>
+DXTEX_HD void block16_init(Block16& r, const PIX* pix, uint32_t rot)
+{
+    r.p2sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        r.px[i] = rotate_pixel(pix[i], rot);
+        r.p2sum += int(udot4(r.px[i], r.px[i]));
+    }
+}
+
+// Texel loops: fully unrolled for register-resident blocks, counted for LDS-resident regions.
+template<class RG, class F>
+DXTEX_HD void for_texels(const RG& rg, F&& f)
+{
+    if constexpr (RG::kStatic)
+    {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) f(k);
+    }
+    else
+    {
+        for (int k = 0; k < rg.count(); ++k) f(k);
+    }
+}
+
+// ---- palette + error of one endpoint pair over a region (GeneratePaletteQuantized + MapColors) --------
+// Combined-index modes (IB2 == 0): 4-channel error. Separate-alpha modes: RGB error with the colour
+// index precision plus alpha error with the alpha index precision (uIndexMode swaps the two).
+template<int MODE, int IM>
+struct PaletteBits
+{
+    typedef ModeInfo<MODE> MI;
+    enum : int { CB = (MI::IB2 == 0) ? MI::IB : (IM ? MI::IB2 : MI::IB),      // colour (or combined) index bits
+                 AB = (MI::IB2 == 0) ? 0 : (IM ? MI::IB : MI::IB2),           // alpha index bits (0 = combined)
+                 NC = 1 << CB, NA = (AB ? (1 << AB) : 1) };
+};
+
+template<int MODE, int IM, class RG>
+DXTEX_HD int map_colors(const RG& rg, uint32_t epA, uint32_t epB)
+{
+    typedef PaletteBits<MODE, IM> PB;
+    const uint32_t ua = unquantize<MODE>(epA), ub = unquantize<MODE>(epB);
+    int total = rg.p2sum;
+
+    if (PB::AB == 0)
+    {
+        uint32_t pal[PB::NC]; int q2[PB::NC];
+#pragma unroll
+        for (int i = 0; i < PB::NC; ++i)
+        {
+            pal[i] = lerp_bytes(ua, ub, weight(PB::CB, i));
+            q2[i] = int(udot4(pal[i], pal[i]));
+        }
+        for_texels(rg, [&](int k)
+        {
+            const uint32_t p = rg.fetch(k);
+            int t[PB::NC];
+#pragma unroll
+            for (int i = 0; i < PB::NC; ++i) t[i] = q2[i] - 2 * int(udot4(p, pal[i]));
+            total += ascent_min(t);
+        });
+    }
+    else
+    {
+        uint32_t pal[PB::NC]; int q2[PB::NC];
+        int pa[PB::NA];
+#pragma unroll
+        for (int i = 0; i < PB::NC; ++i)
+        {
+            pal[i] = lerp_bytes(ua, ub, weight(PB::CB, i)) & 0x00FFFFFFu;
+            q2[i] = int(udot4(pal[i], pal[i]));
+        }
+        const int a0 = int(ua >> 24), a1 = int(ub >> 24);
+#pragma unroll
+        for (int i = 0; i < PB::NA; ++i)
+            pa[i] = (a0 * (64 - weight(PB::AB, i)) + a1 * weight(PB::AB, i) + 32) >> 6;
+        for_texels(rg, [&](int k)
+        {
+            const uint32_t p = rg.fetch(k);
+            const uint32_t prgb = p & 0x00FFFFFFu;
+            const int al = int(p >> 24);
+            int t[PB::NC];
+#pragma unroll
+            for (int i = 0; i < PB::NC; ++i) t[i] = q2[i] - 2 * int(udot4(prgb, pal[i]));
+            int u[PB::NA];
+#pragma unroll
+            for (int i = 0; i < PB::NA; ++i) u[i] = pa[i] * pa[i] - 2 * al * pa[i];
+            total += ascent_min(t) + ascent_min(u);
+        });
+    }
+    return total;
+}
+
+// AssignIndices for one region (:3139-3218): error, per-texel indices (4 bits per texel *position*), and
+// the anchor fix-up that swaps the endpoints when the anchor's index has its top bit set.
+template<int MODE, int IM, class RG>
+DXTEX_HD int assign_indices(const RG& rg, uint32_t& epA, uint32_t& epB, uint32_t anchorPos, uint64_t& idx1, uint64_t& idx2)
+{
+    typedef PaletteBits<MODE, IM> PB;
+    const uint32_t ua = unquantize<MODE>(epA), ub = unquantize<MODE>(epB);
+    int total = rg.p2sum;
+    idx1 = 0; idx2 = 0;
+
+    uint32_t pal[PB::NC]; int q2[PB::NC];
+#pragma unroll
+    for (int i = 0; i < PB::NC; ++i)
+    {
+        pal[i] = lerp_bytes(ua, ub, weight(PB::CB, i));
+        if (PB::AB != 0) pal[i] &= 0x00FFFFFFu;
+        q2[i] = int(udot4(pal[i], pal[i]));
+    }
+    int pa[PB::NA];
+    if (PB::AB != 0)
+    {
+        const int a0 = int(ua >> 24), a1 = int(ub >> 24);
+#pragma unroll
+        for (int i = 0; i < PB::NA; ++i)
+            pa[i] = (a0 * (64 - weight(PB::AB, i)) + a1 * weight(PB::AB, i) + 32) >> 6;
+    }
+
+    for_texels(rg, [&](int k)
+    {
+        const uint32_t p = rg.fetch(k);
+        const uint32_t pc = (PB::AB != 0) ? (p & 0x00FFFFFFu) : p;
+        int t[PB::NC];
+#pragma unroll
+        for (int i = 0; i < PB::NC; ++i) t[i] = q2[i] - 2 * int(udot4(pc, pal[i]));
+        uint32_t i1;
+        total += ascent_min_idx(t, i1);
+        idx1 |= uint64_t(i1) << (4 * rg.pos(k));
+        if (PB::AB != 0)
+        {
+            const int al = int(p >> 24);
+            int u[PB::NA];
+#pragma unroll
+            for (int i = 0; i < PB::NA; ++i) u[i] = pa[i] * pa[i] - 2 * al * pa[i];
+            uint32_t i2;
+            total += ascent_min_idx(u, i2);
+            idx2 |= uint64_t(i2) << (4 * rg.pos(k));
+        }
+    });
+
+    // texel positions of this region, 0xF per member
+    uint64_t member = 0;
+    for_texels(rg, [&](int k) { member |= uint64_t(0xF) << (4 * rg.pos(k)); });
+
+    if ((idx1 >> (4 * anchorPos)) & uint64_t(PB::NC >> 1))
+    {
+        if (PB::AB == 0) { const uint32_t t = epA; epA = epB; epB = t; }
+        else
+        {
+            const uint32_t a = epA, b = epB;
+            epA = (b & 0x00FFFFFFu) | (a & 0xFF000000u);
+            epB = (a & 0x00FFFFFFu) | (b & 0xFF000000u);
+        }
+        // idx = (N - 1) - idx for every member texel == xor with N-1
+        idx1 ^= member & (uint64_t(PB::NC - 1) * 0x1111111111111111ull);
+    }
+    if (PB::AB != 0)
+    {
+        if (idx2 & uint64_t(PB::NA >> 1))      // aIndices2[0]: separate-alpha modes have one region, anchor texel 0
+        {
+            const uint32_t a = epA, b = epB;
+            epA = (a & 0x00FFFFFFu) | (b & 0xFF000000u);
+            epB = (b & 0x00FFFFFFu) | (a & 0xFF000000u);
+            idx2 ^= uint64_t(PB::NA - 1) * 0x1111111111111111ull;
+        }
+    }
+    return total;
+}
+
+// FixEndpointPBits for the endpoint pair of one subset (:3311-3396). Inputs are RGBAPrecWithP-bit values.
+template<int MODE>
+DXTEX_HD void fix_pbits(uint32_t inA, uint32_t inB, uint32_t& outA, uint32_t& outB)
+{
+    typedef ModeInfo<MODE> MI;
+    if (MI::PB == 0) { outA = inA; outB = inB; return; }
+    constexpr int NCH = (MI::AP != MI::APP) ? 4 : 3;      // channels that carry a p-bit
+    uint32_t voteA = 0, voteB = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) { voteA += byte_of(inA, ch) & 1u; voteB += byte_of(inB, ch) & 1u; }
+    uint32_t pA, pB;
+    if (MI::PB == 2)
+    {
+        const uint32_t p = (voteA + voteB) > uint32_t((2 * NCH) >> 1) ? 1u : 0u;
+        pA = p; pB = p;
+    }
+    else
+    {
+        pA = voteA > uint32_t(NCH >> 1) ? 1u : 0u;
+        pB = voteB > uint32_t(NCH >> 1) ? 1u : 0u;
+    }
+    // every byte: ((v >> 1) << 1) | p for p-bit channels; the unencoded alpha byte (255) becomes
+    // uint8((255 << 1) | p), exactly as the reference's second loop does to all four channels.
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+    {
+        const uint32_t va = byte_of(inA, ch), vb = byte_of(inB, ch);
+        const uint32_t ha = (ch < NCH) ? (va >> 1) : va, hb = (ch < NCH) ? (vb >> 1) : vb;
+        a |= (((ha << 1) | pA) & 0xFFu) << (8 * ch);
+        b |= (((hb << 1) | pB) & 0xFFu) << (8 * ch);
+    }
+    outA = a; outB = b;
+}
+
+// Quantize the 8-bit seed endpoints to RGBAPrecWithP (:3428-3429) with D3DX_BC7::Quantize (:806-811):
+//   rnd = min<uint8_t>(255, uint8_t(comp + (1 << (7 - prec))));  q = rnd >> (8 - prec)
+// The cast to uint8_t happens before the min, so the rounding offset WRAPS for bright components (e.g.
+// prec 5: 250 + 4 -> 254 is fine, 253 + 4 -> 1); the min is a no-op. Reproduced as is. For prec == 8 the
+// offset is 1u << -1, which x86 evaluates as 1u << 31: the low byte is unchanged.
+template<int PREC>
+DXTEX_HD uint32_t quantize1(uint32_t v)
+{
+    if (PREC == 0) return 255u;
+    if (PREC == 8) return v;
+    return ((v + (1u << (7 - (PREC & 7)))) & 0xFFu) >> (8 - PREC);
+}
+
+template<int MODE>
+DXTEX_HD uint32_t quantize_endpoint(uint32_t c)
+{
+    typedef ModeInfo<MODE> MI;
+    return quantize1<MI::CPP>(c & 0xFF) | (quantize1<MI::CPP>((c >> 8) & 0xFF) << 8) |
+           (quantize1<MI::CPP>((c >> 16) & 0xFF) << 16) | (quantize1<MI::APP>(c >> 24) << 24);
+}
+
+// ---- endpoint search ---------------------------------------------------------------------------------
+template<int MODE, int IM, int CH, class RG>
+DXTEX_HD int perturb_one(const RG& rg, uint32_t oldA, uint32_t oldB, int oldErr, int do_b, uint32_t& newVal)
+{
+    typedef ModeInfo<MODE> MI;
+    constexpr int prec = (CH == 3) ? MI::APP : MI::CPP;
+    int minErr = oldErr;
+    int cur = int(byte_of(do_b ? oldB : oldA, CH));
+    for (int step = 1 << (prec - 1); step; step >>= 1)
+    {
+        bool improved = false;
+        int beststep = 0;
+#pragma unroll
+        for (int sign = -1; sign <= 1; sign += 2)
+        {
+            const int tmp = cur + sign * step;
+            if (tmp < 0 || tmp >= (1 << prec)) continue;
+            const uint32_t a = do_b ? oldA : with_byte(oldA, CH, uint32_t(tmp));
+            const uint32_t b = do_b ? with_byte(oldB, CH, uint32_t(tmp)) : oldB;
+            const int e = map_colors<MODE, IM>(rg, a, b);
+            if (e < minErr) { improved = true; minErr = e; beststep = sign * step; }
+        }
+        if (improved) cur += beststep;
+    }
+    newVal = uint32_t(cur);
+    return minErr;
+}
+
+template<int MODE, int IM, int CH, class RG>
+DXTEX_HD void exhaustive(const RG& rg, int& orgErr, uint32_t& optA, uint32_t& optB)
+{
+    typedef ModeInfo<MODE> MI;
+    constexpr int prec = (CH == 3) ? MI::APP : MI::CPP;
+    if (orgErr == 0) return;
+    constexpr int delta = 5;
+    const int ca = int(byte_of(optA, CH)), cb = int(byte_of(optB, CH));
+    const int hi = (1 << prec) - 1;                        // prec == 0 -> 0: the loops below do not run
+    const int alow = (ca - delta) > 0 ? (ca - delta) : 0;
+    const int ahigh = (ca + delta) < hi ? (ca + delta) : hi;
+    const int blow = (cb - delta) > 0 ? (cb - delta) : 0;
+    const int bhigh = (cb + delta) < hi ? (cb + delta) : hi;
+    int amin = 0, bmin = 0;
+    int best = orgErr;
+    if (ca <= cb)
+    {
+        for (int a = alow; a <= ahigh; ++a)
+            for (int b = (a > blow ? a : blow); b < bhigh; ++b)
+            {
+                const int e = map_colors<MODE, IM>(rg, with_byte(optA, CH, uint32_t(a)), with_byte(optB, CH, uint32_t(b)));
+                if (e < best) { amin = a; bmin = b; best = e; }
+            }
+    }
+    else
+    {
+        for (int b = blow; b < bhigh; ++b)
+            for (int a = (b > alow ? b : alow); a <= ahigh; ++a)
+            {
+                const int e = map_colors<MODE, IM>(rg, with_byte(optA, CH, uint32_t(a)), with_byte(optB, CH, uint32_t(b)));
+                if (e < best) { amin = a; bmin = b; best = e; }
+            }
+    }
+    if (best < orgErr)
+    {
+        optA = with_byte(optA, CH, uint32_t(amin));
+        optB = with_byte(optB, CH, uint32_t(bmin));
+        orgErr = best;
+    }
+}
+
+// One channel of OptimizeOne's coordinate descent (:3060-3105), quirks included: the B endpoint is
+// never moved by this phase (cnew_b aliases new_a.B[ch], which still holds the old value), only its
+// claimed error is adopted, and the alternating loop re-applies the first A perturbation.
+template<int MODE, int IM, int CH, class RG>
+DXTEX_HD void optimize_channel(const RG& rg, uint32_t& optA, uint32_t& optB, int& optErr)
+{
+    typedef ModeInfo<MODE> MI;
+    constexpr int prec = (CH == 3) ? MI::APP : MI::CPP;
+    if (prec == 0) return;
+    uint32_t newA_val, newB_val, dummy;
+    const int err0 = perturb_one<MODE, IM, CH>(rg, optA, optB, optErr, 0, newA_val);
+    const int err1 = perturb_one<MODE, IM, CH>(rg, optA, optB, optErr, 1, newB_val);
+    (void)newB_val;
+    int do_b;
+    if (err0 < err1)
+    {
+        if (err0 >= optErr) return;
+        optA = with_byte(optA, CH, newA_val);
+        optErr = err0;
+        do_b = 1;
+    }
+    else
+    {
+        if (err1 >= optErr) return;
+        // copt_b = cnew_b == new_a.B[ch] == the current B value: no change
+        optErr = err1;
+        do_b = 0;
+    }
+    for (;;)
+    {
+        const int e = perturb_one<MODE, IM, CH>(rg, optA, optB, optErr, do_b, dummy);
+        if (e >= optErr) break;
+        if (do_b == 0) optA = with_byte(optA, CH, newA_val);     // copt_a = cnew_a (new_a.A[ch] from the first perturbation)
+        // do_b == 1: copt_b = cnew_b (unchanged value)
+        optErr = e;
+        do_b = 1 - do_b;
+    }
+}
+
+template<int MODE, int IM, class RG>
+DXTEX_HD void optimize_one(const RG& rg, int orgErr, uint32_t orgA, uint32_t orgB, uint32_t& optA, uint32_t& optB)
+{
+    int optErr = orgErr;
+    optA = orgA; optB = orgB;
+    optimize_channel<MODE, IM, 0>(rg, optA, optB, optErr);
+    optimize_channel<MODE, IM, 1>(rg, optA, optB, optErr);
+    optimize_channel<MODE, IM, 2>(rg, optA, optB, optErr);
+    optimize_channel<MODE, IM, 3>(rg, optA, optB, optErr);
+    exhaustive<MODE, IM, 0>(rg, optErr, optA, optB);
+    exhaustive<MODE, IM, 1>(rg, optErr, optA, optB);
+    exhaustive<MODE, IM, 2>(rg, optErr, optA, optB);
+    exhaustive<MODE, IM, 3>(rg, optErr, optA, optB);
+}
+
+// Everything Refine does for one subset (:3399-3463) up to, but excluding, the org-vs-opt decision,
+// which needs the totals over all subsets of the candidate.
+struct SubsetResult
+{
+    uint32_t orgA, orgB, optA, optB;
+    uint64_t orgIdx1, orgIdx2, optIdx1, optIdx2;
+    int orgErr, optErr;
+};
+
+template<int MODE, int IM, class RG>
+DXTEX_HD void refine_subset(const RG& rg, uint32_t seedA, uint32_t seedB, uint32_t anchorPos, SubsetResult& out)
+{
+    const uint32_t qa = quantize_endpoint<MODE>(seedA), qb = quantize_endpoint<MODE>(seedB);
+    fix_pbits<MODE>(qa, qb, out.orgA, out.orgB);
+    out.orgErr = assign_indices<MODE, IM>(rg, out.orgA, out.orgB, anchorPos, out.orgIdx1, out.orgIdx2);
+    uint32_t oa, ob;
+    optimize_one<MODE, IM>(rg, out.orgErr, out.orgA, out.orgB, oa, ob);
+    fix_pbits<MODE>(oa, ob, out.optA, out.optB);
+    out.optErr = assign_indices<MODE, IM>(rg, out.optA, out.optB, anchorPos, out.optIdx1, out.optIdx2);
+}
+
+// ---- float seed (OptimizeRGB / OptimizeRGBA with cSteps == 4, :1198-1555) -----------------------------
+// `fpx` = the block's 16 float texels (r,g,b,a); only texels in `mask16` take part, in increasing order.
+// Returns the endpoints clamped to [0,1], scaled by 255 and truncated with the +0.01 bias (:3543-3548).
+template<bool RGBA>
+DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, uint32_t& outB)
+{
+    constexpr float fEpsilon = (0.25f / 64.0f) * (0.25f / 64.0f);
+    constexpr int NC = RGBA ? 4 : 3;
+    float X[4], Y[4];
+    if (RGBA) { X[0] = X[1] = X[2] = X[3] = 1.0f; Y[0] = Y[1] = Y[2] = Y[3] = 0.0f; }
+    else { X[0] = X[1] = X[2] = 3.402823466e+38f; Y[0] = Y[1] = Y[2] = -3.402823466e+38f; X[3] = 0.0f; Y[3] = 0.0f; }
+
+    for (int i = 0; i < 16; ++i)
+        if ((mask16 >> i) & 1u)
+        {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+            {
+                const float v = fpx[i * 4 + c];
+                if (v < X[c]) X[c] = v;
+                if (v > Y[c]) Y[c] = v;
+            }
+        }
+
+    bool done = false;
+    float AB[4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) AB[c] = Y[c] - X[c];
+    float fAB = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
+    if (RGBA) fAB = fAB + AB[3] * AB[3];
+
+    if (fAB < 1.175494351e-38f) done = true;
+
+    if (!done)
+    {
+        const float fABInv = 1.0f / fAB;
+        float Dir[4], Mid[4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { Dir[c] = AB[c] * fABInv; Mid[c] = (X[c] + Y[c]) * 0.5f; }
+
+        float fDir[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) fDir[d] = 0.0f;
+        for (int i = 0; i < 16; ++i)
+            if ((mask16 >> i) & 1u)
+            {
+                float Pt[4];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) Pt[c] = (fpx[i * 4 + c] - Mid[c]) * Dir[c];
+                float f;
+                if (RGBA)
+                {
+                    f = Pt[0] + Pt[1] + Pt[2] + Pt[3]; fDir[0] += f * f;
+                    f = Pt[0] + Pt[1] + Pt[2] - Pt[3]; fDir[1] += f * f;
+                    f = Pt[0] + Pt[1] - Pt[2] + Pt[3]; fDir[2] += f * f;
+                    f = Pt[0] + Pt[1] - Pt[2] - Pt[3]; fDir[3] += f * f;
+                    f = Pt[0] - Pt[1] + Pt[2] + Pt[3]; fDir[4] += f * f;
+                    f = Pt[0] - Pt[1] + Pt[2] - Pt[3]; fDir[5] += f * f;
+                    f = Pt[0] - Pt[1] - Pt[2] + Pt[3]; fDir[6] += f * f;
+                    f = Pt[0] - Pt[1] - Pt[2] - Pt[3]; fDir[7] += f * f;
+                }
+                else
+                {
+                    f = Pt[0] + Pt[1] + Pt[2]; fDir[0] += f * f;
+                    f = Pt[0] + Pt[1] - Pt[2]; fDir[1] += f * f;
+                    f = Pt[0] - Pt[1] + Pt[2]; fDir[2] += f * f;
+                    f = Pt[0] - Pt[1] - Pt[2]; fDir[3] += f * f;
+                }
+            }
+
+        float fDirMax = fDir[0];
+        int iDirMax = 0;
+#pragma unroll
+        for (int d = 1; d < (RGBA ? 8 : 4); ++d)
+            if (fDir[d] > fDirMax) { fDirMax = fDir[d]; iDirMax = d; }
+
+        if (RGBA)
+        {
+            if (iDirMax & 4) { const float t = X[1]; X[1] = Y[1]; Y[1] = t; }
+            if (iDirMax & 2) { const float t = X[2]; X[2] = Y[2]; Y[2] = t; }
+            if (iDirMax & 1) { const float t = X[3]; X[3] = Y[3]; Y[3] = t; }
+        }
+        else
+        {
+            if (iDirMax & 2) { const float t = X[1]; X[1] = Y[1]; Y[1] = t; }
+            if (iDirMax & 1) { const float t = X[2]; X[2] = Y[2]; Y[2] = t; }
+        }
+
+        if (fAB < 1.0f / 4096.0f) done = true;
+
+        if (!done)
+        {
+            const float fSteps = 3.0f;
+            for (int iter = 0; iter < 8; ++iter)
+            {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) Dir[c] = Y[c] - X[c];
+                float fLen = Dir[0] * Dir[0] + Dir[1] * Dir[1] + Dir[2] * Dir[2];
+                if (RGBA) fLen = fLen + Dir[3] * Dir[3];
+                if (fLen < (1.0f / 4096.0f)) break;
+
+                const float fScale = fSteps / fLen;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) Dir[c] *= fScale;
+
+                float d2X = 0.0f, d2Y = 0.0f;
+                float dX[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, dY[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+
+                for (int i = 0; i < 16; ++i)
+                    if ((mask16 >> i) & 1u)
+                    {
+                        float p[4];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) p[c] = fpx[i * 4 + c];
+                        float fDot = (p[0] - X[0]) * Dir[0] + (p[1] - X[1]) * Dir[1] + (p[2] - X[2]) * Dir[2];
+                        if (RGBA) fDot = fDot + (p[3] - X[3]) * Dir[3];
+
+                        uint32_t iStep;
+                        if (fDot <= 0.0f) iStep = 0;
+                        else if (fDot >= fSteps) iStep = 3;
+                        else iStep = uint32_t(fDot + 0.5f);
+
+                        const float pc = (iStep == 0) ? 1.0f : (iStep == 1) ? (2.0f / 3.0f) : (iStep == 2) ? (1.0f / 3.0f) : 0.0f;
+                        const float pd = (iStep == 0) ? 0.0f : (iStep == 1) ? (1.0f / 3.0f) : (iStep == 2) ? (2.0f / 3.0f) : 1.0f;
+                        const float fC = pc * (1.0f / 8.0f);
+                        const float fD = pd * (1.0f / 8.0f);
+                        d2X += fC * pc;
+                        d2Y += fD * pd;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                        {
+                            const float Diff = (X[c] * pc + Y[c] * pd) - p[c];
+                            dX[c] += Diff * fC;
+                            dY[c] += Diff * fD;
+                        }
+                    }
+
+                if (d2X > 0.0f)
+                {
+                    const float f = -1.0f / d2X;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) X[c] += dX[c] * f;
+                }
+                if (d2Y > 0.0f)
+                {
+                    const float f = -1.0f / d2Y;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) Y[c] += dY[c] * f;
+                }
+
+                bool conv;
+                if (RGBA)
+                {
+                    const float ex = dX[0] * dX[0] + dX[1] * dX[1] + dX[2] * dX[2] + dX[3] * dX[3];
+                    const float ey = dY[0] * dY[0] + dY[1] * dY[1] + dY[2] * dY[2] + dY[3] * dY[3];
+                    conv = (ex < fEpsilon) && (ey < fEpsilon);
+                }
+                else
+                {
+                    conv = (dX[0] * dX[0] < fEpsilon) && (dX[1] * dX[1] < fEpsilon) && (dX[2] * dX[2] < fEpsilon) &&
+                           (dY[0] * dY[0] < fEpsilon) && (dY[1] * dY[1] < fEpsilon) && (dY[2] * dY[2] < fEpsilon);
+                }
+                if (conv) break;
+            }
+        }
+    }
+
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+    {
+        float x = X[c], y = Y[c];
+        x = x > 0.0f ? x : 0.0f; x = x < 1.0f ? x : 1.0f;       // std::min(fMax, std::max(fMin, v))
+        y = y > 0.0f ? y : 0.0f; y = y < 1.0f ? y : 1.0f;
+        x *= 255.0f; y *= 255.0f;
+        a |= (uint32_t(x + 0.01f) & 0xFFu) << (8 * c);
+        b |= (uint32_t(y + 0.01f) & 0xFFu) << (8 * c);
+    }
+    outA = a; outB = b;
+}
+
+// RoughMSE's palette error from *unquantised* 8-bit endpoints (:3572-3596) for one region.
+template<int CB, int AB, class RG>
+DXTEX_HD int rough_error(const RG& rg, uint32_t epA, uint32_t epB)
+{
+    constexpr int NC = 1 << CB, NA = AB ? (1 << AB) : 1;
+    int total = rg.p2sum;
+    uint32_t pal[NC]; int q2[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+    {
+        pal[i] = lerp_bytes(epA, epB, weight(CB, i));
+        if (AB != 0) pal[i] &= 0x00FFFFFFu;
+        q2[i] = int(udot4(pal[i], pal[i]));
+    }
+    int pa[NA];
+    if (AB != 0)
+    {
+        const int a0 = int(epA >> 24), a1 = int(epB >> 24);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) pa[i] = (a0 * (64 - weight(AB ? AB : 2, i)) + a1 * weight(AB ? AB : 2, i) + 32) >> 6;
+    }
+    for_texels(rg, [&](int k)
+    {
+        const uint32_t p = rg.fetch(k);
+        const uint32_t pc = (AB != 0) ? (p & 0x00FFFFFFu) : p;
+        int t[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) t[i] = q2[i] - 2 * int(udot4(pc, pal[i]));
+        total += ascent_min(t);
+        if (AB != 0)
+        {
+            const int al = int(p >> 24);
+            int u[NA];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) u[i] = pa[i] * pa[i] - 2 * al * pa[i];
+            total += ascent_min(u);
+        }
+    });
+    return total;
+}
+
+// ---- bit packing (EmitBlock, :3221-3308) ------------------------------------------------------------------
+struct Bits128
+{
+    uint64_t lo, hi;
+    uint32_t pos;
+    DXTEX_HD void init() { lo = 0; hi = 0; pos = 0; }
+    DXTEX_HD void put(uint32_t nbits, uint32_t value)
+    {
+        if (nbits == 0) return;
+        const uint64_t v = uint64_t(value) & ((uint64_t(1) << nbits) - 1);
+        if (pos < 64)
+        {
+            lo |= v << pos;
+            if (pos + nbits > 64) hi |= v >> (64 - pos);
+        }
+        else hi |= v << (pos - 64);
+        pos += nbits;
+    }
+};
+
+// eps[s] = (A, B) of subset s in RGBAPrecWithP units; idx1/idx2 = 4 bits per texel position;
+// anchors = texel positions of the subset anchors (anchor[0] == 0).
+template<int MODE>
+DXTEX_HD void emit_block(uint32_t shape, uint32_t rot, uint32_t im, const uint32_t (&epA)[3], const uint32_t (&epB)[3],
+                         uint64_t idx1, uint64_t idx2, const uint32_t (&anchor)[3], uint64_t& outLo, uint64_t& outHi)
+{
+    typedef ModeInfo<MODE> MI;
+    Bits128 w; w.init();
+    w.put(MODE, 0); w.put(1, 1);
+    w.put(MI::ROTBITS, rot);
+    w.put(MI::IMBITS, im);
+    w.put(MI::PARTBITS, shape);
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+    {
+        constexpr int dummy = 0; (void)dummy;
+        const int prec = (ch == 3) ? MI::AP : MI::CP;
+        const int precP = (ch == 3) ? MI::APP : MI::CPP;
+#pragma unroll
+        for (int s = 0; s < MI::NS; ++s)
+        {
+            const uint32_t a = byte_of(epA[s], ch), b = byte_of(epB[s], ch);
+            if (prec == precP) { w.put(prec, a); w.put(prec, b); }
+            else { w.put(prec, a >> 1); w.put(prec, b >> 1); }
+        }
+    }
+    if (MI::PB == 1)
+    {
+#pragma unroll
+        for (int s = 0; s < MI::NS; ++s) { w.put(1, epA[s] & 1u); w.put(1, epB[s] & 1u); }
+    }
+    else if (MI::PB == 2)
+    {
+        // shared p-bit: majority over the six LSBs of the subset, which fix_pbits has made unanimous
+#pragma unroll
+        for (int s = 0; s < MI::NS; ++s) w.put(1, epA[s] & 1u);
+    }
+    // first index set (colour / combined), anchors one bit short; uIndexMode selects which set goes first
+    const uint64_t i1 = im ? idx2 : idx1;
+    const uint64_t i2 = im ? idx1 : idx2;
+    for (uint32_t i = 0; i < 16; ++i)
+    {
+        bool isAnchor = (i == 0);
+#pragma unroll
+        for (int s = 1; s < MI::NS; ++s) isAnchor = isAnchor || (i == anchor[s]);
+        w.put(isAnchor ? MI::IB - 1 : MI::IB, uint32_t(i1 >> (4 * i)) & 15u);
+    }
+    if (MI::IB2)
+        for (uint32_t i = 0; i < 16; ++i)
+            w.put(i ? MI::IB2 : MI::IB2 - 1, uint32_t(i2 >> (4 * i)) & 15u);
+    outLo = w.lo; outHi = w.hi;
+}
+
+} // namespace bc7
+} // namespace dxtex

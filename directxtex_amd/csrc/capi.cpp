@@ -25,6 +25,8 @@ struct dxtex_ctx
     // grow-only device staging for the host-pointer entry points
     void* stageIn = nullptr; size_t stageInBytes = 0;
     void* stageOut = nullptr; size_t stageOutBytes = 0;
+    // grow-only device scratch for the multi-kernel BC6H/BC7 search (per-mode candidates)
+    void* scratch = nullptr; size_t scratchBytes = 0;
     std::string lastError;
 };
 
@@ -118,6 +120,16 @@ dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width,
     case FMT_BC5_UNORM: case FMT_BC5_SNORM:
         e = launch_bc15_encode(v, dDst, dstRowPitch, dstFormat, flags, threshold, ctx->stream);
         break;
+    case FMT_BC7_UNORM: case FMT_BC7_UNORM_SRGB:
+    {
+        if (flags & DXTEX_COMPRESS_BC7_USE_3SUBSETS)
+            return fail(ctx, DXTEX_E_NOT_SUPPORTED, "TEX_COMPRESS_BC7_USE_3SUBSETS is not implemented yet");
+        const uint64_t nblocks = uint64_t((width + 3) / 4) * uint64_t((height + 3) / 4);
+        hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks));
+        if (hr != DXTEX_S_OK) return hr;
+        e = launch_bc7_encode(v, dDst, dstRowPitch, flags, ctx->scratch, ctx->stream);
+        break;
+    }
     default:
         return fail(ctx, DXTEX_E_NOT_SUPPORTED, "BC format not implemented yet");
     }
@@ -173,6 +185,7 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stageIn) (void)hipFree(ctx->stageIn);
     if (ctx->stageOut) (void)hipFree(ctx->stageOut);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -315,13 +328,23 @@ dxtex_hresult dxtex_encode_blocks(dxtex_ctx* ctx, int32_t bc_format, uint32_t bc
     SrcView v;
     v.pixels = static_cast<const uint8_t*>(ctx->stageIn); v.width = 4; v.height = uint32_t(nblocks * 4);
     v.rowPitch = 64; v.format = FMT_R32G32B32A32_FLOAT; v.tcv = TCV_NONE; v.tsw = TSW_NONE;   // raw floats, as BC_ENCODE receives them
-    time_begin(ctx);
     hipError_t e;
+    if (bc_format == FMT_BC7_UNORM || bc_format == FMT_BC7_UNORM_SRGB)
+    {
+        if (bc_flags & DXTEX_COMPRESS_BC7_USE_3SUBSETS)
+            return fail(ctx, DXTEX_E_NOT_SUPPORTED, "TEX_COMPRESS_BC7_USE_3SUBSETS is not implemented yet");
+        hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks));
+        if (hr != DXTEX_S_OK) return hr;
+    }
+    time_begin(ctx);
     switch (bc_format)
     {
-    case FMT_BC6H_UF16: case FMT_BC6H_SF16: case FMT_BC7_UNORM: case FMT_BC7_UNORM_SRGB:
+    case FMT_BC6H_UF16: case FMT_BC6H_SF16:
         time_end(ctx);
         return fail(ctx, DXTEX_E_NOT_SUPPORTED, "BC format not implemented yet");
+    case FMT_BC7_UNORM: case FMT_BC7_UNORM_SRGB:
+        e = launch_bc7_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_flags, ctx->scratch, ctx->stream);
+        break;
     default:
         e = launch_bc15_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_format, bc_flags, threshold, ctx->stream);
         break;

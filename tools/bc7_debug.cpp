@@ -1,0 +1,257 @@
+// DEVELOPMENT TOOL (not part of the product, not part of the test suite): runs the BC7 core of
+// directxtex_amd/csrc/bc7_core.h on the HOST, next to the reference's D3DX_BC7 class compiled in place
+// with its private members exposed, and compares them stage by stage (seed / RoughMSE / Refine / final
+// block). Build + run:  tools/run_bc7_debug.sh [ntiles] [seed]
+#define DXTEX_HOST_DEBUG 1
+#define private public
+#define protected public
+#include "BC6HBC7.cpp"     // the reference, in place (-I/root/reference/DirectXTex), against oracle/shim
+#undef private
+#undef protected
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../directxtex_amd/csrc/bc67_tables.h"
+#include "../directxtex_amd/csrc/bc7_core.h"
+
+using namespace dxtex;
+using namespace dxtex::bc7;
+
+static uint32_t g_rng = 12345;
+static uint32_t rnd() { g_rng = g_rng * 1664525u + 1013904223u; return g_rng >> 8; }
+
+struct HostBlock
+{
+    float f[64];
+    uint32_t ldr[16];
+    bool hasAlpha;
+};
+
+static void make_block(HostBlock& b, const uint8_t* px)
+{
+    b.hasAlpha = false;
+    for (int i = 0; i < 16; ++i)
+    {
+        uint32_t l = 0;
+        for (int c = 0; c < 4; ++c)
+        {
+            const float v = float(px[i * 4 + c]) * (1.0f / 255.0f);
+            b.f[i * 4 + c] = v;
+            float q = v * 255.0f + 0.01f;
+            q = (q < 255.0f) ? q : 255.0f; q = (0.0f < q) ? q : 0.0f;
+            l |= (uint32_t(q) & 0xFF) << (8 * c);
+        }
+        b.ldr[i] = l;
+        if ((l >> 24) != 0xFF) b.hasAlpha = true;
+    }
+}
+
+struct Cand { uint32_t err, ord; uint64_t lo, hi; bool valid; };
+
+static void seeds2(const HostBlock& b, uint32_t shape, int region, Region& rg, uint32_t& A, uint32_t& B, uint32_t& anchor)
+{
+    const uint32_t m1 = kPart2Mask[shape];
+    const uint32_t m = region ? m1 : ((~m1) & 0xFFFF);
+    region_init(rg, b.ldr, m);
+    if (rg.np == 1) { A = b.ldr[rg.pos(0)]; B = A; }
+    else if (rg.np == 2) { A = b.ldr[rg.pos(0)]; B = b.ldr[rg.pos(1)]; }
+    else seed_endpoints<true>(b.f, m, A, B);
+    anchor = region ? kAnchor2[shape] : 0;
+}
+
+template<int MODE>
+static Cand refine2_one(const HostBlock& b, uint32_t shape, int rank)
+{
+    SubsetResult r[2];
+    for (int region = 0; region < 2; ++region)
+    {
+        Region rg; uint32_t A, B, anchor;
+        seeds2(b, shape, region, rg, A, B, anchor);
+        refine_subset<MODE, 0>(rg, A, B, anchor, r[region]);
+    }
+    const int orgTot = r[0].orgErr + r[1].orgErr, optTot = r[0].optErr + r[1].optErr;
+    const bool useOpt = optTot < orgTot;
+    Cand c; c.valid = true;
+    c.err = uint32_t(useOpt ? optTot : orgTot);
+    c.ord = MODE * 128 + rank;
+    const uint32_t epA[3] = { useOpt ? r[0].optA : r[0].orgA, useOpt ? r[1].optA : r[1].orgA, 0 };
+    const uint32_t epB[3] = { useOpt ? r[0].optB : r[0].orgB, useOpt ? r[1].optB : r[1].orgB, 0 };
+    const uint64_t idx = useOpt ? (r[0].optIdx1 | r[1].optIdx1) : (r[0].orgIdx1 | r[1].orgIdx1);
+    const uint32_t anchor[3] = { 0, kAnchor2[shape], 0 };
+    emit_block<MODE>(shape, 0, 0, epA, epB, idx, 0, anchor, c.lo, c.hi);
+    return c;
+}
+
+template<int MODE, int IM>
+static Cand refine1_one(const HostBlock& b, uint32_t rot)
+{
+    Block16 rg;
+    block16_init(rg, b.ldr, MODE == 6 ? 0u : rot);
+    uint32_t A, B;
+    if (MODE == 6) seed_endpoints<true>(b.f, 0xFFFF, A, B);
+    else
+    {
+        seed_endpoints<false>(b.f, 0xFFFF, A, B);
+        uint32_t mn = 255, mx = 0;
+        for (int i = 0; i < 16; ++i) { const uint32_t al = rg.px[i] >> 24; mn = al < mn ? al : mn; mx = al > mx ? al : mx; }
+        A = (A & 0xFFFFFF) | (mn << 24); B = (B & 0xFFFFFF) | (mx << 24);
+    }
+    SubsetResult r;
+    refine_subset<MODE, IM>(rg, A, B, 0, r);
+    const bool useOpt = r.optErr < r.orgErr;
+    Cand c; c.valid = true;
+    c.err = uint32_t(useOpt ? r.optErr : r.orgErr);
+    const uint32_t sub = (MODE == 4) ? rot * 2 + IM : rot;
+    c.ord = MODE * 128 + sub * 16;
+    const uint32_t epA[3] = { useOpt ? r.optA : r.orgA, 0, 0 }, epB[3] = { useOpt ? r.optB : r.orgB, 0, 0 };
+    const uint32_t anchor[3] = { 0, 0, 0 };
+    emit_block<MODE>(0, rot, IM, epA, epB, useOpt ? r.optIdx1 : r.orgIdx1, useOpt ? r.optIdx2 : r.orgIdx2, anchor, c.lo, c.hi);
+    return c;
+}
+
+static void rough_lists(const HostBlock& b, int* e3, int* e2, uint32_t* l3, uint32_t* l2)
+{
+    for (uint32_t s = 0; s < 64; ++s)
+    {
+        e3[s] = e2[s] = 0;
+        for (int region = 0; region < 2; ++region)
+        {
+            Region rg; uint32_t A, B, anchor;
+            seeds2(b, s, region, rg, A, B, anchor);
+            e3[s] += rough_error<3, 0>(rg, A, B);
+            e2[s] += rough_error<2, 0>(rg, A, B);
+        }
+    }
+    for (int pass = 0; pass < 2; ++pass)
+    {
+        int e[64]; uint32_t sh[64];
+        for (int s = 0; s < 64; ++s) { e[s] = pass ? e2[s] : e3[s]; sh[s] = s; }
+        for (int i = 0; i < 16; ++i)
+            for (int j = i + 1; j < 64; ++j)
+                if (e[i] > e[j]) { std::swap(e[i], e[j]); std::swap(sh[i], sh[j]); }
+        for (int i = 0; i < 16; ++i) (pass ? l2 : l3)[i] = sh[i];
+    }
+}
+
+static void better(Cand& best, const Cand& c)
+{
+    if (!c.valid) return;
+    const uint64_t kb = best.valid ? ((uint64_t(best.err) << 32) | best.ord) : ~0ull;
+    const uint64_t kc = (uint64_t(c.err) << 32) | c.ord;
+    if (kc < kb) best = c;
+}
+
+static void ref_setup(D3DX_BC7::EncodeParams& EP, const HDRColorA* pIn, int mode, int rot)
+{
+    for (size_t i = 0; i < 16; ++i)
+    {
+        EP.aLDRPixels[i].r = uint8_t(std::max<float>(0.0f, std::min<float>(255.0f, pIn[i].r * 255.0f + 0.01f)));
+        EP.aLDRPixels[i].g = uint8_t(std::max<float>(0.0f, std::min<float>(255.0f, pIn[i].g * 255.0f + 0.01f)));
+        EP.aLDRPixels[i].b = uint8_t(std::max<float>(0.0f, std::min<float>(255.0f, pIn[i].b * 255.0f + 0.01f)));
+        EP.aLDRPixels[i].a = uint8_t(std::max<float>(0.0f, std::min<float>(255.0f, pIn[i].a * 255.0f + 0.01f)));
+        switch (rot)
+        {
+        case 1: std::swap(EP.aLDRPixels[i].r, EP.aLDRPixels[i].a); break;
+        case 2: std::swap(EP.aLDRPixels[i].g, EP.aLDRPixels[i].a); break;
+        case 3: std::swap(EP.aLDRPixels[i].b, EP.aLDRPixels[i].a); break;
+        default: break;
+        }
+    }
+    EP.uMode = uint8_t(mode);
+}
+
+int main(int argc, char** argv)
+{
+    const int ntiles = argc > 1 ? atoi(argv[1]) : 200;
+    g_rng = argc > 2 ? uint32_t(atoi(argv[2])) : 12345u;
+    int nbad = 0;
+    for (int t = 0; t < ntiles; ++t)
+    {
+        uint8_t px[64];
+        const int spread = (int[]){ 0, 1, 3, 10, 40, 120 }[rnd() % 6];
+        uint8_t base[4] = { uint8_t(rnd()), uint8_t(rnd()), uint8_t(rnd()), uint8_t(rnd()) };
+        const bool opaque = rnd() & 1;
+        for (int i = 0; i < 16; ++i)
+            for (int c = 0; c < 4; ++c)
+            {
+                int v = base[c] + (spread ? int(rnd() % (2 * spread + 1)) - spread : 0);
+                v = v < 0 ? 0 : v > 255 ? 255 : v;
+                px[i * 4 + c] = (c == 3 && opaque) ? 255 : uint8_t(v);
+            }
+        HostBlock hb; make_block(hb, px);
+
+        // reference
+        alignas(16) HDRColorA pIn[16];
+        memcpy(pIn, hb.f, sizeof(pIn));
+        alignas(16) uint8_t refBlk[16];
+        reinterpret_cast<D3DX_BC7*>(refBlk)->Encode(0, pIn);
+
+        // ours
+        int e3[64], e2[64]; uint32_t l3[16], l2[16];
+        rough_lists(hb, e3, e2, l3, l2);
+        Cand best; best.valid = false;
+        Cand perMode[8]; for (auto& c : perMode) c.valid = false;
+        for (int i = 0; i < 16; ++i) better(perMode[1], refine2_one<1>(hb, l3[i], i));
+        for (int i = 0; i < 16; ++i) better(perMode[3], refine2_one<3>(hb, l2[i], i));
+        for (uint32_t r = 0; r < 4; ++r) { better(perMode[4], refine1_one<4, 0>(hb, r)); better(perMode[4], refine1_one<4, 1>(hb, r)); }
+        for (uint32_t r = 0; r < 4; ++r) better(perMode[5], refine1_one<5, 0>(hb, r));
+        better(perMode[6], refine1_one<6, 0>(hb, 0));
+        if (hb.hasAlpha) for (int i = 0; i < 16; ++i) better(perMode[7], refine2_one<7>(hb, l2[i], i));
+        for (int m = 0; m < 8; ++m) better(best, perMode[m]);
+
+        uint64_t rlo, rhi; memcpy(&rlo, refBlk, 8); memcpy(&rhi, refBlk + 8, 8);
+        if (rlo == best.lo && rhi == best.hi) continue;
+        ++nbad;
+        if (nbad > 3) continue;
+        int refMode = 0; while (refMode < 8 && !((refBlk[0] >> refMode) & 1)) ++refMode;
+        printf("tile %d MISMATCH: ref mode %d, ours mode %u (err %u) spread %d opaque %d\n", t, refMode, best.ord / 128, best.err, spread, int(opaque));
+
+        // stage-by-stage comparison against the reference's own member functions
+        D3DX_BC7 obj;
+        for (int mode : { 1, 3, 7, 4, 5, 6 })
+        {
+            if (mode == 7 && !hb.hasAlpha) continue;
+            const int nrot = (mode == 4 || mode == 5) ? 4 : 1, nim = (mode == 4) ? 2 : 1;
+            const int nshapes = (mode == 1 || mode == 3 || mode == 7) ? 64 : 1;
+            float bestRefErr = FLT_MAX; int bestRefIdx = -1;
+            for (int rot = 0; rot < nrot; ++rot)
+                for (int im = 0; im < nim; ++im)
+                {
+                    D3DX_BC7::EncodeParams EP(pIn);
+                    ref_setup(EP, pIn, mode, rot);
+                    float rough[64]; size_t shp[64];
+                    for (int s = 0; s < nshapes; ++s) { rough[s] = D3DX_BC7::RoughMSE(&EP, s, im); shp[s] = s; }
+                    if (nshapes == 64)
+                    {
+                        const int* mine = (mode == 1) ? e3 : e2;
+                        for (int s = 0; s < 64; ++s)
+                            if (float(mine[s]) != rough[s]) { printf("  mode %d shape %d: rough ref %.0f ours %d\n", mode, s, rough[s], mine[s]); break; }
+                    }
+                    const int items = nshapes == 64 ? 16 : 1;
+                    for (int i = 0; i < items; ++i)
+                        for (int j = i + 1; j < nshapes; ++j)
+                            if (rough[i] > rough[j]) { std::swap(rough[i], rough[j]); std::swap(shp[i], shp[j]); }
+                    for (int i = 0; i < items; ++i)
+                    {
+                        const float e = obj.Refine(&EP, shp[i], rot, im);
+                        uint64_t lo, hi; memcpy(&lo, &obj, 8); memcpy(&hi, reinterpret_cast<uint8_t*>(&obj) + 8, 8);
+                        Cand c;
+                        if (mode == 1) c = refine2_one<1>(hb, uint32_t(shp[i]), i);
+                        else if (mode == 3) c = refine2_one<3>(hb, uint32_t(shp[i]), i);
+                        else if (mode == 7) c = refine2_one<7>(hb, uint32_t(shp[i]), i);
+                        else if (mode == 4) c = im ? refine1_one<4, 1>(hb, rot) : refine1_one<4, 0>(hb, rot);
+                        else if (mode == 5) c = refine1_one<5, 0>(hb, rot);
+                        else c = refine1_one<6, 0>(hb, 0);
+                        if (float(c.err) != e || c.lo != lo || c.hi != hi)
+                            printf("  mode %d rot %d im %d shape %zu: Refine ref err %.0f blk %016llx%016llx | ours err %u blk %016llx%016llx\n",
+                                   mode, rot, im, shp[i], e, (unsigned long long)hi, (unsigned long long)lo, c.err, (unsigned long long)c.hi, (unsigned long long)c.lo);
+                        if (e < bestRefErr) { bestRefErr = e; bestRefIdx = i; }
+                    }
+                }
+            printf("  mode %d: ref best err %.0f, ours %s %u\n", mode, bestRefErr, perMode[mode].valid ? "err" : "n/a", perMode[mode].valid ? perMode[mode].err : 0);
+        }
+    }
+    printf("%d of %d tiles differ\n", nbad, ntiles);
+    return nbad ? 1 : 0;
+}
