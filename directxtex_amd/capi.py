@@ -47,6 +47,8 @@ _SIGS = {
     "dxtex_ctx_synchronize": (ctypes.c_int32, [_ctx_p]),
     "dxtex_ctx_last_error": (ctypes.c_char_p, [_ctx_p]),
     "dxtex_ctx_last_kernel_ms": (ctypes.c_float, [_ctx_p]),
+    "dxtex_ctx_profile_begin": (ctypes.c_int32, [_ctx_p]),
+    "dxtex_ctx_profile_end": (ctypes.c_int32, [_ctx_p, ctypes.c_char_p, ctypes.c_size_t, _P(ctypes.c_float), _P(ctypes.c_uint32), ctypes.c_size_t, _P(ctypes.c_size_t)]),
     "dxtex_is_compressed": (ctypes.c_int, [ctypes.c_int32]),
     "dxtex_bits_per_pixel": (ctypes.c_size_t, [ctypes.c_int32]),
     "dxtex_compute_pitch": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, _P(ctypes.c_size_t), _P(ctypes.c_size_t)]),
@@ -155,6 +157,20 @@ class Context:
 
     def last_kernel_ms(self):
         return float(_lib.dxtex_ctx_last_kernel_ms(self._h))
+
+    def profile_begin(self):
+        self._check(_lib.dxtex_ctx_profile_begin(self._h), "profile_begin")
+
+    def profile_end(self):
+        """-> {kernel name: (total ms, launches)} since profile_begin (synchronises the stream)."""
+        cap = 64
+        names = ctypes.create_string_buffer(4096)
+        ms = (ctypes.c_float * cap)()
+        n = (ctypes.c_uint32 * cap)()
+        cnt = ctypes.c_size_t()
+        self._check(_lib.dxtex_ctx_profile_end(self._h, names, 4096, ms, n, cap, ctypes.byref(cnt)), "profile_end")
+        keys = names.value.decode().split("\n")[:cnt.value]
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(keys)}
 
     # -- Compress -----------------------------------------------------------------------------------
     def compress(self, pixels, width, height, src_format, dst_format, flags=0, threshold=0.5, src_row_pitch=None):

@@ -12,7 +12,7 @@
 //   refine1 : modes 4, 5, 6 - lane = (block, rotation[, index mode]); texels live in registers.
 //   pick    : lane = block; minimum over the per-mode winners in the reference's evaluation order.
 // The per-mode winners travel through a small scratch buffer (24 B per mode per block).
-#include "dxtex_device.h"
+#include "dxtex_kernels.h"
 #include "bc67_tables.h"
 #include "bc7_core.h"
 
@@ -366,8 +366,9 @@ size_t bc7_scratch_bytes(uint64_t nblocks)
 }
 
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
-                             void* scratch, hipStream_t stream)
+                             void* scratch, hipStream_t stream, KernelMarks* marks)
 {
+#define DXTEX_MARK(NAME) do { if (marks) marks->mark(NAME); } while (0)
     Bc7Args a;
     a.src = src; a.dst = dst; a.dstRowPitch = dstRowPitch;
     a.nbw = (src.width + 3) / 4; a.nbh = (src.height + 3) / 4;
@@ -382,18 +383,29 @@ hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPi
 
     if (!quick)
     {
+        DXTEX_MARK("bc7_rough");
         hipLaunchKernelGGL(bc7_rough_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, a);
+        DXTEX_MARK("bc7_refine2_mode1");
         hipLaunchKernelGGL(bc7_refine2_kernel<1>, dim3((nb + 7) / 8), dim3(256), 0, stream, a);
+        DXTEX_MARK("bc7_refine2_mode3");
         hipLaunchKernelGGL(bc7_refine2_kernel<3>, dim3((nb + 7) / 8), dim3(256), 0, stream, a);
+        DXTEX_MARK("bc7_refine2_mode7");
         hipLaunchKernelGGL(bc7_refine2_kernel<7>, dim3((nb + 7) / 8), dim3(256), 0, stream, a);
+        DXTEX_MARK("bc7_refine1_mode4_im0");
         hipLaunchKernelGGL((bc7_refine1_kernel<4, 0>), dim3((nb + 63) / 64), dim3(256), 0, stream, a);
+        DXTEX_MARK("bc7_refine1_mode4_im1");
         hipLaunchKernelGGL((bc7_refine1_kernel<4, 1>), dim3((nb + 63) / 64), dim3(256), 0, stream, a);
+        DXTEX_MARK("bc7_refine1_mode5");
         hipLaunchKernelGGL((bc7_refine1_kernel<5, 0>), dim3((nb + 63) / 64), dim3(256), 0, stream, a);
         slotMask |= (1u << SLOT_M1) | (1u << SLOT_M3) | (1u << SLOT_M7) | (1u << SLOT_M4A) | (1u << SLOT_M4B) | (1u << SLOT_M5);
     }
+    DXTEX_MARK("bc7_refine1_mode6");
     hipLaunchKernelGGL((bc7_refine1_kernel<6, 0>), dim3((nb + 255) / 256), dim3(256), 0, stream, a);
     slotMask |= (1u << SLOT_M6);
+    DXTEX_MARK("bc7_pick");
     hipLaunchKernelGGL(bc7_pick_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, a, slotMask);
+    DXTEX_MARK(nullptr);
+#undef DXTEX_MARK
     return hipGetLastError();
 }
 } // namespace dxtex

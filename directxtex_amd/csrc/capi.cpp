@@ -11,8 +11,24 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace dxtex;
+
+struct dxtex_ctx;
+namespace
+{
+// Per-kernel device timing (dxtex_ctx_profile_*): an event before every kernel and one after the last.
+struct Marks final : dxtex::KernelMarks
+{
+    dxtex_ctx* ctx = nullptr;
+    std::vector<hipEvent_t> pool;        // reused across calls
+    std::vector<const char*> names;      // names[i] labels the interval events[i] -> events[i+1]; nullptr = end of a call
+    size_t used = 0;
+    void mark(const char* kernelName) override;
+    void reset() { names.clear(); used = 0; }
+};
+}
 
 struct dxtex_ctx
 {
@@ -28,7 +44,21 @@ struct dxtex_ctx
     // grow-only device scratch for the multi-kernel BC6H/BC7 search (per-mode candidates)
     void* scratch = nullptr; size_t scratchBytes = 0;
     std::string lastError;
+    bool profiling = false;
+    Marks marks;
 };
+
+void Marks::mark(const char* kernelName)
+{
+    if (used == pool.size())
+    {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        pool.push_back(e);
+    }
+    (void)hipEventRecord(pool[used++], ctx->stream);
+    names.push_back(kernelName);
+}
 
 namespace
 {
@@ -127,7 +157,7 @@ dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width,
         const uint64_t nblocks = uint64_t((width + 3) / 4) * uint64_t((height + 3) / 4);
         hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks));
         if (hr != DXTEX_S_OK) return hr;
-        e = launch_bc7_encode(v, dDst, dstRowPitch, flags, ctx->scratch, ctx->stream);
+        e = launch_bc7_encode(v, dDst, dstRowPitch, flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
         break;
     }
     default:
@@ -174,6 +204,7 @@ dxtex_hresult dxtex_ctx_create(int device, dxtex_ctx** out)
         return DXTEX_E_FAIL;
     }
     ctx->stream = ctx->ownStream;
+    ctx->marks.ctx = ctx;
     *out = ctx;
     return DXTEX_S_OK;
 }
@@ -186,6 +217,7 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
     if (ctx->stageIn) (void)hipFree(ctx->stageIn);
     if (ctx->stageOut) (void)hipFree(ctx->stageOut);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (hipEvent_t e : ctx->marks.pool) (void)hipEventDestroy(e);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     if (ctx->ownStream) (void)hipStreamDestroy(ctx->ownStream);
@@ -219,6 +251,50 @@ float dxtex_ctx_last_kernel_ms(dxtex_ctx* ctx)
     float ms = -1.0f;
     if (hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop) != hipSuccess) return -1.0f;
     return ms;
+}
+
+dxtex_hresult dxtex_ctx_profile_begin(dxtex_ctx* ctx)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    ctx->marks.reset();
+    ctx->profiling = true;
+    return DXTEX_S_OK;
+}
+
+dxtex_hresult dxtex_ctx_profile_end(dxtex_ctx* ctx, char* names, size_t namesBytes, float* ms, uint32_t* launches, size_t capacity, size_t* count)
+{
+    if (!ctx || !count) return DXTEX_E_POINTER;
+    ctx->profiling = false;
+    ScopedDevice sd(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // aggregate by kernel name (pointer identity: names are string literals inside the launchers)
+    std::vector<const char*> uniq; std::vector<double> total; std::vector<uint32_t> n;
+    Marks& m = ctx->marks;
+    for (size_t i = 0; i + 1 < m.used; ++i)
+    {
+        if (!m.names[i]) continue;
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, m.pool[i], m.pool[i + 1]) != hipSuccess) continue;
+        size_t k = 0;
+        for (; k < uniq.size(); ++k) if (uniq[k] == m.names[i]) break;
+        if (k == uniq.size()) { uniq.push_back(m.names[i]); total.push_back(0.0); n.push_back(0); }
+        total[k] += t; n[k] += 1;
+    }
+    *count = uniq.size();
+    size_t off = 0;
+    for (size_t k = 0; k < uniq.size() && k < capacity; ++k)
+    {
+        if (ms) ms[k] = float(total[k]);
+        if (launches) launches[k] = n[k];
+        if (names)
+        {
+            const size_t len = std::strlen(uniq[k]);
+            if (off + len + 1 < namesBytes) { std::memcpy(names + off, uniq[k], len); off += len; names[off++] = '\n'; }
+        }
+    }
+    if (names && namesBytes) names[off < namesBytes ? off : namesBytes - 1] = 0;
+    m.reset();
+    return DXTEX_S_OK;
 }
 
 int dxtex_is_compressed(int32_t format) { return is_bc(format) ? 1 : 0; }
@@ -343,7 +419,7 @@ dxtex_hresult dxtex_encode_blocks(dxtex_ctx* ctx, int32_t bc_format, uint32_t bc
         time_end(ctx);
         return fail(ctx, DXTEX_E_NOT_SUPPORTED, "BC format not implemented yet");
     case FMT_BC7_UNORM: case FMT_BC7_UNORM_SRGB:
-        e = launch_bc7_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_flags, ctx->scratch, ctx->stream);
+        e = launch_bc7_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
         break;
     default:
         e = launch_bc15_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_format, bc_flags, threshold, ctx->stream);

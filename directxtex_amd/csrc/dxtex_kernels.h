@@ -5,11 +5,20 @@
 
 namespace dxtex
 {
+// Optional per-kernel timing hook: launchers call mark(name) immediately before each kernel they enqueue;
+// the context turns consecutive marks into hipEvent pairs on the launch stream.
+struct KernelMarks
+{
+    virtual void mark(const char* kernelName) = 0;
+protected:
+    ~KernelMarks() = default;
+};
+
 hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, int dstFormat,
                               uint32_t flags, float threshold, hipStream_t stream);
 
 // BC7: `scratch` must hold bc7_scratch_bytes(number of 4x4 blocks) bytes of device memory.
 size_t bc7_scratch_bytes(uint64_t nblocks);
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
-                             void* scratch, hipStream_t stream);
+                             void* scratch, hipStream_t stream, KernelMarks* marks);
 } // namespace dxtex

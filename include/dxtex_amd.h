@@ -100,6 +100,14 @@ const char*   dxtex_ctx_last_error(dxtex_ctx* ctx);
  * (hipEvent pair on the context's stream, transfers excluded); -1 if nothing was timed. */
 float         dxtex_ctx_last_kernel_ms(dxtex_ctx* ctx);
 
+/* Per-kernel device timing. Between profile_begin and profile_end every kernel this context launches is
+ * bracketed by hipEvents on the launch stream. profile_end synchronises the stream and returns, per
+ * distinct kernel, the summed duration in ms and the number of launches; `names` receives the kernel
+ * names separated by '\n'. Used by bench.py for the roofline object. */
+dxtex_hresult dxtex_ctx_profile_begin(dxtex_ctx* ctx);
+dxtex_hresult dxtex_ctx_profile_end(dxtex_ctx* ctx, char* names, size_t names_bytes, float* total_ms,
+                                    uint32_t* launches, size_t capacity, size_t* count);
+
 /* ---- format utilities (DirectXTexUtil.cpp:340-1186) ------------------------------------------- */
 
 int           dxtex_is_compressed(int32_t format);
