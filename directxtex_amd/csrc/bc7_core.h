@@ -165,6 +165,20 @@ DXTEX_HD void region_init(Region& r, const uint32_t* pix, uint32_t mask16)
         }
 }
 
+// SlotRegion: the subset's texels copied, in order, to a per-lane column of an LDS array laid out
+// [k][lane] (stride 64 dwords), so that a wavefront's fetch(k) is one conflict-free ds_read_b32. Used by
+// the persistent search loop, where every lane works on a different (block, shape, subset).
+struct SlotRegion
+{
+    enum : bool { kStatic = false };
+    const uint32_t* base;   // &slots[lane]
+    int np;
+    int p2sum;
+    DXTEX_HD int count() const { return np; }
+    DXTEX_HD uint32_t pos(int k) const { return uint32_t(k); }
+    DXTEX_HD uint32_t fetch(int k) const { return base[k * 64]; }
+};
+
 // Block16: all 16 texels of a block held in the lane's registers (already rotated); used by the
 // single-subset modes 4, 5, 6 where every task sees the whole block.
 struct Block16
@@ -529,6 +543,245 @@ DXTEX_HD void optimize_one(const RG& rg, int orgErr, uint32_t orgA, uint32_t org
     exhaustive<MODE, IM, 3>(rg, optErr, optA, optB);
 }
 
+// ---- OptimizeOne as an explicit state machine ------------------------------------------------------------
+// The same search as optimize_one() above, cut at every MapColors call: next() advances to the next
+// endpoint pair that has to be scored (or reports that the search is over), consume() feeds the score back.
+// This lets a wavefront run ONE converged map_colors per iteration while every lane is somewhere else in
+// its own search, and lets a lane that finishes early pick up another task (bc7_encode.hip).
+struct SearchState
+{
+    uint32_t optA, optB;
+    int optErr;
+    int phase;            // 0 = finished, 1 = perturb, 2 = exhaustive
+    int sub;              // perturb: 0 = first pass on A, 1 = first pass on B, 2 = alternating loop
+    int ch, prec;
+    int do_b;
+    int cur, minErr, step, sign, beststep;
+    int improved;         // bool
+    int err0;
+    uint32_t newA;
+    int a, b, alow, ahigh, blow, bhigh, amin, bmin, best;
+    int aleb;             // bool
+    uint32_t candA, candB;
+};
+
+template<int MODE> DXTEX_HD int prec_of(int ch) { return ch == 3 ? int(ModeInfo<MODE>::APP) : int(ModeInfo<MODE>::CPP); }
+
+// NOTE on style: every function below takes the state by const reference, works on a LOCAL copy and
+// returns it by value. Conditional stores to different fields through a reference get merged by LLVM into
+// a store through a selected pointer, after which the struct can no longer be promoted to registers and
+// lives in scratch memory (measured: 116 B/lane of scratch, 3x slower). Local copies are always promoted.
+
+DXTEX_HD SearchState ss_select(bool c, const SearchState& x, const SearchState& y)
+{
+    SearchState r;
+#define DXTEX_SEL(F) r.F = c ? x.F : y.F
+    DXTEX_SEL(optA); DXTEX_SEL(optB); DXTEX_SEL(optErr); DXTEX_SEL(phase); DXTEX_SEL(sub); DXTEX_SEL(ch); DXTEX_SEL(prec);
+    DXTEX_SEL(do_b); DXTEX_SEL(cur); DXTEX_SEL(minErr); DXTEX_SEL(step); DXTEX_SEL(sign); DXTEX_SEL(beststep);
+    DXTEX_SEL(improved); DXTEX_SEL(err0); DXTEX_SEL(newA); DXTEX_SEL(a); DXTEX_SEL(b); DXTEX_SEL(alow); DXTEX_SEL(ahigh);
+    DXTEX_SEL(blow); DXTEX_SEL(bhigh); DXTEX_SEL(amin); DXTEX_SEL(bmin); DXTEX_SEL(best); DXTEX_SEL(aleb);
+    DXTEX_SEL(candA); DXTEX_SEL(candB);
+#undef DXTEX_SEL
+    return r;
+}
+
+DXTEX_HD SearchState ss_begin_perturb(const SearchState& in, int do_b)
+{
+    SearchState s = in;
+    s.phase = 1; s.do_b = do_b;
+    s.cur = int(byte_of(do_b ? s.optB : s.optA, s.ch));
+    s.minErr = s.optErr;
+    s.step = 1 << (s.prec - 1);
+    s.sign = -1; s.improved = false; s.beststep = 0;
+    return s;
+}
+
+template<int MODE>
+DXTEX_HD SearchState ss_begin_exhaustive(const SearchState& in, int ch)
+{
+    SearchState s = in;
+    // Exhaustive() returns at once when the error is already zero (:2980), for every remaining channel
+    const bool over = (ch >= 4) || (s.optErr == 0);
+    const int c = over ? 0 : ch;
+    const int prec = prec_of<MODE>(c);
+    constexpr int delta = 5;
+    const int ca = int(byte_of(s.optA, c)), cb = int(byte_of(s.optB, c));
+    const int hi = (1 << prec) - 1;
+    const int alow = (ca - delta) > 0 ? (ca - delta) : 0;
+    const int ahigh = (ca + delta) < hi ? (ca + delta) : hi;
+    const int blow = (cb - delta) > 0 ? (cb - delta) : 0;
+    const int bhigh = (cb + delta) < hi ? (cb + delta) : hi;
+    const bool aleb = ca <= cb;
+    const int m = alow > blow ? alow : blow;
+    s.phase = over ? 0 : 2;
+    s.ch = c; s.prec = prec;
+    s.alow = alow; s.ahigh = ahigh; s.blow = blow; s.bhigh = bhigh;
+    s.amin = 0; s.bmin = 0; s.best = s.optErr;
+    s.aleb = aleb;
+    s.a = aleb ? alow : m;        // aleb: a = alow, b = max(a, blow);  else: b = blow, a = max(b, alow)
+    s.b = aleb ? m : blow;
+    return s;
+}
+
+template<int MODE>
+DXTEX_HD SearchState ss_next_channel(const SearchState& in)
+{
+    SearchState s = in;
+    int ch = s.ch + 1;
+    while (ch < 4 && prec_of<MODE>(ch) == 0) ++ch;
+    const bool toExh = ch >= 4;
+    SearchState p = s;
+    p.ch = toExh ? s.ch : ch; p.prec = prec_of<MODE>(toExh ? 0 : ch); p.sub = 0;
+    p = ss_begin_perturb(p, 0);
+    const SearchState x = ss_begin_exhaustive<MODE>(s, 0);
+    return ss_select(toExh, x, p);
+}
+
+template<int MODE>
+DXTEX_HD SearchState ss_begin(uint32_t orgA, uint32_t orgB, int orgErr)
+{
+    SearchState s;
+    s.optA = orgA; s.optB = orgB; s.optErr = orgErr;
+    s.phase = 0; s.sub = 0; s.ch = -1; s.prec = 0; s.do_b = 0;
+    s.cur = 0; s.minErr = 0; s.step = 0; s.sign = -1; s.beststep = 0; s.improved = false;
+    s.err0 = 0; s.newA = 0;
+    s.a = s.b = s.alow = s.ahigh = s.blow = s.bhigh = s.amin = s.bmin = s.best = 0; s.aleb = false;
+    s.candA = 0; s.candB = 0;
+    return ss_next_channel<MODE>(s);
+}
+
+template<int MODE>
+DXTEX_HD SearchState ss_perturb_done(const SearchState& in)
+{
+    SearchState s = in;
+    const bool sub0 = (s.sub == 0);
+    const int e = s.minErr;                         // sub 1: fErr1; sub 2: fErr of the alternating loop
+    const bool first = (s.sub == 1);
+    const bool takeA = first ? (s.err0 < e) : (s.do_b == 0);
+    const int claimed = (first && takeA) ? s.err0 : e;
+    const bool giveUp = !sub0 && (claimed >= s.optErr);
+    // sub 0 -> remember the A result, perturb B next
+    // otherwise adopt the claimed error; only the A endpoint ever moves (cnew_b aliases new_a.B[ch],
+    // which still holds the old value)
+    SearchState u = s;
+    u.err0 = sub0 ? s.minErr : s.err0;
+    u.newA = sub0 ? uint32_t(s.cur) : s.newA;
+    u.optA = (!sub0 && takeA) ? with_byte(s.optA, s.ch, s.newA) : s.optA;
+    u.optErr = sub0 ? s.optErr : claimed;
+    u.sub = sub0 ? 1 : 2;
+    const int nextB = sub0 ? 1 : (first ? (takeA ? 1 : 0) : (1 - s.do_b));
+    u = ss_begin_perturb(u, nextB);
+    const SearchState n = ss_next_channel<MODE>(s);
+    return ss_select(giveUp, n, u);
+}
+
+DXTEX_HD SearchState ss_perturb_advance(const SearchState& in)
+{
+    SearchState s = in;
+    const bool second = s.sign > 0;
+    s.cur = (second && s.improved) ? (s.cur + s.beststep) : s.cur;
+    s.improved = second ? false : s.improved;
+    s.beststep = second ? 0 : s.beststep;
+    s.step = second ? (s.step >> 1) : s.step;
+    s.sign = second ? -1 : 1;
+    return s;
+}
+
+template<int MODE>
+DXTEX_HD SearchState ss_exhaustive_done(const SearchState& in)
+{
+    SearchState s = in;
+    const bool better = s.best < s.optErr;
+    s.optA = better ? with_byte(s.optA, s.ch, uint32_t(s.amin)) : s.optA;
+    s.optB = better ? with_byte(s.optB, s.ch, uint32_t(s.bmin)) : s.optB;
+    s.optErr = better ? s.best : s.optErr;
+    return ss_begin_exhaustive<MODE>(s, s.ch + 1);
+}
+
+// Advance to the next candidate (candA/candB); `has` = false when the whole OptimizeOne is finished
+// (optA/optB are final).
+template<int MODE>
+DXTEX_HD SearchState ss_next(const SearchState& in, bool& has)
+{
+    SearchState s = in;
+    bool found = false, over = false;
+    while (!found && !over)
+    {
+        if (s.phase == 0) over = true;
+        else if (s.phase == 1)
+        {
+            const int tmp = s.cur + s.sign * s.step;
+            if (s.step == 0) s = ss_perturb_done<MODE>(s);
+            else if (tmp < 0 || tmp >= (1 << s.prec)) s = ss_perturb_advance(s);
+            else
+            {
+                const uint32_t wa = with_byte(s.optA, s.ch, uint32_t(tmp)), wb = with_byte(s.optB, s.ch, uint32_t(tmp));
+                s.candA = s.do_b ? s.optA : wa;
+                s.candB = s.do_b ? wb : s.optB;
+                found = true;
+            }
+        }
+        else
+        {
+            // exhaustive: outer/inner loop variables are (a, b) when a <= b initially, else (b, a)
+            const int outer = s.aleb ? s.a : s.b, outerEnd = s.aleb ? s.ahigh + 1 : s.bhigh;
+            const int inner = s.aleb ? s.b : s.a, innerEnd = s.aleb ? s.bhigh : s.ahigh + 1;
+            if (outer >= outerEnd) s = ss_exhaustive_done<MODE>(s);
+            else if (inner >= innerEnd)
+            {
+                const int o = outer + 1;
+                const int lo = s.aleb ? s.blow : s.alow;
+                const int i = o > lo ? o : lo;
+                const int na = s.aleb ? o : i, nb = s.aleb ? i : o;
+                s.a = na; s.b = nb;
+            }
+            else
+            {
+                s.candA = with_byte(s.optA, s.ch, uint32_t(s.a));
+                s.candB = with_byte(s.optB, s.ch, uint32_t(s.b));
+                found = true;
+            }
+        }
+    }
+    has = found;
+    return s;
+}
+
+DXTEX_HD SearchState ss_consume(const SearchState& in, int e)
+{
+    SearchState s = in;
+    const bool pert = (s.phase == 1);
+    // perturb: strict improvement over the running minimum (:2953)
+    const bool ltp = pert && (e < s.minErr);
+    s.improved = ltp ? true : s.improved;
+    s.beststep = ltp ? s.sign * s.step : s.beststep;
+    s.minErr = ltp ? e : s.minErr;
+    // exhaustive: strict improvement over the best of the window (:3006)
+    const bool lte = !pert && (e < s.best);
+    s.amin = lte ? s.a : s.amin;
+    s.bmin = lte ? s.b : s.bmin;
+    s.best = lte ? e : s.best;
+    const int incb = (!pert && s.aleb) ? 1 : 0, inca = (!pert && !s.aleb) ? 1 : 0;
+    s.b += incb; s.a += inca;
+    const SearchState adv = ss_perturb_advance(s);
+    return ss_select(pert, adv, s);
+}
+
+// optimize_one() expressed through the state machine (used by the host-side equivalence check).
+template<int MODE, int IM, class RG>
+DXTEX_HD void optimize_one_sm(const RG& rg, int orgErr, uint32_t orgA, uint32_t orgB, uint32_t& optA, uint32_t& optB)
+{
+    SearchState s = ss_begin<MODE>(orgA, orgB, orgErr);
+    for (;;)
+    {
+        bool has;
+        s = ss_next<MODE>(s, has);
+        if (!has) break;
+        s = ss_consume(s, map_colors<MODE, IM>(rg, s.candA, s.candB));
+    }
+    optA = s.optA; optB = s.optB;
+}
+
 // Everything Refine does for one subset (:3399-3463) up to, but excluding, the org-vs-opt decision,
 // which needs the totals over all subsets of the candidate.
 struct SubsetResult
@@ -538,22 +791,56 @@ struct SubsetResult
     int orgErr, optErr;
 };
 
+// Refine, first half: quantise the seed, settle p-bits, assign indices (org candidate).
 template<int MODE, int IM, class RG>
-DXTEX_HD void refine_subset(const RG& rg, uint32_t seedA, uint32_t seedB, uint32_t anchorPos, SubsetResult& out)
+DXTEX_HD void refine_pre(const RG& rg, uint32_t seedA, uint32_t seedB, uint32_t anchorPos, SubsetResult& out)
 {
     const uint32_t qa = quantize_endpoint<MODE>(seedA), qb = quantize_endpoint<MODE>(seedB);
     fix_pbits<MODE>(qa, qb, out.orgA, out.orgB);
     out.orgErr = assign_indices<MODE, IM>(rg, out.orgA, out.orgB, anchorPos, out.orgIdx1, out.orgIdx2);
-    uint32_t oa, ob;
-    optimize_one<MODE, IM>(rg, out.orgErr, out.orgA, out.orgB, oa, ob);
+}
+
+// Refine, second half: the optimised endpoints (from OptimizeOne) get their p-bits and indices (opt candidate).
+template<int MODE, int IM, class RG>
+DXTEX_HD void refine_post(const RG& rg, uint32_t oa, uint32_t ob, uint32_t anchorPos, SubsetResult& out)
+{
     fix_pbits<MODE>(oa, ob, out.optA, out.optB);
     out.optErr = assign_indices<MODE, IM>(rg, out.optA, out.optB, anchorPos, out.optIdx1, out.optIdx2);
+}
+
+template<int MODE, int IM, class RG>
+DXTEX_HD void refine_subset(const RG& rg, uint32_t seedA, uint32_t seedB, uint32_t anchorPos, SubsetResult& out)
+{
+    refine_pre<MODE, IM>(rg, seedA, seedB, anchorPos, out);
+    uint32_t oa, ob;
+#if defined(DXTEX_BC7_USE_STATE_MACHINE)
+    optimize_one_sm<MODE, IM>(rg, out.orgErr, out.orgA, out.orgB, oa, ob);
+#else
+    optimize_one<MODE, IM>(rg, out.orgErr, out.orgA, out.orgB, oa, ob);
+#endif
+    refine_post<MODE, IM>(rg, oa, ob, anchorPos, out);
 }
 
 // ---- float seed (OptimizeRGB / OptimizeRGBA with cSteps == 4, :1198-1555) -----------------------------
 // `fpx` = the block's 16 float texels (r,g,b,a); only texels in `mask16` take part, in increasing order.
 // Returns the endpoints clamped to [0,1], scaled by 255 and truncated with the +0.01 bias (:3543-3548).
-template<bool RGBA>
+// FULL: all 16 texels take part and `fpx` may be a register array (every texel loop is unrolled).
+template<bool FULL, class F>
+DXTEX_HD void for_masked(uint32_t mask16, F&& f)
+{
+    if constexpr (FULL)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) f(i);
+    }
+    else
+    {
+        for (int i = 0; i < 16; ++i)
+            if ((mask16 >> i) & 1u) f(i);
+    }
+}
+
+template<bool RGBA, bool FULL = false>
 DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, uint32_t& outB)
 {
     constexpr float fEpsilon = (0.25f / 64.0f) * (0.25f / 64.0f);
@@ -562,8 +849,7 @@ DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, 
     if (RGBA) { X[0] = X[1] = X[2] = X[3] = 1.0f; Y[0] = Y[1] = Y[2] = Y[3] = 0.0f; }
     else { X[0] = X[1] = X[2] = 3.402823466e+38f; Y[0] = Y[1] = Y[2] = -3.402823466e+38f; X[3] = 0.0f; Y[3] = 0.0f; }
 
-    for (int i = 0; i < 16; ++i)
-        if ((mask16 >> i) & 1u)
+    for_masked<FULL>(mask16, [&](int i)
         {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
@@ -572,7 +858,7 @@ DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, 
                 if (v < X[c]) X[c] = v;
                 if (v > Y[c]) Y[c] = v;
             }
-        }
+        });
 
     bool done = false;
     float AB[4];
@@ -593,8 +879,7 @@ DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, 
         float fDir[8];
 #pragma unroll
         for (int d = 0; d < 8; ++d) fDir[d] = 0.0f;
-        for (int i = 0; i < 16; ++i)
-            if ((mask16 >> i) & 1u)
+        for_masked<FULL>(mask16, [&](int i)
             {
                 float Pt[4];
 #pragma unroll
@@ -618,7 +903,7 @@ DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, 
                     f = Pt[0] - Pt[1] + Pt[2]; fDir[2] += f * f;
                     f = Pt[0] - Pt[1] - Pt[2]; fDir[3] += f * f;
                 }
-            }
+            });
 
         float fDirMax = fDir[0];
         int iDirMax = 0;
@@ -658,8 +943,7 @@ DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, 
                 float d2X = 0.0f, d2Y = 0.0f;
                 float dX[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, dY[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 
-                for (int i = 0; i < 16; ++i)
-                    if ((mask16 >> i) & 1u)
+                for_masked<FULL>(mask16, [&](int i)
                     {
                         float p[4];
 #pragma unroll
@@ -685,7 +969,7 @@ DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, 
                             dX[c] += Diff * fC;
                             dY[c] += Diff * fD;
                         }
-                    }
+                    });
 
                 if (d2X > 0.0f)
                 {

@@ -181,159 +181,351 @@ __global__ void __launch_bounds__(256) bc7_rough_kernel(Bc7Args a)
     }
 }
 
-// ---- refine2: modes 1, 3, 7 (two subsets) ------------------------------------------------------------------------
-template<int MODE>
-__global__ void __launch_bounds__(256) bc7_refine2_kernel(Bc7Args a)
-{
-    __shared__ float sF[4][2][64];
-    __shared__ uint32_t sL[4][2][16];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int half = lane >> 5, rank = (lane >> 1) & 15, region = lane & 1;
-    const uint32_t nb0 = (blockIdx.x * 4 + wave) * 2;
-    if (nb0 >= a.nblocks) return;
-    const uint32_t nb = nb0 + half;
-    const bool valid = nb < a.nblocks;
+// ---- per-mode search kernels ---------------------------------------------------------------------------------------
+// One wavefront owns a run of consecutive blocks and works through all their tasks of one mode in three phases:
+//   pre    (lane = task, fixed assignment, uniform cost): seed -> Quantize -> FixEndpointPBits -> AssignIndices;
+//          the "org" endpoints and error of every task go to an LDS task table.
+//   search (persistent lanes): OptimizeOne as a state machine (bc7_core.h). Every loop iteration scores ONE
+//          candidate endpoint pair per lane with a fully converged map_colors; a lane whose search ends stores
+//          its result and takes the next task from the wave's table, so lanes stay busy although searches differ
+//          in length by an order of magnitude. Tasks are handed out in order of decreasing subset size so that
+//          the lanes of a wave loop over similar texel counts.
+//   post   (lane = task, fixed assignment): FixEndpointPBits + AssignIndices of the optimised endpoints, org-vs-opt
+//          decision over the subsets of a candidate (lane shuffle), first-minimum over the block's candidates
+//          (butterfly), EmitBlock by the winning lane.
 
-    if ((lane & 31) < 16 && valid)
+template<int MODE>
+__global__ void __launch_bounds__(64) bc7_subset2_kernel(Bc7Args a)
+{
+    constexpr int NB = 16;              // blocks per wavefront
+    constexpr int T = NB * 32;          // tasks: 16 candidate shapes x 2 subsets per block
+    constexpr int ROUNDS = T / 64;
+    __shared__ float sF[NB * 64];
+    __shared__ uint32_t sL[NB * 16];
+    __shared__ uint32_t tA[T], tB[T];
+    __shared__ int tErr[T];
+    __shared__ uint16_t sOrder[T];
+    __shared__ uint8_t sNp[T];
+    __shared__ uint32_t sSlot[16 * 64];
+    __shared__ uint32_t sBins[20];
+
+    const int lane = threadIdx.x;
+    const uint32_t nb0 = blockIdx.x * NB;
+    const int slotIdx = (MODE == 1) ? SLOT_M1 : (MODE == 3) ? SLOT_M3 : SLOT_M7;
+    const int listOfs = (MODE == 1) ? 0 : 16;
+
+    for (int t = lane; t < NB * 16; t += 64)
     {
-        uint32_t ldr;
-        load_block_texel(a.src, a.nbw, nb, lane & 15, &sF[wave][half][(lane & 15) * 4], ldr);
-        sL[wave][half][lane & 15] = ldr;
+        const uint32_t nb = nb0 + (uint32_t(t) >> 4);
+        uint32_t ldr = 0;
+        if (nb < a.nblocks) load_block_texel(a.src, a.nbw, nb, t & 15, &sF[(t >> 4) * 64 + (t & 15) * 4], ldr);
+        sL[t] = ldr;
     }
+    if (lane < 20) sBins[lane] = 0;
     wave_lds_sync();
 
-    const uint8_t* lst = a.lists + uint64_t(valid ? nb : nb0) * LIST_BYTES;
-    const bool active = valid && !(MODE == 7 && lst[32] == 0);
-    const int slot = (MODE == 1) ? SLOT_M1 : (MODE == 3) ? SLOT_M3 : SLOT_M7;
-
-    SubsetResult res;
-    res.orgErr = 0; res.optErr = 0; res.orgA = res.orgB = res.optA = res.optB = 0;
-    res.orgIdx1 = res.orgIdx2 = res.optIdx1 = res.optIdx2 = 0;
-    uint32_t shape = 0;
-    if (active)
+    // ---- pre ----
+    auto task_setup = [&](int t, uint32_t& nb, uint32_t& shape, uint32_t& mask, uint32_t& anchor) -> bool
     {
-        const float* fpx = sF[wave][half];
-        const uint32_t* pix = sL[wave][half];
-        shape = lst[(MODE == 1 ? 0 : 16) + rank];
+        const int blk = t >> 5, rank = (t >> 1) & 15, region = t & 1;
+        nb = nb0 + uint32_t(blk);
+        if (nb >= a.nblocks) return false;
+        const uint8_t* lst = a.lists + uint64_t(nb) * LIST_BYTES;
+        if (MODE == 7 && lst[32] == 0) return false;
+        shape = lst[listOfs + rank];
         const uint32_t m1 = kPart2Mask[shape];
-        const uint32_t m = region ? m1 : ((~m1) & 0xFFFFu);
-        Region rg; region_init(rg, pix, m);
+        mask = region ? m1 : ((~m1) & 0xFFFFu);
+        anchor = region ? uint32_t(kAnchor2[shape]) : 0u;
+        return true;
+    };
+    auto task_pre = [&](int t, uint32_t mask, uint32_t anchor, Region& rg, SubsetResult& res)
+    {
+        const int blk = t >> 5;
+        const float* fpx = &sF[blk * 64];
+        const uint32_t* pix = &sL[blk * 16];
+        region_init(rg, pix, mask);
         uint32_t A, B;
         if (rg.np == 1) { A = pix[rg.pos(0)]; B = A; }
         else if (rg.np == 2) { A = pix[rg.pos(0)]; B = pix[rg.pos(1)]; }
-        else seed_endpoints<true>(fpx, m, A, B);
-        refine_subset<MODE, 0>(rg, A, B, region ? uint32_t(kAnchor2[shape]) : 0u, res);
-    }
+        else seed_endpoints<true>(fpx, mask, A, B);
+        refine_pre<MODE, 0>(rg, A, B, anchor, res);
+    };
 
-    // candidate totals over the two subset lanes (fOrgTotErr / fOptTotErr, :3447-3452)
-    const int orgTot = res.orgErr + __shfl_xor(res.orgErr, 1);
-    const int optTot = res.optErr + __shfl_xor(res.optErr, 1);
-    const bool useOpt = optTot < orgTot;
-    const int err = useOpt ? optTot : orgTot;
-    const uint32_t myA = useOpt ? res.optA : res.orgA, myB = useOpt ? res.optB : res.orgB;
-    const uint64_t myIdx = useOpt ? res.optIdx1 : res.orgIdx1;
-    const uint32_t otherA = uint32_t(__shfl_xor(int(myA), 1)), otherB = uint32_t(__shfl_xor(int(myB), 1));
-    const uint64_t otherIdx = uint64_t(uint32_t(__shfl_xor(int(uint32_t(myIdx)), 1))) |
-                              (uint64_t(uint32_t(__shfl_xor(int(uint32_t(myIdx >> 32)), 1))) << 32);
-
-    // first minimum over the 16 candidates of this block, in evaluation order (strict <, :2870)
-    uint32_t key = (uint32_t(err) << 4) | uint32_t(rank);
-    uint32_t best = key;
-#pragma unroll
-    for (int d = 2; d < 32; d <<= 1) best = min(best, uint32_t(__shfl_xor(int(best), d)));
-
-    if (active && region == 0 && key == best)
+    for (int r = 0; r < ROUNDS; ++r)
     {
-        const uint32_t epA[3] = { myA, otherA, 0 }, epB[3] = { myB, otherB, 0 };
-        const uint32_t anchor[3] = { 0, kAnchor2[shape], 0 };
-        Cand c;
-        c.err = uint32_t(err);
-        c.ord = uint32_t(MODE) * 128u + uint32_t(rank);
-        emit_block<MODE>(shape, 0, 0, epA, epB, myIdx | otherIdx, 0, anchor, c.lo, c.hi);
-        a.cands[uint64_t(nb) * NUM_SLOTS + slot] = c;
-    }
-    else if (valid && !active && region == 0 && rank == 0)
-    {
-        Cand c; c.err = 0xFFFFFFFFu; c.ord = 0xFFFFFFFFu; c.lo = 0; c.hi = 0;
-        a.cands[uint64_t(nb) * NUM_SLOTS + slot] = c;
-    }
-}
-
-// ---- refine1: modes 4, 5, 6 (one subset, texels in registers) -----------------------------------------------------
-// MODE 4 runs once per index mode (IM) so that a wavefront never mixes the two palette shapes.
-template<int MODE, int IM>
-__global__ void __launch_bounds__(256) bc7_refine1_kernel(Bc7Args a)
-{
-    constexpr int T = (MODE == 6) ? 1 : 4;            // candidates (rotations) per block in this launch
-    constexpr int BPW = 64 / T;                        // blocks per wavefront
-    constexpr int FSTRIDE = 65, LSTRIDE = 17;          // odd strides: lane = block reads stay conflict-free
-    __shared__ float sF[4][BPW * FSTRIDE];
-    __shared__ uint32_t sL[4][BPW * LSTRIDE];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t nbBase = (blockIdx.x * 4 + wave) * BPW;
-    if (nbBase >= a.nblocks) return;
-
-    for (int t = lane; t < BPW * 16; t += 64)
-    {
-        const uint32_t b = uint32_t(t) >> 4, nbt = nbBase + b;
-        if (nbt < a.nblocks)
+        const int t = r * 64 + lane;
+        uint32_t nb, shape = 0, mask = 0, anchor = 0;
+        const bool active = task_setup(t, nb, shape, mask, anchor);
+        int np = 0;
+        if (active)
         {
-            float f4[4]; uint32_t ldr;
-            load_block_texel(a.src, a.nbw, nbt, t & 15, f4, ldr);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) sF[wave][b * FSTRIDE + (t & 15) * 4 + c] = f4[c];
-            sL[wave][b * LSTRIDE + (t & 15)] = ldr;
+            Region rg; SubsetResult res;
+            task_pre(t, mask, anchor, rg, res);
+            tA[t] = res.orgA; tB[t] = res.orgB; tErr[t] = res.orgErr;
+            np = rg.np;
+            atomicAdd(&sBins[16 - np], 1u);
+        }
+        sNp[t] = uint8_t(np);
+    }
+    wave_lds_sync();
+    // exclusive prefix over the size bins (largest subsets first)
+    if (lane == 0)
+    {
+        uint32_t run = 0;
+        for (int i = 0; i <= 16; ++i) { const uint32_t c = sBins[i]; sBins[i] = run; run += c; }
+        sBins[17] = run;
+    }
+    wave_lds_sync();
+    for (int r = 0; r < ROUNDS; ++r)
+    {
+        const int t = r * 64 + lane;
+        const int np = sNp[t];
+        if (np > 0) sOrder[atomicAdd(&sBins[16 - np], 1u)] = uint16_t(t);
+    }
+    wave_lds_sync();
+    const int nTasks = int(sBins[17]);
+
+    // ---- search ----
+    {
+        SearchState st; st.phase = 0;
+        SlotRegion rg; rg.base = &sSlot[lane]; rg.np = 0; rg.p2sum = 0;
+        int myTask = -1;
+        int nextIdx = 0;
+        for (;;)
+        {
+            if (myTask >= 0 && st.phase == 0)
+            {
+                tA[myTask] = st.optA; tB[myTask] = st.optB;
+                myTask = -1;
+            }
+            const unsigned long long idle = __ballot(myTask < 0);
+            if (idle && nextIdx < nTasks)
+            {
+                const int k = __popcll(idle & ((1ull << lane) - 1ull));
+                if (myTask < 0 && nextIdx + k < nTasks)
+                {
+                    myTask = sOrder[nextIdx + k];
+                    const int blk = myTask >> 5, rank = (myTask >> 1) & 15, region = myTask & 1;
+                    const uint8_t* lst = a.lists + uint64_t(nb0 + blk) * LIST_BYTES;
+                    const uint32_t shape = lst[listOfs + rank];
+                    const uint32_t m1 = kPart2Mask[shape];
+                    const uint32_t mask = region ? m1 : ((~m1) & 0xFFFFu);
+                    const uint32_t* pix = &sL[blk * 16];
+                    int np = 0, p2 = 0;
+                    for (uint32_t i = 0; i < 16; ++i)
+                        if ((mask >> i) & 1u)
+                        {
+                            const uint32_t p = pix[i];
+                            sSlot[np * 64 + lane] = p;
+                            p2 += int(udot4(p, p));
+                            ++np;
+                        }
+                    rg.np = np; rg.p2sum = p2;
+                    st = ss_begin<MODE>(tA[myTask], tB[myTask], tErr[myTask]);
+                }
+                nextIdx += __popcll(idle);
+            }
+            if (__ballot(myTask >= 0) == 0ull) break;
+            bool has = false;
+            if (myTask >= 0) st = ss_next<MODE>(st, has);
+            if (has)
+            {
+                const int e = map_colors<MODE, 0>(rg, st.candA, st.candB);
+                st = ss_consume(st, e);
+            }
         }
     }
     wave_lds_sync();
 
-    const uint32_t b = uint32_t(lane) / T, rot = uint32_t(lane) % T;
-    const uint32_t nb = nbBase + b;
-    const bool valid = nb < a.nblocks;
-    const int slot = (MODE == 6) ? SLOT_M6 : (MODE == 5) ? SLOT_M5 : (IM ? SLOT_M4B : SLOT_M4A);
-
-    SubsetResult res;
-    res.orgErr = 0; res.optErr = 0; res.orgA = res.orgB = res.optA = res.optB = 0;
-    res.orgIdx1 = res.orgIdx2 = res.optIdx1 = res.optIdx2 = 0;
-    if (valid)
+    // ---- post ----
+    for (int r = 0; r < ROUNDS; ++r)
     {
-        const float* fpx = &sF[wave][b * FSTRIDE];
-        Block16 rg;
-        block16_init(rg, &sL[wave][b * LSTRIDE], (MODE == 6) ? 0u : rot);
+        const int t = r * 64 + lane;
+        const int rank = (t >> 1) & 15, region = t & 1;
+        uint32_t nb, shape = 0, mask = 0, anchor = 0;
+        const bool active = task_setup(t, nb, shape, mask, anchor);
+        SubsetResult res;
+        res.orgErr = 0; res.optErr = 0; res.orgA = res.orgB = res.optA = res.optB = 0;
+        res.orgIdx1 = res.orgIdx2 = res.optIdx1 = res.optIdx2 = 0;
+        if (active)
+        {
+            Region rg;
+            task_pre(t, mask, anchor, rg, res);
+            refine_post<MODE, 0>(rg, tA[t], tB[t], anchor, res);
+        }
+        const int orgTot = res.orgErr + __shfl_xor(res.orgErr, 1);
+        const int optTot = res.optErr + __shfl_xor(res.optErr, 1);
+        const bool useOpt = optTot < orgTot;
+        const int err = useOpt ? optTot : orgTot;
+        const uint32_t myA = useOpt ? res.optA : res.orgA, myB = useOpt ? res.optB : res.orgB;
+        const uint64_t myIdx = useOpt ? res.optIdx1 : res.orgIdx1;
+        const uint32_t otherA = uint32_t(__shfl_xor(int(myA), 1)), otherB = uint32_t(__shfl_xor(int(myB), 1));
+        const uint64_t otherIdx = uint64_t(uint32_t(__shfl_xor(int(uint32_t(myIdx)), 1))) |
+                                  (uint64_t(uint32_t(__shfl_xor(int(uint32_t(myIdx >> 32)), 1))) << 32);
+        const uint32_t key = (uint32_t(err) << 4) | uint32_t(rank);
+        uint32_t best = key;
+#pragma unroll
+        for (int d = 2; d < 32; d <<= 1) best = min(best, uint32_t(__shfl_xor(int(best), d)));
+
+        if (active && region == 0 && key == best)
+        {
+            const uint32_t epA[3] = { myA, otherA, 0 }, epB[3] = { myB, otherB, 0 };
+            const uint32_t anchors[3] = { 0, kAnchor2[shape], 0 };
+            Cand c;
+            c.err = uint32_t(err);
+            c.ord = uint32_t(MODE) * 128u + uint32_t(rank);
+            emit_block<MODE>(shape, 0, 0, epA, epB, myIdx | otherIdx, 0, anchors, c.lo, c.hi);
+            a.cands[uint64_t(nb) * NUM_SLOTS + slotIdx] = c;
+        }
+        else if (!active && region == 0 && rank == 0 && (nb0 + uint32_t(t >> 5)) < a.nblocks)
+        {
+            Cand c; c.err = 0xFFFFFFFFu; c.ord = 0xFFFFFFFFu; c.lo = 0; c.hi = 0;
+            a.cands[uint64_t(nb0 + uint32_t(t >> 5)) * NUM_SLOTS + slotIdx] = c;
+        }
+    }
+}
+
+// Modes 4, 5, 6: one subset, the block's texels live in registers. TB candidates per block in one launch
+// (mode 4 runs once per index mode so a wavefront never mixes palette shapes).
+template<int MODE, int IM>
+__global__ void __launch_bounds__(64) bc7_subset1_kernel(Bc7Args a)
+{
+    constexpr int TB = (MODE == 6) ? 1 : 4;
+    constexpr int T = 512;              // tasks per wavefront
+    constexpr int NB = T / TB;
+    constexpr int ROUNDS = T / 64;
+    __shared__ uint32_t tA[T], tB[T];
+    __shared__ int tErr[T];
+
+    const int lane = threadIdx.x;
+    const uint32_t nb0 = blockIdx.x * NB;
+    const int slotIdx = (MODE == 6) ? SLOT_M6 : (MODE == 5) ? SLOT_M5 : (IM ? SLOT_M4B : SLOT_M4A);
+
+    auto load_regs = [&](uint32_t nb, float (&f)[64], uint32_t (&px)[16])
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) load_block_texel(a.src, a.nbw, nb, i, &f[i * 4], px[i]);
+    };
+    auto task_pre = [&](uint32_t nb, uint32_t rot, Block16& rg, SubsetResult& res)
+    {
+        float f[64]; uint32_t px[16];
+        load_regs(nb, f, px);
+        block16_init(rg, px, (MODE == 6) ? 0u : rot);
         uint32_t A, B;
         if (MODE == 6)
-            seed_endpoints<true>(fpx, 0xFFFFu, A, B);
+            seed_endpoints<true, true>(f, 0xFFFFu, A, B);
         else
         {
             // colour endpoints from the *unrotated* float texels, alpha endpoints = min/max of the rotated
             // 8-bit alpha (:3552-3568)
-            seed_endpoints<false>(fpx, 0xFFFFu, A, B);
+            seed_endpoints<false, true>(f, 0xFFFFu, A, B);
             uint32_t mn = 255, mx = 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { const uint32_t al = rg.px[i] >> 24; mn = min(mn, al); mx = max(mx, al); }
             A = (A & 0x00FFFFFFu) | (mn << 24);
             B = (B & 0x00FFFFFFu) | (mx << 24);
         }
-        refine_subset<MODE, IM>(rg, A, B, 0u, res);
-    }
+        refine_pre<MODE, IM>(rg, A, B, 0u, res);
+    };
 
-    const bool useOpt = res.optErr < res.orgErr;
-    const int err = useOpt ? res.optErr : res.orgErr;
-    const uint32_t sub = (MODE == 4) ? (rot * 2 + IM) : rot;
-    uint32_t key = (uint32_t(err) << 4) | sub;
-    uint32_t best = key;
-#pragma unroll
-    for (int d = 1; d < T; d <<= 1) best = min(best, uint32_t(__shfl_xor(int(best), d)));
-
-    if (valid && key == best)
+    // ---- pre ----
+    for (int r = 0; r < ROUNDS; ++r)
     {
-        const uint32_t epA[3] = { useOpt ? res.optA : res.orgA, 0, 0 }, epB[3] = { useOpt ? res.optB : res.orgB, 0, 0 };
-        const uint32_t anchor[3] = { 0, 0, 0 };
-        Cand c;
-        c.err = uint32_t(err);
-        c.ord = uint32_t(MODE) * 128u + sub * 16u;
-        emit_block<MODE>(0, rot, IM, epA, epB, useOpt ? res.optIdx1 : res.orgIdx1, useOpt ? res.optIdx2 : res.orgIdx2, anchor, c.lo, c.hi);
-        a.cands[uint64_t(nb) * NUM_SLOTS + slot] = c;
+        const int t = r * 64 + lane;
+        const uint32_t nb = nb0 + uint32_t(t) / TB, rot = uint32_t(t) % TB;
+        if (nb < a.nblocks)
+        {
+            Block16 rg; SubsetResult res;
+            task_pre(nb, rot, rg, res);
+            tA[t] = res.orgA; tB[t] = res.orgB; tErr[t] = res.orgErr;
+        }
+    }
+    wave_lds_sync();
+    const int nTasks = int(min(uint32_t(T), (a.nblocks > nb0 ? (a.nblocks - nb0) : 0u) * TB));
+
+    // ---- search ----
+    {
+        SearchState st; st.phase = 0;
+        Block16 rg;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rg.px[i] = 0;
+        rg.p2sum = 0;
+        int myTask = -1;
+        int nextIdx = 0;
+        for (;;)
+        {
+            if (myTask >= 0 && st.phase == 0)
+            {
+                tA[myTask] = st.optA; tB[myTask] = st.optB;
+                myTask = -1;
+            }
+            const unsigned long long idle = __ballot(myTask < 0);
+            if (idle && nextIdx < nTasks)
+            {
+                const int k = __popcll(idle & ((1ull << lane) - 1ull));
+                if (myTask < 0 && nextIdx + k < nTasks)
+                {
+                    myTask = nextIdx + k;
+                    const uint32_t nb = nb0 + uint32_t(myTask) / TB, rot = uint32_t(myTask) % TB;
+                    int p2 = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                    {
+                        float f4[4]; uint32_t ldr;
+                        load_block_texel(a.src, a.nbw, nb, i, f4, ldr);
+                        ldr = rotate_pixel(ldr, (MODE == 6) ? 0u : rot);
+                        rg.px[i] = ldr;
+                        p2 += int(udot4(ldr, ldr));
+                    }
+                    rg.p2sum = p2;
+                    st = ss_begin<MODE>(tA[myTask], tB[myTask], tErr[myTask]);
+                }
+                nextIdx += __popcll(idle);
+            }
+            if (__ballot(myTask >= 0) == 0ull) break;
+            bool has = false;
+            if (myTask >= 0) st = ss_next<MODE>(st, has);
+            if (has)
+            {
+                const int e = map_colors<MODE, IM>(rg, st.candA, st.candB);
+                st = ss_consume(st, e);
+            }
+        }
+    }
+    wave_lds_sync();
+
+    // ---- post ----
+    for (int r = 0; r < ROUNDS; ++r)
+    {
+        const int t = r * 64 + lane;
+        const uint32_t nb = nb0 + uint32_t(t) / TB, rot = uint32_t(t) % TB;
+        const bool valid = nb < a.nblocks;
+        SubsetResult res;
+        res.orgErr = 0; res.optErr = 0; res.orgA = res.orgB = res.optA = res.optB = 0;
+        res.orgIdx1 = res.orgIdx2 = res.optIdx1 = res.optIdx2 = 0;
+        if (valid)
+        {
+            Block16 rg;
+            task_pre(nb, rot, rg, res);
+            refine_post<MODE, IM>(rg, tA[t], tB[t], 0u, res);
+        }
+        const bool useOpt = res.optErr < res.orgErr;
+        const int err = useOpt ? res.optErr : res.orgErr;
+        const uint32_t sub = (MODE == 4) ? (rot * 2 + IM) : rot;
+        const uint32_t key = (uint32_t(err) << 4) | sub;
+        uint32_t best = key;
+#pragma unroll
+        for (int d = 1; d < TB; d <<= 1) best = min(best, uint32_t(__shfl_xor(int(best), d)));
+        if (valid && key == best)
+        {
+            const uint32_t epA[3] = { useOpt ? res.optA : res.orgA, 0, 0 }, epB[3] = { useOpt ? res.optB : res.orgB, 0, 0 };
+            const uint32_t anchors[3] = { 0, 0, 0 };
+            Cand c;
+            c.err = uint32_t(err);
+            c.ord = uint32_t(MODE) * 128u + sub * 16u;
+            emit_block<MODE>(0, rot, IM, epA, epB, useOpt ? res.optIdx1 : res.orgIdx1, useOpt ? res.optIdx2 : res.orgIdx2, anchors, c.lo, c.hi);
+            a.cands[uint64_t(nb) * NUM_SLOTS + slotIdx] = c;
+        }
     }
 }
 
@@ -385,22 +577,22 @@ hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPi
     {
         DXTEX_MARK("bc7_rough");
         hipLaunchKernelGGL(bc7_rough_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, a);
-        DXTEX_MARK("bc7_refine2_mode1");
-        hipLaunchKernelGGL(bc7_refine2_kernel<1>, dim3((nb + 7) / 8), dim3(256), 0, stream, a);
-        DXTEX_MARK("bc7_refine2_mode3");
-        hipLaunchKernelGGL(bc7_refine2_kernel<3>, dim3((nb + 7) / 8), dim3(256), 0, stream, a);
-        DXTEX_MARK("bc7_refine2_mode7");
-        hipLaunchKernelGGL(bc7_refine2_kernel<7>, dim3((nb + 7) / 8), dim3(256), 0, stream, a);
-        DXTEX_MARK("bc7_refine1_mode4_im0");
-        hipLaunchKernelGGL((bc7_refine1_kernel<4, 0>), dim3((nb + 63) / 64), dim3(256), 0, stream, a);
-        DXTEX_MARK("bc7_refine1_mode4_im1");
-        hipLaunchKernelGGL((bc7_refine1_kernel<4, 1>), dim3((nb + 63) / 64), dim3(256), 0, stream, a);
-        DXTEX_MARK("bc7_refine1_mode5");
-        hipLaunchKernelGGL((bc7_refine1_kernel<5, 0>), dim3((nb + 63) / 64), dim3(256), 0, stream, a);
+        DXTEX_MARK("bc7_subset2_mode1");
+        hipLaunchKernelGGL(bc7_subset2_kernel<1>, dim3((nb + 15) / 16), dim3(64), 0, stream, a);
+        DXTEX_MARK("bc7_subset2_mode3");
+        hipLaunchKernelGGL(bc7_subset2_kernel<3>, dim3((nb + 15) / 16), dim3(64), 0, stream, a);
+        DXTEX_MARK("bc7_subset2_mode7");
+        hipLaunchKernelGGL(bc7_subset2_kernel<7>, dim3((nb + 15) / 16), dim3(64), 0, stream, a);
+        DXTEX_MARK("bc7_subset1_mode4_im0");
+        hipLaunchKernelGGL((bc7_subset1_kernel<4, 0>), dim3((nb + 127) / 128), dim3(64), 0, stream, a);
+        DXTEX_MARK("bc7_subset1_mode4_im1");
+        hipLaunchKernelGGL((bc7_subset1_kernel<4, 1>), dim3((nb + 127) / 128), dim3(64), 0, stream, a);
+        DXTEX_MARK("bc7_subset1_mode5");
+        hipLaunchKernelGGL((bc7_subset1_kernel<5, 0>), dim3((nb + 127) / 128), dim3(64), 0, stream, a);
         slotMask |= (1u << SLOT_M1) | (1u << SLOT_M3) | (1u << SLOT_M7) | (1u << SLOT_M4A) | (1u << SLOT_M4B) | (1u << SLOT_M5);
     }
-    DXTEX_MARK("bc7_refine1_mode6");
-    hipLaunchKernelGGL((bc7_refine1_kernel<6, 0>), dim3((nb + 255) / 256), dim3(256), 0, stream, a);
+    DXTEX_MARK("bc7_subset1_mode6");
+    hipLaunchKernelGGL((bc7_subset1_kernel<6, 0>), dim3((nb + 511) / 512), dim3(64), 0, stream, a);
     slotMask |= (1u << SLOT_M6);
     DXTEX_MARK("bc7_pick");
     hipLaunchKernelGGL(bc7_pick_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, a, slotMask);
