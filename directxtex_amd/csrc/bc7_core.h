@@ -104,33 +104,46 @@ DXTEX_HD uint32_t lerp_bytes(uint32_t a, uint32_t b, int w)
     return rb | (ga << 8);
 }
 
-// The first local minimum along the palette, as ComputeError's early-breaking linear scan finds it
-// (:1581-1595): keep going while the value does not increase. `t[i]` are errors up to a per-pixel constant.
-template<int N>
-DXTEX_HD int ascent_min(const int (&t)[N])
+// Scores. Squared distances are compared through their negation with the per-texel constant |p|^2 dropped:
+//   score_i = 2 p.q_i - |q_i|^2        (so |p - q_i|^2 = |p|^2 - score_i)
+// which is two chained v_dot4_u32_u8 (the second accumulates onto the first; the accumulator starts at
+// -|q_i|^2), all in wrapping 32-bit arithmetic.
+DXTEX_HD uint32_t udot4acc(uint32_t a, uint32_t b, uint32_t c)
 {
-    int best = t[0];
-    bool done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    return udot4(a, b) + c;
+#endif
+}
+DXTEX_HD int score(uint32_t p, uint32_t q, uint32_t negq2) { return int(udot4acc(p, q, udot4acc(p, q, negq2))); }
+
+// ComputeError scans the palette and stops at the first entry whose error is larger than the best so far
+// (:1581-1595): it finds the first local minimum, i.e. (in scores) s[j-1] for the first j with
+// s[j] < s[j-1], or s[N-1] if the scores never drop. Evaluated from the far end so that the N-1
+// comparisons are independent of each other and of the selects (no serial compare -> mask-or -> select
+// chain through the scalar unit).
+template<int N>
+DXTEX_HD int first_peak(const int (&sc)[N])
+{
+    int res = sc[N - 1];
 #pragma unroll
-    for (int i = 1; i < N; ++i)
-    {
-        done = done || (t[i] > best);
-        best = done ? best : t[i];
-    }
-    return best;
+    for (int i = N - 1; i >= 1; --i) res = (sc[i] < sc[i - 1]) ? sc[i - 1] : res;
+    return res;
 }
 
 template<int N>
-DXTEX_HD int ascent_min_idx(const int (&t)[N], uint32_t& idx)
+DXTEX_HD int first_peak_idx(const int (&sc)[N], uint32_t& idx)
 {
-    int best = t[0];
+    // the scan keeps the FIRST entry of a plateau (strict '<' on errors to replace the best)
+    int best = sc[0];
     bool done = false;
     idx = 0;
 #pragma unroll
     for (int i = 1; i < N; ++i)
     {
-        done = done || (t[i] > best);
-        if (!done && t[i] < best) { best = t[i]; idx = uint32_t(i); }
+        done = done || (sc[i] < best);
+        if (!done && sc[i] > best) { best = sc[i]; idx = uint32_t(i); }
     }
     return best;
 }
@@ -214,7 +227,11 @@ DXTEX_HD void for_texels(const RG& rg, F&& f)
     }
     else
     {
-        for (int k = 0; k < rg.count(); ++k) f(k);
+        // two texels per trip: their compare/select chains interleave and hide the VCC write->read hazard
+        const int n = rg.count();
+        int k = 0;
+        for (; k + 1 < n; k += 2) { f(k); f(k + 1); }
+        if (k < n) f(k);
     }
 }
 
@@ -237,50 +254,47 @@ DXTEX_HD int map_colors(const RG& rg, uint32_t epA, uint32_t epB)
     const uint32_t ua = unquantize<MODE>(epA), ub = unquantize<MODE>(epB);
     int total = rg.p2sum;
 
+    uint32_t pal[PB::NC], nq2[PB::NC];
+#pragma unroll
+    for (int i = 0; i < PB::NC; ++i)
+    {
+        pal[i] = lerp_bytes(ua, ub, weight(PB::CB, i));
+        if (PB::AB != 0) pal[i] &= 0x00FFFFFFu;
+        nq2[i] = 0u - udot4(pal[i], pal[i]);
+    }
     if (PB::AB == 0)
     {
-        uint32_t pal[PB::NC]; int q2[PB::NC];
-#pragma unroll
-        for (int i = 0; i < PB::NC; ++i)
-        {
-            pal[i] = lerp_bytes(ua, ub, weight(PB::CB, i));
-            q2[i] = int(udot4(pal[i], pal[i]));
-        }
         for_texels(rg, [&](int k)
         {
             const uint32_t p = rg.fetch(k);
-            int t[PB::NC];
+            int sc[PB::NC];
 #pragma unroll
-            for (int i = 0; i < PB::NC; ++i) t[i] = q2[i] - 2 * int(udot4(p, pal[i]));
-            total += ascent_min(t);
+            for (int i = 0; i < PB::NC; ++i) sc[i] = score(p, pal[i], nq2[i]);
+            total -= first_peak(sc);
         });
     }
     else
     {
-        uint32_t pal[PB::NC]; int q2[PB::NC];
-        int pa[PB::NA];
-#pragma unroll
-        for (int i = 0; i < PB::NC; ++i)
-        {
-            pal[i] = lerp_bytes(ua, ub, weight(PB::CB, i)) & 0x00FFFFFFu;
-            q2[i] = int(udot4(pal[i], pal[i]));
-        }
+        int pa[PB::NA], npa2[PB::NA];
         const int a0 = int(ua >> 24), a1 = int(ub >> 24);
 #pragma unroll
         for (int i = 0; i < PB::NA; ++i)
+        {
             pa[i] = (a0 * (64 - weight(PB::AB, i)) + a1 * weight(PB::AB, i) + 32) >> 6;
+            npa2[i] = -(pa[i] * pa[i]);
+        }
         for_texels(rg, [&](int k)
         {
             const uint32_t p = rg.fetch(k);
             const uint32_t prgb = p & 0x00FFFFFFu;
-            const int al = int(p >> 24);
-            int t[PB::NC];
+            const int al2 = int(p >> 24) * 2;
+            int sc[PB::NC];
 #pragma unroll
-            for (int i = 0; i < PB::NC; ++i) t[i] = q2[i] - 2 * int(udot4(prgb, pal[i]));
-            int u[PB::NA];
+            for (int i = 0; i < PB::NC; ++i) sc[i] = score(prgb, pal[i], nq2[i]);
+            int su[PB::NA];
 #pragma unroll
-            for (int i = 0; i < PB::NA; ++i) u[i] = pa[i] * pa[i] - 2 * al * pa[i];
-            total += ascent_min(t) + ascent_min(u);
+            for (int i = 0; i < PB::NA; ++i) su[i] = al2 * pa[i] + npa2[i];
+            total -= first_peak(sc) + first_peak(su);
         });
     }
     return total;
@@ -296,13 +310,13 @@ DXTEX_HD int assign_indices(const RG& rg, uint32_t& epA, uint32_t& epB, uint32_t
     int total = rg.p2sum;
     idx1 = 0; idx2 = 0;
 
-    uint32_t pal[PB::NC]; int q2[PB::NC];
+    uint32_t pal[PB::NC], nq2[PB::NC];
 #pragma unroll
     for (int i = 0; i < PB::NC; ++i)
     {
         pal[i] = lerp_bytes(ua, ub, weight(PB::CB, i));
         if (PB::AB != 0) pal[i] &= 0x00FFFFFFu;
-        q2[i] = int(udot4(pal[i], pal[i]));
+        nq2[i] = 0u - udot4(pal[i], pal[i]);
     }
     int pa[PB::NA];
     if (PB::AB != 0)
@@ -317,20 +331,20 @@ DXTEX_HD int assign_indices(const RG& rg, uint32_t& epA, uint32_t& epB, uint32_t
     {
         const uint32_t p = rg.fetch(k);
         const uint32_t pc = (PB::AB != 0) ? (p & 0x00FFFFFFu) : p;
-        int t[PB::NC];
+        int sc[PB::NC];
 #pragma unroll
-        for (int i = 0; i < PB::NC; ++i) t[i] = q2[i] - 2 * int(udot4(pc, pal[i]));
+        for (int i = 0; i < PB::NC; ++i) sc[i] = score(pc, pal[i], nq2[i]);
         uint32_t i1;
-        total += ascent_min_idx(t, i1);
+        total -= first_peak_idx(sc, i1);
         idx1 |= uint64_t(i1) << (4 * rg.pos(k));
         if (PB::AB != 0)
         {
             const int al = int(p >> 24);
-            int u[PB::NA];
+            int su[PB::NA];
 #pragma unroll
-            for (int i = 0; i < PB::NA; ++i) u[i] = pa[i] * pa[i] - 2 * al * pa[i];
+            for (int i = 0; i < PB::NA; ++i) su[i] = 2 * al * pa[i] - pa[i] * pa[i];
             uint32_t i2;
-            total += ascent_min_idx(u, i2);
+            total -= first_peak_idx(su, i2);
             idx2 |= uint64_t(i2) << (4 * rg.pos(k));
         }
     });
@@ -543,243 +557,377 @@ DXTEX_HD void optimize_one(const RG& rg, int orgErr, uint32_t orgA, uint32_t org
     exhaustive<MODE, IM, 3>(rg, optErr, optA, optB);
 }
 
-// ---- OptimizeOne as an explicit state machine ------------------------------------------------------------
-// The same search as optimize_one() above, cut at every MapColors call: next() advances to the next
-// endpoint pair that has to be scored (or reports that the search is over), consume() feeds the score back.
-// This lets a wavefront run ONE converged map_colors per iteration while every lane is somewhere else in
-// its own search, and lets a lane that finishes early pick up another task (bc7_encode.hip).
-struct SearchState
+// ---- OptimizeOne restated for lockstep execution ------------------------------------------------------------
+// The same search as optimize_one() above, cut into pieces that every lane of a wavefront can execute in
+// lockstep although each lane works on a different (block, shape, subset):
+//   * a PERTURB macro-op = one PerturbOne call (:2926-2966): exactly 2 * PREC candidate evaluations, the same
+//     count for every lane, so the macro-op is straight-line code; what differs between lanes (channel, which
+//     endpoint moves, where in OptimizeOne's per-channel logic the lane is) is data, updated by a few selects
+//     between macro-ops (perturb_transition);
+//   * the Exhaustive windows (:2971-3042) flattened into one candidate per loop trip (exh_* functions).
+// While one channel of the endpoints varies, the palette bytes of the other channels and their contribution
+// to |q|^2 do not: they are computed once per macro-op / window (VarPal) and each candidate only re-derives
+// the varying byte. In the separate-alpha modes (4, 5) the colour and alpha errors are independent sums, so a
+// loop that walks colour channels carries the alpha error as a constant and vice versa (CH_COLOR / CH_ALPHA);
+// the combined-index modes walk all their channels in one loop (CH_ALL).
+enum : int { CH_ALL = 0, CH_COLOR = 1, CH_ALPHA = 2 };
+
+template<int MODE, int IM, int CHSET>
+struct LoopCfg
+{
+    typedef ModeInfo<MODE> MI;
+    typedef PaletteBits<MODE, IM> PB;
+    enum : int { kAlpha = (CHSET == CH_ALPHA) ? 1 : 0,
+                 N = kAlpha ? PB::NA : PB::NC,                        // palette entries scored per texel
+                 BITS = kAlpha ? PB::AB : PB::CB,
+                 PREC = kAlpha ? MI::APP : MI::CPP,                   // endpoint precision of the channels this loop walks
+                 CH0 = kAlpha ? 3 : 0,
+                 CH1 = (CHSET == CH_ALL) ? (MI::APP ? 4 : 3) : (CHSET == CH_COLOR ? 3 : 4) };   // one past the last channel
+    static_assert(CHSET != CH_ALL || MI::APP == 0 || MI::APP == MI::CPP, "combined loops need one precision");
+    static_assert((CHSET == CH_ALL) == (PB::AB == 0), "CH_ALL <=> combined colour+alpha indices");
+};
+
+template<int N> struct VarPal { uint32_t palO[N]; uint32_t nq2O[N]; };
+
+// Palette of (epA, epB) with channel `ch` blanked, and minus the squared length of what is left.
+template<int MODE, int IM, int CHSET>
+DXTEX_HD void varpal_init(VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, uint32_t epA, uint32_t epB, int ch)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    if (C::kAlpha) return;
+    const uint32_t ua = unquantize<MODE>(epA), ub = unquantize<MODE>(epB);
+    const uint32_t keep = ~(0xFFu << (8 * ch)) & (CHSET == CH_COLOR ? 0x00FFFFFFu : 0xFFFFFFFFu);
+#pragma unroll
+    for (int i = 0; i < C::N; ++i)
+    {
+        vp.palO[i] = lerp_bytes(ua, ub, weight(C::BITS, i)) & keep;
+        vp.nq2O[i] = 0u - udot4(vp.palO[i], vp.palO[i]);
+    }
+}
+
+// Error of the region when channel `ch` of the endpoints unquantises to (uaC, ubC) and everything else is as
+// in `vp`. `base` = sum of |p|^2 over the part of the texel this loop scores + the constant error of the other part.
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD int eval_var(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, int ch, uint32_t uaC, uint32_t ubC, int base)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    int total = base;
+    if (C::kAlpha)
+    {
+        int pa[C::N], npa2[C::N];
+#pragma unroll
+        for (int i = 0; i < C::N; ++i)
+        {
+            pa[i] = int((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6);
+            npa2[i] = -(pa[i] * pa[i]);
+        }
+        for_texels(rg, [&](int k)
+        {
+            const int al2 = int((rg.fetch(k) >> 23) & 0x1FEu);
+            int su[C::N];
+#pragma unroll
+            for (int i = 0; i < C::N; ++i) su[i] = al2 * pa[i] + npa2[i];
+            total -= first_peak(su);
+        });
+    }
+    else
+    {
+        uint32_t pal[C::N], nq2[C::N];
+        const int sh = 8 * ch;
+#pragma unroll
+        for (int i = 0; i < C::N; ++i)
+        {
+            const uint32_t v = (uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6;
+            pal[i] = vp.palO[i] | (v << sh);
+            nq2[i] = vp.nq2O[i] - v * v;
+        }
+        for_texels(rg, [&](int k)
+        {
+            uint32_t p = rg.fetch(k);
+            if (CHSET == CH_COLOR) p &= 0x00FFFFFFu;
+            int sc[C::N];
+#pragma unroll
+            for (int i = 0; i < C::N; ++i) sc[i] = score(p, pal[i], nq2[i]);
+            total -= first_peak(sc);
+        });
+    }
+    return total;
+}
+
+// The two independent error sums of a separate-alpha mode, without the |p|^2 terms folded in.
+template<int MODE, int IM, class RG>
+DXTEX_HD int color_part_error(const RG& rg, uint32_t epA, uint32_t epB)
+{
+    typedef PaletteBits<MODE, IM> PB;
+    const uint32_t ua = unquantize<MODE>(epA), ub = unquantize<MODE>(epB);
+    uint32_t pal[PB::NC], nq2[PB::NC];
+#pragma unroll
+    for (int i = 0; i < PB::NC; ++i)
+    {
+        pal[i] = lerp_bytes(ua, ub, weight(PB::CB, i)) & 0x00FFFFFFu;
+        nq2[i] = 0u - udot4(pal[i], pal[i]);
+    }
+    int total = 0;
+    for_texels(rg, [&](int k)
+    {
+        const uint32_t p = rg.fetch(k) & 0x00FFFFFFu;
+        int sc[PB::NC];
+#pragma unroll
+        for (int i = 0; i < PB::NC; ++i) sc[i] = score(p, pal[i], nq2[i]);
+        total += int(udot4(p, p)) - first_peak(sc);
+    });
+    return total;
+}
+
+template<int MODE, int IM, class RG>
+DXTEX_HD int alpha_part_error(const RG& rg, uint32_t epA, uint32_t epB)
+{
+    typedef PaletteBits<MODE, IM> PB;
+    const uint32_t ua = unquantize<MODE>(epA), ub = unquantize<MODE>(epB);
+    constexpr int NA = PB::NA, AB = PB::AB ? PB::AB : 2;
+    int pa[NA];
+    const int a0 = int(ua >> 24), a1 = int(ub >> 24);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) pa[i] = (a0 * (64 - weight(AB, i)) + a1 * weight(AB, i) + 32) >> 6;
+    int total = 0;
+    for_texels(rg, [&](int k)
+    {
+        const int al = int(rg.fetch(k) >> 24);
+        int su[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) su[i] = 2 * al * pa[i] - pa[i] * pa[i];
+        total += al * al - first_peak(su);
+    });
+    return total;
+}
+
+// `base` of eval_var for a loop over CHSET, given the endpoints whose other part stays fixed during the loop.
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD int loop_base(const RG& rg, uint32_t epA, uint32_t epB)
+{
+    int own = 0;
+    for_texels(rg, [&](int k)
+    {
+        const uint32_t p = rg.fetch(k);
+        const uint32_t q = (CHSET == CH_COLOR) ? (p & 0x00FFFFFFu) : (CHSET == CH_ALPHA) ? (p >> 24) : p;
+        own += int(udot4(q, q));
+    });
+    if (CHSET == CH_COLOR) return own + alpha_part_error<MODE, IM>(rg, epA, epB);
+    if (CHSET == CH_ALPHA) return own + color_part_error<MODE, IM>(rg, epA, epB);
+    return own;
+}
+
+// Where a lane stands inside OptimizeOne's per-channel logic (:3060-3105).
+struct PerturbState
 {
     uint32_t optA, optB;
     int optErr;
-    int phase;            // 0 = finished, 1 = perturb, 2 = exhaustive
-    int sub;              // perturb: 0 = first pass on A, 1 = first pass on B, 2 = alternating loop
-    int ch, prec;
+    int ch;         // current channel; >= CH1 when the loop's channels are exhausted
+    int sub;        // 0 = first pass on A, 1 = first pass on B, 2 = alternating loop
     int do_b;
-    int cur, minErr, step, sign, beststep;
-    int improved;         // bool
-    int err0;
-    uint32_t newA;
-    int a, b, alow, ahigh, blow, bhigh, amin, bmin, best;
-    int aleb;             // bool
-    uint32_t candA, candB;
+    int err0;       // result of the first pass on A
+    uint32_t newA;  // new_a.A[ch] of the first pass on A
 };
 
-template<int MODE> DXTEX_HD int prec_of(int ch) { return ch == 3 ? int(ModeInfo<MODE>::APP) : int(ModeInfo<MODE>::CPP); }
-
-// NOTE on style: every function below takes the state by const reference, works on a LOCAL copy and
-// returns it by value. Conditional stores to different fields through a reference get merged by LLVM into
-// a store through a selected pointer, after which the struct can no longer be promoted to registers and
-// lives in scratch memory (measured: 116 B/lane of scratch, 3x slower). Local copies are always promoted.
-
-DXTEX_HD SearchState ss_select(bool c, const SearchState& x, const SearchState& y)
+template<int MODE, int IM, int CHSET>
+DXTEX_HD PerturbState perturb_begin(uint32_t optA, uint32_t optB, int optErr)
 {
-    SearchState r;
-#define DXTEX_SEL(F) r.F = c ? x.F : y.F
-    DXTEX_SEL(optA); DXTEX_SEL(optB); DXTEX_SEL(optErr); DXTEX_SEL(phase); DXTEX_SEL(sub); DXTEX_SEL(ch); DXTEX_SEL(prec);
-    DXTEX_SEL(do_b); DXTEX_SEL(cur); DXTEX_SEL(minErr); DXTEX_SEL(step); DXTEX_SEL(sign); DXTEX_SEL(beststep);
-    DXTEX_SEL(improved); DXTEX_SEL(err0); DXTEX_SEL(newA); DXTEX_SEL(a); DXTEX_SEL(b); DXTEX_SEL(alow); DXTEX_SEL(ahigh);
-    DXTEX_SEL(blow); DXTEX_SEL(bhigh); DXTEX_SEL(amin); DXTEX_SEL(bmin); DXTEX_SEL(best); DXTEX_SEL(aleb);
-    DXTEX_SEL(candA); DXTEX_SEL(candB);
-#undef DXTEX_SEL
-    return r;
-}
-
-DXTEX_HD SearchState ss_begin_perturb(const SearchState& in, int do_b)
-{
-    SearchState s = in;
-    s.phase = 1; s.do_b = do_b;
-    s.cur = int(byte_of(do_b ? s.optB : s.optA, s.ch));
-    s.minErr = s.optErr;
-    s.step = 1 << (s.prec - 1);
-    s.sign = -1; s.improved = false; s.beststep = 0;
+    PerturbState s;
+    s.optA = optA; s.optB = optB; s.optErr = optErr;
+    s.ch = LoopCfg<MODE, IM, CHSET>::CH0; s.sub = 0; s.do_b = 0; s.err0 = 0; s.newA = 0;
     return s;
 }
 
-template<int MODE>
-DXTEX_HD SearchState ss_begin_exhaustive(const SearchState& in, int ch)
+// One PerturbOne call (:2926-2966) on channel s.ch of endpoint A (s.do_b == 0) or B: returns the best error
+// found (fMinErr) and the channel value it belongs to. Straight-line: 2 * PREC evaluations for every lane.
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD void perturb_macro(const RG& rg, const PerturbState& s, int base, int& outErr, uint32_t& outVal)
 {
-    SearchState s = in;
-    // Exhaustive() returns at once when the error is already zero (:2980), for every remaining channel
-    const bool over = (ch >= 4) || (s.optErr == 0);
-    const int c = over ? 0 : ch;
-    const int prec = prec_of<MODE>(c);
-    constexpr int delta = 5;
-    const int ca = int(byte_of(s.optA, c)), cb = int(byte_of(s.optB, c));
-    const int hi = (1 << prec) - 1;
-    const int alow = (ca - delta) > 0 ? (ca - delta) : 0;
-    const int ahigh = (ca + delta) < hi ? (ca + delta) : hi;
-    const int blow = (cb - delta) > 0 ? (cb - delta) : 0;
-    const int bhigh = (cb + delta) < hi ? (cb + delta) : hi;
-    const bool aleb = ca <= cb;
-    const int m = alow > blow ? alow : blow;
-    s.phase = over ? 0 : 2;
-    s.ch = c; s.prec = prec;
-    s.alow = alow; s.ahigh = ahigh; s.blow = blow; s.bhigh = bhigh;
-    s.amin = 0; s.bmin = 0; s.best = s.optErr;
-    s.aleb = aleb;
-    s.a = aleb ? alow : m;        // aleb: a = alow, b = max(a, blow);  else: b = blow, a = max(b, alow)
-    s.b = aleb ? m : blow;
-    return s;
-}
-
-template<int MODE>
-DXTEX_HD SearchState ss_next_channel(const SearchState& in)
-{
-    SearchState s = in;
-    int ch = s.ch + 1;
-    while (ch < 4 && prec_of<MODE>(ch) == 0) ++ch;
-    const bool toExh = ch >= 4;
-    SearchState p = s;
-    p.ch = toExh ? s.ch : ch; p.prec = prec_of<MODE>(toExh ? 0 : ch); p.sub = 0;
-    p = ss_begin_perturb(p, 0);
-    const SearchState x = ss_begin_exhaustive<MODE>(s, 0);
-    return ss_select(toExh, x, p);
-}
-
-template<int MODE>
-DXTEX_HD SearchState ss_begin(uint32_t orgA, uint32_t orgB, int orgErr)
-{
-    SearchState s;
-    s.optA = orgA; s.optB = orgB; s.optErr = orgErr;
-    s.phase = 0; s.sub = 0; s.ch = -1; s.prec = 0; s.do_b = 0;
-    s.cur = 0; s.minErr = 0; s.step = 0; s.sign = -1; s.beststep = 0; s.improved = false;
-    s.err0 = 0; s.newA = 0;
-    s.a = s.b = s.alow = s.ahigh = s.blow = s.bhigh = s.amin = s.bmin = s.best = 0; s.aleb = false;
-    s.candA = 0; s.candB = 0;
-    return ss_next_channel<MODE>(s);
-}
-
-template<int MODE>
-DXTEX_HD SearchState ss_perturb_done(const SearchState& in)
-{
-    SearchState s = in;
-    const bool sub0 = (s.sub == 0);
-    const int e = s.minErr;                         // sub 1: fErr1; sub 2: fErr of the alternating loop
-    const bool first = (s.sub == 1);
-    const bool takeA = first ? (s.err0 < e) : (s.do_b == 0);
-    const int claimed = (first && takeA) ? s.err0 : e;
-    const bool giveUp = !sub0 && (claimed >= s.optErr);
-    // sub 0 -> remember the A result, perturb B next
-    // otherwise adopt the claimed error; only the A endpoint ever moves (cnew_b aliases new_a.B[ch],
-    // which still holds the old value)
-    SearchState u = s;
-    u.err0 = sub0 ? s.minErr : s.err0;
-    u.newA = sub0 ? uint32_t(s.cur) : s.newA;
-    u.optA = (!sub0 && takeA) ? with_byte(s.optA, s.ch, s.newA) : s.optA;
-    u.optErr = sub0 ? s.optErr : claimed;
-    u.sub = sub0 ? 1 : 2;
-    const int nextB = sub0 ? 1 : (first ? (takeA ? 1 : 0) : (1 - s.do_b));
-    u = ss_begin_perturb(u, nextB);
-    const SearchState n = ss_next_channel<MODE>(s);
-    return ss_select(giveUp, n, u);
-}
-
-DXTEX_HD SearchState ss_perturb_advance(const SearchState& in)
-{
-    SearchState s = in;
-    const bool second = s.sign > 0;
-    s.cur = (second && s.improved) ? (s.cur + s.beststep) : s.cur;
-    s.improved = second ? false : s.improved;
-    s.beststep = second ? 0 : s.beststep;
-    s.step = second ? (s.step >> 1) : s.step;
-    s.sign = second ? -1 : 1;
-    return s;
-}
-
-template<int MODE>
-DXTEX_HD SearchState ss_exhaustive_done(const SearchState& in)
-{
-    SearchState s = in;
-    const bool better = s.best < s.optErr;
-    s.optA = better ? with_byte(s.optA, s.ch, uint32_t(s.amin)) : s.optA;
-    s.optB = better ? with_byte(s.optB, s.ch, uint32_t(s.bmin)) : s.optB;
-    s.optErr = better ? s.best : s.optErr;
-    return ss_begin_exhaustive<MODE>(s, s.ch + 1);
-}
-
-// Advance to the next candidate (candA/candB); `has` = false when the whole OptimizeOne is finished
-// (optA/optB are final).
-template<int MODE>
-DXTEX_HD SearchState ss_next(const SearchState& in, bool& has)
-{
-    SearchState s = in;
-    bool found = false, over = false;
-    while (!found && !over)
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    VarPal<C::N> vp;
+    varpal_init<MODE, IM, CHSET>(vp, s.optA, s.optB, s.ch);
+    const uint32_t fixedU = unq1<C::PREC>(byte_of(s.do_b ? s.optA : s.optB, s.ch));
+    int cur = int(byte_of(s.do_b ? s.optB : s.optA, s.ch));
+    int minErr = s.optErr;
+#pragma unroll 1
+    for (int step = 1 << (C::PREC - 1); step; step >>= 1)
     {
-        if (s.phase == 0) over = true;
-        else if (s.phase == 1)
+        int beststep = 0;
+#pragma unroll 1
+        for (int sign = -1; sign <= 1; sign += 2)
         {
-            const int tmp = s.cur + s.sign * s.step;
-            if (s.step == 0) s = ss_perturb_done<MODE>(s);
-            else if (tmp < 0 || tmp >= (1 << s.prec)) s = ss_perturb_advance(s);
-            else
-            {
-                const uint32_t wa = with_byte(s.optA, s.ch, uint32_t(tmp)), wb = with_byte(s.optB, s.ch, uint32_t(tmp));
-                s.candA = s.do_b ? s.optA : wa;
-                s.candB = s.do_b ? wb : s.optB;
-                found = true;
-            }
+            const int tmp = cur + sign * step;
+            const bool valid = (tmp >= 0) && (tmp < (1 << C::PREC));
+            const uint32_t u = unq1<C::PREC>(uint32_t(tmp) & ((1u << C::PREC) - 1u));
+            const int e = eval_var<MODE, IM, CHSET>(rg, vp, s.ch, s.do_b ? fixedU : u, s.do_b ? u : fixedU, base);
+            if (valid && e < minErr) { minErr = e; beststep = sign * step; }
         }
-        else
-        {
-            // exhaustive: outer/inner loop variables are (a, b) when a <= b initially, else (b, a)
-            const int outer = s.aleb ? s.a : s.b, outerEnd = s.aleb ? s.ahigh + 1 : s.bhigh;
-            const int inner = s.aleb ? s.b : s.a, innerEnd = s.aleb ? s.bhigh : s.ahigh + 1;
-            if (outer >= outerEnd) s = ss_exhaustive_done<MODE>(s);
-            else if (inner >= innerEnd)
-            {
-                const int o = outer + 1;
-                const int lo = s.aleb ? s.blow : s.alow;
-                const int i = o > lo ? o : lo;
-                const int na = s.aleb ? o : i, nb = s.aleb ? i : o;
-                s.a = na; s.b = nb;
-            }
-            else
-            {
-                s.candA = with_byte(s.optA, s.ch, uint32_t(s.a));
-                s.candB = with_byte(s.optB, s.ch, uint32_t(s.b));
-                found = true;
-            }
-        }
+        cur += beststep;
     }
-    has = found;
+    outErr = minErr; outVal = uint32_t(cur);
+}
+
+// OptimizeOne's bookkeeping between PerturbOne calls, quirks included (see optimize_channel above).
+// Returns the next state; `s.ch >= CH1` afterwards means the loop's channels are done.
+template<int MODE, int IM, int CHSET>
+DXTEX_HD PerturbState perturb_transition(const PerturbState& in, int e, uint32_t val)
+{
+    PerturbState s = in;
+    const bool sub0 = (in.sub == 0), sub1 = (in.sub == 1);
+    const bool takeA = sub1 ? (in.err0 < e) : (in.do_b == 0);
+    const int claimed = (sub1 && takeA) ? in.err0 : e;
+    const bool giveUp = !sub0 && (claimed >= in.optErr);
+    // sub 0: remember the A result, perturb B next. Otherwise adopt the claimed error; only endpoint A ever moves
+    s.err0 = sub0 ? e : in.err0;
+    s.newA = sub0 ? val : in.newA;
+    s.optA = (!sub0 && !giveUp && takeA) ? with_byte(in.optA, in.ch, in.newA) : in.optA;
+    s.optErr = (sub0 || giveUp) ? in.optErr : claimed;
+    s.sub = giveUp ? 0 : (sub0 ? 1 : 2);
+    s.do_b = giveUp ? 0 : (sub0 ? 1 : (sub1 ? (takeA ? 1 : 0) : (1 - in.do_b)));
+    s.ch = giveUp ? in.ch + 1 : in.ch;
     return s;
 }
 
-DXTEX_HD SearchState ss_consume(const SearchState& in, int e)
+// Exhaustive (:2971-3042), one candidate per step. (o, i) are the outer / inner loop variables: (a, b) when
+// the channel starts with a <= b, else (b, a). Note the reference's asymmetric bounds: a <= ahigh, b < bhigh.
+struct ExhState
 {
-    SearchState s = in;
-    const bool pert = (s.phase == 1);
-    // perturb: strict improvement over the running minimum (:2953)
-    const bool ltp = pert && (e < s.minErr);
-    s.improved = ltp ? true : s.improved;
-    s.beststep = ltp ? s.sign * s.step : s.beststep;
-    s.minErr = ltp ? e : s.minErr;
-    // exhaustive: strict improvement over the best of the window (:3006)
-    const bool lte = !pert && (e < s.best);
-    s.amin = lte ? s.a : s.amin;
-    s.bmin = lte ? s.b : s.bmin;
-    s.best = lte ? e : s.best;
-    const int incb = (!pert && s.aleb) ? 1 : 0, inca = (!pert && !s.aleb) ? 1 : 0;
-    s.b += incb; s.a += inca;
-    const SearchState adv = ss_perturb_advance(s);
-    return ss_select(pert, adv, s);
+    uint32_t optA, optB;
+    int optErr;
+    int ch;                 // >= CH1: finished
+    int o, i, oEnd, iEnd, lo;
+    int aleb;
+    int omin, imin, best;
+};
+
+template<int MODE, int IM, int CHSET>
+DXTEX_HD ExhState exh_window(const ExhState& in, int ch)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    ExhState s = in;
+    s.ch = (in.optErr == 0) ? int(C::CH1) : ch;          // Exhaustive returns at once when the error is already zero (:2980)
+    const int c = (s.ch >= C::CH1) ? int(C::CH0) : s.ch;
+    constexpr int delta = 5, hi = (1 << C::PREC) - 1;
+    const int ca = int(byte_of(in.optA, c)), cb = int(byte_of(in.optB, c));
+    const int alow = (ca - delta) > 0 ? (ca - delta) : 0, ahigh = (ca + delta) < hi ? (ca + delta) : hi;
+    const int blow = (cb - delta) > 0 ? (cb - delta) : 0, bhigh = (cb + delta) < hi ? (cb + delta) : hi;
+    s.aleb = ca <= cb;
+    s.o = s.aleb ? alow : blow;
+    s.oEnd = s.aleb ? ahigh + 1 : bhigh;
+    s.lo = s.aleb ? blow : alow;
+    s.iEnd = s.aleb ? bhigh : ahigh + 1;
+    s.i = s.o > s.lo ? s.o : s.lo;
+    s.omin = 0; s.imin = 0; s.best = in.optErr;
+    return s;
 }
 
-// optimize_one() expressed through the state machine (used by the host-side equivalence check).
+// Skip empty inner ranges; returns false when the window is used up.
+DXTEX_HD bool exh_settle(ExhState& s)
+{
+    while (s.o < s.oEnd && s.i >= s.iEnd) { ++s.o; s.i = s.o > s.lo ? s.o : s.lo; }
+    return s.o < s.oEnd;
+}
+
+DXTEX_HD ExhState exh_commit(const ExhState& in)
+{
+    ExhState s = in;
+    if (in.best < in.optErr)
+    {
+        const int a = in.aleb ? in.omin : in.imin, b = in.aleb ? in.imin : in.omin;
+        s.optA = with_byte(in.optA, in.ch, uint32_t(a));
+        s.optB = with_byte(in.optB, in.ch, uint32_t(b));
+        s.optErr = in.best;
+    }
+    return s;
+}
+
+// Advance to the next candidate, opening the following channels' windows as needed. `vp` is rebuilt whenever a
+// new window opens. Returns false when every channel of the loop has been searched.
+template<int MODE, int IM, int CHSET>
+DXTEX_HD bool exh_next(ExhState& s, VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    while (s.ch < C::CH1 && !exh_settle(s))
+    {
+        s = exh_commit(s);
+        s = exh_window<MODE, IM, CHSET>(s, s.ch + 1);
+        if (s.ch < C::CH1) varpal_init<MODE, IM, CHSET>(vp, s.optA, s.optB, s.ch);
+    }
+    return s.ch < C::CH1;
+}
+
+template<int MODE, int IM, int CHSET>
+DXTEX_HD bool exh_begin(ExhState& s, VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, uint32_t optA, uint32_t optB, int optErr)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    s.optA = optA; s.optB = optB; s.optErr = optErr;
+    s.ch = 0; s.o = s.i = s.oEnd = s.iEnd = s.lo = 0; s.aleb = 0; s.omin = s.imin = 0; s.best = optErr;
+    s = exh_window<MODE, IM, CHSET>(s, C::CH0);
+    if (s.ch < C::CH1) varpal_init<MODE, IM, CHSET>(vp, s.optA, s.optB, s.ch);
+    return exh_next<MODE, IM, CHSET>(s, vp);
+}
+
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD void exh_step(const RG& rg, ExhState& s, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, int base)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    const int a = s.aleb ? s.o : s.i, b = s.aleb ? s.i : s.o;
+    const int e = eval_var<MODE, IM, CHSET>(rg, vp, s.ch, unq1<C::PREC>(uint32_t(a)), unq1<C::PREC>(uint32_t(b)), base);
+    if (e < s.best) { s.omin = s.o; s.imin = s.i; s.best = e; }       // strict: the first minimum in loop order wins (:3006)
+    ++s.i;
+}
+
+// optimize_one() through the lockstep pieces, one lane's worth (host-side equivalence check, and the
+// definition of what the search kernels compute).
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD void lockstep_perturb_loop(const RG& rg, uint32_t& optA, uint32_t& optB, int& optErr)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    if (C::PREC == 0) return;
+    const int base = loop_base<MODE, IM, CHSET>(rg, optA, optB);
+    PerturbState s = perturb_begin<MODE, IM, CHSET>(optA, optB, optErr);
+    while (s.ch < C::CH1)
+    {
+        int e; uint32_t v;
+        perturb_macro<MODE, IM, CHSET>(rg, s, base, e, v);
+        s = perturb_transition<MODE, IM, CHSET>(s, e, v);
+    }
+    optA = s.optA; optB = s.optB; optErr = s.optErr;
+}
+
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& optB, int& optErr)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    if (C::PREC == 0) return;
+    const int base = loop_base<MODE, IM, CHSET>(rg, optA, optB);
+    ExhState s; VarPal<C::N> vp;
+    bool has = exh_begin<MODE, IM, CHSET>(s, vp, optA, optB, optErr);
+    while (has)
+    {
+        exh_step<MODE, IM, CHSET>(rg, s, vp, base);
+        has = exh_next<MODE, IM, CHSET>(s, vp);
+    }
+    optA = s.optA; optB = s.optB; optErr = s.optErr;
+}
+
 template<int MODE, int IM, class RG>
-DXTEX_HD void optimize_one_sm(const RG& rg, int orgErr, uint32_t orgA, uint32_t orgB, uint32_t& optA, uint32_t& optB)
+DXTEX_HD void optimize_one_lockstep(const RG& rg, int orgErr, uint32_t orgA, uint32_t orgB, uint32_t& optA, uint32_t& optB)
 {
-    SearchState s = ss_begin<MODE>(orgA, orgB, orgErr);
-    for (;;)
+    optA = orgA; optB = orgB;
+    int err = orgErr;
+    if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
-        bool has;
-        s = ss_next<MODE>(s, has);
-        if (!has) break;
-        s = ss_consume(s, map_colors<MODE, IM>(rg, s.candA, s.candB));
+        lockstep_perturb_loop<MODE, IM, CH_ALL>(rg, optA, optB, err);
+        lockstep_exhaustive_loop<MODE, IM, CH_ALL>(rg, optA, optB, err);
     }
-    optA = s.optA; optB = s.optB;
+    else
+    {
+        lockstep_perturb_loop<MODE, IM, CH_COLOR>(rg, optA, optB, err);
+        lockstep_perturb_loop<MODE, IM, CH_ALPHA>(rg, optA, optB, err);
+        lockstep_exhaustive_loop<MODE, IM, CH_COLOR>(rg, optA, optB, err);
+        lockstep_exhaustive_loop<MODE, IM, CH_ALPHA>(rg, optA, optB, err);
+    }
 }
 
 // Everything Refine does for one subset (:3399-3463) up to, but excluding, the org-vs-opt decision,
@@ -813,8 +961,8 @@ DXTEX_HD void refine_subset(const RG& rg, uint32_t seedA, uint32_t seedB, uint32
 {
     refine_pre<MODE, IM>(rg, seedA, seedB, anchorPos, out);
     uint32_t oa, ob;
-#if defined(DXTEX_BC7_USE_STATE_MACHINE)
-    optimize_one_sm<MODE, IM>(rg, out.orgErr, out.orgA, out.orgB, oa, ob);
+#if defined(DXTEX_BC7_USE_LOCKSTEP)
+    optimize_one_lockstep<MODE, IM>(rg, out.orgErr, out.orgA, out.orgB, oa, ob);
 #else
     optimize_one<MODE, IM>(rg, out.orgErr, out.orgA, out.orgB, oa, ob);
 #endif
@@ -1021,13 +1169,13 @@ DXTEX_HD int rough_error(const RG& rg, uint32_t epA, uint32_t epB)
 {
     constexpr int NC = 1 << CB, NA = AB ? (1 << AB) : 1;
     int total = rg.p2sum;
-    uint32_t pal[NC]; int q2[NC];
+    uint32_t pal[NC], nq2[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i)
     {
         pal[i] = lerp_bytes(epA, epB, weight(CB, i));
         if (AB != 0) pal[i] &= 0x00FFFFFFu;
-        q2[i] = int(udot4(pal[i], pal[i]));
+        nq2[i] = 0u - udot4(pal[i], pal[i]);
     }
     int pa[NA];
     if (AB != 0)
@@ -1040,17 +1188,17 @@ DXTEX_HD int rough_error(const RG& rg, uint32_t epA, uint32_t epB)
     {
         const uint32_t p = rg.fetch(k);
         const uint32_t pc = (AB != 0) ? (p & 0x00FFFFFFu) : p;
-        int t[NC];
+        int sc[NC];
 #pragma unroll
-        for (int i = 0; i < NC; ++i) t[i] = q2[i] - 2 * int(udot4(pc, pal[i]));
-        total += ascent_min(t);
+        for (int i = 0; i < NC; ++i) sc[i] = score(pc, pal[i], nq2[i]);
+        total -= first_peak(sc);
         if (AB != 0)
         {
             const int al = int(p >> 24);
-            int u[NA];
+            int su[NA];
 #pragma unroll
-            for (int i = 0; i < NA; ++i) u[i] = pa[i] * pa[i] - 2 * al * pa[i];
-            total += ascent_min(u);
+            for (int i = 0; i < NA; ++i) su[i] = 2 * al * pa[i] - pa[i] * pa[i];
+            total -= first_peak(su);
         }
     });
     return total;

@@ -3,18 +3,17 @@
 //
 // Decomposition (SIMT-friendly restatement of D3DX_BC7::Encode's mode x rotation x index-mode x shape loops):
 //   rough   : one wavefront per block, lane = partition shape. Each lane fits the float seed endpoints of
-//             its shape's two subsets once, scores them with the 3-bit and the 2-bit palettes (modes 1 / 3,7
+//             its shape's subsets once, scores them with the 3-bit and the 2-bit palettes (modes 1 / 3,7
 //             share the seed), then the wavefront reproduces the reference's partial selection sort
-//             (:2855-2865) with prefix-min scans and ballots and publishes the 16 best shapes per list.
-//   refine2 : modes 1, 3, 7 - lane = (block, rank, subset): 32 lanes per block, two blocks per wavefront.
-//             The two subset lanes of a candidate exchange totals with a lane shuffle; a butterfly
-//             min-reduction over the 16 candidates picks the mode's winner, whose lane packs the block.
-//   refine1 : modes 4, 5, 6 - lane = (block, rotation[, index mode]); texels live in registers.
+//             (:2855-2865) with prefix-min scans and ballots and publishes the best shapes per list. Also
+//             stores the block's 16 texels as packed RGBA8 for the search kernels.
+//   per mode (1, 3, 7, 4 x 2 index modes, 5, 6; 0 and 2 with BC7_USE_3SUBSETS): pre -> bin -> search -> post,
+//             described further down. The per-mode winners travel through a 24 B slot per mode per block.
 //   pick    : lane = block; minimum over the per-mode winners in the reference's evaluation order.
-// The per-mode winners travel through a small scratch buffer (24 B per mode per block).
 #include "dxtex_kernels.h"
 #include "bc67_tables.h"
 #include "bc7_core.h"
+#include <algorithm>
 
 namespace dxtex
 {
@@ -41,10 +40,16 @@ struct Bc7Args
     SrcView src;
     uint8_t* dst;
     uint64_t dstRowPitch;
-    uint32_t nbw, nbh, nblocks;
+    uint32_t nbw, nbh;
+    uint32_t nb0, nblocks;   // this pass covers image blocks [nb0, nb0 + nblocks); scratch arrays are indexed from 0
     uint32_t flags;
     uint8_t* lists;
     Cand* cands;
+    uint32_t* px;            // nblocks x 16 packed RGBA8 texels (D3DX_BC7::Encode's aLDRPixels, :2792-2799)
+    struct TaskRec* recs;    // per-mode task records (reused by every mode)
+    uint32_t* order;         // live tasks of the current mode, sorted by subset size
+    uint8_t* tnp;            // subset size per task (0 = no search needed)
+    uint32_t* counters;      // 35 words, see bc7_bin_* kernels
 };
 
 // One texel of block `nb` (texel t = y*4+x), with the reference's partial-block replication, as float4
@@ -109,8 +114,9 @@ __global__ void __launch_bounds__(256) bc7_rough_kernel(Bc7Args a)
     if (lane < 16)
     {
         uint32_t ldr;
-        load_block_texel(a.src, a.nbw, nb, lane, &sF[wave][lane * 4], ldr);
+        load_block_texel(a.src, a.nbw, a.nb0 + nb, lane, &sF[wave][lane * 4], ldr);
         sL[wave][lane] = ldr;
+        a.px[uint64_t(nb) * 16 + lane] = ldr;
     }
     wave_lds_sync();
     const float* fpx = sF[wave];
@@ -181,352 +187,436 @@ __global__ void __launch_bounds__(256) bc7_rough_kernel(Bc7Args a)
     }
 }
 
-// ---- per-mode search kernels ---------------------------------------------------------------------------------------
-// One wavefront owns a run of consecutive blocks and works through all their tasks of one mode in three phases:
-//   pre    (lane = task, fixed assignment, uniform cost): seed -> Quantize -> FixEndpointPBits -> AssignIndices;
-//          the "org" endpoints and error of every task go to an LDS task table.
-//   search (persistent lanes): OptimizeOne as a state machine (bc7_core.h). Every loop iteration scores ONE
-//          candidate endpoint pair per lane with a fully converged map_colors; a lane whose search ends stores
-//          its result and takes the next task from the wave's table, so lanes stay busy although searches differ
-//          in length by an order of magnitude. Tasks are handed out in order of decreasing subset size so that
-//          the lanes of a wave loop over similar texel counts.
-//   post   (lane = task, fixed assignment): FixEndpointPBits + AssignIndices of the optimised endpoints, org-vs-opt
-//          decision over the subsets of a candidate (lane shuffle), first-minimum over the block's candidates
-//          (butterfly), EmitBlock by the winning lane.
+// ---- per-mode search: pre -> bin/scatter -> search -> post -----------------------------------------------------------
+// A *task* is one subset of one candidate (mode, shape | rotation, index mode) of one block: the unit
+// OptimizeEndPoints (:3113-3136) hands to OptimizeOne. Tasks of one mode are numbered
+//     t = block * TPB + rank * G + subset         (G = lanes per candidate: 1, 2 or 4; rank = candidate number)
+//   pre     (lane = task, natural order): seed -> Quantize -> FixEndpointPBits -> AssignIndices; the "org" endpoints,
+//           their error and the subset size go to the task record. Tasks that need no search (error already 0,
+//           block outside the image, mode 7 on an opaque block) get size 0.
+//   bin     counting sort of the live tasks by subset size (17 bins, wave-aggregated atomics), so that a search
+//           wavefront only ever sees subsets of (almost) one size and its texel loops have one trip count.
+//   search  persistent lanes over a chunk of the sorted list; OptimizeOne cut into lockstep pieces (bc7_core.h):
+//           PERTURB macro-ops first, then the flattened Exhaustive windows; colour and alpha channels of the
+//           separate-alpha modes in separate loops. The subset's texels sit in a per-lane LDS column.
+//   post    (lane = task, natural order): FixEndpointPBits + AssignIndices of the optimised endpoints, org-vs-opt
+//           decision over the subsets of a candidate (lane shuffles), first minimum over the block's candidates
+//           (butterfly), EmitBlock by the winning lane -> per-mode candidate slot.
+struct TaskRec { uint32_t A, B; int err; uint32_t np; };     // 16 bytes
 
-template<int MODE>
-__global__ void __launch_bounds__(64) bc7_subset2_kernel(Bc7Args a)
+template<int MODE, int IM> struct TaskMap
 {
-    constexpr int NB = 16;              // blocks per wavefront
-    constexpr int T = NB * 32;          // tasks: 16 candidate shapes x 2 subsets per block
-    constexpr int ROUNDS = T / 64;
-    __shared__ float sF[NB * 64];
-    __shared__ uint32_t sL[NB * 16];
-    __shared__ uint32_t tA[T], tB[T];
-    __shared__ int tErr[T];
-    __shared__ uint16_t sOrder[T];
-    __shared__ uint8_t sNp[T];
-    __shared__ uint32_t sSlot[16 * 64];
-    __shared__ uint32_t sBins[20];
+    typedef ModeInfo<MODE> MI;
+    enum : int { NS = MI::NS,
+                 G = (NS == 1) ? 1 : (NS == 2) ? 2 : 4,
+                 RANKS = (NS == 1) ? ((MODE == 6) ? 1 : 4) : ((MODE == 0) ? 4 : 16),     // max(1, shapes >> 2) or rotations
+                 TPB = RANKS * G,
+                 LIST = (MODE == 1) ? 0 : (MODE == 0) ? 33 : (MODE == 2) ? 40 : 16,
+                 SLOT = (MODE == 0) ? SLOT_M0 : (MODE == 1) ? SLOT_M1 : (MODE == 2) ? SLOT_M2 : (MODE == 3) ? SLOT_M3 :
+                        (MODE == 4) ? (IM ? SLOT_M4B : SLOT_M4A) : (MODE == 5) ? SLOT_M5 : (MODE == 6) ? SLOT_M6 : SLOT_M7 };
+};
 
-    const int lane = threadIdx.x;
-    const uint32_t nb0 = blockIdx.x * NB;
-    const int slotIdx = (MODE == 1) ? SLOT_M1 : (MODE == 3) ? SLOT_M3 : SLOT_M7;
-    const int listOfs = (MODE == 1) ? 0 : 16;
-
-    for (int t = lane; t < NB * 16; t += 64)
+// Texel mask, anchor and rotation of task `r` (= t % TPB) of block `nb`; false if the task does not exist.
+template<int MODE, int IM>
+__device__ __forceinline__ bool task_geometry(const Bc7Args& a, uint32_t nb, uint32_t r, uint32_t& shape, uint32_t& mask, uint32_t& anchor, uint32_t& rot)
+{
+    typedef TaskMap<MODE, IM> TM;
+    shape = 0; mask = 0xFFFFu; anchor = 0; rot = 0;
+    if (nb >= a.nblocks) return false;
+    if (TM::NS == 1) { rot = (MODE == 6) ? 0u : r; return true; }
+    const uint32_t rank = r / TM::G, region = r % TM::G;
+    if (region >= uint32_t(TM::NS)) return false;
+    const uint8_t* lst = a.lists + uint64_t(nb) * LIST_BYTES;
+    if (MODE == 7 && lst[32] == 0) return false;
+    shape = lst[TM::LIST + rank];
+    if (TM::NS == 2)
     {
-        const uint32_t nb = nb0 + (uint32_t(t) >> 4);
-        uint32_t ldr = 0;
-        if (nb < a.nblocks) load_block_texel(a.src, a.nbw, nb, t & 15, &sF[(t >> 4) * 64 + (t & 15) * 4], ldr);
-        sL[t] = ldr;
-    }
-    if (lane < 20) sBins[lane] = 0;
-    wave_lds_sync();
-
-    // ---- pre ----
-    auto task_setup = [&](int t, uint32_t& nb, uint32_t& shape, uint32_t& mask, uint32_t& anchor) -> bool
-    {
-        const int blk = t >> 5, rank = (t >> 1) & 15, region = t & 1;
-        nb = nb0 + uint32_t(blk);
-        if (nb >= a.nblocks) return false;
-        const uint8_t* lst = a.lists + uint64_t(nb) * LIST_BYTES;
-        if (MODE == 7 && lst[32] == 0) return false;
-        shape = lst[listOfs + rank];
         const uint32_t m1 = kPart2Mask[shape];
         mask = region ? m1 : ((~m1) & 0xFFFFu);
         anchor = region ? uint32_t(kAnchor2[shape]) : 0u;
-        return true;
-    };
-    auto task_pre = [&](int t, uint32_t mask, uint32_t anchor, Region& rg, SubsetResult& res)
+    }
+    else
     {
-        const int blk = t >> 5;
-        const float* fpx = &sF[blk * 64];
-        const uint32_t* pix = &sL[blk * 16];
-        region_init(rg, pix, mask);
-        uint32_t A, B;
-        if (rg.np == 1) { A = pix[rg.pos(0)]; B = A; }
-        else if (rg.np == 2) { A = pix[rg.pos(0)]; B = pix[rg.pos(1)]; }
-        else seed_endpoints<true>(fpx, mask, A, B);
-        refine_pre<MODE, 0>(rg, A, B, anchor, res);
-    };
+        const uint32_t bits = kPart3Bits[shape];
+        mask = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (((bits >> (2 * i)) & 3u) == region) mask |= 1u << i;
+        anchor = (region == 0) ? 0u : (region == 1) ? uint32_t(kAnchor3[shape] & 15) : uint32_t(kAnchor3[shape] >> 4);
+    }
+    return true;
+}
 
-    for (int r = 0; r < ROUNDS; ++r)
+// Refine's first half for one task, from the block's float + 8-bit texels (LDS or registers).
+template<int MODE, int IM>
+__device__ __forceinline__ void task_org(const float* fpx, const uint32_t* pix, uint32_t mask, uint32_t anchor, uint32_t rot,
+                                         SubsetResult& res, int& np, bool wantRegion, Region& rgOut, Block16& b16Out)
+{
+    typedef TaskMap<MODE, IM> TM;
+    if (TM::NS == 1)
     {
-        const int t = r * 64 + lane;
-        uint32_t nb, shape = 0, mask = 0, anchor = 0;
-        const bool active = task_setup(t, nb, shape, mask, anchor);
-        int np = 0;
+        block16_init(b16Out, pix, rot);
+        uint32_t A, B;
+        if (MODE == 6) seed_endpoints<true>(fpx, 0xFFFFu, A, B);
+        else
+        {
+            // colour endpoints from the *unrotated* float texels, alpha endpoints = min/max of the rotated 8-bit alpha (:3552-3568)
+            seed_endpoints<false>(fpx, 0xFFFFu, A, B);
+            uint32_t mn = 255, mx = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const uint32_t al = b16Out.px[i] >> 24; mn = min(mn, al); mx = max(mx, al); }
+            A = (A & 0x00FFFFFFu) | (mn << 24);
+            B = (B & 0x00FFFFFFu) | (mx << 24);
+        }
+        refine_pre<MODE, IM>(b16Out, A, B, 0u, res);
+        np = 16;
+    }
+    else
+    {
+        region_init(rgOut, pix, mask);
+        uint32_t A, B;
+        if (rgOut.np == 1) { A = pix[rgOut.pos(0)]; B = A; }
+        else if (rgOut.np == 2) { A = pix[rgOut.pos(0)]; B = pix[rgOut.pos(1)]; }
+        else seed_endpoints<true>(fpx, mask, A, B);
+        refine_pre<MODE, IM>(rgOut, A, B, anchor, res);
+        np = rgOut.np;
+    }
+}
+
+// Stage the texels of the blocks this wavefront's tasks belong to: BPW blocks per wave.
+template<int BPW>
+__device__ __forceinline__ void stage_blocks(const Bc7Args& a, uint32_t nbFirst, int lane, float* sF, uint32_t* sL)
+{
+    for (int t = lane; t < BPW * 16; t += 64)
+    {
+        const uint32_t nb = nbFirst + (uint32_t(t) >> 4);
+        uint32_t ldr = 0;
+        if (nb < a.nblocks) load_block_texel(a.src, a.nbw, a.nb0 + nb, t & 15, &sF[(t >> 4) * 64 + (t & 15) * 4], ldr);
+        sL[t] = ldr;
+    }
+    wave_lds_sync();
+}
+
+template<int MODE, int IM>
+__global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
+{
+    typedef TaskMap<MODE, IM> TM;
+    constexpr int BPW = (TM::TPB >= 64) ? 1 : 64 / TM::TPB;       // blocks per wavefront
+    __shared__ float sF[4][BPW * 64];
+    __shared__ uint32_t sL[4][BPW * 16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t nbFirst = (blockIdx.x * 4 + wave) * BPW;
+    if (nbFirst >= a.nblocks) return;
+    stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
+
+    const uint32_t blk = uint32_t(lane) / TM::TPB, r = uint32_t(lane) % TM::TPB;
+    const uint32_t nb = nbFirst + blk;
+    uint32_t shape, mask, anchor, rot;
+    const bool active = (blk < uint32_t(BPW)) && task_geometry<MODE, IM>(a, nb, r, shape, mask, anchor, rot);
+    if (nb < a.nblocks && blk < uint32_t(BPW))
+    {
+        TaskRec rec; rec.A = 0; rec.B = 0; rec.err = 0; rec.np = 0;
         if (active)
         {
-            Region rg; SubsetResult res;
-            task_pre(t, mask, anchor, rg, res);
-            tA[t] = res.orgA; tB[t] = res.orgB; tErr[t] = res.orgErr;
-            np = rg.np;
-            atomicAdd(&sBins[16 - np], 1u);
+            SubsetResult res; int np; Region rg; Block16 b16;
+            task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16);
+            rec.A = res.orgA; rec.B = res.orgB; rec.err = res.orgErr;
+            rec.np = (res.orgErr != 0) ? uint32_t(np) : 0u;        // error 0: OptimizeOne cannot move the endpoints
         }
-        sNp[t] = uint8_t(np);
+        a.recs[uint64_t(nb) * TM::TPB + r] = rec;
+        a.tnp[uint64_t(nb) * TM::TPB + r] = uint8_t(rec.np);
     }
-    wave_lds_sync();
-    // exclusive prefix over the size bins (largest subsets first)
-    if (lane == 0)
-    {
-        uint32_t run = 0;
-        for (int i = 0; i <= 16; ++i) { const uint32_t c = sBins[i]; sBins[i] = run; run += c; }
-        sBins[17] = run;
-    }
-    wave_lds_sync();
-    for (int r = 0; r < ROUNDS; ++r)
-    {
-        const int t = r * 64 + lane;
-        const int np = sNp[t];
-        if (np > 0) sOrder[atomicAdd(&sBins[16 - np], 1u)] = uint16_t(t);
-    }
-    wave_lds_sync();
-    const int nTasks = int(sBins[17]);
+}
 
-    // ---- search ----
+// counters: [1..16] histogram by subset size, [18..33] scatter cursors, [34] number of live tasks.
+// Both passes run kBinGroups workgroups over contiguous slices of the task list, histogram in LDS, and touch
+// the 16 global counters once per workgroup.
+constexpr int kBinGroups = 2048;
+
+__global__ void __launch_bounds__(256) bc7_bin_count_kernel(const uint8_t* tnp, uint32_t ntasks, uint32_t* counters)
+{
+    __shared__ uint32_t hist[17];
+    if (threadIdx.x < 17) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t per = (ntasks + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = min(ntasks, t0 + per);
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256)
     {
-        SearchState st; st.phase = 0;
-        SlotRegion rg; rg.base = &sSlot[lane]; rg.np = 0; rg.p2sum = 0;
-        int myTask = -1;
-        int nextIdx = 0;
-        for (;;)
+        const uint32_t np = tnp[t];
+        if (np) atomicAdd(&hist[np], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x <= 16 && hist[threadIdx.x]) atomicAdd(&counters[threadIdx.x], hist[threadIdx.x]);
+}
+
+__global__ void bc7_bin_scan_kernel(uint32_t* counters)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t run = 0;
+    for (int b = 16; b >= 1; --b) { counters[17 + b] = run; run += counters[b]; }    // largest subsets first
+    counters[34] = run;
+}
+
+__global__ void __launch_bounds__(256) bc7_bin_scatter_kernel(const uint8_t* tnp, uint32_t ntasks, uint32_t* counters, uint32_t* order)
+{
+    __shared__ uint32_t hist[17], cursor[17];
+    if (threadIdx.x < 17) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t per = (ntasks + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = min(ntasks, t0 + per);
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256)
+    {
+        const uint32_t np = tnp[t];
+        if (np) atomicAdd(&hist[np], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x <= 16)
+        cursor[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&counters[17 + threadIdx.x], hist[threadIdx.x]) : 0u;
+    __syncthreads();
+    for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256)
+    {
+        const uint32_t np = tnp[t];
+        if (np) order[atomicAdd(&cursor[np], 1u)] = t;
+    }
+}
+
+constexpr int kSearchChunk = 512;       // tasks per search wavefront
+
+// A search lane picks up a task: copies the subset's texels (rotated for modes 4, 5) to its LDS column.
+template<int MODE, int IM>
+__device__ __forceinline__ void search_pickup(const Bc7Args& a, uint32_t t, uint32_t* slotCol, SlotRegion& rg)
+{
+    typedef TaskMap<MODE, IM> TM;
+    const uint32_t nb = t / TM::TPB, r = t % TM::TPB;
+    uint32_t shape, mask, anchor, rot;
+    task_geometry<MODE, IM>(a, nb, r, shape, mask, anchor, rot);
+    const uint32_t* px = a.px + uint64_t(nb) * 16;
+    int np = 0;
+    if (TM::NS == 1)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) slotCol[i * 64] = rotate_pixel(px[i], rot);
+        np = 16;
+    }
+    else
+    {
+        for (uint32_t i = 0; i < 16; ++i)
+            if ((mask >> i) & 1u) { slotCol[np * 64] = px[i]; ++np; }
+    }
+    rg.base = slotCol; rg.np = np; rg.p2sum = 0;
+}
+
+template<int MODE, int IM, int CHSET>
+__device__ __forceinline__ void search_perturb_loop(const Bc7Args& a, const uint32_t* order, int nTasks, int lane,
+                                                    uint32_t* tA, uint32_t* tB, int* tErr, uint32_t* slotCol)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    if (C::PREC == 0) return;
+    PerturbState st = perturb_begin<MODE, IM, CHSET>(0, 0, 0);
+    SlotRegion rg; rg.base = slotCol; rg.np = 0; rg.p2sum = 0;
+    int base = 0, myTask = -1, nextIdx = 0;
+    for (;;)
+    {
+        const unsigned long long idle = __ballot(myTask < 0);
+        if (idle && nextIdx < nTasks)
         {
-            if (myTask >= 0 && st.phase == 0)
+            const int k = __popcll(idle & ((1ull << lane) - 1ull));
+            if (myTask < 0 && nextIdx + k < nTasks)
             {
-                tA[myTask] = st.optA; tB[myTask] = st.optB;
+                myTask = nextIdx + k;
+                search_pickup<MODE, IM>(a, order[myTask], slotCol, rg);
+                st = perturb_begin<MODE, IM, CHSET>(tA[myTask], tB[myTask], tErr[myTask]);
+                base = loop_base<MODE, IM, CHSET>(rg, st.optA, st.optB);
+            }
+            nextIdx += __popcll(idle);
+        }
+        if (__ballot(myTask >= 0) == 0ull) break;
+        if (myTask >= 0)
+        {
+            int e; uint32_t v;
+            perturb_macro<MODE, IM, CHSET>(rg, st, base, e, v);
+            st = perturb_transition<MODE, IM, CHSET>(st, e, v);
+            if (st.ch >= C::CH1)
+            {
+                tA[myTask] = st.optA; tB[myTask] = st.optB; tErr[myTask] = st.optErr;
                 myTask = -1;
             }
-            const unsigned long long idle = __ballot(myTask < 0);
-            if (idle && nextIdx < nTasks)
+        }
+    }
+    wave_lds_sync();
+}
+
+template<int MODE, int IM, int CHSET>
+__device__ __forceinline__ void search_exhaustive_loop(const Bc7Args& a, const uint32_t* order, int nTasks, int lane,
+                                                       uint32_t* tA, uint32_t* tB, int* tErr, uint32_t* slotCol)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    if (C::PREC == 0) return;
+    constexpr int kRefillMin = 8;       // let a few finished lanes wait so that pickups happen in batches
+    ExhState st; st.ch = C::CH1; st.optA = st.optB = 0; st.optErr = 0;
+    st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = 0;
+    VarPal<C::N> vp;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) { vp.palO[i] = 0; vp.nq2O[i] = 0; }
+    SlotRegion rg; rg.base = slotCol; rg.np = 0; rg.p2sum = 0;
+    int base = 0, myTask = -1, nextIdx = 0;
+    for (;;)
+    {
+        const unsigned long long idle = __ballot(myTask < 0);
+        const int nIdle = __popcll(idle);
+        if (nextIdx < nTasks && (nIdle >= kRefillMin || (nIdle && nextIdx + nIdle >= nTasks) || nIdle == 64))
+        {
+            const int k = __popcll(idle & ((1ull << lane) - 1ull));
+            if (myTask < 0 && nextIdx + k < nTasks)
             {
-                const int k = __popcll(idle & ((1ull << lane) - 1ull));
-                if (myTask < 0 && nextIdx + k < nTasks)
-                {
-                    myTask = sOrder[nextIdx + k];
-                    const int blk = myTask >> 5, rank = (myTask >> 1) & 15, region = myTask & 1;
-                    const uint8_t* lst = a.lists + uint64_t(nb0 + blk) * LIST_BYTES;
-                    const uint32_t shape = lst[listOfs + rank];
-                    const uint32_t m1 = kPart2Mask[shape];
-                    const uint32_t mask = region ? m1 : ((~m1) & 0xFFFFu);
-                    const uint32_t* pix = &sL[blk * 16];
-                    int np = 0, p2 = 0;
-                    for (uint32_t i = 0; i < 16; ++i)
-                        if ((mask >> i) & 1u)
-                        {
-                            const uint32_t p = pix[i];
-                            sSlot[np * 64 + lane] = p;
-                            p2 += int(udot4(p, p));
-                            ++np;
-                        }
-                    rg.np = np; rg.p2sum = p2;
-                    st = ss_begin<MODE>(tA[myTask], tB[myTask], tErr[myTask]);
-                }
-                nextIdx += __popcll(idle);
+                myTask = nextIdx + k;
+                search_pickup<MODE, IM>(a, order[myTask], slotCol, rg);
+                const uint32_t oa = tA[myTask], ob = tB[myTask];
+                base = loop_base<MODE, IM, CHSET>(rg, oa, ob);
+                if (!exh_begin<MODE, IM, CHSET>(st, vp, oa, ob, tErr[myTask])) myTask = -1;    // nothing to search: endpoints stay
             }
-            if (__ballot(myTask >= 0) == 0ull) break;
-            bool has = false;
-            if (myTask >= 0) st = ss_next<MODE>(st, has);
-            if (has)
+            nextIdx += nIdle;
+        }
+        if (__ballot(myTask >= 0) == 0ull)
+        {
+            if (nextIdx >= nTasks) break;
+            continue;
+        }
+        if (myTask >= 0)
+        {
+            exh_step<MODE, IM, CHSET>(rg, st, vp, base);
+            if (!exh_next<MODE, IM, CHSET>(st, vp))
             {
-                const int e = map_colors<MODE, 0>(rg, st.candA, st.candB);
-                st = ss_consume(st, e);
+                tA[myTask] = st.optA; tB[myTask] = st.optB; tErr[myTask] = st.optErr;
+                myTask = -1;
             }
         }
     }
     wave_lds_sync();
+}
 
-    // ---- post ----
-    for (int r = 0; r < ROUNDS; ++r)
+template<int MODE, int IM>
+__global__ void __launch_bounds__(64) bc7_search_kernel(Bc7Args a)
+{
+    __shared__ uint32_t tA[kSearchChunk], tB[kSearchChunk];
+    __shared__ int tErr[kSearchChunk];
+    __shared__ uint32_t sSlot[16 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t live = a.counters[34];
+    const uint32_t first = blockIdx.x * uint32_t(kSearchChunk);
+    if (first >= live) return;
+    const int nTasks = int(min(uint32_t(kSearchChunk), live - first));
+    const uint32_t* order = a.order + first;
+    for (int i = lane; i < nTasks; i += 64)
     {
-        const int t = r * 64 + lane;
-        const int rank = (t >> 1) & 15, region = t & 1;
-        uint32_t nb, shape = 0, mask = 0, anchor = 0;
-        const bool active = task_setup(t, nb, shape, mask, anchor);
-        SubsetResult res;
-        res.orgErr = 0; res.optErr = 0; res.orgA = res.orgB = res.optA = res.optB = 0;
-        res.orgIdx1 = res.orgIdx2 = res.optIdx1 = res.optIdx2 = 0;
-        if (active)
-        {
-            Region rg;
-            task_pre(t, mask, anchor, rg, res);
-            refine_post<MODE, 0>(rg, tA[t], tB[t], anchor, res);
-        }
-        const int orgTot = res.orgErr + __shfl_xor(res.orgErr, 1);
-        const int optTot = res.optErr + __shfl_xor(res.optErr, 1);
-        const bool useOpt = optTot < orgTot;
-        const int err = useOpt ? optTot : orgTot;
-        const uint32_t myA = useOpt ? res.optA : res.orgA, myB = useOpt ? res.optB : res.orgB;
-        const uint64_t myIdx = useOpt ? res.optIdx1 : res.orgIdx1;
-        const uint32_t otherA = uint32_t(__shfl_xor(int(myA), 1)), otherB = uint32_t(__shfl_xor(int(myB), 1));
-        const uint64_t otherIdx = uint64_t(uint32_t(__shfl_xor(int(uint32_t(myIdx)), 1))) |
-                                  (uint64_t(uint32_t(__shfl_xor(int(uint32_t(myIdx >> 32)), 1))) << 32);
-        const uint32_t key = (uint32_t(err) << 4) | uint32_t(rank);
-        uint32_t best = key;
-#pragma unroll
-        for (int d = 2; d < 32; d <<= 1) best = min(best, uint32_t(__shfl_xor(int(best), d)));
+        const TaskRec r = a.recs[order[i]];
+        tA[i] = r.A; tB[i] = r.B; tErr[i] = r.err;
+    }
+    wave_lds_sync();
+    uint32_t* slotCol = &sSlot[lane];
+    if constexpr (PaletteBits<MODE, IM>::AB == 0)
+    {
+        search_perturb_loop<MODE, IM, CH_ALL>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
+        search_exhaustive_loop<MODE, IM, CH_ALL>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
+    }
+    else
+    {
+        search_perturb_loop<MODE, IM, CH_COLOR>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
+        search_perturb_loop<MODE, IM, CH_ALPHA>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
+        search_exhaustive_loop<MODE, IM, CH_COLOR>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
+        search_exhaustive_loop<MODE, IM, CH_ALPHA>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
+    }
+    for (int i = lane; i < nTasks; i += 64)
+    {
+        TaskRec* r = a.recs + order[i];
+        r->A = tA[i]; r->B = tB[i];
+    }
+}
 
-        if (active && region == 0 && key == best)
+template<int MODE, int IM>
+__global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
+{
+    typedef TaskMap<MODE, IM> TM;
+    constexpr int BPW = (TM::TPB >= 64) ? 1 : 64 / TM::TPB;
+    __shared__ float sF[4][BPW * 64];
+    __shared__ uint32_t sL[4][BPW * 16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t nbFirst = (blockIdx.x * 4 + wave) * BPW;
+    if (nbFirst >= a.nblocks) return;
+    stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
+
+    const uint32_t blk = uint32_t(lane) / TM::TPB, r = uint32_t(lane) % TM::TPB;
+    const uint32_t nb = nbFirst + blk;
+    const uint32_t rank = r / TM::G, region = r % TM::G;
+    uint32_t shape, mask, anchor, rot;
+    const bool active = (blk < uint32_t(BPW)) && task_geometry<MODE, IM>(a, nb, r, shape, mask, anchor, rot);
+
+    SubsetResult res;
+    res.orgErr = 0; res.optErr = 0; res.orgA = res.orgB = res.optA = res.optB = 0;
+    res.orgIdx1 = res.orgIdx2 = res.optIdx1 = res.optIdx2 = 0;
+    if (active)
+    {
+        int np; Region rg; Block16 b16;
+        task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16);
+        const TaskRec rec = a.recs[uint64_t(nb) * TM::TPB + r];
+        if (TM::NS == 1) refine_post<MODE, IM>(b16, rec.A, rec.B, 0u, res);
+        else refine_post<MODE, IM>(rg, rec.A, rec.B, anchor, res);
+    }
+    // totals over the subsets of the candidate (lanes of one candidate are adjacent)
+    int orgTot = res.orgErr, optTot = res.optErr;
+#pragma unroll
+    for (int d = 1; d < TM::G; d <<= 1) { orgTot += __shfl_xor(orgTot, d); optTot += __shfl_xor(optTot, d); }
+    const bool useOpt = optTot < orgTot;
+    const int err = useOpt ? optTot : orgTot;
+    const uint32_t myA = useOpt ? res.optA : res.orgA, myB = useOpt ? res.optB : res.orgB;
+    const uint64_t myIdx1 = useOpt ? res.optIdx1 : res.orgIdx1, myIdx2 = useOpt ? res.optIdx2 : res.orgIdx2;
+    // gather the candidate's endpoints and indices into its subset-0 lane
+    uint32_t epA[3] = { myA, 0, 0 }, epB[3] = { myB, 0, 0 };
+    uint64_t idx1 = myIdx1;
+#pragma unroll
+    for (int s = 1; s < TM::NS; ++s)
+    {
+        epA[s] = uint32_t(__shfl_down(int(myA), s));
+        epB[s] = uint32_t(__shfl_down(int(myB), s));
+        const uint64_t oi = uint64_t(uint32_t(__shfl_down(int(uint32_t(myIdx1)), s))) |
+                            (uint64_t(uint32_t(__shfl_down(int(uint32_t(myIdx1 >> 32)), s))) << 32);
+        idx1 |= oi;
+    }
+    // evaluation order inside D3DX_BC7::Encode: modes ascending, then rotation, index mode, shape rank
+    const uint32_t sub = (TM::NS == 1) ? ((MODE == 4) ? (rank * 2 + IM) * 16u : rank * 16u) : rank;
+    const uint32_t key = active ? ((uint32_t(err) << 7) | sub) : 0xFFFFFFFFu;
+    uint32_t best = key;
+#pragma unroll
+    for (int d = 1; d < TM::TPB && d < 64; d <<= 1) best = min(best, uint32_t(__shfl_xor(int(best), d)));
+
+    if (blk < uint32_t(BPW) && nb < a.nblocks && region == 0)
+    {
+        if (active && key == best)
         {
-            const uint32_t epA[3] = { myA, otherA, 0 }, epB[3] = { myB, otherB, 0 };
-            const uint32_t anchors[3] = { 0, kAnchor2[shape], 0 };
+            uint32_t anchors[3] = { 0, 0, 0 };
+            if (TM::NS == 2) anchors[1] = kAnchor2[shape];
+            if (TM::NS == 3) { anchors[1] = kAnchor3[shape] & 15; anchors[2] = kAnchor3[shape] >> 4; }
             Cand c;
             c.err = uint32_t(err);
-            c.ord = uint32_t(MODE) * 128u + uint32_t(rank);
-            emit_block<MODE>(shape, 0, 0, epA, epB, myIdx | otherIdx, 0, anchors, c.lo, c.hi);
-            a.cands[uint64_t(nb) * NUM_SLOTS + slotIdx] = c;
+            c.ord = uint32_t(MODE) * 128u + sub;
+            emit_block<MODE>(shape, rot, IM, epA, epB, idx1, myIdx2, anchors, c.lo, c.hi);
+            a.cands[uint64_t(nb) * NUM_SLOTS + TM::SLOT] = c;
         }
-        else if (!active && region == 0 && rank == 0 && (nb0 + uint32_t(t >> 5)) < a.nblocks)
+        else if (!active && rank == 0)
         {
             Cand c; c.err = 0xFFFFFFFFu; c.ord = 0xFFFFFFFFu; c.lo = 0; c.hi = 0;
-            a.cands[uint64_t(nb0 + uint32_t(t >> 5)) * NUM_SLOTS + slotIdx] = c;
+            a.cands[uint64_t(nb) * NUM_SLOTS + TM::SLOT] = c;
         }
     }
 }
 
-// Modes 4, 5, 6: one subset, the block's texels live in registers. TB candidates per block in one launch
-// (mode 4 runs once per index mode so a wavefront never mixes palette shapes).
-template<int MODE, int IM>
-__global__ void __launch_bounds__(64) bc7_subset1_kernel(Bc7Args a)
+// BC7_QUICK skips the rough pass; the search kernels still need the packed texels.
+__global__ void __launch_bounds__(256) bc7_texels_kernel(Bc7Args a)
 {
-    constexpr int TB = (MODE == 6) ? 1 : 4;
-    constexpr int T = 512;              // tasks per wavefront
-    constexpr int NB = T / TB;
-    constexpr int ROUNDS = T / 64;
-    __shared__ uint32_t tA[T], tB[T];
-    __shared__ int tErr[T];
-
-    const int lane = threadIdx.x;
-    const uint32_t nb0 = blockIdx.x * NB;
-    const int slotIdx = (MODE == 6) ? SLOT_M6 : (MODE == 5) ? SLOT_M5 : (IM ? SLOT_M4B : SLOT_M4A);
-
-    auto load_regs = [&](uint32_t nb, float (&f)[64], uint32_t (&px)[16])
-    {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) load_block_texel(a.src, a.nbw, nb, i, &f[i * 4], px[i]);
-    };
-    auto task_pre = [&](uint32_t nb, uint32_t rot, Block16& rg, SubsetResult& res)
-    {
-        float f[64]; uint32_t px[16];
-        load_regs(nb, f, px);
-        block16_init(rg, px, (MODE == 6) ? 0u : rot);
-        uint32_t A, B;
-        if (MODE == 6)
-            seed_endpoints<true, true>(f, 0xFFFFu, A, B);
-        else
-        {
-            // colour endpoints from the *unrotated* float texels, alpha endpoints = min/max of the rotated
-            // 8-bit alpha (:3552-3568)
-            seed_endpoints<false, true>(f, 0xFFFFu, A, B);
-            uint32_t mn = 255, mx = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { const uint32_t al = rg.px[i] >> 24; mn = min(mn, al); mx = max(mx, al); }
-            A = (A & 0x00FFFFFFu) | (mn << 24);
-            B = (B & 0x00FFFFFFu) | (mx << 24);
-        }
-        refine_pre<MODE, IM>(rg, A, B, 0u, res);
-    };
-
-    // ---- pre ----
-    for (int r = 0; r < ROUNDS; ++r)
-    {
-        const int t = r * 64 + lane;
-        const uint32_t nb = nb0 + uint32_t(t) / TB, rot = uint32_t(t) % TB;
-        if (nb < a.nblocks)
-        {
-            Block16 rg; SubsetResult res;
-            task_pre(nb, rot, rg, res);
-            tA[t] = res.orgA; tB[t] = res.orgB; tErr[t] = res.orgErr;
-        }
-    }
-    wave_lds_sync();
-    const int nTasks = int(min(uint32_t(T), (a.nblocks > nb0 ? (a.nblocks - nb0) : 0u) * TB));
-
-    // ---- search ----
-    {
-        SearchState st; st.phase = 0;
-        Block16 rg;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) rg.px[i] = 0;
-        rg.p2sum = 0;
-        int myTask = -1;
-        int nextIdx = 0;
-        for (;;)
-        {
-            if (myTask >= 0 && st.phase == 0)
-            {
-                tA[myTask] = st.optA; tB[myTask] = st.optB;
-                myTask = -1;
-            }
-            const unsigned long long idle = __ballot(myTask < 0);
-            if (idle && nextIdx < nTasks)
-            {
-                const int k = __popcll(idle & ((1ull << lane) - 1ull));
-                if (myTask < 0 && nextIdx + k < nTasks)
-                {
-                    myTask = nextIdx + k;
-                    const uint32_t nb = nb0 + uint32_t(myTask) / TB, rot = uint32_t(myTask) % TB;
-                    int p2 = 0;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                    {
-                        float f4[4]; uint32_t ldr;
-                        load_block_texel(a.src, a.nbw, nb, i, f4, ldr);
-                        ldr = rotate_pixel(ldr, (MODE == 6) ? 0u : rot);
-                        rg.px[i] = ldr;
-                        p2 += int(udot4(ldr, ldr));
-                    }
-                    rg.p2sum = p2;
-                    st = ss_begin<MODE>(tA[myTask], tB[myTask], tErr[myTask]);
-                }
-                nextIdx += __popcll(idle);
-            }
-            if (__ballot(myTask >= 0) == 0ull) break;
-            bool has = false;
-            if (myTask >= 0) st = ss_next<MODE>(st, has);
-            if (has)
-            {
-                const int e = map_colors<MODE, IM>(rg, st.candA, st.candB);
-                st = ss_consume(st, e);
-            }
-        }
-    }
-    wave_lds_sync();
-
-    // ---- post ----
-    for (int r = 0; r < ROUNDS; ++r)
-    {
-        const int t = r * 64 + lane;
-        const uint32_t nb = nb0 + uint32_t(t) / TB, rot = uint32_t(t) % TB;
-        const bool valid = nb < a.nblocks;
-        SubsetResult res;
-        res.orgErr = 0; res.optErr = 0; res.orgA = res.orgB = res.optA = res.optB = 0;
-        res.orgIdx1 = res.orgIdx2 = res.optIdx1 = res.optIdx2 = 0;
-        if (valid)
-        {
-            Block16 rg;
-            task_pre(nb, rot, rg, res);
-            refine_post<MODE, IM>(rg, tA[t], tB[t], 0u, res);
-        }
-        const bool useOpt = res.optErr < res.orgErr;
-        const int err = useOpt ? res.optErr : res.orgErr;
-        const uint32_t sub = (MODE == 4) ? (rot * 2 + IM) : rot;
-        const uint32_t key = (uint32_t(err) << 4) | sub;
-        uint32_t best = key;
-#pragma unroll
-        for (int d = 1; d < TB; d <<= 1) best = min(best, uint32_t(__shfl_xor(int(best), d)));
-        if (valid && key == best)
-        {
-            const uint32_t epA[3] = { useOpt ? res.optA : res.orgA, 0, 0 }, epB[3] = { useOpt ? res.optB : res.orgB, 0, 0 };
-            const uint32_t anchors[3] = { 0, 0, 0 };
-            Cand c;
-            c.err = uint32_t(err);
-            c.ord = uint32_t(MODE) * 128u + sub * 16u;
-            emit_block<MODE>(0, rot, IM, epA, epB, useOpt ? res.optIdx1 : res.orgIdx1, useOpt ? res.optIdx2 : res.orgIdx2, anchors, c.lo, c.hi);
-            a.cands[uint64_t(nb) * NUM_SLOTS + slotIdx] = c;
-        }
-    }
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.nblocks * 16u) return;
+    float f4[4]; uint32_t ldr;
+    load_block_texel(a.src, a.nbw, a.nb0 + (i >> 4), i & 15u, f4, ldr);
+    a.px[i] = ldr;
 }
 
 // ---- pick: first minimum over the per-mode winners, in D3DX_BC7::Encode's order -----------------------------------
@@ -546,57 +636,133 @@ __global__ void __launch_bounds__(256) bc7_pick_kernel(Bc7Args a, uint32_t slotM
         const uint64_t key = (uint64_t(v.err) << 32) | v.ord;
         if (key < bestKey) { bestKey = key; lo = v.lo; hi = v.hi; }
     }
-    const uint32_t by = nb / a.nbw, bx = nb - by * a.nbw;
+    const uint32_t gb = a.nb0 + nb;
+    const uint32_t by = gb / a.nbw, bx = gb - by * a.nbw;
     uint64_t* out = reinterpret_cast<uint64_t*>(a.dst + uint64_t(by) * a.dstRowPitch) + 2 * uint64_t(bx);
     out[0] = lo; out[1] = hi;
 }
 } // namespace
 
-size_t bc7_scratch_bytes(uint64_t nblocks)
+// Scratch layout for a pass over `nb` blocks (every array 256-byte aligned).
+namespace
 {
-    return size_t(nblocks) * (LIST_BYTES + NUM_SLOTS * sizeof(Cand));
+constexpr uint64_t kMaxBlocksPerPass = 1u << 20;      // bounds the scratch (about 1.1 KiB per block)
+constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
+struct ScratchLayout
+{
+    size_t lists, cands, px, recs, order, tnp, counters, total;
+    explicit ScratchLayout(uint64_t nb, bool threeSubsets)
+    {
+        auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+        const size_t tpb = threeSubsets ? kMaxTasksPerBlock : 32;
+        size_t o = 0;
+        lists = o; o = up(o + nb * LIST_BYTES);
+        cands = o; o = up(o + nb * NUM_SLOTS * sizeof(Cand));
+        px = o; o = up(o + nb * 64);
+        recs = o; o = up(o + nb * tpb * sizeof(TaskRec));
+        order = o; o = up(o + nb * tpb * sizeof(uint32_t));
+        tnp = o; o = up(o + nb * tpb);
+        counters = o; o = up(o + 64 * sizeof(uint32_t));
+        total = o;
+    }
+};
+
+template<int MODE, int IM>
+void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const char* const (&names)[4])
+{
+    typedef TaskMap<MODE, IM> TM;
+    constexpr int BPW = (TM::TPB >= 64) ? 1 : 64 / TM::TPB;
+    const uint32_t nb = a.nblocks;
+    const uint32_t ntasks = nb * uint32_t(TM::TPB);
+    const uint32_t gridPP = (nb + 4 * BPW - 1) / (4 * BPW);
+    if (marks) marks->mark(names[0]);
+    hipLaunchKernelGGL((bc7_pre_kernel<MODE, IM>), dim3(gridPP), dim3(256), 0, stream, a);
+    if (marks) marks->mark(names[1]);
+    (void)hipMemsetAsync(a.counters, 0, 35 * sizeof(uint32_t), stream);
+    const uint32_t binGroups = std::min<uint32_t>(kBinGroups, (ntasks + 255) / 256);
+    hipLaunchKernelGGL(bc7_bin_count_kernel, dim3(binGroups), dim3(256), 0, stream, a.tnp, ntasks, a.counters);
+    hipLaunchKernelGGL(bc7_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a.counters);
+    hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tnp, ntasks, a.counters, a.order);
+    if (marks) marks->mark(names[2]);
+    hipLaunchKernelGGL((bc7_search_kernel<MODE, IM>), dim3((ntasks + kSearchChunk - 1) / kSearchChunk), dim3(64), 0, stream, a);
+    if (marks) marks->mark(names[3]);
+    hipLaunchKernelGGL((bc7_post_kernel<MODE, IM>), dim3(gridPP), dim3(256), 0, stream, a);
+}
+} // namespace
+
+size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags)
+{
+    return ScratchLayout(nblocks < kMaxBlocksPerPass ? nblocks : kMaxBlocksPerPass, (flags & BCF_USE_3SUBSETS) != 0).total;
 }
 
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
                              void* scratch, hipStream_t stream, KernelMarks* marks)
 {
 #define DXTEX_MARK(NAME) do { if (marks) marks->mark(NAME); } while (0)
-    Bc7Args a;
-    a.src = src; a.dst = dst; a.dstRowPitch = dstRowPitch;
-    a.nbw = (src.width + 3) / 4; a.nbh = (src.height + 3) / 4;
-    a.nblocks = a.nbw * a.nbh;
-    a.flags = flags;
-    a.lists = static_cast<uint8_t*>(scratch);
-    a.cands = reinterpret_cast<Cand*>(static_cast<uint8_t*>(scratch) + size_t(a.nblocks) * LIST_BYTES);
-    if (!a.nblocks) return hipSuccess;
-    const uint32_t nb = a.nblocks;
+#define DXTEX_MODE(MODE, IM, TAG) do { static const char* const n_[4] = { "bc7_pre_" TAG, "bc7_bin_" TAG, "bc7_search_" TAG, "bc7_post_" TAG }; \
+                                       launch_mode<MODE, IM>(a, stream, marks, n_); } while (0)
+    const uint32_t nbw = (src.width + 3) / 4, nbh = (src.height + 3) / 4;
+    const uint64_t total = uint64_t(nbw) * nbh;
+    if (!total) return hipSuccess;
     const bool quick = (flags & BCF_BC7_QUICK) != 0;
-    uint32_t slotMask = 0;
+    const bool three = (flags & BCF_USE_3SUBSETS) != 0;
+    uint8_t* base = static_cast<uint8_t*>(scratch);
 
-    if (!quick)
+    for (uint64_t first = 0; first < total; first += kMaxBlocksPerPass)
     {
-        DXTEX_MARK("bc7_rough");
-        hipLaunchKernelGGL(bc7_rough_kernel, dim3((nb + 3) / 4), dim3(256), 0, stream, a);
-        DXTEX_MARK("bc7_subset2_mode1");
-        hipLaunchKernelGGL(bc7_subset2_kernel<1>, dim3((nb + 15) / 16), dim3(64), 0, stream, a);
-        DXTEX_MARK("bc7_subset2_mode3");
-        hipLaunchKernelGGL(bc7_subset2_kernel<3>, dim3((nb + 15) / 16), dim3(64), 0, stream, a);
-        DXTEX_MARK("bc7_subset2_mode7");
-        hipLaunchKernelGGL(bc7_subset2_kernel<7>, dim3((nb + 15) / 16), dim3(64), 0, stream, a);
-        DXTEX_MARK("bc7_subset1_mode4_im0");
-        hipLaunchKernelGGL((bc7_subset1_kernel<4, 0>), dim3((nb + 127) / 128), dim3(64), 0, stream, a);
-        DXTEX_MARK("bc7_subset1_mode4_im1");
-        hipLaunchKernelGGL((bc7_subset1_kernel<4, 1>), dim3((nb + 127) / 128), dim3(64), 0, stream, a);
-        DXTEX_MARK("bc7_subset1_mode5");
-        hipLaunchKernelGGL((bc7_subset1_kernel<5, 0>), dim3((nb + 127) / 128), dim3(64), 0, stream, a);
-        slotMask |= (1u << SLOT_M1) | (1u << SLOT_M3) | (1u << SLOT_M7) | (1u << SLOT_M4A) | (1u << SLOT_M4B) | (1u << SLOT_M5);
+        const uint64_t nb = (total - first) < kMaxBlocksPerPass ? (total - first) : kMaxBlocksPerPass;
+        const ScratchLayout L(nb, three);
+        Bc7Args a;
+        a.src = src; a.dst = dst; a.dstRowPitch = dstRowPitch;
+        a.nbw = nbw; a.nbh = nbh; a.nb0 = uint32_t(first); a.nblocks = uint32_t(nb);
+        a.flags = flags;
+        a.lists = base + L.lists;
+        a.cands = reinterpret_cast<Cand*>(base + L.cands);
+        a.px = reinterpret_cast<uint32_t*>(base + L.px);
+        a.recs = reinterpret_cast<TaskRec*>(base + L.recs);
+        a.order = reinterpret_cast<uint32_t*>(base + L.order);
+        a.tnp = base + L.tnp;
+        a.counters = reinterpret_cast<uint32_t*>(base + L.counters);
+        uint32_t slotMask = 0;
+
+        if (!quick)
+        {
+            DXTEX_MARK("bc7_rough");
+            hipLaunchKernelGGL(bc7_rough_kernel, dim3((a.nblocks + 3) / 4), dim3(256), 0, stream, a);
+            if (three)
+            {
+                DXTEX_MODE(0, 0, "mode0");
+                slotMask |= 1u << SLOT_M0;
+            }
+            DXTEX_MODE(1, 0, "mode1");
+            if (three)
+            {
+                DXTEX_MODE(2, 0, "mode2");
+                slotMask |= 1u << SLOT_M2;
+            }
+            DXTEX_MODE(3, 0, "mode3");
+            DXTEX_MODE(4, 0, "mode4_im0");
+            DXTEX_MODE(4, 1, "mode4_im1");
+            DXTEX_MODE(5, 0, "mode5");
+            slotMask |= (1u << SLOT_M1) | (1u << SLOT_M3) | (1u << SLOT_M4A) | (1u << SLOT_M4B) | (1u << SLOT_M5);
+        }
+        else
+        {
+            DXTEX_MARK("bc7_texels");
+            hipLaunchKernelGGL(bc7_texels_kernel, dim3((a.nblocks * 16 + 255) / 256), dim3(256), 0, stream, a);
+        }
+        DXTEX_MODE(6, 0, "mode6");
+        slotMask |= (1u << SLOT_M6);
+        if (!quick)
+        {
+            DXTEX_MODE(7, 0, "mode7");
+            slotMask |= (1u << SLOT_M7);
+        }
+        DXTEX_MARK("bc7_pick");
+        hipLaunchKernelGGL(bc7_pick_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, stream, a, slotMask);
     }
-    DXTEX_MARK("bc7_subset1_mode6");
-    hipLaunchKernelGGL((bc7_subset1_kernel<6, 0>), dim3((nb + 511) / 512), dim3(64), 0, stream, a);
-    slotMask |= (1u << SLOT_M6);
-    DXTEX_MARK("bc7_pick");
-    hipLaunchKernelGGL(bc7_pick_kernel, dim3((nb + 255) / 256), dim3(256), 0, stream, a, slotMask);
     DXTEX_MARK(nullptr);
+#undef DXTEX_MODE
 #undef DXTEX_MARK
     return hipGetLastError();
 }

@@ -152,10 +152,8 @@ dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width,
         break;
     case FMT_BC7_UNORM: case FMT_BC7_UNORM_SRGB:
     {
-        if (flags & DXTEX_COMPRESS_BC7_USE_3SUBSETS)
-            return fail(ctx, DXTEX_E_NOT_SUPPORTED, "TEX_COMPRESS_BC7_USE_3SUBSETS is not implemented yet");
         const uint64_t nblocks = uint64_t((width + 3) / 4) * uint64_t((height + 3) / 4);
-        hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks));
+        hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks, flags));
         if (hr != DXTEX_S_OK) return hr;
         e = launch_bc7_encode(v, dDst, dstRowPitch, flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
         break;
@@ -407,9 +405,7 @@ dxtex_hresult dxtex_encode_blocks(dxtex_ctx* ctx, int32_t bc_format, uint32_t bc
     hipError_t e;
     if (bc_format == FMT_BC7_UNORM || bc_format == FMT_BC7_UNORM_SRGB)
     {
-        if (bc_flags & DXTEX_COMPRESS_BC7_USE_3SUBSETS)
-            return fail(ctx, DXTEX_E_NOT_SUPPORTED, "TEX_COMPRESS_BC7_USE_3SUBSETS is not implemented yet");
-        hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks));
+        hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks, bc_flags));
         if (hr != DXTEX_S_OK) return hr;
     }
     time_begin(ctx);

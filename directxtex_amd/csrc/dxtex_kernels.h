@@ -17,8 +17,8 @@ protected:
 hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, int dstFormat,
                               uint32_t flags, float threshold, hipStream_t stream);
 
-// BC7: `scratch` must hold bc7_scratch_bytes(number of 4x4 blocks) bytes of device memory.
-size_t bc7_scratch_bytes(uint64_t nblocks);
+// BC7: `scratch` must hold bc7_scratch_bytes(number of 4x4 blocks, flags) bytes of device memory.
+size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags);
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
                              void* scratch, hipStream_t stream, KernelMarks* marks);
 } // namespace dxtex

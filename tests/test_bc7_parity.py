@@ -44,6 +44,16 @@ def test_bc7_quick_bit_exact(ctx, oracle):
     _compare(oracle, got, ref, img, w, h, "quick")
 
 
+@pytest.mark.parametrize("alpha", ["opaque", "smooth"])
+def test_bc7_3subsets_bit_exact(ctx, oracle, alpha):
+    """TEX_COMPRESS_BC7_USE_3SUBSETS adds modes 0 and 2 (BC6HBC7.cpp:2805-2815)."""
+    w, h = 48, 32
+    img = synth.rgba8(w, h, seed=9, alpha=alpha)
+    got = ctx.compress(img, w, h, RGBA8, BC7, dx.TEX_COMPRESS_BC7_USE_3SUBSETS, 0.5)
+    ref = oracle.compress_image(img, w, h, RGBA8, BC7, dx.TEX_COMPRESS_BC7_USE_3SUBSETS, 0.5)
+    _compare(oracle, got, ref, img, w, h, "3subsets-" + alpha)
+
+
 @pytest.mark.parametrize("size", [(1, 1), (3, 5), (7, 2), (13, 9)])
 def test_bc7_partial_blocks(ctx, oracle, size):
     w, h = size
