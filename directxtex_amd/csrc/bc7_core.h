@@ -29,6 +29,9 @@ namespace dxtex
 {
 namespace bc7
 {
+#if defined(DXTEX_COUNT_EVALS)
+static long g_evalCount[8], g_evalTexels[8], g_macroCount[8];
+#endif
 // ---- per-mode constants (BC6HBC7.cpp:1106-1124) ---------------------------------------------------
 template<int MODE> struct ModeInfo;
 #define DXTEX_BC7_MODE(M, NS_, PARTBITS_, PB_, ROTBITS_, IMBITS_, IB_, IB2_, CP_, AP_, CPP_, APP_) \
@@ -612,6 +615,9 @@ DXTEX_HD int eval_var(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& v
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     int total = base;
+#if defined(DXTEX_COUNT_EVALS)
+    ++g_evalCount[MODE]; g_evalTexels[MODE] += rg.count();
+#endif
     if (C::kAlpha)
     {
         int pa[C::N], npa2[C::N];
@@ -745,6 +751,9 @@ DXTEX_HD void perturb_macro(const RG& rg, const PerturbState& s, int base, int& 
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     VarPal<C::N> vp;
+#if defined(DXTEX_COUNT_EVALS)
+    ++g_macroCount[MODE];
+#endif
     varpal_init<MODE, IM, CHSET>(vp, s.optA, s.optB, s.ch);
     const uint32_t fixedU = unq1<C::PREC>(byte_of(s.do_b ? s.optA : s.optB, s.ch));
     int cur = int(byte_of(s.do_b ? s.optB : s.optA, s.ch));

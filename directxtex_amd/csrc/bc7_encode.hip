@@ -47,8 +47,8 @@ struct Bc7Args
     Cand* cands;
     uint32_t* px;            // nblocks x 16 packed RGBA8 texels (D3DX_BC7::Encode's aLDRPixels, :2792-2799)
     struct TaskRec* recs;    // per-mode task records (reused by every mode)
-    uint32_t* order;         // live tasks of the current mode, sorted by subset size
-    uint8_t* tnp;            // subset size per task (0 = no search needed)
+    uint2* order;            // live tasks of the current mode, sorted by subset size: (task, tinfo)
+    uint32_t* tinfo;         // per task: texel mask | rotation << 16 | subset size << 24 (size 0 = no search needed)
     uint32_t* counters;      // 35 words, see bc7_bin_* kernels
 };
 
@@ -196,9 +196,10 @@ __global__ void __launch_bounds__(256) bc7_rough_kernel(Bc7Args a)
 //           block outside the image, mode 7 on an opaque block) get size 0.
 //   bin     counting sort of the live tasks by subset size (17 bins, wave-aggregated atomics), so that a search
 //           wavefront only ever sees subsets of (almost) one size and its texel loops have one trip count.
-//   search  persistent lanes over a chunk of the sorted list; OptimizeOne cut into lockstep pieces (bc7_core.h):
-//           PERTURB macro-ops first, then the flattened Exhaustive windows; colour and alpha channels of the
-//           separate-alpha modes in separate loops. The subset's texels sit in a per-lane LDS column.
+//   search  persistent wavefronts pulling from the sorted list; OptimizeOne cut into lockstep pieces (bc7_core.h):
+//           one kernel of PERTURB macro-ops, then one of flattened Exhaustive windows; the colour and alpha
+//           channels of the separate-alpha modes get kernels of their own. Endpoints and error of a task travel
+//           through its record between kernels; the subset's texels sit in a per-lane LDS column.
 //   post    (lane = task, natural order): FixEndpointPBits + AssignIndices of the optimised endpoints, org-vs-opt
 //           decision over the subsets of a candidate (lane shuffles), first minimum over the block's candidates
 //           (butterfly), EmitBlock by the winning lane -> per-mode candidate slot.
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
             rec.np = (res.orgErr != 0) ? uint32_t(np) : 0u;        // error 0: OptimizeOne cannot move the endpoints
         }
         a.recs[uint64_t(nb) * TM::TPB + r] = rec;
-        a.tnp[uint64_t(nb) * TM::TPB + r] = uint8_t(rec.np);
+        a.tinfo[uint64_t(nb) * TM::TPB + r] = (mask & 0xFFFFu) | (rot << 16) | (rec.np << 24);
     }
 }
 
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
 // the 16 global counters once per workgroup.
 constexpr int kBinGroups = 2048;
 
-__global__ void __launch_bounds__(256) bc7_bin_count_kernel(const uint8_t* tnp, uint32_t ntasks, uint32_t* counters)
+__global__ void __launch_bounds__(256) bc7_bin_count_kernel(const uint32_t* tinfo, uint32_t ntasks, uint32_t* counters)
 {
     __shared__ uint32_t hist[17];
     if (threadIdx.x < 17) hist[threadIdx.x] = 0;
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__(256) bc7_bin_count_kernel(const uint8_t* tnp, 
     const uint32_t t0 = blockIdx.x * per, t1 = min(ntasks, t0 + per);
     for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256)
     {
-        const uint32_t np = tnp[t];
+        const uint32_t np = tinfo[t] >> 24;
         if (np) atomicAdd(&hist[np], 1u);
     }
     __syncthreads();
@@ -356,7 +357,7 @@ __global__ void bc7_bin_scan_kernel(uint32_t* counters)
     counters[34] = run;
 }
 
-__global__ void __launch_bounds__(256) bc7_bin_scatter_kernel(const uint8_t* tnp, uint32_t ntasks, uint32_t* counters, uint32_t* order)
+__global__ void __launch_bounds__(256) bc7_bin_scatter_kernel(const uint32_t* tinfo, uint32_t ntasks, uint32_t* counters, uint2* order)
 {
     __shared__ uint32_t hist[17], cursor[17];
     if (threadIdx.x < 17) hist[threadIdx.x] = 0;
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(256) bc7_bin_scatter_kernel(const uint8_t* tnp
     const uint32_t t0 = blockIdx.x * per, t1 = min(ntasks, t0 + per);
     for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256)
     {
-        const uint32_t np = tnp[t];
+        const uint32_t np = tinfo[t] >> 24;
         if (np) atomicAdd(&hist[np], 1u);
     }
     __syncthreads();
@@ -374,22 +375,37 @@ __global__ void __launch_bounds__(256) bc7_bin_scatter_kernel(const uint8_t* tnp
     __syncthreads();
     for (uint32_t t = t0 + threadIdx.x; t < t1; t += 256)
     {
-        const uint32_t np = tnp[t];
-        if (np) order[atomicAdd(&cursor[np], 1u)] = t;
+        const uint32_t ti = tinfo[t], np = ti >> 24;
+        if (np) order[atomicAdd(&cursor[np], 1u)] = make_uint2(t, ti);
     }
 }
 
-constexpr int kSearchChunk = 512;       // tasks per search wavefront
+// Work distribution of the search kernels: a fixed number of persistent wavefronts pull task indices from
+// one global counter (counters[kQueueBase + loop]); a lane that finishes its task takes the next one, so lanes
+// stay busy although searches differ in length by an order of magnitude, and there is no per-chunk tail.
+constexpr int kQueueBase = 36;          // counters[36..39]: queue heads of the (up to 4) loops of a mode
+constexpr int kSearchWaves = 8192;      // 256 CUs x 4 SIMDs x 8 wave slots
+
+__device__ __forceinline__ uint32_t queue_take(uint32_t* head, unsigned long long idle, int lane)
+{
+    // one atomic per refill: the first idle lane reserves a run of indices for all idle lanes
+    const int leader = __ffsll((long long)idle) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(head, uint32_t(__popcll(idle)));
+    base = uint32_t(__shfl(int(base), leader));
+    return base + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+}
 
 // A search lane picks up a task: copies the subset's texels (rotated for modes 4, 5) to its LDS column.
 template<int MODE, int IM>
-__device__ __forceinline__ void search_pickup(const Bc7Args& a, uint32_t t, uint32_t* slotCol, SlotRegion& rg)
+__device__ __forceinline__ void search_pickup(const Bc7Args& a, uint2 task, uint32_t* slotCol, SlotRegion& rg)
 {
     typedef TaskMap<MODE, IM> TM;
-    const uint32_t nb = t / TM::TPB, r = t % TM::TPB;
-    uint32_t shape, mask, anchor, rot;
-    task_geometry<MODE, IM>(a, nb, r, shape, mask, anchor, rot);
-    const uint32_t* px = a.px + uint64_t(nb) * 16;
+    const uint32_t nb = task.x / TM::TPB;
+    const uint32_t mask = task.y & 0xFFFFu, rot = (task.y >> 16) & 3u;
+    const uint4* px4 = reinterpret_cast<const uint4*>(a.px + uint64_t(nb) * 16);
+    const uint4 q0 = px4[0], q1 = px4[1], q2 = px4[2], q3 = px4[3];
+    const uint32_t px[16] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
     int np = 0;
     if (TM::NS == 1)
     {
@@ -399,136 +415,117 @@ __device__ __forceinline__ void search_pickup(const Bc7Args& a, uint32_t t, uint
     }
     else
     {
-        for (uint32_t i = 0; i < 16; ++i)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
             if ((mask >> i) & 1u) { slotCol[np * 64] = px[i]; ++np; }
     }
     rg.base = slotCol; rg.np = np; rg.p2sum = 0;
 }
 
+// The PERTURB phase of OptimizeOne (:3060-3105) for the channels of CHSET, over every live task of the mode.
 template<int MODE, int IM, int CHSET>
-__device__ __forceinline__ void search_perturb_loop(const Bc7Args& a, const uint32_t* order, int nTasks, int lane,
-                                                    uint32_t* tA, uint32_t* tB, int* tErr, uint32_t* slotCol)
+__global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
-    if (C::PREC == 0) return;
+    __shared__ uint32_t sSlot[16 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t live = a.counters[34];
+    uint32_t* head = a.counters + kQueueBase + loop;
+    uint32_t* slotCol = &sSlot[lane];
+
     PerturbState st = perturb_begin<MODE, IM, CHSET>(0, 0, 0);
     SlotRegion rg; rg.base = slotCol; rg.np = 0; rg.p2sum = 0;
-    int base = 0, myTask = -1, nextIdx = 0;
+    int base = 0;
+    uint32_t myTask = 0xFFFFFFFFu;
+    bool drained = false;
     for (;;)
     {
-        const unsigned long long idle = __ballot(myTask < 0);
-        if (idle && nextIdx < nTasks)
+        const unsigned long long idle = __ballot(myTask == 0xFFFFFFFFu);
+        if (idle && !drained)
         {
-            const int k = __popcll(idle & ((1ull << lane) - 1ull));
-            if (myTask < 0 && nextIdx + k < nTasks)
+            const uint32_t idx = queue_take(head, idle, lane);
+            if (myTask == 0xFFFFFFFFu && idx < live)
             {
-                myTask = nextIdx + k;
-                search_pickup<MODE, IM>(a, order[myTask], slotCol, rg);
-                st = perturb_begin<MODE, IM, CHSET>(tA[myTask], tB[myTask], tErr[myTask]);
+                const uint2 task = a.order[idx];
+                myTask = task.x;
+                const TaskRec r = a.recs[myTask];
+                search_pickup<MODE, IM>(a, task, slotCol, rg);
+                st = perturb_begin<MODE, IM, CHSET>(r.A, r.B, r.err);
                 base = loop_base<MODE, IM, CHSET>(rg, st.optA, st.optB);
             }
-            nextIdx += __popcll(idle);
+            drained = __ballot(myTask == 0xFFFFFFFFu) != 0ull;      // somebody came back empty-handed: the queue is used up
         }
-        if (__ballot(myTask >= 0) == 0ull) break;
-        if (myTask >= 0)
+        if (__ballot(myTask != 0xFFFFFFFFu) == 0ull) break;
+        if (myTask != 0xFFFFFFFFu)
         {
             int e; uint32_t v;
             perturb_macro<MODE, IM, CHSET>(rg, st, base, e, v);
             st = perturb_transition<MODE, IM, CHSET>(st, e, v);
             if (st.ch >= C::CH1)
             {
-                tA[myTask] = st.optA; tB[myTask] = st.optB; tErr[myTask] = st.optErr;
-                myTask = -1;
+                TaskRec* r = a.recs + myTask;
+                r->A = st.optA; r->B = st.optB; r->err = st.optErr;
+                myTask = 0xFFFFFFFFu;
             }
         }
     }
-    wave_lds_sync();
 }
 
+// The Exhaustive phase (:2971-3042) for the channels of CHSET.
 template<int MODE, int IM, int CHSET>
-__device__ __forceinline__ void search_exhaustive_loop(const Bc7Args& a, const uint32_t* order, int nTasks, int lane,
-                                                       uint32_t* tA, uint32_t* tB, int* tErr, uint32_t* slotCol)
+__global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
-    if (C::PREC == 0) return;
     constexpr int kRefillMin = 8;       // let a few finished lanes wait so that pickups happen in batches
+    __shared__ uint32_t sSlot[16 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t live = a.counters[34];
+    uint32_t* head = a.counters + kQueueBase + loop;
+    uint32_t* slotCol = &sSlot[lane];
+
     ExhState st; st.ch = C::CH1; st.optA = st.optB = 0; st.optErr = 0;
     st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = 0;
     VarPal<C::N> vp;
 #pragma unroll
     for (int i = 0; i < C::N; ++i) { vp.palO[i] = 0; vp.nq2O[i] = 0; }
     SlotRegion rg; rg.base = slotCol; rg.np = 0; rg.p2sum = 0;
-    int base = 0, myTask = -1, nextIdx = 0;
+    int base = 0;
+    uint32_t myTask = 0xFFFFFFFFu;
+    bool drained = false;
     for (;;)
     {
-        const unsigned long long idle = __ballot(myTask < 0);
+        const unsigned long long idle = __ballot(myTask == 0xFFFFFFFFu);
         const int nIdle = __popcll(idle);
-        if (nextIdx < nTasks && (nIdle >= kRefillMin || (nIdle && nextIdx + nIdle >= nTasks) || nIdle == 64))
+        if (!drained && (nIdle >= kRefillMin))
         {
-            const int k = __popcll(idle & ((1ull << lane) - 1ull));
-            if (myTask < 0 && nextIdx + k < nTasks)
+            const uint32_t idx = queue_take(head, idle, lane);
+            if (myTask == 0xFFFFFFFFu && idx < live)
             {
-                myTask = nextIdx + k;
-                search_pickup<MODE, IM>(a, order[myTask], slotCol, rg);
-                const uint32_t oa = tA[myTask], ob = tB[myTask];
-                base = loop_base<MODE, IM, CHSET>(rg, oa, ob);
-                if (!exh_begin<MODE, IM, CHSET>(st, vp, oa, ob, tErr[myTask])) myTask = -1;    // nothing to search: endpoints stay
+                const uint2 task = a.order[idx];
+                myTask = task.x;
+                const TaskRec r = a.recs[myTask];
+                search_pickup<MODE, IM>(a, task, slotCol, rg);
+                base = loop_base<MODE, IM, CHSET>(rg, r.A, r.B);
+                if (!exh_begin<MODE, IM, CHSET>(st, vp, r.A, r.B, r.err)) myTask = 0xFFFFFFFEu;     // nothing to search: endpoints stay
             }
-            nextIdx += nIdle;
+            drained = __ballot(myTask == 0xFFFFFFFFu) != 0ull;
+            if (myTask == 0xFFFFFFFEu) myTask = 0xFFFFFFFFu;
         }
-        if (__ballot(myTask >= 0) == 0ull)
+        if (__ballot(myTask != 0xFFFFFFFFu) == 0ull)
         {
-            if (nextIdx >= nTasks) break;
+            if (drained) break;
             continue;
         }
-        if (myTask >= 0)
+        if (myTask != 0xFFFFFFFFu)
         {
             exh_step<MODE, IM, CHSET>(rg, st, vp, base);
             if (!exh_next<MODE, IM, CHSET>(st, vp))
             {
-                tA[myTask] = st.optA; tB[myTask] = st.optB; tErr[myTask] = st.optErr;
-                myTask = -1;
+                TaskRec* r = a.recs + myTask;
+                r->A = st.optA; r->B = st.optB; r->err = st.optErr;
+                myTask = 0xFFFFFFFFu;
             }
         }
-    }
-    wave_lds_sync();
-}
-
-template<int MODE, int IM>
-__global__ void __launch_bounds__(64) bc7_search_kernel(Bc7Args a)
-{
-    __shared__ uint32_t tA[kSearchChunk], tB[kSearchChunk];
-    __shared__ int tErr[kSearchChunk];
-    __shared__ uint32_t sSlot[16 * 64];
-    const int lane = threadIdx.x;
-    const uint32_t live = a.counters[34];
-    const uint32_t first = blockIdx.x * uint32_t(kSearchChunk);
-    if (first >= live) return;
-    const int nTasks = int(min(uint32_t(kSearchChunk), live - first));
-    const uint32_t* order = a.order + first;
-    for (int i = lane; i < nTasks; i += 64)
-    {
-        const TaskRec r = a.recs[order[i]];
-        tA[i] = r.A; tB[i] = r.B; tErr[i] = r.err;
-    }
-    wave_lds_sync();
-    uint32_t* slotCol = &sSlot[lane];
-    if constexpr (PaletteBits<MODE, IM>::AB == 0)
-    {
-        search_perturb_loop<MODE, IM, CH_ALL>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
-        search_exhaustive_loop<MODE, IM, CH_ALL>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
-    }
-    else
-    {
-        search_perturb_loop<MODE, IM, CH_COLOR>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
-        search_perturb_loop<MODE, IM, CH_ALPHA>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
-        search_exhaustive_loop<MODE, IM, CH_COLOR>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
-        search_exhaustive_loop<MODE, IM, CH_ALPHA>(a, order, nTasks, lane, tA, tB, tErr, slotCol);
-    }
-    for (int i = lane; i < nTasks; i += 64)
-    {
-        TaskRec* r = a.recs + order[i];
-        r->A = tA[i]; r->B = tB[i];
     }
 }
 
@@ -650,7 +647,7 @@ constexpr uint64_t kMaxBlocksPerPass = 1u << 20;      // bounds the scratch (abo
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
 struct ScratchLayout
 {
-    size_t lists, cands, px, recs, order, tnp, counters, total;
+    size_t lists, cands, px, recs, order, tinfo, counters, total;
     explicit ScratchLayout(uint64_t nb, bool threeSubsets)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -660,15 +657,15 @@ struct ScratchLayout
         cands = o; o = up(o + nb * NUM_SLOTS * sizeof(Cand));
         px = o; o = up(o + nb * 64);
         recs = o; o = up(o + nb * tpb * sizeof(TaskRec));
-        order = o; o = up(o + nb * tpb * sizeof(uint32_t));
-        tnp = o; o = up(o + nb * tpb);
+        order = o; o = up(o + nb * tpb * sizeof(uint2));
+        tinfo = o; o = up(o + nb * tpb * sizeof(uint32_t));
         counters = o; o = up(o + 64 * sizeof(uint32_t));
         total = o;
     }
 };
 
 template<int MODE, int IM>
-void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const char* const (&names)[4])
+void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const char* const (&names)[7])
 {
     typedef TaskMap<MODE, IM> TM;
     constexpr int BPW = (TM::TPB >= 64) ? 1 : 64 / TM::TPB;
@@ -678,14 +675,30 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     if (marks) marks->mark(names[0]);
     hipLaunchKernelGGL((bc7_pre_kernel<MODE, IM>), dim3(gridPP), dim3(256), 0, stream, a);
     if (marks) marks->mark(names[1]);
-    (void)hipMemsetAsync(a.counters, 0, 35 * sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(a.counters, 0, 64 * sizeof(uint32_t), stream);
     const uint32_t binGroups = std::min<uint32_t>(kBinGroups, (ntasks + 255) / 256);
-    hipLaunchKernelGGL(bc7_bin_count_kernel, dim3(binGroups), dim3(256), 0, stream, a.tnp, ntasks, a.counters);
+    hipLaunchKernelGGL(bc7_bin_count_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters);
     hipLaunchKernelGGL(bc7_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a.counters);
-    hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tnp, ntasks, a.counters, a.order);
+    hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order);
     if (marks) marks->mark(names[2]);
-    hipLaunchKernelGGL((bc7_search_kernel<MODE, IM>), dim3((ntasks + kSearchChunk - 1) / kSearchChunk), dim3(64), 0, stream, a);
-    if (marks) marks->mark(names[3]);
+    const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
+    if constexpr (PaletteBits<MODE, IM>::AB == 0)
+    {
+        hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
+        if (marks) marks->mark(names[4]);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1);
+    }
+    else
+    {
+        hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 0);
+        if (marks) marks->mark(names[3]);
+        hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 1);
+        if (marks) marks->mark(names[4]);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2);
+        if (marks) marks->mark(names[5]);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3);
+    }
+    if (marks) marks->mark(names[6]);
     hipLaunchKernelGGL((bc7_post_kernel<MODE, IM>), dim3(gridPP), dim3(256), 0, stream, a);
 }
 } // namespace
@@ -699,7 +712,8 @@ hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPi
                              void* scratch, hipStream_t stream, KernelMarks* marks)
 {
 #define DXTEX_MARK(NAME) do { if (marks) marks->mark(NAME); } while (0)
-#define DXTEX_MODE(MODE, IM, TAG) do { static const char* const n_[4] = { "bc7_pre_" TAG, "bc7_bin_" TAG, "bc7_search_" TAG, "bc7_post_" TAG }; \
+#define DXTEX_MODE(MODE, IM, TAG) do { static const char* const n_[7] = { "bc7_pre_" TAG, "bc7_bin_" TAG, "bc7_perturb_" TAG, "bc7_perturb_alpha_" TAG, \
+                                           "bc7_exhaustive_" TAG, "bc7_exhaustive_alpha_" TAG, "bc7_post_" TAG }; \
                                        launch_mode<MODE, IM>(a, stream, marks, n_); } while (0)
     const uint32_t nbw = (src.width + 3) / 4, nbh = (src.height + 3) / 4;
     const uint64_t total = uint64_t(nbw) * nbh;
@@ -720,8 +734,8 @@ hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPi
         a.cands = reinterpret_cast<Cand*>(base + L.cands);
         a.px = reinterpret_cast<uint32_t*>(base + L.px);
         a.recs = reinterpret_cast<TaskRec*>(base + L.recs);
-        a.order = reinterpret_cast<uint32_t*>(base + L.order);
-        a.tnp = base + L.tnp;
+        a.order = reinterpret_cast<uint2*>(base + L.order);
+        a.tinfo = reinterpret_cast<uint32_t*>(base + L.tinfo);
         a.counters = reinterpret_cast<uint32_t*>(base + L.counters);
         uint32_t slotMask = 0;
 

@@ -252,6 +252,10 @@ int main(int argc, char** argv)
             printf("  mode %d: ref best err %.0f, ours %s %u\n", mode, bestRefErr, perMode[mode].valid ? "err" : "n/a", perMode[mode].valid ? perMode[mode].err : 0);
         }
     }
+#if defined(DXTEX_COUNT_EVALS)
+    for (int m = 0; m < 8; ++m)
+        if (g_evalCount[m]) printf("mode %d: %.1f evals/tile, %.1f macro-ops/tile, %.2f texels/eval\n", m, double(g_evalCount[m]) / ntiles, double(g_macroCount[m]) / ntiles, double(g_evalTexels[m]) / g_evalCount[m]);
+#endif
     printf("%d of %d tiles differ\n", nbad, ntiles);
     return nbad ? 1 : 0;
 }
