@@ -14,6 +14,7 @@
 #include "bc67_tables.h"
 #include "bc7_core.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace dxtex
 {
@@ -386,14 +387,32 @@ __global__ void __launch_bounds__(256) bc7_bin_scatter_kernel(const uint32_t* ti
 constexpr int kQueueBase = 36;          // counters[36..39]: queue heads of the (up to 4) loops of a mode
 constexpr int kSearchWaves = 8192;      // 256 CUs x 4 SIMDs x 8 wave slots
 
-__device__ __forceinline__ uint32_t queue_take(uint32_t* head, unsigned long long idle, int lane)
+constexpr uint32_t kQueueBatch = 128;   // indices a wavefront reserves per atomic (same-address atomics serialise in L2)
+
+struct WaveQueue
 {
-    // one atomic per refill: the first idle lane reserves a run of indices for all idle lanes
-    const int leader = __ffsll((long long)idle) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(head, uint32_t(__popcll(idle)));
-    base = uint32_t(__shfl(int(base), leader));
-    return base + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+    uint32_t lo, hi;     // reserved, not yet handed out (wave-uniform)
+    bool drained;        // the global counter has passed the end of the list
+};
+
+// Hands the idle lanes (mask `idle`) indices into the sorted task list; returns 0xFFFFFFFF for a lane that gets
+// none this time. One global atomic per kQueueBatch tasks.
+__device__ __forceinline__ uint32_t queue_take(WaveQueue& q, uint32_t* head, uint32_t live, unsigned long long idle, int lane)
+{
+    if (q.lo >= q.hi && !q.drained)
+    {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(head, kQueueBatch);
+        base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
+        q.lo = base;
+        q.hi = min(base + kQueueBatch, live);
+        if (base >= live) { q.drained = true; q.hi = q.lo; }
+    }
+    const uint32_t k = uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+    const uint32_t avail = q.hi - q.lo;
+    const uint32_t mine = (((idle >> lane) & 1ull) && k < avail) ? (q.lo + k) : 0xFFFFFFFFu;
+    q.lo += min(uint32_t(__popcll(idle)), avail);
+    return mine;
 }
 
 // A search lane picks up a task: copies the subset's texels (rotated for modes 4, 5) to its LDS column.
@@ -437,14 +456,14 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
     SlotRegion rg; rg.base = slotCol; rg.np = 0; rg.p2sum = 0;
     int base = 0;
     uint32_t myTask = 0xFFFFFFFFu;
-    bool drained = false;
+    WaveQueue q; q.lo = q.hi = 0; q.drained = false;
     for (;;)
     {
         const unsigned long long idle = __ballot(myTask == 0xFFFFFFFFu);
-        if (idle && !drained)
+        if (idle && !(q.drained && q.lo >= q.hi))
         {
-            const uint32_t idx = queue_take(head, idle, lane);
-            if (myTask == 0xFFFFFFFFu && idx < live)
+            const uint32_t idx = queue_take(q, head, live, idle, lane);
+            if (idx != 0xFFFFFFFFu)
             {
                 const uint2 task = a.order[idx];
                 myTask = task.x;
@@ -453,9 +472,12 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
                 st = perturb_begin<MODE, IM, CHSET>(r.A, r.B, r.err);
                 base = loop_base<MODE, IM, CHSET>(rg, st.optA, st.optB);
             }
-            drained = __ballot(myTask == 0xFFFFFFFFu) != 0ull;      // somebody came back empty-handed: the queue is used up
         }
-        if (__ballot(myTask != 0xFFFFFFFFu) == 0ull) break;
+        if (__ballot(myTask != 0xFFFFFFFFu) == 0ull)
+        {
+            if (q.drained && q.lo >= q.hi) break;
+            continue;
+        }
         if (myTask != 0xFFFFFFFFu)
         {
             int e; uint32_t v;
@@ -473,10 +495,11 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
 
 // The Exhaustive phase (:2971-3042) for the channels of CHSET.
 template<int MODE, int IM, int CHSET>
-__global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop)
+__global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop, int kRefillMin, int kTransMin)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
-    constexpr int kRefillMin = 8;       // let a few finished lanes wait so that pickups happen in batches
+    // kRefillMin: let a few finished lanes wait so that pickups happen in batches; kTransMin: likewise for lanes
+    // that have to open their next window
     __shared__ uint32_t sSlot[16 * 64];
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
@@ -491,40 +514,50 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop)
     SlotRegion rg; rg.base = slotCol; rg.np = 0; rg.p2sum = 0;
     int base = 0;
     uint32_t myTask = 0xFFFFFFFFu;
-    bool drained = false;
+    WaveQueue q; q.lo = q.hi = 0; q.drained = false;
     for (;;)
     {
         const unsigned long long idle = __ballot(myTask == 0xFFFFFFFFu);
         const int nIdle = __popcll(idle);
-        if (!drained && (nIdle >= kRefillMin))
+        if (!(q.drained && q.lo >= q.hi) && (nIdle >= kRefillMin))
         {
-            const uint32_t idx = queue_take(head, idle, lane);
-            if (myTask == 0xFFFFFFFFu && idx < live)
+            const uint32_t idx = queue_take(q, head, live, idle, lane);
+            if (idx != 0xFFFFFFFFu)
             {
                 const uint2 task = a.order[idx];
                 myTask = task.x;
                 const TaskRec r = a.recs[myTask];
                 search_pickup<MODE, IM>(a, task, slotCol, rg);
                 base = loop_base<MODE, IM, CHSET>(rg, r.A, r.B);
-                if (!exh_begin<MODE, IM, CHSET>(st, vp, r.A, r.B, r.err)) myTask = 0xFFFFFFFEu;     // nothing to search: endpoints stay
+                if (!exh_begin<MODE, IM, CHSET>(st, vp, r.A, r.B, r.err)) myTask = 0xFFFFFFFFu;     // nothing to search: endpoints stay
             }
-            drained = __ballot(myTask == 0xFFFFFFFFu) != 0ull;
-            if (myTask == 0xFFFFFFFEu) myTask = 0xFFFFFFFFu;
         }
-        if (__ballot(myTask != 0xFFFFFFFFu) == 0ull)
+        // Lanes whose window is used up wait until kTransMin of them can open their next windows together
+        // (committing a window and rebuilding the palette cache costs about half an evaluation).
+        const unsigned long long busy = __ballot(myTask != 0xFFFFFFFFu);
+        const unsigned long long waiting = __ballot(myTask != 0xFFFFFFFFu && st.o >= st.oEnd);
+        if (busy == 0ull)
         {
-            if (drained) break;
+            if (q.drained && q.lo >= q.hi) break;
             continue;
         }
-        if (myTask != 0xFFFFFFFFu)
+        if (__popcll(waiting) >= kTransMin || waiting == busy)
+        {
+            if (myTask != 0xFFFFFFFFu && st.o >= st.oEnd)
+            {
+                if (!exh_next<MODE, IM, CHSET>(st, vp))
+                {
+                    TaskRec* r = a.recs + myTask;
+                    r->A = st.optA; r->B = st.optB; r->err = st.optErr;
+                    myTask = 0xFFFFFFFFu;
+                }
+            }
+            continue;
+        }
+        if (myTask != 0xFFFFFFFFu && st.o < st.oEnd)
         {
             exh_step<MODE, IM, CHSET>(rg, st, vp, base);
-            if (!exh_next<MODE, IM, CHSET>(st, vp))
-            {
-                TaskRec* r = a.recs + myTask;
-                r->A = st.optA; r->B = st.optB; r->err = st.optErr;
-                myTask = 0xFFFFFFFFu;
-            }
+            exh_settle(st);
         }
     }
 }
@@ -682,11 +715,13 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order);
     if (marks) marks->mark(names[2]);
     const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
+    static const int refillMin = getenv("DXTEX_BC7_REFILL_MIN") ? atoi(getenv("DXTEX_BC7_REFILL_MIN")) : 8;
+    static const int transMin = getenv("DXTEX_BC7_TRANS_MIN") ? atoi(getenv("DXTEX_BC7_TRANS_MIN")) : 8;
     if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
         if (marks) marks->mark(names[4]);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1, refillMin, transMin);
     }
     else
     {
@@ -694,9 +729,9 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
         if (marks) marks->mark(names[3]);
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 1);
         if (marks) marks->mark(names[4]);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2, refillMin, transMin);
         if (marks) marks->mark(names[5]);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3, refillMin, transMin);
     }
     if (marks) marks->mark(names[6]);
     hipLaunchKernelGGL((bc7_post_kernel<MODE, IM>), dim3(gridPP), dim3(256), 0, stream, a);
