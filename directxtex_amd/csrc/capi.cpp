@@ -4,6 +4,7 @@
 #include "../../include/dxtex_amd.h"
 #include "dxtex_formats.h"
 #include "dxtex_kernels.h"
+#include "dxtex_plan.h"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -428,12 +429,76 @@ dxtex_hresult dxtex_encode_blocks(dxtex_ctx* ctx, int32_t bc_format, uint32_t bc
     return DXTEX_S_OK;
 }
 
-dxtex_hresult dxtex_decode_blocks(dxtex_ctx* ctx, int32_t, const uint8_t*, size_t, float*)
-{ return fail(ctx, DXTEX_E_NOTIMPL, "dxtex_decode_blocks: not implemented yet"); }
-dxtex_hresult dxtex_decompress(dxtex_ctx* ctx, const dxtex_image*, const dxtex_image*)
-{ return fail(ctx, DXTEX_E_NOTIMPL, "dxtex_decompress: not implemented yet"); }
-dxtex_hresult dxtex_decompress_device(dxtex_ctx* ctx, const dxtex_image*, const dxtex_image*)
-{ return fail(ctx, DXTEX_E_NOTIMPL, "dxtex_decompress_device: not implemented yet"); }
+// DecompressBC (DirectXTexCompress.cpp:425-535): BC image -> uncompressed image of the same size, on device pointers.
+static dxtex_hresult submit_decompress(dxtex_ctx* ctx, const uint8_t* dSrc, int srcFormat, size_t srcRowPitch,
+                                       uint8_t* dDst, int dstFormat, size_t dstRowPitch, size_t width, size_t height)
+{
+    const FmtInfo* in = format_info(srcFormat);
+    const FmtInfo* out = format_info(dstFormat);
+    if (!in || !(in->cls & FC_BC)) return fail(ctx, DXTEX_E_INVALIDARG, "source image is not block compressed");
+    if (out && (out->cls & FC_BC)) return fail(ctx, DXTEX_E_INVALIDARG, "destination format is block compressed");
+    if (!out) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "destination format is not supported by the MI355X path");
+    if (!width || !height) return fail(ctx, DXTEX_E_INVALIDARG, "empty image");
+    const ConvertPlan plan = resolve_convert_plan(*in, *out, 0);
+    hipError_t e = launch_bc_decode(dSrc, srcRowPitch, srcFormat, dDst, dstRowPitch, dstFormat, uint32_t(width), uint32_t(height), plan, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    return DXTEX_S_OK;
+}
+
+dxtex_hresult dxtex_decompress_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst)
+{
+    dxtex_hresult hr = check_pair(ctx, src, dst);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    time_begin(ctx);
+    hr = submit_decompress(ctx, src->pixels, src->format, src->rowPitch, dst->pixels, dst->format, dst->rowPitch, src->width, src->height);
+    time_end(ctx);
+    return hr;
+}
+
+dxtex_hresult dxtex_decompress(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst)
+{
+    dxtex_hresult hr = check_pair(ctx, src, dst);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    const size_t nbh = std::max<size_t>(1, (src->height + 3) / 4);
+    const size_t srcBytes = src->rowPitch * nbh, dstBytes = dst->rowPitch * dst->height;
+    hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
+    hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    time_begin(ctx);
+    hr = submit_decompress(ctx, static_cast<const uint8_t*>(ctx->stageIn), src->format, src->rowPitch,
+                           static_cast<uint8_t*>(ctx->stageOut), dst->format, dst->rowPitch, src->width, src->height);
+    time_end(ctx);
+    if (hr != DXTEX_S_OK) return hr;
+    HIP_TRY(ctx, hipMemcpyAsync(dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DXTEX_S_OK;
+}
+
+dxtex_hresult dxtex_decode_blocks(dxtex_ctx* ctx, int32_t bc_format, const uint8_t* bc, size_t nblocks, float* rgba)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!rgba || !bc) return fail(ctx, DXTEX_E_POINTER, "null buffer");
+    const size_t bb = bc_block_bytes(bc_format);
+    if (!bb) return fail(ctx, DXTEX_E_INVALIDARG, "not a BC format");
+    if (!nblocks) return DXTEX_S_OK;
+    ScopedDevice sd(ctx->device);
+    // nblocks blocks == a BC image 4 texels wide and 4*nblocks high; the raw decoder output is R32G32B32A32_FLOAT
+    const size_t srcBytes = nblocks * bb, dstBytes = nblocks * 256;
+    dxtex_hresult hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
+    hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, bc, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    ConvertPlan plan; plan.srgbIn = 0; plan.tcv = TCV_NONE; plan.tsw = TSW_NONE; plan.srgbOut = 0;
+    time_begin(ctx);
+    hipError_t e = launch_bc_decode(static_cast<const uint8_t*>(ctx->stageIn), bb, bc_format, static_cast<uint8_t*>(ctx->stageOut), 64,
+                                    FMT_R32G32B32A32_FLOAT, 4, uint32_t(nblocks * 4), plan, ctx->stream);
+    time_end(ctx);
+    if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    HIP_TRY(ctx, hipMemcpyAsync(rgba, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DXTEX_S_OK;
+}
 dxtex_hresult dxtex_generate_mips(dxtex_ctx* ctx, const dxtex_image*, size_t, uint32_t)
 { return fail(ctx, DXTEX_E_NOTIMPL, "dxtex_generate_mips: not implemented yet"); }
 dxtex_hresult dxtex_generate_mips_device(dxtex_ctx* ctx, const dxtex_image*, size_t, uint32_t)

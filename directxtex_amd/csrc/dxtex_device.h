@@ -61,6 +61,7 @@ enum : int
     TCV_CLAMP_SNORM = 2,     // FLOAT -> SNORM  (:3521-3526)
     TCV_UNORM_TO_SNORM = 3,  // UNORM -> SNORM  v*2 + -1, unfused (:3495-3501)
     TCV_SNORM_TO_UNORM = 4,  // SNORM -> UNORM  v*0.5 + 0.5 (:3457-3463)
+    TCV_X2BIAS_TO_UNORM = 5, // FLOAT -> UNORM with TEX_FILTER_FLOAT_X2BIAS: clamp(v,-1,1)*0.5 + 0.5 (:3469-3477)
 };
 enum : int
 {
@@ -126,6 +127,52 @@ __device__ __forceinline__ Texel load_texel(const uint8_t* row, uint32_t x, int 
         t.r = v.x; t.g = v.y; t.b = v.z; t.a = v.w;
         break;
     }
+    case FMT_R16G16B16A16_UNORM:
+    {
+        // XMLoadUShortN4: float(v) * (1/65535)
+        const uint2 v = reinterpret_cast<const uint2*>(row)[x];
+        t.r = float(v.x & 0xFFFF) * (1.0f / 65535.0f); t.g = float(v.x >> 16) * (1.0f / 65535.0f);
+        t.b = float(v.y & 0xFFFF) * (1.0f / 65535.0f); t.a = float(v.y >> 16) * (1.0f / 65535.0f);
+        break;
+    }
+    case FMT_R8G8B8A8_SNORM:
+    {
+        // XMLoadByteN4: float(int8) * (1/127), then max with -1
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        const float c[4] = { float(int8_t(v & 0xFF)), float(int8_t((v >> 8) & 0xFF)), float(int8_t((v >> 16) & 0xFF)), float(int8_t(v >> 24)) };
+        t.r = fmaxf(c[0] * (1.0f / 127.0f), -1.0f); t.g = fmaxf(c[1] * (1.0f / 127.0f), -1.0f);
+        t.b = fmaxf(c[2] * (1.0f / 127.0f), -1.0f); t.a = fmaxf(c[3] * (1.0f / 127.0f), -1.0f);
+        break;
+    }
+    case FMT_R32G32_FLOAT:
+    {
+        const float2 v = reinterpret_cast<const float2*>(row)[x];
+        t.r = v.x; t.g = v.y; t.b = 0.0f; t.a = 1.0f;
+        break;
+    }
+    case FMT_R16G16_FLOAT:
+    {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.r = __half2float(__ushort_as_half(uint16_t(v & 0xFFFF))); t.g = __half2float(__ushort_as_half(uint16_t(v >> 16)));
+        t.b = 0.0f; t.a = 1.0f;
+        break;
+    }
+    case FMT_R16G16_UNORM:
+    {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.r = float(v & 0xFFFF) * (1.0f / 65535.0f); t.g = float(v >> 16) * (1.0f / 65535.0f); t.b = 0.0f; t.a = 1.0f;
+        break;
+    }
+    case FMT_R8G8_SNORM:
+    {
+        const uint16_t v = reinterpret_cast<const uint16_t*>(row)[x];
+        t.r = fmaxf(float(int8_t(v & 0xFF)) * (1.0f / 127.0f), -1.0f); t.g = fmaxf(float(int8_t(v >> 8)) * (1.0f / 127.0f), -1.0f);
+        t.b = 0.0f; t.a = 1.0f;
+        break;
+    }
+    case FMT_R16_UNORM:
+        t.r = float(reinterpret_cast<const uint16_t*>(row)[x]) / 65535.0f; t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;   // :1054-1065
+        break;
     case FMT_R8_UNORM:
         // true division here, unlike the packed loads (DirectXTexConvert.cpp:1113)
         t.r = float(row[x]) / 255.0f; t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;
@@ -163,6 +210,7 @@ __device__ __forceinline__ float tcv1(float v, int tcv)
     case TCV_CLAMP_SNORM: { float m = (v > -1.0f) ? v : -1.0f; return (m < 1.0f) ? m : 1.0f; }
     case TCV_UNORM_TO_SNORM: return v * 2.0f + -1.0f;
     case TCV_SNORM_TO_UNORM: return v * 0.5f + 0.5f;
+    case TCV_X2BIAS_TO_UNORM: { float m = (v > -1.0f) ? v : -1.0f; m = (m < 1.0f) ? m : 1.0f; return m * 0.5f + 0.5f; }
     default: return v;
     }
 }

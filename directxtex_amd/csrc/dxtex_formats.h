@@ -24,6 +24,13 @@ inline const FmtInfo* format_info(int format)
         { FMT_B8G8R8A8_UNORM_SRGB, 32, FC_UNORM | FC_R | FC_G | FC_B | FC_A | FC_SRGB },
         { FMT_B8G8R8X8_UNORM, 32, FC_UNORM | FC_R | FC_G | FC_B },
         { FMT_B8G8R8X8_UNORM_SRGB, 32, FC_UNORM | FC_R | FC_G | FC_B | FC_SRGB },
+        { FMT_R16G16B16A16_UNORM, 64, FC_UNORM | FC_R | FC_G | FC_B | FC_A },
+        { FMT_R8G8B8A8_SNORM, 32, FC_SNORM | FC_R | FC_G | FC_B | FC_A },
+        { FMT_R32G32_FLOAT, 64, FC_FLOAT | FC_R | FC_G },
+        { FMT_R16G16_FLOAT, 32, FC_FLOAT | FC_R | FC_G },
+        { FMT_R16G16_UNORM, 32, FC_UNORM | FC_R | FC_G },
+        { FMT_R8G8_SNORM, 16, FC_SNORM | FC_R | FC_G },
+        { FMT_R16_UNORM, 16, FC_UNORM | FC_R },
         { FMT_R8G8_UNORM, 16, FC_UNORM | FC_R | FC_G },
         { FMT_R8_UNORM, 8, FC_UNORM | FC_R },
         { FMT_R8_SNORM, 8, FC_SNORM | FC_R },

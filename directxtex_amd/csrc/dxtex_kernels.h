@@ -21,4 +21,9 @@ hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowP
 size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags);
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
                              void* scratch, hipStream_t stream, KernelMarks* marks);
+
+// BC -> uncompressed (DecompressBC). `plan` = resolve_convert_plan(bc format, target format, TEX_FILTER_DEFAULT).
+struct ConvertPlan;
+hipError_t launch_bc_decode(const uint8_t* src, uint64_t srcRowPitch, int srcFormat, uint8_t* dst, uint64_t dstRowPitch, int dstFormat,
+                            uint32_t width, uint32_t height, const ConvertPlan& plan, hipStream_t stream);
 } // namespace dxtex

@@ -1,0 +1,109 @@
+// Host-side resolution of ConvertScanline (DirectXTexConvert.cpp:3080-3854) for the non-depth formats this
+// library handles: which of the per-texel steps (sRGB decode, range conversion, channel shuffle, sRGB encode) a
+// given (input format, output format, TEX_FILTER flags) triple needs. The kernels then run apply_plan() per texel.
+#pragma once
+#include "dxtex_formats.h"
+#include "dxtex_store.h"
+
+namespace dxtex
+{
+enum : uint32_t
+{
+    TF_FLOAT_X2BIAS = 0x200, TF_COPY_RED = 0x1000, TF_COPY_GREEN = 0x2000, TF_COPY_BLUE = 0x4000, TF_COPY_ALPHA = 0x8000,
+    TF_SRGB_IN = 0x1000000, TF_SRGB_OUT = 0x2000000,
+};
+
+inline ConvertPlan resolve_convert_plan(const FmtInfo& in, const FmtInfo& out, uint32_t flags)
+{
+    ConvertPlan p; p.srgbIn = 0; p.tcv = TCV_NONE; p.tsw = TSW_NONE; p.srgbOut = 0;
+
+    // :3123-3167
+    if (in.cls & FC_SRGB) flags |= TF_SRGB_IN;
+    if (in.format == FMT_A8_UNORM) flags &= ~TF_SRGB_IN;
+    if (out.cls & FC_SRGB) flags |= TF_SRGB_OUT;
+    if (out.format == FMT_A8_UNORM) flags &= ~TF_SRGB_OUT;
+    if ((flags & (TF_SRGB_IN | TF_SRGB_OUT)) == (TF_SRGB_IN | TF_SRGB_OUT)) flags &= ~(TF_SRGB_IN | TF_SRGB_OUT);
+    if ((flags & TF_SRGB_IN) && (in.cls & (FC_FLOAT | FC_UNORM))) p.srgbIn = 1;
+    if ((flags & TF_SRGB_OUT) && (out.cls & (FC_FLOAT | FC_UNORM))) p.srgbOut = 1;
+
+    // the reference compares its CONVF_* words; what can differ among our formats: type class, channel set, BC-ness,
+    // BGR order. BGR-only differences reach no branch below, so they can be left out of the test.
+    const uint32_t kDiffMask = FC_UNORM | FC_SNORM | FC_FLOAT | FC_BC | FC_R | FC_G | FC_B | FC_A;
+    const uint32_t diff = (in.cls ^ out.cls) & kDiffMask;
+    if (!diff) return p;
+
+    if (out.cls & FC_UNORM)
+    {
+        if (in.cls & FC_SNORM) p.tcv = TCV_SNORM_TO_UNORM;                                            // :3457-3463
+        else if (in.cls & FC_FLOAT) p.tcv = (flags & TF_FLOAT_X2BIAS) ? TCV_X2BIAS_TO_UNORM : TCV_SATURATE;   // :3465-3489
+    }
+    else if (out.cls & FC_SNORM)
+    {
+        if (in.cls & FC_UNORM) p.tcv = TCV_UNORM_TO_SNORM;                                            // :3495-3501
+        else if (in.cls & FC_FLOAT) p.tcv = TCV_CLAMP_SNORM;                                          // :3521-3526
+    }
+    else if (diff & FC_UNORM)
+    {
+        if ((out.cls & FC_FLOAT) && (flags & TF_FLOAT_X2BIAS)) p.tcv = TCV_UNORM_TO_SNORM;            // UNORM (x2 bias) -> FLOAT, :3536-3546
+    }
+
+    const uint32_t inRGBA = in.cls & (FC_R | FC_G | FC_B | FC_A), outRGBA = out.cls & (FC_R | FC_G | FC_B | FC_A);
+    const uint32_t inRGB = in.cls & (FC_R | FC_G | FC_B), outRGB = out.cls & (FC_R | FC_G | FC_B);
+    const uint32_t kRGB = FC_R | FC_G | FC_B;
+    if (outRGBA == FC_A && !(in.cls & FC_A))
+    {
+        // !A -> A format (:3596-3652)
+        switch (flags & (TF_COPY_RED | TF_COPY_GREEN | TF_COPY_BLUE))
+        {
+        case TF_COPY_GREEN: p.tsw = TSW_SPLAT_Y; break;
+        case TF_COPY_BLUE: p.tsw = TSW_SPLAT_Z; break;
+        case TF_COPY_RED: p.tsw = TSW_SPLAT_X; break;
+        default: p.tsw = ((in.cls & FC_UNORM) && inRGB == kRGB) ? TSW_GRAY_SPLAT : TSW_SPLAT_X; break;
+        }
+    }
+    else if (inRGBA == FC_A && !(out.cls & FC_A)) p.tsw = TSW_A_TO_RGB;                               // :3654-3664
+    else if (inRGB == FC_R)
+    {
+        if (outRGB == kRGB) p.tsw = TSW_R_TO_RGB;                                                      // :3667-3679
+        else if (outRGB == (FC_R | FC_G)) p.tsw = TSW_R_TO_RG;                                         // :3680-3691
+    }
+    else if (inRGB == kRGB)
+    {
+        if (outRGB == FC_R)
+        {
+            // RGB(A) -> R format (:3696-3771)
+            switch (flags & (TF_COPY_RED | TF_COPY_GREEN | TF_COPY_BLUE | TF_COPY_ALPHA))
+            {
+            case TF_COPY_GREEN: p.tsw = TSW_G_TO_R; break;
+            case TF_COPY_BLUE: p.tsw = TSW_B_TO_R; break;
+            case TF_COPY_ALPHA: p.tsw = TSW_A_TO_R; break;
+            case TF_COPY_RED: break;
+            default: if (in.cls & FC_UNORM) p.tsw = TSW_RGB_TO_R_GRAY; break;
+            }
+        }
+        else if (outRGB == (FC_R | FC_G))
+        {
+            // RGB(A) -> RG format (:3773-3838)
+            if ((flags & TF_COPY_ALPHA) && (in.cls & FC_A))
+            {
+                switch (flags & (TF_COPY_RED | TF_COPY_GREEN | TF_COPY_BLUE | TF_COPY_ALPHA))
+                {
+                case TF_COPY_GREEN | TF_COPY_ALPHA: p.tsw = TSW_GA_TO_RG; break;
+                case TF_COPY_BLUE | TF_COPY_ALPHA: p.tsw = TSW_BA_TO_RG; break;
+                default: p.tsw = TSW_RA_TO_RG; break;
+                }
+            }
+            else
+            {
+                switch (flags & (TF_COPY_RED | TF_COPY_GREEN | TF_COPY_BLUE))
+                {
+                case TF_COPY_RED | TF_COPY_BLUE: p.tsw = TSW_RB_TO_RG; break;
+                case TF_COPY_GREEN | TF_COPY_BLUE: p.tsw = TSW_GB_TO_RG; break;
+                default: break;
+                }
+            }
+        }
+    }
+    return p;
+}
+} // namespace dxtex

@@ -188,6 +188,66 @@ def decode_image(payload, width, height, bc_fmt):
     return img[:height, :width]
 
 
+# ---- StoreScanline restatement (DirectXTexConvert.cpp:1629-2533) ------------------------------------------
+# Packed stores are DirectXMath's (SSE2 flavour): see the header of directxtex_amd/csrc/dxtex_store.h for the
+# behaviours assumed; PARITY UNPINNED at that boundary.
+
+def _trunc_u8_biased(v):
+    s = (v.astype(np.float32) + _F(0.5 / 255.0)).astype(np.float32)
+    s = np.minimum(np.maximum(s, _F(0)), _F(1))
+    return (s * _F(255.0)).astype(np.float32).astype(np.uint8)       # truncation
+
+
+def _half_clamped(v):
+    s = np.minimum(np.maximum(v.astype(np.float32), _F(-65504.0)), _F(65504.0))
+    return s.astype(np.float16)                                        # IEEE round to nearest even
+
+
+def store_image(img, fmt):
+    """(H, W, 4) float32 -> tight-pitch bytes of `fmt`, exactly what StoreScanline writes."""
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape[:2]
+    if fmt == 2:
+        return img.reshape(-1).view(np.uint8).copy()
+    if fmt == 10:
+        return _half_clamped(img).reshape(-1).view(np.uint8).copy()
+    if fmt in (28, 29):
+        return _trunc_u8_biased(img).reshape(-1)
+    if fmt in (87, 91):
+        return _trunc_u8_biased(img[..., [2, 1, 0, 3]]).reshape(-1)
+    if fmt in (88, 93):
+        t = img[..., [2, 1, 0, 3]].copy(); t[..., 3] = 1.0
+        return _trunc_u8_biased(t).reshape(-1)
+    if fmt == 61:       # R8_UNORM (:1958-1971)
+        s = np.maximum(np.minimum((img[..., 0] + _F(0.5 / 255.0)).astype(np.float32), _F(1)), _F(0))
+        return (s * _F(255.0)).astype(np.float32).astype(np.uint8).reshape(-1)
+    if fmt == 65:       # A8_UNORM
+        s = np.maximum(np.minimum((img[..., 3] + _F(0.5 / 255.0)).astype(np.float32), _F(1)), _F(0))
+        return (s * _F(255.0)).astype(np.float32).astype(np.uint8).reshape(-1)
+    if fmt == 49:       # R8G8_UNORM: XMStoreUByteN2 = saturate, *255 + 0.5, truncate
+        s = np.minimum(np.maximum(img[..., :2], _F(0)), _F(1))
+        return ((s * _F(255.0)).astype(np.float32) + _F(0.5)).astype(np.float32).astype(np.uint8).reshape(-1)
+    if fmt == 63:       # R8_SNORM: lroundf(clamp(v) * 127) (:1988-2001)
+        s = np.maximum(np.minimum(img[..., 0], _F(1)), _F(-1))
+        p = (s * _F(127.0)).astype(np.float32)
+        r = np.where(p >= 0, np.floor(p + _F(0.5)), np.ceil(p - _F(0.5)))       # half away from zero
+        return r.astype(np.int8).view(np.uint8).reshape(-1)
+    if fmt == 51:       # R8G8_SNORM: XMStoreByteN2 = clamp, *127, round to nearest even
+        s = np.minimum(np.maximum(img[..., :2], _F(-1)), _F(1))
+        return np.rint((s * _F(127.0)).astype(np.float32)).astype(np.int8).view(np.uint8).reshape(-1)
+    if fmt == 41:
+        return np.ascontiguousarray(img[..., 0]).reshape(-1).view(np.uint8).copy()
+    if fmt == 54:
+        return _half_clamped(img[..., 0]).reshape(-1).view(np.uint8).copy()
+    raise NotImplementedError(fmt)
+
+
+def decompress_image(payload, width, height, bc_fmt, dst_fmt):
+    """Oracle for DirectX::Decompress on one image (DecompressBC, DirectXTexCompress.cpp:425-535): reference block
+    decoder + ConvertScanline (a no-op for the default target formats) + StoreScanline."""
+    return store_image(decode_image(payload, width, height, bc_fmt), dst_fmt)
+
+
 def compute_mse(a, b):
     """ComputeMSE (DirectXTexMisc.cpp:27-176): per-channel sum of squared differences / (w*h), on floats."""
     d = a.astype(np.float64) - b.astype(np.float64)
