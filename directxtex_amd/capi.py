@@ -217,6 +217,19 @@ class Context:
         self._check(_lib.dxtex_decompress(self._h, ctypes.byref(src), ctypes.byref(dst)), "decompress")
         return out
 
+    def decompress_device(self, src_ptr, width, height, bc_format, dst_ptr, dst_format):
+        src = device_image(src_ptr, width, height, bc_format)
+        dst = device_image(dst_ptr, width, height, dst_format)
+        self._check(_lib.dxtex_decompress_device(self._h, ctypes.byref(src), ctypes.byref(dst)), "decompress_device")
+
+    def compute_mse_device(self, a_ptr, a_format, b_ptr, b_format, width, height):
+        """Per-channel MSE (4 doubles) of two device images of the same size."""
+        a = device_image(a_ptr, width, height, a_format)
+        b = device_image(b_ptr, width, height, b_format)
+        out = (ctypes.c_double * 4)()
+        self._check(_lib.dxtex_compute_mse_device(self._h, ctypes.byref(a), ctypes.byref(b), out), "compute_mse_device")
+        return np.array(list(out), np.float64)
+
     # -- GenerateMipMaps / Convert / Resize ---------------------------------------------------------
     def generate_mips(self, level0, width, height, fmt, nlevels, filter_flags):
         """Returns [level0, level1, ...] as numpy uint8 buffers with tight pitch."""

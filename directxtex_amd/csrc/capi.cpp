@@ -5,6 +5,7 @@
 #include "dxtex_formats.h"
 #include "dxtex_kernels.h"
 #include "dxtex_plan.h"
+#include "triangle_filter.h"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -44,6 +45,10 @@ struct dxtex_ctx
     void* stageOut = nullptr; size_t stageOutBytes = 0;
     // grow-only device scratch for the multi-kernel BC6H/BC7 search (per-mode candidates)
     void* scratch = nullptr; size_t scratchBytes = 0;
+    // triangle-filter gather tables (host copies stay alive until the next call: the upload is stream-ordered)
+    void* triBuf = nullptr; size_t triBytes = 0;
+    std::vector<uint8_t> triHost;
+    void* mseBuf = nullptr; size_t mseBytes = 0;
     std::string lastError;
     bool profiling = false;
     Marks marks;
@@ -216,6 +221,8 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
     if (ctx->stageIn) (void)hipFree(ctx->stageIn);
     if (ctx->stageOut) (void)hipFree(ctx->stageOut);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->triBuf) (void)hipFree(ctx->triBuf);
+    if (ctx->mseBuf) (void)hipFree(ctx->mseBuf);
     for (hipEvent_t e : ctx->marks.pool) (void)hipEventDestroy(e);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
@@ -499,20 +506,268 @@ dxtex_hresult dxtex_decode_blocks(dxtex_ctx* ctx, int32_t bc_format, const uint8
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
-dxtex_hresult dxtex_generate_mips(dxtex_ctx* ctx, const dxtex_image*, size_t, uint32_t)
-{ return fail(ctx, DXTEX_E_NOTIMPL, "dxtex_generate_mips: not implemented yet"); }
-dxtex_hresult dxtex_generate_mips_device(dxtex_ctx* ctx, const dxtex_image*, size_t, uint32_t)
-{ return fail(ctx, DXTEX_E_NOTIMPL, "dxtex_generate_mips_device: not implemented yet"); }
-dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image*, const dxtex_image*, uint32_t, float)
-{ return fail(ctx, DXTEX_E_NOTIMPL, "dxtex_convert: not implemented yet"); }
-dxtex_hresult dxtex_convert_device(dxtex_ctx* ctx, const dxtex_image*, const dxtex_image*, uint32_t, float)
-{ return fail(ctx, DXTEX_E_NOTIMPL, "dxtex_convert_device: not implemented yet"); }
-dxtex_hresult dxtex_resize(dxtex_ctx* ctx, const dxtex_image*, const dxtex_image*, uint32_t)
-{ return fail(ctx, DXTEX_E_NOTIMPL, "dxtex_resize: not implemented yet"); }
-dxtex_hresult dxtex_resize_device(dxtex_ctx* ctx, const dxtex_image*, const dxtex_image*, uint32_t)
-{ return fail(ctx, DXTEX_E_NOTIMPL, "dxtex_resize_device: not implemented yet"); }
-dxtex_hresult dxtex_compute_mse_device(dxtex_ctx* ctx, const dxtex_image*, const dxtex_image*, double*)
-{ return fail(ctx, DXTEX_E_NOTIMPL, "dxtex_compute_mse_device: not implemented yet"); }
+// ---- GenerateMipMaps / Resize / Convert ----------------------------------------------------------------------------------
+namespace
+{
+constexpr uint32_t kFilterModeMask = 0xF00000u, kFilterDitherMask = 0xF0000u;
+inline bool ispow2(size_t x) { return x != 0 && (x & (x - 1)) == 0; }
+
+struct LevelPair { const uint8_t* src; size_t srcPitch, sw, sh; uint8_t* dst; size_t dstPitch, dw, dh; };
+
+// Builds the triangle tables of every (src -> dst) pair into one device buffer, then launches the filter per pair.
+dxtex_hresult submit_resizes(dxtex_ctx* ctx, const std::vector<LevelPair>& pairs, int format, uint32_t mode, uint32_t flags, bool mipAlias)
+{
+    std::vector<size_t> base(pairs.size(), 0);
+    if (mode == DXTEX_FILTER_TRIANGLE)
+    {
+        std::vector<uint8_t>& host = ctx->triHost;
+        host.clear();
+        std::vector<uint32_t> ofs; std::vector<TriEntry> ent;
+        struct Slot { size_t ofsX, entX, ofsY, entY; };
+        std::vector<Slot> slots(pairs.size());
+        auto append = [&](const void* p, size_t bytes) { const size_t at = (host.size() + 15) & ~size_t(15); host.resize(at + bytes); std::memcpy(host.data() + at, p, bytes); return at; };
+        for (size_t i = 0; i < pairs.size(); ++i)
+        {
+            build_triangle_axis(pairs[i].sw, pairs[i].dw, (flags & DXTEX_FILTER_WRAP_U) != 0, ofs, ent);
+            slots[i].ofsX = append(ofs.data(), ofs.size() * 4); slots[i].entX = append(ent.data(), std::max<size_t>(1, ent.size()) * 8);
+            build_triangle_axis(pairs[i].sh, pairs[i].dh, (flags & DXTEX_FILTER_WRAP_V) != 0, ofs, ent);
+            slots[i].ofsY = append(ofs.data(), ofs.size() * 4); slots[i].entY = append(ent.data(), std::max<size_t>(1, ent.size()) * 8);
+        }
+        host.resize(host.size() + 16);
+        dxtex_hresult hr = ensure(ctx, &ctx->triBuf, &ctx->triBytes, host.size()); if (hr != DXTEX_S_OK) return hr;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->triBuf, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+        const uint8_t* d = static_cast<const uint8_t*>(ctx->triBuf);
+        for (size_t i = 0; i < pairs.size(); ++i)
+        {
+            TriangleTables t;
+            t.ofsX = reinterpret_cast<const uint32_t*>(d + slots[i].ofsX); t.entX = d + slots[i].entX;
+            t.ofsY = reinterpret_cast<const uint32_t*>(d + slots[i].ofsY); t.entY = d + slots[i].entY;
+            const LevelPair& p = pairs[i];
+            hipError_t e = launch_resize(p.src, p.srcPitch, uint32_t(p.sw), uint32_t(p.sh), p.dst, p.dstPitch, uint32_t(p.dw), uint32_t(p.dh),
+                                         format, mode, flags, mipAlias, &t, ctx->stream);
+            if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+        }
+        return DXTEX_S_OK;
+    }
+    const LevelPair* twoHigh = nullptr;      // box mips: the last source level that was 2 texels high (resize_box_kernel's stale tap)
+    for (const LevelPair& p : pairs)
+    {
+        if (mipAlias && p.sh >= 2) twoHigh = &p;
+        const bool stale = mipAlias && mode == DXTEX_FILTER_BOX && p.sh == 1 && p.sw > 1 && twoHigh;
+        hipError_t e = launch_resize(p.src, p.srcPitch, uint32_t(p.sw), uint32_t(p.sh), p.dst, p.dstPitch, uint32_t(p.dw), uint32_t(p.dh),
+                                     format, mode, flags, mipAlias, nullptr, ctx->stream,
+                                     stale ? twoHigh->src : nullptr, stale ? twoHigh->srcPitch : 0, stale ? uint32_t(twoHigh->sw) : 0u);
+        if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    }
+    return DXTEX_S_OK;
+}
+
+// GenerateMipMaps' checks and filter choice (DirectXTexMipmaps.cpp:2828-3017, non-WIC path)
+dxtex_hresult check_mips(dxtex_ctx* ctx, const dxtex_image* levels, size_t nlevels, uint32_t filter, uint32_t* mode)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!levels || nlevels <= 1) return fail(ctx, DXTEX_E_INVALIDARG, "need at least two levels");
+    const FmtInfo* f = format_info(levels[0].format);
+    if (f && (f->cls & FC_BC)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "cannot filter a block-compressed image");
+    if (!f) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "format is not supported by the MI355X path");
+    size_t w = levels[0].width, h = levels[0].height;
+    if (!w || !h) return fail(ctx, DXTEX_E_INVALIDARG, "empty image");
+    for (size_t i = 0; i < nlevels; ++i)
+    {
+        if (!levels[i].pixels) return fail(ctx, DXTEX_E_POINTER, "null pixels");
+        if (levels[i].width != w || levels[i].height != h || levels[i].format != levels[0].format)
+            return fail(ctx, DXTEX_E_INVALIDARG, "levels do not form a mip chain");
+        if (i + 1 < nlevels && w == 1 && h == 1) return fail(ctx, DXTEX_E_INVALIDARG, "too many levels");     // CalculateMipLevels
+        w = std::max<size_t>(1, w >> 1); h = std::max<size_t>(1, h >> 1);
+    }
+    uint32_t m = filter & kFilterModeMask;
+    if (!m) m = (ispow2(levels[0].width) && ispow2(levels[0].height)) ? DXTEX_FILTER_BOX : DXTEX_FILTER_LINEAR;
+    if (m != DXTEX_FILTER_POINT && m != DXTEX_FILTER_LINEAR && m != DXTEX_FILTER_CUBIC && m != DXTEX_FILTER_BOX && m != DXTEX_FILTER_TRIANGLE)
+        return fail(ctx, DXTEX_E_NOT_SUPPORTED, "unknown filter mode");
+    if (m == DXTEX_FILTER_BOX && (!ispow2(levels[0].width) || !ispow2(levels[0].height)))
+        return fail(ctx, DXTEX_E_FAIL, "the box filter needs power-of-two dimensions");                         // :1005
+    *mode = m;
+    return DXTEX_S_OK;
+}
+} // namespace
+
+dxtex_hresult dxtex_generate_mips_device(dxtex_ctx* ctx, const dxtex_image* levels, size_t nlevels, uint32_t filter)
+{
+    uint32_t mode = 0;
+    dxtex_hresult hr = check_mips(ctx, levels, nlevels, filter, &mode);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    std::vector<LevelPair> pairs;
+    for (size_t i = 1; i < nlevels; ++i)
+        pairs.push_back({ levels[i - 1].pixels, levels[i - 1].rowPitch, levels[i - 1].width, levels[i - 1].height,
+                          levels[i].pixels, levels[i].rowPitch, levels[i].width, levels[i].height });
+    time_begin(ctx);
+    hr = submit_resizes(ctx, pairs, levels[0].format, mode, filter, true);
+    time_end(ctx);
+    return hr;
+}
+
+dxtex_hresult dxtex_generate_mips(dxtex_ctx* ctx, const dxtex_image* levels, size_t nlevels, uint32_t filter)
+{
+    uint32_t mode = 0;
+    dxtex_hresult hr = check_mips(ctx, levels, nlevels, filter, &mode);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    // one device allocation holding the whole chain, 256-byte aligned levels
+    std::vector<size_t> at(nlevels);
+    size_t total = 0;
+    for (size_t i = 0; i < nlevels; ++i) { at[i] = total; total += (levels[i].rowPitch * levels[i].height + 255) & ~size_t(255); }
+    hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, total); if (hr != DXTEX_S_OK) return hr;
+    uint8_t* d = static_cast<uint8_t*>(ctx->stageIn);
+    HIP_TRY(ctx, hipMemcpyAsync(d, levels[0].pixels, levels[0].rowPitch * levels[0].height, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<LevelPair> pairs;
+    for (size_t i = 1; i < nlevels; ++i)
+        pairs.push_back({ d + at[i - 1], levels[i - 1].rowPitch, levels[i - 1].width, levels[i - 1].height,
+                          d + at[i], levels[i].rowPitch, levels[i].width, levels[i].height });
+    time_begin(ctx);
+    hr = submit_resizes(ctx, pairs, levels[0].format, mode, filter, true);
+    time_end(ctx);
+    if (hr != DXTEX_S_OK) return hr;
+    for (size_t i = 1; i < nlevels; ++i)
+        HIP_TRY(ctx, hipMemcpyAsync(levels[i].pixels, d + at[i], levels[i].rowPitch * levels[i].height, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DXTEX_S_OK;
+}
+
+namespace
+{
+// Resize's checks and filter choice (DirectXTexResize.cpp:807-843, :854-930)
+dxtex_hresult check_resize(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, uint32_t* mode)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!src || !dst) return fail(ctx, DXTEX_E_INVALIDARG, "null image");
+    if (!dst->width || !dst->height || !src->width || !src->height) return fail(ctx, DXTEX_E_INVALIDARG, "empty image");
+    if (src->width > 0xFFFFFFFFull || src->height > 0xFFFFFFFFull || dst->width > 0xFFFFFFFFull || dst->height > 0xFFFFFFFFull)
+        return fail(ctx, DXTEX_E_INVALIDARG, "image too large");
+    if (!src->pixels || !dst->pixels) return fail(ctx, DXTEX_E_POINTER, "null pixels");
+    const FmtInfo* f = format_info(src->format);
+    if (f && (f->cls & FC_BC)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "cannot resize a block-compressed image");
+    if (!f) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "format is not supported by the MI355X path");
+    if (src->format != dst->format) return fail(ctx, DXTEX_E_INVALIDARG, "Resize keeps the format");
+    uint32_t m = filter & kFilterModeMask;
+    const bool half = ((dst->width << 1) == src->width) && ((dst->height << 1) == src->height);
+    if (!m) m = half ? DXTEX_FILTER_BOX : DXTEX_FILTER_LINEAR;
+    if (m != DXTEX_FILTER_POINT && m != DXTEX_FILTER_LINEAR && m != DXTEX_FILTER_CUBIC && m != DXTEX_FILTER_BOX && m != DXTEX_FILTER_TRIANGLE)
+        return fail(ctx, DXTEX_E_NOT_SUPPORTED, "unknown filter mode");
+    if (m == DXTEX_FILTER_BOX && !half) return fail(ctx, DXTEX_E_FAIL, "the box filter needs an exact 2:1 reduction");   // :319-320
+    *mode = m;
+    return DXTEX_S_OK;
+}
+} // namespace
+
+dxtex_hresult dxtex_resize_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter)
+{
+    uint32_t mode = 0;
+    dxtex_hresult hr = check_resize(ctx, src, dst, filter, &mode);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    std::vector<LevelPair> pairs{ { src->pixels, src->rowPitch, src->width, src->height, dst->pixels, dst->rowPitch, dst->width, dst->height } };
+    time_begin(ctx);
+    hr = submit_resizes(ctx, pairs, src->format, mode, filter, false);
+    time_end(ctx);
+    return hr;
+}
+
+dxtex_hresult dxtex_resize(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter)
+{
+    uint32_t mode = 0;
+    dxtex_hresult hr = check_resize(ctx, src, dst, filter, &mode);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    const size_t srcBytes = src->rowPitch * src->height, dstBytes = dst->rowPitch * dst->height;
+    hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
+    hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<LevelPair> pairs{ { static_cast<const uint8_t*>(ctx->stageIn), src->rowPitch, src->width, src->height,
+                                    static_cast<uint8_t*>(ctx->stageOut), dst->rowPitch, dst->width, dst->height } };
+    time_begin(ctx);
+    hr = submit_resizes(ctx, pairs, src->format, mode, filter, false);
+    time_end(ctx);
+    if (hr != DXTEX_S_OK) return hr;
+    HIP_TRY(ctx, hipMemcpyAsync(dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DXTEX_S_OK;
+}
+
+namespace
+{
+// ConvertEx's checks (DirectXTexConvert.cpp:5107-5125); dithering is not implemented on this path
+dxtex_hresult check_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, ConvertPlan* plan)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!src || !dst) return fail(ctx, DXTEX_E_INVALIDARG, "null image");
+    if (src->format == dst->format) return fail(ctx, DXTEX_E_INVALIDARG, "source and destination formats are the same");
+    if (!src->pixels || !dst->pixels) return fail(ctx, DXTEX_E_POINTER, "null pixels");
+    const FmtInfo* in = format_info(src->format);
+    const FmtInfo* out = format_info(dst->format);
+    if ((in && (in->cls & FC_BC)) || (out && (out->cls & FC_BC))) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "Convert does not take block-compressed formats");
+    if (!in || !out) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "format is not supported by the MI355X path");
+    if (src->width != dst->width || src->height != dst->height) return fail(ctx, DXTEX_E_FAIL, "size mismatch");
+    if (filter & kFilterDitherMask) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "dithered conversion is not implemented on the MI355X path");
+    *plan = resolve_convert_plan(*in, *out, filter);
+    return DXTEX_S_OK;
+}
+} // namespace
+
+dxtex_hresult dxtex_convert_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float)
+{
+    ConvertPlan plan;
+    dxtex_hresult hr = check_convert(ctx, src, dst, filter, &plan);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    time_begin(ctx);
+    hipError_t e = launch_convert(src->pixels, src->rowPitch, src->format, dst->pixels, dst->rowPitch, dst->format,
+                                  uint32_t(src->width), uint32_t(src->height), plan, ctx->stream);
+    time_end(ctx);
+    if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    return DXTEX_S_OK;
+}
+
+dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float)
+{
+    ConvertPlan plan;
+    dxtex_hresult hr = check_convert(ctx, src, dst, filter, &plan);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    const size_t srcBytes = src->rowPitch * src->height, dstBytes = dst->rowPitch * dst->height;
+    hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
+    hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    time_begin(ctx);
+    hipError_t e = launch_convert(static_cast<const uint8_t*>(ctx->stageIn), src->rowPitch, src->format, static_cast<uint8_t*>(ctx->stageOut),
+                                  dst->rowPitch, dst->format, uint32_t(src->width), uint32_t(src->height), plan, ctx->stream);
+    time_end(ctx);
+    if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    HIP_TRY(ctx, hipMemcpyAsync(dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DXTEX_S_OK;
+}
+
+dxtex_hresult dxtex_compute_mse_device(dxtex_ctx* ctx, const dxtex_image* a, const dxtex_image* b, double mse[4])
+{
+    dxtex_hresult hr = check_pair(ctx, a, b);
+    if (hr != DXTEX_S_OK) return hr;
+    if (!mse) return fail(ctx, DXTEX_E_POINTER, "null result");
+    const FmtInfo* fa = format_info(a->format);
+    const FmtInfo* fb = format_info(b->format);
+    if (!fa || !fb || (fa->cls & FC_BC) || (fb->cls & FC_BC)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "ComputeMSE takes uncompressed images (decompress first)");
+    ScopedDevice sd(ctx->device);
+    hr = ensure(ctx, &ctx->mseBuf, &ctx->mseBytes, 4 * sizeof(double)); if (hr != DXTEX_S_OK) return hr;
+    hipError_t e = launch_mse(a->pixels, a->rowPitch, a->format, b->pixels, b->rowPitch, b->format, uint32_t(a->width), uint32_t(a->height),
+                              static_cast<double*>(ctx->mseBuf), ctx->stream);
+    if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    double sum[4];
+    HIP_TRY(ctx, hipMemcpyAsync(sum, ctx->mseBuf, sizeof(sum), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const double n = double(a->width) * double(a->height);
+    for (int c = 0; c < 4; ++c) mse[c] = sum[c] / n;
+    return DXTEX_S_OK;
+}
 
 dxtex_hresult dxtex_device_alloc(dxtex_ctx* ctx, size_t bytes, void** out)
 {

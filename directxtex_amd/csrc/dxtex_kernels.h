@@ -26,4 +26,22 @@ hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPi
 struct ConvertPlan;
 hipError_t launch_bc_decode(const uint8_t* src, uint64_t srcRowPitch, int srcFormat, uint8_t* dst, uint64_t dstRowPitch, int dstFormat,
                             uint32_t width, uint32_t height, const ConvertPlan& plan, hipStream_t stream);
+
+// Convert (ConvertCustom without dithering): same size, different format.
+hipError_t launch_convert(const uint8_t* src, uint64_t srcPitch, int srcFormat, uint8_t* dst, uint64_t dstPitch, int dstFormat,
+                          uint32_t width, uint32_t height, const ConvertPlan& plan, hipStream_t stream);
+
+// Resize / one mip level. filterMode = TEX_FILTER_POINT..TRIANGLE (already resolved, never 0); filterFlags carries the
+// wrap / mirror / sRGB bits. `tri` (device pointers) is required for TEX_FILTER_TRIANGLE: per destination column / row
+// ofs[i]..ofs[i+1] indexes (source index, fp32 weight bits) pairs, see triangle_filter.h. `staleLevel` (box mips only):
+// the last level of the chain that was 2 texels high, see resize_box_kernel.
+struct TriangleTables { const uint32_t* ofsX; const void* entX; const uint32_t* ofsY; const void* entY; };
+hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, uint32_t srcH, uint8_t* dst, uint64_t dstPitch,
+                         uint32_t dstW, uint32_t dstH, int format, uint32_t filterMode, uint32_t filterFlags, bool mipAlias,
+                         const TriangleTables* tri, hipStream_t stream,
+                         const uint8_t* staleLevel = nullptr, uint64_t stalePitch = 0, uint32_t staleW = 0);
+
+// ComputeMSE: out4 (device) receives the per-channel SUM of squared differences; divide by width * height on the host.
+hipError_t launch_mse(const uint8_t* a, uint64_t aPitch, int aFormat, const uint8_t* b, uint64_t bPitch, int bFormat,
+                      uint32_t width, uint32_t height, double* out4, hipStream_t stream);
 } // namespace dxtex

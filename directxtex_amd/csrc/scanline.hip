@@ -1,0 +1,350 @@
+// Scanline-layer kernels for gfx950: Convert, Resize / GenerateMipMaps filters, ComputeMSE.
+//
+//   reference                                                             here
+//   ConvertCustom (DirectXTexConvert.cpp:4804-4913, no-dither branch)      convert_kernel
+//   Resize{Point,Box,Linear,Cubic,Triangle}Filter (DirectXTexResize.cpp:255-803) and
+//   Generate2DMips{Point,Box,Linear,Cubic,Triangle}Filter (DirectXTexMipmaps.cpp:907-1602)   resize_*_kernel
+//   ComputeMSE_ (DirectXTexMisc.cpp:27-176)                                mse_kernel
+//
+// The reference walks scanlines through a float4 row buffer (LoadScanline -> filter -> StoreScanline). Here every
+// lane owns one destination texel and reads the source texels it needs straight from HBM/L2 with LoadScanline's
+// per-texel arithmetic; nothing is staged, so a level costs one read of the source footprint (the 2x2 / 4x4
+// neighbourhoods of adjacent lanes overlap in L1/L2) and one coalesced write of the destination. The per-texel
+// fp32 expressions are evaluated in exactly the reference's order (compile with -ffp-contract=off), so results are
+// bit-identical for the non-sRGB formats; sRGB goes through powf and is within 1 ulp per step.
+#include "dxtex_kernels.h"
+#include "dxtex_store.h"
+#include <algorithm>
+
+namespace dxtex
+{
+namespace
+{
+struct ImgView
+{
+    uint8_t* pixels;
+    uint64_t rowPitch;
+    uint32_t width, height;
+    int format;
+};
+
+struct ResizeArgs
+{
+    ImgView src, dst;
+    int srgbIn, srgbOut;    // LoadScanlineLinear / StoreScanlineLinear convert sRGB <-> linear around the filter
+    int wrapU, wrapV, mirrorU, mirrorV;
+    int mipAlias;           // Generate2DMipsBoxFilter: rows / columns alias when the source is 1 high / 1 wide
+    ImgView stale;          // ... and what its never-refreshed fourth row pointer still sees (see resize_box_kernel)
+    // triangle filter tables (device memory): per destination row / column a run of (source index, weight)
+    const uint32_t* triOfsX; const uint2* triX;
+    const uint32_t* triOfsY; const uint2* triY;
+};
+
+__device__ __forceinline__ Texel load_linear(const ImgView& v, uint32_t x, uint32_t y, int srgb)
+{
+    Texel t = load_texel(v.pixels + uint64_t(y) * v.rowPitch, x, v.format);
+    if (srgb) { t.r = srgb_to_linear1(t.r); t.g = srgb_to_linear1(t.g); t.b = srgb_to_linear1(t.b); }
+    return t;
+}
+
+__device__ __forceinline__ void store_linear(const ImgView& v, uint32_t x, uint32_t y, int srgb, Texel t)
+{
+    if (srgb) { t.r = linear_to_srgb1(t.r); t.g = linear_to_srgb1(t.g); t.b = linear_to_srgb1(t.b); }
+    store_texel(v.pixels + uint64_t(y) * v.rowPitch, x, v.format, t);
+}
+
+#define DXTEX_PER_CHANNEL(EXPR_R, EXPR_G, EXPR_B, EXPR_A) Texel{ (EXPR_R), (EXPR_G), (EXPR_B), (EXPR_A) }
+
+// ---- Convert -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) convert_kernel(ImgView src, ImgView dst, ConvertPlan plan)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (x >= src.width) return;
+    const Texel t = load_texel(src.pixels + uint64_t(y) * src.rowPitch, x, src.format);
+    store_texel(dst.pixels + uint64_t(y) * dst.rowPitch, x, dst.format, apply_plan(t, plan));
+}
+
+// ---- point (:255-309 / :907-987): 16.16 fixed-point stepping -----------------------------------------------------------------
+__global__ void __launch_bounds__(256) resize_point_kernel(ResizeArgs a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (x >= a.dst.width) return;
+    const uint64_t xinc = (uint64_t(a.src.width) << 16) / a.dst.width;
+    const uint64_t yinc = (uint64_t(a.src.height) << 16) / a.dst.height;
+    const uint32_t sx = uint32_t((uint64_t(x) * xinc) >> 16), sy = uint32_t((uint64_t(y) * yinc) >> 16);
+    const Texel t = load_texel(a.src.pixels + uint64_t(sy) * a.src.rowPitch, sx, a.src.format);
+    store_texel(a.dst.pixels + uint64_t(y) * a.dst.rowPitch, x, a.dst.format, t);
+}
+
+// ---- box (filters.h:31-37): (((p0 + p1) + p2) + p3) * 0.25 with p0 = (2x, 2y), p1 = (2x, 2y+1), p2 = (2x+1, 2y), p3 = (2x+1, 2y+1)
+__global__ void __launch_bounds__(256) resize_box_kernel(ResizeArgs a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (x >= a.dst.width) return;
+    // Generate2DMipsBoxFilter: a 1-high source reads the same row twice, a 1-wide source the same column (:1024-1033)
+    const bool oneRow = a.mipAlias && a.src.height <= 1, oneCol = a.mipAlias && a.src.width <= 1;
+    const uint32_t x0 = oneCol ? 0u : 2u * x, x1 = oneCol ? 0u : 2u * x + 1u;
+    const uint32_t y0 = oneRow ? 0u : 2u * y, y1 = oneRow ? 0u : 2u * y + 1u;
+    const Texel p0 = load_linear(a.src, x0, y0, a.srgbIn), p1 = load_linear(a.src, x0, y1, a.srgbIn);
+    const Texel p2 = load_linear(a.src, x1, y0, a.srgbIn);
+    // Reference quirk, reproduced: urow3 = urow1 + 1 is computed once, before the level loop (:1017), and is not
+    // re-pointed when a 1-high source makes urow1 alias urow0 (:1024-1027). For W x 1 sources with W > 1 the fourth
+    // tap therefore still reads the old second-row buffer: row 1 of the last level that was 2 texels high.
+    const bool staleTap = oneRow && !oneCol && a.stale.pixels != nullptr;
+    const Texel p3 = staleTap ? load_linear(a.stale, x1, 1u, a.srgbIn) : load_linear(a.src, x1, y1, a.srgbIn);
+    Texel r;
+    r.r = (((p0.r + p1.r) + p2.r) + p3.r) * 0.25f;
+    r.g = (((p0.g + p1.g) + p2.g) + p3.g) * 0.25f;
+    r.b = (((p0.b + p1.b) + p2.b) + p3.b) * 0.25f;
+    r.a = (((p0.a + p1.a) + p2.a) + p3.a) * 0.25f;
+    store_linear(a.dst, x, y, a.srgbOut, r);
+}
+
+// ---- linear (filters.h:57-104) ---------------------------------------------------------------------------------------------
+struct Lin { uint32_t u0, u1; float w0, w1; };
+__device__ __forceinline__ Lin linear_entry(uint32_t source, uint32_t dest, bool wrap, uint32_t u)
+{
+    const float scale = float(source) / float(dest);
+    const float srcB = (float(u) + 0.5f) * scale + 0.5f;
+    long long isrcB = (long long)srcB;
+    long long isrcA = isrcB - 1;
+    const float weight = 1.0f + float(isrcB) - srcB;
+    if (isrcA < 0) isrcA = wrap ? (long long)source - 1 : 0;
+    if ((unsigned long long)isrcB >= source) isrcB = wrap ? 0 : (long long)source - 1;
+    Lin e; e.u0 = uint32_t(isrcA); e.w0 = weight; e.u1 = uint32_t(isrcB); e.w1 = 1.0f - weight;
+    return e;
+}
+
+__global__ void __launch_bounds__(256) resize_linear_kernel(ResizeArgs a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (x >= a.dst.width) return;
+    const Lin tx = linear_entry(a.src.width, a.dst.width, a.wrapU != 0, x);
+    const Lin ty = linear_entry(a.src.height, a.dst.height, a.wrapV != 0, y);
+    const Texel p00 = load_linear(a.src, tx.u0, ty.u0, a.srgbIn), p01 = load_linear(a.src, tx.u1, ty.u0, a.srgbIn);
+    const Texel p10 = load_linear(a.src, tx.u0, ty.u1, a.srgbIn), p11 = load_linear(a.src, tx.u1, ty.u1, a.srgbIn);
+    // BILINEAR_INTERPOLATE: ((r0[u0]*wx0 + r0[u1]*wx1) * wy0) + ((r1[u0]*wx0 + r1[u1]*wx1) * wy1)
+#define DXTEX_BILERP(C) (((p00.C * tx.w0 + p01.C * tx.w1) * ty.w0) + ((p10.C * tx.w0 + p11.C * tx.w1) * ty.w1))
+    Texel r;
+    r.r = DXTEX_BILERP(r); r.g = DXTEX_BILERP(g); r.b = DXTEX_BILERP(b); r.a = DXTEX_BILERP(a);
+#undef DXTEX_BILERP
+    store_linear(a.dst, x, y, a.srgbOut, r);
+}
+
+// ---- cubic (filters.h:106-207) -----------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long bounduvw(long long u, long long maxu, bool wrap, bool mirror)
+{
+    if (wrap)
+    {
+        if (u < 0) u = maxu + u + 1;
+        else if (u > maxu) u = u - maxu - 1;
+    }
+    else if (mirror)
+    {
+        if (u < 0) u = (-u) - 1;
+        else if (u > maxu) u = maxu - (u - maxu - 1);
+    }
+    u = (u < maxu) ? u : maxu;
+    u = (u > 0) ? u : 0;
+    return u;
+}
+
+struct Cub { uint32_t u0, u1, u2, u3; float x; };
+__device__ __forceinline__ Cub cubic_entry(uint32_t source, uint32_t dest, bool wrap, bool mirror, uint32_t u)
+{
+    const float scale = float(source) / float(dest);
+    const float srcB = (float(u) + 0.5f) * scale - 0.5f;
+    const long long maxu = (long long)source - 1;
+    const long long iB = bounduvw((long long)srcB, maxu, wrap, mirror);
+    Cub e;
+    e.u0 = uint32_t(bounduvw(iB - 1, maxu, wrap, mirror));
+    e.u1 = uint32_t(iB);
+    e.u2 = uint32_t(bounduvw(iB + 1, maxu, wrap, mirror));
+    e.u3 = uint32_t(bounduvw(iB + 2, maxu, wrap, mirror));
+    e.x = srcB - float(iB);
+    return e;
+}
+
+// CUBIC_INTERPOLATE for one channel, operation for operation
+__device__ __forceinline__ float cubic1(float dx, float p0, float p1, float p2, float p3)
+{
+    const float a0 = p1;
+    const float d0 = p0 - a0, d2 = p2 - a0, d3 = p3 - a0;
+    float a1 = d2 - (1.0f / 3.0f) * d0;
+    a1 = a1 - (1.0f / 6.0f) * d3;
+    const float a2 = (1.0f / 2.0f) * d0 + (1.0f / 2.0f) * d2;
+    float a3 = (1.0f / 6.0f) * d3 - (1.0f / 6.0f) * d0;
+    a3 = a3 - (1.0f / 2.0f) * d2;
+    const float dx2 = dx * dx;
+    const float dx3 = dx2 * dx;
+    return ((a0 + a1 * dx) + a2 * dx2) + a3 * dx3;
+}
+
+__global__ void __launch_bounds__(256) resize_cubic_kernel(ResizeArgs a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (x >= a.dst.width) return;
+    const Cub tx = cubic_entry(a.src.width, a.dst.width, a.wrapU != 0, a.mirrorU != 0, x);
+    const Cub ty = cubic_entry(a.src.height, a.dst.height, a.wrapV != 0, a.mirrorV != 0, y);
+    const uint32_t ys[4] = { ty.u0, ty.u1, ty.u2, ty.u3 };
+    Texel c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+    {
+        const Texel p0 = load_linear(a.src, tx.u0, ys[r], a.srgbIn), p1 = load_linear(a.src, tx.u1, ys[r], a.srgbIn);
+        const Texel p2 = load_linear(a.src, tx.u2, ys[r], a.srgbIn), p3 = load_linear(a.src, tx.u3, ys[r], a.srgbIn);
+        c[r].r = cubic1(tx.x, p0.r, p1.r, p2.r, p3.r); c[r].g = cubic1(tx.x, p0.g, p1.g, p2.g, p3.g);
+        c[r].b = cubic1(tx.x, p0.b, p1.b, p2.b, p3.b); c[r].a = cubic1(tx.x, p0.a, p1.a, p2.a, p3.a);
+    }
+    Texel o;
+    o.r = cubic1(ty.x, c[0].r, c[1].r, c[2].r, c[3].r); o.g = cubic1(ty.x, c[0].g, c[1].g, c[2].g, c[3].g);
+    o.b = cubic1(ty.x, c[0].b, c[1].b, c[2].b, c[3].b); o.a = cubic1(ty.x, c[0].a, c[1].a, c[2].a, c[3].a);
+    store_linear(a.dst, x, y, a.srgbOut, o);
+}
+
+// ---- triangle (filters.h:209-419; accumulation order of DirectXTexMipmaps.cpp:1517-1542 / DirectXTexResize.cpp:730-760) ----------
+// The reference scatters every source texel into accumulation rows; the sum a destination texel receives is ordered
+// by (source row, source column, row-list entry, column-list entry). The host inverts the filter lists so that a lane
+// can gather its texel's contributions in that same order: acc = acc + src * (wy * wx), unfused.
+__global__ void __launch_bounds__(256) resize_triangle_kernel(ResizeArgs a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (x >= a.dst.width) return;
+    const uint32_t yb = a.triOfsY[y], ye = a.triOfsY[y + 1];
+    const uint32_t xb = a.triOfsX[x], xe = a.triOfsX[x + 1];
+    Texel acc; acc.r = acc.g = acc.b = acc.a = 0.0f;
+    uint32_t i = yb;
+    while (i < ye)
+    {
+        const uint32_t sy = a.triY[i].x;
+        uint32_t iEnd = i + 1;
+        while (iEnd < ye && a.triY[iEnd].x == sy) ++iEnd;
+        uint32_t k = xb;
+        while (k < xe)
+        {
+            const uint32_t sx = a.triX[k].x;
+            uint32_t kEnd = k + 1;
+            while (kEnd < xe && a.triX[kEnd].x == sx) ++kEnd;
+            const Texel p = load_linear(a.src, sx, sy, a.srgbIn);
+            for (uint32_t j = i; j < iEnd; ++j)
+            {
+                const float wy = __uint_as_float(a.triY[j].y);
+                for (uint32_t m = k; m < kEnd; ++m)
+                {
+                    const float w = wy * __uint_as_float(a.triX[m].y);
+                    acc.r = p.r * w + acc.r; acc.g = p.g * w + acc.g; acc.b = p.b * w + acc.b; acc.a = p.a * w + acc.a;
+                }
+            }
+            k = kEnd;
+        }
+        i = iEnd;
+    }
+    store_linear(a.dst, x, y, a.srgbOut, acc);
+}
+
+// ---- ComputeMSE: sum over texels of (v1 - v2)^2 per channel, accumulated in fp64 ----------------------------------------------
+__global__ void __launch_bounds__(256) mse_kernel(ImgView a, ImgView b, int srgbA, int srgbB, int ignoreAlpha, double* out)
+{
+    __shared__ double part[4][4];
+    double s[4] = { 0.0, 0.0, 0.0, 0.0 };
+    for (uint32_t y = blockIdx.y; y < a.height; y += gridDim.y)
+        for (uint32_t x = blockIdx.x * 256u + threadIdx.x; x < a.width; x += gridDim.x * 256u)
+        {
+            Texel p = load_texel(a.pixels + uint64_t(y) * a.rowPitch, x, a.format);
+            Texel q = load_texel(b.pixels + uint64_t(y) * b.rowPitch, x, b.format);
+            if (srgbA) { p.r = powf(p.r, 2.2f); p.g = powf(p.g, 2.2f); p.b = powf(p.b, 2.2f); p.a = powf(p.a, 2.2f); }     // XMVectorPow(v, g_Gamma22)
+            if (srgbB) { q.r = powf(q.r, 2.2f); q.g = powf(q.g, 2.2f); q.b = powf(q.b, 2.2f); q.a = powf(q.a, 2.2f); }
+            const float d[4] = { p.r - q.r, p.g - q.g, p.b - q.b, ignoreAlpha ? 0.0f : p.a - q.a };
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] += double(d[c]) * double(d[c]);
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        for (int d = 32; d >= 1; d >>= 1) s[c] += __shfl_xor(s[c], d);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { part[wave][0] = s[0]; part[wave][1] = s[1]; part[wave][2] = s[2]; part[wave][3] = s[3]; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        atomicAdd(&out[threadIdx.x], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+ImgView make_view(const uint8_t* p, uint64_t pitch, uint32_t w, uint32_t h, int fmt)
+{
+    ImgView v; v.pixels = const_cast<uint8_t*>(p); v.rowPitch = pitch; v.width = w; v.height = h; v.format = fmt;
+    return v;
+}
+
+bool srgb_linear_format(int format)
+{
+    return format == FMT_R8G8B8A8_UNORM_SRGB || format == FMT_B8G8R8A8_UNORM_SRGB || format == FMT_B8G8R8X8_UNORM_SRGB;
+}
+
+bool can_srgb(int format)
+{
+    // LoadScanlineLinear / StoreScanlineLinear: "can't treat A8, XR, Depth, SNORM, UINT, or SINT as sRGB" (:2842-2858)
+    switch (format)
+    {
+    case FMT_R32G32B32A32_FLOAT: case FMT_R16G16B16A16_FLOAT: case FMT_R16G16B16A16_UNORM: case FMT_R32G32_FLOAT:
+    case FMT_R8G8B8A8_UNORM: case FMT_R16G16_FLOAT: case FMT_R16G16_UNORM: case FMT_R32_FLOAT: case FMT_R8G8_UNORM:
+    case FMT_R16_FLOAT: case FMT_R16_UNORM: case FMT_R8_UNORM: case FMT_B8G8R8A8_UNORM: case FMT_B8G8R8X8_UNORM:
+        return true;
+    default:
+        return srgb_linear_format(format);
+    }
+}
+} // namespace
+
+hipError_t launch_convert(const uint8_t* src, uint64_t srcPitch, int srcFormat, uint8_t* dst, uint64_t dstPitch, int dstFormat,
+                          uint32_t width, uint32_t height, const ConvertPlan& plan, hipStream_t stream)
+{
+    if (!width || !height) return hipSuccess;
+    hipLaunchKernelGGL(convert_kernel, dim3((width + 255) / 256, height), dim3(256), 0, stream,
+                       make_view(src, srcPitch, width, height, srcFormat), make_view(dst, dstPitch, width, height, dstFormat), plan);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, uint32_t srcH, uint8_t* dst, uint64_t dstPitch,
+                         uint32_t dstW, uint32_t dstH, int format, uint32_t filterMode, uint32_t filterFlags, bool mipAlias,
+                         const TriangleTables* tri, hipStream_t stream, const uint8_t* staleLevel, uint64_t stalePitch, uint32_t staleW)
+{
+    if (!dstW || !dstH) return hipSuccess;
+    ResizeArgs a;
+    a.stale = make_view(staleLevel, stalePitch, staleW, 2, format);
+    a.src = make_view(src, srcPitch, srcW, srcH, format);
+    a.dst = make_view(dst, dstPitch, dstW, dstH, format);
+    // sRGB formats filter in linear space; TEX_FILTER_SRGB forces it for the other colour formats (:2803-2945)
+    const bool wantIn = srgb_linear_format(format) || (filterFlags & 0x1000000u), wantOut = srgb_linear_format(format) || (filterFlags & 0x2000000u);
+    a.srgbIn = (can_srgb(format) && wantIn) ? 1 : 0;
+    a.srgbOut = (can_srgb(format) && wantOut) ? 1 : 0;
+    a.wrapU = (filterFlags & 0x1u) != 0; a.wrapV = (filterFlags & 0x2u) != 0;
+    a.mirrorU = (filterFlags & 0x10u) != 0; a.mirrorV = (filterFlags & 0x20u) != 0;
+    a.mipAlias = mipAlias ? 1 : 0;
+    a.triOfsX = tri ? tri->ofsX : nullptr; a.triX = tri ? reinterpret_cast<const uint2*>(tri->entX) : nullptr;
+    a.triOfsY = tri ? tri->ofsY : nullptr; a.triY = tri ? reinterpret_cast<const uint2*>(tri->entY) : nullptr;
+    const dim3 grid((dstW + 255) / 256, dstH), block(256);
+    switch (filterMode)
+    {
+    case 0x100000u: hipLaunchKernelGGL(resize_point_kernel, grid, block, 0, stream, a); break;
+    case 0x200000u: hipLaunchKernelGGL(resize_linear_kernel, grid, block, 0, stream, a); break;
+    case 0x300000u: hipLaunchKernelGGL(resize_cubic_kernel, grid, block, 0, stream, a); break;
+    case 0x400000u: hipLaunchKernelGGL(resize_box_kernel, grid, block, 0, stream, a); break;
+    case 0x500000u: hipLaunchKernelGGL(resize_triangle_kernel, grid, block, 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_mse(const uint8_t* a, uint64_t aPitch, int aFormat, const uint8_t* b, uint64_t bPitch, int bFormat,
+                      uint32_t width, uint32_t height, double* out4, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(out4, 0, 4 * sizeof(double), stream);
+    if (e != hipSuccess) return e;
+    if (!width || !height) return hipSuccess;
+    const bool ignoreAlpha = aFormat == FMT_B8G8R8X8_UNORM || aFormat == FMT_B8G8R8X8_UNORM_SRGB || bFormat == FMT_B8G8R8X8_UNORM || bFormat == FMT_B8G8R8X8_UNORM_SRGB;
+    const uint32_t gx = std::min<uint32_t>((width + 255) / 256, 64), gy = std::min<uint32_t>(height, 1024);
+    hipLaunchKernelGGL(mse_kernel, dim3(gx, gy), dim3(256), 0, stream, make_view(a, aPitch, width, height, aFormat),
+                       make_view(b, bPitch, width, height, bFormat), srgb_linear_format(aFormat) ? 1 : 0, srgb_linear_format(bFormat) ? 1 : 0,
+                       ignoreAlpha ? 1 : 0, out4);
+    return hipGetLastError();
+}
+} // namespace dxtex

@@ -34,6 +34,16 @@ def _load_ref():
         lib.dxtex_ref_decode_blocks.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         lib.dxtex_ref_decode_blocks.restype = ctypes.c_int
         lib.dxtex_ref_num_threads.restype = ctypes.c_int
+        vp, sz, i32p = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int32)
+        lib.dxtex_ref_compress.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_int, ctypes.c_uint32, ctypes.c_float, vp, sz, i32p]
+        lib.dxtex_ref_decompress.argtypes = [vp, sz, sz, ctypes.c_int, ctypes.c_int, vp, sz, i32p]
+        lib.dxtex_ref_generate_mips.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_uint32, sz, vp, sz, i32p]
+        lib.dxtex_ref_resize.argtypes = [vp, sz, sz, ctypes.c_int, sz, sz, sz, ctypes.c_uint32, vp, sz, i32p]
+        lib.dxtex_ref_convert.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_int, ctypes.c_uint32, ctypes.c_float, vp, sz, i32p]
+        for f in (lib.dxtex_ref_compress, lib.dxtex_ref_decompress, lib.dxtex_ref_generate_mips, lib.dxtex_ref_resize, lib.dxtex_ref_convert):
+            f.restype = ctypes.c_int64
+        lib.dxtex_ref_compute_mse.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, sz, sz, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        lib.dxtex_ref_compute_mse.restype = ctypes.c_int
         _ref = lib
     return _ref
 
@@ -259,3 +269,84 @@ def psnr_rgb(a, b):
     m = compute_mse(a, b)
     s = float(m[0] + m[1] + m[2])
     return float("inf") if s == 0 else 10.0 * np.log10(3.0 / s)
+
+
+# ---- the reference's own image drivers (oracle/_ref: DirectXTexCompress / Mipmaps / Resize / Misc.cpp compiled in place) ----
+
+class RefError(RuntimeError):
+    def __init__(self, hr):
+        self.hresult = hr & 0xFFFFFFFF
+        super().__init__(f"reference returned HRESULT 0x{self.hresult:08X}")
+
+
+BPP = {2: 128, 10: 64, 11: 64, 16: 64, 28: 32, 29: 32, 31: 32, 34: 32, 35: 32, 41: 32, 49: 16, 51: 16, 54: 16, 56: 16, 61: 8, 63: 8, 65: 8,
+       87: 32, 88: 32, 91: 32, 93: 32}
+
+
+def image_bytes(fmt, w, h):
+    if fmt in BC_BLOCK_BYTES:
+        return max(1, (w + 3) // 4) * max(1, (h + 3) // 4) * BC_BLOCK_BYTES[fmt]
+    return (w * BPP[fmt] + 7) // 8 * h
+
+
+def _run(fn, out_bytes, *args):
+    out = np.zeros(out_bytes, np.uint8)
+    hr = ctypes.c_int32(0)
+    n = fn(*args, out.ctypes.data, out.nbytes, ctypes.byref(hr))
+    if n < 0:
+        raise RefError(hr.value if n == -1 else 0x8007000E)
+    return out[:n]
+
+
+def ref_compress_image(pixels, width, height, src_fmt, dst_fmt, flags=0, threshold=0.5, row_pitch=0):
+    """DirectX::Compress of the reference (DirectXTexCompress.cpp:643-760) -> tight BC payload."""
+    px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
+    return _run(_load_ref().dxtex_ref_compress, image_bytes(dst_fmt, width, height), px.ctypes.data, width, height, src_fmt, row_pitch, dst_fmt, flags, threshold)
+
+
+def ref_decompress_image(payload, width, height, bc_fmt, dst_fmt):
+    """DirectX::Decompress of the reference (DirectXTexCompress.cpp:852-910)."""
+    px = np.ascontiguousarray(payload, np.uint8).reshape(-1)
+    return _run(_load_ref().dxtex_ref_decompress, image_bytes(dst_fmt, width, height), px.ctypes.data, width, height, bc_fmt, dst_fmt)
+
+
+def mip_sizes(width, height, levels):
+    out = []
+    for _ in range(levels):
+        out.append((width, height))
+        width, height = max(1, width >> 1), max(1, height >> 1)
+    return out
+
+
+def ref_generate_mips(pixels, width, height, fmt, filter_flags, levels):
+    """DirectX::GenerateMipMaps (DirectXTexMipmaps.cpp:2828-3017, custom filters) -> list of tight per-level buffers."""
+    px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
+    sizes = mip_sizes(width, height, levels)
+    blob = _run(_load_ref().dxtex_ref_generate_mips, sum(image_bytes(fmt, w, h) for w, h in sizes), px.ctypes.data, width, height, fmt, 0, filter_flags, levels)
+    res, at = [], 0
+    for w, h in sizes:
+        n = image_bytes(fmt, w, h)
+        res.append(blob[at:at + n].copy()); at += n
+    return res
+
+
+def ref_resize(pixels, width, height, fmt, new_width, new_height, filter_flags):
+    """DirectX::Resize (DirectXTexResize.cpp:854-930, custom filters)."""
+    px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
+    return _run(_load_ref().dxtex_ref_resize, image_bytes(fmt, new_width, new_height), px.ctypes.data, width, height, fmt, 0, new_width, new_height, filter_flags)
+
+
+def ref_convert(pixels, width, height, src_fmt, dst_fmt, filter_flags=0, threshold=0.5):
+    """ConvertCustom's plain branch (DirectXTexConvert.cpp:4887-4909) over oracle/restate/scanline.cpp."""
+    px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
+    return _run(_load_ref().dxtex_ref_convert, image_bytes(dst_fmt, width, height), px.ctypes.data, width, height, src_fmt, 0, dst_fmt, filter_flags, threshold)
+
+
+def ref_compute_mse(a, fmt_a, b, fmt_b, width, height):
+    """DirectX::ComputeMSE (DirectXTexMisc.cpp:27-176, fp32 accumulation) -> per-channel MSE (4,) float32."""
+    pa = np.ascontiguousarray(a).view(np.uint8).reshape(-1); pb = np.ascontiguousarray(b).view(np.uint8).reshape(-1)
+    m = ctypes.c_float(0); v = (ctypes.c_float * 4)()
+    hr = _load_ref().dxtex_ref_compute_mse(pa.ctypes.data, fmt_a, pb.ctypes.data, fmt_b, width, height, ctypes.byref(m), v)
+    if hr != 0:
+        raise RefError(hr)
+    return np.array(list(v), np.float32)

@@ -5,6 +5,8 @@
 #include "DirectXTexP.h"
 #include "BC.h"
 #include <omp.h>
+#include <vector>
+#include <algorithm>
 
 using namespace DirectX;
 
@@ -90,5 +92,100 @@ extern "C"
             memcpy(rgba + size_t(nb) * 64, temp, sizeof(temp));
         }
         return 0;
+    }
+
+    // ---- image-level drivers: the reference's own Compress / Decompress / GenerateMipMaps / Resize / ComputeMSE
+    // (DirectXTexCompress.cpp, DirectXTexMipmaps.cpp, DirectXTexResize.cpp, DirectXTexMisc.cpp compiled in place) on top
+    // of oracle/restate/scanline.cpp. Results are copied out level by level with tight pitch.
+    static Image make_image(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t rowPitch)
+    {
+        Image img;
+        img.width = w; img.height = h; img.format = DXGI_FORMAT(fmt);
+        size_t rp = 0, sp = 0;
+        ComputePitch(img.format, w, h, rp, sp);
+        img.rowPitch = rowPitch ? rowPitch : rp;
+        const size_t rows = IsCompressed(img.format) ? std::max<size_t>(1, (h + 3) / 4) : h;
+        img.slicePitch = img.rowPitch * rows;
+        img.pixels = const_cast<uint8_t*>(pixels);
+        return img;
+    }
+
+    static int64_t copy_out(const ScratchImage& si, uint8_t* out, size_t capacity)
+    {
+        size_t at = 0;
+        for (size_t i = 0; i < si.GetImageCount(); ++i)
+        {
+            const Image& im = si.GetImages()[i];
+            size_t rp = 0, sp = 0;
+            ComputePitch(im.format, im.width, im.height, rp, sp);
+            if (at + sp > capacity) return -2;
+            const size_t rows = sp / rp;
+            for (size_t y = 0; y < rows; ++y) memcpy(out + at + y * rp, im.pixels + y * im.rowPitch, rp);
+            at += sp;
+        }
+        return int64_t(at);
+    }
+
+    // returns bytes written (>= 0) or the negated HRESULT-ish failure: -1 = call failed (hr in *hrOut), -2 = capacity
+    int64_t dxtex_ref_compress(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t rowPitch, int dstFmt, uint32_t flags, float threshold,
+                               uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        ScratchImage si;
+        const HRESULT hr = Compress(make_image(pixels, w, h, fmt, rowPitch), DXGI_FORMAT(dstFmt), TEX_COMPRESS_FLAGS(flags), threshold, si);
+        if (hrOut) *hrOut = int32_t(hr);
+        return FAILED(hr) ? -1 : copy_out(si, out, capacity);
+    }
+
+    int64_t dxtex_ref_decompress(const uint8_t* payload, size_t w, size_t h, int fmt, int dstFmt, uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        ScratchImage si;
+        const HRESULT hr = Decompress(make_image(payload, w, h, fmt, 0), DXGI_FORMAT(dstFmt), si);
+        if (hrOut) *hrOut = int32_t(hr);
+        return FAILED(hr) ? -1 : copy_out(si, out, capacity);
+    }
+
+    int64_t dxtex_ref_generate_mips(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t rowPitch, uint32_t filter, size_t levels,
+                                    uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        ScratchImage si;
+        const HRESULT hr = GenerateMipMaps(make_image(pixels, w, h, fmt, rowPitch), TEX_FILTER_FLAGS(filter), levels, si, false);
+        if (hrOut) *hrOut = int32_t(hr);
+        return FAILED(hr) ? -1 : copy_out(si, out, capacity);
+    }
+
+    int64_t dxtex_ref_resize(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t rowPitch, size_t nw, size_t nh, uint32_t filter,
+                             uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        ScratchImage si;
+        const HRESULT hr = Resize(make_image(pixels, w, h, fmt, rowPitch), nw, nh, TEX_FILTER_FLAGS(filter), si);
+        if (hrOut) *hrOut = int32_t(hr);
+        return FAILED(hr) ? -1 : copy_out(si, out, capacity);
+    }
+
+    // ConvertCustom's no-dither branch (DirectXTexConvert.cpp:4887-4909), restated: DirectXTexConvert.cpp is not compiled
+    int64_t dxtex_ref_convert(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t rowPitch, int dstFmt, uint32_t filter, float threshold,
+                              uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        const Image src = make_image(pixels, w, h, fmt, rowPitch);
+        size_t rp = 0, sp = 0;
+        ComputePitch(DXGI_FORMAT(dstFmt), w, h, rp, sp);
+        if (hrOut) *hrOut = 0;
+        if (sp > capacity) return -2;
+        std::vector<XMVECTOR> row(w);
+        for (size_t y = 0; y < h; ++y)
+        {
+            if (!Internal::LoadScanline(row.data(), w, src.pixels + y * src.rowPitch, src.rowPitch, src.format)) { if (hrOut) *hrOut = int32_t(E_FAIL); return -1; }
+            Internal::ConvertScanline(row.data(), w, DXGI_FORMAT(dstFmt), src.format, TEX_FILTER_FLAGS(filter));
+            if (!Internal::StoreScanline(out + y * rp, rp, DXGI_FORMAT(dstFmt), row.data(), w, threshold)) { if (hrOut) *hrOut = int32_t(E_FAIL); return -1; }
+        }
+        return int64_t(sp);
+    }
+
+    int dxtex_ref_compute_mse(const uint8_t* a, int fmtA, const uint8_t* b, int fmtB, size_t w, size_t h, float* mse, float* mseV)
+    {
+        float m = 0.f;
+        const HRESULT hr = ComputeMSE(make_image(a, w, h, fmtA, 0), make_image(b, w, h, fmtB, 0), m, mseV, CMSE_DEFAULT);
+        if (mse) *mse = m;
+        return int(hr);
     }
 }

@@ -1,0 +1,450 @@
+// TEST INFRASTRUCTURE ONLY. CPU restatement of the reference's scanline layer - LoadScanline / StoreScanline /
+// LoadScanlineLinear / StoreScanlineLinear / ConvertScanline of DirectXTexConvert.cpp - for the formats the MI355X
+// path handles, with the reference's own signatures (DirectXTexP.h:401-441) so that the reference's real drivers
+// (DirectXTexMipmaps.cpp, DirectXTexResize.cpp, DirectXTexMisc.cpp, DirectXTexCompress.cpp, compiled in place into
+// oracle/_ref) link against it. DirectXTexConvert.cpp itself cannot be compiled here: it is 163 DirectXMath symbols
+// deep and DirectXMath is not vendored in /root/reference.
+//
+// PARITY UNPINNED at this layer: the packed loads / stores are DirectXMath's; what is written below is its SSE2
+// behaviour as published (see directxtex_amd/csrc/dxtex_store.h for the list), and the reference holds no test
+// vectors for it. Every case cites the reference lines it follows.
+#include "DirectXTexP.h"
+
+#include <cmath>
+#include <cstring>
+
+using namespace DirectX;
+
+namespace
+{
+    inline float clampf(float v, float lo, float hi) { v = (v > lo) ? v : lo; return (v < hi) ? v : hi; }   // maxps, minps
+
+    // XMConvertHalfToFloat / XMConvertFloatToHalf come from the shim (IEEE, round to nearest even).
+    inline uint8_t store_ubn_biased(float v)
+    {
+        // XMVectorAdd(v, g_8BitBiasV) then XMStoreUByteN4: clamp, * 255, truncate (DirectXTexConvert.cpp:1759-1772)
+        float s = v + (0.5f / 255.f);
+        s = clampf(s, 0.f, 1.f);
+        return uint8_t(uint32_t(s * 255.0f));
+    }
+    inline uint8_t store_ubn2(float v) { const float s = clampf(v, 0.f, 1.f); return uint8_t(uint32_t(s * 255.0f + 0.5f)); }
+    inline int8_t store_bn(float v) { const float s = clampf(v, -1.f, 1.f); return int8_t(int32_t(nearbyintf(s * 127.0f))); }
+    inline uint16_t store_usn(float v) { const float s = clampf(v, 0.f, 1.f); return uint16_t(uint32_t(nearbyintf(s * 65535.0f))); }
+    inline uint16_t store_half(float v) { return PackedVector::XMConvertFloatToHalf(clampf(v, -65504.f, 65504.f)); }
+    inline float loadh(uint16_t h) { return PackedVector::XMConvertHalfToFloat(h); }
+
+    inline float srgb_to_rgb(float v)
+    {
+        // XMColorSRGBToRGB
+        const float s = clampf(v, 0.f, 1.f);
+        const float lo = s / 12.92f;
+        const float hi = powf((s + 0.055f) / 1.055f, 2.4f);
+        return (s > 0.04045f) ? hi : lo;
+    }
+    inline float rgb_to_srgb(float v)
+    {
+        // XMColorRGBToSRGB
+        const float s = clampf(v, 0.f, 1.f);
+        const float lo = s * 12.92f;
+        const float hi = 1.055f * powf(s, 1.0f / 2.4f) - 0.055f;
+        return (s > 0.0031308f) ? hi : lo;
+    }
+
+    enum : uint32_t { C_UNORM = 1, C_SNORM = 2, C_FLOAT = 4, C_R = 0x10, C_G = 0x20, C_B = 0x40, C_A = 0x80, C_BC = 8 };
+    // the CONVF_* words of g_ConvertTable (DirectXTexConvert.cpp:2960-3047), reduced to what the supported formats use
+    uint32_t conv_flags(DXGI_FORMAT f)
+    {
+        switch (int(f))
+        {
+        case DXGI_FORMAT_R32G32B32A32_FLOAT: case DXGI_FORMAT_R16G16B16A16_FLOAT: return C_FLOAT | C_R | C_G | C_B | C_A;
+        case DXGI_FORMAT_R16G16B16A16_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB:
+        case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB: return C_UNORM | C_R | C_G | C_B | C_A;
+        case DXGI_FORMAT_B8G8R8X8_UNORM: case DXGI_FORMAT_B8G8R8X8_UNORM_SRGB: return C_UNORM | C_R | C_G | C_B;
+        case DXGI_FORMAT_R8G8B8A8_SNORM: return C_SNORM | C_R | C_G | C_B | C_A;
+        case DXGI_FORMAT_R32G32_FLOAT: case DXGI_FORMAT_R16G16_FLOAT: return C_FLOAT | C_R | C_G;
+        case DXGI_FORMAT_R16G16_UNORM: case DXGI_FORMAT_R8G8_UNORM: return C_UNORM | C_R | C_G;
+        case DXGI_FORMAT_R8G8_SNORM: return C_SNORM | C_R | C_G;
+        case DXGI_FORMAT_R32_FLOAT: case DXGI_FORMAT_R16_FLOAT: return C_FLOAT | C_R;
+        case DXGI_FORMAT_R16_UNORM: case DXGI_FORMAT_R8_UNORM: return C_UNORM | C_R;
+        case DXGI_FORMAT_R8_SNORM: return C_SNORM | C_R;
+        case DXGI_FORMAT_A8_UNORM: return C_UNORM | C_A;
+        case DXGI_FORMAT_BC1_UNORM: case DXGI_FORMAT_BC1_UNORM_SRGB: case DXGI_FORMAT_BC2_UNORM: case DXGI_FORMAT_BC2_UNORM_SRGB:
+        case DXGI_FORMAT_BC3_UNORM: case DXGI_FORMAT_BC3_UNORM_SRGB: case DXGI_FORMAT_BC7_UNORM: case DXGI_FORMAT_BC7_UNORM_SRGB:
+            return C_UNORM | C_BC | C_R | C_G | C_B | C_A;
+        case DXGI_FORMAT_BC4_UNORM: return C_UNORM | C_BC | C_R;
+        case DXGI_FORMAT_BC4_SNORM: return C_SNORM | C_BC | C_R;
+        case DXGI_FORMAT_BC5_UNORM: return C_UNORM | C_BC | C_R | C_G;
+        case DXGI_FORMAT_BC5_SNORM: return C_SNORM | C_BC | C_R | C_G;
+        case DXGI_FORMAT_BC6H_UF16: case DXGI_FORMAT_BC6H_SF16: return C_FLOAT | C_BC | C_R | C_G | C_B | C_A;
+        default: return 0;
+        }
+    }
+
+    bool is_srgb_format(DXGI_FORMAT f)
+    {
+        switch (int(f))
+        {
+        case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB: case DXGI_FORMAT_BC1_UNORM_SRGB: case DXGI_FORMAT_BC2_UNORM_SRGB: case DXGI_FORMAT_BC3_UNORM_SRGB:
+        case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB: case DXGI_FORMAT_B8G8R8X8_UNORM_SRGB: case DXGI_FORMAT_BC7_UNORM_SRGB: return true;
+        default: return false;
+        }
+    }
+
+    // the format list of LoadScanlineLinear / StoreScanlineLinear (:2813-2858, :2890-2928), supported subset
+    bool linear_filter_srgb_ok(DXGI_FORMAT f)
+    {
+        switch (int(f))
+        {
+        case DXGI_FORMAT_R32G32B32A32_FLOAT: case DXGI_FORMAT_R16G16B16A16_FLOAT: case DXGI_FORMAT_R16G16B16A16_UNORM: case DXGI_FORMAT_R32G32_FLOAT:
+        case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R16G16_FLOAT: case DXGI_FORMAT_R16G16_UNORM: case DXGI_FORMAT_R32_FLOAT:
+        case DXGI_FORMAT_R8G8_UNORM: case DXGI_FORMAT_R16_FLOAT: case DXGI_FORMAT_R16_UNORM: case DXGI_FORMAT_R8_UNORM:
+        case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8X8_UNORM: return true;
+        default: return false;
+        }
+    }
+}
+
+// ---- LoadScanline (DirectXTexConvert.cpp:779-1619) ---------------------------------------------------------------------------
+bool DirectX::Internal::LoadScanline(XMVECTOR* pDestination, size_t count, const void* pSource, size_t size, DXGI_FORMAT format) noexcept
+{
+    if (!pDestination || !count || !pSource || !size) return false;
+    const uint8_t* s = static_cast<const uint8_t*>(pSource);
+    auto texels = [&](size_t bytes) { const size_t n = size / bytes; return n < count ? n : count; };
+    switch (int(format))
+    {
+    case DXGI_FORMAT_R32G32B32A32_FLOAT:        // :798-803
+    {
+        const size_t n = texels(16);
+        memcpy(pDestination, s, n * 16);
+        return true;
+    }
+    case DXGI_FORMAT_R16G16B16A16_FLOAT:        // XMLoadHalf4, :820-821
+        for (size_t i = 0, n = texels(8); i < n; ++i)
+        {
+            const uint16_t* h = reinterpret_cast<const uint16_t*>(s + i * 8);
+            pDestination[i] = XMVectorSet(loadh(h[0]), loadh(h[1]), loadh(h[2]), loadh(h[3]));
+        }
+        return true;
+    case DXGI_FORMAT_R16G16B16A16_UNORM:        // XMLoadUShortN4
+        for (size_t i = 0, n = texels(8); i < n; ++i)
+        {
+            const uint16_t* h = reinterpret_cast<const uint16_t*>(s + i * 8);
+            pDestination[i] = XMVectorSet(float(h[0]) * (1.0f / 65535.0f), float(h[1]) * (1.0f / 65535.0f), float(h[2]) * (1.0f / 65535.0f), float(h[3]) * (1.0f / 65535.0f));
+        }
+        return true;
+    case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB:      // XMLoadUByteN4, :909-911
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const uint8_t* b = s + i * 4;
+            pDestination[i] = XMVectorSet(float(b[0]) * (1.0f / 255.0f), float(b[1]) * (1.0f / 255.0f), float(b[2]) * (1.0f / 255.0f), float(b[3]) * (1.0f / 255.0f));
+        }
+        return true;
+    case DXGI_FORMAT_R8G8B8A8_SNORM:            // XMLoadByteN4, :916-917
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const int8_t* b = reinterpret_cast<const int8_t*>(s + i * 4);
+            float v[4];
+            for (int c = 0; c < 4; ++c) { v[c] = float(b[c]) * (1.0f / 127.0f); v[c] = (v[c] > -1.0f) ? v[c] : -1.0f; }
+            pDestination[i] = XMVectorSet(v[0], v[1], v[2], v[3]);
+        }
+        return true;
+    case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB:      // :1260-1273
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const uint8_t* b = s + i * 4;
+            pDestination[i] = XMVectorSet(float(b[2]) * (1.0f / 255.0f), float(b[1]) * (1.0f / 255.0f), float(b[0]) * (1.0f / 255.0f), float(b[3]) * (1.0f / 255.0f));
+        }
+        return true;
+    case DXGI_FORMAT_B8G8R8X8_UNORM: case DXGI_FORMAT_B8G8R8X8_UNORM_SRGB:      // :1275-1289
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const uint8_t* b = s + i * 4;
+            pDestination[i] = XMVectorSet(float(b[2]) * (1.0f / 255.0f), float(b[1]) * (1.0f / 255.0f), float(b[0]) * (1.0f / 255.0f), 1.0f);
+        }
+        return true;
+    case DXGI_FORMAT_R32G32_FLOAT:              // LOAD_SCANLINE2(XMFLOAT2, ..., g_XMIdentityR3)
+        for (size_t i = 0, n = texels(8); i < n; ++i)
+        {
+            const float* f = reinterpret_cast<const float*>(s + i * 8);
+            pDestination[i] = XMVectorSet(f[0], f[1], 0.f, 1.f);
+        }
+        return true;
+    case DXGI_FORMAT_R16G16_FLOAT:              // :922-923
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const uint16_t* h = reinterpret_cast<const uint16_t*>(s + i * 4);
+            pDestination[i] = XMVectorSet(loadh(h[0]), loadh(h[1]), 0.f, 1.f);
+        }
+        return true;
+    case DXGI_FORMAT_R16G16_UNORM:              // :925-926
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const uint16_t* h = reinterpret_cast<const uint16_t*>(s + i * 4);
+            pDestination[i] = XMVectorSet(float(h[0]) * (1.0f / 65535.0f), float(h[1]) * (1.0f / 65535.0f), 0.f, 1.f);
+        }
+        return true;
+    case DXGI_FORMAT_R32_FLOAT:                 // :938-950
+        for (size_t i = 0, n = texels(4); i < n; ++i) pDestination[i] = XMVectorSet(reinterpret_cast<const float*>(s)[i], 0.f, 0.f, 1.f);
+        return true;
+    case DXGI_FORMAT_R8G8_UNORM:                // XMLoadUByteN2, :1028-1029
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+            pDestination[i] = XMVectorSet(float(s[i * 2]) * (1.0f / 255.0f), float(s[i * 2 + 1]) * (1.0f / 255.0f), 0.f, 1.f);
+        return true;
+    case DXGI_FORMAT_R8G8_SNORM:                // XMLoadByteN2, :1034-1035
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            float x = float(int8_t(s[i * 2])) * (1.0f / 127.0f), y = float(int8_t(s[i * 2 + 1])) * (1.0f / 127.0f);
+            x = (x > -1.0f) ? x : -1.0f; y = (y > -1.0f) ? y : -1.0f;
+            pDestination[i] = XMVectorSet(x, y, 0.f, 1.f);
+        }
+        return true;
+    case DXGI_FORMAT_R16_FLOAT:                 // :1040-1051
+        for (size_t i = 0, n = texels(2); i < n; ++i) pDestination[i] = XMVectorSet(loadh(reinterpret_cast<const uint16_t*>(s)[i]), 0.f, 0.f, 1.f);
+        return true;
+    case DXGI_FORMAT_R16_UNORM:                 // :1054-1065
+        for (size_t i = 0, n = texels(2); i < n; ++i) pDestination[i] = XMVectorSet(float(reinterpret_cast<const uint16_t*>(s)[i]) / 65535.f, 0.f, 0.f, 1.f);
+        return true;
+    case DXGI_FORMAT_R8_UNORM:                  // :1106-1117
+        for (size_t i = 0, n = texels(1); i < n; ++i) pDestination[i] = XMVectorSet(float(s[i]) / 255.f, 0.f, 0.f, 1.f);
+        return true;
+    case DXGI_FORMAT_R8_SNORM:                  // :1132-1143
+        for (size_t i = 0, n = texels(1); i < n; ++i) pDestination[i] = XMVectorSet(float(int8_t(s[i])) / 127.f, 0.f, 0.f, 1.f);
+        return true;
+    case DXGI_FORMAT_A8_UNORM:                  // :1158-1169
+        for (size_t i = 0, n = texels(1); i < n; ++i) pDestination[i] = XMVectorSet(0.f, 0.f, 0.f, float(s[i]) / 255.f);
+        return true;
+    default:
+        return false;
+    }
+}
+
+// ---- StoreScanline (:1629-2533) --------------------------------------------------------------------------------------------------
+bool DirectX::Internal::StoreScanline(void* pDestination, size_t size, DXGI_FORMAT format, const XMVECTOR* pSource, size_t count, float) noexcept
+{
+    if (!pDestination || !size || !pSource || !count) return false;
+    uint8_t* d = static_cast<uint8_t*>(pDestination);
+    auto texels = [&](size_t bytes) { const size_t n = size / bytes; return n < count ? n : count; };
+    switch (int(format))
+    {
+    case DXGI_FORMAT_R32G32B32A32_FLOAT:
+        memcpy(d, pSource, texels(16) * 16);
+        return true;
+    case DXGI_FORMAT_R16G16B16A16_FLOAT:        // clamp to +-65504, XMStoreHalf4 (:1689-1702)
+        for (size_t i = 0, n = texels(8); i < n; ++i)
+        {
+            uint16_t* h = reinterpret_cast<uint16_t*>(d + i * 8);
+            for (int c = 0; c < 4; ++c) h[c] = store_half(pSource[i].f[c]);
+        }
+        return true;
+    case DXGI_FORMAT_R16G16B16A16_UNORM:
+        for (size_t i = 0, n = texels(8); i < n; ++i)
+        {
+            uint16_t* h = reinterpret_cast<uint16_t*>(d + i * 8);
+            for (int c = 0; c < 4; ++c) h[c] = store_usn(pSource[i].f[c]);
+        }
+        return true;
+    case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB:      // :1759-1772
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+            for (int c = 0; c < 4; ++c) d[i * 4 + c] = store_ubn_biased(pSource[i].f[c]);
+        return true;
+    case DXGI_FORMAT_R8G8B8A8_SNORM:
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+            for (int c = 0; c < 4; ++c) d[i * 4 + c] = uint8_t(store_bn(pSource[i].f[c]));
+        return true;
+    case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB:      // :2141-2155
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            d[i * 4 + 0] = store_ubn_biased(pSource[i].f[2]); d[i * 4 + 1] = store_ubn_biased(pSource[i].f[1]);
+            d[i * 4 + 2] = store_ubn_biased(pSource[i].f[0]); d[i * 4 + 3] = store_ubn_biased(pSource[i].f[3]);
+        }
+        return true;
+    case DXGI_FORMAT_B8G8R8X8_UNORM: case DXGI_FORMAT_B8G8R8X8_UNORM_SRGB:      // :2157-2171
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            d[i * 4 + 0] = store_ubn_biased(pSource[i].f[2]); d[i * 4 + 1] = store_ubn_biased(pSource[i].f[1]);
+            d[i * 4 + 2] = store_ubn_biased(pSource[i].f[0]); d[i * 4 + 3] = store_ubn_biased(1.0f);
+        }
+        return true;
+    case DXGI_FORMAT_R32G32_FLOAT:
+        for (size_t i = 0, n = texels(8); i < n; ++i) { float* f = reinterpret_cast<float*>(d + i * 8); f[0] = pSource[i].f[0]; f[1] = pSource[i].f[1]; }
+        return true;
+    case DXGI_FORMAT_R16G16_FLOAT:              // :1783-1796
+        for (size_t i = 0, n = texels(4); i < n; ++i) { uint16_t* h = reinterpret_cast<uint16_t*>(d + i * 4); h[0] = store_half(pSource[i].f[0]); h[1] = store_half(pSource[i].f[1]); }
+        return true;
+    case DXGI_FORMAT_R16G16_UNORM:
+        for (size_t i = 0, n = texels(4); i < n; ++i) { uint16_t* h = reinterpret_cast<uint16_t*>(d + i * 4); h[0] = store_usn(pSource[i].f[0]); h[1] = store_usn(pSource[i].f[1]); }
+        return true;
+    case DXGI_FORMAT_R32_FLOAT:                 // :1811-1823
+        for (size_t i = 0, n = texels(4); i < n; ++i) reinterpret_cast<float*>(d)[i] = pSource[i].f[0];
+        return true;
+    case DXGI_FORMAT_R8G8_UNORM:                // XMStoreUByteN2, :1870-1871
+        for (size_t i = 0, n = texels(2); i < n; ++i) { d[i * 2] = store_ubn2(pSource[i].f[0]); d[i * 2 + 1] = store_ubn2(pSource[i].f[1]); }
+        return true;
+    case DXGI_FORMAT_R8G8_SNORM:                // XMStoreByteN2, :1876-1877
+        for (size_t i = 0, n = texels(2); i < n; ++i) { d[i * 2] = uint8_t(store_bn(pSource[i].f[0])); d[i * 2 + 1] = uint8_t(store_bn(pSource[i].f[1])); }
+        return true;
+    case DXGI_FORMAT_R16_FLOAT:                 // :1882-1896
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            float v = pSource[i].f[0];
+            v = std::max<float>(std::min<float>(v, 65504.f), -65504.f);
+            reinterpret_cast<uint16_t*>(d)[i] = PackedVector::XMConvertFloatToHalf(v);
+        }
+        return true;
+    case DXGI_FORMAT_R16_UNORM:                 // :1898-1912
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            float v = pSource[i].f[0];
+            v = std::max<float>(std::min<float>(v, 1.f), 0.f);
+            reinterpret_cast<uint16_t*>(d)[i] = static_cast<uint16_t>(v * 65535.f + 0.5f);
+        }
+        return true;
+    case DXGI_FORMAT_R8_UNORM:                  // :1958-1971
+        for (size_t i = 0, n = texels(1); i < n; ++i)
+        {
+            float v = pSource[i].f[0] + (0.5f / 255.f);
+            v = std::max<float>(std::min<float>(v, 1.f), 0.f);
+            d[i] = static_cast<uint8_t>(v * 255.f);
+        }
+        return true;
+    case DXGI_FORMAT_R8_SNORM:                  // :1988-2001
+        for (size_t i = 0, n = texels(1); i < n; ++i)
+        {
+            float v = pSource[i].f[0];
+            v = std::max<float>(std::min<float>(v, 1.f), -1.f);
+            d[i] = uint8_t(static_cast<int8_t>(lroundf(v * 127.f)));
+        }
+        return true;
+    case DXGI_FORMAT_A8_UNORM:                  // :2018-2031
+        for (size_t i = 0, n = texels(1); i < n; ++i)
+        {
+            float v = pSource[i].f[3] + (0.5f / 255.f);
+            v = std::max<float>(std::min<float>(v, 1.f), 0.f);
+            d[i] = static_cast<uint8_t>(v * 255.f);
+        }
+        return true;
+    default:
+        return false;
+    }
+}
+
+bool DirectX::Internal::StoreScanlineDither(void*, size_t, DXGI_FORMAT, XMVECTOR*, size_t, float, size_t, size_t, XMVECTOR*) noexcept
+{
+    return false;       // dithered stores are out of scope
+}
+
+// ---- LoadScanlineLinear / StoreScanlineLinear (:2803-2945) -----------------------------------------------------------------------
+bool DirectX::Internal::LoadScanlineLinear(XMVECTOR* pDestination, size_t count, const void* pSource, size_t size, DXGI_FORMAT format, TEX_FILTER_FLAGS flags) noexcept
+{
+    uint32_t fl = uint32_t(flags);
+    if (format == DXGI_FORMAT_R8G8B8A8_UNORM_SRGB || format == DXGI_FORMAT_B8G8R8A8_UNORM_SRGB || format == DXGI_FORMAT_B8G8R8X8_UNORM_SRGB) fl |= TEX_FILTER_SRGB;
+    else if (!linear_filter_srgb_ok(format)) fl &= ~uint32_t(TEX_FILTER_SRGB);
+    if (!LoadScanline(pDestination, count, pSource, size, format)) return false;
+    if (fl & TEX_FILTER_SRGB_IN)
+        for (size_t i = 0; i < count; ++i)
+            for (int c = 0; c < 3; ++c) pDestination[i].f[c] = srgb_to_rgb(pDestination[i].f[c]);
+    return true;
+}
+
+bool DirectX::Internal::StoreScanlineLinear(void* pDestination, size_t size, DXGI_FORMAT format, XMVECTOR* pSource, size_t count, TEX_FILTER_FLAGS flags, float threshold) noexcept
+{
+    if (!pSource || !count) return false;
+    uint32_t fl = uint32_t(flags);
+    if (format == DXGI_FORMAT_R8G8B8A8_UNORM_SRGB || format == DXGI_FORMAT_B8G8R8A8_UNORM_SRGB || format == DXGI_FORMAT_B8G8R8X8_UNORM_SRGB) fl |= TEX_FILTER_SRGB;
+    else if (!linear_filter_srgb_ok(format)) fl &= ~uint32_t(TEX_FILTER_SRGB);
+    if (fl & TEX_FILTER_SRGB_OUT)
+        for (size_t i = 0; i < count; ++i)
+            for (int c = 0; c < 3; ++c) pSource[i].f[c] = rgb_to_srgb(pSource[i].f[c]);
+    return StoreScanline(pDestination, size, format, pSource, count, threshold);
+}
+
+// ---- ConvertScanline (:3080-3854), non-depth formats -----------------------------------------------------------------------------
+void DirectX::Internal::ConvertScanline(XMVECTOR* pBuffer, size_t count, DXGI_FORMAT outFormat, DXGI_FORMAT inFormat, TEX_FILTER_FLAGS tflags) noexcept
+{
+    if (!pBuffer) return;
+    const uint32_t in = conv_flags(inFormat), out = conv_flags(outFormat);
+    if (!in || !out) return;
+    uint32_t flags = uint32_t(tflags);
+    if (is_srgb_format(inFormat)) flags |= TEX_FILTER_SRGB_IN;
+    if (inFormat == DXGI_FORMAT_A8_UNORM) flags &= ~uint32_t(TEX_FILTER_SRGB_IN);
+    if (is_srgb_format(outFormat)) flags |= TEX_FILTER_SRGB_OUT;
+    if (outFormat == DXGI_FORMAT_A8_UNORM) flags &= ~uint32_t(TEX_FILTER_SRGB_OUT);
+    if ((flags & TEX_FILTER_SRGB) == TEX_FILTER_SRGB) flags &= ~uint32_t(TEX_FILTER_SRGB);
+
+    auto each = [&](auto&& fn) { for (size_t i = 0; i < count; ++i) fn(pBuffer[i].f); };
+
+    if ((flags & TEX_FILTER_SRGB_IN) && (in & (C_FLOAT | C_UNORM)))
+        each([](float* v) { for (int c = 0; c < 3; ++c) v[c] = srgb_to_rgb(v[c]); });
+
+    const uint32_t diff = in ^ out;
+    if (diff != 0)
+    {
+        if (out & C_UNORM)
+        {
+            if (in & C_SNORM) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = v[c] * 0.5f + 0.5f; });                       // :3457-3463
+            else if (in & C_FLOAT)
+            {
+                if (flags & TEX_FILTER_FLOAT_X2BIAS) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = clampf(v[c], -1.f, 1.f) * 0.5f + 0.5f; });   // :3469-3477
+                else each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = clampf(v[c], 0.f, 1.f); });                               // :3481-3486
+            }
+        }
+        else if (out & C_SNORM)
+        {
+            if (in & C_UNORM) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = v[c] * 2.0f + -1.0f; });                       // :3495-3501
+            else if (in & C_FLOAT) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = clampf(v[c], -1.f, 1.f); });               // :3521-3526
+        }
+        else if (diff & C_UNORM)
+        {
+            if ((out & C_FLOAT) && (flags & TEX_FILTER_FLOAT_X2BIAS))
+                each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = v[c] * 2.0f + -1.0f; });                                     // :3536-3546
+        }
+
+        const uint32_t RGBA = C_R | C_G | C_B | C_A, RGB = C_R | C_G | C_B;
+        auto gray = [](const float* v) { return (v[0] * 0.2125f + v[1] * 0.7154f) + v[2] * 0.0721f; };         // XMVector3Dot(v, g_Grayscale)
+        const uint32_t copy3 = flags & (TEX_FILTER_RGB_COPY_RED | TEX_FILTER_RGB_COPY_GREEN | TEX_FILTER_RGB_COPY_BLUE);
+        const uint32_t copy4 = flags & (TEX_FILTER_RGB_COPY_RED | TEX_FILTER_RGB_COPY_GREEN | TEX_FILTER_RGB_COPY_BLUE | TEX_FILTER_RGB_COPY_ALPHA);
+        if (((out & RGBA) == C_A) && !(in & C_A))
+        {
+            // :3596-3652
+            if (copy3 == TEX_FILTER_RGB_COPY_GREEN) each([](float* v) { v[0] = v[2] = v[3] = v[1]; });
+            else if (copy3 == TEX_FILTER_RGB_COPY_BLUE) each([](float* v) { v[0] = v[1] = v[3] = v[2]; });
+            else if (copy3 != TEX_FILTER_RGB_COPY_RED && (in & C_UNORM) && ((in & RGB) == RGB)) each([&](float* v) { const float g = gray(v); v[0] = v[1] = v[2] = v[3] = g; });
+            else each([](float* v) { v[1] = v[2] = v[3] = v[0]; });
+        }
+        else if (((in & RGBA) == C_A) && !(out & C_A)) each([](float* v) { v[0] = v[1] = v[2] = v[3]; });                          // :3654-3664
+        else if ((in & RGB) == C_R)
+        {
+            if ((out & RGB) == RGB) each([](float* v) { v[1] = v[2] = v[0]; });                                                     // :3667-3679
+            else if ((out & RGB) == (C_R | C_G)) each([](float* v) { v[1] = v[0]; });                                               // :3680-3691
+        }
+        else if ((in & RGB) == RGB)
+        {
+            if ((out & RGB) == C_R)
+            {
+                // :3696-3771
+                if (copy4 == TEX_FILTER_RGB_COPY_GREEN) each([](float* v) { v[0] = v[2] = v[1]; });
+                else if (copy4 == TEX_FILTER_RGB_COPY_BLUE) each([](float* v) { v[0] = v[1] = v[2]; });
+                else if (copy4 == TEX_FILTER_RGB_COPY_ALPHA) each([](float* v) { v[0] = v[1] = v[2] = v[3]; });
+                else if (copy4 != TEX_FILTER_RGB_COPY_RED && (in & C_UNORM)) each([&](float* v) { const float g = gray(v); v[0] = v[1] = v[2] = g; });
+            }
+            else if ((out & RGB) == (C_R | C_G))
+            {
+                // :3773-3838
+                if ((flags & TEX_FILTER_RGB_COPY_ALPHA) && (in & C_A))
+                {
+                    if (copy4 == (TEX_FILTER_RGB_COPY_GREEN | TEX_FILTER_RGB_COPY_ALPHA)) each([](float* v) { v[0] = v[1]; v[1] = v[3]; });
+                    else if (copy4 == (TEX_FILTER_RGB_COPY_BLUE | TEX_FILTER_RGB_COPY_ALPHA)) each([](float* v) { v[0] = v[2]; v[1] = v[3]; });
+                    else each([](float* v) { v[1] = v[3]; });
+                }
+                else
+                {
+                    if (copy3 == (TEX_FILTER_RGB_COPY_RED | TEX_FILTER_RGB_COPY_BLUE)) each([](float* v) { v[1] = v[2]; });
+                    else if (copy3 == (TEX_FILTER_RGB_COPY_GREEN | TEX_FILTER_RGB_COPY_BLUE)) each([](float* v) { v[0] = v[1]; v[1] = v[2]; });
+                }
+            }
+        }
+    }
+
+    if ((flags & TEX_FILTER_SRGB_OUT) && (out & (C_FLOAT | C_UNORM)))
+        each([](float* v) { for (int c = 0; c < 3; ++c) v[c] = rgb_to_srgb(v[c]); });
+}

@@ -133,6 +133,19 @@ namespace DirectX
         const float d = (A.f[0] * B.f[0] + A.f[2] * B.f[2]) + (A.f[1] * B.f[1] + A.f[3] * B.f[3]);
         return XMVectorReplicate(d);
     }
+    // XMVectorSum: x+y+z+w in every lane; SSE2 shape (x+y) + (z+w)
+    inline XMVECTOR XMVectorSum(FXMVECTOR V) noexcept { return XMVectorReplicate((V.f[0] + V.f[1]) + (V.f[2] + V.f[3])); }
+    inline XMVECTOR XMVectorMergeXY(FXMVECTOR A, FXMVECTOR B) noexcept { return XMVECTOR{ { A.f[0], B.f[0], A.f[1], B.f[1] } }; }
+    template<uint32_t P0, uint32_t P1, uint32_t P2, uint32_t P3>
+    inline XMVECTOR XMVectorPermute(FXMVECTOR A, FXMVECTOR B) noexcept
+    {
+        const float* s[2] = { A.f, B.f };
+        return XMVECTOR{ { s[P0 >> 2][P0 & 3], s[P1 >> 2][P1 & 3], s[P2 >> 2][P2 & 3], s[P3 >> 2][P3 & 3] } };
+    }
+    inline XMVECTOR XMVectorPow(FXMVECTOR A, FXMVECTOR B) noexcept
+    {
+        return XMVECTOR{ { powf(A.f[0], B.f[0]), powf(A.f[1], B.f[1]), powf(A.f[2], B.f[2]), powf(A.f[3], B.f[3]) } };
+    }
     inline bool XMVector4Less(FXMVECTOR A, FXMVECTOR B) noexcept
     {
         return A.f[0] < B.f[0] && A.f[1] < B.f[1] && A.f[2] < B.f[2] && A.f[3] < B.f[3];

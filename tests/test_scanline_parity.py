@@ -1,0 +1,137 @@
+"""GenerateMipMaps / Resize / Convert / ComputeMSE on the GPU against the reference's own drivers (DirectXTexMipmaps.cpp,
+DirectXTexResize.cpp, DirectXTexMisc.cpp compiled in place into oracle/_ref, on top of the restated scanline layer).
+Bar: byte-identical output for every non-sRGB format (the filters are fp32 expression-for-expression restatements);
+sRGB formats go through powf on both sides, so they are allowed to differ by one 8-bit step."""
+import numpy as np
+import pytest
+
+import directxtex_amd as dx
+from directxtex_amd import synth
+
+pytestmark = pytest.mark.gpu
+RGBA8, RGBA8S, RGBA16F, RGBA32F, R8, RG8, BGRA8 = 28, 29, 10, 2, 61, 49, 87
+POINT, LINEAR, CUBIC, BOX, TRIANGLE = 0x100000, 0x200000, 0x300000, 0x400000, 0x500000
+WRAP, MIRROR = 0x3, 0x30
+
+
+def _image(w, h, fmt, seed):
+    rgba = synth.rgba8(w, h, seed=seed, alpha="smooth")
+    if fmt in (RGBA8, RGBA8S):
+        return rgba
+    if fmt == BGRA8:
+        return np.ascontiguousarray(rgba[..., [2, 1, 0, 3]])
+    if fmt == R8:
+        return np.ascontiguousarray(rgba[..., 0])
+    if fmt == RG8:
+        return np.ascontiguousarray(rgba[..., :2])
+    f = rgba.astype(np.float32) / 255.0 * 4.0 - 0.5
+    return f.astype(np.float16) if fmt == RGBA16F else f.astype(np.float32)
+
+
+def _levels(w, h):
+    n = 1
+    while w > 1 or h > 1:
+        w, h = max(1, w >> 1), max(1, h >> 1); n += 1
+    return n
+
+
+@pytest.mark.parametrize("flt", [0, POINT, BOX, LINEAR, CUBIC, TRIANGLE, CUBIC | WRAP, CUBIC | MIRROR, LINEAR | WRAP, TRIANGLE | WRAP])
+@pytest.mark.parametrize("fmt,size", [(RGBA8, (64, 32)), (RGBA16F, (32, 32)), (RGBA32F, (16, 64)), (R8, (64, 64)), (RGBA8, (57, 23)), (BGRA8, (40, 40)), (RGBA8, (256, 4))])
+def test_generate_mips(ctx, oracle, fmt, size, flt):
+    w, h = size
+    pow2 = (w & (w - 1)) == 0 and (h & (h - 1)) == 0
+    if (flt & 0xF00000) == BOX and not pow2:
+        pytest.skip("box needs power-of-two sizes (E_FAIL in the reference too)")
+    img = _image(w, h, fmt, seed=w * 7 + h)
+    n = _levels(w, h)
+    got = ctx.generate_mips(img, w, h, fmt, n, flt)
+    ref = oracle.ref_generate_mips(img, w, h, fmt, flt, n)
+    for lvl in range(n):
+        assert np.array_equal(got[lvl], ref[lvl]), (fmt, size, hex(flt), lvl, np.nonzero(got[lvl] != ref[lvl])[0][:8])
+
+
+@pytest.mark.parametrize("flt", [BOX, LINEAR, CUBIC, TRIANGLE])
+def test_generate_mips_srgb(ctx, oracle, flt):
+    w, h = 64, 64
+    img = _image(w, h, RGBA8S, seed=5)
+    got = ctx.generate_mips(img, w, h, RGBA8S, 4, flt)
+    ref = oracle.ref_generate_mips(img, w, h, RGBA8S, flt, 4)
+    for lvl in range(4):
+        d = np.abs(got[lvl].astype(np.int32) - ref[lvl].astype(np.int32))
+        assert d.max() <= 1, (hex(flt), lvl, int(d.max()))
+
+
+@pytest.mark.parametrize("flt", [0, POINT, LINEAR, CUBIC, TRIANGLE, TRIANGLE | WRAP, CUBIC | MIRROR])
+@pytest.mark.parametrize("dims", [((64, 48), (32, 24)), ((64, 48), (100, 31)), ((33, 17), (64, 64)), ((128, 8), (5, 3)), ((16, 16), (16, 16))])
+@pytest.mark.parametrize("fmt", [RGBA8, RGBA32F])
+def test_resize(ctx, oracle, fmt, dims, flt):
+    (w, h), (nw, nh) = dims
+    img = _image(w, h, fmt, seed=w + nh)
+    got = ctx.resize(img, w, h, fmt, nw, nh, flt)
+    ref = oracle.ref_resize(img, w, h, fmt, nw, nh, flt)
+    assert np.array_equal(got, ref), (fmt, dims, hex(flt), np.nonzero(got != ref)[0][:8])
+
+
+def test_resize_box_needs_half(ctx):
+    img = _image(32, 32, RGBA8, 1)
+    with pytest.raises(dx.DxtexError) as e:
+        ctx.resize(img, 32, 32, RGBA8, 20, 16, BOX)
+    assert e.value.hresult & 0xFFFFFFFF == 0x80004005        # E_FAIL, DirectXTexResize.cpp:319-320
+
+
+CONV = [(RGBA8, RGBA32F), (RGBA8, RGBA16F), (RGBA32F, RGBA8), (RGBA16F, RGBA8), (RGBA8, BGRA8), (RGBA8, R8), (RGBA8, RG8), (R8, RGBA8), (RGBA8, 65), (65, RGBA8),
+        (RGBA8, 31), (31, RGBA8), (RGBA32F, 51), (RGBA8, 63), (RGBA32F, 54), (RGBA32F, 41), (RGBA8, 11), (11, RGBA8), (RGBA32F, 35), (RGBA8, 56), (RGBA8, 88), (RGBA32F, 34), (RGBA32F, 16)]
+
+
+@pytest.mark.parametrize("pair", CONV)
+@pytest.mark.parametrize("flags", [0, 0x2000, 0x8000, 0x200])
+def test_convert(ctx, oracle, pair, flags):
+    src_fmt, dst_fmt = pair
+    w, h = 61, 19
+    rng = np.random.default_rng(src_fmt * 131 + dst_fmt)
+    nbytes = oracle.image_bytes(src_fmt, w, h)
+    if src_fmt in (RGBA32F, RGBA16F):
+        v = (rng.random((h, w, 4), dtype=np.float32) * 3 - 1).astype(np.float32 if src_fmt == RGBA32F else np.float16)
+        img = v
+    else:
+        img = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    got = ctx.convert(img, w, h, src_fmt, dst_fmt, flags, 0.5)
+    ref = oracle.ref_convert(img, w, h, src_fmt, dst_fmt, flags, 0.5)
+    assert np.array_equal(got, ref), (pair, hex(flags), np.nonzero(got != ref)[0][:8])
+
+
+def test_convert_srgb(ctx, oracle):
+    w, h = 64, 16
+    img = _image(w, h, RGBA8, 9)
+    for src_fmt, dst_fmt in ((RGBA8S, RGBA32F), (RGBA8, RGBA8S)):
+        got = ctx.convert(img, w, h, src_fmt, dst_fmt, 0, 0.5)
+        ref = oracle.ref_convert(img, w, h, src_fmt, dst_fmt, 0, 0.5)
+        if dst_fmt == RGBA32F:
+            assert np.allclose(got.view(np.float32), ref.view(np.float32), rtol=0, atol=2e-6)
+        else:
+            assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= 1
+
+
+def test_convert_errors(ctx):
+    img = _image(16, 16, RGBA8, 2)
+    with pytest.raises(dx.DxtexError) as e:
+        ctx.convert(img, 16, 16, RGBA8, RGBA8)
+    assert e.value.hresult & 0xFFFFFFFF == 0x80070057        # E_INVALIDARG, DirectXTexConvert.cpp:5107-5110
+    with pytest.raises(dx.DxtexError) as e:
+        ctx.convert(img, 16, 16, RGBA8, 71)
+    assert e.value.hresult & 0xFFFFFFFF == 0x80070032        # HRESULT_E_NOT_SUPPORTED, :5115-5119
+
+
+def test_compute_mse(ctx, oracle):
+    import torch
+    w, h = 256, 128
+    a = _image(w, h, RGBA8, 3)
+    payload = ctx.compress(a, w, h, RGBA8, 98, 0, 0.5)
+    b = ctx.decompress(payload, w, h, 98, RGBA8)
+    ta = torch.from_numpy(a.reshape(-1).copy()).cuda(); tb = torch.from_numpy(b.copy()).cuda()
+    got = ctx.compute_mse_device(ta.data_ptr(), RGBA8, tb.data_ptr(), RGBA8, w, h)
+    ref32 = oracle.ref_compute_mse(a, RGBA8, b, RGBA8, w, h)
+    fa = oracle.load_image(a, w, h, RGBA8); fb = oracle.load_image(b, w, h, RGBA8)
+    ref64 = oracle.compute_mse(fa, fb)
+    assert np.allclose(got, ref64, rtol=1e-6, atol=0)
+    assert np.allclose(got, ref32, rtol=2e-4, atol=0)        # the reference accumulates in fp32, serially
