@@ -1,0 +1,409 @@
+// DirectXTexAMD.cpp - see DirectXTexAMD.h. Validation order and error codes follow the reference functions cited at
+// each entry point; the work itself is done by libdxtex_amd.so (HIP kernels) through include/dxtex_amd.h.
+#include "DirectXTexAMD.h"
+#include "../../include/dxtex_amd.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace DirectXTexAMD
+{
+namespace
+{
+    inline dxtex_image View(const Image& i) noexcept
+    {
+        dxtex_image v;
+        v.width = i.width; v.height = i.height; v.format = int32_t(i.format);
+        v.rowPitch = i.rowPitch; v.slicePitch = i.slicePitch; v.pixels = i.pixels;
+        return v;
+    }
+
+    inline bool IsKnown(DXGI_FORMAT fmt) noexcept { return dxtex_bits_per_pixel(int32_t(fmt)) != 0; }
+
+    DXGI_FORMAT DefaultDecompress(DXGI_FORMAT format) noexcept
+    {
+        switch (format)
+        {
+        case DXGI_FORMAT_BC1_UNORM: case DXGI_FORMAT_BC2_UNORM: case DXGI_FORMAT_BC3_UNORM: case DXGI_FORMAT_BC7_UNORM: return DXGI_FORMAT_R8G8B8A8_UNORM;
+        case DXGI_FORMAT_BC1_UNORM_SRGB: case DXGI_FORMAT_BC2_UNORM_SRGB: case DXGI_FORMAT_BC3_UNORM_SRGB: case DXGI_FORMAT_BC7_UNORM_SRGB: return DXGI_FORMAT_R8G8B8A8_UNORM_SRGB;
+        case DXGI_FORMAT_BC4_UNORM: return DXGI_FORMAT_R8_UNORM;
+        case DXGI_FORMAT_BC4_SNORM: return DXGI_FORMAT_R8_SNORM;
+        case DXGI_FORMAT_BC5_UNORM: return DXGI_FORMAT_R8G8_UNORM;
+        case DXGI_FORMAT_BC5_SNORM: return DXGI_FORMAT_R8G8_SNORM;
+        case DXGI_FORMAT_BC6H_UF16: case DXGI_FORMAT_BC6H_SF16: return DXGI_FORMAT_R32G32B32A32_FLOAT;
+        default: return DXGI_FORMAT_UNKNOWN;
+        }
+    }
+
+    inline bool ispow2(size_t x) noexcept { return x != 0 && (x & (x - 1)) == 0; }
+}
+
+bool IsCompressed(DXGI_FORMAT fmt) noexcept { return dxtex_is_compressed(int32_t(fmt)) != 0; }
+size_t BitsPerPixel(DXGI_FORMAT fmt) noexcept { return dxtex_bits_per_pixel(int32_t(fmt)); }
+
+HRESULT ComputePitch(DXGI_FORMAT fmt, size_t width, size_t height, size_t& rowPitch, size_t& slicePitch) noexcept
+{
+    return dxtex_compute_pitch(int32_t(fmt), width, height, &rowPitch, &slicePitch);
+}
+
+bool CalculateMipLevels(size_t width, size_t height, size_t& mipLevels) noexcept
+{
+    size_t full = 1;
+    for (size_t w = width, h = height; w > 1 || h > 1; ++full) { if (w > 1) w >>= 1; if (h > 1) h >>= 1; }
+    if (mipLevels > 1) { if (mipLevels > full) return false; }
+    else if (mipLevels == 0) mipLevels = full;
+    else mipLevels = 1;
+    return true;
+}
+
+size_t TexMetadata::ComputeIndex(size_t mip, size_t item, size_t slice) const noexcept
+{
+    if (mip >= mipLevels || slice > 0 || item >= arraySize) return size_t(-1);
+    return item * mipLevels + mip;
+}
+
+// ---- ScratchImage --------------------------------------------------------------------------------------------------------
+ScratchImage& ScratchImage::operator=(ScratchImage&& o) noexcept
+{
+    if (this != &o)
+    {
+        Release();
+        m_nimages = o.m_nimages; m_size = o.m_size; m_metadata = o.m_metadata;
+        m_images = std::move(o.m_images); m_memory = o.m_memory;
+        o.m_nimages = 0; o.m_size = 0; o.m_memory = nullptr;
+    }
+    return *this;
+}
+
+void ScratchImage::Release() noexcept
+{
+    m_nimages = 0; m_size = 0;
+    m_images.reset();
+    if (m_memory) { std::free(m_memory); m_memory = nullptr; }
+    m_metadata = TexMetadata();
+}
+
+HRESULT ScratchImage::Initialize(const TexMetadata& mdata) noexcept
+{
+    if (!IsKnown(mdata.format)) return E_INVALIDARG;
+    if (mdata.dimension == TEX_DIMENSION_TEXTURE3D) return HRESULT_E_NOT_SUPPORTED;     // volume textures are outside this path
+    if (!mdata.width || !mdata.height || mdata.depth != 1 || !mdata.arraySize) return E_INVALIDARG;
+    size_t mipLevels = mdata.mipLevels;
+    if (!CalculateMipLevels(mdata.width, mdata.height, mipLevels)) return E_INVALIDARG;
+
+    Release();
+    m_metadata = mdata;
+    m_metadata.mipLevels = mipLevels;
+
+    // DetermineImageArray / SetupImageArray (DirectXTexImage.cpp:34-268): item-major, then mip
+    const size_t nimages = mdata.arraySize * mipLevels;
+    uint64_t total = 0;
+    for (size_t item = 0; item < mdata.arraySize; ++item)
+    {
+        size_t w = mdata.width, h = mdata.height;
+        for (size_t level = 0; level < mipLevels; ++level)
+        {
+            size_t rp, sp;
+            const HRESULT hr = ComputePitch(mdata.format, w, h, rp, sp);
+            if (FAILED(hr)) { Release(); return hr; }
+            total += sp;
+            if (h > 1) h >>= 1;
+            if (w > 1) w >>= 1;
+        }
+    }
+    m_images.reset(new (std::nothrow) Image[nimages]);
+    if (!m_images) { Release(); return E_OUTOFMEMORY; }
+    const size_t bytes = (size_t(total) + 15) & ~size_t(15);
+    m_memory = static_cast<uint8_t*>(std::aligned_alloc(16, std::max<size_t>(bytes, 16)));
+    if (!m_memory) { Release(); return E_OUTOFMEMORY; }
+    std::memset(m_memory, 0, std::max<size_t>(bytes, 16));        // zero-filled like the reference (DirectXTexImage.cpp:376)
+    m_size = size_t(total);
+    m_nimages = nimages;
+
+    uint8_t* p = m_memory;
+    size_t index = 0;
+    for (size_t item = 0; item < mdata.arraySize; ++item)
+    {
+        size_t w = mdata.width, h = mdata.height;
+        for (size_t level = 0; level < mipLevels; ++level, ++index)
+        {
+            Image& im = m_images[index];
+            im.width = w; im.height = h; im.format = mdata.format;
+            ComputePitch(mdata.format, w, h, im.rowPitch, im.slicePitch);
+            im.pixels = p;
+            p += im.slicePitch;
+            if (h > 1) h >>= 1;
+            if (w > 1) w >>= 1;
+        }
+    }
+    return S_OK;
+}
+
+HRESULT ScratchImage::Initialize2D(DXGI_FORMAT fmt, size_t width, size_t height, size_t arraySize, size_t mipLevels) noexcept
+{
+    TexMetadata m;
+    m.width = width; m.height = height; m.depth = 1; m.arraySize = arraySize; m.mipLevels = mipLevels;
+    m.format = fmt; m.dimension = TEX_DIMENSION_TEXTURE2D;
+    return Initialize(m);
+}
+
+HRESULT ScratchImage::InitializeFromImage(const Image& src) noexcept
+{
+    if (!src.pixels) return E_POINTER;
+    const HRESULT hr = Initialize2D(src.format, src.width, src.height, 1, 1);
+    if (FAILED(hr)) return hr;
+    const Image& dst = m_images[0];
+    const size_t rows = IsCompressed(src.format) ? std::max<size_t>(1, (src.height + 3) / 4) : src.height;
+    const size_t n = std::min(src.rowPitch, dst.rowPitch);
+    for (size_t y = 0; y < rows; ++y) std::memcpy(dst.pixels + y * dst.rowPitch, src.pixels + y * src.rowPitch, n);
+    return S_OK;
+}
+
+const Image* ScratchImage::GetImage(size_t mip, size_t item, size_t slice) const noexcept
+{
+    const size_t i = m_metadata.ComputeIndex(mip, item, slice);
+    return (i < m_nimages) ? &m_images[i] : nullptr;
+}
+
+// ---- Device ----------------------------------------------------------------------------------------------------------------
+Device::~Device() { if (m_ctx) dxtex_ctx_destroy(m_ctx); }
+HRESULT Device::Create(int hipDevice) noexcept
+{
+    if (m_ctx) { dxtex_ctx_destroy(m_ctx); m_ctx = nullptr; }
+    return dxtex_ctx_create(hipDevice, &m_ctx);
+}
+const char* Device::LastError() const noexcept { return m_ctx ? dxtex_ctx_last_error(m_ctx) : "no device"; }
+
+// ---- Compress (CompressEx, DirectXTexCompress.cpp:664-850) --------------------------------------------------------------------
+HRESULT Compress(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_COMPRESS_FLAGS compress, float threshold, ScratchImage& image) noexcept
+{
+    if (!device) return E_POINTER;
+    if (IsCompressed(srcImage.format) || !IsCompressed(format) || srcImage.format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
+    if (!IsKnown(srcImage.format)) return HRESULT_E_NOT_SUPPORTED;
+    HRESULT hr = image.Initialize2D(format, srcImage.width, srcImage.height, 1, 1);
+    if (FAILED(hr)) return hr;
+    const Image* img = image.GetImage(0, 0, 0);
+    if (!img) { image.Release(); return E_POINTER; }
+    const dxtex_image s = View(srcImage), d = View(*img);
+    hr = dxtex_compress(device.Get(), &s, &d, uint32_t(compress), threshold);
+    if (FAILED(hr)) image.Release();
+    return hr;
+}
+
+HRESULT Compress(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                 TEX_COMPRESS_FLAGS compress, float threshold, ScratchImage& cImages) noexcept
+{
+    if (!device) return E_POINTER;
+    if (!srcImages || !nimages) return E_INVALIDARG;
+    if (IsCompressed(metadata.format) || !IsCompressed(format)) return E_INVALIDARG;
+    if (!IsKnown(metadata.format)) return HRESULT_E_NOT_SUPPORTED;
+    cImages.Release();
+    TexMetadata m2 = metadata;
+    m2.format = format;
+    HRESULT hr = cImages.Initialize(m2);
+    if (FAILED(hr)) return hr;
+    if (nimages != cImages.GetImageCount()) { cImages.Release(); return E_FAIL; }
+    const Image* dest = cImages.GetImages();
+    for (size_t i = 0; i < nimages; ++i)
+    {
+        if (srcImages[i].format != metadata.format) { cImages.Release(); return E_FAIL; }
+        if (srcImages[i].width != dest[i].width || srcImages[i].height != dest[i].height) { cImages.Release(); return E_FAIL; }     // :800-804
+        const dxtex_image s = View(srcImages[i]), d = View(dest[i]);
+        hr = dxtex_compress(device.Get(), &s, &d, uint32_t(compress), threshold);
+        if (FAILED(hr)) { cImages.Release(); return hr; }
+    }
+    return S_OK;
+}
+
+// ---- Decompress (DirectXTexCompress.cpp:852-979) -------------------------------------------------------------------------------
+HRESULT Decompress(Device& device, const Image& cImage, DXGI_FORMAT format, ScratchImage& image) noexcept
+{
+    if (!device) return E_POINTER;
+    if (!IsCompressed(cImage.format) || IsCompressed(format)) return E_INVALIDARG;
+    if (format == DXGI_FORMAT_UNKNOWN)
+    {
+        format = DefaultDecompress(cImage.format);
+        if (format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
+    }
+    else if (!IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
+    HRESULT hr = image.Initialize2D(format, cImage.width, cImage.height, 1, 1);
+    if (FAILED(hr)) return hr;
+    const Image* img = image.GetImage(0, 0, 0);
+    if (!img) { image.Release(); return E_POINTER; }
+    const dxtex_image s = View(cImage), d = View(*img);
+    hr = dxtex_decompress(device.Get(), &s, &d);
+    if (FAILED(hr)) image.Release();
+    return hr;
+}
+
+HRESULT Decompress(Device& device, const Image* cImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format, ScratchImage& images) noexcept
+{
+    if (!device) return E_POINTER;
+    if (!cImages || !nimages) return E_INVALIDARG;
+    if (!IsCompressed(metadata.format) || IsCompressed(format)) return E_INVALIDARG;
+    if (format == DXGI_FORMAT_UNKNOWN)
+    {
+        format = DefaultDecompress(cImages[0].format);
+        if (format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
+    }
+    else if (!IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
+    images.Release();
+    TexMetadata m2 = metadata;
+    m2.format = format;
+    HRESULT hr = images.Initialize(m2);
+    if (FAILED(hr)) return hr;
+    if (nimages != images.GetImageCount()) { images.Release(); return E_FAIL; }
+    const Image* dest = images.GetImages();
+    for (size_t i = 0; i < nimages; ++i)
+    {
+        if (cImages[i].format != metadata.format) { images.Release(); return E_FAIL; }
+        const dxtex_image s = View(cImages[i]), d = View(dest[i]);
+        hr = dxtex_decompress(device.Get(), &s, &d);
+        if (FAILED(hr)) { images.Release(); return hr; }
+    }
+    return S_OK;
+}
+
+// ---- GenerateMipMaps (DirectXTexMipmaps.cpp:2828-3247) ---------------------------------------------------------------------------
+HRESULT GenerateMipMaps(Device& device, const Image& baseImage, TEX_FILTER_FLAGS filter, size_t levels, ScratchImage& mipChain) noexcept
+{
+    if (!device) return E_POINTER;
+    if (baseImage.format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
+    if (!baseImage.pixels) return E_POINTER;
+    if (!CalculateMipLevels(baseImage.width, baseImage.height, levels)) return E_INVALIDARG;
+    if (levels <= 1) return E_INVALIDARG;
+    if (IsCompressed(baseImage.format) || !IsKnown(baseImage.format)) return HRESULT_E_NOT_SUPPORTED;
+
+    HRESULT hr = mipChain.Initialize2D(baseImage.format, baseImage.width, baseImage.height, 1, levels);
+    if (FAILED(hr)) return hr;
+    // Setup2DMips (:851-904): the base image goes to the top of the chain
+    const Image* top = mipChain.GetImage(0, 0, 0);
+    for (size_t y = 0; y < baseImage.height; ++y)
+        std::memcpy(top->pixels + y * top->rowPitch, baseImage.pixels + y * baseImage.rowPitch, std::min(top->rowPitch, baseImage.rowPitch));
+    std::vector<dxtex_image> views(levels);
+    for (size_t l = 0; l < levels; ++l) views[l] = View(*mipChain.GetImage(l, 0, 0));
+    hr = dxtex_generate_mips(device.Get(), views.data(), levels, uint32_t(filter));
+    if (FAILED(hr)) mipChain.Release();
+    return hr;
+}
+
+HRESULT GenerateMipMaps(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_FILTER_FLAGS filter,
+                        size_t levels, ScratchImage& mipChain) noexcept
+{
+    if (!device) return E_POINTER;
+    if (!srcImages || !nimages || metadata.format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
+    if (metadata.dimension == TEX_DIMENSION_TEXTURE3D || IsCompressed(metadata.format) || !IsKnown(metadata.format)) return HRESULT_E_NOT_SUPPORTED;
+    if (!CalculateMipLevels(metadata.width, metadata.height, levels)) return E_INVALIDARG;
+    if (levels <= 1) return E_INVALIDARG;
+    // base images = mip 0 of every array item (:3160-3188)
+    std::vector<const Image*> base;
+    for (size_t item = 0; item < metadata.arraySize; ++item)
+    {
+        const size_t index = metadata.ComputeIndex(0, item, 0);
+        if (index >= nimages) return E_FAIL;
+        const Image& src = srcImages[index];
+        if (!src.pixels) return E_POINTER;
+        if (src.format != metadata.format || src.width != metadata.width || src.height != metadata.height) return E_FAIL;
+        base.push_back(&src);
+    }
+    TexMetadata m2 = metadata;
+    m2.mipLevels = levels;
+    HRESULT hr = mipChain.Initialize(m2);
+    if (FAILED(hr)) return hr;
+    for (size_t item = 0; item < metadata.arraySize; ++item)
+    {
+        const Image* top = mipChain.GetImage(0, item, 0);
+        for (size_t y = 0; y < top->height; ++y)
+            std::memcpy(top->pixels + y * top->rowPitch, base[item]->pixels + y * base[item]->rowPitch, std::min(top->rowPitch, base[item]->rowPitch));
+        std::vector<dxtex_image> views(levels);
+        for (size_t l = 0; l < levels; ++l) views[l] = View(*mipChain.GetImage(l, item, 0));
+        hr = dxtex_generate_mips(device.Get(), views.data(), levels, uint32_t(filter));
+        if (FAILED(hr)) { mipChain.Release(); return hr; }
+    }
+    return S_OK;
+}
+
+// ---- Resize (DirectXTexResize.cpp:854-930) ----------------------------------------------------------------------------------------
+HRESULT Resize(Device& device, const Image& srcImage, size_t width, size_t height, TEX_FILTER_FLAGS filter, ScratchImage& image) noexcept
+{
+    if (!device) return E_POINTER;
+    if (width == 0 || height == 0) return E_INVALIDARG;
+    if (srcImage.width > UINT32_MAX || srcImage.height > UINT32_MAX || width > UINT32_MAX || height > UINT32_MAX) return E_INVALIDARG;
+    if (!srcImage.pixels) return E_POINTER;
+    if (IsCompressed(srcImage.format) || !IsKnown(srcImage.format)) return HRESULT_E_NOT_SUPPORTED;
+    HRESULT hr = image.Initialize2D(srcImage.format, width, height, 1, 1);
+    if (FAILED(hr)) return hr;
+    const Image* rimage = image.GetImage(0, 0, 0);
+    if (!rimage) return E_POINTER;
+    const dxtex_image s = View(srcImage), d = View(*rimage);
+    hr = dxtex_resize(device.Get(), &s, &d, uint32_t(filter));
+    if (FAILED(hr)) image.Release();
+    return hr;
+}
+
+// ---- Convert (ConvertEx, DirectXTexConvert.cpp:5107-5176) ---------------------------------------------------------------------------
+HRESULT Convert(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_FILTER_FLAGS filter, float threshold, ScratchImage& image) noexcept
+{
+    if (!device) return E_POINTER;
+    if (srcImage.format == format || format == DXGI_FORMAT_UNKNOWN || srcImage.format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
+    if (!srcImage.pixels) return E_POINTER;
+    if (IsCompressed(srcImage.format) || IsCompressed(format) || !IsKnown(srcImage.format) || !IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
+    if (srcImage.width > UINT32_MAX || srcImage.height > UINT32_MAX) return E_INVALIDARG;
+    HRESULT hr = image.Initialize2D(format, srcImage.width, srcImage.height, 1, 1);
+    if (FAILED(hr)) return hr;
+    const Image* rimage = image.GetImage(0, 0, 0);
+    if (!rimage) { image.Release(); return E_POINTER; }
+    const dxtex_image s = View(srcImage), d = View(*rimage);
+    hr = dxtex_convert(device.Get(), &s, &d, uint32_t(filter), threshold);
+    if (FAILED(hr)) image.Release();
+    return hr;
+}
+
+// ---- ComputeMSE (DirectXTexMisc.cpp:181-260): compressed inputs are decompressed first -----------------------------------------------
+HRESULT ComputeMSE(Device& device, const Image& image1, const Image& image2, float& mse, float* mseV) noexcept
+{
+    if (!device) return E_POINTER;
+    if (!image1.pixels || !image2.pixels) return E_POINTER;
+    if (image1.width != image2.width || image1.height != image2.height) return E_INVALIDARG;
+    ScratchImage t1, t2;
+    const Image* a = &image1;
+    const Image* b = &image2;
+    if (IsCompressed(image1.format))
+    {
+        const HRESULT hr = Decompress(device, image1, DXGI_FORMAT_UNKNOWN, t1);
+        if (FAILED(hr)) return hr;
+        a = t1.GetImage(0, 0, 0);
+    }
+    if (IsCompressed(image2.format))
+    {
+        const HRESULT hr = Decompress(device, image2, DXGI_FORMAT_UNKNOWN, t2);
+        if (FAILED(hr)) return hr;
+        b = t2.GetImage(0, 0, 0);
+    }
+    // stage both on the device, reduce there
+    void* da = nullptr; void* db = nullptr;
+    const size_t na = a->rowPitch * a->height, nb = b->rowPitch * b->height;
+    HRESULT hr = dxtex_device_alloc(device.Get(), na, &da);
+    if (FAILED(hr)) return hr;
+    hr = dxtex_device_alloc(device.Get(), nb, &db);
+    if (FAILED(hr)) { dxtex_device_free(device.Get(), da); return hr; }
+    double v[4] = { 0, 0, 0, 0 };
+    hr = dxtex_memcpy_h2d(device.Get(), da, a->pixels, na);
+    if (SUCCEEDED(hr)) hr = dxtex_memcpy_h2d(device.Get(), db, b->pixels, nb);
+    if (SUCCEEDED(hr))
+    {
+        dxtex_image va = View(*a), vb = View(*b);
+        va.pixels = static_cast<uint8_t*>(da); vb.pixels = static_cast<uint8_t*>(db);
+        hr = dxtex_compute_mse_device(device.Get(), &va, &vb, v);
+    }
+    dxtex_device_free(device.Get(), da);
+    dxtex_device_free(device.Get(), db);
+    if (FAILED(hr)) return hr;
+    if (mseV) for (int c = 0; c < 4; ++c) mseV[c] = float(v[c]);
+    mse = float(v[0]) + float(v[1]) + float(v[2]) + float(v[3]);
+    return S_OK;
+}
+} // namespace DirectXTexAMD

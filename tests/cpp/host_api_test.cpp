@@ -1,0 +1,120 @@
+// Exercises the C++ host layer (directxtex_amd/host/DirectXTexAMD.h) the way a DirectXTex user would.
+//   host_api_test cpu            - container / pitch / index rules only, no GPU needed
+//   host_api_test gpu <outdir>   - Compress, Decompress, GenerateMipMaps, Resize, Convert, ComputeMSE on device 0;
+//                                  writes the results to <outdir> for tests/test_host_api.py to compare with the oracle
+#include "../../directxtex_amd/host/DirectXTexAMD.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace DirectXTexAMD;
+
+#define CHECK(cond) do { if (!(cond)) { std::fprintf(stderr, "FAILED line %d: %s\n", __LINE__, #cond); return 1; } } while (0)
+
+static void dump(const std::string& path, const void* p, size_t n)
+{
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (f) { std::fwrite(p, 1, n, f); std::fclose(f); }
+}
+
+static int cpu_checks()
+{
+    size_t rp = 0, sp = 0;
+    CHECK(ComputePitch(DXGI_FORMAT_BC1_UNORM, 256, 256, rp, sp) == S_OK && rp == 512 && sp == 512 * 64);
+    CHECK(ComputePitch(DXGI_FORMAT_BC7_UNORM, 5, 7, rp, sp) == S_OK && rp == 32 && sp == 64);
+    CHECK(ComputePitch(DXGI_FORMAT_R8G8B8A8_UNORM, 13, 3, rp, sp) == S_OK && rp == 52 && sp == 156);
+    size_t lv = 0;
+    CHECK(CalculateMipLevels(8192, 8192, lv) && lv == 14);
+    lv = 20; CHECK(!CalculateMipLevels(64, 64, lv));
+    lv = 3; CHECK(CalculateMipLevels(64, 1, lv) && lv == 3);
+
+    ScratchImage si;
+    CHECK(si.Initialize2D(DXGI_FORMAT_R8G8B8A8_UNORM, 20, 10, 3, 0) == S_OK);
+    CHECK(si.GetMetadata().mipLevels == 5 && si.GetImageCount() == 15);
+    // item-major, then mip; tightly packed; zero filled; 16-byte aligned
+    CHECK((reinterpret_cast<uintptr_t>(si.GetPixels()) & 15) == 0);
+    const Image* a = si.GetImage(0, 0, 0); const Image* b = si.GetImage(1, 0, 0); const Image* c = si.GetImage(0, 1, 0);
+    CHECK(a && b && c && a->pixels == si.GetPixels() && b->pixels == a->pixels + a->slicePitch);
+    CHECK(b->width == 10 && b->height == 5 && si.GetImage(4, 2, 0)->width == 1 && si.GetImage(4, 2, 0)->height == 1);
+    size_t chain = 0; for (size_t l = 0; l < 5; ++l) chain += si.GetImage(l, 0, 0)->slicePitch;
+    CHECK(c->pixels == a->pixels + chain && si.GetPixelsSize() == chain * 3);
+    for (size_t i = 0; i < si.GetPixelsSize(); ++i) CHECK(si.GetPixels()[i] == 0);
+    CHECK(si.GetImage(5, 0, 0) == nullptr && si.GetImage(0, 3, 0) == nullptr && si.GetImage(0, 0, 1) == nullptr);
+    CHECK(si.GetMetadata().ComputeIndex(2, 1, 0) == 7);
+    CHECK(si.Initialize2D(DXGI_FORMAT_UNKNOWN, 4, 4, 1, 1) == E_INVALIDARG);
+    CHECK(si.Initialize2D(DXGI_FORMAT_BC3_UNORM, 0, 4, 1, 1) == E_INVALIDARG);
+    CHECK(si.Initialize2D(DXGI_FORMAT_BC3_UNORM, 9, 9, 1, 0) == S_OK && si.GetMetadata().mipLevels == 4 && si.GetImage(3, 0, 0)->slicePitch == 16);
+
+    // without a device every entry point refuses to work: there is no CPU path
+    Device none;
+    ScratchImage out;
+    Image img = *si.GetImage(0, 0, 0);
+    CHECK(Compress(none, img, DXGI_FORMAT_BC1_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, out) == E_POINTER);
+    std::puts("cpu checks OK");
+    return 0;
+}
+
+static int gpu_run(const std::string& outdir)
+{
+    Device dev;
+    if (FAILED(dev.Create(0))) { std::fprintf(stderr, "no gfx950 device\n"); return 2; }
+
+    const size_t W = 96, H = 64;
+    std::vector<uint8_t> px(W * H * 4);
+    uint32_t s = 12345;
+    for (size_t y = 0; y < H; ++y)
+        for (size_t x = 0; x < W; ++x)
+        {
+            s = s * 1664525u + 1013904223u;
+            uint8_t* p = &px[(y * W + x) * 4];
+            p[0] = uint8_t(x * 2 + ((s >> 24) & 15)); p[1] = uint8_t(y * 3 + ((s >> 20) & 15)); p[2] = uint8_t((x + y) + ((s >> 16) & 31)); p[3] = uint8_t(255 - ((s >> 8) & 63));
+        }
+    Image src; src.width = W; src.height = H; src.format = DXGI_FORMAT_R8G8B8A8_UNORM; src.rowPitch = W * 4; src.slicePitch = W * H * 4; src.pixels = px.data();
+    dump(outdir + "/src.bin", px.data(), px.size());
+
+    ScratchImage bc7, bc3, back, mips, resized, conv;
+    CHECK(Compress(dev, src, DXGI_FORMAT_BC7_UNORM, TEX_COMPRESS_DEFAULT, TEX_THRESHOLD_DEFAULT, bc7) == S_OK);
+    dump(outdir + "/bc7.bin", bc7.GetPixels(), bc7.GetPixelsSize());
+    CHECK(Decompress(dev, *bc7.GetImage(0, 0, 0), DXGI_FORMAT_UNKNOWN, back) == S_OK);
+    CHECK(back.GetMetadata().format == DXGI_FORMAT_R8G8B8A8_UNORM);
+    dump(outdir + "/bc7_decoded.bin", back.GetPixels(), back.GetPixelsSize());
+
+    CHECK(GenerateMipMaps(dev, src, TEX_FILTER_CUBIC, 0, mips) == S_OK);
+    CHECK(mips.GetMetadata().mipLevels == 7 && mips.GetImageCount() == 7);
+    dump(outdir + "/mips_cubic.bin", mips.GetPixels(), mips.GetPixelsSize());
+    // mip chain -> BC3, the array overload
+    CHECK(Compress(dev, mips.GetImages(), mips.GetImageCount(), mips.GetMetadata(), DXGI_FORMAT_BC3_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, bc3) == S_OK);
+    CHECK(bc3.GetImageCount() == 7 && bc3.GetImage(6, 0, 0)->slicePitch == 16);
+    dump(outdir + "/mips_bc3.bin", bc3.GetPixels(), bc3.GetPixelsSize());
+
+    CHECK(Resize(dev, src, 50, 70, TEX_FILTER_TRIANGLE, resized) == S_OK);
+    dump(outdir + "/resized_triangle.bin", resized.GetPixels(), resized.GetPixelsSize());
+    CHECK(Convert(dev, src, DXGI_FORMAT_R16G16B16A16_FLOAT, TEX_FILTER_DEFAULT, 0.5f, conv) == S_OK);
+    dump(outdir + "/converted_f16.bin", conv.GetPixels(), conv.GetPixelsSize());
+
+    float mse = 0, v[4];
+    CHECK(ComputeMSE(dev, src, *bc7.GetImage(0, 0, 0), mse, v) == S_OK);
+    std::printf("mse %.9g %.9g %.9g %.9g %.9g\n", mse, v[0], v[1], v[2], v[3]);
+
+    // error behaviour
+    ScratchImage bad;
+    CHECK(Compress(dev, *bc7.GetImage(0, 0, 0), DXGI_FORMAT_BC1_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, bad) == E_INVALIDARG);
+    CHECK(Compress(dev, src, DXGI_FORMAT_R8G8B8A8_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, bad) == E_INVALIDARG);
+    CHECK(Convert(dev, src, DXGI_FORMAT_R8G8B8A8_UNORM, TEX_FILTER_DEFAULT, 0.5f, bad) == E_INVALIDARG);
+    CHECK(Resize(dev, src, 50, 32, TEX_FILTER_BOX, bad) == E_FAIL && bad.GetPixels() == nullptr);
+    CHECK(GenerateMipMaps(dev, src, TEX_FILTER_BOX, 0, bad) == E_FAIL);          // 96 is not a power of two
+    CHECK(GenerateMipMaps(dev, src, TEX_FILTER_DEFAULT, 1, bad) == E_INVALIDARG);
+    std::puts("gpu run OK");
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc >= 2 && !std::strcmp(argv[1], "cpu")) return cpu_checks();
+    if (argc >= 3 && !std::strcmp(argv[1], "gpu")) return gpu_run(argv[2]);
+    std::fprintf(stderr, "usage: host_api_test cpu | gpu <outdir>\n");
+    return 64;
+}

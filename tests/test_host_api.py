@@ -1,0 +1,45 @@
+"""The C++ host layer (directxtex_amd/host/DirectXTexAMD.h): ScratchImage layout rules on the CPU, and the whole
+Compress / Decompress / GenerateMipMaps / Resize / Convert / ComputeMSE surface on the GPU, compared with the
+reference's own drivers (oracle/_ref)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "directxtex_amd", "lib", "host_api_test")
+
+
+def _exe():
+    if not os.path.exists(EXE):
+        pytest.fail(f"{EXE} missing: run __graft_entry__.build()")
+    return EXE
+
+
+def test_host_layer_cpu_rules():
+    r = subprocess.run([_exe(), "cpu"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_host_layer_on_gpu(tmp_path, oracle):
+    r = subprocess.run([_exe(), "gpu", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    W, H = 96, 64
+    rd = lambda n: np.fromfile(os.path.join(tmp_path, n), np.uint8)
+    src = rd("src.bin")
+    bc7 = rd("bc7.bin")
+    assert np.array_equal(bc7, oracle.ref_compress_image(src, W, H, 28, 98, 0, 0.5))
+    assert np.array_equal(rd("bc7_decoded.bin"), oracle.ref_decompress_image(bc7, W, H, 98, 28))
+    mips = oracle.ref_generate_mips(src, W, H, 28, 0x300000, 7)
+    assert np.array_equal(rd("mips_cubic.bin"), np.concatenate(mips))
+    sizes = oracle.mip_sizes(W, H, 7)
+    bc3 = np.concatenate([oracle.ref_compress_image(m, w, h, 28, 77, 0, 0.5) for m, (w, h) in zip(mips, sizes)])
+    assert np.array_equal(rd("mips_bc3.bin"), bc3)
+    assert np.array_equal(rd("resized_triangle.bin"), oracle.ref_resize(src, W, H, 28, 50, 70, 0x500000))
+    assert np.array_equal(rd("converted_f16.bin"), oracle.ref_convert(src, W, H, 28, 10, 0, 0.5))
+    line = [l for l in r.stdout.splitlines() if l.startswith("mse ")][0].split()
+    got = np.array([float(x) for x in line[2:6]])
+    ref = oracle.ref_compute_mse(src, 28, oracle.ref_decompress_image(bc7, W, H, 98, 28), 28, W, H)
+    assert np.allclose(got, ref, rtol=2e-4)
