@@ -93,3 +93,355 @@ DXTEX_HD6 int finish_unquantize(int comp, bool isSigned)
 
 } // namespace bc6h
 } // namespace dxtex
+
+// ======================================================================================================================
+// BC6H encoder core (D3DX_BC6H::Encode, BC6HBC7.cpp:1817-1859): everything one lane computes for one region of one
+// candidate (mode, shape). The kernels in bc6h_encode.hip pair the lanes of a candidate's two regions up and reduce
+// over candidates. Unlike BC7 the errors are NOT exact integers here: they are fp32 sums of fp32 squares of values up
+// to 2^17, accumulated texel by texel (Norm :1167-1173, MapColorsQuantized :2044-2077), and every comparison the
+// search makes depends on those roundings. They are reproduced operation for operation (-ffp-contract=off), which is
+// why the texels and palettes are kept as floats holding exact integers: float(a) - float(b) == float(a - b) here.
+// Quirks kept: OptimizeEndPoints hands region 0 ALL sixteen texels (it indexes g_aPartitionTable with the region
+// number instead of the region count, :2215); PerturbOne never tries a negative endpoint (:2112, :2118);
+// RoughMSE skips the error of 1- and 2-texel regions (:2523-2534).
+// ======================================================================================================================
+#include "bc67_tables.h"
+
+namespace dxtex
+{
+namespace bc6h
+{
+struct ModeRt
+{
+    int index;          // 0..13, position in the encoder's mode order
+    int code;           // mode bits
+    int regions2;       // 1 = two regions (32 shapes), 0 = one region
+    int transformed;
+    int prec;           // base endpoint precision (the same for r, g, b in every mode)
+    int delta[3];       // precision of the other endpoints
+};
+
+DXTEX_HD6 int weight3(int i) { return i == 0 ? 0 : i == 1 ? 9 : i == 2 ? 18 : i == 3 ? 27 : i == 4 ? 37 : i == 5 ? 46 : i == 6 ? 55 : 64; }
+DXTEX_HD6 int weight4(int i)
+{
+    return i == 0 ? 0 : i == 1 ? 4 : i == 2 ? 9 : i == 3 ? 13 : i == 4 ? 17 : i == 5 ? 21 : i == 6 ? 26 : i == 7 ? 30
+         : i == 8 ? 34 : i == 9 ? 38 : i == 10 ? 43 : i == 11 ? 47 : i == 12 ? 51 : i == 13 ? 55 : i == 14 ? 60 : 64;
+}
+template<int N> DXTEX_HD6 int weight_of(int i) { return N == 8 ? weight3(i) : weight4(i); }
+
+// NBits (:1176-1194)
+DXTEX_HD6 int nbits(int n, bool isSigned)
+{
+    int nb;
+    if (n == 0) return 0;
+    if (n > 0) { for (nb = 0; n; ++nb, n >>= 1) {} return nb + (isSigned ? 1 : 0); }
+    for (nb = 0; n < -1; ++nb, n >>= 1) {}
+    return nb + 1;
+}
+
+// Norm (:1167-1173) on floats that hold exact integers
+DXTEX_HD6 float norm3(float pr, float pg, float pb, float qr, float qg, float qb)
+{
+    const float dr = pr - qr, dg = pg - qg, db = pb - qb;
+    return dr * dr + dg * dg + db * db;
+}
+
+// The early-breaking palette scan shared by MapColors, MapColorsQuantized and AssignIndices: first local minimum.
+template<int N>
+DXTEX_HD6 float scan_min(const float (&e)[N])
+{
+    float res = e[N - 1];
+#pragma unroll
+    for (int i = N - 1; i >= 1; --i) res = (e[i] > e[i - 1]) ? e[i - 1] : res;
+    return res;
+}
+template<int N>
+DXTEX_HD6 float scan_min_idx(const float (&e)[N], uint32_t& idx)
+{
+    float best = e[0];
+    bool done = false;
+    idx = 0;
+#pragma unroll
+    for (int i = 1; i < N; ++i)
+    {
+        done = done || (e[i] > best) || !(best > 0.0f);
+        if (!done && e[i] < best) { best = e[i]; idx = uint32_t(i); }
+    }
+    return best;
+}
+
+// A region's texels: texel k of the region is at block position pos(k); values as floats holding exact ints.
+struct Texels
+{
+    const float* r; const float* g; const float* b;     // r[k * stride] etc.
+    int stride;
+    int np;
+};
+
+// Palette of quantised endpoints (GeneratePaletteQuantized, :1990-2040) for one channel
+template<int N>
+DXTEX_HD6 void palette_channel(int qa, int qb, int prec, bool isSigned, float (&out)[N])
+{
+    const int ua = unquantize(qa, prec, isSigned), ub = unquantize(qb, prec, isSigned);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+        const int w = weight_of<N>(i);
+        out[i] = float(finish_unquantize((ua * (64 - w) + ub * w + 32) >> 6, isSigned));
+    }
+}
+
+struct EndPts { int A[3], B[3]; };
+
+// MapColorsQuantized (:2044-2077): total fp32 error of the texels against the palette of `ep`
+template<int N>
+DXTEX_HD6 float map_colors_q(const Texels& tx, const float (&pr)[N], const float (&pg)[N], const float (&pb)[N])
+{
+    float tot = 0.0f;
+    for (int k = 0; k < tx.np; ++k)
+    {
+        const float r = tx.r[k * tx.stride], g = tx.g[k * tx.stride], b = tx.b[k * tx.stride];
+        float e[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) e[i] = norm3(r, g, b, pr[i], pg[i], pb[i]);
+        tot += scan_min(e);
+    }
+    return tot;
+}
+
+// AssignIndices for one region (:2260-2301) + SwapIndices (:2228-2255). `pos` = 4-bit block positions of the region's
+// texels; indices come back as 4 bits per block position.
+template<int N>
+DXTEX_HD6 float assign_indices6(const Texels& tx, uint64_t pos, EndPts& ep, int prec, bool isSigned, uint32_t anchorPos, uint64_t& idxOut)
+{
+    float pr[N], pg[N], pb[N];
+    palette_channel<N>(ep.A[0], ep.B[0], prec, isSigned, pr);
+    palette_channel<N>(ep.A[1], ep.B[1], prec, isSigned, pg);
+    palette_channel<N>(ep.A[2], ep.B[2], prec, isSigned, pb);
+    float tot = 0.0f;
+    uint64_t idx = 0, member = 0;
+    for (int k = 0; k < tx.np; ++k)
+    {
+        const float r = tx.r[k * tx.stride], g = tx.g[k * tx.stride], b = tx.b[k * tx.stride];
+        float e[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) e[i] = norm3(r, g, b, pr[i], pg[i], pb[i]);
+        uint32_t ix;
+        tot += scan_min_idx(e, ix);
+        const uint32_t p = uint32_t(pos >> (4 * k)) & 15u;
+        idx |= uint64_t(ix) << (4 * p);
+        member |= uint64_t(0xF) << (4 * p);
+    }
+    if ((idx >> (4 * anchorPos)) & uint64_t(N >> 1))
+    {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const int t = ep.A[c]; ep.A[c] = ep.B[c]; ep.B[c] = t; }
+        idx ^= member & (uint64_t(N - 1) * 0x1111111111111111ull);
+    }
+    idxOut = idx;
+    return tot;
+}
+
+// EndPointsFit for the endpoints ONE lane holds (:1945-1986): region 0 -> (A absolute, B delta); region 1 -> both delta
+DXTEX_HD6 bool endpoints_fit(const EndPts& t, int region, const ModeRt& m, bool isSigned)
+{
+    const bool ds = m.transformed || isSigned;
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+    {
+        if (region == 0) ok = ok && (nbits(t.A[c], isSigned) <= m.prec);
+        else ok = ok && (nbits(t.A[c], ds) <= m.delta[c]);
+        ok = ok && (nbits(t.B[c], ds) <= m.delta[c]);
+    }
+    return ok;
+}
+
+// TransformForward for one lane's endpoints (:1146-1151); a0 = region 0's A
+DXTEX_HD6 EndPts transform_forward(const EndPts& e, int region, const int (&a0)[3])
+{
+    EndPts t = e;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+    {
+        if (region != 0) t.A[c] = e.A[c] - a0[c];
+        t.B[c] = e.B[c] - a0[c];
+    }
+    return t;
+}
+
+// ---- OptimizeOne (:2145-2194) as lockstep pieces ---------------------------------------------------------------------------
+struct Perturb6
+{
+    EndPts ep;
+    float err;
+    int ch;         // 0..2, 3 = finished
+    int sub;        // 0 = first pass on A, 1 = first pass on B, 2 = alternating loop
+    int do_b;
+    float err0;     // result of the first pass on A
+    int new0;       // value found by the first pass on A
+};
+
+DXTEX_HD6 Perturb6 perturb6_begin(const EndPts& ep, float err)
+{
+    Perturb6 s; s.ep = ep; s.err = err; s.ch = 0; s.sub = 0; s.do_b = 0; s.err0 = 0.0f; s.new0 = 0;
+    return s;
+}
+
+// One PerturbOne call (:2081-2141): 2 * prec candidate evaluations, straight-line.
+template<int N>
+DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, bool isSigned, float& outErr, int& outVal)
+{
+    // palettes of the three channels for the current endpoints; channel s.ch is rebuilt per candidate
+    float base[3][N];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) palette_channel<N>(s.ep.A[c], s.ep.B[c], prec, isSigned, base[c]);
+    const int fixedQ = (s.ch == 0) ? (s.do_b ? s.ep.A[0] : s.ep.B[0]) : (s.ch == 1) ? (s.do_b ? s.ep.A[1] : s.ep.B[1]) : (s.do_b ? s.ep.A[2] : s.ep.B[2]);
+    int cur = (s.ch == 0) ? (s.do_b ? s.ep.B[0] : s.ep.A[0]) : (s.ch == 1) ? (s.do_b ? s.ep.B[1] : s.ep.A[1]) : (s.do_b ? s.ep.B[2] : s.ep.A[2]);
+    float minErr = s.err;
+#pragma unroll 1
+    for (int step = 1 << (prec - 1); step; step >>= 1)
+    {
+        int beststep = 0;
+#pragma unroll 1
+        for (int sign = -1; sign <= 1; sign += 2)
+        {
+            const int tmp = cur + sign * step;
+            const bool valid = (tmp >= 0) && (tmp < (1 << prec));
+            float var[N];
+            palette_channel<N>(s.do_b ? fixedQ : tmp, s.do_b ? tmp : fixedQ, prec, isSigned, var);
+            float pr[N], pg[N], pb[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+            {
+                pr[i] = (s.ch == 0) ? var[i] : base[0][i];
+                pg[i] = (s.ch == 1) ? var[i] : base[1][i];
+                pb[i] = (s.ch == 2) ? var[i] : base[2][i];
+            }
+            const float e = map_colors_q<N>(tx, pr, pg, pb);
+            if (valid && e < minErr) { minErr = e; beststep = sign * step; }
+        }
+        cur += beststep;
+    }
+    outErr = minErr; outVal = cur;
+}
+
+DXTEX_HD6 void set_channel(EndPts& ep, int ch, int do_b, int v)
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (c == ch) { if (do_b) ep.B[c] = v; else ep.A[c] = v; }
+}
+
+DXTEX_HD6 Perturb6 perturb6_transition(const Perturb6& in, float e, int val)
+{
+    Perturb6 s = in;
+    if (in.sub == 0) { s.err0 = e; s.new0 = val; s.sub = 1; s.do_b = 1; return s; }
+    if (in.sub == 1)
+    {
+        // e = fErr1 (B side, value `val`), err0 / new0 = A side
+        if (in.err0 < e)
+        {
+            if (in.err0 >= in.err) { s.ch = in.ch + 1; s.sub = 0; s.do_b = 0; return s; }
+            set_channel(s.ep, in.ch, 0, in.new0); s.err = in.err0; s.do_b = 1;
+        }
+        else
+        {
+            if (e >= in.err) { s.ch = in.ch + 1; s.sub = 0; s.do_b = 0; return s; }
+            set_channel(s.ep, in.ch, 1, val); s.err = e; s.do_b = 0;
+        }
+        s.sub = 2;
+        return s;
+    }
+    if (e >= in.err) { s.ch = in.ch + 1; s.sub = 0; s.do_b = 0; return s; }
+    set_channel(s.ep, in.ch, in.do_b, val); s.err = e; s.do_b = 1 - in.do_b;
+    return s;
+}
+
+template<int N>
+DXTEX_HD6 void optimize_one6(const Texels& tx, const EndPts& org, float orgErr, int prec, bool isSigned, EndPts& opt)
+{
+    Perturb6 s = perturb6_begin(org, orgErr);
+    while (s.ch < 3)
+    {
+        float e; int v;
+        perturb6_macro<N>(tx, s, prec, isSigned, e, v);
+        s = perturb6_transition(s, e, v);
+    }
+    opt = s.ep;
+}
+
+// ---- rough pass pieces -----------------------------------------------------------------------------------------------------
+// INTColor::Set (:498-508) for one float: XMStoreHalf4 (round to nearest even) then F16ToINT
+DXTEX_HD6 int float_to_int16f(float v, bool isSigned)
+{
+#if defined(DXTEX_HOST_DEBUG)
+    const uint32_t h = dxtex_host_float_to_half(v);
+#else
+    const uint32_t h = __half_as_ushort(__float2half_rn(v));
+#endif
+    return f16_to_int(h, isSigned);
+}
+
+DXTEX_HD6 int clamp_seed(int v, bool isSigned)
+{
+    const int lo = isSigned ? -int(F16MAX) : 0, hi = int(F16MAX);
+    v = (v > lo) ? v : lo;              // std::min(iMax, std::max(iMin, v))
+    return (v < hi) ? v : hi;
+}
+
+// MapColors (:2467-2494): rough error of a region against the UNQUANTISED palette of the seed (:2430-2464)
+template<int N>
+DXTEX_HD6 float rough_error6(const Texels& tx, const EndPts& seed)
+{
+    float pr[N], pg[N], pb[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+        const int w = weight_of<N>(i);
+        pr[i] = float((seed.A[0] * (64 - w) + seed.B[0] * w + 32) >> 6);
+        pg[i] = float((seed.A[1] * (64 - w) + seed.B[1] * w + 32) >> 6);
+        pb[i] = float((seed.A[2] * (64 - w) + seed.B[2] * w + 32) >> 6);
+    }
+    return map_colors_q<N>(tx, pr, pg, pb);
+}
+
+// ---- EmitBlock (:2330-2373) --------------------------------------------------------------------------------------------------
+struct Bits128w
+{
+    uint64_t lo, hi; uint32_t pos;
+    DXTEX_HD6 void put(uint32_t nbits, uint32_t value)
+    {
+        if (!nbits) return;
+        const uint64_t v = uint64_t(value) & ((uint64_t(1) << nbits) - 1);
+        if (pos < 64) { lo |= v << pos; if (pos + nbits > 64) hi |= v >> (64 - pos); }
+        else hi |= v << (pos - 64);
+        pos += nbits;
+    }
+};
+
+// ep[0..3] = A0, B0, A1, B1 as they go into the block (delta-transformed when the mode is)
+DXTEX_HD6 void emit_block6(const ModeRt& m, uint32_t shape, const int (&ep)[4][3], uint64_t idx, uint32_t anchor1, uint64_t& lo, uint64_t& hi)
+{
+    Bits128w w; w.lo = 0; w.hi = 0; w.pos = 0;
+    const uint32_t headerBits = m.regions2 ? 82u : 65u;
+    const uint8_t* desc = kBc6hHeader[m.index];
+    for (uint32_t bit = 0; bit < headerBits; ++bit)
+    {
+        const uint32_t f = desc[bit] >> 4, k = desc[bit] & 15u;
+        uint32_t v;
+        if (f == 1) v = uint32_t(m.code) >> k;
+        else if (f == 2) v = shape >> k;
+        else { const uint32_t q = f - 3; v = uint32_t(ep[q & 3][q >> 2] >> k); }
+        w.put(1, v & 1u);
+    }
+    const uint32_t ib = m.regions2 ? 3u : 4u;
+    for (uint32_t i = 0; i < 16; ++i)
+    {
+        const bool isAnchor = (i == 0) || (m.regions2 && i == anchor1);
+        w.put(isAnchor ? ib - 1 : ib, uint32_t(idx >> (4 * i)) & 15u);
+    }
+    lo = w.lo; hi = w.hi;
+}
+} // namespace bc6h
+} // namespace dxtex

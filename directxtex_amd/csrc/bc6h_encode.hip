@@ -1,0 +1,516 @@
+// BC6H encoder kernels for gfx950: byte-identical to D3DX_BC6H::Encode (BC6HBC7.cpp:1817-1859) for BC6H_UF16 and
+// BC6H_SF16. What one lane computes is in bc6h_core.h; this file spreads it over the machine the same way
+// bc7_encode.hip does for BC7:
+//   rough   : one wavefront per block, lane = partition shape (32 two-region shapes + the one-region case). Float
+//             OptimizeRGB seeds, RoughMSE against the unquantised palette, the reference's partial selection sort
+//             (:1836-1848) -> the 8 best shapes and their seeds. The ranking does not depend on the mode, so it is
+//             done once for the ten two-region modes.
+//   per mode (14, in the encoder's order):
+//     pre     lane = (block, candidate shape, region): QuantizeEndPts -> AssignIndices -> SwapIndices ->
+//             TransformForward -> EndPointsFit (the two region lanes of a candidate combine with shuffles).
+//     bin     counting sort of the live tasks by texel count (search_common.h).
+//     perturb persistent wavefronts pulling tasks from a global queue; OptimizeOne (:2145-2194) as straight-line
+//             PERTURB macro-ops of 2 * precision candidate evaluations each (BC6H has no exhaustive phase).
+//     post    AssignIndices / SwapIndices of the optimised endpoints, org-vs-opt decision (:2401-2424), first minimum
+//             over the block's candidates, EmitBlock into the block's running best if it is strictly better - modes run
+//             in order on one stream, which reproduces Encode's "fBestErr" sequence.
+//   store   running best -> destination image.
+// The search is VALU-bound fp32 work (10 ops per texel x palette entry); HBM traffic is 9 B/texel algorithmic.
+#include "dxtex_kernels.h"
+#include "bc67_tables.h"
+#include "bc7_core.h"
+#include "bc6h_core.h"
+#include "search_common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstdio>
+#include <vector>
+
+namespace dxtex
+{
+namespace
+{
+using namespace bc6h;
+
+struct Rec6 { int A[3], B[3]; float err; uint32_t valid; };        // 32 bytes per task
+struct Best6 { float err; uint32_t pad; uint64_t lo, hi; };        // 24 bytes per block
+
+enum : int { SEED_INTS = 17 * 6 + 2 };      // 8 shapes x 2 regions + the one-region seed, 6 ints each (+ pad)
+
+struct Bc6hArgs
+{
+    SrcView src;
+    uint8_t* dst; uint64_t dstRowPitch;
+    uint32_t nbw, nbh, nb0, nblocks;
+    int isSigned;
+    float* fpix;            // nblocks x 3 x 16: the block's texels as INTColor values held in floats (r[16], g[16], b[16])
+    uint8_t* lists;         // nblocks x 8 shape ids
+    int* seeds;             // nblocks x SEED_INTS
+    Rec6* recs;
+    uint2* order; uint32_t* tinfo; uint32_t* counters;
+    Best6* best;
+    ModeRt mode;
+};
+
+__device__ __forceinline__ Texels slot_texels(float* slot /* &sSlot[0][0][lane] */, int np)
+{
+    Texels t; t.r = slot; t.g = slot + 16 * 64; t.b = slot + 32 * 64; t.stride = 64; t.np = np;
+    return t;
+}
+
+// Copies the texels selected by `mask` from a block's float planes (r[16], g[16], b[16]) into the lane's LDS column
+// and returns their packed block positions.
+__device__ __forceinline__ int gather_texels(const float* planes, uint32_t mask, float* slot, uint64_t& pos)
+{
+    int np = 0; pos = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if ((mask >> i) & 1u)
+        {
+            slot[np * 64] = planes[i]; slot[(16 + np) * 64] = planes[16 + i]; slot[(32 + np) * 64] = planes[32 + i];
+            pos |= uint64_t(i) << (4 * np);
+            ++np;
+        }
+    return np;
+}
+
+// ---- rough ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
+{
+    __shared__ float sF[4][64];
+    __shared__ float sP[4][48];
+    __shared__ float sSlot[4][48 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t nb = blockIdx.x * 4 + wave;
+    if (nb >= a.nblocks) return;
+    const bool sg = a.isSigned != 0;
+
+    if (lane < 16)
+    {
+        // one texel of the block, with the reference's partial-block replication (DirectXTexCompress.cpp:315-341)
+        const uint32_t gb = a.nb0 + nb;
+        const uint32_t by = gb / a.nbw, bx = gb - by * a.nbw;
+        const uint32_t x0 = bx * 4, y0 = by * 4;
+        const uint32_t pw = min(4u, a.src.width - x0), ph = min(4u, a.src.height - y0);
+        const uint32_t sx = x0 + replicate_src(lane & 3, pw), sy = y0 + replicate_src(lane >> 2, ph);
+        const Texel px = convert_texel(load_texel(a.src.pixels + uint64_t(sy) * a.src.rowPitch, sx, a.src.format), a.src.tcv, a.src.tsw);
+        sF[wave][lane * 4 + 0] = px.r; sF[wave][lane * 4 + 1] = px.g; sF[wave][lane * 4 + 2] = px.b; sF[wave][lane * 4 + 3] = px.a;
+        const float ir = float(float_to_int16f(px.r, sg)), ig = float(float_to_int16f(px.g, sg)), ib = float(float_to_int16f(px.b, sg));
+        sP[wave][lane] = ir; sP[wave][16 + lane] = ig; sP[wave][32 + lane] = ib;
+        float* gp = a.fpix + uint64_t(nb) * 48;
+        gp[lane] = ir; gp[16 + lane] = ig; gp[32 + lane] = ib;
+    }
+    if (lane == 0) { Best6 b; b.err = 3.402823466e+38f; b.pad = 0; b.lo = 0; b.hi = 0; a.best[nb] = b; }
+    wave_lds_sync();
+    const float* fpx = sF[wave];
+    const float* planes = sP[wave];
+    float* slot = &sSlot[wave][lane];
+
+    // lanes 0..31: two-region shape `lane`; lane 32: the one-region case
+    EndPts seed[2];
+    float rough = 0.0f;
+    const int nreg = (lane < 32) ? 2 : (lane == 32 ? 1 : 0);
+    const uint32_t m1 = (lane < 32) ? uint32_t(kPart2Mask[lane & 31]) : 0u;
+#pragma unroll 1
+    for (int r = 0; r < nreg; ++r)
+    {
+        const uint32_t mask = (lane < 32) ? (r ? m1 : ((~m1) & 0xFFFFu)) : 0xFFFFu;
+        uint64_t pos;
+        const int np = gather_texels(planes, mask, slot, pos);
+        EndPts s;
+        if (np == 1)
+        {
+            s.A[0] = s.B[0] = int(slot[0]); s.A[1] = s.B[1] = int(slot[16 * 64]); s.A[2] = s.B[2] = int(slot[32 * 64]);
+        }
+        else if (np == 2)
+        {
+            s.A[0] = int(slot[0]); s.A[1] = int(slot[16 * 64]); s.A[2] = int(slot[32 * 64]);
+            s.B[0] = int(slot[64]); s.B[1] = int(slot[17 * 64]); s.B[2] = int(slot[33 * 64]);
+        }
+        else
+        {
+            float X[4], Y[4];
+            bc7::seed_fit<false>(fpx, mask, X, Y);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+            {
+                s.A[c] = clamp_seed(float_to_int16f(X[c], sg), sg);
+                s.B[c] = clamp_seed(float_to_int16f(Y[c], sg), sg);
+            }
+            // one-region modes are never ranked, their rough error is not needed
+            if (lane < 32) rough += rough_error6<8>(slot_texels(slot, np), s);
+        }
+        seed[r] = s;
+    }
+
+    int key = (lane < 32) ? __float_as_int(rough) : 0x7FFFFFFF;
+    uint32_t shp = uint32_t(lane);
+    for (int i = 0; i < 8; ++i) selection_pass(key, shp, lane, i);
+    int* sd = a.seeds + uint64_t(nb) * SEED_INTS;
+    // lane i < 8 now knows the i-th best shape; its seeds still sit in lane `shp`
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+        {
+            const int va = __shfl(seed[r].A[c], int(shp)), vb = __shfl(seed[r].B[c], int(shp));
+            if (lane < 8) { sd[(lane * 2 + r) * 6 + c] = va; sd[(lane * 2 + r) * 6 + 3 + c] = vb; }
+        }
+    if (lane < 8) a.lists[uint64_t(nb) * 8 + lane] = uint8_t(shp);
+    if (lane == 32)
+    {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sd[16 * 6 + c] = seed[0].A[c]; sd[16 * 6 + 3 + c] = seed[0].B[c]; }
+    }
+}
+
+// ---- pre / post --------------------------------------------------------------------------------------------------------------
+// Lane layout of pre / post: two-region modes use 16 lanes per block (rank * 2 + region), one-region modes 1 lane.
+template<int REGIONS2> struct Lay6 { enum : int { TPB = REGIONS2 ? 16 : 1, N = REGIONS2 ? 8 : 16, BPW = 64 / TPB }; };
+
+struct Org6
+{
+    EndPts ep;              // quantised, anchor-fixed endpoints of this lane's region
+    EndPts epT;             // the same after TransformForward (what EmitBlock would write)
+    float err; uint64_t idx;
+    bool fit;               // the whole candidate passes EndPointsFit
+    uint32_t shape, mask, anchor; uint64_t pos; int np;
+};
+
+// Refine's first half (:2386-2393) for this lane's region; needs the partner lane of the candidate for the transform.
+template<int REGIONS2>
+__device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, uint32_t r, const float* planes, float* slot, Org6& o)
+{
+    typedef Lay6<REGIONS2> L;
+    const bool sg = a.isSigned != 0;
+    const uint32_t rank = REGIONS2 ? (r >> 1) : 0u, region = REGIONS2 ? (r & 1u) : 0u;
+    o.shape = REGIONS2 ? uint32_t(a.lists[uint64_t(nb) * 8 + rank]) : 0u;
+    const uint32_t m1 = REGIONS2 ? uint32_t(kPart2Mask[o.shape]) : 0u;
+    o.mask = REGIONS2 ? (region ? m1 : ((~m1) & 0xFFFFu)) : 0xFFFFu;
+    o.anchor = (REGIONS2 && region) ? uint32_t(kAnchor2[o.shape]) : 0u;
+    const int* sd = a.seeds + uint64_t(nb) * SEED_INTS + (REGIONS2 ? (rank * 2 + region) * 6 : 16 * 6);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+    {
+        o.ep.A[c] = quantize(sd[c], a.mode.prec, sg);
+        o.ep.B[c] = quantize(sd[3 + c], a.mode.prec, sg);
+    }
+    o.np = gather_texels(planes, o.mask, slot, o.pos);
+    o.err = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, o.ep, a.mode.prec, sg, o.anchor, o.idx);
+    int a0[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a0[c] = REGIONS2 ? __shfl(o.ep.A[c], (threadIdx.x & 63) & ~1) : o.ep.A[c];
+    o.epT = a.mode.transformed ? transform_forward(o.ep, int(region), a0) : o.ep;
+    bool fit = endpoints_fit(o.epT, int(region), a.mode, sg);
+    if (REGIONS2) { const int partner = __shfl_xor(int(fit), 1); fit = fit && (partner != 0); }     // no short-circuit around the shuffle
+    o.fit = fit;
+}
+
+template<int REGIONS2>
+__global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
+{
+    typedef Lay6<REGIONS2> L;
+    __shared__ float sSlot[4][48 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t nbFirst = (blockIdx.x * 4 + wave) * L::BPW;
+    if (nbFirst >= a.nblocks) return;
+    const uint32_t blk = uint32_t(lane) / L::TPB, r = uint32_t(lane) % L::TPB;
+    const uint32_t nb = min(nbFirst + blk, a.nblocks - 1);       // out-of-range lanes shadow the last block (shuffles stay defined)
+    const bool inRange = (nbFirst + blk) < a.nblocks;
+    float planes[48];
+    const float4* gp = reinterpret_cast<const float4*>(a.fpix + uint64_t(nb) * 48);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const float4 v = gp[i]; planes[4 * i] = v.x; planes[4 * i + 1] = v.y; planes[4 * i + 2] = v.z; planes[4 * i + 3] = v.w; }
+    Org6 o;
+    org_candidate<REGIONS2>(a, nb, r, planes, &sSlot[wave][lane], o);
+#if defined(DXTEX_BC6H_TRACE)
+    if (nb == 0 && a.mode.index == 0) printf("pre r %u shape %u fit %d A %d %d %d B %d %d %d | T A %d %d %d B %d %d %d err %.9g np %d tr %d delta %d %d %d\n", r, o.shape, int(o.fit), o.ep.A[0], o.ep.A[1], o.ep.A[2], o.ep.B[0], o.ep.B[1], o.ep.B[2], o.epT.A[0], o.epT.A[1], o.epT.A[2], o.epT.B[0], o.epT.B[1], o.epT.B[2], o.err, o.np, a.mode.transformed, a.mode.delta[0], a.mode.delta[1], a.mode.delta[2]);
+#endif
+    if (!inRange) return;
+    const uint64_t t = uint64_t(nb) * L::TPB + r;
+    Rec6 rec;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { rec.A[c] = o.ep.A[c]; rec.B[c] = o.ep.B[c]; }
+    rec.err = o.err; rec.valid = o.fit ? 1u : 0u;
+    a.recs[t] = rec;
+    // OptimizeEndPoints' quirk (:2215): region 0 is optimised against all sixteen texels. Nothing to search when the
+    // candidate does not fit or its error is already 0 (PerturbOne only accepts strictly smaller errors).
+    const bool region0 = !REGIONS2 || (r & 1u) == 0;
+    const uint32_t smask = region0 ? 0xFFFFu : o.mask;
+    const uint32_t snp = (o.fit && o.err > 0.0f) ? uint32_t(region0 ? 16 : o.np) : 0u;
+    a.tinfo[t] = smask | (snp << 24);
+}
+
+template<int REGIONS2>
+__global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
+{
+    typedef Lay6<REGIONS2> L;
+    __shared__ float sSlot[4][48 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t nbFirst = (blockIdx.x * 4 + wave) * L::BPW;
+    if (nbFirst >= a.nblocks) return;
+    const bool sg = a.isSigned != 0;
+    const uint32_t blk = uint32_t(lane) / L::TPB, r = uint32_t(lane) % L::TPB;
+    const uint32_t nb = min(nbFirst + blk, a.nblocks - 1);
+    const bool inRange = (nbFirst + blk) < a.nblocks;
+    const uint32_t rank = REGIONS2 ? (r >> 1) : 0u, region = REGIONS2 ? (r & 1u) : 0u;
+    float planes[48];
+    const float4* gp = reinterpret_cast<const float4*>(a.fpix + uint64_t(nb) * 48);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const float4 v = gp[i]; planes[4 * i] = v.x; planes[4 * i + 1] = v.y; planes[4 * i + 2] = v.z; planes[4 * i + 3] = v.w; }
+    float* slot = &sSlot[wave][lane];
+    Org6 o;
+    org_candidate<REGIONS2>(a, nb, r, planes, slot, o);
+
+    // the optimised endpoints (== the org ones where no search ran)
+    const Rec6 rec = a.recs[uint64_t(nb) * L::TPB + r];
+    EndPts opt;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { opt.A[c] = rec.A[c]; opt.B[c] = rec.B[c]; }
+    uint64_t optIdx;
+    const float optErr = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, opt, a.mode.prec, sg, o.anchor, optIdx);
+    float orgTot = 0.0f + o.err, optTot = 0.0f + optErr;
+    if (REGIONS2)
+    {
+        // fTot += aErr[0]; fTot += aErr[1] (:2401-2406): region 0 first
+        const float oe = __shfl_xor(o.err, 1), pe = __shfl_xor(optErr, 1);
+        orgTot = region ? (0.0f + oe) + o.err : (0.0f + o.err) + oe;
+        optTot = region ? (0.0f + pe) + optErr : (0.0f + optErr) + pe;
+    }
+    int b0[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) b0[c] = REGIONS2 ? __shfl(opt.A[c], lane & ~1) : opt.A[c];
+    const EndPts optT = a.mode.transformed ? transform_forward(opt, int(region), b0) : opt;
+    bool fitOpt = endpoints_fit(optT, int(region), a.mode, sg);
+    if (REGIONS2) { const int partner = __shfl_xor(int(fitOpt), 1); fitOpt = fitOpt && (partner != 0); }
+    const bool useOpt = fitOpt && (optTot < orgTot);
+    const float err = useOpt ? optTot : orgTot;
+    const EndPts fin = useOpt ? optT : o.epT;
+    const uint64_t myIdx = useOpt ? optIdx : o.idx;
+
+    // first minimum over the block's candidates, in rank order
+    const bool valid = o.fit && inRange;
+    uint64_t key = valid ? ((uint64_t(uint32_t(__float_as_int(err))) << 8) | rank) : ~0ull;
+    uint64_t bestKey = key;
+    if (REGIONS2)
+    {
+#pragma unroll
+        for (int d = 2; d < 16; d <<= 1)
+        {
+            const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(bestKey)), d)), hi = uint32_t(__shfl_xor(int(uint32_t(bestKey >> 32)), d));
+            const uint64_t other = (uint64_t(hi) << 32) | lo;
+            bestKey = other < bestKey ? other : bestKey;
+        }
+    }
+    // region 1's endpoints and indices travel to the candidate's region-0 lane
+    int ep[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+    {
+        ep[0][c] = fin.A[c]; ep[1][c] = fin.B[c];
+        ep[2][c] = REGIONS2 ? __shfl_down(fin.A[c], 1) : 0;
+        ep[3][c] = REGIONS2 ? __shfl_down(fin.B[c], 1) : 0;
+    }
+    uint64_t idx = myIdx;
+    if (REGIONS2)
+        idx |= uint64_t(uint32_t(__shfl_down(int(uint32_t(myIdx)), 1))) | (uint64_t(uint32_t(__shfl_down(int(uint32_t(myIdx >> 32)), 1))) << 32);
+    if (valid && region == 0 && key == bestKey)
+    {
+        Best6* b = a.best + nb;
+        if (err < b->err)         // Refine only emits when it beats fBestErr (:2412-2424)
+        {
+            Best6 n; n.err = err; n.pad = 0;
+            emit_block6(a.mode, o.shape, ep, idx, REGIONS2 ? uint32_t(kAnchor2[o.shape]) : 0u, n.lo, n.hi);
+            *b = n;
+        }
+    }
+}
+
+// ---- perturb ------------------------------------------------------------------------------------------------------------------
+template<int N>
+__global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a)
+{
+    __shared__ float sSlot[48 * 64];
+    const int lane = threadIdx.x;
+    const bool sg = a.isSigned != 0;
+    const uint32_t live = a.counters[34];
+    uint32_t* head = a.counters + kQueueBase;
+    float* slot = &sSlot[lane];
+    const int TPB = (N == 8) ? 16 : 1;
+
+    EndPts zero; for (int c = 0; c < 3; ++c) { zero.A[c] = 0; zero.B[c] = 0; }
+    Perturb6 st = perturb6_begin(zero, 0.0f);
+    Texels tx = slot_texels(slot, 0);
+    uint32_t myTask = 0xFFFFFFFFu;
+    WaveQueue q; q.lo = q.hi = 0; q.drained = false;
+    for (;;)
+    {
+        const unsigned long long idle = __ballot(myTask == 0xFFFFFFFFu);
+        if (idle && !(q.drained && q.lo >= q.hi))
+        {
+            const uint32_t idx = queue_take(q, head, live, idle, lane);
+            if (idx != 0xFFFFFFFFu)
+            {
+                const uint2 task = a.order[idx];
+                myTask = task.x;
+                const Rec6 rec = a.recs[myTask];
+                const uint32_t nb = myTask / uint32_t(TPB);
+                float planes[48];
+                const float4* gp = reinterpret_cast<const float4*>(a.fpix + uint64_t(nb) * 48);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) { const float4 v = gp[i]; planes[4 * i] = v.x; planes[4 * i + 1] = v.y; planes[4 * i + 2] = v.z; planes[4 * i + 3] = v.w; }
+                uint64_t pos;
+                tx.np = gather_texels(planes, task.y & 0xFFFFu, slot, pos);
+                EndPts e;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { e.A[c] = rec.A[c]; e.B[c] = rec.B[c]; }
+                st = perturb6_begin(e, rec.err);
+            }
+        }
+        if (__ballot(myTask != 0xFFFFFFFFu) == 0ull)
+        {
+            if (q.drained && q.lo >= q.hi) break;
+            continue;
+        }
+        if (myTask != 0xFFFFFFFFu)
+        {
+            float e; int v;
+            perturb6_macro<N>(tx, st, a.mode.prec, sg, e, v);
+            st = perturb6_transition(st, e, v);
+            if (st.ch >= 3)
+            {
+                Rec6* r = a.recs + myTask;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { r->A[c] = st.ep.A[c]; r->B[c] = st.ep.B[c]; }
+                myTask = 0xFFFFFFFFu;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) bc6h_store_kernel(Bc6hArgs a)
+{
+    const uint32_t nb = blockIdx.x * 256u + threadIdx.x;
+    if (nb >= a.nblocks) return;
+    const Best6 b = a.best[nb];
+    const uint32_t gb = a.nb0 + nb;
+    const uint32_t by = gb / a.nbw, bx = gb - by * a.nbw;
+    uint64_t* out = reinterpret_cast<uint64_t*>(a.dst + uint64_t(by) * a.dstRowPitch) + 2 * uint64_t(bx);
+    out[0] = b.lo; out[1] = b.hi;
+}
+
+constexpr uint64_t kMaxBlocksPerPass6 = 1u << 20;
+struct Scratch6
+{
+    size_t fpix, lists, seeds, recs, order, tinfo, counters, best, total;
+    explicit Scratch6(uint64_t nb)
+    {
+        auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
+        size_t o = 0;
+        fpix = o; o = up(o + nb * 48 * sizeof(float));
+        lists = o; o = up(o + nb * 8);
+        seeds = o; o = up(o + nb * SEED_INTS * sizeof(int));
+        recs = o; o = up(o + nb * 16 * sizeof(Rec6));
+        order = o; o = up(o + nb * 16 * sizeof(uint2));
+        tinfo = o; o = up(o + nb * 16 * sizeof(uint32_t));
+        counters = o; o = up(o + 64 * sizeof(uint32_t));
+        best = o; o = up(o + nb * sizeof(Best6));
+        total = o;
+    }
+};
+} // namespace
+
+size_t bc6h_scratch_bytes(uint64_t nblocks)
+{
+    return Scratch6(nblocks < kMaxBlocksPerPass6 ? nblocks : kMaxBlocksPerPass6).total;
+}
+
+hipError_t launch_bc6h_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, bool isSigned, void* scratch,
+                              hipStream_t stream, KernelMarks* marks)
+{
+#define DXTEX_MARK(NAME) do { if (marks) marks->mark(NAME); } while (0)
+    const uint32_t nbw = (src.width + 3) / 4, nbh = (src.height + 3) / 4;
+    const uint64_t total = uint64_t(nbw) * nbh;
+    if (!total) return hipSuccess;
+    uint8_t* base = static_cast<uint8_t*>(scratch);
+    for (uint64_t first = 0; first < total; first += kMaxBlocksPerPass6)
+    {
+        const uint64_t nb = (total - first) < kMaxBlocksPerPass6 ? (total - first) : kMaxBlocksPerPass6;
+        const Scratch6 L(nb);
+        Bc6hArgs a;
+        a.src = src; a.dst = dst; a.dstRowPitch = dstRowPitch;
+        a.nbw = nbw; a.nbh = nbh; a.nb0 = uint32_t(first); a.nblocks = uint32_t(nb);
+        a.isSigned = isSigned ? 1 : 0;
+        a.fpix = reinterpret_cast<float*>(base + L.fpix);
+        a.lists = base + L.lists;
+        a.seeds = reinterpret_cast<int*>(base + L.seeds);
+        a.recs = reinterpret_cast<Rec6*>(base + L.recs);
+        a.order = reinterpret_cast<uint2*>(base + L.order);
+        a.tinfo = reinterpret_cast<uint32_t*>(base + L.tinfo);
+        a.counters = reinterpret_cast<uint32_t*>(base + L.counters);
+        a.best = reinterpret_cast<Best6*>(base + L.best);
+        a.mode = ModeRt();
+
+        DXTEX_MARK("bc6h_rough");
+        hipLaunchKernelGGL(bc6h_rough_kernel, dim3((a.nblocks + 3) / 4), dim3(256), 0, stream, a);
+        if (getenv("DXTEX_BC6H_DUMP"))     // development aid: rank lists and seeds of the first blocks
+        {
+            (void)hipStreamSynchronize(stream);
+            const uint32_t n = std::min<uint32_t>(a.nblocks, 4);
+            std::vector<uint8_t> l(n * 8); std::vector<int> sd(n * SEED_INTS);
+            (void)hipMemcpy(l.data(), a.lists, l.size(), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(sd.data(), a.seeds, sd.size() * 4, hipMemcpyDeviceToHost);
+            for (uint32_t b = 0; b < n; ++b)
+            {
+                fprintf(stderr, "block %u shapes:", b);
+                for (int i = 0; i < 8; ++i) fprintf(stderr, " %d", l[b * 8 + i]);
+                fprintf(stderr, "\n  seeds rank0:");
+                for (int i = 0; i < 12; ++i) fprintf(stderr, " %d", sd[b * SEED_INTS + i]);
+                fprintf(stderr, "\n");
+            }
+        }
+        static const int onlyMode = getenv("DXTEX_BC6H_ONLY_MODE") ? atoi(getenv("DXTEX_BC6H_ONLY_MODE")) : -1;     // development aid
+        static const bool noSearch = getenv("DXTEX_BC6H_NO_SEARCH") != nullptr;
+        for (int mi = 0; mi < 14; ++mi)
+        {
+            if (onlyMode >= 0 && mi != onlyMode) continue;
+            static const Bc6hMode kModes[14] = {
+                { 0x00, 1, 1, 3, { 10, 10, 10 }, { 5, 5, 5 } }, { 0x01, 1, 1, 3, { 7, 7, 7 }, { 6, 6, 6 } }, { 0x02, 1, 1, 3, { 11, 11, 11 }, { 5, 4, 4 } },
+                { 0x06, 1, 1, 3, { 11, 11, 11 }, { 4, 5, 4 } }, { 0x0a, 1, 1, 3, { 11, 11, 11 }, { 4, 4, 5 } }, { 0x0e, 1, 1, 3, { 9, 9, 9 }, { 5, 5, 5 } },
+                { 0x12, 1, 1, 3, { 8, 8, 8 }, { 6, 5, 5 } }, { 0x16, 1, 1, 3, { 8, 8, 8 }, { 5, 6, 5 } }, { 0x1a, 1, 1, 3, { 8, 8, 8 }, { 5, 5, 6 } },
+                { 0x1e, 1, 0, 3, { 6, 6, 6 }, { 6, 6, 6 } }, { 0x03, 0, 0, 4, { 10, 10, 10 }, { 10, 10, 10 } }, { 0x07, 0, 1, 4, { 11, 11, 11 }, { 9, 9, 9 } },
+                { 0x0b, 0, 1, 4, { 12, 12, 12 }, { 8, 8, 8 } }, { 0x0f, 0, 1, 4, { 16, 16, 16 }, { 4, 4, 4 } } };     // == kBc6hModes (device table), host copy
+            const Bc6hMode& k = kModes[mi];
+            a.mode.index = mi; a.mode.code = k.code; a.mode.regions2 = k.regions2; a.mode.transformed = k.transformed; a.mode.prec = k.prec[0];
+            for (int c = 0; c < 3; ++c) a.mode.delta[c] = k.delta[c];
+            const uint32_t tpb = k.regions2 ? 16u : 1u, bpw = 64u / tpb;
+            const uint32_t ntasks = a.nblocks * tpb;
+            const uint32_t gridPP = (a.nblocks + 4 * bpw - 1) / (4 * bpw);
+            const uint32_t binGroups = std::min<uint32_t>(kBinGroups, (ntasks + 255) / 256);
+            const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
+            static const char* const nPre[2] = { "bc6h_pre_1region", "bc6h_pre_2region" }, * const nBin[2] = { "bc6h_bin_1region", "bc6h_bin_2region" },
+                             * const nPer[2] = { "bc6h_perturb_1region", "bc6h_perturb_2region" }, * const nPost[2] = { "bc6h_post_1region", "bc6h_post_2region" };
+            DXTEX_MARK(nPre[k.regions2]);
+            if (k.regions2) hipLaunchKernelGGL(bc6h_pre_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL(bc6h_pre_kernel<0>, dim3(gridPP), dim3(256), 0, stream, a);
+            DXTEX_MARK(nBin[k.regions2]);
+            (void)hipMemsetAsync(a.counters, 0, 64 * sizeof(uint32_t), stream);
+            hipLaunchKernelGGL(bc7_bin_count_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters);
+            hipLaunchKernelGGL(bc7_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a.counters);
+            hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order);
+            DXTEX_MARK(nPer[k.regions2]);
+            if (noSearch) {}
+            else if (k.regions2) hipLaunchKernelGGL(bc6h_perturb_kernel<8>, dim3(waves), dim3(64), 0, stream, a);
+            else hipLaunchKernelGGL(bc6h_perturb_kernel<16>, dim3(waves), dim3(64), 0, stream, a);
+            DXTEX_MARK(nPost[k.regions2]);
+            if (k.regions2) hipLaunchKernelGGL(bc6h_post_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL(bc6h_post_kernel<0>, dim3(gridPP), dim3(256), 0, stream, a);
+        }
+        DXTEX_MARK("bc6h_store");
+        hipLaunchKernelGGL(bc6h_store_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, stream, a);
+    }
+    DXTEX_MARK(nullptr);
+#undef DXTEX_MARK
+    return hipGetLastError();
+}
+} // namespace dxtex

@@ -997,12 +997,12 @@ DXTEX_HD void for_masked(uint32_t mask16, F&& f)
     }
 }
 
+// The raw fit: X / Y are the end points OptimizeRGB / OptimizeRGBA return (pX, pY), before any clamping.
 template<bool RGBA, bool FULL = false>
-DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, uint32_t& outB)
+DXTEX_HD void seed_fit(const float* fpx, uint32_t mask16, float (&X)[4], float (&Y)[4])
 {
     constexpr float fEpsilon = (0.25f / 64.0f) * (0.25f / 64.0f);
     constexpr int NC = RGBA ? 4 : 3;
-    float X[4], Y[4];
     if (RGBA) { X[0] = X[1] = X[2] = X[3] = 1.0f; Y[0] = Y[1] = Y[2] = Y[3] = 0.0f; }
     else { X[0] = X[1] = X[2] = 3.402823466e+38f; Y[0] = Y[1] = Y[2] = -3.402823466e+38f; X[3] = 0.0f; Y[3] = 0.0f; }
 
@@ -1158,6 +1158,14 @@ DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, 
         }
     }
 
+}
+
+template<bool RGBA, bool FULL = false>
+DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, uint32_t& outB)
+{
+    constexpr int NC = RGBA ? 4 : 3;
+    float X[4], Y[4];
+    seed_fit<RGBA, FULL>(fpx, mask16, X, Y);
     uint32_t a = 0, b = 0;
 #pragma unroll
     for (int c = 0; c < NC; ++c)

@@ -164,6 +164,14 @@ dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width,
         e = launch_bc7_encode(v, dDst, dstRowPitch, flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
         break;
     }
+    case FMT_BC6H_UF16: case FMT_BC6H_SF16:
+    {
+        const uint64_t nblocks = uint64_t((width + 3) / 4) * uint64_t((height + 3) / 4);
+        hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc6h_scratch_bytes(nblocks));
+        if (hr != DXTEX_S_OK) return hr;
+        e = launch_bc6h_encode(v, dDst, dstRowPitch, dstFormat == FMT_BC6H_SF16, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
+        break;
+    }
     default:
         return fail(ctx, DXTEX_E_NOT_SUPPORTED, "BC format not implemented yet");
     }
@@ -416,12 +424,17 @@ dxtex_hresult dxtex_encode_blocks(dxtex_ctx* ctx, int32_t bc_format, uint32_t bc
         hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks, bc_flags));
         if (hr != DXTEX_S_OK) return hr;
     }
+    if (bc_format == FMT_BC6H_UF16 || bc_format == FMT_BC6H_SF16)
+    {
+        hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc6h_scratch_bytes(nblocks));
+        if (hr != DXTEX_S_OK) return hr;
+    }
     time_begin(ctx);
     switch (bc_format)
     {
     case FMT_BC6H_UF16: case FMT_BC6H_SF16:
-        time_end(ctx);
-        return fail(ctx, DXTEX_E_NOT_SUPPORTED, "BC format not implemented yet");
+        e = launch_bc6h_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_format == FMT_BC6H_SF16, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
+        break;
     case FMT_BC7_UNORM: case FMT_BC7_UNORM_SRGB:
         e = launch_bc7_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
         break;

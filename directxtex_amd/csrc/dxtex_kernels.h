@@ -22,6 +22,11 @@ size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags);
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
                              void* scratch, hipStream_t stream, KernelMarks* marks);
 
+// BC6H (UF16 / SF16): `scratch` must hold bc6h_scratch_bytes(number of 4x4 blocks) bytes of device memory.
+size_t bc6h_scratch_bytes(uint64_t nblocks);
+hipError_t launch_bc6h_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, bool isSigned, void* scratch,
+                              hipStream_t stream, KernelMarks* marks);
+
 // BC -> uncompressed (DecompressBC). `plan` = resolve_convert_plan(bc format, target format, TEX_FILTER_DEFAULT).
 struct ConvertPlan;
 hipError_t launch_bc_decode(const uint8_t* src, uint64_t srcRowPitch, int srcFormat, uint8_t* dst, uint64_t dstRowPitch, int dstFormat,

@@ -1,0 +1,81 @@
+"""BC6H (UF16 / SF16): the HIP encoder reproduces D3DX_BC6H::Encode (BC6HBC7.cpp:1817-1859) block for block; the
+north_star's one-sided MSE tolerance (MSE_gpu <= 1.02 * MSE_cpu + 1e-7) is asserted too, on half-float bit patterns
+decoded by the reference decoder."""
+import numpy as np
+import pytest
+
+import directxtex_amd as dx
+from directxtex_amd import synth
+
+pytestmark = pytest.mark.gpu
+UF16, SF16, RGBA16F, RGBA32F = 95, 96, 10, 2
+
+
+def _hdr_image(w, h, seed, signed=False):
+    """SURVEY.md section 8d recipe: half(exp2(uniform(-8, 6)) * smooth gradient), finite; optionally with negatives."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    grad = 0.25 + 0.75 * np.stack([x / max(1, w - 1), y / max(1, h - 1), (x + y) / max(1, w + h - 2)], -1)
+    patch = rng.uniform(-8, 6, ((h + 7) // 8, (w + 7) // 8, 1)).astype(np.float32)
+    ev = np.kron(patch, np.ones((8, 8, 1), np.float32))[:h, :w]
+    v = np.exp2(ev) * grad * (1.0 + 0.1 * rng.standard_normal((h, w, 3)).astype(np.float32))
+    if signed:
+        v = v * np.sign(rng.standard_normal((h, w, 3))).astype(np.float32)
+    img = np.concatenate([v, np.ones((h, w, 1), np.float32)], -1)
+    return img.astype(np.float16)
+
+
+def _check(oracle, got, ref, tag):
+    g = got.reshape(-1, 16); r = ref.reshape(-1, 16)
+    bad = np.nonzero((g != r).any(axis=1))[0]
+    assert bad.size == 0, f"{tag}: {bad.size} of {len(g)} blocks differ; first {bad[:8]}, mode bits gpu {[int(x) & 31 for x in g[bad[:8], 0]]} ref {[int(x) & 31 for x in r[bad[:8], 0]]}"
+
+
+@pytest.mark.parametrize("fmt", [UF16, SF16])
+@pytest.mark.parametrize("size", [(64, 64), (13, 9), (1, 1)])
+def test_bc6h_bit_exact(ctx, oracle, fmt, size):
+    w, h = size
+    img = _hdr_image(w, h, seed=w + h + fmt, signed=(fmt == SF16))
+    got = ctx.compress(img, w, h, RGBA16F, fmt, 0, 0.5)
+    ref = oracle.ref_compress_image(img, w, h, RGBA16F, fmt, 0, 0.5)
+    _check(oracle, got, ref, f"{fmt} {size}")
+    # stated tolerance, measured on the decoded texels
+    src = img.astype(np.float32)[..., :3]
+    dg = oracle.decode_image(got, w, h, fmt)[..., :3]; dr = oracle.decode_image(ref, w, h, fmt)[..., :3]
+    assert float(((dg - src) ** 2).mean()) <= 1.02 * float(((dr - src) ** 2).mean()) + 1e-7
+
+
+@pytest.mark.parametrize("fmt", [UF16, SF16])
+def test_bc6h_special_blocks(ctx, oracle, fmt):
+    """flat, two-value, tiny, huge, negative and LDR-range tiles through the BC_ENCODE-shaped hook."""
+    rng = np.random.default_rng(fmt)
+    tiles = []
+    for v in (0.0, 1.0, 65504.0, 1e-6, -1.0):
+        tiles.append(np.full((16, 4), v, np.float32))
+    t = np.zeros((16, 4), np.float32); t[::2, :3] = 4.0; tiles.append(t)
+    for scale in (1e-3, 0.1, 1.0, 8.0, 200.0, 30000.0):
+        for _ in range(20):
+            base = rng.random((1, 4), dtype=np.float32)
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                t = np.repeat(base, 16, 0)
+            elif kind == 1:
+                t = base + 0.02 * rng.random((16, 4), dtype=np.float32)
+            elif kind == 2:
+                t = rng.random((16, 4), dtype=np.float32)
+            else:
+                t = rng.random((16, 4), dtype=np.float32) - 0.3
+            tiles.append((t * scale).astype(np.float32))
+    tiles = np.stack(tiles); tiles[..., 3] = 1.0
+    got = ctx.encode_blocks(fmt, tiles, 0)
+    ref = oracle.ref_encode_blocks(fmt, tiles, 0)
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of {len(tiles)} blocks differ, first {bad[:8]}"
+
+
+def test_bc6h_from_rgba32f_and_rgba8(ctx, oracle):
+    w, h = 32, 16
+    img32 = _hdr_image(w, h, seed=3).astype(np.float32)
+    assert np.array_equal(ctx.compress(img32, w, h, RGBA32F, UF16, 0, 0.5), oracle.ref_compress_image(img32, w, h, RGBA32F, UF16, 0, 0.5))
+    img8 = synth.rgba8(w, h, seed=4, alpha="opaque")
+    assert np.array_equal(ctx.compress(img8, w, h, 28, UF16, 0, 0.5), oracle.ref_compress_image(img8, w, h, 28, UF16, 0, 0.5))

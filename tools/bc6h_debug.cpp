@@ -1,0 +1,182 @@
+// DEVELOPMENT TOOL (not part of the product, not part of the test suite): runs the BC6H core of
+// directxtex_amd/csrc/bc6h_core.h on the HOST, in the order the kernels of bc6h_encode.hip use it, next to the
+// reference's D3DX_BC6H::Encode compiled in place, and compares the emitted blocks.
+// Build + run:  tools/run_bc6h_debug.sh [ntiles] [seed]
+#define DXTEX_HOST_DEBUG 1
+#define private public
+#define protected public
+#include "BC6HBC7.cpp"     // the reference, in place (-I/root/reference/DirectXTex), against oracle/shim
+#undef private
+#undef protected
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+static inline uint32_t dxtex_host_float_to_half(float v) { return DirectX::PackedVector::XMConvertFloatToHalf(v); }
+#include "../directxtex_amd/csrc/bc7_core.h"
+#include "../directxtex_amd/csrc/bc6h_core.h"
+
+using namespace dxtex;
+using namespace dxtex::bc6h;
+
+static uint32_t g_rng = 1;
+static uint32_t rnd() { g_rng = g_rng * 1664525u + 1013904223u; return g_rng >> 8; }
+static float frand() { return float(rnd() & 0xFFFF) / 65535.0f; }
+
+static ModeRt mode_rt(int i)
+{
+    ModeRt m; const Bc6hMode& k = kBc6hModes[i];
+    m.index = i; m.code = k.code; m.regions2 = k.regions2; m.transformed = k.transformed; m.prec = k.prec[0];
+    for (int c = 0; c < 3; ++c) m.delta[c] = k.delta[c];
+    return m;
+}
+
+struct Region6 { float r[16], g[16], b[16]; uint64_t pos; int np; };
+static void gather(const int ipx[16][3], uint32_t mask, Region6& rg)
+{
+    rg.np = 0; rg.pos = 0;
+    for (int i = 0; i < 16; ++i)
+        if ((mask >> i) & 1) { rg.r[rg.np] = float(ipx[i][0]); rg.g[rg.np] = float(ipx[i][1]); rg.b[rg.np] = float(ipx[i][2]); rg.pos |= uint64_t(i) << (4 * rg.np); ++rg.np; }
+}
+static Texels tex(const Region6& rg) { Texels t; t.r = rg.r; t.g = rg.g; t.b = rg.b; t.stride = 1; t.np = rg.np; return t; }
+
+static EndPts seed_region(const float* fpx, const int ipx[16][3], uint32_t mask, bool isSigned, int& np)
+{
+    EndPts s; np = __builtin_popcount(mask);
+    int first = -1, second = -1;
+    for (int i = 0; i < 16; ++i) if ((mask >> i) & 1) { if (first < 0) first = i; else if (second < 0) second = i; }
+    if (np == 1) { for (int c = 0; c < 3; ++c) { s.A[c] = ipx[first][c]; s.B[c] = ipx[first][c]; } return s; }
+    if (np == 2) { for (int c = 0; c < 3; ++c) { s.A[c] = ipx[first][c]; s.B[c] = ipx[second][c]; } return s; }
+    float X[4], Y[4];
+    bc7::seed_fit<false>(fpx, mask, X, Y);
+    for (int c = 0; c < 3; ++c) { s.A[c] = clamp_seed(float_to_int16f(X[c], isSigned), isSigned); s.B[c] = clamp_seed(float_to_int16f(Y[c], isSigned), isSigned); }
+    return s;
+}
+
+static int g_onlyMode = -1; static bool g_noSearch = false;
+template<int N>
+static bool refine_host(const ModeRt& m, bool isSigned, uint32_t shape, const EndPts seeds[2], const int ipx[16][3], float& bestErr, uint64_t& lo, uint64_t& hi)
+{
+    const int nreg = m.regions2 ? 2 : 1;
+    const uint32_t m1 = m.regions2 ? kPart2Mask[shape] : 0u;
+    const uint32_t masks[2] = { m.regions2 ? ((~m1) & 0xFFFFu) : 0xFFFFu, m1 };
+    const uint32_t anchors[2] = { 0u, m.regions2 ? uint32_t(kAnchor2[shape]) : 0u };
+    EndPts org[2], opt[2]; float orgErr[2] = { 0, 0 }, optErr[2] = { 0, 0 }; uint64_t orgIdx[2] = { 0, 0 }, optIdx[2] = { 0, 0 };
+    Region6 rg[2], all; gather(ipx, 0xFFFF, all);
+    for (int r = 0; r < nreg; ++r)
+    {
+        gather(ipx, masks[r], rg[r]);
+        for (int c = 0; c < 3; ++c) { org[r].A[c] = quantize(seeds[r].A[c], m.prec, isSigned); org[r].B[c] = quantize(seeds[r].B[c], m.prec, isSigned); }
+        orgErr[r] = assign_indices6<N>(tex(rg[r]), rg[r].pos, org[r], m.prec, isSigned, anchors[r], orgIdx[r]);
+    }
+    int a0[3] = { org[0].A[0], org[0].A[1], org[0].A[2] };
+    bool fit = true;
+    EndPts orgT[2];
+    for (int r = 0; r < nreg; ++r) { orgT[r] = m.transformed ? transform_forward(org[r], r, a0) : org[r]; fit = fit && endpoints_fit(orgT[r], r, m, isSigned); }
+    if (getenv("DXTEX_BC6H_DUMP")) { printf("  mode %d shape %u fit %d:", m.index, shape, int(fit)); for (int r = 0; r < nreg; ++r) { printf(" | A"); for (int c = 0; c < 3; ++c) printf(" %d", orgT[r].A[c]); printf(" B"); for (int c = 0; c < 3; ++c) printf(" %d", orgT[r].B[c]); } printf(" err %.9g %.9g\n", orgErr[0], orgErr[1]); }
+    if (!fit) return false;
+    for (int r = 0; r < nreg; ++r)
+    {
+        const Region6& sr = (r == 0) ? all : rg[r];          // the reference's region-0 quirk
+        if (g_noSearch) opt[r] = org[r]; else optimize_one6<N>(tex(sr), org[r], orgErr[r], m.prec, isSigned, opt[r]);
+        optErr[r] = assign_indices6<N>(tex(rg[r]), rg[r].pos, opt[r], m.prec, isSigned, anchors[r], optIdx[r]);
+    }
+    float orgTot = 0.0f, optTot = 0.0f;
+    for (int r = 0; r < nreg; ++r) { orgTot += orgErr[r]; optTot += optErr[r]; }
+    int b0[3] = { opt[0].A[0], opt[0].A[1], opt[0].A[2] };
+    bool fitOpt = true; EndPts optT[2];
+    for (int r = 0; r < nreg; ++r) { optT[r] = m.transformed ? transform_forward(opt[r], r, b0) : opt[r]; fitOpt = fitOpt && endpoints_fit(optT[r], r, m, isSigned); }
+    const bool useOpt = fitOpt && optTot < orgTot;
+    const float err = useOpt ? optTot : orgTot;
+    if (!(err < bestErr)) return true;
+    bestErr = err;
+    int ep[4][3] = {};
+    for (int r = 0; r < nreg; ++r)
+        for (int c = 0; c < 3; ++c) { ep[2 * r][c] = (useOpt ? optT[r] : orgT[r]).A[c]; ep[2 * r + 1][c] = (useOpt ? optT[r] : orgT[r]).B[c]; }
+    const uint64_t idx = useOpt ? (optIdx[0] | optIdx[1]) : (orgIdx[0] | orgIdx[1]);
+    emit_block6(m, shape, ep, idx, anchors[1], lo, hi);
+    return true;
+}
+
+static void encode_host(const float* fpx, bool isSigned, uint64_t& lo, uint64_t& hi)
+{
+    int ipx[16][3];
+    for (int i = 0; i < 16; ++i) for (int c = 0; c < 3; ++c) ipx[i][c] = float_to_int16f(fpx[i * 4 + c], isSigned);
+    EndPts seeds2[32][2], seed1[2];
+    float rough[32]; uint32_t shp[32];
+    Region6 rg;
+    for (uint32_t s = 0; s < 32; ++s)
+    {
+        const uint32_t m1 = kPart2Mask[s];
+        const uint32_t masks[2] = { (~m1) & 0xFFFFu, m1 };
+        rough[s] = 0.0f; shp[s] = s;
+        for (int r = 0; r < 2; ++r)
+        {
+            int np; seeds2[s][r] = seed_region(fpx, ipx, masks[r], isSigned, np);
+            if (np > 2) { gather(ipx, masks[r], rg); rough[s] += rough_error6<8>(tex(rg), seeds2[s][r]); }
+        }
+    }
+    for (int i = 0; i < 8; ++i) for (int j = i + 1; j < 32; ++j) if (rough[i] > rough[j]) { std::swap(rough[i], rough[j]); std::swap(shp[i], shp[j]); }
+    if (getenv("DXTEX_BC6H_DUMP")) { printf("shapes:"); for (int i = 0; i < 8; ++i) printf(" %u", shp[i]); printf("\n  seeds rank0:"); for (int r = 0; r < 2; ++r) { for (int c = 0; c < 3; ++c) printf(" %d", seeds2[shp[0]][r].A[c]); for (int c = 0; c < 3; ++c) printf(" %d", seeds2[shp[0]][r].B[c]); } printf("\n  rough:"); for (int i = 0; i < 10; ++i) printf(" %.9g", rough[i]); printf("\n"); }
+    { int np; seed1[0] = seed_region(fpx, ipx, 0xFFFF, isSigned, np); }
+    float best = FLT_MAX; lo = hi = 0;
+    for (int mi = 0; mi < 14 && best > 0; ++mi)
+    {
+        if (g_onlyMode >= 0 && mi != g_onlyMode) continue;
+        const ModeRt m = mode_rt(mi);
+        if (m.regions2) { for (int i = 0; i < 8 && best > 0; ++i) refine_host<8>(m, isSigned, shp[i], seeds2[shp[i]], ipx, best, lo, hi); }
+        else refine_host<16>(m, isSigned, 0, seed1, ipx, best, lo, hi);
+    }
+}
+
+int main(int argc, char** argv)
+{
+    if (argc >= 4 && !strcmp(argv[1], "file"))
+    {
+        FILE* f = fopen(argv[2], "rb"); const bool sg = atoi(argv[3]) != 0;
+        if (argc > 4) g_onlyMode = atoi(argv[4]);
+        if (argc > 5) g_noSearch = atoi(argv[5]) != 0;
+        alignas(16) float px[64]; int t = 0;
+        while (fread(px, sizeof(px), 1, f) == 1) { uint64_t lo, hi; encode_host(px, sg, lo, hi); printf("%d %016llx %016llx\n", t++, (unsigned long long)lo, (unsigned long long)hi); }
+        return 0;
+    }
+    const int ntiles = argc > 1 ? atoi(argv[1]) : 100;
+    g_rng = argc > 2 ? uint32_t(atoi(argv[2])) : 1u;
+    int nbad = 0;
+    for (int t = 0; t < ntiles; ++t)
+    {
+        alignas(16) float px[64];
+        const int kind = rnd() % 6;
+        const float scale = (float[]){ 0.001f, 0.1f, 1.0f, 8.0f, 200.0f, 30000.0f }[rnd() % 6];
+        const float base[3] = { frand(), frand(), frand() };
+        for (int i = 0; i < 16; ++i)
+        {
+            for (int c = 0; c < 3; ++c)
+            {
+                float v;
+                if (kind == 0) v = base[c];
+                else if (kind == 1) v = base[c] + 0.02f * frand();
+                else if (kind == 2) v = base[c] * (0.5f + frand());
+                else if (kind == 3) v = frand();
+                else if (kind == 4) v = (i & 3) * 0.25f * base[c] + 0.1f * frand();
+                else v = frand() - 0.3f;            // some negatives
+                px[i * 4 + c] = v * scale;
+            }
+            px[i * 4 + 3] = 1.0f;
+        }
+        for (int sg = 0; sg < 2; ++sg)
+        {
+            alignas(16) uint8_t ref[16];
+            reinterpret_cast<D3DX_BC6H*>(ref)->Encode(sg != 0, reinterpret_cast<const HDRColorA*>(px));
+            uint64_t lo, hi; encode_host(px, sg != 0, lo, hi);
+            uint64_t rlo, rhi; memcpy(&rlo, ref, 8); memcpy(&rhi, ref + 8, 8);
+            if (rlo == lo && rhi == hi) continue;
+            ++nbad;
+            if (nbad <= 5) printf("tile %d signed %d kind %d scale %g MISMATCH ref %016llx%016llx ours %016llx%016llx (mode bits ref %x ours %x)\n", t, sg, kind, scale,
+                                  (unsigned long long)rhi, (unsigned long long)rlo, (unsigned long long)hi, (unsigned long long)lo, unsigned(rlo & 31), unsigned(lo & 31));
+        }
+    }
+    printf("%d of %d encodes differ\n", nbad, ntiles * 2);
+    return nbad ? 1 : 0;
+}
