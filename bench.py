@@ -74,26 +74,81 @@ def cpu_baseline(img, budget_s=15.0):
                       f"OpenMP over blocks, {dt:.1f} s", "psnr_db": round(psnr, 3)}, (x0, y0, side, payload)
 
 
+def other_workloads(ctx, dev, img):
+    """The other configurations of BASELINE.json, measured once each AFTER the timed region (reported, not the metric):
+    device-resident inputs, per-call wall time with a stream sync, algorithmic GB/s per SURVEY.md section 8d."""
+    import torch
+    import directxtex_amd as dx
+    RGBA8, RGBA16F = dx.DXGI_FORMAT_R8G8B8A8_UNORM, dx.DXGI_FORMAT_R16G16B16A16_FLOAT
+    out = {}
+
+    def timed(fn, n):
+        fn(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n
+
+    src = torch.from_numpy(img).to(dev)
+    for name, fmt, bpt, n in (("bc1", dx.DXGI_FORMAT_BC1_UNORM, 4.5, 20), ("bc3", dx.DXGI_FORMAT_BC3_UNORM, 5.0, 20), ("bc5", dx.DXGI_FORMAT_BC5_UNORM, 5.0, 20)):
+        rp, sp = dx.compute_pitch(fmt, WIDTH, HEIGHT)
+        dst = torch.empty(sp, dtype=torch.uint8, device=dev)
+        dt = timed(lambda: ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), fmt, 0, 0.5), n)
+        out[f"{name}_4096"] = {"ms": round(dt * 1e3, 3), "Mtexels_s": round(WIDTH * HEIGHT / dt / 1e6, 1), "algorithmic_GBs": round(WIDTH * HEIGHT * bpt / dt / 1e9, 1)}
+    # cfg3: 4096^2 RGBA16F -> BC6H_UF16
+    hdr = torch.from_numpy((img.astype(np.float32) * (8.0 / 255.0)).astype(np.float16)).to(dev)
+    rp, sp = dx.compute_pitch(dx.DXGI_FORMAT_BC6H_UF16, WIDTH, HEIGHT)
+    dst = torch.empty(sp, dtype=torch.uint8, device=dev)
+    dt = timed(lambda: ctx.compress_device(hdr.data_ptr(), WIDTH, HEIGHT, RGBA16F, dst.data_ptr(), dx.DXGI_FORMAT_BC6H_UF16, 0, 0.5), 2)
+    out["bc6h_uf16_4096"] = {"ms": round(dt * 1e3, 2), "Mtexels_s": round(WIDTH * HEIGHT / dt / 1e6, 2), "algorithmic_GBs": round(WIDTH * HEIGHT * 9.0 / dt / 1e9, 2)}
+    # decode BC7 4096^2 -> RGBA8 (0.5 + ... 1 B read + 4 B written per texel)
+    rp7, sp7 = dx.compute_pitch(dx.DXGI_FORMAT_BC7_UNORM, WIDTH, HEIGHT)
+    bc7 = torch.empty(sp7, dtype=torch.uint8, device=dev)
+    ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, bc7.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, dx.TEX_COMPRESS_BC7_QUICK, 0.5)
+    back = torch.empty(WIDTH * HEIGHT * 4, dtype=torch.uint8, device=dev)
+    dt = timed(lambda: ctx.decompress_device(bc7.data_ptr(), WIDTH, HEIGHT, dx.DXGI_FORMAT_BC7_UNORM, back.data_ptr(), RGBA8), 20)
+    out["bc7_decode_4096"] = {"ms": round(dt * 1e3, 3), "Mtexels_s": round(WIDTH * HEIGHT / dt / 1e6, 1), "algorithmic_GBs": round(WIDTH * HEIGHT * 5.0 / dt / 1e9, 1)}
+    # cfg4: 8192^2 RGBA8 full mip chain (box, cubic) then BC3 of all 14 levels
+    big = src.reshape(HEIGHT, WIDTH, 4).repeat(2, 2, 1).contiguous()
+    w = h = 8192
+    sizes = []
+    while True:
+        sizes.append((w, h))
+        if w == 1 and h == 1:
+            break
+        w, h = max(1, w >> 1), max(1, h >> 1)
+    bufs = [big.reshape(-1)] + [torch.empty(a * b * 4, dtype=torch.uint8, device=dev) for a, b in sizes[1:]]
+    levels = [dx.capi.device_image(t.data_ptr(), a, b, RGBA8) for t, (a, b) in zip(bufs, sizes)]
+    chain_bytes = sum(a * b * 4 for a, b in sizes[:-1]) + sum(a * b * 4 for a, b in sizes[1:])
+    for name, flt in (("box", dx.TEX_FILTER_BOX), ("cubic", dx.TEX_FILTER_CUBIC)):
+        dt = timed(lambda: ctx.generate_mips_device(levels, flt), 5)
+        out[f"mips_{name}_8192"] = {"ms": round(dt * 1e3, 3), "algorithmic_GBs": round(chain_bytes / dt / 1e9, 1)}
+    bc3 = [torch.empty(dx.compute_pitch(dx.DXGI_FORMAT_BC3_UNORM, a, b)[1], dtype=torch.uint8, device=dev) for a, b in sizes]
+    dsts = [dx.capi.device_image(t.data_ptr(), a, b, dx.DXGI_FORMAT_BC3_UNORM) for t, (a, b) in zip(bc3, sizes)]
+    dt = timed(lambda: ctx.compress_many_device(levels, dsts, 0, 0.5), 5)
+    tex = sum(a * b for a, b in sizes)
+    out["mipchain_bc3_8192"] = {"ms": round(dt * 1e3, 3), "Mtexels_s": round(tex / dt / 1e6, 1), "algorithmic_GBs": round(tex * 5.0 / dt / 1e9, 1)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (BC1/BC3/BC6H/mips/decode) reported next to the headline")
     args = ap.parse_args()
 
     import torch
     import directxtex_amd as dx
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    from directxtex_amd import sharding
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    rank, world = sharding.init_from_env("nccl", torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
     distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world if distributed else 1
     if args.gpus != n_gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={n_gpus}", file=sys.stderr)
@@ -113,8 +168,7 @@ def main():
                             dst.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, dx.TEX_COMPRESS_DEFAULT, 0.5)
 
     def barrier():
-        if distributed:
-            dist.barrier()
+        sharding.barrier(world)
 
     for _ in range(args.warmup):
         step()
@@ -131,12 +185,8 @@ def main():
     elapsed = time.perf_counter() - t0
     kernels = ctx.profile_end()
 
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    texels = float(WIDTH) * HEIGHT * args.steps * n_gpus
+    # whole-job throughput: texels of all ranks / slowest rank's time (no data-path collective anywhere)
+    elapsed, texels = sharding.aggregate(elapsed, float(WIDTH) * HEIGHT * args.steps, world, dev)
     value = texels / elapsed / 1e6
 
     if rank == 0:
@@ -183,6 +233,12 @@ def main():
             except Exception as e:                              # the baseline must never break the bench line
                 extra["cpu_baseline_error"] = repr(e)
 
+        if n_gpus == 1 and not args.no_extra:
+            try:
+                extra["other_workloads"] = other_workloads(ctx, dev, img)
+            except Exception as e:
+                extra["other_workloads_error"] = repr(e)
+
         line = {
             "metric": "Mtexels/s BC7 encode (4096^2 RGBA8, TEX_COMPRESS_DEFAULT)",
             "value": round(value, 3), "unit": "Mtexels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -199,6 +255,7 @@ def main():
 
     ctx.close()
     if distributed:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -6,4 +6,5 @@ parity tests and ``bench.py`` can drive the library; the product is the shared l
 or PyTorch fallback: if the library is missing, importing :mod:`directxtex_amd.capi` raises.
 """
 from .formats import *  # noqa: F401,F403
-from .capi import (Context, DxtexError, Image, compute_pitch, is_compressed, bits_per_pixel, library_path)  # noqa: F401
+from . import capi  # noqa: F401
+from .capi import (Context, DxtexError, Image, compute_pitch, device_image, is_compressed, bits_per_pixel, library_path)  # noqa: F401

@@ -248,6 +248,11 @@ class Context:
         self._check(_lib.dxtex_generate_mips(self._h, arr, nlevels, filter_flags), "generate_mips")
         return bufs
 
+    def generate_mips_device(self, levels, filter_flags):
+        """levels: list of device Images (capi.device_image) forming a mip chain; fills levels[1:] from levels[0]."""
+        arr = (Image * len(levels))(*levels)
+        self._check(_lib.dxtex_generate_mips_device(self._h, arr, len(levels), filter_flags), "generate_mips_device")
+
     def convert(self, pixels, width, height, src_format, dst_format, filter_flags=0, threshold=0.5):
         pixels = np.ascontiguousarray(pixels)
         src = _host_image(pixels, width, height, src_format)

@@ -1,0 +1,57 @@
+"""The N > 1 path of bench.py on CPU: two processes, gloo backend, same sharding and timing-aggregation code
+(directxtex_amd/sharding.py) the GPU run uses with nccl/RCCL. No collective touches texture data."""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, time, json
+sys.path.insert(0, %r)
+from directxtex_amd import sharding
+rank, world = sharding.init_from_env("gloo")
+mine = sharding.images_for_rank(11, world, rank)
+sharding.barrier(world)
+t0 = time.perf_counter()
+time.sleep(0.05 * (rank + 1))                     # rank 1 is the slow one
+elapsed = time.perf_counter() - t0
+sharding.barrier(world)
+tmax, total = sharding.aggregate(elapsed, len(mine) * 2048 * 2048, world)
+print(json.dumps({"rank": rank, "world": world, "mine": mine, "tmax": tmax, "total": total, "elapsed": elapsed}), flush=True)
+import torch.distributed as dist
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_two_rank_sharding_and_timing():
+    import json
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("{")][-1]))
+    outs.sort(key=lambda d: d["rank"])
+    # every image exactly once, round-robin
+    assert outs[0]["mine"] == [0, 2, 4, 6, 8, 10] and outs[1]["mine"] == [1, 3, 5, 7, 9]
+    # both ranks agree on the aggregate: MAX of the times (the slow rank's), SUM of the texels
+    assert outs[0]["tmax"] == outs[1]["tmax"] >= outs[1]["elapsed"] - 1e-9
+    assert outs[0]["tmax"] >= max(o["elapsed"] for o in outs) - 1e-9
+    assert outs[0]["total"] == outs[1]["total"] == 11 * 2048 * 2048
+
+
+def test_single_rank_is_identity():
+    sys.path.insert(0, ROOT)
+    from directxtex_amd import sharding
+    assert sharding.images_for_rank(5, 1, 0) == [0, 1, 2, 3, 4]
+    assert sharding.aggregate(0.5, 100, 1) == (0.5, 100.0)
