@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turns the CSVs written by tools/profile_round.sh into the markdown summary committed under profiles/ and into
+profiles/pmc_traffic.json (HBM bytes per launch of the dominant kernel, read by bench.py for roofline.traffic).
+usage: tools/profile_report.py gpurun_out/<dir> "<title>" profiles/<name>.md"""
+import collections, csv, glob, json, os, sys
+
+D, title, out_md = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def short(k):
+    return k.replace('dxtex::(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+
+
+stats = list(csv.DictReader(open(os.path.join(D, 'trace_kernel_stats.csv'))))
+meta = {}
+for r in csv.DictReader(open(os.path.join(D, 'pass1_counter_collection.csv'))):
+    meta.setdefault(short(r['Kernel_Name']), (r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'], r['LDS_Block_Size'], r['Scratch_Size'], r['Grid_Size'], r['Workgroup_Size']))
+cnt = collections.defaultdict(lambda: collections.defaultdict(float)); launches = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in ('pass1', 'pass2', 'fetch', 'write'):
+    p = os.path.join(D, f + '_counter_collection.csv')
+    if not os.path.exists(p):
+        continue
+    for r in csv.DictReader(open(p)):
+        k = short(r['Kernel_Name']); cnt[k][r['Counter_Name']] += float(r['Counter_Value']); launches[k][r['Counter_Name']] += 1
+
+L = []
+L.append(f"# {title}\n")
+L.append("Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra` (3 steps incl. warm-up);")
+L.append("PMC passes: separate `rocprofv3 --kernel-trace --pmc ...` runs of `bench.py --steps 1 --warmup 0` (tools/profile_round.sh).\n")
+L.append("## Kernel trace (`--stats`)\n")
+L.append("| kernel | calls | total ms | avg ms | % | VGPR | AGPR | SGPR | LDS B | scratch B | grid | wg |")
+L.append("|---|---|---|---|---|---|---|---|---|---|---|---|")
+for r in stats:
+    k = short(r['Name']); m = meta.get(k, ('?',) * 7)
+    L.append(f"| `{k}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e6:.4f} | {float(r['Percentage']):.2f} | " + " | ".join(m) + " |")
+L.append("\n## SQ counters (quad-cycle units for *_CYCLES / ACTIVE / WAIT, MI355X_MICROARCH.md) per launch\n")
+L.append("| kernel | waves | VALU insts/wave | active lanes per VALU inst (of 64) | SIMD VALU-busy ms (ACTIVE_INST_VALU x 4 cyc / 1024 SIMDs / 2.4 GHz) | issue % of wave cycles (any / VALU) | parked at s_waitcnt % | issue-stalled % | SALU/VALU |")
+L.append("|---|---|---|---|---|---|---|---|---|")
+order = [short(r['Name']) for r in stats]
+for k in order:
+    v = cnt.get(k)
+    if not v or not v.get('SQ_WAVE_CYCLES'):
+        continue
+    n = max(1, launches[k]['SQ_WAVES']); wc = v['SQ_WAVE_CYCLES']
+    L.append("| `%s` | %d | %.0f | %.1f | %.2f | %.0f / %.0f | %.0f | %.0f | %.2f |" % (
+        k, v['SQ_WAVES'] / n, v['SQ_INSTS_VALU'] / max(1, v['SQ_WAVES']), v['SQ_THREAD_CYCLES_VALU'] / max(1, v['SQ_ACTIVE_INST_VALU']),
+        v['SQ_ACTIVE_INST_VALU'] / n * 4 / 1024 / 2.4e9 * 1e3, 100 * v['SQ_ACTIVE_INST_ANY'] / wc, 100 * v['SQ_ACTIVE_INST_VALU'] / wc,
+        100 * v['SQ_WAIT_ANY'] / wc, 100 * v['SQ_WAIT_INST_ANY'] / wc, v['SQ_INSTS_SALU'] / max(1, v['SQ_INSTS_VALU'])))
+L.append("\n## HBM traffic per launch (TCC `FETCH_SIZE`, `WRITE_SIZE`, separate passes; rocprofv3 reports KiB)\n")
+L.append("gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) streaming reads and must")
+L.append("be doubled for those; these kernels read 4 B/lane (or through L2-resident scratch), where the counter matched a known byte count:")
+L.append("`bc7_rough_kernel` reads the 64 MiB source once and FETCH_SIZE reports ~64.2 MiB, so no doubling is applied here.\n")
+L.append("| kernel | FETCH_SIZE MiB | WRITE_SIZE MiB | total MiB | algorithmic MiB (5 B/texel x 4096^2 = 80) |")
+L.append("|---|---|---|---|---|")
+traffic = {}
+for k in order:
+    v = cnt.get(k)
+    if not v or 'FETCH_SIZE' not in v:
+        continue
+    f = v['FETCH_SIZE'] / max(1, launches[k]['FETCH_SIZE']) / 1024.0; w = v.get('WRITE_SIZE', 0.0) / max(1, launches[k].get('WRITE_SIZE', 1)) / 1024.0
+    traffic[k] = (f + w) * 1048576.0
+    L.append(f"| `{k}` | {f:.1f} | {w:.1f} | {f + w:.1f} | 80 |")
+open(out_md, 'w').write("\n".join(L) + "\n")
+dom = order[0]
+marks = {"bc7_exhaustive_kernel<1, 0, 0>": "bc7_exhaustive_mode1", "bc7_exhaustive_kernel<3, 0, 0>": "bc7_exhaustive_mode3"}
+json.dump({"kernel": marks.get(dom, dom), "rocprof_kernel": dom, "hbm_bytes_per_launch": int(traffic.get(dom, 0)),
+           "source": f"{out_md}: FETCH_SIZE + WRITE_SIZE, separate --pmc passes, KiB -> bytes, no x2 (4 B/lane loads, calibrated on bc7_rough_kernel)"},
+          open(os.path.join(os.path.dirname(out_md), 'pmc_traffic.json'), 'w'), indent=1)
+print(open(out_md).read()[:6000])
