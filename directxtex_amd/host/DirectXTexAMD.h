@@ -152,3 +152,35 @@ HRESULT Convert(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_F
 // mse = sum of the per-channel values, mseV[4] the per-channel MSE over [0,1] floats
 HRESULT ComputeMSE(Device& device, const Image& image1, const Image& image2, float& mse, float* mseV) noexcept;
 } // namespace DirectXTexAMD
+
+// ---- DDS container: the on-disk format either side of the path ---------------------------------
+// Subset of DirectXTexDDS.cpp: 1D/2D textures, arrays and cubemaps of the formats this library handles; legacy (DX9)
+// pixel formats are read when they map 1:1 onto one of those formats (no expansion / swizzling), and written exactly
+// where the reference writes them (EncodeDDSHeader, DirectXTexDDS.cpp:711-1033). File names are UTF-8 char strings.
+namespace DirectXTexAMD
+{
+enum DDS_FLAGS : uint32_t { DDS_FLAGS_NONE = 0x0, DDS_FLAGS_FORCE_DX10_EXT = 0x10000, DDS_FLAGS_FORCE_DX10_EXT_MISC2 = 0x20000 };
+enum TEX_MISC_FLAG : uint32_t { TEX_MISC_TEXTURECUBE = 0x4 };
+
+class Blob
+{
+public:
+    Blob() noexcept = default;
+    ~Blob() { Release(); }
+    Blob(const Blob&) = delete;
+    Blob& operator=(const Blob&) = delete;
+    HRESULT Initialize(size_t size) noexcept;
+    void Release() noexcept;
+    uint8_t* GetBufferPointer() const noexcept { return m_buffer; }
+    size_t GetBufferSize() const noexcept { return m_size; }
+private:
+    uint8_t* m_buffer = nullptr;
+    size_t m_size = 0;
+};
+
+HRESULT GetMetadataFromDDSMemory(const void* pSource, size_t size, DDS_FLAGS flags, TexMetadata& metadata) noexcept;
+HRESULT LoadFromDDSMemory(const void* pSource, size_t size, DDS_FLAGS flags, TexMetadata* metadata, ScratchImage& image) noexcept;
+HRESULT LoadFromDDSFile(const char* szFile, DDS_FLAGS flags, TexMetadata* metadata, ScratchImage& image) noexcept;
+HRESULT SaveToDDSMemory(const Image* images, size_t nimages, const TexMetadata& metadata, DDS_FLAGS flags, Blob& blob) noexcept;
+HRESULT SaveToDDSFile(const Image* images, size_t nimages, const TexMetadata& metadata, DDS_FLAGS flags, const char* szFile) noexcept;
+} // namespace DirectXTexAMD

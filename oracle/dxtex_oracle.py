@@ -44,6 +44,10 @@ def _load_ref():
             f.restype = ctypes.c_int64
         lib.dxtex_ref_compute_mse.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, sz, sz, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         lib.dxtex_ref_compute_mse.restype = ctypes.c_int
+        lib.dxtex_ref_save_dds.argtypes = [vp, sz, sz, ctypes.c_int, sz, sz, ctypes.c_uint32, ctypes.c_uint32, vp, sz, i32p]
+        lib.dxtex_ref_save_dds.restype = ctypes.c_int64
+        lib.dxtex_ref_load_dds.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64), vp, sz, i32p]
+        lib.dxtex_ref_load_dds.restype = ctypes.c_int64
         _ref = lib
     return _ref
 
@@ -350,3 +354,27 @@ def ref_compute_mse(a, fmt_a, b, fmt_b, width, height):
     if hr != 0:
         raise RefError(hr)
     return np.array(list(v), np.float32)
+
+
+def texture_bytes(fmt, width, height, array_size, mip_levels):
+    return array_size * sum(image_bytes(fmt, w, h) for w, h in mip_sizes(width, height, mip_levels))
+
+
+def ref_save_dds(pixels, width, height, fmt, array_size=1, mip_levels=1, misc_flags=0, dds_flags=0):
+    """DirectX::SaveToDDSMemory (DirectXTexDDS.cpp:2403-2698) of a texture given in ScratchImage order with tight pitches."""
+    px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
+    assert px.size == texture_bytes(fmt, width, height, array_size, mip_levels)
+    return _run(_load_ref().dxtex_ref_save_dds, px.size + 256, px.ctypes.data, width, height, fmt, array_size, mip_levels, misc_flags, dds_flags)
+
+
+def ref_load_dds(data):
+    """DirectX::LoadFromDDSMemory (DirectXTexDDS.cpp:2008-2090) -> (metadata dict, tight pixel blob)."""
+    d = np.ascontiguousarray(data, np.uint8)
+    meta = (ctypes.c_uint64 * 7)()
+    out = np.zeros(d.size + 64, np.uint8)
+    hr = ctypes.c_int32(0)
+    n = _load_ref().dxtex_ref_load_dds(d.ctypes.data, d.size, meta, out.ctypes.data, out.nbytes, ctypes.byref(hr))
+    if n < 0:
+        raise RefError(hr.value)
+    keys = ("width", "height", "format", "arraySize", "mipLevels", "miscFlags", "miscFlags2")
+    return {k: int(v) for k, v in zip(keys, meta)}, out[:n]

@@ -188,4 +188,37 @@ extern "C"
         if (mse) *mse = m;
         return int(hr);
     }
+
+    // ---- DDS container (DirectXTexDDS.cpp compiled in place): used to pin the host layer's reader / writer -----------------
+    // `pixels`: the images of the texture in ScratchImage order, each with its default (tight) pitch.
+    int64_t dxtex_ref_save_dds(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t arraySize, size_t mipLevels, uint32_t miscFlags,
+                               uint32_t ddsFlags, uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        TexMetadata m = {};
+        m.width = w; m.height = h; m.depth = 1; m.arraySize = arraySize; m.mipLevels = mipLevels; m.miscFlags = miscFlags;
+        m.format = DXGI_FORMAT(fmt); m.dimension = TEX_DIMENSION_TEXTURE2D;
+        ScratchImage si;
+        HRESULT hr = si.Initialize(m);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        memcpy(si.GetPixels(), pixels, si.GetPixelsSize());
+        Blob blob;
+        hr = SaveToDDSMemory(si.GetImages(), si.GetImageCount(), si.GetMetadata(), DDS_FLAGS(ddsFlags), blob);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        if (blob.GetBufferSize() > capacity) return -2;
+        memcpy(out, blob.GetBufferPointer(), blob.GetBufferSize());
+        return int64_t(blob.GetBufferSize());
+    }
+
+    // meta[0..6] = width, height, format, arraySize, mipLevels, miscFlags, miscFlags2
+    int64_t dxtex_ref_load_dds(const uint8_t* file, size_t size, uint64_t* meta, uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        ScratchImage si; TexMetadata m = {};
+        const HRESULT hr = LoadFromDDSMemory(file, size, DDS_FLAGS_NONE, &m, si);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        meta[0] = m.width; meta[1] = m.height; meta[2] = uint64_t(m.format); meta[3] = m.arraySize; meta[4] = m.mipLevels; meta[5] = m.miscFlags; meta[6] = m.miscFlags2;
+        return copy_out(si, out, capacity);
+    }
 }

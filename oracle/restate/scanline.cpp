@@ -448,3 +448,30 @@ void DirectX::Internal::ConvertScanline(XMVECTOR* pBuffer, size_t count, DXGI_FO
     if ((flags & TEX_FILTER_SRGB_OUT) && (out & (C_FLOAT | C_UNORM)))
         each([](float* v) { for (int c = 0; c < 3; ++c) v[c] = rgb_to_srgb(v[c]); });
 }
+
+// ---- the three scanline helpers the DDS reader links against (DirectXTexConvert.cpp:207-700) ---------------------------------
+// Only what the formats of this library need: a plain copy (optionally forcing 8-bit alpha opaque). Legacy expansion
+// (24 bpp, 16-bit 565 / 5551 / 4444, palettes) and channel swizzles are outside the supported subset and report failure.
+void DirectX::Internal::CopyScanline(void* pDestination, size_t outSize, const void* pSource, size_t inSize, DXGI_FORMAT format, uint32_t tflags) noexcept
+{
+    const size_t n = outSize < inSize ? outSize : inSize;
+    if (pDestination != pSource) memcpy(pDestination, pSource, n);
+    if (tflags & TEXP_SCANLINE_SETALPHA)
+    {
+        switch (int(format))
+        {
+        case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB: case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB:
+            for (size_t i = 3; i < n; i += 4) static_cast<uint8_t*>(pDestination)[i] = 0xFF;
+            break;
+        default:
+            break;
+        }
+    }
+}
+
+bool DirectX::Internal::ExpandScanline(void*, size_t, DXGI_FORMAT, const void*, size_t, DXGI_FORMAT, uint32_t) noexcept { return false; }
+void DirectX::Internal::SwizzleScanline(void* pDestination, size_t outSize, const void* pSource, size_t inSize, DXGI_FORMAT, uint32_t) noexcept
+{
+    const size_t n = outSize < inSize ? outSize : inSize;
+    if (pDestination != pSource) memcpy(pDestination, pSource, n);
+}

@@ -111,8 +111,39 @@ static int gpu_run(const std::string& outdir)
     return 0;
 }
 
+// dds_save <tight pixels.bin> <w> <h> <format> <arraySize> <mipLevels> <miscFlags> <ddsFlags> <out.dds>
+static int dds_save(char** a)
+{
+    const size_t w = std::strtoull(a[1], nullptr, 10), h = std::strtoull(a[2], nullptr, 10);
+    TexMetadata m; m.width = w; m.height = h; m.depth = 1; m.format = DXGI_FORMAT(std::atoi(a[3]));
+    m.arraySize = std::strtoull(a[4], nullptr, 10); m.mipLevels = std::strtoull(a[5], nullptr, 10); m.miscFlags = uint32_t(std::strtoul(a[6], nullptr, 0));
+    ScratchImage si;
+    HRESULT hr = si.Initialize(m);
+    if (FAILED(hr)) { std::printf("hr %08x\n", unsigned(hr)); return 3; }
+    FILE* f = std::fopen(a[0], "rb");
+    if (!f || std::fread(si.GetPixels(), 1, si.GetPixelsSize(), f) != si.GetPixelsSize()) return 4;
+    std::fclose(f);
+    hr = SaveToDDSFile(si.GetImages(), si.GetImageCount(), si.GetMetadata(), DDS_FLAGS(std::strtoul(a[7], nullptr, 0)), a[8]);
+    std::printf("hr %08x\n", unsigned(hr));
+    return FAILED(hr) ? 3 : 0;
+}
+
+// dds_load <in.dds> <out tight pixels.bin>: prints the metadata
+static int dds_load(char** a)
+{
+    ScratchImage si; TexMetadata m;
+    const HRESULT hr = LoadFromDDSFile(a[0], DDS_FLAGS_NONE, &m, si);
+    std::printf("hr %08x\n", unsigned(hr));
+    if (FAILED(hr)) return 3;
+    std::printf("meta %zu %zu %u %zu %zu %u %u\n", m.width, m.height, unsigned(m.format), m.arraySize, m.mipLevels, m.miscFlags, m.miscFlags2);
+    dump(a[1], si.GetPixels(), si.GetPixelsSize());
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc >= 11 && !std::strcmp(argv[1], "dds_save")) return dds_save(argv + 2);
+    if (argc >= 4 && !std::strcmp(argv[1], "dds_load")) return dds_load(argv + 2);
     if (argc >= 2 && !std::strcmp(argv[1], "cpu")) return cpu_checks();
     if (argc >= 3 && !std::strcmp(argv[1], "gpu")) return gpu_run(argv[2]);
     std::fprintf(stderr, "usage: host_api_test cpu | gpu <outdir>\n");
