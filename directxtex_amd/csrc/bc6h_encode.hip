@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(256) bc6h_store_kernel(Bc6hArgs a)
     out[0] = b.lo; out[1] = b.hi;
 }
 
-constexpr uint64_t kMaxBlocksPerPass6 = 1u << 20;
+const uint64_t kMaxBlocksPerPass6 = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(getenv("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 20);
 struct Scratch6
 {
     size_t fpix, lists, seeds, recs, order, tinfo, counters, best, total;

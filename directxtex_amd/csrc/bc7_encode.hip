@@ -553,7 +553,8 @@ __global__ void __launch_bounds__(256) bc7_pick_kernel(Bc7Args a, uint32_t slotM
 // Scratch layout for a pass over `nb` blocks (every array 256-byte aligned).
 namespace
 {
-constexpr uint64_t kMaxBlocksPerPass = 1u << 20;      // bounds the scratch (about 1.1 KiB per block)
+// bounds the scratch (about 1.1 KiB per block); DXTEX_MAX_BLOCKS_PER_PASS shrinks it so tests can exercise the pass loop
+const uint64_t kMaxBlocksPerPass = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(getenv("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 20);
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
 struct ScratchLayout
 {

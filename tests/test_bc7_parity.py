@@ -86,3 +86,23 @@ def test_bc7_special_blocks(ctx, oracle):
     ref = oracle.ref_encode_blocks(BC7, rgba, 0)
     bad = np.nonzero((got != ref).any(axis=1))[0]
     assert bad.size == 0, f"{bad.size} of {len(tiles)} blocks differ, first {bad[:8]}"
+
+
+def test_multi_pass_images(oracle):
+    """Images with more than 2^20 blocks are encoded in passes over block ranges; shrink the pass size to exercise that."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys; sys.path.insert(0, %r)
+        import numpy as np, directxtex_amd as dx, oracle
+        from directxtex_amd import synth
+        c = dx.Context(0)
+        w, h = 52, 36                      # 13 x 9 = 117 blocks, 7 passes of 17 blocks
+        img = synth.rgba8(w, h, seed=8, alpha="smooth")
+        assert np.array_equal(c.compress(img, w, h, 28, 98, 0, 0.5), oracle.ref_compress_image(img, w, h, 28, 98, 0, 0.5))
+        hdr = (img.astype(np.float32) / 255 * 6).astype(np.float16)
+        assert np.array_equal(c.compress(hdr, w, h, 10, 95, 0, 0.5), oracle.ref_compress_image(hdr, w, h, 10, 95, 0, 0.5))
+        print("multi-pass OK")
+    """ % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DXTEX_MAX_BLOCKS_PER_PASS="17"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "multi-pass OK" in r.stdout, r.stdout + r.stderr
