@@ -203,7 +203,8 @@ __device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, ui
     o.epT = a.mode.transformed ? transform_forward(o.ep, int(region), a0) : o.ep;
     bool fit = endpoints_fit(o.epT, int(region), a.mode, sg);
     if (REGIONS2) { const int partner = __shfl_xor(int(fit), 1); fit = fit && (partner != 0); }     // no short-circuit around the shuffle
-    o.fit = fit;
+    // Encode() stops at the first candidate that reaches error 0 (:1823, :1851): nothing later can be strictly better
+    o.fit = fit && (a.best[nb].err > 0.0f);
 }
 
 template<int REGIONS2>

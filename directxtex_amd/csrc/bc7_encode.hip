@@ -43,6 +43,7 @@ struct Bc7Args
     uint2* order;            // live tasks of the current mode, sorted by subset size: (task, tinfo)
     uint32_t* tinfo;         // per task: texel mask | rotation << 16 | subset size << 24 (size 0 = no search needed)
     uint32_t* counters;      // 35 words, see bc7_bin_* kernels
+    uint8_t* done;           // per block: a mode already reached error 0, Encode() would stop here (:2803, :2835, :2845)
 };
 
 // One texel of block `nb` (texel t = y*4+x), with the reference's partial-block replication, as float4
@@ -81,6 +82,7 @@ __global__ void __launch_bounds__(256) bc7_rough_kernel(Bc7Args a)
         load_block_texel(a.src, a.nbw, a.nb0 + nb, lane, &sF[wave][lane * 4], ldr);
         sL[wave][lane] = ldr;
         a.px[uint64_t(nb) * 16 + lane] = ldr;
+        if (lane == 0) a.done[nb] = 0;
     }
     wave_lds_sync();
     const float* fpx = sF[wave];
@@ -188,6 +190,7 @@ __device__ __forceinline__ bool task_geometry(const Bc7Args& a, uint32_t nb, uin
     typedef TaskMap<MODE, IM> TM;
     shape = 0; mask = 0xFFFFu; anchor = 0; rot = 0;
     if (nb >= a.nblocks) return false;
+    if (a.done[nb]) return false;          // fMSEBest == 0: the reference skips every remaining mode and candidate
     if (TM::NS == 1) { rot = (MODE == 6) ? 0u : r; return true; }
     const uint32_t rank = r / TM::G, region = r % TM::G;
     if (region >= uint32_t(TM::NS)) return false;
@@ -507,6 +510,7 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
             c.ord = uint32_t(MODE) * 128u + sub;
             emit_block<MODE>(shape, rot, IM, epA, epB, idx1, myIdx2, anchors, c.lo, c.hi);
             a.cands[uint64_t(nb) * NUM_SLOTS + TM::SLOT] = c;
+            if (err == 0) a.done[nb] = 1;
         }
         else if (!active && rank == 0)
         {
@@ -524,6 +528,7 @@ __global__ void __launch_bounds__(256) bc7_texels_kernel(Bc7Args a)
     float f4[4]; uint32_t ldr;
     load_block_texel(a.src, a.nbw, a.nb0 + (i >> 4), i & 15u, f4, ldr);
     a.px[i] = ldr;
+    if ((i & 15u) == 0) a.done[i >> 4] = 0;
 }
 
 // ---- pick: first minimum over the per-mode winners, in D3DX_BC7::Encode's order -----------------------------------
@@ -558,7 +563,7 @@ const uint64_t kMaxBlocksPerPass = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::ma
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
 struct ScratchLayout
 {
-    size_t lists, cands, px, recs, order, tinfo, counters, total;
+    size_t lists, cands, px, recs, order, tinfo, counters, done, total;
     explicit ScratchLayout(uint64_t nb, bool threeSubsets)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -571,6 +576,7 @@ struct ScratchLayout
         order = o; o = up(o + nb * tpb * sizeof(uint2));
         tinfo = o; o = up(o + nb * tpb * sizeof(uint32_t));
         counters = o; o = up(o + 64 * sizeof(uint32_t));
+        done = o; o = up(o + nb);
         total = o;
     }
 };
@@ -650,6 +656,7 @@ hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPi
         a.order = reinterpret_cast<uint2*>(base + L.order);
         a.tinfo = reinterpret_cast<uint32_t*>(base + L.tinfo);
         a.counters = reinterpret_cast<uint32_t*>(base + L.counters);
+        a.done = base + L.done;
         uint32_t slotMask = 0;
 
         if (!quick)
