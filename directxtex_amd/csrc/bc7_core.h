@@ -624,7 +624,7 @@ DXTEX_HD int eval_var(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& v
 #pragma unroll
         for (int i = 0; i < C::N; ++i)
         {
-            pa[i] = int((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6);
+            pa[i] = int(((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6) & 0xFFu);
             npa2[i] = -(pa[i] * pa[i]);
         }
         for_texels(rg, [&](int k)
@@ -643,7 +643,7 @@ DXTEX_HD int eval_var(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& v
 #pragma unroll
         for (int i = 0; i < C::N; ++i)
         {
-            const uint32_t v = (uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6;
+            const uint32_t v = ((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6) & 0xFFu;
             pal[i] = vp.palO[i] | (v << sh);
             nq2[i] = vp.nq2O[i] - v * v;
         }
