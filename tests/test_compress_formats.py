@@ -1,0 +1,72 @@
+"""Compress from every supported source format (the ConvertScanline branches CompressBC reaches), row pitches wider than
+the image, and the C ABI's error codes, against the reference's real Compress driver (oracle/_ref)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import directxtex_amd as dx
+
+pytestmark = pytest.mark.gpu
+
+SRC = [28, 29, 87, 88, 2, 10, 11, 31, 49, 51, 61, 63, 65, 41, 54, 16, 34, 35, 56]
+DST = [71, 77, 80, 81, 83, 84, 98, 95]
+
+
+def _pixels(oracle, fmt, w, h, seed):
+    rng = np.random.default_rng(seed)
+    if fmt in (2, 16, 41):
+        n = {2: 4, 16: 2, 41: 1}[fmt]
+        return (rng.random((h, w, n), dtype=np.float32) * 1.5 - 0.25).astype(np.float32)
+    if fmt in (10, 34, 54):
+        n = {10: 4, 34: 2, 54: 1}[fmt]
+        return (rng.random((h, w, n), dtype=np.float32) * 1.5 - 0.25).astype(np.float16)
+    return rng.integers(0, 256, oracle.image_bytes(fmt, w, h), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("src", SRC)
+@pytest.mark.parametrize("dst", DST)
+def test_source_formats(ctx, oracle, src, dst):
+    srgb_in, srgb_out = src in (29, 91, 93), dst in (72, 75, 78, 99)
+    if srgb_in != srgb_out:
+        with pytest.raises(dx.DxtexError) as e:        # one-sided sRGB needs pow(): documented as not supported
+            ctx.compress(_pixels(oracle, src, 8, 8, 1), 8, 8, src, dst, 0x100000, 0.5)
+        assert e.value.hresult & 0xFFFFFFFF == 0x80070032
+        return
+    w, h = 23, 10
+    px = _pixels(oracle, src, w, h, src * 100 + dst)
+    flags = 0x100000 if dst == 98 else 0               # BC7_QUICK keeps the oracle fast
+    got = ctx.compress(px, w, h, src, dst, flags, 0.5)
+    ref = oracle.ref_compress_image(px, w, h, src, dst, flags, 0.5)
+    assert np.array_equal(got, ref), (src, dst, np.nonzero(got != ref)[0][:8])
+
+
+def test_wide_row_pitch(ctx, oracle):
+    w, h, pitch = 30, 18, 256
+    rng = np.random.default_rng(3)
+    buf = rng.integers(0, 256, (h, pitch), dtype=np.uint8)
+    got = ctx.compress(buf, w, h, 28, 77, 0, 0.5, src_row_pitch=pitch)
+    tight = np.ascontiguousarray(buf[:, :w * 4])
+    assert np.array_equal(got, oracle.ref_compress_image(tight, w, h, 28, 77, 0, 0.5))
+    assert np.array_equal(got, oracle.ref_compress_image(buf, w, h, 28, 77, 0, 0.5, row_pitch=pitch))
+
+
+def test_c_abi_error_codes(ctx):
+    from directxtex_amd import capi
+    lib = capi._lib
+    px = np.zeros(16 * 16 * 4, np.uint8); out = np.zeros(16 * 16, np.uint8)
+    def img(arr, w, h, fmt):
+        rp, sp = dx.compute_pitch(fmt, w, h)
+        return capi.Image(w, h, fmt, rp, sp, arr.ctypes.data if arr is not None else None)
+    h = ctx._h
+    E_POINTER, E_INVALIDARG, E_FAIL, NOT_SUPPORTED = 0x80004003, 0x80070057, 0x80004005, 0x80070032
+    u = lambda hr: hr & 0xFFFFFFFF
+    s, d = img(px, 16, 16, 28), img(out, 16, 16, 77)
+    assert u(lib.dxtex_compress(None, ctypes.byref(s), ctypes.byref(d), 0, 0.5)) == E_POINTER
+    assert u(lib.dxtex_compress(h, ctypes.byref(img(None, 16, 16, 28)), ctypes.byref(d), 0, 0.5)) == E_POINTER      # null pixels, :80-81
+    assert u(lib.dxtex_compress(h, ctypes.byref(d), ctypes.byref(d), 0, 0.5)) == E_INVALIDARG                        # compressed source, :671
+    assert u(lib.dxtex_compress(h, ctypes.byref(s), ctypes.byref(s), 0, 0.5)) == E_INVALIDARG                        # uncompressed target
+    assert u(lib.dxtex_compress(h, ctypes.byref(s), ctypes.byref(img(out, 12, 16, 77)), 0, 0.5)) == E_FAIL           # size mismatch, :800-804
+    assert u(lib.dxtex_compress(h, ctypes.byref(capi.Image(16, 16, 24, 64, 1024, px.ctypes.data)), ctypes.byref(d), 0, 0.5)) == NOT_SUPPORTED     # R10G10B10A2 not on this path
+    assert u(lib.dxtex_decompress(h, ctypes.byref(s), ctypes.byref(s))) == E_INVALIDARG                              # :857
+    assert b"" != lib.dxtex_ctx_last_error(h)
