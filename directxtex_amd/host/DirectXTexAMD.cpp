@@ -344,6 +344,39 @@ HRESULT Resize(Device& device, const Image& srcImage, size_t width, size_t heigh
     return hr;
 }
 
+// Resize (complex), DirectXTexResize.cpp:942-1103: only mip 0 of every array item / depth slice is resized, the result has
+// one mip level.
+HRESULT Resize(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, size_t width, size_t height,
+               TEX_FILTER_FLAGS filter, ScratchImage& result) noexcept
+{
+    if (!device) return E_POINTER;
+    if (!srcImages || !nimages || width == 0 || height == 0) return E_INVALIDARG;
+    if (width > UINT32_MAX || height > UINT32_MAX || metadata.width > UINT32_MAX || metadata.height > UINT32_MAX) return E_INVALIDARG;
+    if (IsCompressed(metadata.format) || !IsKnown(metadata.format)) return HRESULT_E_NOT_SUPPORTED;
+    TexMetadata mdata2 = metadata;
+    mdata2.width = width;
+    mdata2.height = height;
+    mdata2.mipLevels = 1;
+    HRESULT hr = result.Initialize(mdata2);
+    if (FAILED(hr)) return hr;
+    const bool volume = metadata.dimension == TEX_DIMENSION_TEXTURE3D;
+    const size_t count = volume ? metadata.depth : metadata.arraySize;
+    for (size_t i = 0; i < count; ++i)
+    {
+        const size_t srcIndex = volume ? metadata.ComputeIndex(0, 0, i) : metadata.ComputeIndex(0, i, 0);
+        if (srcIndex >= nimages) { result.Release(); return E_FAIL; }
+        const Image& srcimg = srcImages[srcIndex];
+        const Image* destimg = volume ? result.GetImage(0, 0, i) : result.GetImage(0, i, 0);
+        if (!destimg || !srcimg.pixels) { result.Release(); return E_POINTER; }
+        if (srcimg.format != metadata.format) { result.Release(); return E_FAIL; }
+        if (srcimg.width > UINT32_MAX || srcimg.height > UINT32_MAX) { result.Release(); return E_FAIL; }
+        const dxtex_image s = View(srcimg), d = View(*destimg);
+        hr = dxtex_resize(device.Get(), &s, &d, uint32_t(filter));
+        if (FAILED(hr)) { result.Release(); return hr; }
+    }
+    return S_OK;
+}
+
 // ---- Convert (ConvertEx, DirectXTexConvert.cpp:5107-5176) ---------------------------------------------------------------------------
 HRESULT Convert(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_FILTER_FLAGS filter, float threshold, ScratchImage& image) noexcept
 {
@@ -360,6 +393,36 @@ HRESULT Convert(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_F
     hr = dxtex_convert(device.Get(), &s, &d, uint32_t(filter), threshold);
     if (FAILED(hr)) image.Release();
     return hr;
+}
+
+// Convert (complex), DirectXTexConvert.cpp:5198-5370: every image of the set (all items, mips, slices) is converted.
+HRESULT Convert(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                TEX_FILTER_FLAGS filter, float threshold, ScratchImage& result) noexcept
+{
+    if (!device) return E_POINTER;
+    if (!srcImages || !nimages || metadata.format == format || format == DXGI_FORMAT_UNKNOWN || metadata.format == DXGI_FORMAT_UNKNOWN)
+        return E_INVALIDARG;
+    if (IsCompressed(metadata.format) || IsCompressed(format) || !IsKnown(metadata.format) || !IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
+    if (metadata.width > UINT32_MAX || metadata.height > UINT32_MAX) return E_INVALIDARG;
+    TexMetadata mdata2 = metadata;
+    mdata2.format = format;
+    HRESULT hr = result.Initialize(mdata2);
+    if (FAILED(hr)) return hr;
+    if (nimages != result.GetImageCount()) { result.Release(); return E_FAIL; }
+    const Image* dest = result.GetImages();
+    if (!dest) { result.Release(); return E_POINTER; }
+    for (size_t i = 0; i < nimages; ++i)
+    {
+        const Image& src = srcImages[i];
+        if (src.format != metadata.format) { result.Release(); return E_FAIL; }
+        if (src.width > UINT32_MAX || src.height > UINT32_MAX) { result.Release(); return E_FAIL; }
+        if (src.width != dest[i].width || src.height != dest[i].height) { result.Release(); return E_FAIL; }
+        if (!src.pixels) { result.Release(); return E_POINTER; }
+        const dxtex_image s = View(src), d = View(dest[i]);
+        hr = dxtex_convert(device.Get(), &s, &d, uint32_t(filter), threshold);
+        if (FAILED(hr)) { result.Release(); return hr; }
+    }
+    return S_OK;
 }
 
 // ---- ComputeMSE (DirectXTexMisc.cpp:181-260): compressed inputs are decompressed first -----------------------------------------------

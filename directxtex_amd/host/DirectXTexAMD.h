@@ -148,7 +148,11 @@ HRESULT GenerateMipMaps(Device& device, const Image& baseImage, TEX_FILTER_FLAGS
 HRESULT GenerateMipMaps(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_FILTER_FLAGS filter,
                         size_t levels, ScratchImage& mipChain) noexcept;
 HRESULT Resize(Device& device, const Image& srcImage, size_t width, size_t height, TEX_FILTER_FLAGS filter, ScratchImage& image) noexcept;
+HRESULT Resize(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, size_t width, size_t height,
+               TEX_FILTER_FLAGS filter, ScratchImage& result) noexcept;
 HRESULT Convert(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_FILTER_FLAGS filter, float threshold, ScratchImage& image) noexcept;
+HRESULT Convert(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                TEX_FILTER_FLAGS filter, float threshold, ScratchImage& result) noexcept;
 // mse = sum of the per-channel values, mseV[4] the per-channel MSE over [0,1] floats
 HRESULT ComputeMSE(Device& device, const Image& image1, const Image& image2, float& mse, float* mseV) noexcept;
 } // namespace DirectXTexAMD

@@ -95,6 +95,15 @@ static int gpu_run(const std::string& outdir)
     CHECK(Convert(dev, src, DXGI_FORMAT_R16G16B16A16_FLOAT, TEX_FILTER_DEFAULT, 0.5f, conv) == S_OK);
     dump(outdir + "/converted_f16.bin", conv.GetPixels(), conv.GetPixelsSize());
 
+    // array overloads: the whole mip chain converted, every chain's top level resized
+    ScratchImage convAll, resizedAll;
+    CHECK(Convert(dev, mips.GetImages(), mips.GetImageCount(), mips.GetMetadata(), DXGI_FORMAT_B8G8R8A8_UNORM, TEX_FILTER_DEFAULT, 0.5f, convAll) == S_OK);
+    CHECK(convAll.GetImageCount() == 7 && convAll.GetMetadata().format == DXGI_FORMAT_B8G8R8A8_UNORM);
+    dump(outdir + "/mips_bgra.bin", convAll.GetPixels(), convAll.GetPixelsSize());
+    CHECK(Resize(dev, mips.GetImages(), mips.GetImageCount(), mips.GetMetadata(), 40, 24, TEX_FILTER_LINEAR, resizedAll) == S_OK);
+    CHECK(resizedAll.GetImageCount() == 1 && resizedAll.GetMetadata().mipLevels == 1 && resizedAll.GetMetadata().width == 40);
+    dump(outdir + "/resized_linear_array.bin", resizedAll.GetPixels(), resizedAll.GetPixelsSize());
+
     float mse = 0, v[4];
     CHECK(ComputeMSE(dev, src, *bc7.GetImage(0, 0, 0), mse, v) == S_OK);
     std::printf("mse %.9g %.9g %.9g %.9g %.9g\n", mse, v[0], v[1], v[2], v[3]);

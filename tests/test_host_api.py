@@ -39,6 +39,9 @@ def test_host_layer_on_gpu(tmp_path, oracle):
     assert np.array_equal(rd("mips_bc3.bin"), bc3)
     assert np.array_equal(rd("resized_triangle.bin"), oracle.ref_resize(src, W, H, 28, 50, 70, 0x500000))
     assert np.array_equal(rd("converted_f16.bin"), oracle.ref_convert(src, W, H, 28, 10, 0, 0.5))
+    bgra = np.concatenate([oracle.ref_convert(m, w, h, 28, 87, 0, 0.5).reshape(-1) for m, (w, h) in zip(mips, sizes)])
+    assert np.array_equal(rd("mips_bgra.bin"), bgra)
+    assert np.array_equal(rd("resized_linear_array.bin"), oracle.ref_resize(mips[0], W, H, 28, 40, 24, 0x200000).reshape(-1))
     line = [l for l in r.stdout.splitlines() if l.startswith("mse ")][0].split()
     got = np.array([float(x) for x in line[2:6]])
     ref = oracle.ref_compute_mse(src, 28, oracle.ref_decompress_image(bc7, W, H, 98, 28), 28, W, H)
