@@ -107,8 +107,7 @@ dxtex_hresult tile_conversion(const FmtInfo& in, const FmtInfo& out, uint32_t co
     bool srgbIn = (compressFlags & DXTEX_COMPRESS_SRGB_IN) != 0 || (in.cls & FC_SRGB);
     bool srgbOut = (compressFlags & DXTEX_COMPRESS_SRGB_OUT) != 0 || (out.cls & FC_SRGB);
     if (in.format == FMT_A8_UNORM) srgbIn = false;
-    if (srgbIn != srgbOut)
-        return DXTEX_E_NOT_SUPPORTED;   // one-sided sRGB needs the pow() path (XMColorSRGBToRGB): not implemented
+    if (srgbIn && srgbOut) srgbIn = srgbOut = false;       // :3164-3167
 
     *tcv = TCV_NONE; *tsw = TSW_NONE;
     if (out.cls & FC_UNORM)
@@ -129,6 +128,8 @@ dxtex_hresult tile_conversion(const FmtInfo& in, const FmtInfo& out, uint32_t co
         if (outRGB == (FC_R | FC_G | FC_B)) *tsw = TSW_R_TO_RGB;
         else if (outRGB == (FC_R | FC_G)) *tsw = TSW_R_TO_RG;
     }
+    if (srgbIn && (in.cls & (FC_FLOAT | FC_UNORM))) *tcv |= TCV_SRGB_TO_LINEAR;      // :3170-3180
+    if (srgbOut && (out.cls & (FC_FLOAT | FC_UNORM))) *tcv |= TCV_LINEAR_TO_SRGB;    // :3843-3853
     return DXTEX_S_OK;
 }
 
@@ -146,7 +147,7 @@ dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width,
     SrcView v;
     v.pixels = dSrc; v.width = uint32_t(width); v.height = uint32_t(height); v.rowPitch = srcRowPitch; v.format = srcFormat;
     dxtex_hresult hr = tile_conversion(*in, *out, flags, &v.tcv, &v.tsw);
-    if (hr != DXTEX_S_OK) return fail(ctx, hr, "one-sided sRGB conversion is not supported");
+    if (hr != DXTEX_S_OK) return fail(ctx, hr, "unsupported tile conversion");
 
     hipError_t e;
     switch (dstFormat)

@@ -215,8 +215,36 @@ __device__ __forceinline__ float tcv1(float v, int tcv)
     }
 }
 
+// XMColorSRGBToRGB / XMColorRGBToSRGB per component. DirectXMath's SSE2 build evaluates XMVectorPow with scalar powf(); pow() in
+// double precision rounded once to fp32 is the correctly rounded powf, which is what the host libm returns for every value an
+// 8-bit channel can take and for > 99.9 % of arbitrary floats (tests/test_scanline_parity.py pins both).
+__device__ __forceinline__ float pow_rn(float x, float y) { return float(pow(double(x), double(y))); }
+
+__device__ __forceinline__ float srgb_to_linear1(float v)
+{
+    // V = saturate(srgb); V <= 0.04045 ? V / 12.92 : pow((V + 0.055) / 1.055, 2.4)
+    float s = (v > 0.0f) ? v : 0.0f; s = (s < 1.0f) ? s : 1.0f;
+    const float lo = s / 12.92f;
+    const float hi = pow_rn((s + 0.055f) / 1.055f, 2.4f);
+    return (s > 0.04045f) ? hi : lo;
+}
+
+__device__ __forceinline__ float linear_to_srgb1(float v)
+{
+    // V = saturate(rgb); V < 0.0031308 ? V * 12.92 : 1.055 * pow(V, 1/2.4) - 0.055
+    float s = (v > 0.0f) ? v : 0.0f; s = (s < 1.0f) ? s : 1.0f;
+    const float lo = s * 12.92f;
+    const float hi = 1.055f * pow_rn(s, 1.0f / 2.4f) - 0.055f;
+    return (s > 0.0031308f) ? hi : lo;
+}
+
+enum : int { TCV_SRGB_TO_LINEAR = 0x100, TCV_LINEAR_TO_SRGB = 0x200 };   // or-ed into SrcView::tcv by the compress path
+
 __device__ __forceinline__ Texel convert_texel(Texel t, int tcv, int tsw)
 {
+    if (tcv & TCV_SRGB_TO_LINEAR) { t.r = srgb_to_linear1(t.r); t.g = srgb_to_linear1(t.g); t.b = srgb_to_linear1(t.b); }   // first, :3170-3180
+    const int srgbOut = tcv & TCV_LINEAR_TO_SRGB;
+    tcv &= 0xFF;
     if (tcv != TCV_NONE)
     {
         t.r = tcv1(t.r, tcv); t.g = tcv1(t.g, tcv); t.b = tcv1(t.b, tcv); t.a = tcv1(t.a, tcv);
@@ -228,6 +256,7 @@ __device__ __forceinline__ Texel convert_texel(Texel t, int tcv, int tsw)
     case TSW_A_TO_RGB: t.r = t.a; t.g = t.a; t.b = t.a; break;
     default: break;
     }
+    if (srgbOut) { t.r = linear_to_srgb1(t.r); t.g = linear_to_srgb1(t.g); t.b = linear_to_srgb1(t.b); }                    // last, :3843-3853
     return t;
 }
 

@@ -39,24 +39,6 @@ struct ConvertPlan
     int srgbOut;     // XMColorRGBToSRGB last
 };
 
-__device__ __forceinline__ float srgb_to_linear1(float v)
-{
-    // XMColorSRGBToRGB: V = saturate(srgb); V <= 0.04045 ? V / 12.92 : pow((V + 0.055) / 1.055, 2.4)
-    float s = (v > 0.0f) ? v : 0.0f; s = (s < 1.0f) ? s : 1.0f;
-    const float lo = s / 12.92f;
-    const float hi = powf((s + 0.055f) / 1.055f, 2.4f);
-    return (s > 0.04045f) ? hi : lo;
-}
-
-__device__ __forceinline__ float linear_to_srgb1(float v)
-{
-    // XMColorRGBToSRGB: V = saturate(rgb); V < 0.0031308 ? V * 12.92 : 1.055 * pow(V, 1/2.4) - 0.055
-    float s = (v > 0.0f) ? v : 0.0f; s = (s < 1.0f) ? s : 1.0f;
-    const float lo = s * 12.92f;
-    const float hi = 1.055f * powf(s, 1.0f / 2.4f) - 0.055f;
-    return (s > 0.0031308f) ? hi : lo;
-}
-
 __device__ __forceinline__ Texel apply_plan(Texel t, const ConvertPlan& p)
 {
     if (p.srgbIn) { t.r = srgb_to_linear1(t.r); t.g = srgb_to_linear1(t.g); t.b = srgb_to_linear1(t.b); }

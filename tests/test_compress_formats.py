@@ -10,7 +10,7 @@ import directxtex_amd as dx
 pytestmark = pytest.mark.gpu
 
 SRC = [28, 29, 87, 88, 2, 10, 11, 31, 49, 51, 61, 63, 65, 41, 54, 16, 34, 35, 56]
-DST = [71, 77, 80, 81, 83, 84, 98, 95]
+DST = [71, 72, 77, 80, 81, 83, 84, 98, 99, 95]
 
 
 def _pixels(oracle, fmt, w, h, seed):
@@ -27,18 +27,37 @@ def _pixels(oracle, fmt, w, h, seed):
 @pytest.mark.parametrize("src", SRC)
 @pytest.mark.parametrize("dst", DST)
 def test_source_formats(ctx, oracle, src, dst):
-    srgb_in, srgb_out = src in (29, 91, 93), dst in (72, 75, 78, 99)
-    if srgb_in != srgb_out:
-        with pytest.raises(dx.DxtexError) as e:        # one-sided sRGB needs pow(): documented as not supported
-            ctx.compress(_pixels(oracle, src, 8, 8, 1), 8, 8, src, dst, 0x100000, 0.5)
-        assert e.value.hresult & 0xFFFFFFFF == 0x80070032
-        return
     w, h = 23, 10
     px = _pixels(oracle, src, w, h, src * 100 + dst)
-    flags = 0x100000 if dst == 98 else 0               # BC7_QUICK keeps the oracle fast
+    flags = 0x100000 if dst in (98, 99) else 0         # BC7_QUICK keeps the oracle fast
     got = ctx.compress(px, w, h, src, dst, flags, 0.5)
     ref = oracle.ref_compress_image(px, w, h, src, dst, flags, 0.5)
-    assert np.array_equal(got, ref), (src, dst, np.nonzero(got != ref)[0][:8])
+    if px.dtype == np.uint8 or (src == 29) == (dst in (72, 99)):
+        assert np.array_equal(got, ref), (src, dst, np.nonzero(got != ref)[0][:8])
+    else:
+        # one-sided sRGB on arbitrary floats goes through pow(): correctly rounded here, libm's powf in the reference,
+        # which differ by 1 ulp on < 0.1 % of values; a block only changes when that ulp crosses a quantisation step
+        bs = 8 if dst in (71, 72, 80, 81) else 16
+        same = (got.reshape(-1, bs) == ref.reshape(-1, bs)).all(axis=1).mean()
+        assert same >= 0.9, (src, dst, same)
+
+
+@pytest.mark.parametrize("flags", [0x1000000, 0x2000000, 0x3000000])
+@pytest.mark.parametrize("dst", [71, 77, 98, 95])
+def test_srgb_flags(ctx, oracle, dst, flags):
+    """TEX_COMPRESS_SRGB_IN / _OUT / both on 8-bit sources (DirectXTexCompress.cpp:34-45, DirectXTexConvert.cpp:3164-3180,3843-3853)."""
+    w, h = 32, 16
+    px = _pixels(oracle, 28, w, h, dst + (flags >> 24))
+    f = flags | (0x100000 if dst == 98 else 0)
+    src = 10 if dst == 95 else 28
+    if src == 10:
+        px = (np.random.default_rng(4).random((h, w, 4), dtype=np.float32)).astype(np.float16)
+    got = ctx.compress(px, w, h, src, dst, f, 0.5)
+    ref = oracle.ref_compress_image(px, w, h, src, dst, f, 0.5)
+    if src == 28 or flags == 0x3000000:
+        assert np.array_equal(got, ref)
+    else:
+        assert (got.reshape(-1, 16) == ref.reshape(-1, 16)).all(axis=1).mean() >= 0.9
 
 
 def test_wide_row_pitch(ctx, oracle):
