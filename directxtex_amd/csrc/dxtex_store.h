@@ -105,6 +105,44 @@ __device__ __forceinline__ uint32_t store_usn(float v)
     return uint32_t(rintf(s * 65535.0f));
 }
 
+// The 4-byte formats as one packed word (same expressions as the cases of store_texel below).
+__device__ __forceinline__ bool is_packed32(int format)
+{
+    switch (format)
+    {
+    case FMT_R8G8B8A8_UNORM: case FMT_R8G8B8A8_UNORM_SRGB: case FMT_B8G8R8A8_UNORM: case FMT_B8G8R8A8_UNORM_SRGB:
+    case FMT_B8G8R8X8_UNORM: case FMT_B8G8R8X8_UNORM_SRGB: case FMT_R8G8B8A8_SNORM:
+        return true;
+    default:
+        return false;
+    }
+}
+
+__device__ __forceinline__ uint32_t pack_texel32(int format, const Texel& t)
+{
+    switch (format)
+    {
+    case FMT_R8G8B8A8_UNORM:
+    case FMT_R8G8B8A8_UNORM_SRGB:
+        return store_ubn_biased(t.r) | (store_ubn_biased(t.g) << 8) | (store_ubn_biased(t.b) << 16) | (store_ubn_biased(t.a) << 24);
+    case FMT_B8G8R8A8_UNORM:
+    case FMT_B8G8R8A8_UNORM_SRGB:
+        return store_ubn_biased(t.b) | (store_ubn_biased(t.g) << 8) | (store_ubn_biased(t.r) << 16) | (store_ubn_biased(t.a) << 24);
+    case FMT_B8G8R8X8_UNORM:
+    case FMT_B8G8R8X8_UNORM_SRGB:
+        // XMVectorPermute<2,1,0,7>(v, g_XMIdentityR3): w = 1 (:2157-2171)
+        return store_ubn_biased(t.b) | (store_ubn_biased(t.g) << 8) | (store_ubn_biased(t.r) << 16) | (store_ubn_biased(1.0f) << 24);
+    default:   // FMT_R8G8B8A8_SNORM
+        return (uint32_t(store_bn(t.r)) & 0xFF) | ((uint32_t(store_bn(t.g)) & 0xFF) << 8) |
+               ((uint32_t(store_bn(t.b)) & 0xFF) << 16) | ((uint32_t(store_bn(t.a)) & 0xFF) << 24);
+    }
+}
+
+__device__ __forceinline__ uint2 pack_texel_half4(const Texel& t)
+{
+    return make_uint2(uint32_t(store_half(t.r)) | (uint32_t(store_half(t.g)) << 16), uint32_t(store_half(t.b)) | (uint32_t(store_half(t.a)) << 16));
+}
+
 // One texel, StoreScanline semantics. Returns false for a format this library cannot write.
 __device__ __forceinline__ void store_texel(uint8_t* row, uint32_t x, int format, const Texel& t)
 {
@@ -114,28 +152,14 @@ __device__ __forceinline__ void store_texel(uint8_t* row, uint32_t x, int format
         reinterpret_cast<float4*>(row)[x] = make_float4(t.r, t.g, t.b, t.a);
         break;
     case FMT_R16G16B16A16_FLOAT:
-        reinterpret_cast<uint2*>(row)[x] = make_uint2(uint32_t(store_half(t.r)) | (uint32_t(store_half(t.g)) << 16),
-                                                      uint32_t(store_half(t.b)) | (uint32_t(store_half(t.a)) << 16));
+        reinterpret_cast<uint2*>(row)[x] = pack_texel_half4(t);
         break;
     case FMT_R16G16B16A16_UNORM:
         reinterpret_cast<uint2*>(row)[x] = make_uint2(store_usn(t.r) | (store_usn(t.g) << 16), store_usn(t.b) | (store_usn(t.a) << 16));
         break;
-    case FMT_R8G8B8A8_UNORM:
-    case FMT_R8G8B8A8_UNORM_SRGB:
-        reinterpret_cast<uint32_t*>(row)[x] = store_ubn_biased(t.r) | (store_ubn_biased(t.g) << 8) | (store_ubn_biased(t.b) << 16) | (store_ubn_biased(t.a) << 24);
-        break;
-    case FMT_B8G8R8A8_UNORM:
-    case FMT_B8G8R8A8_UNORM_SRGB:
-        reinterpret_cast<uint32_t*>(row)[x] = store_ubn_biased(t.b) | (store_ubn_biased(t.g) << 8) | (store_ubn_biased(t.r) << 16) | (store_ubn_biased(t.a) << 24);
-        break;
-    case FMT_B8G8R8X8_UNORM:
-    case FMT_B8G8R8X8_UNORM_SRGB:
-        // XMVectorPermute<2,1,0,7>(v, g_XMIdentityR3): w = 1 (:2157-2171)
-        reinterpret_cast<uint32_t*>(row)[x] = store_ubn_biased(t.b) | (store_ubn_biased(t.g) << 8) | (store_ubn_biased(t.r) << 16) | (store_ubn_biased(1.0f) << 24);
-        break;
-    case FMT_R8G8B8A8_SNORM:
-        reinterpret_cast<uint32_t*>(row)[x] = (uint32_t(store_bn(t.r)) & 0xFF) | ((uint32_t(store_bn(t.g)) & 0xFF) << 8) |
-                                              ((uint32_t(store_bn(t.b)) & 0xFF) << 16) | ((uint32_t(store_bn(t.a)) & 0xFF) << 24);
+    case FMT_R8G8B8A8_UNORM: case FMT_R8G8B8A8_UNORM_SRGB: case FMT_B8G8R8A8_UNORM: case FMT_B8G8R8A8_UNORM_SRGB:
+    case FMT_B8G8R8X8_UNORM: case FMT_B8G8R8X8_UNORM_SRGB: case FMT_R8G8B8A8_SNORM:
+        reinterpret_cast<uint32_t*>(row)[x] = pack_texel32(format, t);
         break;
     case FMT_R32G32_FLOAT:
         reinterpret_cast<float2*>(row)[x] = make_float2(t.r, t.g);

@@ -31,3 +31,31 @@ elif what in ("bc1", "bc3", "bc5"):
     dt, k = run(lambda: ctx.compress_device(img.data_ptr(), size, size, 28, out.data_ptr(), fmt, 0, 0.5), 10)
     bpt = 4.5 if fmt == 71 else 5.0
     print("%s %dx%d: %.3f ms, %.0f Mtexels/s, %.0f GB/s algorithmic" % (what, size, size, dt * 1e3, size * size / dt / 1e6, size * size * bpt / dt / 1e9))
+elif what == "decode":
+    img = torch.from_numpy(rgba).to(dev)
+    for name, fmt, dstfmt, flags in (("bc1", 71, 28, 0), ("bc3", 77, 28, 0), ("bc5", 83, 28, 0), ("bc7", 98, 28, 0x100000), ("bc6h", 95, 10, 0)):
+        srcfmt, src = 28, img
+        if fmt == 95:
+            srcfmt, src = 10, torch.from_numpy((rgba.astype(np.float32) / 255.0 * 4.0).astype(np.float16)).to(dev)
+            if size > 2048:
+                pass
+        rp, sp = dx.compute_pitch(fmt, size, size); bc = torch.empty(sp, dtype=torch.uint8, device=dev)
+        ctx.compress_device(src.data_ptr(), size, size, srcfmt, bc.data_ptr(), fmt, flags, 0.5)
+        bpp = 8 if dstfmt == 10 else 4
+        back = torch.empty(size * size * bpp, dtype=torch.uint8, device=dev)
+        dt, k = run(lambda: ctx.decompress_device(bc.data_ptr(), size, size, fmt, back.data_ptr(), dstfmt), 20)
+        by = sp + size * size * bpp
+        print("decode %s %dx%d: %.3f ms, %.0f Mtexels/s, %.0f GB/s algorithmic  %s" % (name, size, size, dt * 1e3, size * size / dt / 1e6, by / dt / 1e9, k))
+elif what in ("mips_box", "mips_cubic", "mips_linear", "mips_triangle"):
+    flt = {"mips_box": dx.TEX_FILTER_BOX, "mips_cubic": dx.TEX_FILTER_CUBIC, "mips_linear": dx.TEX_FILTER_LINEAR, "mips_triangle": dx.TEX_FILTER_TRIANGLE}[what]
+    img = torch.from_numpy(rgba).to(dev)
+    sizes = []; w = h = size
+    while True:
+        sizes.append((w, h))
+        if w == 1 and h == 1: break
+        w, h = max(1, w >> 1), max(1, h >> 1)
+    bufs = [img.reshape(-1)] + [torch.empty(a * b * 4, dtype=torch.uint8, device=dev) for a, b in sizes[1:]]
+    levels = [dx.capi.device_image(t.data_ptr(), a, b, 28) for t, (a, b) in zip(bufs, sizes)]
+    by = sum(a * b * 4 for a, b in sizes[:-1]) + sum(a * b * 4 for a, b in sizes[1:])
+    dt, k = run(lambda: ctx.generate_mips_device(levels, flt), 10)
+    print("%s %dx%d: %.3f ms, %.0f GB/s algorithmic %s" % (what, size, size, dt * 1e3, by / dt / 1e9, k))
