@@ -63,6 +63,10 @@ _SIGS = {
     "dxtex_generate_mips_device": (ctypes.c_int32, [_ctx_p, _P(Image), ctypes.c_size_t, ctypes.c_uint32]),
     "dxtex_convert": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
     "dxtex_convert_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
+    "dxtex_premultiply_alpha": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32]),
+    "dxtex_premultiply_alpha_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32]),
+    "dxtex_scale_mips_alpha_for_coverage": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_size_t, ctypes.c_float]),
+    "dxtex_scale_mips_alpha_for_coverage_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_size_t, ctypes.c_float]),
     "dxtex_resize": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32]),
     "dxtex_resize_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32]),
     "dxtex_compute_mse_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), _P(ctypes.c_double)]),
@@ -261,6 +265,32 @@ class Context:
         dst = Image(width, height, dst_format, rp, sp, out.ctypes.data)
         self._check(_lib.dxtex_convert(self._h, ctypes.byref(src), ctypes.byref(dst), filter_flags, threshold), "convert")
         return out
+
+    def premultiply_alpha(self, pixels, width, height, fmt, flags=0):
+        """DirectX::PremultiplyAlpha (flags = TEX_PMALPHA_*: 0x1 IGNORE_SRGB, 0x2 REVERSE, 0x1000000 / 0x2000000 SRGB_IN / OUT)."""
+        pixels = np.ascontiguousarray(pixels)
+        src = _host_image(pixels, width, height, fmt)
+        rp, sp = compute_pitch(fmt, width, height)
+        out = np.zeros(sp, np.uint8)
+        dst = Image(width, height, fmt, rp, sp, out.ctypes.data)
+        self._check(_lib.dxtex_premultiply_alpha(self._h, ctypes.byref(src), ctypes.byref(dst), flags), "premultiply_alpha")
+        return out
+
+    def scale_mips_alpha_for_coverage(self, levels, width, height, fmt, alpha_reference):
+        """DirectX::ScaleMipMapsAlphaForCoverage on a list of tight per-level buffers; returns the new levels."""
+        levels = [np.ascontiguousarray(l).view(np.uint8).reshape(-1) for l in levels]
+        n = len(levels)
+        srcs, dsts, outs = [], [], []
+        w, h = width, height
+        for l in levels:
+            srcs.append(_host_image(l, w, h, fmt))
+            rp, sp = compute_pitch(fmt, w, h)
+            o = np.zeros(sp, np.uint8); outs.append(o)
+            dsts.append(Image(w, h, fmt, rp, sp, o.ctypes.data))
+            w, h = max(1, w >> 1), max(1, h >> 1)
+        a = (Image * n)(*srcs); b = (Image * n)(*dsts)
+        self._check(_lib.dxtex_scale_mips_alpha_for_coverage(self._h, a, b, n, alpha_reference), "scale_mips_alpha_for_coverage")
+        return outs
 
     def resize(self, pixels, width, height, fmt, new_width, new_height, filter_flags=0):
         pixels = np.ascontiguousarray(pixels)

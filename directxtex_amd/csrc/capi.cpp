@@ -762,6 +762,154 @@ dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_
     return DXTEX_S_OK;
 }
 
+namespace
+{
+// PremultiplyAlpha's checks (DirectXTexPMAlpha.cpp:214-231)
+dxtex_hresult check_pmalpha(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!src || !dst) return fail(ctx, DXTEX_E_INVALIDARG, "null image");
+    if (!src->pixels || !dst->pixels) return fail(ctx, DXTEX_E_POINTER, "null pixels");
+    const FmtInfo* f = format_info(src->format);
+    if (!f || (f->cls & FC_BC) || !(f->cls & FC_A)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "PremultiplyAlpha needs an uncompressed format with alpha");
+    if (src->width > 0xFFFFFFFFull || src->height > 0xFFFFFFFFull) return fail(ctx, DXTEX_E_INVALIDARG, "image too large");
+    if (src->format != dst->format || src->width != dst->width || src->height != dst->height) return fail(ctx, DXTEX_E_FAIL, "size or format mismatch");
+    return DXTEX_S_OK;
+}
+
+// EstimateAlphaScaleForCoverage (DirectXTexMipmaps.cpp:310-352) around the device coverage count
+dxtex_hresult alpha_coverage(dxtex_ctx* ctx, const uint8_t* d, const dxtex_image& im, float scale, float alphaReference, float* coverage)
+{
+    dxtex_hresult hr = ensure(ctx, &ctx->mseBuf, &ctx->mseBytes, 4 * sizeof(double)); if (hr != DXTEX_S_OK) return hr;
+    hipError_t e = launch_alpha_coverage(d, im.rowPitch, im.format, uint32_t(im.width), uint32_t(im.height), scale, alphaReference,
+                                         static_cast<unsigned long long*>(ctx->mseBuf), ctx->stream);
+    if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    unsigned long long n = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n, ctx->mseBuf, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const float cscale = static_cast<float>((im.width - 1) * (im.height - 1) * 8 * 8);      // :299-303
+    *coverage = (cscale > 0.f) ? static_cast<float>(size_t(n)) / cscale : 0.0f;
+    return DXTEX_S_OK;
+}
+
+dxtex_hresult check_coverage_chain(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, size_t nlevels)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!src || !dst || !nlevels) return fail(ctx, DXTEX_E_INVALIDARG, "empty mip chain");
+    const FmtInfo* f = format_info(src[0].format);
+    if (f && (f->cls & FC_BC)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "ScaleMipMapsAlphaForCoverage does not take block-compressed formats");
+    if (!f) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "format is not supported by the MI355X path");
+    for (size_t i = 0; i < nlevels; ++i)
+    {
+        if (!src[i].pixels || !dst[i].pixels) return fail(ctx, DXTEX_E_POINTER, "null pixels");
+        if (src[i].format != src[0].format || dst[i].format != src[0].format || src[i].width != dst[i].width || src[i].height != dst[i].height)
+            return fail(ctx, DXTEX_E_FAIL, "level size or format mismatch");
+    }
+    return DXTEX_S_OK;
+}
+
+// the body of ScaleMipMapsAlphaForCoverage (:3503-3553) on device-resident levels
+dxtex_hresult submit_coverage_chain(dxtex_ctx* ctx, const std::vector<const uint8_t*>& s, const std::vector<uint8_t*>& d, const dxtex_image* src,
+                                    const dxtex_image* dst, size_t nlevels, float alphaReference)
+{
+    float target = 0.0f;
+    dxtex_hresult hr = alpha_coverage(ctx, s[0], src[0], 1.0f, alphaReference, &target);
+    if (hr != DXTEX_S_OK) return hr;
+    const FmtInfo* f = format_info(src[0].format);
+    const size_t rowBytes = (src[0].width * f->bpp + 7) / 8;
+    HIP_TRY(ctx, hipMemcpy2DAsync(d[0], dst[0].rowPitch, s[0], src[0].rowPitch, std::min(rowBytes, std::min(src[0].rowPitch, dst[0].rowPitch)), src[0].height,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    for (size_t level = 1; level < nlevels; ++level)
+    {
+        float lo = 0.0f, hi = 4.0f, scale = 1.0f;
+        for (int i = 0; i < 10; ++i)
+        {
+            float cov = 0.0f;
+            hr = alpha_coverage(ctx, s[level], src[level], scale, alphaReference, &cov);
+            if (hr != DXTEX_S_OK) return hr;
+            if (cov < target) lo = scale;
+            else if (cov > target) hi = scale;
+            else break;
+            scale = (lo + hi) * 0.5f;
+        }
+        hipError_t e = launch_scale_alpha(s[level], src[level].rowPitch, d[level], dst[level].rowPitch, src[level].format, uint32_t(src[level].width),
+                                          uint32_t(src[level].height), scale, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    }
+    return DXTEX_S_OK;
+}
+} // namespace
+
+dxtex_hresult dxtex_premultiply_alpha_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t flags)
+{
+    dxtex_hresult hr = check_pmalpha(ctx, src, dst);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    time_begin(ctx);
+    hipError_t e = launch_pmalpha(src->pixels, src->rowPitch, dst->pixels, dst->rowPitch, src->format, uint32_t(src->width), uint32_t(src->height), flags, ctx->stream);
+    time_end(ctx);
+    if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    return DXTEX_S_OK;
+}
+
+dxtex_hresult dxtex_premultiply_alpha(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t flags)
+{
+    dxtex_hresult hr = check_pmalpha(ctx, src, dst);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    const size_t srcBytes = src->rowPitch * src->height, dstBytes = dst->rowPitch * dst->height;
+    hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
+    hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    time_begin(ctx);
+    hipError_t e = launch_pmalpha(static_cast<const uint8_t*>(ctx->stageIn), src->rowPitch, static_cast<uint8_t*>(ctx->stageOut), dst->rowPitch, src->format,
+                                  uint32_t(src->width), uint32_t(src->height), flags, ctx->stream);
+    time_end(ctx);
+    if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    HIP_TRY(ctx, hipMemcpyAsync(dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DXTEX_S_OK;
+}
+
+dxtex_hresult dxtex_scale_mips_alpha_for_coverage_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, size_t nlevels, float alphaReference)
+{
+    dxtex_hresult hr = check_coverage_chain(ctx, src, dst, nlevels);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    std::vector<const uint8_t*> s(nlevels); std::vector<uint8_t*> d(nlevels);
+    for (size_t i = 0; i < nlevels; ++i) { s[i] = src[i].pixels; d[i] = dst[i].pixels; }
+    return submit_coverage_chain(ctx, s, d, src, dst, nlevels, alphaReference);
+}
+
+dxtex_hresult dxtex_scale_mips_alpha_for_coverage(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, size_t nlevels, float alphaReference)
+{
+    dxtex_hresult hr = check_coverage_chain(ctx, src, dst, nlevels);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    std::vector<size_t> atS(nlevels), atD(nlevels);
+    size_t totalS = 0, totalD = 0;
+    for (size_t i = 0; i < nlevels; ++i)
+    {
+        atS[i] = totalS; totalS += (src[i].rowPitch * src[i].height + 255) & ~size_t(255);
+        atD[i] = totalD; totalD += (dst[i].rowPitch * dst[i].height + 255) & ~size_t(255);
+    }
+    hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, totalS); if (hr != DXTEX_S_OK) return hr;
+    hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, totalD); if (hr != DXTEX_S_OK) return hr;
+    std::vector<const uint8_t*> s(nlevels); std::vector<uint8_t*> d(nlevels);
+    for (size_t i = 0; i < nlevels; ++i)
+    {
+        s[i] = static_cast<const uint8_t*>(ctx->stageIn) + atS[i]; d[i] = static_cast<uint8_t*>(ctx->stageOut) + atD[i];
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->stageIn) + atS[i], src[i].pixels, src[i].rowPitch * src[i].height, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->stageOut, 0, totalD, ctx->stream));
+    hr = submit_coverage_chain(ctx, s, d, src, dst, nlevels, alphaReference);
+    if (hr != DXTEX_S_OK) return hr;
+    for (size_t i = 0; i < nlevels; ++i)
+        HIP_TRY(ctx, hipMemcpyAsync(dst[i].pixels, d[i], dst[i].rowPitch * dst[i].height, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DXTEX_S_OK;
+}
+
 dxtex_hresult dxtex_compute_mse_device(dxtex_ctx* ctx, const dxtex_image* a, const dxtex_image* b, double mse[4])
 {
     dxtex_hresult hr = check_pair(ctx, a, b);

@@ -49,4 +49,12 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
 // ComputeMSE: out4 (device) receives the per-channel SUM of squared differences; divide by width * height on the host.
 hipError_t launch_mse(const uint8_t* a, uint64_t aPitch, int aFormat, const uint8_t* b, uint64_t bPitch, int bFormat,
                       uint32_t width, uint32_t height, double* out4, hipStream_t stream);
+// PremultiplyAlpha / DemultiplyAlpha (DirectXTexPMAlpha.cpp:30-205); pmFlags = TEX_PMALPHA_*
+hipError_t launch_pmalpha(const uint8_t* src, uint64_t srcPitch, uint8_t* dst, uint64_t dstPitch, int format, uint32_t width, uint32_t height,
+                          uint32_t pmFlags, hipStream_t stream);
+// ScaleAlpha and CalculateAlphaCoverage (DirectXTexMipmaps.cpp:143-305); *count receives the number of covered sub-samples
+hipError_t launch_scale_alpha(const uint8_t* src, uint64_t srcPitch, uint8_t* dst, uint64_t dstPitch, int format, uint32_t width, uint32_t height,
+                              float scale, hipStream_t stream);
+hipError_t launch_alpha_coverage(const uint8_t* src, uint64_t srcPitch, int format, uint32_t width, uint32_t height, float scale, float alphaReference,
+                                 unsigned long long* count, hipStream_t stream);
 } // namespace dxtex

@@ -64,6 +64,65 @@ __global__ void __launch_bounds__(256) convert_kernel(ImgView src, ImgView dst, 
     store_texel(dst.pixels + uint64_t(y) * dst.rowPitch, x, dst.format, apply_plan(t, plan));
 }
 
+// ---- PremultiplyAlpha / DemultiplyAlpha (DirectXTexPMAlpha.cpp:30-205): rgb * a, or rgb / a where a > 0, in linear space ------------
+__global__ void __launch_bounds__(256) pmalpha_kernel(ImgView src, ImgView dst, int srgbIn, int srgbOut, int reverse)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (x >= src.width) return;
+    Texel t = load_linear(src, x, y, srgbIn);
+    if (!reverse) { t.r = t.r * t.a; t.g = t.g * t.a; t.b = t.b * t.a; }
+    else if (t.a > 0.0f) { t.r = t.r / t.a; t.g = t.g / t.a; t.b = t.b / t.a; }
+    else { t.r = t.g = t.b = t.a; }     // as written (:134-141): with alpha <= 0 the select picks the undivided alpha splat, not the colour
+    store_linear(dst, x, y, srgbOut, t);
+}
+
+// ---- ScaleMipMapsAlphaForCoverage (DirectXTexMipmaps.cpp:143-352) ---------------------------------------------------------------------
+// ScaleAlpha: alpha * scale, colour untouched.
+__global__ void __launch_bounds__(256) scale_alpha_kernel(ImgView src, ImgView dst, float scale)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (x >= src.width) return;
+    Texel t = load_texel(src.pixels + uint64_t(y) * src.rowPitch, x, src.format);
+    t.a = t.a * scale;
+    store_texel(dst.pixels + uint64_t(y) * dst.rowPitch, x, dst.format, t);
+}
+
+// CalculateAlphaCoverage: every 2x2 quad of scaled, saturated alphas is sampled at 8x8 sub-positions with bilinear weights and
+// the samples above alphaReference are counted. Reproduced as written, including that the running vector `v` is overwritten
+// with the (splatted) sum after every sub-sample (:283), so samples 2..64 of a quad see the previous sum, not the four alphas.
+__global__ void __launch_bounds__(256) alpha_coverage_kernel(ImgView src, float scale, float alphaReference, unsigned long long* count)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    uint32_t n = 0;
+    if (x + 1 < src.width)
+    {
+        const uint8_t* row0 = src.pixels + uint64_t(y) * src.rowPitch;
+        const uint8_t* row1 = row0 + src.rowPitch;
+        float v[4];
+        v[0] = load_texel(row0, x, src.format).a * scale; v[1] = load_texel(row1, x, src.format).a * scale;
+        v[2] = load_texel(row0, x + 1, src.format).a * scale; v[3] = load_texel(row1, x + 1, src.format).a * scale;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { float m = (v[i] > 0.0f) ? v[i] : 0.0f; v[i] = (m < 1.0f) ? m : 1.0f; }      // XMVectorSaturate
+#pragma unroll 1
+        for (int sy = 0; sy < 8; ++sy)
+        {
+            const float fy = (float(sy) + 0.5f) / 8.0f, ify = 1.0f - fy;
+#pragma unroll
+            for (int sx = 0; sx < 8; ++sx)
+            {
+                const float fx = (float(sx) + 0.5f) / 8.0f, ifx = 1.0f - fx;
+                const float s = (v[0] * (ifx * ify) + v[1] * (ifx * fy)) + (v[2] * (fx * ify) + v[3] * (fx * fy));   // XMVectorSum: (x + y) + (z + w)
+                v[0] = v[1] = v[2] = v[3] = s;
+                n += (s > alphaReference) ? 1u : 0u;
+            }
+        }
+    }
+    // wave total, one atomic per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63u) == 0 && n) atomicAdd(count, static_cast<unsigned long long>(n));
+}
+
 // ---- point (:255-309 / :907-987): 16.16 fixed-point stepping -----------------------------------------------------------------
 __global__ void __launch_bounds__(256) resize_point_kernel(ResizeArgs a)
 {
@@ -331,6 +390,39 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
     case 0x500000u: hipLaunchKernelGGL(resize_triangle_kernel, grid, block, 0, stream, a); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_pmalpha(const uint8_t* src, uint64_t srcPitch, uint8_t* dst, uint64_t dstPitch, int format, uint32_t width, uint32_t height,
+                          uint32_t pmFlags, hipStream_t stream)
+{
+    if (!width || !height) return hipSuccess;
+    // TEX_PMALPHA_IGNORE_SRGB (0x1): plain Load/StoreScanline; otherwise the *Linear wrappers with the SRGB_IN/OUT bits (:68-112)
+    const bool linear = !(pmFlags & 0x1u);
+    const bool wantIn = linear && (srgb_linear_format(format) || (pmFlags & 0x1000000u)), wantOut = linear && (srgb_linear_format(format) || (pmFlags & 0x2000000u));
+    hipLaunchKernelGGL(pmalpha_kernel, dim3((width + 255) / 256, height), dim3(256), 0, stream,
+                       make_view(src, srcPitch, width, height, format), make_view(dst, dstPitch, width, height, format),
+                       (can_srgb(format) && wantIn) ? 1 : 0, (can_srgb(format) && wantOut) ? 1 : 0, (pmFlags & 0x2u) ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_scale_alpha(const uint8_t* src, uint64_t srcPitch, uint8_t* dst, uint64_t dstPitch, int format, uint32_t width, uint32_t height,
+                              float scale, hipStream_t stream)
+{
+    if (!width || !height) return hipSuccess;
+    hipLaunchKernelGGL(scale_alpha_kernel, dim3((width + 255) / 256, height), dim3(256), 0, stream,
+                       make_view(src, srcPitch, width, height, format), make_view(dst, dstPitch, width, height, format), scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_alpha_coverage(const uint8_t* src, uint64_t srcPitch, int format, uint32_t width, uint32_t height, float scale, float alphaReference,
+                                 unsigned long long* count, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    if (width < 2 || height < 2) return hipSuccess;
+    hipLaunchKernelGGL(alpha_coverage_kernel, dim3((width - 1 + 255) / 256, height - 1), dim3(256), 0, stream,
+                       make_view(src, srcPitch, width, height, format), scale, alphaReference, count);
     return hipGetLastError();
 }
 

@@ -425,6 +425,85 @@ HRESULT Convert(Device& device, const Image* srcImages, size_t nimages, const Te
     return S_OK;
 }
 
+// ---- PremultiplyAlpha (DirectXTexPMAlpha.cpp:214-341) ----------------------------------------------------------------------------------
+namespace
+{
+constexpr uint32_t TEX_MISC2_ALPHA_MODE_MASK = 0x7, TEX_ALPHA_MODE_STRAIGHT = 1, TEX_ALPHA_MODE_PREMULTIPLIED = 2;
+bool HasAlphaChannel(DXGI_FORMAT f) noexcept
+{
+    switch (int(f))
+    {
+    case 2: case 10: case 11: case 13: case 24: case 28: case 29: case 31: case 65: case 87: case 91:       // RGBA32F, RGBA16F/UNORM/SNORM, 10:10:10:2, RGBA8*, A8, BGRA8*
+        return true;
+    default:
+        return false;
+    }
+}
+}
+
+HRESULT PremultiplyAlpha(Device& device, const Image& srcImage, TEX_PMALPHA_FLAGS flags, ScratchImage& image) noexcept
+{
+    if (!device) return E_POINTER;
+    if (!srcImage.pixels) return E_POINTER;
+    if (IsCompressed(srcImage.format) || !IsKnown(srcImage.format) || !HasAlphaChannel(srcImage.format)) return HRESULT_E_NOT_SUPPORTED;
+    if (srcImage.width > UINT32_MAX || srcImage.height > UINT32_MAX) return E_INVALIDARG;
+    HRESULT hr = image.Initialize2D(srcImage.format, srcImage.width, srcImage.height, 1, 1);
+    if (FAILED(hr)) return hr;
+    const Image* rimage = image.GetImage(0, 0, 0);
+    if (!rimage) { image.Release(); return E_POINTER; }
+    const dxtex_image s = View(srcImage), d = View(*rimage);
+    hr = dxtex_premultiply_alpha(device.Get(), &s, &d, uint32_t(flags));
+    if (FAILED(hr)) image.Release();
+    return hr;
+}
+
+HRESULT PremultiplyAlpha(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_PMALPHA_FLAGS flags, ScratchImage& result) noexcept
+{
+    if (!device) return E_POINTER;
+    if (!srcImages || !nimages) return E_INVALIDARG;
+    if (IsCompressed(metadata.format) || !IsKnown(metadata.format) || !HasAlphaChannel(metadata.format)) return HRESULT_E_NOT_SUPPORTED;
+    if (metadata.width > UINT32_MAX || metadata.height > UINT32_MAX) return E_INVALIDARG;
+    const bool isPM = (metadata.miscFlags2 & TEX_MISC2_ALPHA_MODE_MASK) == TEX_ALPHA_MODE_PREMULTIPLIED;
+    if (isPM != ((flags & TEX_PMALPHA_REVERSE) != 0)) return E_FAIL;                      // :283-284
+    TexMetadata mdata2 = metadata;
+    mdata2.miscFlags2 = (mdata2.miscFlags2 & ~TEX_MISC2_ALPHA_MODE_MASK) | ((flags & TEX_PMALPHA_REVERSE) ? TEX_ALPHA_MODE_STRAIGHT : TEX_ALPHA_MODE_PREMULTIPLIED);
+    HRESULT hr = result.Initialize(mdata2);
+    if (FAILED(hr)) return hr;
+    if (nimages != result.GetImageCount()) { result.Release(); return E_FAIL; }
+    const Image* dest = result.GetImages();
+    if (!dest) { result.Release(); return E_POINTER; }
+    for (size_t i = 0; i < nimages; ++i)
+    {
+        const Image& src = srcImages[i];
+        if (src.format != metadata.format) { result.Release(); return E_FAIL; }
+        if (src.width > UINT32_MAX || src.height > UINT32_MAX) return E_FAIL;
+        if (src.width != dest[i].width || src.height != dest[i].height) { result.Release(); return E_FAIL; }
+        const dxtex_image s = View(src), d = View(dest[i]);
+        hr = dxtex_premultiply_alpha(device.Get(), &s, &d, uint32_t(flags));
+        if (FAILED(hr)) { result.Release(); return hr; }
+    }
+    return S_OK;
+}
+
+// ---- ScaleMipMapsAlphaForCoverage (DirectXTexMipmaps.cpp:3483-3556) ------------------------------------------------------------------
+HRESULT ScaleMipMapsAlphaForCoverage(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, size_t item,
+                                     float alphaReference, ScratchImage& mipChain) noexcept
+{
+    if (!device) return E_POINTER;
+    if (!srcImages || !nimages || metadata.format == DXGI_FORMAT_UNKNOWN || nimages > metadata.mipLevels || !mipChain.GetImages()) return E_INVALIDARG;
+    if (metadata.dimension == TEX_DIMENSION_TEXTURE3D || IsCompressed(metadata.format) || !IsKnown(metadata.format)) return HRESULT_E_NOT_SUPPORTED;
+    if (srcImages[0].format != metadata.format || srcImages[0].width != metadata.width || srcImages[0].height != metadata.height) return E_FAIL;
+    if (nimages < metadata.mipLevels) return E_FAIL;                                       // :3532-3533, reached at the first missing level
+    std::vector<dxtex_image> s(metadata.mipLevels), d(metadata.mipLevels);
+    for (size_t level = 0; level < metadata.mipLevels; ++level)
+    {
+        const Image* dst = mipChain.GetImage(level, item, 0);
+        if (!dst || !dst->pixels || !srcImages[level].pixels) return E_POINTER;
+        s[level] = View(srcImages[level]); d[level] = View(*dst);
+    }
+    return dxtex_scale_mips_alpha_for_coverage(device.Get(), s.data(), d.data(), s.size(), alphaReference);
+}
+
 // ---- ComputeMSE (DirectXTexMisc.cpp:181-260): compressed inputs are decompressed first -----------------------------------------------
 HRESULT ComputeMSE(Device& device, const Image& image1, const Image& image2, float& mse, float* mseV) noexcept
 {

@@ -154,6 +154,18 @@ HRESULT Convert(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_F
 HRESULT Convert(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
                 TEX_FILTER_FLAGS filter, float threshold, ScratchImage& result) noexcept;
 // mse = sum of the per-channel values, mseV[4] the per-channel MSE over [0,1] floats
+// PremultiplyAlpha (DirectXTex.h:864-884). TEX_PMALPHA_FLAGS values as in the reference.
+enum TEX_PMALPHA_FLAGS : uint32_t
+{
+    TEX_PMALPHA_DEFAULT = 0, TEX_PMALPHA_IGNORE_SRGB = 0x1, TEX_PMALPHA_REVERSE = 0x2,
+    TEX_PMALPHA_SRGB_IN = 0x1000000, TEX_PMALPHA_SRGB_OUT = 0x2000000, TEX_PMALPHA_SRGB = 0x3000000,
+};
+HRESULT PremultiplyAlpha(Device& device, const Image& srcImage, TEX_PMALPHA_FLAGS flags, ScratchImage& image) noexcept;
+HRESULT PremultiplyAlpha(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_PMALPHA_FLAGS flags, ScratchImage& result) noexcept;
+// ScaleMipMapsAlphaForCoverage (DirectXTex.h:848-851): mipChain must already be initialised with the chain's layout
+HRESULT ScaleMipMapsAlphaForCoverage(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, size_t item,
+                                     float alphaReference, ScratchImage& mipChain) noexcept;
+
 HRESULT ComputeMSE(Device& device, const Image& image1, const Image& image2, float& mse, float* mseV) noexcept;
 } // namespace DirectXTexAMD
 

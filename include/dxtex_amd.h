@@ -163,6 +163,22 @@ dxtex_hresult dxtex_resize_device(dxtex_ctx* ctx, const dxtex_image* src, const 
  * mse[4] over [0,1] floats. Used for PSNR reporting without a D2H round trip. */
 dxtex_hresult dxtex_compute_mse_device(dxtex_ctx* ctx, const dxtex_image* a, const dxtex_image* b, double mse[4]);
 
+/* PremultiplyAlpha / its REVERSE (DirectXTex.h:864-884, DirectXTexPMAlpha.cpp:214-262): same size and format on both sides,
+ * the format must carry alpha (else DXTEX_E_NOT_SUPPORTED). `flags` = TEX_PMALPHA_FLAGS. */
+#define DXTEX_PMALPHA_DEFAULT      0x0u
+#define DXTEX_PMALPHA_IGNORE_SRGB  0x1u
+#define DXTEX_PMALPHA_REVERSE      0x2u
+#define DXTEX_PMALPHA_SRGB_IN      0x1000000u
+#define DXTEX_PMALPHA_SRGB_OUT     0x2000000u
+dxtex_hresult dxtex_premultiply_alpha(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t flags);
+dxtex_hresult dxtex_premultiply_alpha_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t flags);
+
+/* ScaleMipMapsAlphaForCoverage (DirectXTex.h:848-851, DirectXTexMipmaps.cpp:3483-3556) for one mip chain: dst[0] = src[0];
+ * every further level gets its alpha scaled so that its coverage at `alphaReference` matches level 0's (10-step bisection,
+ * :310-352). src[i] and dst[i] have the same size and format. */
+dxtex_hresult dxtex_scale_mips_alpha_for_coverage(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, size_t nlevels, float alphaReference);
+dxtex_hresult dxtex_scale_mips_alpha_for_coverage_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, size_t nlevels, float alphaReference);
+
 /* ---- device memory helpers (so non-HIP hosts can stay resident in HBM) -------------------------- */
 dxtex_hresult dxtex_device_alloc(dxtex_ctx* ctx, size_t bytes, void** out);
 dxtex_hresult dxtex_device_free(dxtex_ctx* ctx, void* p);

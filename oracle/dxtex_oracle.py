@@ -40,7 +40,10 @@ def _load_ref():
         lib.dxtex_ref_generate_mips.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_uint32, sz, vp, sz, i32p]
         lib.dxtex_ref_resize.argtypes = [vp, sz, sz, ctypes.c_int, sz, sz, sz, ctypes.c_uint32, vp, sz, i32p]
         lib.dxtex_ref_convert.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_int, ctypes.c_uint32, ctypes.c_float, vp, sz, i32p]
-        for f in (lib.dxtex_ref_compress, lib.dxtex_ref_decompress, lib.dxtex_ref_generate_mips, lib.dxtex_ref_resize, lib.dxtex_ref_convert):
+        lib.dxtex_ref_premultiply_alpha.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_uint32, vp, sz, i32p]
+        lib.dxtex_ref_scale_mips_alpha.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_float, vp, sz, i32p]
+        for f in (lib.dxtex_ref_compress, lib.dxtex_ref_decompress, lib.dxtex_ref_generate_mips, lib.dxtex_ref_resize, lib.dxtex_ref_convert,
+                  lib.dxtex_ref_premultiply_alpha, lib.dxtex_ref_scale_mips_alpha):
             f.restype = ctypes.c_int64
         lib.dxtex_ref_compute_mse.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, sz, sz, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         lib.dxtex_ref_compute_mse.restype = ctypes.c_int
@@ -344,6 +347,24 @@ def ref_convert(pixels, width, height, src_fmt, dst_fmt, filter_flags=0, thresho
     """ConvertCustom's plain branch (DirectXTexConvert.cpp:4887-4909) over oracle/restate/scanline.cpp."""
     px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
     return _run(_load_ref().dxtex_ref_convert, image_bytes(dst_fmt, width, height), px.ctypes.data, width, height, src_fmt, 0, dst_fmt, filter_flags, threshold)
+
+
+def ref_premultiply_alpha(pixels, width, height, fmt, flags=0):
+    """DirectX::PremultiplyAlpha (DirectXTexPMAlpha.cpp:214-262); flags = TEX_PMALPHA_* (0x1 IGNORE_SRGB, 0x2 REVERSE, SRGB_IN/OUT)."""
+    px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
+    return _run(_load_ref().dxtex_ref_premultiply_alpha, image_bytes(fmt, width, height), px.ctypes.data, width, height, fmt, 0, flags)
+
+
+def ref_scale_mips_alpha_for_coverage(levels, width, height, fmt, alpha_reference):
+    """DirectX::ScaleMipMapsAlphaForCoverage (DirectXTexMipmaps.cpp:3483-3556) on a list of tight per-level buffers."""
+    chain = np.concatenate([np.ascontiguousarray(l).view(np.uint8).reshape(-1) for l in levels])
+    sizes = mip_sizes(width, height, len(levels))
+    blob = _run(_load_ref().dxtex_ref_scale_mips_alpha, chain.size, chain.ctypes.data, width, height, fmt, len(levels), alpha_reference)
+    res, at = [], 0
+    for w, h in sizes:
+        n = image_bytes(fmt, w, h)
+        res.append(blob[at:at + n].copy()); at += n
+    return res
 
 
 def ref_compute_mse(a, fmt_a, b, fmt_b, width, height):

@@ -181,6 +181,38 @@ extern "C"
         return int64_t(sp);
     }
 
+    // PremultiplyAlpha (DirectXTexPMAlpha.cpp:214-262); flags = TEX_PMALPHA_*
+    int64_t dxtex_ref_premultiply_alpha(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t rowPitch, uint32_t flags,
+                                        uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        ScratchImage si;
+        const HRESULT hr = PremultiplyAlpha(make_image(pixels, w, h, fmt, rowPitch), TEX_PMALPHA_FLAGS(flags), si);
+        if (hrOut) *hrOut = int32_t(hr);
+        return FAILED(hr) ? -1 : copy_out(si, out, capacity);
+    }
+
+    // ScaleMipMapsAlphaForCoverage (DirectXTexMipmaps.cpp:3483-3556) over a tight mip chain of `levels` images
+    int64_t dxtex_ref_scale_mips_alpha(const uint8_t* chain, size_t w, size_t h, int fmt, size_t levels, float alphaReference,
+                                       uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        ScratchImage in, si;
+        HRESULT hr = in.Initialize2D(DXGI_FORMAT(fmt), w, h, 1, levels);
+        if (SUCCEEDED(hr)) hr = si.Initialize2D(DXGI_FORMAT(fmt), w, h, 1, levels);
+        if (FAILED(hr)) { if (hrOut) *hrOut = int32_t(hr); return -1; }
+        size_t at = 0;
+        for (size_t l = 0; l < levels; ++l)
+        {
+            const Image& im = in.GetImages()[l];
+            size_t rp = 0, sp = 0;
+            ComputePitch(im.format, im.width, im.height, rp, sp);
+            for (size_t y = 0; y < im.height; ++y) memcpy(im.pixels + y * im.rowPitch, chain + at + y * rp, rp);
+            at += sp;
+        }
+        hr = ScaleMipMapsAlphaForCoverage(in.GetImages(), in.GetImageCount(), in.GetMetadata(), 0, alphaReference, si);
+        if (hrOut) *hrOut = int32_t(hr);
+        return FAILED(hr) ? -1 : copy_out(si, out, capacity);
+    }
+
     int dxtex_ref_compute_mse(const uint8_t* a, int fmtA, const uint8_t* b, int fmtB, size_t w, size_t h, float* mse, float* mseV)
     {
         float m = 0.f;

@@ -104,6 +104,18 @@ static int gpu_run(const std::string& outdir)
     CHECK(resizedAll.GetImageCount() == 1 && resizedAll.GetMetadata().mipLevels == 1 && resizedAll.GetMetadata().width == 40);
     dump(outdir + "/resized_linear_array.bin", resizedAll.GetPixels(), resizedAll.GetPixelsSize());
 
+    // premultiplied alpha and alpha-to-coverage preserving mips
+    ScratchImage pm, cov;
+    CHECK(PremultiplyAlpha(dev, src, TEX_PMALPHA_DEFAULT, pm) == S_OK);
+    dump(outdir + "/premultiplied.bin", pm.GetPixels(), pm.GetPixelsSize());
+    CHECK(cov.Initialize2D(src.format, W, H, 1, mips.GetMetadata().mipLevels) == S_OK);
+    CHECK(ScaleMipMapsAlphaForCoverage(dev, mips.GetImages(), mips.GetImageCount(), mips.GetMetadata(), 0, 0.6f, cov) == S_OK);
+    dump(outdir + "/mips_coverage.bin", cov.GetPixels(), cov.GetPixelsSize());
+    {
+        ScratchImage r8; Image one = src; one.format = DXGI_FORMAT_R8_UNORM; one.rowPitch = W;
+        CHECK(PremultiplyAlpha(dev, one, TEX_PMALPHA_DEFAULT, r8) == HRESULT_E_NOT_SUPPORTED);
+    }
+
     float mse = 0, v[4];
     CHECK(ComputeMSE(dev, src, *bc7.GetImage(0, 0, 0), mse, v) == S_OK);
     std::printf("mse %.9g %.9g %.9g %.9g %.9g\n", mse, v[0], v[1], v[2], v[3]);

@@ -42,6 +42,8 @@ def test_host_layer_on_gpu(tmp_path, oracle):
     bgra = np.concatenate([oracle.ref_convert(m, w, h, 28, 87, 0, 0.5).reshape(-1) for m, (w, h) in zip(mips, sizes)])
     assert np.array_equal(rd("mips_bgra.bin"), bgra)
     assert np.array_equal(rd("resized_linear_array.bin"), oracle.ref_resize(mips[0], W, H, 28, 40, 24, 0x200000).reshape(-1))
+    assert np.array_equal(rd("premultiplied.bin"), oracle.ref_premultiply_alpha(src, W, H, 28, 0))
+    assert np.array_equal(rd("mips_coverage.bin"), np.concatenate(oracle.ref_scale_mips_alpha_for_coverage(mips, W, H, 28, 0.6)))
     line = [l for l in r.stdout.splitlines() if l.startswith("mse ")][0].split()
     got = np.array([float(x) for x in line[2:6]])
     ref = oracle.ref_compute_mse(src, 28, oracle.ref_decompress_image(bc7, W, H, 98, 28), 28, W, H)

@@ -104,3 +104,27 @@ def test_reference_error_codes():
     with pytest.raises(oracle.RefError) as e:
         oracle.ref_resize(img, 8, 8, RGBA8, 5, 4, 0x400000)          # box needs 2:1
     assert e.value.hresult == 0x80004005
+
+
+def test_demultiply_alpha_quirk():
+    """DemultiplyAlpha (DirectXTexPMAlpha.cpp:134-141): with alpha <= 0 nothing is divided and the select returns the alpha
+    splat for RGB - the colour is lost. The GPU kernel reproduces this; pinned here so the oracle keeps saying so."""
+    x = np.array([[0.5, 0.25, 0.125, 0.5], [0.3, 0.6, 0.9, 0.0], [0.1, 0.2, 0.3, -1.0]], np.float32)
+    r = oracle.ref_premultiply_alpha(x.view(np.uint8).reshape(-1), 3, 1, 2, 2).view(np.float32).reshape(3, 4)
+    assert np.array_equal(r, np.array([[1.0, 0.5, 0.25, 0.5], [0, 0, 0, 0], [-1, -1, -1, -1]], np.float32))
+
+
+def test_alpha_coverage_running_vector_quirk():
+    """CalculateAlphaCoverage (DirectXTexMipmaps.cpp:277-289) overwrites the quad's alpha vector with the first sub-sample's sum,
+    so a quad (1, 0, 0, 0) - true bilinear coverage at reference 0.5 is 7/64 - feeds sample k+1 with sample k's splatted value.
+    A single fully opaque texel among transparent ones must therefore not change the level-1 alpha the way a true bilinear
+    estimate would; the test just pins the reference's output on a small asymmetric image."""
+    img = np.zeros((4, 4, 4), np.float32); img[..., :3] = 0.5
+    img[0, 0, 3] = 1.0; img[1, 2, 3] = 0.8; img[3, 3, 3] = 0.3
+    mips = oracle.ref_generate_mips(img, 4, 4, 2, 0x400000, 3)
+    out = oracle.ref_scale_mips_alpha_for_coverage(mips, 4, 4, 2, 0.25)
+    a1 = out[1].view(np.float32).reshape(2, 2, 4)[..., 3]
+    m1 = mips[1].view(np.float32).reshape(2, 2, 4)[..., 3]
+    assert np.array_equal(out[0], mips[0])
+    scale = a1[0, 0] / m1[0, 0]
+    assert np.allclose(a1, m1 * scale, rtol=1e-6) and 0.0 < scale <= 4.0

@@ -135,3 +135,42 @@ def test_compute_mse(ctx, oracle):
     ref64 = oracle.compute_mse(fa, fb)
     assert np.allclose(got, ref64, rtol=1e-6, atol=0)
     assert np.allclose(got, ref32, rtol=2e-4, atol=0)        # the reference accumulates in fp32, serially
+
+
+# ---- PremultiplyAlpha / ScaleMipMapsAlphaForCoverage -----------------------------------------------
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 0x1000000, 0x2000002])
+@pytest.mark.parametrize("fmt", [RGBA8, RGBA8S, 87, 10, RGBA32F])
+def test_premultiply_alpha(ctx, oracle, fmt, flags):
+    w, h = 37, 19
+    img = _image(w, h, fmt, seed=fmt + flags % 7)
+    got = ctx.premultiply_alpha(img, w, h, fmt, flags)
+    ref = oracle.ref_premultiply_alpha(img, w, h, fmt, flags)
+    srgb_path = not (flags & 1) and (fmt in (RGBA8S,) or flags & 0x3000000)
+    if srgb_path and fmt in (10, RGBA32F):
+        # pow() on arbitrary floats: 1 ulp apart from libm's powf on < 0.1 % of values
+        g, r = (got.view(np.uint16), ref.view(np.uint16)) if fmt == 10 else (got.view(np.uint32), ref.view(np.uint32))
+        assert (g != r).mean() < 0.01
+    elif srgb_path:
+        assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= 1 and (got != ref).mean() < 0.01
+    else:
+        assert np.array_equal(got, ref), (fmt, flags, np.nonzero(got != ref)[0][:8])
+
+
+def test_premultiply_alpha_errors(ctx):
+    img = _image(8, 8, 49, 1)              # R8G8_UNORM: no alpha
+    with pytest.raises(dx.DxtexError) as e:
+        ctx.premultiply_alpha(img, 8, 8, 49, 0)
+    assert e.value.hresult & 0xFFFFFFFF == 0x80070032        # HRESULT_E_NOT_SUPPORTED, DirectXTexPMAlpha.cpp:222-227
+
+
+@pytest.mark.parametrize("ref_alpha", [0.5, 0.25, 0.9])
+@pytest.mark.parametrize("fmt", [RGBA8, RGBA32F, 10])
+def test_scale_mips_alpha_for_coverage(ctx, oracle, fmt, ref_alpha):
+    w, h = 64, 32
+    img = _image(w, h, fmt, seed=11)
+    mips = oracle.ref_generate_mips(img, w, h, fmt, BOX, 6)
+    got = ctx.scale_mips_alpha_for_coverage(mips, w, h, fmt, ref_alpha)
+    ref = oracle.ref_scale_mips_alpha_for_coverage(mips, w, h, fmt, ref_alpha)
+    for lvl, (g, r) in enumerate(zip(got, ref)):
+        assert np.array_equal(g, r), (fmt, lvl)
+    assert any((g != m).any() for g, m in zip(got[1:], mips[1:]))      # some level really was rescaled
