@@ -133,8 +133,9 @@ dxtex_hresult tile_conversion(const FmtInfo& in, const FmtInfo& out, uint32_t co
     return DXTEX_S_OK;
 }
 
-dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width, size_t height, int srcFormat, size_t srcRowPitch,
-                              uint8_t* dDst, int dstFormat, size_t dstRowPitch, uint32_t flags, float threshold)
+// Compress' argument checks (DirectXTexCompress.cpp:671-676, :741-745) and the source view the tile loaders take
+dxtex_hresult compress_view(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width, size_t height, int srcFormat, size_t srcRowPitch, int dstFormat,
+                            uint32_t flags, SrcView* view)
 {
     const FmtInfo* in = format_info(srcFormat);
     const FmtInfo* out = format_info(dstFormat);
@@ -143,11 +144,20 @@ dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width,
     if (!in) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "source format is not supported by the MI355X path");
     if (!width || !height) return fail(ctx, DXTEX_E_INVALIDARG, "empty image");
     if (width > 0xFFFFFFFCull || height > 0xFFFFFFFCull) return fail(ctx, DXTEX_E_INVALIDARG, "image too large");
-
     SrcView v;
     v.pixels = dSrc; v.width = uint32_t(width); v.height = uint32_t(height); v.rowPitch = srcRowPitch; v.format = srcFormat;
-    dxtex_hresult hr = tile_conversion(*in, *out, flags, &v.tcv, &v.tsw);
+    const dxtex_hresult hr = tile_conversion(*in, *out, flags, &v.tcv, &v.tsw);
     if (hr != DXTEX_S_OK) return fail(ctx, hr, "unsupported tile conversion");
+    *view = v;
+    return DXTEX_S_OK;
+}
+
+dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width, size_t height, int srcFormat, size_t srcRowPitch,
+                              uint8_t* dDst, int dstFormat, size_t dstRowPitch, uint32_t flags, float threshold)
+{
+    SrcView v;
+    dxtex_hresult hr = compress_view(ctx, dSrc, width, height, srcFormat, srcRowPitch, dstFormat, flags, &v);
+    if (hr != DXTEX_S_OK) return hr;
 
     hipError_t e;
     switch (dstFormat)
@@ -361,6 +371,31 @@ dxtex_hresult dxtex_compress_many_device(dxtex_ctx* ctx, const dxtex_image* srcs
     if (!ctx) return DXTEX_E_POINTER;
     if (!srcs || !dsts || !count) return fail(ctx, DXTEX_E_INVALIDARG, "empty batch");
     ScopedDevice sd(ctx->device);
+    // BC7 arrays go through the per-mode pipeline as one block list (launch_bc7_encode_many): the pipeline's latency floor and
+    // tails are paid once per 2^22 blocks instead of once per image
+    bool allBc7 = count > 1;
+    for (size_t i = 0; i < count && allBc7; ++i) allBc7 = dsts[i].format == FMT_BC7_UNORM || dsts[i].format == FMT_BC7_UNORM_SRGB;
+    if (allBc7)
+    {
+        std::vector<BcImage> batch(count);
+        uint64_t nblocks = 0;
+        for (size_t i = 0; i < count; ++i)
+        {
+            dxtex_hresult hr = check_pair(ctx, &srcs[i], &dsts[i]);
+            if (hr == DXTEX_S_OK)
+                hr = compress_view(ctx, srcs[i].pixels, srcs[i].width, srcs[i].height, srcs[i].format, srcs[i].rowPitch, dsts[i].format, flags, &batch[i].src);
+            if (hr != DXTEX_S_OK) return hr;
+            batch[i].dst = dsts[i].pixels; batch[i].dstRowPitch = dsts[i].rowPitch;
+            nblocks += uint64_t((srcs[i].width + 3) / 4) * uint64_t((srcs[i].height + 3) / 4);
+        }
+        dxtex_hresult hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks, flags, count));
+        if (hr != DXTEX_S_OK) return hr;
+        time_begin(ctx);
+        const hipError_t e = launch_bc7_encode_many(batch.data(), count, flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
+        time_end(ctx);
+        if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+        return DXTEX_S_OK;
+    }
     time_begin(ctx);
     for (size_t i = 0; i < count; ++i)
     {

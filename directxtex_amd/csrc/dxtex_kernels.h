@@ -17,10 +17,13 @@ protected:
 hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, int dstFormat,
                               uint32_t flags, float threshold, hipStream_t stream);
 
-// BC7: `scratch` must hold bc7_scratch_bytes(number of 4x4 blocks, flags) bytes of device memory.
-size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags);
+// BC7: `scratch` must hold bc7_scratch_bytes(total number of 4x4 blocks, flags, number of images) bytes of device memory.
+// The _many form runs an array of images (a mip chain, a texture array) through the per-mode pipeline as one block list.
+struct BcImage { SrcView src; uint8_t* dst; uint64_t dstRowPitch; };
+size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags, size_t nimages = 1);
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
                              void* scratch, hipStream_t stream, KernelMarks* marks);
+hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t flags, void* scratch, hipStream_t stream, KernelMarks* marks);
 
 // BC6H (UF16 / SF16): `scratch` must hold bc6h_scratch_bytes(number of 4x4 blocks) bytes of device memory.
 size_t bc6h_scratch_bytes(uint64_t nblocks);

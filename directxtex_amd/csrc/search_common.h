@@ -119,11 +119,13 @@ __device__ __forceinline__ uint32_t queue_take(WaveQueue& q, uint32_t* head, uin
 {
     if (q.lo >= q.hi && !q.drained)
     {
+        // short lists (small images): one task per lane, so that the serial length of a task is paid once, not twice
+        const uint32_t batch = (live > uint32_t(kSearchWaves) * 64u) ? kQueueBatch : 64u;
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(head, kQueueBatch);
+        if (lane == 0) base = atomicAdd(head, batch);
         base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
         q.lo = base;
-        q.hi = min(base + kQueueBatch, live);
+        q.hi = min(base + batch, live);
         if (base >= live) { q.drained = true; q.hi = q.lo; }
     }
     const uint32_t k = uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));

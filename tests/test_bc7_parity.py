@@ -106,3 +106,36 @@ def test_multi_pass_images(oracle):
     """ % root)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DXTEX_MAX_BLOCKS_PER_PASS="17"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "multi-pass OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("pass_blocks", [None, "23"])
+def test_array_goes_through_one_block_list(oracle, pass_blocks):
+    """dxtex_compress_many_device hands a BC7 array (here: a mip chain plus two unrelated images, different sizes and source
+    formats) to the pipeline as ONE block list cut into per-image segments; with a 23-block pass the segments also straddle
+    passes. Every image must still be byte-identical to the reference's per-image Compress."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys; sys.path.insert(0, %r)
+        import numpy as np, torch, directxtex_amd as dx, oracle
+        from directxtex_amd import synth
+        c = dx.Context(0); dev = torch.device("cuda", 0)
+        base = synth.rgba8(40, 24, seed=3, alpha="smooth")
+        imgs = [(m, w, h, 28) for m, (w, h) in zip(oracle.ref_generate_mips(base, 40, 24, 28, 0x200000, 6), oracle.mip_sizes(40, 24, 6))]
+        imgs.append((synth.rgba8(17, 9, seed=4, alpha="opaque"), 17, 9, 28))
+        imgs.append(((synth.rgba8(12, 12, seed=5, alpha="smooth").astype(np.float32) / 255).astype(np.float16), 12, 12, 10))
+        src_t = [torch.from_numpy(np.ascontiguousarray(p).view(np.uint8).reshape(-1).copy()).to(dev) for p, _, _, _ in imgs]
+        dst_t = [torch.zeros(dx.compute_pitch(98, w, h)[1], dtype=torch.uint8, device=dev) for _, w, h, _ in imgs]
+        srcs = [dx.capi.device_image(t.data_ptr(), w, h, f) for t, (_, w, h, f) in zip(src_t, imgs)]
+        dsts = [dx.capi.device_image(t.data_ptr(), w, h, 98) for t, (_, w, h, _) in zip(dst_t, imgs)]
+        c.compress_many_device(srcs, dsts, 0, 0.5)
+        torch.cuda.synchronize()
+        for t, (p, w, h, f) in zip(dst_t, imgs):
+            assert np.array_equal(t.cpu().numpy(), oracle.ref_compress_image(p, w, h, f, 98, 0, 0.5)), (w, h, f)
+        print("array OK")
+    """ % root)
+    env = dict(os.environ)
+    if pass_blocks:
+        env["DXTEX_MAX_BLOCKS_PER_PASS"] = pass_blocks
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "array OK" in r.stdout, r.stdout + r.stderr
