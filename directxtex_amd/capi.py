@@ -61,6 +61,7 @@ _SIGS = {
     "dxtex_decode_blocks": (ctypes.c_int32, [_ctx_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dxtex_generate_mips": (ctypes.c_int32, [_ctx_p, _P(Image), ctypes.c_size_t, ctypes.c_uint32]),
     "dxtex_generate_mips_device": (ctypes.c_int32, [_ctx_p, _P(Image), ctypes.c_size_t, ctypes.c_uint32]),
+    "dxtex_compress_many": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_size_t, ctypes.c_uint32, ctypes.c_float]),
     "dxtex_convert": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
     "dxtex_convert_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
     "dxtex_premultiply_alpha": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32]),

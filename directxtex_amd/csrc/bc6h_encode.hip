@@ -39,9 +39,8 @@ enum : int { SEED_INTS = 17 * 6 + 2 };      // 8 shapes x 2 regions + the one-re
 
 struct Bc6hArgs
 {
-    SrcView src;
-    uint8_t* dst; uint64_t dstRowPitch;
-    uint32_t nbw, nbh, nb0, nblocks;
+    SegTable seg;           // the images behind this pass (search_common.h)
+    uint32_t nblocks;       // blocks in this pass; scratch arrays are indexed by pass-local block number
     int isSigned;
     float* fpix;            // nblocks x 3 x 16: the block's texels as INTColor values held in floats (r[16], g[16], b[16])
     uint8_t* lists;         // nblocks x 8 shape ids
@@ -88,12 +87,13 @@ __global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
     if (lane < 16)
     {
         // one texel of the block, with the reference's partial-block replication (DirectXTexCompress.cpp:315-341)
-        const uint32_t gb = a.nb0 + nb;
-        const uint32_t by = gb / a.nbw, bx = gb - by * a.nbw;
+        const BcSeg& im = seg_of(a.seg, nb);
+        const uint32_t gb = im.nb0 + (nb - im.l0);
+        const uint32_t by = gb / im.nbw, bx = gb - by * im.nbw;
         const uint32_t x0 = bx * 4, y0 = by * 4;
-        const uint32_t pw = min(4u, a.src.width - x0), ph = min(4u, a.src.height - y0);
+        const uint32_t pw = min(4u, im.src.width - x0), ph = min(4u, im.src.height - y0);
         const uint32_t sx = x0 + replicate_src(lane & 3, pw), sy = y0 + replicate_src(lane >> 2, ph);
-        const Texel px = convert_texel(load_texel(a.src.pixels + uint64_t(sy) * a.src.rowPitch, sx, a.src.format), a.src.tcv, a.src.tsw);
+        const Texel px = convert_texel(load_texel(im.src.pixels + uint64_t(sy) * im.src.rowPitch, sx, im.src.format), im.src.tcv, im.src.tsw);
         sF[wave][lane * 4 + 0] = px.r; sF[wave][lane * 4 + 1] = px.g; sF[wave][lane * 4 + 2] = px.b; sF[wave][lane * 4 + 3] = px.a;
         const float ir = float(float_to_int16f(px.r, sg)), ig = float(float_to_int16f(px.g, sg)), ib = float(float_to_int16f(px.b, sg));
         sP[wave][lane] = ir; sP[wave][16 + lane] = ig; sP[wave][32 + lane] = ib;
@@ -394,13 +394,14 @@ __global__ void __launch_bounds__(256) bc6h_store_kernel(Bc6hArgs a)
     const uint32_t nb = blockIdx.x * 256u + threadIdx.x;
     if (nb >= a.nblocks) return;
     const Best6 b = a.best[nb];
-    const uint32_t gb = a.nb0 + nb;
-    const uint32_t by = gb / a.nbw, bx = gb - by * a.nbw;
-    uint64_t* out = reinterpret_cast<uint64_t*>(a.dst + uint64_t(by) * a.dstRowPitch) + 2 * uint64_t(bx);
+    const BcSeg& im = seg_of(a.seg, nb);
+    const uint32_t gb = im.nb0 + (nb - im.l0);
+    const uint32_t by = gb / im.nbw, bx = gb - by * im.nbw;
+    uint64_t* out = reinterpret_cast<uint64_t*>(im.dst + uint64_t(by) * im.dstRowPitch) + 2 * uint64_t(bx);
     out[0] = b.lo; out[1] = b.hi;
 }
 
-const uint64_t kMaxBlocksPerPass6 = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(getenv("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 20);
+const uint64_t kMaxBlocksPerPass6 = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(getenv("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 22);
 struct Scratch6
 {
     size_t fpix, lists, seeds, recs, order, tinfo, counters, best, total;
@@ -421,26 +422,35 @@ struct Scratch6
 };
 } // namespace
 
-size_t bc6h_scratch_bytes(uint64_t nblocks)
+size_t bc6h_scratch_bytes(uint64_t nblocks, size_t nimages)
 {
-    return Scratch6(nblocks < kMaxBlocksPerPass6 ? nblocks : kMaxBlocksPerPass6).total;
+    return Scratch6(nblocks < kMaxBlocksPerPass6 ? nblocks : kMaxBlocksPerPass6).total + seg_table_bytes(nblocks, kMaxBlocksPerPass6, nimages);
 }
 
 hipError_t launch_bc6h_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, bool isSigned, void* scratch,
                               hipStream_t stream, KernelMarks* marks)
 {
+    BcImage one; one.src = src; one.dst = dst; one.dstRowPitch = dstRowPitch;
+    return launch_bc6h_encode_many(&one, 1, isSigned, scratch, stream, marks);
+}
+
+hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isSigned, void* scratch, hipStream_t stream, KernelMarks* marks)
+{
 #define DXTEX_MARK(NAME) do { if (marks) marks->mark(NAME); } while (0)
-    const uint32_t nbw = (src.width + 3) / 4, nbh = (src.height + 3) / 4;
-    const uint64_t total = uint64_t(nbw) * nbh;
-    if (!total) return hipSuccess;
+    std::vector<BcSeg> segs;
+    std::vector<BcPass> passes;
+    uint64_t perPass = 0;
+    if (!build_passes(images, count, kMaxBlocksPerPass6, segs, passes, &perPass)) return hipSuccess;
+    const Scratch6 L(perPass);
     uint8_t* base = static_cast<uint8_t*>(scratch);
-    for (uint64_t first = 0; first < total; first += kMaxBlocksPerPass6)
+    BcSeg* dSegs = reinterpret_cast<BcSeg*>(base + L.total);
+    const hipError_t ce = upload_segments(dSegs, segs, passes, stream);
+    if (ce != hipSuccess) return ce;
+    for (const BcPass& pass : passes)
     {
-        const uint64_t nb = (total - first) < kMaxBlocksPerPass6 ? (total - first) : kMaxBlocksPerPass6;
-        const Scratch6 L(nb);
         Bc6hArgs a;
-        a.src = src; a.dst = dst; a.dstRowPitch = dstRowPitch;
-        a.nbw = nbw; a.nbh = nbh; a.nb0 = uint32_t(first); a.nblocks = uint32_t(nb);
+        set_pass(a.seg, dSegs, segs, pass);
+        a.nblocks = pass.nblocks;
         a.isSigned = isSigned ? 1 : 0;
         a.fpix = reinterpret_cast<float*>(base + L.fpix);
         a.lists = base + L.lists;

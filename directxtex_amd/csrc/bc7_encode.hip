@@ -29,26 +29,9 @@ struct Cand { uint32_t err; uint32_t ord; uint64_t lo, hi; };   // ord = evaluat
 enum : int { SLOT_M0 = 0, SLOT_M1, SLOT_M2, SLOT_M3, SLOT_M4A, SLOT_M4B, SLOT_M5, SLOT_M6, SLOT_M7, NUM_SLOTS };
 enum : int { LIST_BYTES = 64 };   // per block: [0..15] 3-bit list, [16..31] 2-bit list, [32] hasAlpha, [33..36] mode-0 list, [40..55] mode-2 list
 
-// A pass covers up to kMaxBlocksPerPass blocks taken from one or more images (an array / mip chain goes through the per-mode
-// pipeline as ONE block list, so small images do not pay the pipeline's latency floor each). A segment is the run of one
-// image's blocks inside the pass; only the kernels that touch pixels or the payload (rough / texels / pre / post staging, pick)
-// look segments up, everything between works on pass-local block numbers.
-struct Seg
-{
-    SrcView src;
-    uint8_t* dst;
-    uint64_t dstRowPitch;
-    uint32_t nbw;            // blocks per row of the image
-    uint32_t nb0;            // first block of the image in this segment
-    uint32_t l0;             // pass-local number of that block
-    uint32_t pad;
-};
-
 struct Bc7Args
 {
-    Seg inl[2];              // nseg <= 2 (a single image, the usual case): the segments travel in the kernel arguments
-    const Seg* segs;         // otherwise: segments of this pass in device memory, ascending l0
-    uint32_t nseg;
+    SegTable seg;            // the images behind this pass (search_common.h)
     uint32_t nblocks;        // blocks in this pass; scratch arrays are indexed by pass-local block number
     uint32_t flags;
     uint8_t* lists;
@@ -60,14 +43,6 @@ struct Bc7Args
     uint32_t* counters;      // 35 words, see bc7_bin_* kernels
     uint8_t* done;           // per block: a mode already reached error 0, Encode() would stop here (:2803, :2835, :2845)
 };
-
-__device__ __forceinline__ const Seg& seg_of(const Bc7Args& a, uint32_t local)
-{
-    if (a.nseg <= 2) return (a.nseg == 2 && a.inl[1].l0 <= local) ? a.inl[1] : a.inl[0];
-    uint32_t lo = 0, hi = a.nseg;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.segs[mid].l0 <= local) lo = mid; else hi = mid; }
-    return a.segs[lo];
-}
 
 // One texel of block `nb` (texel t = y*4+x), with the reference's partial-block replication, as float4
 // plus the 8-bit value D3DX_BC7::Encode derives from it (:2792-2799).
@@ -102,7 +77,7 @@ __global__ void __launch_bounds__(256) bc7_rough_kernel(Bc7Args a)
     if (lane < 16)
     {
         uint32_t ldr;
-        const Seg& sg = seg_of(a, nb);
+        const BcSeg& sg = seg_of(a.seg, nb);
         load_block_texel(sg.src, sg.nbw, sg.nb0 + (nb - sg.l0), lane, &sF[wave][lane * 4], ldr);
         sL[wave][lane] = ldr;
         a.px[uint64_t(nb) * 16 + lane] = ldr;
@@ -284,7 +259,7 @@ __device__ __forceinline__ void stage_blocks(const Bc7Args& a, uint32_t nbFirst,
         uint32_t ldr = 0;
         if (nb < a.nblocks)
         {
-            const Seg& sg = seg_of(a, nb);
+            const BcSeg& sg = seg_of(a.seg, nb);
             load_block_texel(sg.src, sg.nbw, sg.nb0 + (nb - sg.l0), t & 15, &sF[(t >> 4) * 64 + (t & 15) * 4], ldr);
         }
         sL[t] = ldr;
@@ -554,7 +529,7 @@ __global__ void __launch_bounds__(256) bc7_texels_kernel(Bc7Args a)
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= a.nblocks * 16u) return;
     float f4[4]; uint32_t ldr;
-    const Seg& sg = seg_of(a, i >> 4);
+    const BcSeg& sg = seg_of(a.seg, i >> 4);
     load_block_texel(sg.src, sg.nbw, sg.nb0 + ((i >> 4) - sg.l0), i & 15u, f4, ldr);
     a.px[i] = ldr;
     if ((i & 15u) == 0) a.done[i >> 4] = 0;
@@ -577,7 +552,7 @@ __global__ void __launch_bounds__(256) bc7_pick_kernel(Bc7Args a, uint32_t slotM
         const uint64_t key = (uint64_t(v.err) << 32) | v.ord;
         if (key < bestKey) { bestKey = key; lo = v.lo; hi = v.hi; }
     }
-    const Seg& sg = seg_of(a, nb);
+    const BcSeg& sg = seg_of(a.seg, nb);
     const uint32_t gb = sg.nb0 + (nb - sg.l0);
     const uint32_t by = gb / sg.nbw, bx = gb - by * sg.nbw;
     uint64_t* out = reinterpret_cast<uint64_t*>(sg.dst + uint64_t(by) * sg.dstRowPitch) + 2 * uint64_t(bx);
@@ -654,9 +629,8 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
 
 size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags, size_t nimages)
 {
-    const uint64_t perPass = nblocks < kMaxBlocksPerPass ? nblocks : kMaxBlocksPerPass;
-    const uint64_t passes = perPass ? (nblocks + perPass - 1) / perPass : 1;
-    return ScratchLayout(perPass, (flags & BCF_USE_3SUBSETS) != 0).total + ((nimages + passes + 1) * sizeof(Seg) + 255 & ~size_t(255));
+    return ScratchLayout(nblocks < kMaxBlocksPerPass ? nblocks : kMaxBlocksPerPass, (flags & BCF_USE_3SUBSETS) != 0).total +
+           seg_table_bytes(nblocks, kMaxBlocksPerPass, nimages);
 }
 
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
@@ -672,55 +646,23 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
 #define DXTEX_MODE(MODE, IM, TAG) do { static const char* const n_[7] = { "bc7_pre_" TAG, "bc7_bin_" TAG, "bc7_perturb_" TAG, "bc7_perturb_alpha_" TAG, \
                                            "bc7_exhaustive_" TAG, "bc7_exhaustive_alpha_" TAG, "bc7_post_" TAG }; \
                                        launch_mode<MODE, IM>(a, stream, marks, n_); } while (0)
-    // cut the concatenated block list of all images into passes, and every pass into per-image segments
-    struct Pass { uint32_t seg0, nseg, nblocks; };
-    std::vector<Seg> segs;
-    std::vector<Pass> passes;
-    uint64_t total = 0;
-    for (size_t i = 0; i < count; ++i) total += uint64_t((images[i].src.width + 3) / 4) * ((images[i].src.height + 3) / 4);
-    if (!total) return hipSuccess;
-    const uint64_t perPass = total < kMaxBlocksPerPass ? total : kMaxBlocksPerPass;
-    {
-        Pass cur = { 0, 0, 0 };
-        for (size_t i = 0; i < count; ++i)
-        {
-            const uint32_t nbw = (images[i].src.width + 3) / 4, nbh = (images[i].src.height + 3) / 4;
-            uint64_t left = uint64_t(nbw) * nbh, at = 0;
-            while (left)
-            {
-                const uint64_t take = std::min<uint64_t>(left, perPass - cur.nblocks);
-                Seg sg; sg.src = images[i].src; sg.dst = images[i].dst; sg.dstRowPitch = images[i].dstRowPitch;
-                sg.nbw = nbw; sg.nb0 = uint32_t(at); sg.l0 = cur.nblocks; sg.pad = 0;
-                segs.push_back(sg);
-                ++cur.nseg; cur.nblocks += uint32_t(take); at += take; left -= take;
-                if (cur.nblocks == perPass) { passes.push_back(cur); cur = { uint32_t(segs.size()), 0, 0 }; }
-            }
-        }
-        if (cur.nblocks) passes.push_back(cur);
-    }
+    std::vector<BcSeg> segs;
+    std::vector<BcPass> passes;
+    uint64_t perPass = 0;
+    if (!build_passes(images, count, kMaxBlocksPerPass, segs, passes, &perPass)) return hipSuccess;
     const bool three = (flags & BCF_USE_3SUBSETS) != 0;
     const ScratchLayout L(perPass, three);
     uint8_t* base = static_cast<uint8_t*>(scratch);
-    Seg* dSegs = reinterpret_cast<Seg*>(base + L.total);
-    bool needTable = false;
-    for (const Pass& pass : passes) needTable |= pass.nseg > 2;
-    if (needTable)
-    {
-        // stream-ordered (the previous call's kernels may still be reading the old table); the source is pageable, which HIP
-        // stages or waits on before returning - the vector is kept alive until the next call regardless
-        static thread_local std::vector<Seg> keep;
-        keep.swap(segs);
-        const hipError_t ce = hipMemcpyAsync(dSegs, keep.data(), keep.size() * sizeof(Seg), hipMemcpyHostToDevice, stream);
-        if (ce != hipSuccess) return ce;
-        segs = keep;
-    }
+    BcSeg* dSegs = reinterpret_cast<BcSeg*>(base + L.total);
+    const hipError_t ce = upload_segments(dSegs, segs, passes, stream);
+    if (ce != hipSuccess) return ce;
     const bool quick = (flags & BCF_BC7_QUICK) != 0;
 
-    for (const Pass& pass : passes)
+    for (const BcPass& pass : passes)
     {
         Bc7Args a;
-        a.segs = dSegs + pass.seg0; a.nseg = pass.nseg; a.nblocks = pass.nblocks;
-        a.inl[0] = segs[pass.seg0]; a.inl[1] = segs[pass.seg0 + (pass.nseg > 1 ? 1 : 0)];
+        set_pass(a.seg, dSegs, segs, pass);
+        a.nblocks = pass.nblocks;
         a.flags = flags;
         a.lists = base + L.lists;
         a.cands = reinterpret_cast<Cand*>(base + L.cands);

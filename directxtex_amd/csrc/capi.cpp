@@ -371,11 +371,15 @@ dxtex_hresult dxtex_compress_many_device(dxtex_ctx* ctx, const dxtex_image* srcs
     if (!ctx) return DXTEX_E_POINTER;
     if (!srcs || !dsts || !count) return fail(ctx, DXTEX_E_INVALIDARG, "empty batch");
     ScopedDevice sd(ctx->device);
-    // BC7 arrays go through the per-mode pipeline as one block list (launch_bc7_encode_many): the pipeline's latency floor and
+    // BC7 / BC6H arrays go through the per-mode pipeline as one block list (launch_bc7_encode_many / launch_bc6h_encode_many): the pipeline's latency floor and
     // tails are paid once per 2^22 blocks instead of once per image
-    bool allBc7 = count > 1;
-    for (size_t i = 0; i < count && allBc7; ++i) allBc7 = dsts[i].format == FMT_BC7_UNORM || dsts[i].format == FMT_BC7_UNORM_SRGB;
-    if (allBc7)
+    bool allBc7 = count > 1, allBc6 = count > 1;
+    for (size_t i = 0; i < count; ++i)
+    {
+        allBc7 = allBc7 && (dsts[i].format == FMT_BC7_UNORM || dsts[i].format == FMT_BC7_UNORM_SRGB);
+        allBc6 = allBc6 && dsts[i].format == dsts[0].format && (dsts[i].format == FMT_BC6H_UF16 || dsts[i].format == FMT_BC6H_SF16);
+    }
+    if (allBc7 || allBc6)
     {
         std::vector<BcImage> batch(count);
         uint64_t nblocks = 0;
@@ -388,10 +392,11 @@ dxtex_hresult dxtex_compress_many_device(dxtex_ctx* ctx, const dxtex_image* srcs
             batch[i].dst = dsts[i].pixels; batch[i].dstRowPitch = dsts[i].rowPitch;
             nblocks += uint64_t((srcs[i].width + 3) / 4) * uint64_t((srcs[i].height + 3) / 4);
         }
-        dxtex_hresult hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks, flags, count));
+        dxtex_hresult hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, allBc7 ? bc7_scratch_bytes(nblocks, flags, count) : bc6h_scratch_bytes(nblocks, count));
         if (hr != DXTEX_S_OK) return hr;
         time_begin(ctx);
-        const hipError_t e = launch_bc7_encode_many(batch.data(), count, flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
+        const hipError_t e = allBc7 ? launch_bc7_encode_many(batch.data(), count, flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr)
+                                    : launch_bc6h_encode_many(batch.data(), count, dsts[0].format == FMT_BC6H_SF16, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
         time_end(ctx);
         if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
         return DXTEX_S_OK;
@@ -406,6 +411,40 @@ dxtex_hresult dxtex_compress_many_device(dxtex_ctx* ctx, const dxtex_image* srcs
         if (hr != DXTEX_S_OK) { time_end(ctx); return hr; }
     }
     time_end(ctx);
+    return DXTEX_S_OK;
+}
+
+// Array form of dxtex_compress with host pointers: every image is staged into one device buffer, the whole array is
+// submitted as one dxtex_compress_many_device, and the payloads come back together.
+dxtex_hresult dxtex_compress_many(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts, size_t count, uint32_t flags, float threshold)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!srcs || !dsts || !count) return fail(ctx, DXTEX_E_INVALIDARG, "empty batch");
+    ScopedDevice sd(ctx->device);
+    std::vector<dxtex_image> ds(count), dd(count);
+    std::vector<size_t> atS(count), atD(count), bytesD(count);
+    size_t totalS = 0, totalD = 0;
+    for (size_t i = 0; i < count; ++i)
+    {
+        const dxtex_hresult hr = check_pair(ctx, &srcs[i], &dsts[i]);
+        if (hr != DXTEX_S_OK) return hr;
+        atS[i] = totalS; totalS += (srcs[i].rowPitch * srcs[i].height + 255) & ~size_t(255);
+        bytesD[i] = dsts[i].rowPitch * std::max<size_t>(1, (srcs[i].height + 3) / 4);
+        atD[i] = totalD; totalD += (bytesD[i] + 255) & ~size_t(255);
+    }
+    dxtex_hresult hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, totalS); if (hr != DXTEX_S_OK) return hr;
+    hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, totalD); if (hr != DXTEX_S_OK) return hr;
+    for (size_t i = 0; i < count; ++i)
+    {
+        ds[i] = srcs[i]; ds[i].pixels = static_cast<uint8_t*>(ctx->stageIn) + atS[i];
+        dd[i] = dsts[i]; dd[i].pixels = static_cast<uint8_t*>(ctx->stageOut) + atD[i];
+        HIP_TRY(ctx, hipMemcpyAsync(ds[i].pixels, srcs[i].pixels, srcs[i].rowPitch * srcs[i].height, hipMemcpyHostToDevice, ctx->stream));
+    }
+    hr = dxtex_compress_many_device(ctx, ds.data(), dd.data(), count, flags, threshold);
+    if (hr != DXTEX_S_OK) return hr;
+    for (size_t i = 0; i < count; ++i)
+        HIP_TRY(ctx, hipMemcpyAsync(dsts[i].pixels, dd[i].pixels, bytesD[i], hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
 

@@ -5,11 +5,100 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
+#include <vector>
+#include "dxtex_kernels.h"
 
 namespace dxtex
 {
 namespace
 {
+// ---- passes and segments ---------------------------------------------------------------------------------------------
+// A pass covers up to a fixed number of blocks taken from one or more images (an array / mip chain goes through the
+// per-mode pipeline as ONE block list, so small images do not each pay the pipeline's latency floor and tails). A segment
+// is the run of one image's blocks inside a pass; only the kernels that touch pixels or the payload look segments up,
+// everything between works on pass-local block numbers.
+struct BcSeg
+{
+    SrcView src;
+    uint8_t* dst;
+    uint64_t dstRowPitch;
+    uint32_t nbw;            // blocks per row of the image
+    uint32_t nb0;            // first block of the image in this segment
+    uint32_t l0;             // pass-local number of that block
+    uint32_t pad;
+};
+
+struct SegTable
+{
+    BcSeg inl[2];            // nseg <= 2 (a single image, the usual case): the segments travel in the kernel arguments
+    const BcSeg* segs;       // otherwise: the pass's segments in device memory, ascending l0
+    uint32_t nseg;
+};
+
+__device__ __forceinline__ const BcSeg& seg_of(const SegTable& t, uint32_t local)
+{
+    if (t.nseg <= 2) return (t.nseg == 2 && t.inl[1].l0 <= local) ? t.inl[1] : t.inl[0];
+    uint32_t lo = 0, hi = t.nseg;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (t.segs[mid].l0 <= local) lo = mid; else hi = mid; }
+    return t.segs[lo];
+}
+
+struct BcPass { uint32_t seg0, nseg, nblocks; };
+
+// Cuts the concatenated block list of `count` images into passes of at most `perPass` blocks and per-image segments.
+inline uint64_t build_passes(const BcImage* images, size_t count, uint64_t maxPerPass, std::vector<BcSeg>& segs, std::vector<BcPass>& passes, uint64_t* perPassOut)
+{
+    uint64_t total = 0;
+    for (size_t i = 0; i < count; ++i) total += uint64_t((images[i].src.width + 3) / 4) * ((images[i].src.height + 3) / 4);
+    const uint64_t perPass = total < maxPerPass ? total : maxPerPass;
+    *perPassOut = perPass;
+    if (!total) return 0;
+    BcPass cur = { 0, 0, 0 };
+    for (size_t i = 0; i < count; ++i)
+    {
+        const uint32_t nbw = (images[i].src.width + 3) / 4, nbh = (images[i].src.height + 3) / 4;
+        uint64_t left = uint64_t(nbw) * nbh, at = 0;
+        while (left)
+        {
+            const uint64_t take = std::min<uint64_t>(left, perPass - cur.nblocks);
+            BcSeg sg; sg.src = images[i].src; sg.dst = images[i].dst; sg.dstRowPitch = images[i].dstRowPitch;
+            sg.nbw = nbw; sg.nb0 = uint32_t(at); sg.l0 = cur.nblocks; sg.pad = 0;
+            segs.push_back(sg);
+            ++cur.nseg; cur.nblocks += uint32_t(take); at += take; left -= take;
+            if (cur.nblocks == perPass) { passes.push_back(cur); cur = { uint32_t(segs.size()), 0, 0 }; }
+        }
+    }
+    if (cur.nblocks) passes.push_back(cur);
+    return total;
+}
+
+// Uploads the segment table when some pass needs it (more than two segments). Stream-ordered: the previous call's kernels may
+// still be reading the old table. The source is pageable, which HIP stages or waits on before returning; the vector is kept
+// alive until the next call regardless.
+inline hipError_t upload_segments(BcSeg* dSegs, std::vector<BcSeg>& segs, const std::vector<BcPass>& passes, hipStream_t stream)
+{
+    bool needTable = false;
+    for (const BcPass& pass : passes) needTable |= pass.nseg > 2;
+    if (!needTable) return hipSuccess;
+    static thread_local std::vector<BcSeg> keep;
+    keep = segs;
+    return hipMemcpyAsync(dSegs, keep.data(), keep.size() * sizeof(BcSeg), hipMemcpyHostToDevice, stream);
+}
+
+inline void set_pass(SegTable& t, const BcSeg* dSegs, const std::vector<BcSeg>& segs, const BcPass& pass)
+{
+    t.segs = dSegs + pass.seg0; t.nseg = pass.nseg;
+    t.inl[0] = segs[pass.seg0]; t.inl[1] = segs[pass.seg0 + (pass.nseg > 1 ? 1 : 0)];
+}
+
+inline size_t seg_table_bytes(uint64_t nblocks, uint64_t maxPerPass, size_t nimages)
+{
+    const uint64_t perPass = nblocks < maxPerPass ? nblocks : maxPerPass;
+    const uint64_t passes = perPass ? (nblocks + perPass - 1) / perPass : 1;
+    return ((nimages + passes + 1) * sizeof(BcSeg) + 255) & ~size_t(255);
+}
+
 // Lanes of one wavefront exchange data through LDS: DS operations of a wave execute in order, so only the
 // compiler has to be told not to move accesses across this point.
 __device__ __forceinline__ void wave_lds_sync()

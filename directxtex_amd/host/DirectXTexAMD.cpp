@@ -207,15 +207,16 @@ HRESULT Compress(Device& device, const Image* srcImages, size_t nimages, const T
     if (FAILED(hr)) return hr;
     if (nimages != cImages.GetImageCount()) { cImages.Release(); return E_FAIL; }
     const Image* dest = cImages.GetImages();
+    std::vector<dxtex_image> s(nimages), d(nimages);
     for (size_t i = 0; i < nimages; ++i)
     {
         if (srcImages[i].format != metadata.format) { cImages.Release(); return E_FAIL; }
         if (srcImages[i].width != dest[i].width || srcImages[i].height != dest[i].height) { cImages.Release(); return E_FAIL; }     // :800-804
-        const dxtex_image s = View(srcImages[i]), d = View(dest[i]);
-        hr = dxtex_compress(device.Get(), &s, &d, uint32_t(compress), threshold);
-        if (FAILED(hr)) { cImages.Release(); return hr; }
+        s[i] = View(srcImages[i]); d[i] = View(dest[i]);
     }
-    return S_OK;
+    hr = dxtex_compress_many(device.Get(), s.data(), d.data(), nimages, uint32_t(compress), threshold);      // the whole array in one submission
+    if (FAILED(hr)) cImages.Release();
+    return hr;
 }
 
 // ---- Decompress (DirectXTexCompress.cpp:852-979) -------------------------------------------------------------------------------

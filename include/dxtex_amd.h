@@ -129,10 +129,14 @@ dxtex_hresult dxtex_compress(dxtex_ctx* ctx, const dxtex_image* src, const dxtex
 dxtex_hresult dxtex_compress_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst,
                                     uint32_t compress_flags, float threshold);
 
-/* Batch of `count` independent images (texture array / atlas pages) on device memory; one stream-ordered
- * submission. */
+/* Batch of `count` independent images (texture array, mip chain, atlas pages: the array overload of Compress,
+ * DirectXTexCompress.cpp:722-846) on device memory; one stream-ordered submission. BC6H / BC7 arrays go through the
+ * search pipeline as one block list, so many small images cost what one image of the same total size costs. */
 dxtex_hresult dxtex_compress_many_device(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts,
                                          size_t count, uint32_t compress_flags, float threshold);
+/* Same with host pointers (staged through one device buffer, returns when the payloads are back). */
+dxtex_hresult dxtex_compress_many(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts,
+                                  size_t count, uint32_t compress_flags, float threshold);
 
 /* BC -> uncompressed (R8G8B8A8_UNORM, R16G16B16A16_FLOAT, R32G32B32A32_FLOAT, R8_UNORM/SNORM, R8G8_*).
  * Host and device variants as above. */

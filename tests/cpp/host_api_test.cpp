@@ -89,6 +89,9 @@ static int gpu_run(const std::string& outdir)
     CHECK(Compress(dev, mips.GetImages(), mips.GetImageCount(), mips.GetMetadata(), DXGI_FORMAT_BC3_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, bc3) == S_OK);
     CHECK(bc3.GetImageCount() == 7 && bc3.GetImage(6, 0, 0)->slicePitch == 16);
     dump(outdir + "/mips_bc3.bin", bc3.GetPixels(), bc3.GetPixelsSize());
+    ScratchImage bc7chain;     // BC7 arrays run through the search pipeline as one block list
+    CHECK(Compress(dev, mips.GetImages(), mips.GetImageCount(), mips.GetMetadata(), DXGI_FORMAT_BC7_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, bc7chain) == S_OK);
+    dump(outdir + "/mips_bc7.bin", bc7chain.GetPixels(), bc7chain.GetPixelsSize());
 
     CHECK(Resize(dev, src, 50, 70, TEX_FILTER_TRIANGLE, resized) == S_OK);
     dump(outdir + "/resized_triangle.bin", resized.GetPixels(), resized.GetPixelsSize());

@@ -132,6 +132,15 @@ def test_array_goes_through_one_block_list(oracle, pass_blocks):
         torch.cuda.synchronize()
         for t, (p, w, h, f) in zip(dst_t, imgs):
             assert np.array_equal(t.cpu().numpy(), oracle.ref_compress_image(p, w, h, f, 98, 0, 0.5)), (w, h, f)
+        # the same through BC6H_UF16 (shares the pass / segment machinery)
+        hdr = [((synth.rgba8(w, h, seed=20 + i, alpha="opaque").astype(np.float32) / 255 * 5).astype(np.float16), w, h) for i, (w, h) in enumerate([(20, 12), (7, 5), (1, 1), (33, 4)])]
+        hs = [torch.from_numpy(p.view(np.uint8).reshape(-1).copy()).to(dev) for p, _, _ in hdr]
+        hd = [torch.zeros(dx.compute_pitch(95, w, h)[1], dtype=torch.uint8, device=dev) for _, w, h in hdr]
+        c.compress_many_device([dx.capi.device_image(t.data_ptr(), w, h, 10) for t, (_, w, h) in zip(hs, hdr)],
+                               [dx.capi.device_image(t.data_ptr(), w, h, 95) for t, (_, w, h) in zip(hd, hdr)], 0, 0.5)
+        torch.cuda.synchronize()
+        for t, (p, w, h) in zip(hd, hdr):
+            assert np.array_equal(t.cpu().numpy(), oracle.ref_compress_image(p, w, h, 10, 95, 0, 0.5)), ("bc6h", w, h)
         print("array OK")
     """ % root)
     env = dict(os.environ)

@@ -37,6 +37,8 @@ def test_host_layer_on_gpu(tmp_path, oracle):
     sizes = oracle.mip_sizes(W, H, 7)
     bc3 = np.concatenate([oracle.ref_compress_image(m, w, h, 28, 77, 0, 0.5) for m, (w, h) in zip(mips, sizes)])
     assert np.array_equal(rd("mips_bc3.bin"), bc3)
+    bc7c = np.concatenate([oracle.ref_compress_image(m, w, h, 28, 98, 0, 0.5) for m, (w, h) in zip(mips, sizes)])
+    assert np.array_equal(rd("mips_bc7.bin"), bc7c)
     assert np.array_equal(rd("resized_triangle.bin"), oracle.ref_resize(src, W, H, 28, 50, 70, 0x500000))
     assert np.array_equal(rd("converted_f16.bin"), oracle.ref_convert(src, W, H, 28, 10, 0, 0.5))
     bgra = np.concatenate([oracle.ref_convert(m, w, h, 28, 87, 0, 0.5).reshape(-1) for m, (w, h) in zip(mips, sizes)])
