@@ -230,6 +230,8 @@ def main():
                 if t.get("kernel") == dom:
                     roof["traffic"] = t.get("hbm_bytes_per_launch")
                     roof["traffic_source"] = t.get("source")
+                    if t.get("valu"):
+                        roof["valu_from_profile"] = t["valu"]      # SQ counters of the same kernel (profiles/): what actually bounds it
             except Exception:
                 pass
 

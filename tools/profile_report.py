@@ -63,7 +63,11 @@ for k in order:
 open(out_md, 'w').write("\n".join(L) + "\n")
 dom = order[0]
 marks = {"bc7_exhaustive_kernel<1, 0, 0>": "bc7_exhaustive_mode1", "bc7_exhaustive_kernel<3, 0, 0>": "bc7_exhaustive_mode3"}
-json.dump({"kernel": marks.get(dom, dom), "rocprof_kernel": dom, "hbm_bytes_per_launch": int(traffic.get(dom, 0)),
+vd = cnt.get(dom, {}); nd = max(1, launches[dom]['SQ_WAVES']) if dom in launches else 1
+avg_ms = next((float(r['AverageNs']) / 1e6 for r in stats if short(r['Name']) == dom), 0.0)
+valu = {"simd_valu_busy_ms_at_2p4GHz": round(vd.get('SQ_ACTIVE_INST_VALU', 0) / nd * 4 / 1024 / 2.4e9 * 1e3, 2), "kernel_avg_ms": round(avg_ms, 3),
+        "active_lanes_per_valu_inst": round(vd.get('SQ_THREAD_CYCLES_VALU', 0) / max(1, vd.get('SQ_ACTIVE_INST_VALU', 1)), 1)}
+json.dump({"kernel": marks.get(dom, dom), "rocprof_kernel": dom, "hbm_bytes_per_launch": int(traffic.get(dom, 0)), "valu": valu,
            "source": f"{out_md}: FETCH_SIZE + WRITE_SIZE, separate --pmc passes, KiB -> bytes, no x2 (4 B/lane loads, calibrated on bc7_rough_kernel)"},
           open(os.path.join(os.path.dirname(out_md), 'pmc_traffic.json'), 'w'), indent=1)
 print(open(out_md).read()[:6000])
