@@ -168,12 +168,12 @@ class Context:
 
     def profile_end(self):
         """-> {kernel name: (total ms, launches)} since profile_begin (synchronises the stream)."""
-        cap = 64
-        names = ctypes.create_string_buffer(4096)
+        cap = 256
+        names = ctypes.create_string_buffer(16384)
         ms = (ctypes.c_float * cap)()
         n = (ctypes.c_uint32 * cap)()
         cnt = ctypes.c_size_t()
-        self._check(_lib.dxtex_ctx_profile_end(self._h, names, 4096, ms, n, cap, ctypes.byref(cnt)), "profile_end")
+        self._check(_lib.dxtex_ctx_profile_end(self._h, names, 16384, ms, n, cap, ctypes.byref(cnt)), "profile_end")
         keys = names.value.decode().split("\n")[:cnt.value]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(keys)}
 

@@ -1241,6 +1241,67 @@ struct Bits128
     }
 };
 
+// ---- exact pruning ------------------------------------------------------------------------------------------------------
+// A lower bound on the error that ANY endpoints and indices of a BC7 mode can reach on one subset. Every palette entry is
+// ((64 - w) e0 + w e1 + 32) >> 6 per channel, i.e. within 0.5 per channel (0.5 sqrt(C) in distance) of a point on the real
+// line through the unquantised endpoints e0, e1. So a texel's distance to its palette entry is at least its distance to that
+// line minus 0.5 sqrt(C), and over the subset (triangle inequality in l2)
+//     error >= ( sqrt(sum_t dist(p_t, line)^2) - 0.5 sqrt(C n) )^2   whenever the bracket is positive,
+// and sum_t dist^2 is at least what the best-fit line leaves: tr(S) - lambda_max(S), S the scatter matrix of the n texels over
+// the C channels the line lives in (3 colour channels, or 4 when alpha is interpolated with them). lambda_max is bounded from
+// ABOVE by ||N^16||_F^(1/16) (N = S / tr S, four squarings: (sum lambda_i^32)^(1/32) >= lambda_max, and tight unless the
+// two largest eigenvalues are within a few per cent). A candidate partition whose bound exceeds an error some other
+// candidate or mode of the block has already reached can never win D3DX_BC7::Encode's "first minimum" (:2835-2848), so
+// its OptimizeOne search (:3045-3110) is skipped - the output does not change, only work that cannot matter is dropped.
+// Returned rounded down (and shaved) so that float rounding can only weaken the bound.
+DXTEX_HD int subset_lower_bound(const uint32_t* pix, uint32_t mask16, uint32_t rot, int C)
+{
+    uint32_t n = 0, s[4] = { 0, 0, 0, 0 }, ss[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };    // ss: (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+    for (uint32_t i = 0; i < 16; ++i)
+        if ((mask16 >> i) & 1u)
+        {
+            const uint32_t p = rotate_pixel(pix[i], rot);
+            const uint32_t c0 = p & 0xFFu, c1 = (p >> 8) & 0xFFu, c2 = (p >> 16) & 0xFFu, c3 = (C == 4) ? (p >> 24) : 0u;
+            ++n; s[0] += c0; s[1] += c1; s[2] += c2; s[3] += c3;
+            ss[0] += c0 * c0; ss[1] += c0 * c1; ss[2] += c0 * c2; ss[3] += c0 * c3;
+            ss[4] += c1 * c1; ss[5] += c1 * c2; ss[6] += c1 * c3;
+            ss[7] += c2 * c2; ss[8] += c2 * c3; ss[9] += c3 * c3;
+        }
+    if (n < 2) return 0;
+    // M = n * S, exact integers (|entries| <= 16 * 16 * 255^2)
+    const int M00 = int(n * ss[0]) - int(s[0] * s[0]), M01 = int(n * ss[1]) - int(s[0] * s[1]), M02 = int(n * ss[2]) - int(s[0] * s[2]), M03 = int(n * ss[3]) - int(s[0] * s[3]);
+    const int M11 = int(n * ss[4]) - int(s[1] * s[1]), M12 = int(n * ss[5]) - int(s[1] * s[2]), M13 = int(n * ss[6]) - int(s[1] * s[3]);
+    const int M22 = int(n * ss[7]) - int(s[2] * s[2]), M23 = int(n * ss[8]) - int(s[2] * s[3]), M33 = int(n * ss[9]) - int(s[3] * s[3]);
+    const int T = M00 + M11 + M22 + M33;
+    if (T <= 0) return 0;
+    const double inv = 1.0 / double(T);
+    double a00 = M00 * inv, a01 = M01 * inv, a02 = M02 * inv, a03 = M03 * inv, a11 = M11 * inv, a12 = M12 * inv, a13 = M13 * inv,
+           a22 = M22 * inv, a23 = M23 * inv, a33 = M33 * inv;
+    for (int k = 0; k < 4; ++k)
+    {
+        const double b00 = a00 * a00 + a01 * a01 + a02 * a02 + a03 * a03;
+        const double b01 = a00 * a01 + a01 * a11 + a02 * a12 + a03 * a13;
+        const double b02 = a00 * a02 + a01 * a12 + a02 * a22 + a03 * a23;
+        const double b03 = a00 * a03 + a01 * a13 + a02 * a23 + a03 * a33;
+        const double b11 = a01 * a01 + a11 * a11 + a12 * a12 + a13 * a13;
+        const double b12 = a01 * a02 + a11 * a12 + a12 * a22 + a13 * a23;
+        const double b13 = a01 * a03 + a11 * a13 + a12 * a23 + a13 * a33;
+        const double b22 = a02 * a02 + a12 * a12 + a22 * a22 + a23 * a23;
+        const double b23 = a02 * a03 + a12 * a13 + a22 * a23 + a23 * a33;
+        const double b33 = a03 * a03 + a13 * a13 + a23 * a23 + a33 * a33;
+        a00 = b00; a01 = b01; a02 = b02; a03 = b03; a11 = b11; a12 = b12; a13 = b13; a22 = b22; a23 = b23; a33 = b33;
+    }
+    const double f2 = a00 * a00 + a11 * a11 + a22 * a22 + a33 * a33 + 2.0 * (a01 * a01 + a02 * a02 + a03 * a03 + a12 * a12 + a13 * a13 + a23 * a23);
+    double lam = sqrt(sqrt(sqrt(sqrt(sqrt(f2)))));          // ||N^16||_F ^ (1/16)
+    lam = lam * (1.0 + 1e-9);
+    if (lam >= 1.0) return 0;
+    const double resid = double(T) * (1.0 - lam) / double(n);       // tr(S) - lambda_max(S), S = M / n
+    const double d = sqrt(resid) - 0.5 * sqrt(double(C) * double(n)) - 1e-3;
+    if (d <= 0.0) return 0;
+    const double lb = d * d * 0.99999 - 1.0;
+    return (lb > 0.0) ? int(lb) : 0;
+}
+
 // eps[s] = (A, B) of subset s in RGBAPrecWithP units; idx1/idx2 = 4 bits per texel position;
 // anchors = texel positions of the subset anchors (anchor[0] == 0).
 template<int MODE>

@@ -29,6 +29,8 @@ struct Cand { uint32_t err; uint32_t ord; uint64_t lo, hi; };   // ord = evaluat
 enum : int { SLOT_M0 = 0, SLOT_M1, SLOT_M2, SLOT_M3, SLOT_M4A, SLOT_M4B, SLOT_M5, SLOT_M6, SLOT_M7, NUM_SLOTS };
 enum : int { LIST_BYTES = 64 };   // per block: [0..15] 3-bit list, [16..31] 2-bit list, [32] hasAlpha, [33..36] mode-0 list, [40..55] mode-2 list
 
+enum : int { PHASE_ALL = 0, PHASE_EARLY = 1, PHASE_LATE = 2 };
+
 struct Bc7Args
 {
     SegTable seg;            // the images behind this pass (search_common.h)
@@ -41,7 +43,12 @@ struct Bc7Args
     uint2* order;            // live tasks of the current mode, sorted by subset size: (task, tinfo)
     uint32_t* tinfo;         // per task: texel mask | rotation << 16 | subset size << 24 (size 0 = no search needed)
     uint32_t* counters;      // 35 words, see bc7_bin_* kernels
-    uint8_t* done;           // per block: a mode already reached error 0, Encode() would stop here (:2803, :2835, :2845)
+    uint32_t* zeroOrd;       // per block: evaluation-order key of the first candidate (in Encode's order) known to reach error 0;
+                             // Encode() returns there (:2803, :2835, :2845), so later candidates are never looked at
+    int* bestErr;            // per block: smallest error an already finished mode reached (subset_lower_bound prunes against it)
+    int prune;               // 0 = search every candidate like the reference does (DXTEX_BC7_NO_PRUNE, for A/B runs)
+    int early6Pct;           // rough kernel: mode 6 goes first where 100 * lower bound <= early6Pct * best 3-bit rough error
+    int phase;               // which blocks this launch of a mode owns: PHASE_ALL, or the early / late half of a split mode
 };
 
 // One texel of block `nb` (texel t = y*4+x), with the reference's partial-block replication, as float4
@@ -81,7 +88,7 @@ __global__ void __launch_bounds__(256) bc7_rough_kernel(Bc7Args a)
         load_block_texel(sg.src, sg.nbw, sg.nb0 + (nb - sg.l0), lane, &sF[wave][lane * 4], ldr);
         sL[wave][lane] = ldr;
         a.px[uint64_t(nb) * 16 + lane] = ldr;
-        if (lane == 0) a.done[nb] = 0;
+        if (lane == 0) { a.zeroOrd[nb] = 0xFFFFFFFFu; a.bestErr[nb] = 0x7FFFFFFF; }
     }
     wave_lds_sync();
     const float* fpx = sF[wave];
@@ -117,7 +124,14 @@ __global__ void __launch_bounds__(256) bc7_rough_kernel(Bc7Args a)
             selection_pass(eb, sb, lane, i);
         }
         if (lane < 16) { lst[lane] = uint8_t(sa); lst[16 + lane] = uint8_t(sb); }
-        if (lane == 0) lst[32] = hasAlpha ? 1 : 0;
+        if (lane == 0)
+        {
+            lst[32] = hasAlpha ? 1 : 0;
+            // Scheduling hint, not a result: mode 6 (one subset, RGBA on one line) runs BEFORE the two-subset modes for blocks
+            // where it has a chance against them - its lower bound does not exceed the best 3-bit rough error - so that its
+            // result can prune their candidates; elsewhere it runs last and is mostly pruned itself. See launch order below.
+            lst[37] = (hasAlpha || int64_t(subset_lower_bound(pix, 0xFFFFu, 0u, 4)) * 100 <= int64_t(ea) * a.early6Pct) ? 1 : 0;
+        }
     }
 
     // ---- 3-subset shapes: modes 0 (first 16 shapes) and 2 (64 shapes) ----
@@ -182,6 +196,27 @@ template<int MODE, int IM> struct TaskMap
                         (MODE == 4) ? (IM ? SLOT_M4B : SLOT_M4A) : (MODE == 5) ? SLOT_M5 : (MODE == 6) ? SLOT_M6 : SLOT_M7 };
 };
 
+// Position of a candidate in D3DX_BC7::Encode's loop nest: modes ascending, then rotation, index mode, shape rank (:2805-2886)
+template<int MODE, int IM>
+__device__ __forceinline__ uint32_t candidate_sub(uint32_t rank)
+{
+    return (TaskMap<MODE, IM>::NS == 1) ? ((MODE == 4) ? (rank * 2 + IM) * 16u : rank * 16u) : rank;
+}
+template<int MODE, int IM>
+__device__ __forceinline__ uint32_t candidate_ord(uint32_t rank) { return uint32_t(MODE) * 128u + candidate_sub<MODE, IM>(rank); }
+
+// Modes 4, 5 and 6 are launched twice when the rough pass has run: early (before the two-subset modes) for the blocks they are
+// likely to win - blocks with alpha for 4 / 5, blocks flagged by the rough kernel for 6 - and late for the others. A launch
+// must not touch the candidate slot of a block it does not own.
+template<int MODE>
+__device__ __forceinline__ bool phase_owns(const Bc7Args& a, uint32_t nb)
+{
+    if (a.phase == PHASE_ALL || (MODE != 4 && MODE != 5 && MODE != 6)) return true;
+    const uint8_t* lst = a.lists + uint64_t(nb) * LIST_BYTES;
+    const bool early = (MODE == 6) ? (lst[37] != 0) : (lst[32] != 0);
+    return early == (a.phase == PHASE_EARLY);
+}
+
 // Texel mask, anchor and rotation of task `r` (= t % TPB) of block `nb`; false if the task does not exist.
 template<int MODE, int IM>
 __device__ __forceinline__ bool task_geometry(const Bc7Args& a, uint32_t nb, uint32_t r, uint32_t& shape, uint32_t& mask, uint32_t& anchor, uint32_t& rot)
@@ -189,9 +224,12 @@ __device__ __forceinline__ bool task_geometry(const Bc7Args& a, uint32_t nb, uin
     typedef TaskMap<MODE, IM> TM;
     shape = 0; mask = 0xFFFFu; anchor = 0; rot = 0;
     if (nb >= a.nblocks) return false;
-    if (a.done[nb]) return false;          // fMSEBest == 0: the reference skips every remaining mode and candidate
-    if (TM::NS == 1) { rot = (MODE == 6) ? 0u : r; return true; }
+    if (!phase_owns<MODE>(a, nb)) return false;
     const uint32_t rank = r / TM::G, region = r % TM::G;
+    // fMSEBest == 0: the reference returns from Encode, i.e. skips every candidate that comes later in ITS order. The modes
+    // may run in any order here, so the comparison is on the evaluation-order key, not on "some mode is done".
+    if (a.zeroOrd[nb] < candidate_ord<MODE, IM>(rank)) return false;
+    if (TM::NS == 1) { rot = (MODE == 6) ? 0u : r; return true; }
     if (region >= uint32_t(TM::NS)) return false;
     const uint8_t* lst = a.lists + uint64_t(nb) * LIST_BYTES;
     if (MODE == 7 && lst[32] == 0) return false;
@@ -277,22 +315,58 @@ __global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nbFirst = (blockIdx.x * 4 + wave) * BPW;
     if (nbFirst >= a.nblocks) return;
-    stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
-
     const uint32_t blk = uint32_t(lane) / TM::TPB, r = uint32_t(lane) % TM::TPB;
     const uint32_t nb = nbFirst + blk;
     uint32_t shape, mask, anchor, rot;
     const bool active = (blk < uint32_t(BPW)) && task_geometry<MODE, IM>(a, nb, r, shape, mask, anchor, rot);
+    TaskRec rec; rec.A = 0; rec.B = 0; rec.err = 0; rec.np = 0;
+    if (!__any(active))
+    {
+        // nothing to do for these blocks (another phase owns them, mode 7 on opaque blocks, Encode already returned): the task
+        // list still needs their size-0 entries
+        if (nb < a.nblocks && blk < uint32_t(BPW))
+        {
+            a.recs[uint64_t(nb) * TM::TPB + r] = rec;
+            a.tinfo[uint64_t(nb) * TM::TPB + r] = 0;
+        }
+        return;
+    }
+    stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
+    int lb = 0;
+    if (active)
+    {
+        SubsetResult res; int np; Region rg; Block16 b16;
+        task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16);
+        rec.A = res.orgA; rec.B = res.orgB; rec.err = res.orgErr;
+        rec.np = (res.orgErr != 0) ? uint32_t(np) : 0u;        // error 0: OptimizeOne cannot move the endpoints
+        if (a.prune && rec.np)
+        {
+            lb = subset_lower_bound(&sL[wave][blk * 16], mask, rot, (MODE >= 6) ? 4 : 3);
+            if (MODE < 4)
+            {
+                // colour-only modes decode alpha as 255 (Unquantize, :841), whatever the indices: that part of the error is exact
+                const uint32_t* pix = &sL[wave][blk * 16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) if ((mask >> i) & 1u) { const int da = 255 - int(pix[i] >> 24); lb += da * da; }
+            }
+        }
+    }
+    if (a.prune)
+    {
+        // Exact pruning (bc7_core.h, subset_lower_bound): a candidate whose lower bound exceeds an error that is already on the
+        // table for this block - the unoptimised error of another candidate of this mode, or the result of a finished mode -
+        // cannot become Encode's first minimum; its subsets keep their seed endpoints and are not searched.
+        int candOrg = active ? rec.err : 0, candLb = lb;
+#pragma unroll
+        for (int d = 1; d < TM::G; d <<= 1) { candOrg += __shfl_xor(candOrg, d); candLb += __shfl_xor(candLb, d); }
+        int table = active ? candOrg : 0x7FFFFFFF;
+#pragma unroll
+        for (int d = TM::G; d < TM::TPB && d < 64; d <<= 1) table = min(table, __shfl_xor(table, d));
+        if (nb < a.nblocks && blk < uint32_t(BPW)) table = min(table, a.bestErr[nb]);
+        if (candLb > table) rec.np = 0;
+    }
     if (nb < a.nblocks && blk < uint32_t(BPW))
     {
-        TaskRec rec; rec.A = 0; rec.B = 0; rec.err = 0; rec.np = 0;
-        if (active)
-        {
-            SubsetResult res; int np; Region rg; Block16 b16;
-            task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16);
-            rec.A = res.orgA; rec.B = res.orgB; rec.err = res.orgErr;
-            rec.np = (res.orgErr != 0) ? uint32_t(np) : 0u;        // error 0: OptimizeOne cannot move the endpoints
-        }
         a.recs[uint64_t(nb) * TM::TPB + r] = rec;
         a.tinfo[uint64_t(nb) * TM::TPB + r] = (mask & 0xFFFFu) | (rot << 16) | (rec.np << 24);
     }
@@ -455,13 +529,22 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nbFirst = (blockIdx.x * 4 + wave) * BPW;
     if (nbFirst >= a.nblocks) return;
-    stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
-
     const uint32_t blk = uint32_t(lane) / TM::TPB, r = uint32_t(lane) % TM::TPB;
     const uint32_t nb = nbFirst + blk;
     const uint32_t rank = r / TM::G, region = r % TM::G;
     uint32_t shape, mask, anchor, rot;
     const bool active = (blk < uint32_t(BPW)) && task_geometry<MODE, IM>(a, nb, r, shape, mask, anchor, rot);
+    const bool mine = blk < uint32_t(BPW) && nb < a.nblocks && phase_owns<MODE>(a, nb);
+    if (!__any(active))
+    {
+        if (mine && r == 0)
+        {
+            Cand c; c.err = 0xFFFFFFFFu; c.ord = 0xFFFFFFFFu; c.lo = 0; c.hi = 0;
+            a.cands[uint64_t(nb) * NUM_SLOTS + TM::SLOT] = c;
+        }
+        return;
+    }
+    stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
 
     SubsetResult res;
     res.orgErr = 0; res.optErr = 0; res.orgA = res.orgB = res.optA = res.optB = 0;
@@ -495,7 +578,7 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
         idx1 |= oi;
     }
     // evaluation order inside D3DX_BC7::Encode: modes ascending, then rotation, index mode, shape rank
-    const uint32_t sub = (TM::NS == 1) ? ((MODE == 4) ? (rank * 2 + IM) * 16u : rank * 16u) : rank;
+    const uint32_t sub = candidate_sub<MODE, IM>(rank);
     const uint32_t key = active ? ((uint32_t(err) << 7) | sub) : 0xFFFFFFFFu;
     uint32_t best = key;
 #pragma unroll
@@ -513,9 +596,10 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
             c.ord = uint32_t(MODE) * 128u + sub;
             emit_block<MODE>(shape, rot, IM, epA, epB, idx1, myIdx2, anchors, c.lo, c.hi);
             a.cands[uint64_t(nb) * NUM_SLOTS + TM::SLOT] = c;
-            if (err == 0) a.done[nb] = 1;
+            if (err == 0 && c.ord < a.zeroOrd[nb]) a.zeroOrd[nb] = c.ord;
+            if (err < a.bestErr[nb]) a.bestErr[nb] = err;
         }
-        else if (!active && rank == 0)
+        else if (!active && rank == 0 && mine)
         {
             Cand c; c.err = 0xFFFFFFFFu; c.ord = 0xFFFFFFFFu; c.lo = 0; c.hi = 0;
             a.cands[uint64_t(nb) * NUM_SLOTS + TM::SLOT] = c;
@@ -532,7 +616,7 @@ __global__ void __launch_bounds__(256) bc7_texels_kernel(Bc7Args a)
     const BcSeg& sg = seg_of(a.seg, i >> 4);
     load_block_texel(sg.src, sg.nbw, sg.nb0 + ((i >> 4) - sg.l0), i & 15u, f4, ldr);
     a.px[i] = ldr;
-    if ((i & 15u) == 0) a.done[i >> 4] = 0;
+    if ((i & 15u) == 0) { a.zeroOrd[i >> 4] = 0xFFFFFFFFu; a.bestErr[i >> 4] = 0x7FFFFFFF; }
 }
 
 // ---- pick: first minimum over the per-mode winners, in D3DX_BC7::Encode's order -----------------------------------
@@ -568,7 +652,7 @@ const uint64_t kMaxBlocksPerPass = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::ma
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
 struct ScratchLayout
 {
-    size_t lists, cands, px, recs, order, tinfo, counters, done, total;
+    size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, total;
     explicit ScratchLayout(uint64_t nb, bool threeSubsets)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -581,7 +665,8 @@ struct ScratchLayout
         order = o; o = up(o + nb * tpb * sizeof(uint2));
         tinfo = o; o = up(o + nb * tpb * sizeof(uint32_t));
         counters = o; o = up(o + 64 * sizeof(uint32_t));
-        done = o; o = up(o + nb);
+        zeroOrd = o; o = up(o + nb * sizeof(uint32_t));
+        bestErr = o; o = up(o + nb * sizeof(int));
         total = o;
     }
 };
@@ -671,41 +756,69 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         a.order = reinterpret_cast<uint2*>(base + L.order);
         a.tinfo = reinterpret_cast<uint32_t*>(base + L.tinfo);
         a.counters = reinterpret_cast<uint32_t*>(base + L.counters);
-        a.done = base + L.done;
+        a.zeroOrd = reinterpret_cast<uint32_t*>(base + L.zeroOrd);
+        a.bestErr = reinterpret_cast<int*>(base + L.bestErr);
+        static const bool noPrune = getenv("DXTEX_BC7_NO_PRUNE") != nullptr;
+        a.prune = noPrune ? 0 : 1;
+        static const int early6 = getenv("DXTEX_BC7_EARLY6_PCT") ? atoi(getenv("DXTEX_BC7_EARLY6_PCT")) : 100;
+        a.early6Pct = early6;
         uint32_t slotMask = 0;
 
         if (!quick)
         {
             DXTEX_MARK("bc7_rough");
             hipLaunchKernelGGL(bc7_rough_kernel, dim3((a.nblocks + 3) / 4), dim3(256), 0, stream, a);
-            if (three)
-            {
-                DXTEX_MODE(0, 0, "mode0");
-                slotMask |= 1u << SLOT_M0;
-            }
-            DXTEX_MODE(1, 0, "mode1");
-            if (three)
-            {
-                DXTEX_MODE(2, 0, "mode2");
-                slotMask |= 1u << SLOT_M2;
-            }
-            DXTEX_MODE(3, 0, "mode3");
-            DXTEX_MODE(4, 0, "mode4_im0");
-            DXTEX_MODE(4, 1, "mode4_im1");
-            DXTEX_MODE(5, 0, "mode5");
-            slotMask |= (1u << SLOT_M1) | (1u << SLOT_M3) | (1u << SLOT_M4A) | (1u << SLOT_M4B) | (1u << SLOT_M5);
         }
         else
         {
             DXTEX_MARK("bc7_texels");
             hipLaunchKernelGGL(bc7_texels_kernel, dim3((a.nblocks * 16 + 255) / 256), dim3(256), 0, stream, a);
         }
-        DXTEX_MODE(6, 0, "mode6");
-        slotMask |= (1u << SLOT_M6);
-        if (!quick)
+        // The modes are independent until `pick` (which restores Encode's order through the candidates' keys), so they may run
+        // in any order; what the order changes is how early a good error is on the table for subset_lower_bound to prune with.
+        // Step codes: mode number (8 = mode 4 with index mode 1), +10 = the early half of a split mode, +20 = its late half.
+        // Default: mode 6 for the blocks the rough pass flagged, then the alpha-carrying modes for blocks that have alpha, then
+        // the reference's order for everything else. With BC7_QUICK only mode 6 exists and nothing is split.
+        static const std::vector<int> order = []
         {
-            DXTEX_MODE(7, 0, "mode7");
-            slotMask |= (1u << SLOT_M7);
+            std::vector<int> o;
+            const char* e = getenv("DXTEX_BC7_ORDER");
+            const char* p = e ? e : "16,7,14,18,15,0,1,2,3,24,28,25,26";
+            while (*p)
+            {
+                if (*p >= '0' && *p <= '9') { o.push_back(int(strtol(p, const_cast<char**>(&p), 10))); }
+                else ++p;
+            }
+            return o;
+        }();
+        a.phase = PHASE_ALL;
+        if (quick) { DXTEX_MODE(6, 0, "mode6"); slotMask |= 1u << SLOT_M6; }
+        for (const int step : order)
+        {
+            if (quick) break;
+            if (!three && (step == 0 || step == 2)) continue;
+            a.phase = (step >= 20) ? PHASE_LATE : (step >= 10) ? PHASE_EARLY : PHASE_ALL;
+            switch (step)
+            {
+            case 0: DXTEX_MODE(0, 0, "mode0"); slotMask |= 1u << SLOT_M0; break;
+            case 1: DXTEX_MODE(1, 0, "mode1"); slotMask |= 1u << SLOT_M1; break;
+            case 2: DXTEX_MODE(2, 0, "mode2"); slotMask |= 1u << SLOT_M2; break;
+            case 3: DXTEX_MODE(3, 0, "mode3"); slotMask |= 1u << SLOT_M3; break;
+            case 4: DXTEX_MODE(4, 0, "mode4_im0"); slotMask |= 1u << SLOT_M4A; break;
+            case 14: DXTEX_MODE(4, 0, "mode4_im0_early"); slotMask |= 1u << SLOT_M4A; break;
+            case 24: DXTEX_MODE(4, 0, "mode4_im0_late"); slotMask |= 1u << SLOT_M4A; break;
+            case 8: DXTEX_MODE(4, 1, "mode4_im1"); slotMask |= 1u << SLOT_M4B; break;
+            case 18: DXTEX_MODE(4, 1, "mode4_im1_early"); slotMask |= 1u << SLOT_M4B; break;
+            case 28: DXTEX_MODE(4, 1, "mode4_im1_late"); slotMask |= 1u << SLOT_M4B; break;
+            case 5: DXTEX_MODE(5, 0, "mode5"); slotMask |= 1u << SLOT_M5; break;
+            case 15: DXTEX_MODE(5, 0, "mode5_early"); slotMask |= 1u << SLOT_M5; break;
+            case 25: DXTEX_MODE(5, 0, "mode5_late"); slotMask |= 1u << SLOT_M5; break;
+            case 6: DXTEX_MODE(6, 0, "mode6"); slotMask |= 1u << SLOT_M6; break;
+            case 16: DXTEX_MODE(6, 0, "mode6_early"); slotMask |= 1u << SLOT_M6; break;
+            case 26: DXTEX_MODE(6, 0, "mode6_late"); slotMask |= 1u << SLOT_M6; break;
+            case 7: DXTEX_MODE(7, 0, "mode7"); slotMask |= 1u << SLOT_M7; break;
+            default: break;
+            }
         }
         DXTEX_MARK("bc7_pick");
         hipLaunchKernelGGL(bc7_pick_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, stream, a, slotMask);
