@@ -335,6 +335,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a)
     const int lane = threadIdx.x;
     const bool sg = a.isSigned != 0;
     const uint32_t live = a.counters[34];
+    if (live == 0) return;
     uint32_t* head = a.counters + kQueueBase;
     float* slot = &sSlot[lane];
     const int TPB = (N == 8) ? 16 : 1;

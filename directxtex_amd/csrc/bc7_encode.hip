@@ -406,6 +406,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
     __shared__ uint32_t sSlot[16 * 64];
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
+    if (live == 0) return;           // nothing survived pre (a phase that owns no block, everything pruned): skip the queue atomics
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
 
@@ -460,6 +461,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
     __shared__ uint32_t sSlot[16 * 64];
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
+    if (live == 0) return;           // nothing survived pre (a phase that owns no block, everything pruned): skip the queue atomics
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
 
