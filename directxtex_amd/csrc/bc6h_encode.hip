@@ -42,6 +42,7 @@ struct Bc6hArgs
     SegTable seg;           // the images behind this pass (search_common.h)
     uint32_t nblocks;       // blocks in this pass; scratch arrays are indexed by pass-local block number
     int isSigned;
+    int prune;              // 0 = search every candidate like the reference does (DXTEX_BC6H_NO_PRUNE, for A/B runs)
     float* fpix;            // nblocks x 3 x 16: the block's texels as INTColor values held in floats (r[16], g[16], b[16])
     uint8_t* lists;         // nblocks x 8 shape ids
     int* seeds;             // nblocks x SEED_INTS
@@ -168,6 +169,52 @@ __global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
 // Lane layout of pre / post: two-region modes use 16 lanes per block (rank * 2 + region), one-region modes 1 lane.
 template<int REGIONS2> struct Lay6 { enum : int { TPB = REGIONS2 ? 16 : 1, N = REGIONS2 ? 8 : 16, BPW = 64 / TPB }; };
 
+// ---- exact pruning (same argument as bc7_core.h, subset_lower_bound) ---------------------------------------------------------------
+// A BC6H palette entry is FinishUnquantize(((64 - w) A + w B + 32) >> 6) per channel (:1930-1940, :2044-2077): within 1.5 of a
+// point on the real line through the scaled unquantised endpoints, so within 1.5 sqrt(3) in distance. Hence for ANY endpoints
+//     sum_t |texel_t - palette(t)|^2  >=  ( sqrt(tr S - lambda_max(S)) - 3 sqrt(n) )^2     when the bracket is positive,
+// S the 3x3 scatter matrix of the region's texels (INTColor values). lambda_max is bounded from above by ||N^16||_F^(1/16),
+// N = S / tr S. A candidate (mode, shape) whose bound exceeds the block's running best can never pass Refine's
+// "fOptErr < fBestErr" / "fOrgErr < fBestErr" tests (:2412-2424), so it is not searched. The reference accumulates its errors
+// in fp32; the margin below is far wider than that rounding.
+__device__ __forceinline__ float region_lower_bound6(const float* planes, uint32_t mask)
+{
+    double n = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, q00 = 0.0, q01 = 0.0, q02 = 0.0, q11 = 0.0, q12 = 0.0, q22 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if ((mask >> i) & 1u)
+        {
+            const double x = planes[i], y = planes[16 + i], z = planes[32 + i];       // exact integers
+            n += 1.0; s0 += x; s1 += y; s2 += z;
+            q00 += x * x; q01 += x * y; q02 += x * z; q11 += y * y; q12 += y * z; q22 += z * z;
+        }
+    if (n < 2.0) return 0.0f;
+    // M = n * S (exact in double: |entries| < 2^53)
+    const double M00 = n * q00 - s0 * s0, M01 = n * q01 - s0 * s1, M02 = n * q02 - s0 * s2, M11 = n * q11 - s1 * s1, M12 = n * q12 - s1 * s2, M22 = n * q22 - s2 * s2;
+    const double T = M00 + M11 + M22;
+    if (!(T > 0.0)) return 0.0f;
+    const double inv = 1.0 / T;
+    double a00 = M00 * inv, a01 = M01 * inv, a02 = M02 * inv, a11 = M11 * inv, a12 = M12 * inv, a22 = M22 * inv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+        const double b00 = a00 * a00 + a01 * a01 + a02 * a02;
+        const double b01 = a00 * a01 + a01 * a11 + a02 * a12;
+        const double b02 = a00 * a02 + a01 * a12 + a02 * a22;
+        const double b11 = a01 * a01 + a11 * a11 + a12 * a12;
+        const double b12 = a01 * a02 + a11 * a12 + a12 * a22;
+        const double b22 = a02 * a02 + a12 * a12 + a22 * a22;
+        a00 = b00; a01 = b01; a02 = b02; a11 = b11; a12 = b12; a22 = b22;
+    }
+    const double f2 = a00 * a00 + a11 * a11 + a22 * a22 + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12);
+    const double lam = sqrt(sqrt(sqrt(sqrt(sqrt(f2))))) * (1.0 + 1e-9);
+    if (lam >= 1.0) return 0.0f;
+    const double resid = T * (1.0 - lam) / n;
+    const double d = sqrt(resid) - 3.0 * sqrt(n) - 1e-3;
+    if (d <= 0.0) return 0.0f;
+    return float(d * d * 0.9999);
+}
+
 struct Org6
 {
     EndPts ep;              // quantised, anchor-fixed endpoints of this lane's region
@@ -227,6 +274,25 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
 #if defined(DXTEX_BC6H_TRACE)
     if (nb == 0 && a.mode.index == 0) printf("pre r %u shape %u fit %d A %d %d %d B %d %d %d | T A %d %d %d B %d %d %d err %.9g np %d tr %d delta %d %d %d\n", r, o.shape, int(o.fit), o.ep.A[0], o.ep.A[1], o.ep.A[2], o.ep.B[0], o.ep.B[1], o.ep.B[2], o.epT.A[0], o.epT.A[1], o.epT.A[2], o.epT.B[0], o.epT.B[1], o.epT.B[2], o.err, o.np, a.mode.transformed, a.mode.delta[0], a.mode.delta[1], a.mode.delta[2]);
 #endif
+    // exact pruning: the candidate's lower bound (over its PROPER regions - what Refine scores) against the running best
+    bool prune = false;
+    if (a.prune)
+    {
+        float lb = region_lower_bound6(planes, o.mask);
+        if (REGIONS2) lb += __shfl_xor(lb, 1);
+        // what is already on the table: the running best of the earlier modes and, within this mode, the unoptimised error of
+        // every candidate that fits (Refine emits at least that, :2412-2424)
+        float table = o.fit ? o.err : 3.0e38f;
+        if (REGIONS2)
+        {
+            const float pe = __shfl_xor(o.err, 1);
+            table = o.fit ? o.err + pe : 3.0e38f;
+#pragma unroll
+            for (int d = 2; d < 16; d <<= 1) table = fminf(table, __shfl_xor(table, d));
+        }
+        table = fminf(table * 1.00001f, a.best[nb].err);
+        prune = lb > table;
+    }
     if (!inRange) return;
     const uint64_t t = uint64_t(nb) * L::TPB + r;
     Rec6 rec;
@@ -238,7 +304,8 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
     // candidate does not fit or its error is already 0 (PerturbOne only accepts strictly smaller errors).
     const bool region0 = !REGIONS2 || (r & 1u) == 0;
     const uint32_t smask = region0 ? 0xFFFFu : o.mask;
-    const uint32_t snp = (o.fit && o.err > 0.0f) ? uint32_t(region0 ? 16 : o.np) : 0u;
+    uint32_t snp = (o.fit && o.err > 0.0f) ? uint32_t(region0 ? 16 : o.np) : 0u;
+    if (prune) snp = 0;
     a.tinfo[t] = smask | (snp << 24);
 }
 
@@ -453,6 +520,8 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         set_pass(a.seg, dSegs, segs, pass);
         a.nblocks = pass.nblocks;
         a.isSigned = isSigned ? 1 : 0;
+        static const bool noPrune = getenv("DXTEX_BC6H_NO_PRUNE") != nullptr;
+        a.prune = noPrune ? 0 : 1;
         a.fpix = reinterpret_cast<float*>(base + L.fpix);
         a.lists = base + L.lists;
         a.seeds = reinterpret_cast<int*>(base + L.seeds);

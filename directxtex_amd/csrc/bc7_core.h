@@ -1302,6 +1302,66 @@ DXTEX_HD int subset_lower_bound(const uint32_t* pix, uint32_t mask16, uint32_t r
     return (lb > 0.0) ? int(lb) : 0;
 }
 
+// The separate-alpha modes (4, 5) give the fourth slot of the (rotated) texel a scalar palette of K = 2^bits entries of its own.
+// Whatever those K values are, the slot's error over the 16 texels is at least the optimum of 1-D K-means on the 16 values:
+// exact dynamic programme over the sorted values (clusters are runs), D_k(j) = min_i D_{k-1}(i-1) + SSE(i..j), fully unrolled
+// so that every array index is a constant. fp32 with a downward margin (values <= 16 * 255^2).
+template<int K>
+DXTEX_HD int scalar_kmeans_lower_bound(const uint32_t* pix, uint32_t rot)
+{
+    int v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = int(rotate_pixel(pix[i], rot) >> 24);
+    // bitonic sorting network, ascending
+#pragma unroll
+    for (int k = 2; k <= 16; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+            {
+                const int l = i ^ j;
+                if (l > i)
+                {
+                    const int lo = (v[i] < v[l]) ? v[i] : v[l], hi = (v[i] < v[l]) ? v[l] : v[i];
+                    if ((i & k) == 0) { v[i] = lo; v[l] = hi; } else { v[i] = hi; v[l] = lo; }
+                }
+            }
+    if (v[0] == v[15]) return 0;
+    float s1[17], s2[17];
+    s1[0] = 0.0f; s2[0] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s1[i + 1] = s1[i] + float(v[i]); s2[i + 1] = s2[i] + float(v[i] * v[i]); }      // exact: < 2^24
+    float d[16], e[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const float m = s1[j + 1]; d[j] = s2[j + 1] - m * m * (1.0f / float(j + 1)); }
+#pragma unroll
+    for (int k = 2; k <= K; ++k)
+    {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+        {
+            float best = (j < k) ? 0.0f : 3.0e38f;          // at most k points: one cluster each
+            if (j >= k)
+            {
+#pragma unroll
+                for (int i = k - 1; i <= j; ++i)
+                {
+                    const float m = s1[j + 1] - s1[i];
+                    const float c = (s2[j + 1] - s2[i]) - m * m * (1.0f / float(j - i + 1));
+                    const float t = d[i - 1] + ((c > 0.0f) ? c : 0.0f);
+                    best = (t < best) ? t : best;
+                }
+            }
+            e[j] = best;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d[j] = e[j];
+    }
+    const float lb = d[15] * 0.9999f - 4.0f;
+    return (lb > 0.0f) ? int(lb) : 0;
+}
+
 // eps[s] = (A, B) of subset s in RGBAPrecWithP units; idx1/idx2 = 4 bits per texel position;
 // anchors = texel positions of the subset anchors (anchor[0] == 0).
 template<int MODE>

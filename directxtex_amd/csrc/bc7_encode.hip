@@ -217,6 +217,8 @@ __device__ __forceinline__ bool phase_owns(const Bc7Args& a, uint32_t nb)
     return early == (a.phase == PHASE_EARLY);
 }
 
+__device__ __forceinline__ bool lst_has_alpha(const Bc7Args& a, uint32_t nb) { return a.lists[uint64_t(nb) * LIST_BYTES + 32] != 0; }
+
 // Texel mask, anchor and rotation of task `r` (= t % TPB) of block `nb`; false if the task does not exist.
 template<int MODE, int IM>
 __device__ __forceinline__ bool task_geometry(const Bc7Args& a, uint32_t nb, uint32_t r, uint32_t& shape, uint32_t& mask, uint32_t& anchor, uint32_t& rot)
@@ -342,6 +344,12 @@ __global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
         if (a.prune && rec.np)
         {
             lb = subset_lower_bound(&sL[wave][blk * 16], mask, rot, (MODE >= 6) ? 4 : 3);
+            if (MODE == 4 || MODE == 5)
+            {
+                // the scalar slot: 3-bit indices for mode 4 with index mode 0, 2-bit otherwise
+                if (rot != 0 || lst_has_alpha(a, nb))
+                    lb += scalar_kmeans_lower_bound<(MODE == 4 && IM == 0) ? 8 : 4>(&sL[wave][blk * 16], rot);
+            }
             if (MODE < 4)
             {
                 // colour-only modes decode alpha as 255 (Unquantize, :841), whatever the indices: that part of the error is exact
