@@ -148,3 +148,35 @@ def test_array_goes_through_one_block_list(oracle, pass_blocks):
         env["DXTEX_MAX_BLOCKS_PER_PASS"] = pass_blocks
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "array OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_pruning_changes_nothing():
+    """subset_lower_bound / region_lower_bound6 only drop candidates that cannot win: the payloads with pruning (default) and
+    without (DXTEX_BC7_NO_PRUNE / DXTEX_BC6H_NO_PRUNE) must be the same bytes, and so must any legal order of the modes."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, hashlib; sys.path.insert(0, %r)
+        import numpy as np, directxtex_amd as dx
+        from directxtex_amd import synth
+        c = dx.Context(0)
+        yy, xx = np.mgrid[0:256, 0:256]
+        smooth = np.stack([xx, yy, (xx + yy) // 2, 255 - xx // 2], -1).astype(np.uint8)
+        imgs = [synth.rgba8(384, 256, seed=21, alpha="opaque"), synth.rgba8(256, 256, seed=22, alpha="smooth"), synth.rgba8(256, 256, seed=23, alpha="binary"),
+                smooth, np.random.default_rng(5).integers(0, 256, (128, 128, 4), dtype=np.uint8)]
+        for im in imgs:
+            h, w = im.shape[:2]
+            for flags in (0, 0x80000):
+                print(hashlib.sha256(c.compress(im, w, h, 28, 98, flags, 0.5).tobytes()).hexdigest())
+            hdr = (im.astype(np.float32) / 255 * 7 - (2 if flags else 0)).astype(np.float16)
+            for fmt in (95, 96):
+                print(hashlib.sha256(c.compress(hdr, w, h, 10, fmt, 0, 0.5).tobytes()).hexdigest())
+    """ % root)
+    outs = []
+    for env in ({}, {"DXTEX_BC7_NO_PRUNE": "1", "DXTEX_BC6H_NO_PRUNE": "1"}, {"DXTEX_BC7_ORDER": "7,6,5,8,4,3,2,1,0"}, {"DXTEX_BC7_ORDER": "26,25,3,1,16,7,15,14,18,24,28,0,2"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.split())
+    assert len(outs[0]) == 20
+    for o in outs[1:]:
+        assert o == outs[0]
