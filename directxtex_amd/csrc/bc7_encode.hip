@@ -45,6 +45,7 @@ struct Bc7Args
     uint32_t* counters;      // 35 words, see bc7_bin_* kernels
     uint32_t* zeroOrd;       // per block: evaluation-order key of the first candidate (in Encode's order) known to reach error 0;
                              // Encode() returns there (:2803, :2835, :2845), so later candidates are never looked at
+    uint2* seeds;            // per block 64 shapes x 2 subsets: the float-fit endpoints RoughMSE derives (:3526-3552), reused by Refine
     int* bestErr;            // per block: smallest error an already finished mode reached (subset_lower_bound prunes against it)
     int prune;               // 0 = search every candidate like the reference does (DXTEX_BC7_NO_PRUNE, for A/B runs)
     int early6Pct;           // rough kernel: mode 6 goes first where 100 * lower bound <= early6Pct * best 3-bit rough error
@@ -113,6 +114,7 @@ __global__ void __launch_bounds__(256) bc7_rough_kernel(Bc7Args a)
             if (rg.np == 1) { A = pix[rg.pos(0)]; B = A; }
             else if (rg.np == 2) { A = pix[rg.pos(0)]; B = pix[rg.pos(1)]; }
             else seed_endpoints<true>(fpx, m, A, B);
+            a.seeds[uint64_t(nb) * 128 + shape * 2 + r] = make_uint2(A, B);      // Refine starts from the same fit (:3411-3417)
             e3 += rough_error<3, 0>(rg, A, B);
             e2 += rough_error<2, 0>(rg, A, B);
         }
@@ -256,7 +258,7 @@ __device__ __forceinline__ bool task_geometry(const Bc7Args& a, uint32_t nb, uin
 // Refine's first half for one task, from the block's float + 8-bit texels (LDS or registers).
 template<int MODE, int IM>
 __device__ __forceinline__ void task_org(const float* fpx, const uint32_t* pix, uint32_t mask, uint32_t anchor, uint32_t rot,
-                                         SubsetResult& res, int& np, bool wantRegion, Region& rgOut, Block16& b16Out)
+                                         SubsetResult& res, int& np, bool wantRegion, Region& rgOut, Block16& b16Out, const uint2* seed = nullptr)
 {
     typedef TaskMap<MODE, IM> TM;
     if (TM::NS == 1)
@@ -281,7 +283,8 @@ __device__ __forceinline__ void task_org(const float* fpx, const uint32_t* pix, 
     {
         region_init(rgOut, pix, mask);
         uint32_t A, B;
-        if (rgOut.np == 1) { A = pix[rgOut.pos(0)]; B = A; }
+        if (seed) { const uint2 sd = *seed; A = sd.x; B = sd.y; }          // the rough pass already fitted this subset
+        else if (rgOut.np == 1) { A = pix[rgOut.pos(0)]; B = A; }
         else if (rgOut.np == 2) { A = pix[rgOut.pos(0)]; B = pix[rgOut.pos(1)]; }
         else seed_endpoints<true>(fpx, mask, A, B);
         refine_pre<MODE, IM>(rgOut, A, B, anchor, res);
@@ -303,6 +306,18 @@ __device__ __forceinline__ void stage_blocks(const Bc7Args& a, uint32_t nbFirst,
             load_block_texel(sg.src, sg.nbw, sg.nb0 + (nb - sg.l0), t & 15, &sF[(t >> 4) * 64 + (t & 15) * 4], ldr);
         }
         sL[t] = ldr;
+    }
+    wave_lds_sync();
+}
+
+// The two-subset modes need no float texels once the fits are stored: their 8-bit texels come from the pass's scratch.
+template<int BPW>
+__device__ __forceinline__ void stage_packed(const Bc7Args& a, uint32_t nbFirst, int lane, uint32_t* sL)
+{
+    for (int t = lane; t < BPW * 16; t += 64)
+    {
+        const uint32_t nb = nbFirst + (uint32_t(t) >> 4);
+        sL[t] = (nb < a.nblocks) ? a.px[uint64_t(nb) * 16 + (t & 15)] : 0u;
     }
     wave_lds_sync();
 }
@@ -333,12 +348,14 @@ __global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
         }
         return;
     }
-    stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
+    if constexpr (TM::NS == 2) stage_packed<BPW>(a, nbFirst, lane, sL[wave]);
+    else stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
     int lb = 0;
     if (active)
     {
         SubsetResult res; int np; Region rg; Block16 b16;
-        task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16);
+        task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
+                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G) : nullptr);
         rec.A = res.orgA; rec.B = res.orgB; rec.err = res.orgErr;
         rec.np = (res.orgErr != 0) ? uint32_t(np) : 0u;        // error 0: OptimizeOne cannot move the endpoints
         if (a.prune && rec.np)
@@ -554,7 +571,8 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
         }
         return;
     }
-    stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
+    if constexpr (TM::NS == 2) stage_packed<BPW>(a, nbFirst, lane, sL[wave]);
+    else stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
 
     SubsetResult res;
     res.orgErr = 0; res.optErr = 0; res.orgA = res.orgB = res.optA = res.optB = 0;
@@ -562,7 +580,8 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
     if (active)
     {
         int np; Region rg; Block16 b16;
-        task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16);
+        task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
+                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G) : nullptr);
         const TaskRec rec = a.recs[uint64_t(nb) * TM::TPB + r];
         if (TM::NS == 1) refine_post<MODE, IM>(b16, rec.A, rec.B, 0u, res);
         else refine_post<MODE, IM>(rg, rec.A, rec.B, anchor, res);
@@ -662,7 +681,7 @@ const uint64_t kMaxBlocksPerPass = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::ma
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
 struct ScratchLayout
 {
-    size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, total;
+    size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, seeds, total;
     explicit ScratchLayout(uint64_t nb, bool threeSubsets)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -677,6 +696,7 @@ struct ScratchLayout
         counters = o; o = up(o + 64 * sizeof(uint32_t));
         zeroOrd = o; o = up(o + nb * sizeof(uint32_t));
         bestErr = o; o = up(o + nb * sizeof(int));
+        seeds = o; o = up(o + nb * 128 * sizeof(uint2));
         total = o;
     }
 };
@@ -768,6 +788,7 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         a.counters = reinterpret_cast<uint32_t*>(base + L.counters);
         a.zeroOrd = reinterpret_cast<uint32_t*>(base + L.zeroOrd);
         a.bestErr = reinterpret_cast<int*>(base + L.bestErr);
+        a.seeds = reinterpret_cast<uint2*>(base + L.seeds);
         static const bool noPrune = getenv("DXTEX_BC7_NO_PRUNE") != nullptr;
         a.prune = noPrune ? 0 : 1;
         static const int early6 = getenv("DXTEX_BC7_EARLY6_PCT") ? atoi(getenv("DXTEX_BC7_EARLY6_PCT")) : 100;
