@@ -45,6 +45,7 @@ struct Bc7Args
     uint32_t* counters;      // 35 words, see bc7_bin_* kernels
     uint32_t* zeroOrd;       // per block: evaluation-order key of the first candidate (in Encode's order) known to reach error 0;
                              // Encode() returns there (:2803, :2835, :2845), so later candidates are never looked at
+    uint2* seeds1;           // per block: the whole-block RGB fit (modes 4, 5) and RGBA fit (mode 6), :3541-3568
     uint2* seeds;            // per block 64 shapes x 2 subsets: the float-fit endpoints RoughMSE derives (:3526-3552), reused by Refine
     int* bestErr;            // per block: smallest error an already finished mode reached (subset_lower_bound prunes against it)
     int prune;               // 0 = search every candidate like the reference does (DXTEX_BC7_NO_PRUNE, for A/B runs)
@@ -105,9 +106,13 @@ __global__ void __launch_bounds__(256) bc7_rough_kernel(Bc7Args a)
         const uint32_t shape = lane;
         const uint32_t m1 = kPart2Mask[shape], m0 = (~m1) & 0xFFFFu;
         int e3 = 0, e2 = 0;
+        // every lane takes its LARGER subset first: the trip counts of a wavefront are then max(larger) + max(smaller) <= 15 + 8
+        // instead of max(subset 0) + max(subset 1) ~ 29 (the error sums are integers, their order is free)
+        const int big = (__popc(m1) > __popc(m0)) ? 1 : 0;
 #pragma unroll 1
-        for (int r = 0; r < 2; ++r)
+        for (int k = 0; k < 2; ++k)
         {
+            const int r = k ^ big;
             const uint32_t m = r ? m1 : m0;
             Region rg; region_init(rg, pix, m);
             uint32_t A, B;
@@ -265,11 +270,12 @@ __device__ __forceinline__ void task_org(const float* fpx, const uint32_t* pix, 
     {
         block16_init(b16Out, pix, rot);
         uint32_t A, B;
-        if (MODE == 6) seed_endpoints<true>(fpx, 0xFFFFu, A, B);
-        else
+        if (seed) { const uint2 sd = seed[(MODE == 6) ? 1 : 0]; A = sd.x; B = sd.y; }     // bc7_block_seeds_kernel fitted the block once
+        else if (MODE == 6) seed_endpoints<true>(fpx, 0xFFFFu, A, B);
+        else seed_endpoints<false>(fpx, 0xFFFFu, A, B);
+        if (MODE != 6)
         {
             // colour endpoints from the *unrotated* float texels, alpha endpoints = min/max of the rotated 8-bit alpha (:3552-3568)
-            seed_endpoints<false>(fpx, 0xFFFFu, A, B);
             uint32_t mn = 255, mx = 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { const uint32_t al = b16Out.px[i] >> 24; mn = min(mn, al); mx = max(mx, al); }
@@ -348,14 +354,14 @@ __global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
         }
         return;
     }
-    if constexpr (TM::NS == 2) stage_packed<BPW>(a, nbFirst, lane, sL[wave]);
+    if constexpr (TM::NS != 3) stage_packed<BPW>(a, nbFirst, lane, sL[wave]);
     else stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
     int lb = 0;
     if (active)
     {
         SubsetResult res; int np; Region rg; Block16 b16;
         task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
-                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G) : nullptr);
+                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G) : (TM::NS == 1) ? a.seeds1 + uint64_t(nb) * 2 : nullptr);
         rec.A = res.orgA; rec.B = res.orgB; rec.err = res.orgErr;
         rec.np = (res.orgErr != 0) ? uint32_t(np) : 0u;        // error 0: OptimizeOne cannot move the endpoints
         if (a.prune && rec.np)
@@ -571,7 +577,7 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
         }
         return;
     }
-    if constexpr (TM::NS == 2) stage_packed<BPW>(a, nbFirst, lane, sL[wave]);
+    if constexpr (TM::NS != 3) stage_packed<BPW>(a, nbFirst, lane, sL[wave]);
     else stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
 
     SubsetResult res;
@@ -581,7 +587,7 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
     {
         int np; Region rg; Block16 b16;
         task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
-                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G) : nullptr);
+                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G) : (TM::NS == 1) ? a.seeds1 + uint64_t(nb) * 2 : nullptr);
         const TaskRec rec = a.recs[uint64_t(nb) * TM::TPB + r];
         if (TM::NS == 1) refine_post<MODE, IM>(b16, rec.A, rec.B, 0u, res);
         else refine_post<MODE, IM>(rg, rec.A, rec.B, anchor, res);
@@ -636,6 +642,23 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
     }
 }
 
+// The whole-block fits the single-subset modes start from (RoughMSE with one region, :3541-3568): RGB for modes 4 / 5 (every
+// rotation and index mode uses the same one - it is taken from the unrotated floats), RGBA for mode 6. One lane per block, one
+// launch per fit; the 16 texels sit in registers (FULL = constant trip counts).
+template<bool RGBA>
+__global__ void __launch_bounds__(256) bc7_block_seeds_kernel(Bc7Args a)
+{
+    const uint32_t nb = blockIdx.x * 256u + threadIdx.x;
+    if (nb >= a.nblocks) return;
+    const BcSeg& sg = seg_of(a.seg, nb);
+    float f[64];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { uint32_t ldr; load_block_texel(sg.src, sg.nbw, sg.nb0 + (nb - sg.l0), uint32_t(t), &f[t * 4], ldr); }
+    uint32_t A, B;
+    seed_endpoints<RGBA, true>(f, 0xFFFFu, A, B);
+    a.seeds1[uint64_t(nb) * 2 + (RGBA ? 1 : 0)] = make_uint2(A, B);
+}
+
 // BC7_QUICK skips the rough pass; the search kernels still need the packed texels.
 __global__ void __launch_bounds__(256) bc7_texels_kernel(Bc7Args a)
 {
@@ -681,7 +704,7 @@ const uint64_t kMaxBlocksPerPass = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::ma
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
 struct ScratchLayout
 {
-    size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, seeds, total;
+    size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, seeds, seeds1, total;
     explicit ScratchLayout(uint64_t nb, bool threeSubsets)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -697,6 +720,7 @@ struct ScratchLayout
         zeroOrd = o; o = up(o + nb * sizeof(uint32_t));
         bestErr = o; o = up(o + nb * sizeof(int));
         seeds = o; o = up(o + nb * 128 * sizeof(uint2));
+        seeds1 = o; o = up(o + nb * 2 * sizeof(uint2));
         total = o;
     }
 };
@@ -789,6 +813,7 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         a.zeroOrd = reinterpret_cast<uint32_t*>(base + L.zeroOrd);
         a.bestErr = reinterpret_cast<int*>(base + L.bestErr);
         a.seeds = reinterpret_cast<uint2*>(base + L.seeds);
+        a.seeds1 = reinterpret_cast<uint2*>(base + L.seeds1);
         static const bool noPrune = getenv("DXTEX_BC7_NO_PRUNE") != nullptr;
         a.prune = noPrune ? 0 : 1;
         static const int early6 = getenv("DXTEX_BC7_EARLY6_PCT") ? atoi(getenv("DXTEX_BC7_EARLY6_PCT")) : 100;
@@ -805,6 +830,9 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
             DXTEX_MARK("bc7_texels");
             hipLaunchKernelGGL(bc7_texels_kernel, dim3((a.nblocks * 16 + 255) / 256), dim3(256), 0, stream, a);
         }
+        DXTEX_MARK("bc7_block_seeds");
+        if (!quick) hipLaunchKernelGGL(bc7_block_seeds_kernel<false>, dim3((a.nblocks + 255) / 256), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(bc7_block_seeds_kernel<true>, dim3((a.nblocks + 255) / 256), dim3(256), 0, stream, a);
         // The modes are independent until `pick` (which restores Encode's order through the candidates' keys), so they may run
         // in any order; what the order changes is how early a good error is on the table for subset_lower_bound to prune with.
         // Step codes: mode number (8 = mode 4 with index mode 1), +10 = the early half of a split mode, +20 = its late half.
