@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/golden.json: outputs of THE REFERENCE (oracle/_ref: the reference's own sources compiled in place,
+see oracle/Makefile) on small seeded inputs, as SHA-256 digests plus the first bytes of every output. Run in the container that
+has /root/reference:   python tests/golden/make_golden.py
+tests/test_golden.py then checks (a) that oracle/_ref still reproduces these digests (CPU) and (b) that the HIP path does (GPU) -
+the second works on a box that has neither /root/reference nor oracle/_ref."""
+import hashlib, json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from directxtex_amd import synth
+
+RGBA8, RGBA8S, BGRA8, RGBA16F, RGBA32F = 28, 29, 87, 10, 2
+
+
+def inputs():
+    """name -> (array, width, height, format); everything derives from synth.rgba8 (pure numpy, seeded)."""
+    a = synth.rgba8(40, 28, seed=101, alpha="smooth")
+    b = synth.rgba8(32, 32, seed=102, alpha="opaque")
+    c = synth.rgba8(24, 16, seed=103, alpha="binary")
+    hdr = (synth.rgba8(32, 24, seed=104, alpha="opaque").astype(np.float32) / 255.0 * 9.0).astype(np.float16)
+    sgn = (synth.rgba8(16, 16, seed=105, alpha="opaque").astype(np.float32) / 255.0 * 6.0 - 3.0).astype(np.float16)
+    f32 = (synth.rgba8(20, 12, seed=106, alpha="smooth").astype(np.float32) / 255.0 * 1.5 - 0.25).astype(np.float32)
+    return {"a": (a, 40, 28, RGBA8), "b": (b, 32, 32, RGBA8), "c": (c, 24, 16, RGBA8), "hdr": (hdr, 32, 24, RGBA16F),
+            "sgn": (sgn, 16, 16, RGBA16F), "f32": (f32, 20, 12, RGBA32F)}
+
+
+def cases():
+    """(case id, kind, input name, parameters) - shared with tests/test_golden.py."""
+    out = []
+    for fmt in (71, 74, 77, 80, 81, 83, 84):
+        for flags in (0, 0x10000 | 0x20000, 0x40000):
+            out.append((f"compress/{fmt}/{flags:#x}/a", "compress", "a", {"dst": fmt, "flags": flags}))
+        out.append((f"compress/{fmt}/0/c", "compress", "c", {"dst": fmt, "flags": 0}))
+    for flags in (0, 0x100000, 0x80000):
+        for name in ("a", "b", "c"):
+            out.append((f"compress/98/{flags:#x}/{name}", "compress", name, {"dst": 98, "flags": flags}))
+    out.append(("compress/99/0/a", "compress", "a", {"dst": 99, "flags": 0}))            # one-sided sRGB
+    out.append(("compress/95/0/hdr", "compress", "hdr", {"dst": 95, "flags": 0}))
+    out.append(("compress/96/0/sgn", "compress", "sgn", {"dst": 96, "flags": 0}))
+    out.append(("compress/95/0/f32", "compress", "f32", {"dst": 95, "flags": 0}))
+    for fmt, name, back in ((71, "c", RGBA8), (74, "a", RGBA8), (77, "a", BGRA8), (80, "a", RGBA8), (84, "a", RGBA16F), (98, "a", RGBA8), (95, "hdr", RGBA16F), (96, "sgn", RGBA32F)):
+        out.append((f"decompress/{fmt}/{name}/{back}", "decompress", name, {"bc": fmt, "dst": back}))
+    for flt in (0x100000, 0x200000, 0x300000, 0x400000, 0x500000, 0x300000 | 0x1, 0x500000 | 0x20):
+        out.append((f"mips/{flt:#x}/b", "mips", "b", {"filter": flt, "levels": 6}))
+    out.append(("mips/0x200000/a", "mips", "a", {"filter": 0x200000, "levels": 0}))
+    for flt, (nw, nh) in ((0x100000, (13, 9)), (0x200000, (64, 40)), (0x300000, (25, 31)), (0x500000, (17, 50)), (0x400000, (20, 14))):
+        out.append((f"resize/{flt:#x}/{nw}x{nh}/a", "resize", "a", {"filter": flt, "w": nw, "h": nh}))
+    for name, dst in (("a", RGBA16F), ("a", BGRA8), ("a", 49), ("f32", RGBA8), ("f32", 31), ("hdr", RGBA32F), ("a", RGBA8S)):
+        out.append((f"convert/{name}/{dst}", "convert", name, {"dst": dst}))
+    for flags in (0, 1, 2, 3):
+        out.append((f"pmalpha/{flags}/a", "pmalpha", "a", {"flags": flags}))
+    out.append(("coverage/0.4/b", "coverage", "b", {"ref": 0.4, "levels": 6}))
+    return out
+
+
+def run_case(kind, arr, w, h, fmt, p, api):
+    """api: object with the reference-shaped calls; returns bytes."""
+    if kind == "compress":
+        return bytes(api.compress(arr, w, h, fmt, p["dst"], p["flags"]))
+    if kind == "decompress":
+        pay = api.compress(arr, w, h, fmt, p["bc"], 0x100000 if p["bc"] in (98, 99) else 0)
+        return bytes(api.decompress(pay, w, h, p["bc"], p["dst"]))
+    if kind == "mips":
+        return b"".join(bytes(l) for l in api.mips(arr, w, h, fmt, p["filter"], p["levels"]))
+    if kind == "resize":
+        return bytes(api.resize(arr, w, h, fmt, p["w"], p["h"], p["filter"]))
+    if kind == "convert":
+        return bytes(api.convert(arr, w, h, fmt, p["dst"]))
+    if kind == "pmalpha":
+        return bytes(api.pmalpha(arr, w, h, fmt, p["flags"]))
+    if kind == "coverage":
+        return b"".join(bytes(l) for l in api.coverage(api.mips(arr, w, h, fmt, 0x400000, p["levels"]), w, h, fmt, p["ref"]))
+    raise ValueError(kind)
+
+
+class RefApi:
+    def __init__(self):
+        import dxtex_oracle as o
+        self.o = o
+    def compress(self, a, w, h, f, dst, flags): return self.o.ref_compress_image(a, w, h, f, dst, flags, 0.5)
+    def decompress(self, pay, w, h, bc, dst): return self.o.ref_decompress_image(pay, w, h, bc, dst)
+    def mips(self, a, w, h, f, flt, levels):
+        n = levels or len(self.o.mip_sizes(w, h, 32)[: 1 + int(np.floor(np.log2(max(w, h))))])
+        return self.o.ref_generate_mips(a, w, h, f, flt, n)
+    def resize(self, a, w, h, f, nw, nh, flt): return self.o.ref_resize(a, w, h, f, nw, nh, flt)
+    def convert(self, a, w, h, f, dst): return self.o.ref_convert(a, w, h, f, dst, 0, 0.5)
+    def pmalpha(self, a, w, h, f, flags): return self.o.ref_premultiply_alpha(a, w, h, f, flags)
+    def coverage(self, levels, w, h, f, ref): return self.o.ref_scale_mips_alpha_for_coverage(levels, w, h, f, ref)
+
+
+def main():
+    api = RefApi()
+    ins = inputs()
+    gold = {"_generator": "tests/golden/make_golden.py over oracle/_ref (the reference compiled in place)", "cases": {}}
+    for cid, kind, name, p in cases():
+        arr, w, h, fmt = ins[name]
+        out = run_case(kind, arr, w, h, fmt, p, api)
+        gold["cases"][cid] = {"sha256": hashlib.sha256(out).hexdigest(), "bytes": len(out), "head": out[:16].hex()}
+    gold["inputs"] = {k: hashlib.sha256(np.ascontiguousarray(v[0]).tobytes()).hexdigest() for k, v in ins.items()}
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.json"), "w") as f:
+        json.dump(gold, f, indent=1, sort_keys=True)
+    print(len(gold["cases"]), "cases written")
+
+
+if __name__ == "__main__":
+    main()
