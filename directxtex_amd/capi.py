@@ -29,6 +29,12 @@ def _load():
     return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
 
 
+class Volume(ctypes.Structure):
+    """dxtex_volume (include/dxtex_amd.h): one mip level of a volume texture."""
+    _fields_ = [("width", ctypes.c_size_t), ("height", ctypes.c_size_t), ("depth", ctypes.c_size_t), ("format", ctypes.c_int32),
+                ("rowPitch", ctypes.c_size_t), ("slicePitch", ctypes.c_size_t), ("pixels", ctypes.c_void_p)]
+
+
 class Image(ctypes.Structure):
     """Mirrors ``dxtex_image`` / ``DirectX::Image`` (DirectXTex.h:437-445)."""
     _fields_ = [("width", ctypes.c_size_t), ("height", ctypes.c_size_t), ("format", ctypes.c_int32),
@@ -64,6 +70,8 @@ _SIGS = {
     "dxtex_compress_many": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_size_t, ctypes.c_uint32, ctypes.c_float]),
     "dxtex_convert": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
     "dxtex_convert_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
+    "dxtex_generate_mips3d": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]),
+    "dxtex_generate_mips3d_device": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]),
     "dxtex_premultiply_alpha": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32]),
     "dxtex_premultiply_alpha_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32]),
     "dxtex_scale_mips_alpha_for_coverage": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_size_t, ctypes.c_float]),
@@ -266,6 +274,22 @@ class Context:
         dst = Image(width, height, dst_format, rp, sp, out.ctypes.data)
         self._check(_lib.dxtex_convert(self._h, ctypes.byref(src), ctypes.byref(dst), filter_flags, threshold), "convert")
         return out
+
+    def generate_mips3d(self, volume, width, height, depth, fmt, nlevels, filter_flags):
+        """DirectX::GenerateMipMaps3D: `volume` = the base slices (tight, consecutive). Returns one uint8 buffer per level."""
+        bufs, vols = [], []
+        w, h, d = width, height, depth
+        for i in range(nlevels):
+            rp, sp = compute_pitch(fmt, w, h)
+            buf = np.zeros(sp * d, np.uint8)
+            if i == 0:
+                buf[:] = np.ascontiguousarray(volume).view(np.uint8).reshape(-1)[:sp * d]
+            bufs.append(buf)
+            vols.append(Volume(w, h, d, fmt, rp, sp, buf.ctypes.data))
+            w, h, d = max(1, w >> 1), max(1, h >> 1), max(1, d >> 1)
+        arr = (Volume * nlevels)(*vols)
+        self._check(_lib.dxtex_generate_mips3d(self._h, arr, nlevels, filter_flags), "generate_mips3d")
+        return bufs
 
     def premultiply_alpha(self, pixels, width, height, fmt, flags=0):
         """DirectX::PremultiplyAlpha (flags = TEX_PMALPHA_*: 0x1 IGNORE_SRGB, 0x2 REVERSE, 0x1000000 / 0x2000000 SRGB_IN / OUT)."""

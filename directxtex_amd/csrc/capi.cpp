@@ -724,6 +724,140 @@ dxtex_hresult dxtex_generate_mips(dxtex_ctx* ctx, const dxtex_image* levels, siz
 
 namespace
 {
+// GenerateMipMaps3D's checks and filter choice (DirectXTexMipmaps.cpp:3254-3305)
+dxtex_hresult check_mips3d(dxtex_ctx* ctx, const dxtex_volume* levels, size_t nlevels, uint32_t filter, uint32_t* mode)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!levels || nlevels <= 1) return fail(ctx, DXTEX_E_INVALIDARG, "need at least two levels");
+    const FmtInfo* f = format_info(levels[0].format);
+    if (f && (f->cls & FC_BC)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "cannot filter a block-compressed volume");
+    if (!f) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "format is not supported by the MI355X path");
+    size_t w = levels[0].width, h = levels[0].height, d = levels[0].depth;
+    if (!w || !h || !d || d > 32767) return fail(ctx, DXTEX_E_INVALIDARG, "bad volume dimensions");           // depth > INT16_MAX, :3264
+    if (filter & 0x20000000u) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "TEX_FILTER_FORCE_WIC");
+    for (size_t i = 0; i < nlevels; ++i)
+    {
+        if (!levels[i].pixels) return fail(ctx, DXTEX_E_POINTER, "null pixels");
+        if (levels[i].width != w || levels[i].height != h || levels[i].depth != d || levels[i].format != levels[0].format)
+            return fail(ctx, DXTEX_E_INVALIDARG, "levels do not form a volume mip chain");
+        if (i + 1 < nlevels && w == 1 && h == 1 && d == 1) return fail(ctx, DXTEX_E_INVALIDARG, "too many levels");     // CalculateMipLevels3D
+        w = std::max<size_t>(1, w >> 1); h = std::max<size_t>(1, h >> 1); d = std::max<size_t>(1, d >> 1);
+    }
+    const bool pow2 = ispow2(levels[0].width) && ispow2(levels[0].height) && ispow2(levels[0].depth);
+    uint32_t m = filter & kFilterModeMask;
+    if (!m) m = pow2 ? DXTEX_FILTER_BOX : DXTEX_FILTER_TRIANGLE;
+    if (m != DXTEX_FILTER_POINT && m != DXTEX_FILTER_LINEAR && m != DXTEX_FILTER_CUBIC && m != DXTEX_FILTER_BOX && m != DXTEX_FILTER_TRIANGLE)
+        return fail(ctx, DXTEX_E_NOT_SUPPORTED, "unknown filter mode");
+    if (m == DXTEX_FILTER_BOX && !pow2) return fail(ctx, DXTEX_E_FAIL, "the box filter needs power-of-two dimensions");   // :1831-1832
+    *mode = m;
+    return DXTEX_S_OK;
+}
+
+// The level loop of Generate3DMips*Filter on device-resident levels: 3-D kernels while the source is more than one slice deep,
+// then the reference's 2-D branches (the kernels GenerateMipMaps uses) - except the triangle filter, which has no 2-D branch.
+dxtex_hresult submit_mips3d(dxtex_ctx* ctx, const std::vector<VolumeView>& lv, uint32_t mode, uint32_t flags)
+{
+    const int format = lv[0].format;
+    struct Slot { size_t ofsX, entX, ofsY, entY, ofsZ, entZ; };
+    std::vector<Slot> slots(lv.size());
+    const uint8_t* tri = nullptr;
+    if (mode == DXTEX_FILTER_TRIANGLE)
+    {
+        std::vector<uint8_t>& host = ctx->triHost;
+        host.clear();
+        std::vector<uint32_t> ofs; std::vector<TriEntry> ent;
+        auto append = [&](const void* p, size_t bytes) { const size_t at = (host.size() + 15) & ~size_t(15); host.resize(at + bytes); std::memcpy(host.data() + at, p, bytes); return at; };
+        for (size_t i = 1; i < lv.size(); ++i)
+        {
+            build_triangle_axis(lv[i - 1].width, lv[i].width, (flags & DXTEX_FILTER_WRAP_U) != 0, ofs, ent);
+            slots[i].ofsX = append(ofs.data(), ofs.size() * 4); slots[i].entX = append(ent.data(), std::max<size_t>(1, ent.size()) * 8);
+            build_triangle_axis(lv[i - 1].height, lv[i].height, (flags & DXTEX_FILTER_WRAP_V) != 0, ofs, ent);
+            slots[i].ofsY = append(ofs.data(), ofs.size() * 4); slots[i].entY = append(ent.data(), std::max<size_t>(1, ent.size()) * 8);
+            build_triangle_axis(lv[i - 1].depth, lv[i].depth, (flags & 0x4u) != 0, ofs, ent);
+            slots[i].ofsZ = append(ofs.data(), ofs.size() * 4); slots[i].entZ = append(ent.data(), std::max<size_t>(1, ent.size()) * 8);
+        }
+        host.resize(host.size() + 16);
+        dxtex_hresult hr = ensure(ctx, &ctx->triBuf, &ctx->triBytes, host.size()); if (hr != DXTEX_S_OK) return hr;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->triBuf, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+        tri = static_cast<const uint8_t*>(ctx->triBuf);
+    }
+    const VolumeView* twoHigh = nullptr;     // box: the last SOURCE level that was 2 texels high (what urow1 / vrow1's old buffers hold)
+    for (size_t i = 1; i < lv.size(); ++i)
+    {
+        const VolumeView& s = lv[i - 1]; const VolumeView& d = lv[i];
+        if (s.height >= 2) twoHigh = &s;
+        // row 1 of the last slice pair loaded into urow1 / vrow1 at that level: slices depth-2 and depth-1 (a one-slice level only has urow1)
+        const bool stale = mode == DXTEX_FILTER_BOX && s.height == 1 && s.width > 1 && twoHigh;
+        const uint8_t* staleU = stale ? twoHigh->pixels + uint64_t(twoHigh->depth >= 2 ? twoHigh->depth - 2 : 0) * twoHigh->slicePitch : nullptr;
+        const uint8_t* staleV = stale ? twoHigh->pixels + uint64_t(twoHigh->depth - 1) * twoHigh->slicePitch : nullptr;
+        hipError_t e;
+        if (s.depth > 1 || mode == DXTEX_FILTER_TRIANGLE)
+        {
+            TriangleTables3 t{};
+            if (tri)
+            {
+                t.ofsX = reinterpret_cast<const uint32_t*>(tri + slots[i].ofsX); t.entX = tri + slots[i].entX;
+                t.ofsY = reinterpret_cast<const uint32_t*>(tri + slots[i].ofsY); t.entY = tri + slots[i].entY;
+                t.ofsZ = reinterpret_cast<const uint32_t*>(tri + slots[i].ofsZ); t.entZ = tri + slots[i].entZ;
+            }
+            e = launch_resize3d(s, d, mode, flags, tri ? &t : nullptr, ctx->stream, staleU, staleV, stale ? twoHigh->rowPitch : 0, stale ? twoHigh->width : 0u);
+        }
+        else
+            e = launch_resize(s.pixels, s.rowPitch, s.width, s.height, const_cast<uint8_t*>(d.pixels), d.rowPitch, d.width, d.height, format, mode, flags, true,
+                              nullptr, ctx->stream, staleU, stale ? twoHigh->rowPitch : 0, stale ? twoHigh->width : 0u);
+        if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    }
+    return DXTEX_S_OK;
+}
+
+VolumeView view_of(const dxtex_volume& v, const uint8_t* pixels)
+{
+    VolumeView o; o.pixels = pixels; o.rowPitch = v.rowPitch; o.slicePitch = v.slicePitch;
+    o.width = uint32_t(v.width); o.height = uint32_t(v.height); o.depth = uint32_t(v.depth); o.format = v.format;
+    return o;
+}
+} // namespace
+
+dxtex_hresult dxtex_generate_mips3d_device(dxtex_ctx* ctx, const dxtex_volume* levels, size_t nlevels, uint32_t filter)
+{
+    uint32_t mode = 0;
+    dxtex_hresult hr = check_mips3d(ctx, levels, nlevels, filter, &mode);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    std::vector<VolumeView> lv(nlevels);
+    for (size_t i = 0; i < nlevels; ++i) lv[i] = view_of(levels[i], levels[i].pixels);
+    time_begin(ctx);
+    hr = submit_mips3d(ctx, lv, mode, filter);
+    time_end(ctx);
+    return hr;
+}
+
+dxtex_hresult dxtex_generate_mips3d(dxtex_ctx* ctx, const dxtex_volume* levels, size_t nlevels, uint32_t filter)
+{
+    uint32_t mode = 0;
+    dxtex_hresult hr = check_mips3d(ctx, levels, nlevels, filter, &mode);
+    if (hr != DXTEX_S_OK) return hr;
+    ScopedDevice sd(ctx->device);
+    std::vector<size_t> at(nlevels);
+    size_t total = 0;
+    for (size_t i = 0; i < nlevels; ++i) { at[i] = total; total += (levels[i].slicePitch * levels[i].depth + 255) & ~size_t(255); }
+    hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, total); if (hr != DXTEX_S_OK) return hr;
+    uint8_t* d = static_cast<uint8_t*>(ctx->stageIn);
+    HIP_TRY(ctx, hipMemcpyAsync(d, levels[0].pixels, levels[0].slicePitch * levels[0].depth, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<VolumeView> lv(nlevels);
+    for (size_t i = 0; i < nlevels; ++i) lv[i] = view_of(levels[i], d + at[i]);
+    time_begin(ctx);
+    hr = submit_mips3d(ctx, lv, mode, filter);
+    time_end(ctx);
+    if (hr != DXTEX_S_OK) return hr;
+    for (size_t i = 1; i < nlevels; ++i)
+        HIP_TRY(ctx, hipMemcpyAsync(levels[i].pixels, d + at[i], levels[i].slicePitch * levels[i].depth, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DXTEX_S_OK;
+}
+
+namespace
+{
 // Resize's checks and filter choice (DirectXTexResize.cpp:807-843, :854-930)
 dxtex_hresult check_resize(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, uint32_t* mode)
 {

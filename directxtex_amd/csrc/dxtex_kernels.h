@@ -50,6 +50,12 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
                          const TriangleTables* tri, hipStream_t stream,
                          const uint8_t* staleLevel = nullptr, uint64_t stalePitch = 0, uint32_t staleW = 0);
 
+// Volume mips (Generate3DMips*Filter): one level whose source is more than one slice deep. Slices of a level are `slicePitch` apart.
+struct VolumeView { const uint8_t* pixels; uint64_t rowPitch, slicePitch; uint32_t width, height, depth; int format; };
+struct TriangleTables3 { const uint32_t* ofsX; const void* entX; const uint32_t* ofsY; const void* entY; const uint32_t* ofsZ; const void* entZ; };
+hipError_t launch_resize3d(const VolumeView& src, const VolumeView& dst, uint32_t filterMode, uint32_t filterFlags, const TriangleTables3* tri,
+                           hipStream_t stream, const uint8_t* staleU = nullptr, const uint8_t* staleV = nullptr, uint64_t stalePitch = 0, uint32_t staleW = 0);
+
 // ComputeMSE: out4 (device) receives the per-channel SUM of squared differences; divide by width * height on the host.
 hipError_t launch_mse(const uint8_t* a, uint64_t aPitch, int aFormat, const uint8_t* b, uint64_t bPitch, int bFormat,
                       uint32_t width, uint32_t height, double* out4, hipStream_t stream);

@@ -301,6 +301,179 @@ __global__ void __launch_bounds__(256) resize_triangle_kernel(ResizeArgs a)
     store_linear(a.dst, x, y, a.srgbOut, acc);
 }
 
+// ---- volume mips: Generate3DMips{Point,Box,Linear,Cubic,Triangle}Filter (DirectXTexMipmaps.cpp:1666-2826) ----------------------------
+// One lane = one destination texel (x, y = blockIdx.y, z = blockIdx.z) of a level whose SOURCE has depth > 1; levels whose source
+// is one slice deep take the reference's 2-D branch, i.e. the kernels above.
+struct Vol
+{
+    uint8_t* pixels;                 // slice 0
+    uint64_t rowPitch, slicePitch;
+    uint32_t width, height, depth;
+    int format;
+};
+
+struct Resize3Args
+{
+    Vol src, dst;
+    int srgbIn, srgbOut;
+    int wrapU, wrapV, wrapW, mirrorU, mirrorV, mirrorW;
+    ImgView staleU, staleV;          // box: what the never re-pointed urow3 / vrow3 still see on W x 1 x D levels (see resize3d_box_kernel)
+    const uint32_t* triOfsX; const uint2* triX;
+    const uint32_t* triOfsY; const uint2* triY;
+    const uint32_t* triOfsZ; const uint2* triZ;
+};
+
+__device__ __forceinline__ ImgView slice_of(const Vol& v, uint32_t z)
+{
+    ImgView s; s.pixels = v.pixels + uint64_t(z) * v.slicePitch; s.rowPitch = v.rowPitch; s.width = v.width; s.height = v.height; s.format = v.format;
+    return s;
+}
+
+// point (:1666-1813): source slice (z * zinc) >> 16, then the 2-D point filter inside it
+__global__ void __launch_bounds__(256) resize3d_point_kernel(Resize3Args a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= a.dst.width) return;
+    const uint64_t zinc = (uint64_t(a.src.depth) << 16) / a.dst.depth;
+    const uint64_t xinc = (uint64_t(a.src.width) << 16) / a.dst.width, yinc = (uint64_t(a.src.height) << 16) / a.dst.height;
+    const ImgView src = slice_of(a.src, uint32_t((uint64_t(z) * zinc) >> 16)), dst = slice_of(a.dst, z);
+    const uint32_t sx = uint32_t((uint64_t(x) * xinc) >> 16), sy = uint32_t((uint64_t(y) * yinc) >> 16);
+    store_texel(dst.pixels + uint64_t(y) * dst.rowPitch, x, dst.format, load_texel(src.pixels + uint64_t(sy) * src.rowPitch, sx, src.format));
+}
+
+// box (:1815-1990): AVERAGE8 over slices (2z, 2z+1) x rows x columns, summed in the macro's order, x 0.125.
+__global__ void __launch_bounds__(256) resize3d_box_kernel(Resize3Args a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= a.dst.width) return;
+    const bool oneRow = a.src.height <= 1, oneCol = a.src.width <= 1;
+    const uint32_t za = min(2u * z, a.src.depth - 1u), zb = min(za + 1u, a.src.depth - 1u);
+    const ImgView A = slice_of(a.src, za), B = slice_of(a.src, zb);
+    const uint32_t x0 = oneCol ? 0u : 2u * x, x1 = oneCol ? 0u : 2u * x + 1u;
+    const uint32_t y0 = oneRow ? 0u : 2u * y, y1 = oneRow ? 0u : 2u * y + 1u;
+    // Reference quirk, reproduced: urow3 = urow1 + 1 and vrow3 = vrow1 + 1 are set once, before the level loop (:1849-1852); a
+    // 1-high source re-points urow1 / vrow1 (:1857-1861) but not urow3 / vrow3 unless the source is also 1 wide (:1863-1869).
+    // On W x 1 x D sources (W > 1) the fourth tap of either slice therefore still reads the old second-row buffers: row 1 of the
+    // last two slices of the last level that was 2 texels high.
+    const bool staleTap = oneRow && !oneCol && a.staleU.pixels != nullptr;
+    const Texel p0 = load_linear(A, x0, y0, a.srgbIn), p1 = load_linear(A, x0, y1, a.srgbIn), p2 = load_linear(A, x1, y0, a.srgbIn);
+    const Texel p3 = staleTap ? load_linear(a.staleU, x1, 1u, a.srgbIn) : load_linear(A, x1, y1, a.srgbIn);
+    const Texel p4 = load_linear(B, x0, y0, a.srgbIn), p5 = load_linear(B, x0, y1, a.srgbIn), p6 = load_linear(B, x1, y0, a.srgbIn);
+    const Texel p7 = staleTap ? load_linear(a.staleV, x1, 1u, a.srgbIn) : load_linear(B, x1, y1, a.srgbIn);
+#define DXTEX_AVG8(C) ((((((((p0.C + p1.C) + p2.C) + p3.C) + p4.C) + p5.C) + p6.C) + p7.C) * 0.125f)
+    Texel r;
+    r.r = DXTEX_AVG8(r); r.g = DXTEX_AVG8(g); r.b = DXTEX_AVG8(b); r.a = DXTEX_AVG8(a);
+#undef DXTEX_AVG8
+    store_linear(slice_of(a.dst, z), x, y, a.srgbOut, r);
+}
+
+// linear (:1992-2188): TRILINEAR_INTERPOLATE (filters.h:106-113)
+__global__ void __launch_bounds__(256) resize3d_linear_kernel(Resize3Args a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= a.dst.width) return;
+    const Lin tx = linear_entry(a.src.width, a.dst.width, a.wrapU != 0, x);
+    const Lin ty = linear_entry(a.src.height, a.dst.height, a.wrapV != 0, y);
+    const Lin tz = linear_entry(a.src.depth, a.dst.depth, a.wrapW != 0, z);
+    const ImgView A = slice_of(a.src, tz.u0), B = slice_of(a.src, tz.u1);
+    const Texel a00 = load_linear(A, tx.u0, ty.u0, a.srgbIn), a01 = load_linear(A, tx.u1, ty.u0, a.srgbIn);
+    const Texel a10 = load_linear(A, tx.u0, ty.u1, a.srgbIn), a11 = load_linear(A, tx.u1, ty.u1, a.srgbIn);
+    const Texel b00 = load_linear(B, tx.u0, ty.u0, a.srgbIn), b01 = load_linear(B, tx.u1, ty.u0, a.srgbIn);
+    const Texel b10 = load_linear(B, tx.u0, ty.u1, a.srgbIn), b11 = load_linear(B, tx.u1, ty.u1, a.srgbIn);
+#define DXTEX_TRILERP(C) ((((a00.C * tx.w0 + a01.C * tx.w1) * ty.w0 + (a10.C * tx.w0 + a11.C * tx.w1) * ty.w1) * tz.w0) + \
+                          (((b00.C * tx.w0 + b01.C * tx.w1) * ty.w0 + (b10.C * tx.w0 + b11.C * tx.w1) * ty.w1) * tz.w1))
+    Texel r;
+    r.r = DXTEX_TRILERP(r); r.g = DXTEX_TRILERP(g); r.b = DXTEX_TRILERP(b); r.a = DXTEX_TRILERP(a);
+#undef DXTEX_TRILERP
+    store_linear(slice_of(a.dst, z), x, y, a.srgbOut, r);
+}
+
+// cubic (:2190-2572): per source slice the 2-D cubic (rows through toX, then toY), then CUBIC_INTERPOLATE through toZ
+__global__ void __launch_bounds__(256) resize3d_cubic_kernel(Resize3Args a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= a.dst.width) return;
+    const Cub tx = cubic_entry(a.src.width, a.dst.width, a.wrapU != 0, a.mirrorU != 0, x);
+    const Cub ty = cubic_entry(a.src.height, a.dst.height, a.wrapV != 0, a.mirrorV != 0, y);
+    const Cub tz = cubic_entry(a.src.depth, a.dst.depth, a.wrapW != 0, a.mirrorW != 0, z);
+    const uint32_t ys[4] = { ty.u0, ty.u1, ty.u2, ty.u3 }, zs[4] = { tz.u0, tz.u1, tz.u2, tz.u3 };
+    Texel d[4];
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j)
+    {
+        const ImgView S = slice_of(a.src, zs[j]);
+        Texel c[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            const Texel p0 = load_linear(S, tx.u0, ys[r], a.srgbIn), p1 = load_linear(S, tx.u1, ys[r], a.srgbIn);
+            const Texel p2 = load_linear(S, tx.u2, ys[r], a.srgbIn), p3 = load_linear(S, tx.u3, ys[r], a.srgbIn);
+            c[r].r = cubic1(tx.x, p0.r, p1.r, p2.r, p3.r); c[r].g = cubic1(tx.x, p0.g, p1.g, p2.g, p3.g);
+            c[r].b = cubic1(tx.x, p0.b, p1.b, p2.b, p3.b); c[r].a = cubic1(tx.x, p0.a, p1.a, p2.a, p3.a);
+        }
+        Texel o;
+        o.r = cubic1(ty.x, c[0].r, c[1].r, c[2].r, c[3].r); o.g = cubic1(ty.x, c[0].g, c[1].g, c[2].g, c[3].g);
+        o.b = cubic1(ty.x, c[0].b, c[1].b, c[2].b, c[3].b); o.a = cubic1(ty.x, c[0].a, c[1].a, c[2].a, c[3].a);
+        if (j == 0) d[0] = o; else if (j == 1) d[1] = o; else if (j == 2) d[2] = o; else d[3] = o;
+    }
+    Texel o;
+    o.r = cubic1(tz.x, d[0].r, d[1].r, d[2].r, d[3].r); o.g = cubic1(tz.x, d[0].g, d[1].g, d[2].g, d[3].g);
+    o.b = cubic1(tz.x, d[0].b, d[1].b, d[2].b, d[3].b); o.a = cubic1(tz.x, d[0].a, d[1].a, d[2].a, d[3].a);
+    store_linear(slice_of(a.dst, z), x, y, a.srgbOut, o);
+}
+
+// triangle (:2574-2826): acc = src * ((wz * wy) * wx) + acc, contributions ordered by (source slice, source row, source column,
+// slice-list entry, row-list entry, column-list entry) - gathered per destination texel from the inverted lists, as in 2-D.
+__global__ void __launch_bounds__(256) resize3d_triangle_kernel(Resize3Args a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= a.dst.width) return;
+    const uint32_t zb = a.triOfsZ[z], ze = a.triOfsZ[z + 1];
+    const uint32_t yb = a.triOfsY[y], ye = a.triOfsY[y + 1];
+    const uint32_t xb = a.triOfsX[x], xe = a.triOfsX[x + 1];
+    Texel acc; acc.r = acc.g = acc.b = acc.a = 0.0f;
+    uint32_t h = zb;
+    while (h < ze)
+    {
+        const uint32_t sz = a.triZ[h].x;
+        uint32_t hEnd = h + 1;
+        while (hEnd < ze && a.triZ[hEnd].x == sz) ++hEnd;
+        const ImgView S = slice_of(a.src, sz);
+        uint32_t i = yb;
+        while (i < ye)
+        {
+            const uint32_t sy = a.triY[i].x;
+            uint32_t iEnd = i + 1;
+            while (iEnd < ye && a.triY[iEnd].x == sy) ++iEnd;
+            uint32_t k = xb;
+            while (k < xe)
+            {
+                const uint32_t sx = a.triX[k].x;
+                uint32_t kEnd = k + 1;
+                while (kEnd < xe && a.triX[kEnd].x == sx) ++kEnd;
+                const Texel p = load_linear(S, sx, sy, a.srgbIn);
+                for (uint32_t g = h; g < hEnd; ++g)
+                {
+                    const float wz = __uint_as_float(a.triZ[g].y);
+                    for (uint32_t j = i; j < iEnd; ++j)
+                    {
+                        const float wzy = wz * __uint_as_float(a.triY[j].y);
+                        for (uint32_t m = k; m < kEnd; ++m)
+                        {
+                            const float w = wzy * __uint_as_float(a.triX[m].y);
+                            acc.r = p.r * w + acc.r; acc.g = p.g * w + acc.g; acc.b = p.b * w + acc.b; acc.a = p.a * w + acc.a;
+                        }
+                    }
+                }
+                k = kEnd;
+            }
+            i = iEnd;
+        }
+        h = hEnd;
+    }
+    store_linear(slice_of(a.dst, z), x, y, a.srgbOut, acc);
+}
+
 // ---- ComputeMSE: sum over texels of (v1 - v2)^2 per channel, accumulated in fp64 ----------------------------------------------
 __global__ void __launch_bounds__(256) mse_kernel(ImgView a, ImgView b, int srgbA, int srgbB, int ignoreAlpha, double* out)
 {
@@ -423,6 +596,38 @@ hipError_t launch_alpha_coverage(const uint8_t* src, uint64_t srcPitch, int form
     if (width < 2 || height < 2) return hipSuccess;
     hipLaunchKernelGGL(alpha_coverage_kernel, dim3((width - 1 + 255) / 256, height - 1), dim3(256), 0, stream,
                        make_view(src, srcPitch, width, height, format), scale, alphaReference, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize3d(const VolumeView& src, const VolumeView& dst, uint32_t filterMode, uint32_t filterFlags, const TriangleTables3* tri,
+                           hipStream_t stream, const uint8_t* staleU, const uint8_t* staleV, uint64_t stalePitch, uint32_t staleW)
+{
+    if (!dst.width || !dst.height || !dst.depth) return hipSuccess;
+    Resize3Args a;
+    auto vol = [](const VolumeView& v) { Vol o; o.pixels = const_cast<uint8_t*>(v.pixels); o.rowPitch = v.rowPitch; o.slicePitch = v.slicePitch;
+                                         o.width = v.width; o.height = v.height; o.depth = v.depth; o.format = v.format; return o; };
+    a.src = vol(src); a.dst = vol(dst);
+    const int format = src.format;
+    const bool wantIn = srgb_linear_format(format) || (filterFlags & 0x1000000u), wantOut = srgb_linear_format(format) || (filterFlags & 0x2000000u);
+    a.srgbIn = (can_srgb(format) && wantIn) ? 1 : 0;
+    a.srgbOut = (can_srgb(format) && wantOut) ? 1 : 0;
+    a.wrapU = (filterFlags & 0x1u) != 0; a.wrapV = (filterFlags & 0x2u) != 0; a.wrapW = (filterFlags & 0x4u) != 0;
+    a.mirrorU = (filterFlags & 0x10u) != 0; a.mirrorV = (filterFlags & 0x20u) != 0; a.mirrorW = (filterFlags & 0x40u) != 0;
+    a.staleU = make_view(staleU, stalePitch, staleW, 2, format);
+    a.staleV = make_view(staleV, stalePitch, staleW, 2, format);
+    a.triOfsX = tri ? tri->ofsX : nullptr; a.triX = tri ? reinterpret_cast<const uint2*>(tri->entX) : nullptr;
+    a.triOfsY = tri ? tri->ofsY : nullptr; a.triY = tri ? reinterpret_cast<const uint2*>(tri->entY) : nullptr;
+    a.triOfsZ = tri ? tri->ofsZ : nullptr; a.triZ = tri ? reinterpret_cast<const uint2*>(tri->entZ) : nullptr;
+    const dim3 grid((dst.width + 255) / 256, dst.height, dst.depth), block(256);
+    switch (filterMode)
+    {
+    case 0x100000u: hipLaunchKernelGGL(resize3d_point_kernel, grid, block, 0, stream, a); break;
+    case 0x200000u: hipLaunchKernelGGL(resize3d_linear_kernel, grid, block, 0, stream, a); break;
+    case 0x300000u: hipLaunchKernelGGL(resize3d_cubic_kernel, grid, block, 0, stream, a); break;
+    case 0x400000u: hipLaunchKernelGGL(resize3d_box_kernel, grid, block, 0, stream, a); break;
+    case 0x500000u: hipLaunchKernelGGL(resize3d_triangle_kernel, grid, block, 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

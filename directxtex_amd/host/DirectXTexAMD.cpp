@@ -61,8 +61,27 @@ bool CalculateMipLevels(size_t width, size_t height, size_t& mipLevels) noexcept
 
 size_t TexMetadata::ComputeIndex(size_t mip, size_t item, size_t slice) const noexcept
 {
-    if (mip >= mipLevels || slice > 0 || item >= arraySize) return size_t(-1);
+    if (mip >= mipLevels) return size_t(-1);
+    if (dimension == TEX_DIMENSION_TEXTURE3D)
+    {
+        // a volume: level by level, the level's slices consecutive; no arrays of volumes (DirectXTexUtil.cpp:1714-1738)
+        if (item > 0) return size_t(-1);
+        size_t index = 0, d = depth;
+        for (size_t level = 0; level < mip; ++level) { index += d; if (d > 1) d >>= 1; }
+        return (slice < d) ? index + slice : size_t(-1);
+    }
+    if (slice > 0 || item >= arraySize) return size_t(-1);
     return item * mipLevels + mip;
+}
+
+bool CalculateMipLevels3D(size_t width, size_t height, size_t depth, size_t& mipLevels) noexcept
+{
+    // CountMips3D (DirectXTexMipmaps.cpp:45-66): until all three dimensions reach 1
+    size_t maxMips = 1;
+    for (size_t w = width, h = height, d = depth; w > 1 || h > 1 || d > 1; ++maxMips) { if (w > 1) w >>= 1; if (h > 1) h >>= 1; if (d > 1) d >>= 1; }
+    if (mipLevels > 1) return mipLevels <= maxMips;
+    mipLevels = (mipLevels == 0) ? maxMips : 1;
+    return true;
 }
 
 // ---- ScratchImage --------------------------------------------------------------------------------------------------------
@@ -89,29 +108,35 @@ void ScratchImage::Release() noexcept
 HRESULT ScratchImage::Initialize(const TexMetadata& mdata) noexcept
 {
     if (!IsKnown(mdata.format)) return E_INVALIDARG;
-    if (mdata.dimension == TEX_DIMENSION_TEXTURE3D) return HRESULT_E_NOT_SUPPORTED;     // volume textures are outside this path
-    if (!mdata.width || !mdata.height || mdata.depth != 1 || !mdata.arraySize) return E_INVALIDARG;
+    const bool volume = mdata.dimension == TEX_DIMENSION_TEXTURE3D;
+    if (!mdata.width || !mdata.height || !mdata.depth || !mdata.arraySize) return E_INVALIDARG;
+    if (volume ? (mdata.arraySize != 1) : (mdata.depth != 1)) return E_INVALIDARG;          // DirectXTexImage.cpp:312-330
     size_t mipLevels = mdata.mipLevels;
-    if (!CalculateMipLevels(mdata.width, mdata.height, mipLevels)) return E_INVALIDARG;
+    if (volume ? !CalculateMipLevels3D(mdata.width, mdata.height, mdata.depth, mipLevels) : !CalculateMipLevels(mdata.width, mdata.height, mipLevels))
+        return E_INVALIDARG;
 
     Release();
     m_metadata = mdata;
     m_metadata.mipLevels = mipLevels;
 
-    // DetermineImageArray / SetupImageArray (DirectXTexImage.cpp:34-268): item-major, then mip
-    const size_t nimages = mdata.arraySize * mipLevels;
+    // DetermineImageArray / SetupImageArray (DirectXTexImage.cpp:34-268): item-major then mip; a volume goes level by level with
+    // the level's slices consecutive
+    size_t nimages = 0;
     uint64_t total = 0;
-    for (size_t item = 0; item < mdata.arraySize; ++item)
+    const size_t items = volume ? 1 : mdata.arraySize;
+    for (size_t item = 0; item < items; ++item)
     {
-        size_t w = mdata.width, h = mdata.height;
+        size_t w = mdata.width, h = mdata.height, d = volume ? mdata.depth : 1;
         for (size_t level = 0; level < mipLevels; ++level)
         {
             size_t rp, sp;
             const HRESULT hr = ComputePitch(mdata.format, w, h, rp, sp);
             if (FAILED(hr)) { Release(); return hr; }
-            total += sp;
+            total += uint64_t(sp) * d;
+            nimages += d;
             if (h > 1) h >>= 1;
             if (w > 1) w >>= 1;
+            if (d > 1) d >>= 1;
         }
     }
     m_images.reset(new (std::nothrow) Image[nimages]);
@@ -125,21 +150,33 @@ HRESULT ScratchImage::Initialize(const TexMetadata& mdata) noexcept
 
     uint8_t* p = m_memory;
     size_t index = 0;
-    for (size_t item = 0; item < mdata.arraySize; ++item)
+    for (size_t item = 0; item < items; ++item)
     {
-        size_t w = mdata.width, h = mdata.height;
-        for (size_t level = 0; level < mipLevels; ++level, ++index)
+        size_t w = mdata.width, h = mdata.height, d = volume ? mdata.depth : 1;
+        for (size_t level = 0; level < mipLevels; ++level)
         {
-            Image& im = m_images[index];
-            im.width = w; im.height = h; im.format = mdata.format;
-            ComputePitch(mdata.format, w, h, im.rowPitch, im.slicePitch);
-            im.pixels = p;
-            p += im.slicePitch;
+            for (size_t slice = 0; slice < d; ++slice, ++index)
+            {
+                Image& im = m_images[index];
+                im.width = w; im.height = h; im.format = mdata.format;
+                ComputePitch(mdata.format, w, h, im.rowPitch, im.slicePitch);
+                im.pixels = p;
+                p += im.slicePitch;
+            }
             if (h > 1) h >>= 1;
             if (w > 1) w >>= 1;
+            if (d > 1) d >>= 1;
         }
     }
     return S_OK;
+}
+
+HRESULT ScratchImage::Initialize3D(DXGI_FORMAT fmt, size_t width, size_t height, size_t depth, size_t mipLevels) noexcept
+{
+    TexMetadata m;
+    m.width = width; m.height = height; m.depth = depth; m.arraySize = 1; m.mipLevels = mipLevels;
+    m.format = fmt; m.dimension = TEX_DIMENSION_TEXTURE3D;
+    return Initialize(m);
 }
 
 HRESULT ScratchImage::Initialize2D(DXGI_FORMAT fmt, size_t width, size_t height, size_t arraySize, size_t mipLevels) noexcept
@@ -325,6 +362,55 @@ HRESULT GenerateMipMaps(Device& device, const Image* srcImages, size_t nimages, 
         if (FAILED(hr)) { mipChain.Release(); return hr; }
     }
     return S_OK;
+}
+
+// ---- GenerateMipMaps3D (DirectXTexMipmaps.cpp:3254-3361) -------------------------------------------------------------------------------
+HRESULT GenerateMipMaps3D(Device& device, const Image* baseImages, size_t depth, TEX_FILTER_FLAGS filter, size_t levels, ScratchImage& mipChain) noexcept
+{
+    if (!device) return E_POINTER;
+    if (!baseImages || !depth || depth > INT16_MAX) return E_INVALIDARG;
+    const DXGI_FORMAT format = baseImages[0].format;
+    const size_t width = baseImages[0].width, height = baseImages[0].height;
+    if (!CalculateMipLevels3D(width, height, depth, levels)) return E_INVALIDARG;
+    if (levels <= 1) return E_INVALIDARG;
+    for (size_t slice = 0; slice < depth; ++slice)
+    {
+        if (!baseImages[slice].pixels) return E_POINTER;
+        if (baseImages[slice].format != format || baseImages[slice].width != width || baseImages[slice].height != height) return E_FAIL;
+    }
+    if (IsCompressed(format) || !IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
+    // Setup3DMips (:1608-1664): the base slices go to the top level
+    HRESULT hr = mipChain.Initialize3D(format, width, height, depth, levels);
+    if (FAILED(hr)) return hr;
+    for (size_t slice = 0; slice < depth; ++slice)
+    {
+        const Image* dest = mipChain.GetImage(0, 0, slice);
+        if (!dest) { mipChain.Release(); return E_POINTER; }
+        for (size_t y = 0; y < height; ++y)
+            std::memcpy(dest->pixels + y * dest->rowPitch, baseImages[slice].pixels + y * baseImages[slice].rowPitch, std::min(dest->rowPitch, baseImages[slice].rowPitch));
+    }
+    std::vector<dxtex_volume> lv(levels);
+    size_t d = depth;
+    for (size_t l = 0; l < levels; ++l)
+    {
+        const Image* first = mipChain.GetImage(l, 0, 0);
+        lv[l] = dxtex_volume{ first->width, first->height, d, int32_t(first->format), first->rowPitch, first->slicePitch, first->pixels };
+        if (d > 1) d >>= 1;
+    }
+    hr = dxtex_generate_mips3d(device.Get(), lv.data(), lv.size(), uint32_t(filter));
+    if (FAILED(hr)) mipChain.Release();
+    return hr;
+}
+
+HRESULT GenerateMipMaps3D(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_FILTER_FLAGS filter, size_t levels,
+                          ScratchImage& mipChain) noexcept
+{
+    // the complex overload (:3364-3480): the metadata must describe a volume, the base slices are its first `depth` images
+    if (!srcImages || !nimages || metadata.dimension != TEX_DIMENSION_TEXTURE3D) return E_INVALIDARG;
+    if (metadata.depth > nimages) return E_FAIL;
+    for (size_t slice = 0; slice < metadata.depth; ++slice)
+        if (srcImages[slice].format != metadata.format || srcImages[slice].width != metadata.width || srcImages[slice].height != metadata.height) return E_FAIL;
+    return GenerateMipMaps3D(device, srcImages, metadata.depth, filter, levels, mipChain);
 }
 
 // ---- Resize (DirectXTexResize.cpp:854-930) ----------------------------------------------------------------------------------------

@@ -71,6 +71,7 @@ size_t BitsPerPixel(DXGI_FORMAT fmt) noexcept;
 HRESULT ComputePitch(DXGI_FORMAT fmt, size_t width, size_t height, size_t& rowPitch, size_t& slicePitch) noexcept;
 // CalculateMipLevels (DirectXTexMipmaps.cpp:40-69): mipLevels == 0 asks for the full chain
 bool CalculateMipLevels(size_t width, size_t height, size_t& mipLevels) noexcept;
+bool CalculateMipLevels3D(size_t width, size_t height, size_t depth, size_t& mipLevels) noexcept;
 
 struct TexMetadata
 {
@@ -103,6 +104,7 @@ public:
 
     HRESULT Initialize(const TexMetadata& mdata) noexcept;
     HRESULT Initialize2D(DXGI_FORMAT fmt, size_t width, size_t height, size_t arraySize, size_t mipLevels) noexcept;
+    HRESULT Initialize3D(DXGI_FORMAT fmt, size_t width, size_t height, size_t depth, size_t mipLevels) noexcept;
     HRESULT InitializeFromImage(const Image& srcImage) noexcept;      // copies the pixels
     void Release() noexcept;
 
@@ -147,6 +149,10 @@ HRESULT Decompress(Device& device, const Image* cImages, size_t nimages, const T
 HRESULT GenerateMipMaps(Device& device, const Image& baseImage, TEX_FILTER_FLAGS filter, size_t levels, ScratchImage& mipChain) noexcept;
 HRESULT GenerateMipMaps(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_FILTER_FLAGS filter,
                         size_t levels, ScratchImage& mipChain) noexcept;
+// volume textures (DirectXTex.h:853-858): the base slices are `depth` images of one size
+HRESULT GenerateMipMaps3D(Device& device, const Image* baseImages, size_t depth, TEX_FILTER_FLAGS filter, size_t levels, ScratchImage& mipChain) noexcept;
+HRESULT GenerateMipMaps3D(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_FILTER_FLAGS filter, size_t levels,
+                          ScratchImage& mipChain) noexcept;
 HRESULT Resize(Device& device, const Image& srcImage, size_t width, size_t height, TEX_FILTER_FLAGS filter, ScratchImage& image) noexcept;
 HRESULT Resize(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, size_t width, size_t height,
                TEX_FILTER_FLAGS filter, ScratchImage& result) noexcept;

@@ -17,7 +17,7 @@ namespace
     constexpr uint32_t kMagic = 0x20534444u;       // "DDS "
     constexpr uint32_t FOURCC = 0x4, RGB = 0x40, RGBA = 0x41, LUM = 0x20000, LUMA = 0x20001, ALPHA = 0x2, BUMPDUDV = 0x80000;
     constexpr uint32_t HF_TEXTURE = 0x1007, HF_MIPMAP = 0x20000, HF_PITCH = 0x8, HF_LINEARSIZE = 0x80000, HF_VOLUME = 0x800000;
-    constexpr uint32_t CAPS_TEXTURE = 0x1000, CAPS_MIPMAP = 0x400008, CAPS_CUBEMAP = 0x8, CAPS2_CUBEMAP_ALL = 0xFE00, CAPS2_CUBEMAP = 0x200;
+    constexpr uint32_t CAPS_TEXTURE = 0x1000, CAPS_MIPMAP = 0x400008, CAPS_CUBEMAP = 0x8, CAPS2_CUBEMAP_ALL = 0xFE00, CAPS2_CUBEMAP = 0x200, CAPS2_VOLUME = 0x200000;
 
 #pragma pack(push, 1)
     struct PixelFormat { uint32_t size, flags, fourCC, bitCount, rMask, gMask, bMask, aMask; };
@@ -100,20 +100,25 @@ namespace
                 if (x.miscFlag & TEX_MISC_TEXTURECUBE) { m.miscFlags |= TEX_MISC_TEXTURECUBE; m.arraySize *= 6; }
                 m.width = h.width; m.height = h.height; m.depth = 1; m.dimension = TEX_DIMENSION_TEXTURE2D;
                 break;
+            case TEX_DIMENSION_TEXTURE3D:
+                if (!(h.flags & HF_VOLUME)) return HRESULT(0x8007000D);                      // DirectXTexDDS.cpp:465-478
+                if (m.arraySize > 1) return HRESULT_E_NOT_SUPPORTED;
+                m.width = h.width; m.height = h.height; m.depth = h.depth; m.dimension = TEX_DIMENSION_TEXTURE3D;
+                break;
             default:
-                return HRESULT_E_NOT_SUPPORTED;           // volume textures are outside this subset
+                return HRESULT(0x8007000D);
             }
         }
         else
         {
             m.arraySize = 1;
-            if (h.flags & HF_VOLUME) return HRESULT_E_NOT_SUPPORTED;
-            if (h.caps2 & CAPS2_CUBEMAP)
+            m.width = h.width; m.height = h.height; m.depth = 1; m.dimension = TEX_DIMENSION_TEXTURE2D;
+            if (h.flags & HF_VOLUME) { m.depth = h.depth; m.dimension = TEX_DIMENSION_TEXTURE3D; }        // :497-504
+            else if (h.caps2 & CAPS2_CUBEMAP)
             {
                 if ((h.caps2 & CAPS2_CUBEMAP_ALL) != CAPS2_CUBEMAP_ALL) return HRESULT_E_NOT_SUPPORTED;      // all six faces required
                 m.arraySize = 6; m.miscFlags |= TEX_MISC_TEXTURECUBE;
             }
-            m.width = h.width; m.height = h.height; m.depth = 1; m.dimension = TEX_DIMENSION_TEXTURE2D;
             m.format = DXGI_FORMAT_UNKNOWN;
             for (const Legacy& l : kLegacy)
                 if (SamePF(l.pf, h.pf)) { m.format = l.format; break; }
@@ -121,9 +126,10 @@ namespace
             if ((h.pf.flags & FOURCC) && (h.pf.fourCC == cc('D', 'X', 'T', '2') || h.pf.fourCC == cc('D', 'X', 'T', '4')))
                 m.miscFlags2 = 2;         // TEX_ALPHA_MODE_PREMULTIPLIED
         }
-        if (!m.width || !m.height) return HRESULT(0x8007000D);
+        if (!m.width || !m.height || !m.depth) return HRESULT(0x8007000D);
         size_t full = 0;
-        if (!CalculateMipLevels(m.width, m.height, full) || m.mipLevels > full) return HRESULT(0x8007000D);
+        const bool okMips = (m.dimension == TEX_DIMENSION_TEXTURE3D) ? CalculateMipLevels3D(m.width, m.height, m.depth, full) : CalculateMipLevels(m.width, m.height, full);
+        if (!okMips || m.mipLevels > full) return HRESULT(0x8007000D);
         return S_OK;
     }
 }
@@ -177,7 +183,8 @@ HRESULT SaveToDDSMemory(const Image* images, size_t nimages, const TexMetadata& 
 {
     if (!images || !nimages) return E_INVALIDARG;
     if (BitsPerPixel(metadata.format) == 0) return E_INVALIDARG;
-    if (metadata.dimension == TEX_DIMENSION_TEXTURE3D) return HRESULT_E_NOT_SUPPORTED;
+    const bool volume = metadata.dimension == TEX_DIMENSION_TEXTURE3D;
+    if (volume && (metadata.depth > 0xFFFF || metadata.arraySize != 1)) return E_INVALIDARG;
     uint32_t fl = uint32_t(flags);
     const bool cube = (metadata.miscFlags & TEX_MISC_TEXTURECUBE) != 0;
     if (metadata.arraySize > 1 && !(metadata.arraySize == 6 && metadata.dimension == TEX_DIMENSION_TEXTURE2D && cube)) fl |= DDS_FLAGS_FORCE_DX10_EXT;
@@ -192,7 +199,12 @@ HRESULT SaveToDDSMemory(const Image* images, size_t nimages, const TexMetadata& 
     // every image with its default pitch, in ScratchImage order
     size_t payload = 0;
     std::vector<size_t> rp(nimages), sp(nimages);
-    const size_t expected = metadata.arraySize * (metadata.mipLevels ? metadata.mipLevels : 1);
+    size_t expected = metadata.arraySize * (metadata.mipLevels ? metadata.mipLevels : 1);
+    if (volume)
+    {
+        expected = 0;
+        for (size_t l = 0, d = metadata.depth; l < (metadata.mipLevels ? metadata.mipLevels : 1); ++l) { expected += d; if (d > 1) d >>= 1; }
+    }
     if (nimages != expected) return E_FAIL;
     for (size_t i = 0; i < nimages; ++i)
     {
@@ -217,6 +229,7 @@ HRESULT SaveToDDSMemory(const Image* images, size_t nimages, const TexMetadata& 
     h.width = uint32_t(metadata.width);
     h.height = (metadata.dimension == TEX_DIMENSION_TEXTURE1D) ? 1u : uint32_t(metadata.height);
     h.depth = 1;
+    if (volume) { h.flags |= HF_VOLUME; h.caps2 |= CAPS2_VOLUME; h.depth = uint32_t(metadata.depth); }      // :951-962
     if (metadata.dimension == TEX_DIMENSION_TEXTURE2D && cube) { h.caps |= CAPS_CUBEMAP; h.caps2 |= CAPS2_CUBEMAP_ALL; }
     size_t rp0, sp0;
     ComputePitch(metadata.format, metadata.width, metadata.height, rp0, sp0);

@@ -157,6 +157,20 @@ dxtex_hresult dxtex_decode_blocks(dxtex_ctx* ctx, int32_t bc_format, const uint8
 dxtex_hresult dxtex_generate_mips(dxtex_ctx* ctx, const dxtex_image* levels, size_t nlevels, uint32_t filter);
 dxtex_hresult dxtex_generate_mips_device(dxtex_ctx* ctx, const dxtex_image* levels, size_t nlevels, uint32_t filter);
 
+/* GenerateMipMaps3D (DirectXTex.h:853-858, DirectXTexMipmaps.cpp:3254-3361): volume textures. A level is `depth` slices of
+ * `slicePitch` bytes starting at `pixels` (the layout ScratchImage::Initialize3D gives a level, DirectXTexImage.cpp:228-262);
+ * levels[0] holds the base slices, levels[1..] are filled, each from the STORED previous level. Level i is
+ * max(1, w>>i) x max(1, h>>i) x max(1, d>>i). filter 0 = box when all three dimensions are powers of two, else triangle. */
+typedef struct dxtex_volume
+{
+    size_t   width, height, depth;
+    int32_t  format;
+    size_t   rowPitch, slicePitch;
+    uint8_t* pixels;
+} dxtex_volume;
+dxtex_hresult dxtex_generate_mips3d(dxtex_ctx* ctx, const dxtex_volume* levels, size_t nlevels, uint32_t filter);
+dxtex_hresult dxtex_generate_mips3d_device(dxtex_ctx* ctx, const dxtex_volume* levels, size_t nlevels, uint32_t filter);
+
 dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float threshold);
 dxtex_hresult dxtex_convert_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float threshold);
 

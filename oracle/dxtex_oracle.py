@@ -40,6 +40,10 @@ def _load_ref():
         lib.dxtex_ref_generate_mips.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_uint32, sz, vp, sz, i32p]
         lib.dxtex_ref_resize.argtypes = [vp, sz, sz, ctypes.c_int, sz, sz, sz, ctypes.c_uint32, vp, sz, i32p]
         lib.dxtex_ref_convert.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_int, ctypes.c_uint32, ctypes.c_float, vp, sz, i32p]
+        lib.dxtex_ref_save_dds_volume.argtypes = [vp, sz, sz, sz, ctypes.c_int, sz, ctypes.c_uint32, vp, sz, i32p]
+        lib.dxtex_ref_save_dds_volume.restype = ctypes.c_int64
+        lib.dxtex_ref_generate_mips3d.argtypes = [vp, sz, sz, sz, ctypes.c_int, ctypes.c_uint32, sz, vp, sz, i32p]
+        lib.dxtex_ref_generate_mips3d.restype = ctypes.c_int64
         lib.dxtex_ref_premultiply_alpha.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_uint32, vp, sz, i32p]
         lib.dxtex_ref_scale_mips_alpha.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_float, vp, sz, i32p]
         for f in (lib.dxtex_ref_compress, lib.dxtex_ref_decompress, lib.dxtex_ref_generate_mips, lib.dxtex_ref_resize, lib.dxtex_ref_convert,
@@ -349,6 +353,26 @@ def ref_convert(pixels, width, height, src_fmt, dst_fmt, filter_flags=0, thresho
     return _run(_load_ref().dxtex_ref_convert, image_bytes(dst_fmt, width, height), px.ctypes.data, width, height, src_fmt, 0, dst_fmt, filter_flags, threshold)
 
 
+def mip_sizes3d(width, height, depth, levels):
+    out = []
+    for _ in range(levels):
+        out.append((width, height, depth))
+        width, height, depth = max(1, width >> 1), max(1, height >> 1), max(1, depth >> 1)
+    return out
+
+
+def ref_generate_mips3d(volume, width, height, depth, fmt, filter_flags, levels):
+    """DirectX::GenerateMipMaps3D (DirectXTexMipmaps.cpp:3254-3361) -> list of per-level buffers (slices consecutive, tight)."""
+    px = np.ascontiguousarray(volume).view(np.uint8).reshape(-1)
+    sizes = mip_sizes3d(width, height, depth, levels)
+    blob = _run(_load_ref().dxtex_ref_generate_mips3d, sum(image_bytes(fmt, w, h) * d for w, h, d in sizes), px.ctypes.data, width, height, depth, fmt, filter_flags, levels)
+    res, at = [], 0
+    for w, h, d in sizes:
+        n = image_bytes(fmt, w, h) * d
+        res.append(blob[at:at + n].copy()); at += n
+    return res
+
+
 def ref_premultiply_alpha(pixels, width, height, fmt, flags=0):
     """DirectX::PremultiplyAlpha (DirectXTexPMAlpha.cpp:214-262); flags = TEX_PMALPHA_* (0x1 IGNORE_SRGB, 0x2 REVERSE, SRGB_IN/OUT)."""
     px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
@@ -386,6 +410,12 @@ def ref_save_dds(pixels, width, height, fmt, array_size=1, mip_levels=1, misc_fl
     px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
     assert px.size == texture_bytes(fmt, width, height, array_size, mip_levels)
     return _run(_load_ref().dxtex_ref_save_dds, px.size + 256, px.ctypes.data, width, height, fmt, array_size, mip_levels, misc_flags, dds_flags)
+
+
+def ref_save_dds_volume(pixels, width, height, depth, fmt, mip_levels=1, dds_flags=0):
+    """DirectX::SaveToDDSMemory of a volume texture given in ScratchImage order with tight pitches."""
+    px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
+    return _run(_load_ref().dxtex_ref_save_dds_volume, px.size + 256, px.ctypes.data, width, height, depth, fmt, mip_levels, dds_flags)
 
 
 def ref_load_dds(data):

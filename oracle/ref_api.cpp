@@ -181,6 +181,21 @@ extern "C"
         return int64_t(sp);
     }
 
+    // GenerateMipMaps3D (DirectXTexMipmaps.cpp:3254-3361). `pixels`: the `depth` base slices, tight pitch, consecutive.
+    // Output: the volume's images in ScratchImage order (level by level, the level's slices consecutive), tight pitch.
+    int64_t dxtex_ref_generate_mips3d(const uint8_t* pixels, size_t w, size_t h, size_t d, int fmt, uint32_t filter, size_t levels,
+                                      uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        std::vector<Image> base(d);
+        size_t rp = 0, sp = 0;
+        ComputePitch(DXGI_FORMAT(fmt), w, h, rp, sp);
+        for (size_t z = 0; z < d; ++z) base[z] = make_image(pixels + z * sp, w, h, fmt, 0);
+        ScratchImage si;
+        const HRESULT hr = GenerateMipMaps3D(base.data(), d, TEX_FILTER_FLAGS(filter), levels, si);
+        if (hrOut) *hrOut = int32_t(hr);
+        return FAILED(hr) ? -1 : copy_out(si, out, capacity);
+    }
+
     // PremultiplyAlpha (DirectXTexPMAlpha.cpp:214-262); flags = TEX_PMALPHA_*
     int64_t dxtex_ref_premultiply_alpha(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t rowPitch, uint32_t flags,
                                         uint8_t* out, size_t capacity, int32_t* hrOut)
@@ -231,6 +246,24 @@ extern "C"
         m.format = DXGI_FORMAT(fmt); m.dimension = TEX_DIMENSION_TEXTURE2D;
         ScratchImage si;
         HRESULT hr = si.Initialize(m);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        memcpy(si.GetPixels(), pixels, si.GetPixelsSize());
+        Blob blob;
+        hr = SaveToDDSMemory(si.GetImages(), si.GetImageCount(), si.GetMetadata(), DDS_FLAGS(ddsFlags), blob);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        if (blob.GetBufferSize() > capacity) return -2;
+        memcpy(out, blob.GetBufferPointer(), blob.GetBufferSize());
+        return int64_t(blob.GetBufferSize());
+    }
+
+    // the same for a volume texture: `pixels` in ScratchImage order (level by level, slices consecutive), tight pitches
+    int64_t dxtex_ref_save_dds_volume(const uint8_t* pixels, size_t w, size_t h, size_t d, int fmt, size_t mipLevels, uint32_t ddsFlags,
+                                      uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        ScratchImage si;
+        HRESULT hr = si.Initialize3D(DXGI_FORMAT(fmt), w, h, d, mipLevels);
         if (hrOut) *hrOut = int32_t(hr);
         if (FAILED(hr)) return -1;
         memcpy(si.GetPixels(), pixels, si.GetPixelsSize());

@@ -48,6 +48,17 @@ static int cpu_checks()
     CHECK(si.Initialize2D(DXGI_FORMAT_BC3_UNORM, 0, 4, 1, 1) == E_INVALIDARG);
     CHECK(si.Initialize2D(DXGI_FORMAT_BC3_UNORM, 9, 9, 1, 0) == S_OK && si.GetMetadata().mipLevels == 4 && si.GetImage(3, 0, 0)->slicePitch == 16);
 
+    // volumes: level by level, the level's slices consecutive (DirectXTexImage.cpp:228-262, DirectXTexUtil.cpp:1714-1738)
+    ScratchImage v3;
+    CHECK(v3.Initialize3D(DXGI_FORMAT_R8G8B8A8_UNORM, 16, 8, 4, 0) == S_OK);
+    CHECK(v3.GetMetadata().mipLevels == 5 && v3.GetImageCount() == 4 + 2 + 1 + 1 + 1 && v3.GetMetadata().dimension == TEX_DIMENSION_TEXTURE3D);
+    CHECK(v3.GetImage(0, 0, 3)->pixels == v3.GetPixels() + 3 * 16 * 8 * 4 && v3.GetImage(1, 0, 0)->pixels == v3.GetPixels() + 4 * 16 * 8 * 4);
+    CHECK(v3.GetImage(1, 0, 1)->width == 8 && v3.GetImage(1, 0, 2) == nullptr && v3.GetImage(4, 0, 0)->width == 1 && v3.GetImage(0, 1, 0) == nullptr);
+    CHECK(v3.GetMetadata().ComputeIndex(2, 0, 0) == 6 && v3.GetMetadata().ComputeIndex(3, 0, 0) == 7);
+    lv = 0; CHECK(CalculateMipLevels3D(4, 2, 32, lv) && lv == 6);
+    lv = 7; CHECK(!CalculateMipLevels3D(4, 2, 32, lv));
+    CHECK(v3.Initialize3D(DXGI_FORMAT_R8G8B8A8_UNORM, 4, 4, 0, 1) == E_INVALIDARG);
+
     // without a device every entry point refuses to work: there is no CPU path
     Device none;
     ScratchImage out;
@@ -119,6 +130,30 @@ static int gpu_run(const std::string& outdir)
         CHECK(PremultiplyAlpha(dev, one, TEX_PMALPHA_DEFAULT, r8) == HRESULT_E_NOT_SUPPORTED);
     }
 
+    // a volume texture: 8 slices cut from the image, GenerateMipMaps3D, DDS round trip
+    {
+        const size_t VW = 32, VH = 16, VD = 8;
+        std::vector<Image> slices(VD);
+        for (size_t z = 0; z < VD; ++z)
+        {
+            slices[z] = src; slices[z].width = VW; slices[z].height = VH;
+            slices[z].pixels = px.data() + (z * 4) * src.rowPitch + (z * 8) * 4;           // a shifted window per slice
+        }
+        ScratchImage vol, volBack;
+        CHECK(GenerateMipMaps3D(dev, slices.data(), VD, TEX_FILTER_CUBIC, 0, vol) == S_OK);
+        CHECK(vol.GetMetadata().dimension == TEX_DIMENSION_TEXTURE3D && vol.GetMetadata().mipLevels == 6 && vol.GetImageCount() == 8 + 4 + 2 + 1 + 1 + 1);
+        CHECK(vol.GetImage(1, 0, 3) != nullptr && vol.GetImage(1, 0, 4) == nullptr && vol.GetImage(5, 0, 0)->width == 1);
+        dump(outdir + "/volume_mips.bin", vol.GetPixels(), vol.GetPixelsSize());
+        const std::string f = outdir + "/volume.dds";
+        CHECK(SaveToDDSFile(vol.GetImages(), vol.GetImageCount(), vol.GetMetadata(), DDS_FLAGS_NONE, f.c_str()) == S_OK);
+        TexMetadata vm;
+        CHECK(LoadFromDDSFile(f.c_str(), DDS_FLAGS_NONE, &vm, volBack) == S_OK);
+        CHECK(vm.dimension == TEX_DIMENSION_TEXTURE3D && vm.depth == VD && vm.mipLevels == 6 && volBack.GetPixelsSize() == vol.GetPixelsSize());
+        CHECK(std::memcmp(volBack.GetPixels(), vol.GetPixels(), vol.GetPixelsSize()) == 0);
+        ScratchImage bad3;
+        CHECK(GenerateMipMaps3D(dev, slices.data(), 7, TEX_FILTER_BOX, 0, bad3) == E_FAIL);          // 7 slices: not a power of two
+    }
+
     float mse = 0, v[4];
     CHECK(ComputeMSE(dev, src, *bc7.GetImage(0, 0, 0), mse, v) == S_OK);
     std::printf("mse %.9g %.9g %.9g %.9g %.9g\n", mse, v[0], v[1], v[2], v[3]);
@@ -141,6 +176,7 @@ static int dds_save(char** a)
     const size_t w = std::strtoull(a[1], nullptr, 10), h = std::strtoull(a[2], nullptr, 10);
     TexMetadata m; m.width = w; m.height = h; m.depth = 1; m.format = DXGI_FORMAT(std::atoi(a[3]));
     m.arraySize = std::strtoull(a[4], nullptr, 10); m.mipLevels = std::strtoull(a[5], nullptr, 10); m.miscFlags = uint32_t(std::strtoul(a[6], nullptr, 0));
+    if (a[9]) { m.depth = std::strtoull(a[9], nullptr, 10); m.dimension = TEX_DIMENSION_TEXTURE3D; }      // optional 10th argument: a volume
     ScratchImage si;
     HRESULT hr = si.Initialize(m);
     if (FAILED(hr)) { std::printf("hr %08x\n", unsigned(hr)); return 3; }

@@ -46,6 +46,11 @@ def test_host_layer_on_gpu(tmp_path, oracle):
     assert np.array_equal(rd("resized_linear_array.bin"), oracle.ref_resize(mips[0], W, H, 28, 40, 24, 0x200000).reshape(-1))
     assert np.array_equal(rd("premultiplied.bin"), oracle.ref_premultiply_alpha(src, W, H, 28, 0))
     assert np.array_equal(rd("mips_coverage.bin"), np.concatenate(oracle.ref_scale_mips_alpha_for_coverage(mips, W, H, 28, 0.6)))
+    img = src.reshape(H, W, 4)
+    vol = np.stack([img[z * 4:z * 4 + 16, z * 8:z * 8 + 32] for z in range(8)])
+    vmips = oracle.ref_generate_mips3d(vol, 32, 16, 8, 28, 0x300000, 6)
+    assert np.array_equal(rd("volume_mips.bin"), np.concatenate(vmips))
+    assert np.array_equal(rd("volume.dds"), oracle.ref_save_dds_volume(np.concatenate(vmips), 32, 16, 8, 28, 6, 0))
     line = [l for l in r.stdout.splitlines() if l.startswith("mse ")][0].split()
     got = np.array([float(x) for x in line[2:6]])
     ref = oracle.ref_compute_mse(src, 28, oracle.ref_decompress_image(bc7, W, H, 98, 28), 28, W, H)

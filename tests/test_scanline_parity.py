@@ -174,3 +174,36 @@ def test_scale_mips_alpha_for_coverage(ctx, oracle, fmt, ref_alpha):
     for lvl, (g, r) in enumerate(zip(got, ref)):
         assert np.array_equal(g, r), (fmt, lvl)
     assert any((g != m).any() for g, m in zip(got[1:], mips[1:]))      # some level really was rescaled
+
+
+# ---- GenerateMipMaps3D ------------------------------------------------------------------------------
+def _volume(w, h, d, fmt, seed):
+    return np.stack([_image(w, h, fmt, seed + 31 * z) for z in range(d)])
+
+
+@pytest.mark.parametrize("flt", [0, POINT, BOX, LINEAR, CUBIC, TRIANGLE, LINEAR | WRAP | 0x4, CUBIC | MIRROR | 0x40, TRIANGLE | WRAP | 0x4])
+@pytest.mark.parametrize("dims", [(16, 8, 8), (8, 8, 2), (4, 2, 8), (32, 1, 4), (2, 16, 16), (12, 10, 6), (5, 3, 7)])
+@pytest.mark.parametrize("fmt", [RGBA8, RGBA32F])
+def test_generate_mips3d(ctx, oracle, fmt, dims, flt):
+    w, h, d = dims
+    pow2 = all(v & (v - 1) == 0 for v in dims)
+    if (flt & 0xF00000) == BOX and not pow2:
+        pytest.skip("the box filter needs power-of-two dimensions")
+    if h == 1 and (flt & 0xF00000) in (BOX, 0):
+        pytest.skip("W x 1 x D base with the box filter: the reference averages uninitialised scanline buffers")
+    n = 1 + int(np.floor(np.log2(max(dims))))
+    vol = _volume(w, h, d, fmt, seed=w * 5 + h * 3 + d)
+    got = ctx.generate_mips3d(vol, w, h, d, fmt, n, flt)
+    ref = oracle.ref_generate_mips3d(vol, w, h, d, fmt, flt, n)
+    for lvl in range(n):
+        assert np.array_equal(got[lvl], ref[lvl]), (fmt, dims, hex(flt), lvl, np.nonzero(got[lvl] != ref[lvl])[0][:8])
+
+
+def test_generate_mips3d_errors(ctx):
+    vol = _volume(6, 4, 2, RGBA8, 3)
+    with pytest.raises(dx.DxtexError) as e:
+        ctx.generate_mips3d(vol, 6, 4, 2, RGBA8, 3, BOX)
+    assert e.value.hresult & 0xFFFFFFFF == 0x80004005        # E_FAIL, DirectXTexMipmaps.cpp:1831-1832
+    with pytest.raises(dx.DxtexError) as e:
+        ctx.generate_mips3d(vol, 6, 4, 2, RGBA8, 5, LINEAR)
+    assert e.value.hresult & 0xFFFFFFFF == 0x80070057        # E_INVALIDARG: more levels than CalculateMipLevels3D allows
