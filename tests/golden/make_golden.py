@@ -51,6 +51,8 @@ def cases():
     for flags in (0, 1, 2, 3):
         out.append((f"pmalpha/{flags}/a", "pmalpha", "a", {"flags": flags}))
     out.append(("coverage/0.4/b", "coverage", "b", {"ref": 0.4, "levels": 6}))
+    for flt in (0x100000, 0x200000, 0x300000, 0x400000, 0x500000):
+        out.append((f"mips3d/{flt:#x}/b", "mips3d", "b", {"filter": flt, "w": 16, "h": 8, "d": 8}))         # `b` read as 8 slices of 16 x 8
     return out
 
 
@@ -69,6 +71,9 @@ def run_case(kind, arr, w, h, fmt, p, api):
         return bytes(api.convert(arr, w, h, fmt, p["dst"]))
     if kind == "pmalpha":
         return bytes(api.pmalpha(arr, w, h, fmt, p["flags"]))
+    if kind == "mips3d":
+        vol = np.ascontiguousarray(arr).reshape(-1)[: p["w"] * p["h"] * p["d"] * 4]
+        return b"".join(bytes(l) for l in api.mips3d(vol, p["w"], p["h"], p["d"], fmt, p["filter"], 5))
     if kind == "coverage":
         return b"".join(bytes(l) for l in api.coverage(api.mips(arr, w, h, fmt, 0x400000, p["levels"]), w, h, fmt, p["ref"]))
     raise ValueError(kind)
@@ -83,6 +88,7 @@ class RefApi:
     def mips(self, a, w, h, f, flt, levels):
         n = levels or len(self.o.mip_sizes(w, h, 32)[: 1 + int(np.floor(np.log2(max(w, h))))])
         return self.o.ref_generate_mips(a, w, h, f, flt, n)
+    def mips3d(self, v, w, h, d, f, flt, n): return self.o.ref_generate_mips3d(v, w, h, d, f, flt, n)
     def resize(self, a, w, h, f, nw, nh, flt): return self.o.ref_resize(a, w, h, f, nw, nh, flt)
     def convert(self, a, w, h, f, dst): return self.o.ref_convert(a, w, h, f, dst, 0, 0.5)
     def pmalpha(self, a, w, h, f, flags): return self.o.ref_premultiply_alpha(a, w, h, f, flags)
