@@ -992,8 +992,8 @@ DXTEX_HD void for_masked(uint32_t mask16, F&& f)
     }
     else
     {
-        for (int i = 0; i < 16; ++i)
-            if ((mask16 >> i) & 1u) f(i);
+        // set bits in ascending order: the trip count is the subset size, not 16 (the texels live in LDS, any index is fine)
+        for (uint32_t m = mask16 & 0xFFFFu; m; m &= m - 1u) f(int(__builtin_ctz(m)));
     }
 }
 
