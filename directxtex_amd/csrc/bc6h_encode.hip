@@ -107,26 +107,25 @@ __global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
     const float* planes = sP[wave];
     float* slot = &sSlot[wave][lane];
 
-    // lanes 0..31: two-region shape `lane`; lane 32: the one-region case
-    EndPts seed[2];
-    float rough = 0.0f;
-    const int nreg = (lane < 32) ? 2 : (lane == 32 ? 1 : 0);
-    const uint32_t m1 = (lane < 32) ? uint32_t(kPart2Mask[lane & 31]) : 0u;
-#pragma unroll 1
-    for (int r = 0; r < nreg; ++r)
+    // lane = shape + 32 * region: every lane fits ONE subset of a two-region shape (the one-region fit has a kernel of its own,
+    // bc6h_block_seed_kernel, so that it does not cost this wavefront a second full pass with one lane active)
+    const uint32_t shape = uint32_t(lane) & 31u, region = uint32_t(lane) >> 5;
+    const uint32_t m1 = uint32_t(kPart2Mask[shape]);
+    const uint32_t mask = region ? m1 : ((~m1) & 0xFFFFu);
+    EndPts seed;
+    float part = 0.0f;
+    bool ranked = false;
     {
-        const uint32_t mask = (lane < 32) ? (r ? m1 : ((~m1) & 0xFFFFu)) : 0xFFFFu;
         uint64_t pos;
         const int np = gather_texels(planes, mask, slot, pos);
-        EndPts s;
         if (np == 1)
         {
-            s.A[0] = s.B[0] = int(slot[0]); s.A[1] = s.B[1] = int(slot[16 * 64]); s.A[2] = s.B[2] = int(slot[32 * 64]);
+            seed.A[0] = seed.B[0] = int(slot[0]); seed.A[1] = seed.B[1] = int(slot[16 * 64]); seed.A[2] = seed.B[2] = int(slot[32 * 64]);
         }
         else if (np == 2)
         {
-            s.A[0] = int(slot[0]); s.A[1] = int(slot[16 * 64]); s.A[2] = int(slot[32 * 64]);
-            s.B[0] = int(slot[64]); s.B[1] = int(slot[17 * 64]); s.B[2] = int(slot[33 * 64]);
+            seed.A[0] = int(slot[0]); seed.A[1] = int(slot[16 * 64]); seed.A[2] = int(slot[32 * 64]);
+            seed.B[0] = int(slot[64]); seed.B[1] = int(slot[17 * 64]); seed.B[2] = int(slot[33 * 64]);
         }
         else
         {
@@ -135,33 +134,64 @@ __global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
 #pragma unroll
             for (int c = 0; c < 3; ++c)
             {
-                s.A[c] = clamp_seed(float_to_int16f(X[c], sg), sg);
-                s.B[c] = clamp_seed(float_to_int16f(Y[c], sg), sg);
+                seed.A[c] = clamp_seed(float_to_int16f(X[c], sg), sg);
+                seed.B[c] = clamp_seed(float_to_int16f(Y[c], sg), sg);
             }
-            // one-region modes are never ranked, their rough error is not needed
-            if (lane < 32) rough += rough_error6<8>(slot_texels(slot, np), s);
+            part = rough_error6<8>(slot_texels(slot, np), seed);
+            ranked = true;
         }
-        seed[r] = s;
     }
+    // RoughMSE's total (:2523-2556): fError += error of region 0, then of region 1; regions of one or two texels add nothing
+    const float p1 = __shfl(part, int(shape + 32u));
+    const int r1 = __shfl(int(ranked), int(shape + 32u));
+    float rough = 0.0f;
+    if (ranked) rough += part;
+    if (r1) rough += p1;
 
     int key = (lane < 32) ? __float_as_int(rough) : 0x7FFFFFFF;
     uint32_t shp = uint32_t(lane);
     for (int i = 0; i < 8; ++i) selection_pass(key, shp, lane, i);
     int* sd = a.seeds + uint64_t(nb) * SEED_INTS;
-    // lane i < 8 now knows the i-th best shape; its seeds still sit in lane `shp`
+    // lane i < 8 now knows the i-th best shape; its seeds still sit in lanes `shp` (region 0) and `shp + 32` (region 1)
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c)
         {
-            const int va = __shfl(seed[r].A[c], int(shp)), vb = __shfl(seed[r].B[c], int(shp));
+            const int from = int((shp & 31u) + 32u * uint32_t(r));
+            const int va = __shfl(seed.A[c], from), vb = __shfl(seed.B[c], from);
             if (lane < 8) { sd[(lane * 2 + r) * 6 + c] = va; sd[(lane * 2 + r) * 6 + 3 + c] = vb; }
         }
     if (lane < 8) a.lists[uint64_t(nb) * 8 + lane] = uint8_t(shp);
-    if (lane == 32)
-    {
+}
+
+// The one-region seed (:2513-2521 with uPartitions == 0): the whole block fitted once, one lane per block, texels in registers.
+__global__ void __launch_bounds__(256) bc6h_block_seed_kernel(Bc6hArgs a)
+{
+    const uint32_t nb = blockIdx.x * 256u + threadIdx.x;
+    if (nb >= a.nblocks) return;
+    const bool sg = a.isSigned != 0;
+    const BcSeg& im = seg_of(a.seg, nb);
+    const uint32_t gb = im.nb0 + (nb - im.l0);
+    const uint32_t by = gb / im.nbw, bx = gb - by * im.nbw;
+    const uint32_t x0 = bx * 4, y0 = by * 4;
+    const uint32_t pw = min(4u, im.src.width - x0), ph = min(4u, im.src.height - y0);
+    float f[64];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { sd[16 * 6 + c] = seed[0].A[c]; sd[16 * 6 + 3 + c] = seed[0].B[c]; }
+    for (uint32_t t = 0; t < 16; ++t)
+    {
+        const uint32_t sx = x0 + replicate_src(t & 3, pw), sy = y0 + replicate_src(t >> 2, ph);
+        const Texel px = convert_texel(load_texel(im.src.pixels + uint64_t(sy) * im.src.rowPitch, sx, im.src.format), im.src.tcv, im.src.tsw);
+        f[t * 4 + 0] = px.r; f[t * 4 + 1] = px.g; f[t * 4 + 2] = px.b; f[t * 4 + 3] = px.a;
+    }
+    float X[4], Y[4];
+    bc7::seed_fit<false, true>(f, 0xFFFFu, X, Y);
+    int* sd = a.seeds + uint64_t(nb) * SEED_INTS;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+    {
+        sd[16 * 6 + c] = clamp_seed(float_to_int16f(X[c], sg), sg);
+        sd[16 * 6 + 3 + c] = clamp_seed(float_to_int16f(Y[c], sg), sg);
     }
 }
 
@@ -534,6 +564,8 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
 
         DXTEX_MARK("bc6h_rough");
         hipLaunchKernelGGL(bc6h_rough_kernel, dim3((a.nblocks + 3) / 4), dim3(256), 0, stream, a);
+        DXTEX_MARK("bc6h_block_seed");
+        hipLaunchKernelGGL(bc6h_block_seed_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, stream, a);
         if (getenv("DXTEX_BC6H_DUMP"))     // development aid: rank lists and seeds of the first blocks
         {
             (void)hipStreamSynchronize(stream);
