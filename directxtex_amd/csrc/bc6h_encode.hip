@@ -34,6 +34,7 @@ using namespace bc6h;
 
 struct Rec6 { int A[3], B[3]; float err; uint32_t valid; };        // 32 bytes per task
 struct Best6 { float err; uint32_t pad; uint64_t lo, hi; };        // 24 bytes per block
+struct OrgSave { int A[3], B[3]; float err; uint32_t pad; uint64_t idx; };      // 40 bytes per task: Refine's unoptimised half, pre -> post
 
 enum : int { SEED_INTS = 17 * 6 + 2 };      // 8 shapes x 2 regions + the one-region seed, 6 ints each (+ pad)
 
@@ -47,6 +48,7 @@ struct Bc6hArgs
     uint8_t* lists;         // nblocks x 8 shape ids
     int* seeds;             // nblocks x SEED_INTS
     Rec6* recs;
+    OrgSave* orgs;          // per task: endpoints (after SwapIndices), error and indices of the unoptimised candidate
     uint2* order; uint32_t* tinfo; uint32_t* counters;
     Best6* best;
     ModeRt mode;
@@ -256,7 +258,7 @@ struct Org6
 
 // Refine's first half (:2386-2393) for this lane's region; needs the partner lane of the candidate for the transform.
 template<int REGIONS2>
-__device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, uint32_t r, const float* planes, float* slot, Org6& o)
+__device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, uint32_t r, const float* planes, float* slot, Org6& o, const OrgSave* saved = nullptr)
 {
     typedef Lay6<REGIONS2> L;
     const bool sg = a.isSigned != 0;
@@ -266,14 +268,25 @@ __device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, ui
     o.mask = REGIONS2 ? (region ? m1 : ((~m1) & 0xFFFFu)) : 0xFFFFu;
     o.anchor = (REGIONS2 && region) ? uint32_t(kAnchor2[o.shape]) : 0u;
     const int* sd = a.seeds + uint64_t(nb) * SEED_INTS + (REGIONS2 ? (rank * 2 + region) * 6 : 16 * 6);
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-    {
-        o.ep.A[c] = quantize(sd[c], a.mode.prec, sg);
-        o.ep.B[c] = quantize(sd[3 + c], a.mode.prec, sg);
-    }
     o.np = gather_texels(planes, o.mask, slot, o.pos);
-    o.err = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, o.ep, a.mode.prec, sg, o.anchor, o.idx);
+    if (saved)
+    {
+        // post: the pre kernel of this mode already quantised the seeds and assigned the indices
+        const OrgSave sv = *saved;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o.ep.A[c] = sv.A[c]; o.ep.B[c] = sv.B[c]; }
+        o.err = sv.err; o.idx = sv.idx;
+    }
+    else
+    {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+        {
+            o.ep.A[c] = quantize(sd[c], a.mode.prec, sg);
+            o.ep.B[c] = quantize(sd[3 + c], a.mode.prec, sg);
+        }
+        o.err = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, o.ep, a.mode.prec, sg, o.anchor, o.idx);
+    }
     int a0[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) a0[c] = REGIONS2 ? __shfl(o.ep.A[c], (threadIdx.x & 63) & ~1) : o.ep.A[c];
@@ -325,6 +338,13 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
     }
     if (!inRange) return;
     const uint64_t t = uint64_t(nb) * L::TPB + r;
+    {
+        OrgSave sv;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sv.A[c] = o.ep.A[c]; sv.B[c] = o.ep.B[c]; }
+        sv.err = o.err; sv.pad = 0; sv.idx = o.idx;
+        a.orgs[t] = sv;
+    }
     Rec6 rec;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { rec.A[c] = o.ep.A[c]; rec.B[c] = o.ep.B[c]; }
@@ -358,7 +378,7 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     for (int i = 0; i < 12; ++i) { const float4 v = gp[i]; planes[4 * i] = v.x; planes[4 * i + 1] = v.y; planes[4 * i + 2] = v.z; planes[4 * i + 3] = v.w; }
     float* slot = &sSlot[wave][lane];
     Org6 o;
-    org_candidate<REGIONS2>(a, nb, r, planes, slot, o);
+    org_candidate<REGIONS2>(a, nb, r, planes, slot, o, a.orgs + uint64_t(nb) * L::TPB + r);
 
     // the optimised endpoints (== the org ones where no search ran)
     const Rec6 rec = a.recs[uint64_t(nb) * L::TPB + r];
@@ -502,7 +522,7 @@ __global__ void __launch_bounds__(256) bc6h_store_kernel(Bc6hArgs a)
 const uint64_t kMaxBlocksPerPass6 = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(getenv("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 22);
 struct Scratch6
 {
-    size_t fpix, lists, seeds, recs, order, tinfo, counters, best, total;
+    size_t fpix, lists, seeds, recs, orgs, order, tinfo, counters, best, total;
     explicit Scratch6(uint64_t nb)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -511,6 +531,7 @@ struct Scratch6
         lists = o; o = up(o + nb * 8);
         seeds = o; o = up(o + nb * SEED_INTS * sizeof(int));
         recs = o; o = up(o + nb * 16 * sizeof(Rec6));
+        orgs = o; o = up(o + nb * 16 * sizeof(OrgSave));
         order = o; o = up(o + nb * 16 * sizeof(uint2));
         tinfo = o; o = up(o + nb * 16 * sizeof(uint32_t));
         counters = o; o = up(o + 64 * sizeof(uint32_t));
@@ -556,6 +577,7 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         a.lists = base + L.lists;
         a.seeds = reinterpret_cast<int*>(base + L.seeds);
         a.recs = reinterpret_cast<Rec6*>(base + L.recs);
+        a.orgs = reinterpret_cast<OrgSave*>(base + L.orgs);
         a.order = reinterpret_cast<uint2*>(base + L.order);
         a.tinfo = reinterpret_cast<uint32_t*>(base + L.tinfo);
         a.counters = reinterpret_cast<uint32_t*>(base + L.counters);
