@@ -44,6 +44,8 @@ struct Bc6hArgs
     uint32_t nblocks;       // blocks in this pass; scratch arrays are indexed by pass-local block number
     int isSigned;
     int prune;              // 0 = search every candidate like the reference does (DXTEX_BC6H_NO_PRUNE, for A/B runs)
+    uint32_t taskBase;      // one-region modes: the four modes' tasks share the arrays, mode slot m owns [m * nblocks, (m + 1) * nblocks)
+    int prec1[4];           // ... and the search kernel runs them as ONE list: endpoint precision of mode slot m
     float* fpix;            // nblocks x 3 x 16: the block's texels as INTColor values held in floats (r[16], g[16], b[16])
     uint8_t* lists;         // nblocks x 8 shape ids
     int* seeds;             // nblocks x SEED_INTS
@@ -337,7 +339,7 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
         prune = lb > table;
     }
     if (!inRange) return;
-    const uint64_t t = uint64_t(nb) * L::TPB + r;
+    const uint64_t t = REGIONS2 ? uint64_t(nb) * L::TPB + r : uint64_t(a.taskBase) + nb;
     {
         OrgSave sv;
 #pragma unroll
@@ -356,6 +358,8 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
     const uint32_t smask = region0 ? 0xFFFFu : o.mask;
     uint32_t snp = (o.fit && o.err > 0.0f) ? uint32_t(region0 ? 16 : o.np) : 0u;
     if (prune) snp = 0;
+    // one-region tasks are sorted by mode slot instead (13 + slot: the 16-bit mode, the longest search, goes first); all have 16 texels
+    if (!REGIONS2 && snp) snp = 13u + a.taskBase / a.nblocks;
     a.tinfo[t] = smask | (snp << 24);
 }
 
@@ -378,10 +382,11 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     for (int i = 0; i < 12; ++i) { const float4 v = gp[i]; planes[4 * i] = v.x; planes[4 * i + 1] = v.y; planes[4 * i + 2] = v.z; planes[4 * i + 3] = v.w; }
     float* slot = &sSlot[wave][lane];
     Org6 o;
-    org_candidate<REGIONS2>(a, nb, r, planes, slot, o, a.orgs + uint64_t(nb) * L::TPB + r);
+    const uint64_t t = REGIONS2 ? uint64_t(nb) * L::TPB + r : uint64_t(a.taskBase) + nb;
+    org_candidate<REGIONS2>(a, nb, r, planes, slot, o, a.orgs + t);
 
     // the optimised endpoints (== the org ones where no search ran)
-    const Rec6 rec = a.recs[uint64_t(nb) * L::TPB + r];
+    const Rec6 rec = a.recs[t];
     EndPts opt;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { opt.A[c] = rec.A[c]; opt.B[c] = rec.B[c]; }
@@ -461,6 +466,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a)
     Perturb6 st = perturb6_begin(zero, 0.0f);
     Texels tx = slot_texels(slot, 0);
     uint32_t myTask = 0xFFFFFFFFu;
+    int prec = a.mode.prec;
     WaveQueue q; q.lo = q.hi = 0; q.drained = false;
     for (;;)
     {
@@ -473,7 +479,8 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a)
                 const uint2 task = a.order[idx];
                 myTask = task.x;
                 const Rec6 rec = a.recs[myTask];
-                const uint32_t nb = myTask / uint32_t(TPB);
+                const uint32_t nb = (N == 8) ? myTask / uint32_t(TPB) : myTask % a.nblocks;
+                prec = (N == 8) ? a.mode.prec : a.prec1[myTask / a.nblocks];
                 float planes[48];
                 const float4* gp = reinterpret_cast<const float4*>(a.fpix + uint64_t(nb) * 48);
 #pragma unroll
@@ -494,7 +501,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a)
         if (myTask != 0xFFFFFFFFu)
         {
             float e; int v;
-            perturb6_macro<N>(tx, st, a.mode.prec, sg, e, v);
+            perturb6_macro<N>(tx, st, prec, sg, e, v);
             st = perturb6_transition(st, e, v);
             if (st.ch >= 3)
             {
@@ -606,40 +613,71 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         }
         static const int onlyMode = getenv("DXTEX_BC6H_ONLY_MODE") ? atoi(getenv("DXTEX_BC6H_ONLY_MODE")) : -1;     // development aid
         static const bool noSearch = getenv("DXTEX_BC6H_NO_SEARCH") != nullptr;
-        for (int mi = 0; mi < 14; ++mi)
+        static const Bc6hMode kModes[14] = {
+            { 0x00, 1, 1, 3, { 10, 10, 10 }, { 5, 5, 5 } }, { 0x01, 1, 1, 3, { 7, 7, 7 }, { 6, 6, 6 } }, { 0x02, 1, 1, 3, { 11, 11, 11 }, { 5, 4, 4 } },
+            { 0x06, 1, 1, 3, { 11, 11, 11 }, { 4, 5, 4 } }, { 0x0a, 1, 1, 3, { 11, 11, 11 }, { 4, 4, 5 } }, { 0x0e, 1, 1, 3, { 9, 9, 9 }, { 5, 5, 5 } },
+            { 0x12, 1, 1, 3, { 8, 8, 8 }, { 6, 5, 5 } }, { 0x16, 1, 1, 3, { 8, 8, 8 }, { 5, 6, 5 } }, { 0x1a, 1, 1, 3, { 8, 8, 8 }, { 5, 5, 6 } },
+            { 0x1e, 1, 0, 3, { 6, 6, 6 }, { 6, 6, 6 } }, { 0x03, 0, 0, 4, { 10, 10, 10 }, { 10, 10, 10 } }, { 0x07, 0, 1, 4, { 11, 11, 11 }, { 9, 9, 9 } },
+            { 0x0b, 0, 1, 4, { 12, 12, 12 }, { 8, 8, 8 } }, { 0x0f, 0, 1, 4, { 16, 16, 16 }, { 4, 4, 4 } } };     // == kBc6hModes (device table), host copy
+        auto set_mode = [&](int mi)
         {
-            if (onlyMode >= 0 && mi != onlyMode) continue;
-            static const Bc6hMode kModes[14] = {
-                { 0x00, 1, 1, 3, { 10, 10, 10 }, { 5, 5, 5 } }, { 0x01, 1, 1, 3, { 7, 7, 7 }, { 6, 6, 6 } }, { 0x02, 1, 1, 3, { 11, 11, 11 }, { 5, 4, 4 } },
-                { 0x06, 1, 1, 3, { 11, 11, 11 }, { 4, 5, 4 } }, { 0x0a, 1, 1, 3, { 11, 11, 11 }, { 4, 4, 5 } }, { 0x0e, 1, 1, 3, { 9, 9, 9 }, { 5, 5, 5 } },
-                { 0x12, 1, 1, 3, { 8, 8, 8 }, { 6, 5, 5 } }, { 0x16, 1, 1, 3, { 8, 8, 8 }, { 5, 6, 5 } }, { 0x1a, 1, 1, 3, { 8, 8, 8 }, { 5, 5, 6 } },
-                { 0x1e, 1, 0, 3, { 6, 6, 6 }, { 6, 6, 6 } }, { 0x03, 0, 0, 4, { 10, 10, 10 }, { 10, 10, 10 } }, { 0x07, 0, 1, 4, { 11, 11, 11 }, { 9, 9, 9 } },
-                { 0x0b, 0, 1, 4, { 12, 12, 12 }, { 8, 8, 8 } }, { 0x0f, 0, 1, 4, { 16, 16, 16 }, { 4, 4, 4 } } };     // == kBc6hModes (device table), host copy
             const Bc6hMode& k = kModes[mi];
             a.mode.index = mi; a.mode.code = k.code; a.mode.regions2 = k.regions2; a.mode.transformed = k.transformed; a.mode.prec = k.prec[0];
             for (int c = 0; c < 3; ++c) a.mode.delta[c] = k.delta[c];
-            const uint32_t tpb = k.regions2 ? 16u : 1u, bpw = 64u / tpb;
-            const uint32_t ntasks = a.nblocks * tpb;
-            const uint32_t gridPP = (a.nblocks + 4 * bpw - 1) / (4 * bpw);
+        };
+        auto sort_tasks = [&](uint32_t ntasks)
+        {
             const uint32_t binGroups = std::min<uint32_t>(kBinGroups, (ntasks + 255) / 256);
-            const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
-            static const char* const nPre[2] = { "bc6h_pre_1region", "bc6h_pre_2region" }, * const nBin[2] = { "bc6h_bin_1region", "bc6h_bin_2region" },
-                             * const nPer[2] = { "bc6h_perturb_1region", "bc6h_perturb_2region" }, * const nPost[2] = { "bc6h_post_1region", "bc6h_post_2region" };
-            DXTEX_MARK(nPre[k.regions2]);
-            if (k.regions2) hipLaunchKernelGGL(bc6h_pre_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL(bc6h_pre_kernel<0>, dim3(gridPP), dim3(256), 0, stream, a);
-            DXTEX_MARK(nBin[k.regions2]);
             (void)hipMemsetAsync(a.counters, 0, 64 * sizeof(uint32_t), stream);
             hipLaunchKernelGGL(bc7_bin_count_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters);
             hipLaunchKernelGGL(bc7_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a.counters);
             hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order);
-            DXTEX_MARK(nPer[k.regions2]);
-            if (noSearch) {}
-            else if (k.regions2) hipLaunchKernelGGL(bc6h_perturb_kernel<8>, dim3(waves), dim3(64), 0, stream, a);
-            else hipLaunchKernelGGL(bc6h_perturb_kernel<16>, dim3(waves), dim3(64), 0, stream, a);
-            DXTEX_MARK(nPost[k.regions2]);
-            if (k.regions2) hipLaunchKernelGGL(bc6h_post_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL(bc6h_post_kernel<0>, dim3(gridPP), dim3(256), 0, stream, a);
+        };
+        a.taskBase = 0;
+        for (int m = 0; m < 4; ++m) a.prec1[m] = kModes[10 + m].prec[0];
+        // the ten two-region modes, one after the other: pre -> sort -> search -> post (post folds the mode into the running best)
+        for (int mi = 0; mi < 10; ++mi)
+        {
+            if (onlyMode >= 0 && mi != onlyMode) continue;
+            set_mode(mi);
+            const uint32_t ntasks = a.nblocks * 16u;
+            const uint32_t gridPP = (a.nblocks + 15) / 16;
+            DXTEX_MARK("bc6h_pre_2region");
+            hipLaunchKernelGGL(bc6h_pre_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
+            DXTEX_MARK("bc6h_bin_2region");
+            sort_tasks(ntasks);
+            DXTEX_MARK("bc6h_perturb_2region");
+            if (!noSearch) hipLaunchKernelGGL(bc6h_perturb_kernel<8>, dim3(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64)), dim3(64), 0, stream, a);
+            DXTEX_MARK("bc6h_post_2region");
+            hipLaunchKernelGGL(bc6h_post_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
+        }
+        // The four one-region modes have ONE task per block each - a long serial chain on one lane - so a search kernel per mode would
+        // only be as fast as its slowest lane. Their pre kernels run first (each prunes against the best of the two-region modes),
+        // the four task lists are searched as one list (4x the tasks per lane, sorted by mode), then the posts fold the modes into
+        // the running best in the reference's order.
+        {
+            const uint32_t gridPP = (a.nblocks + 255) / 256;
+            DXTEX_MARK("bc6h_pre_1region");
+            for (int m = 0; m < 4; ++m)
+            {
+                if (onlyMode >= 0 && 10 + m != onlyMode) continue;
+                set_mode(10 + m); a.taskBase = uint32_t(m) * a.nblocks;
+                hipLaunchKernelGGL(bc6h_pre_kernel<0>, dim3(gridPP), dim3(256), 0, stream, a);
+            }
+            const uint32_t ntasks = a.nblocks * 4u;
+            if (onlyMode >= 0)        // development aid: the slots of the modes that did not run hold no tasks
+                for (int m = 0; m < 4; ++m) if (10 + m != onlyMode) (void)hipMemsetAsync(a.tinfo + uint64_t(m) * a.nblocks, 0, uint64_t(a.nblocks) * 4, stream);
+            DXTEX_MARK("bc6h_bin_1region");
+            sort_tasks(ntasks);
+            DXTEX_MARK("bc6h_perturb_1region");
+            if (!noSearch) hipLaunchKernelGGL(bc6h_perturb_kernel<16>, dim3(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64)), dim3(64), 0, stream, a);
+            DXTEX_MARK("bc6h_post_1region");
+            for (int m = 0; m < 4; ++m)
+            {
+                if (onlyMode >= 0 && 10 + m != onlyMode) continue;
+                set_mode(10 + m); a.taskBase = uint32_t(m) * a.nblocks;
+                hipLaunchKernelGGL(bc6h_post_kernel<0>, dim3(gridPP), dim3(256), 0, stream, a);
+            }
         }
         DXTEX_MARK("bc6h_store");
         hipLaunchKernelGGL(bc6h_store_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, stream, a);
