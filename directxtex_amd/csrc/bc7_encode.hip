@@ -46,6 +46,7 @@ struct Bc7Args
     uint32_t* zeroOrd;       // per block: evaluation-order key of the first candidate (in Encode's order) known to reach error 0;
                              // Encode() returns there (:2803, :2835, :2845), so later candidates are never looked at
     uint2* seeds1;           // per block: the whole-block RGB fit (modes 4, 5) and RGBA fit (mode 6), :3541-3568
+    uint2* seeds3;           // BC7_USE_3SUBSETS only: per block 64 shapes x 3 subsets (modes 0 and 2)
     uint2* seeds;            // per block 64 shapes x 2 subsets: the float-fit endpoints RoughMSE derives (:3526-3552), reused by Refine
     int* bestErr;            // per block: smallest error an already finished mode reached (subset_lower_bound prunes against it)
     int prune;               // 0 = search every candidate like the reference does (DXTEX_BC7_NO_PRUNE, for A/B runs)
@@ -157,6 +158,7 @@ __global__ void __launch_bounds__(256) bc7_rough_kernel(Bc7Args a)
             if (rg.np == 1) { A = pix[rg.pos(0)]; B = A; }
             else if (rg.np == 2) { A = pix[rg.pos(0)]; B = pix[rg.pos(1)]; }
             else seed_endpoints<true>(fpx, m, A, B);
+            a.seeds3[uint64_t(nb) * 192 + shape * 3 + r] = make_uint2(A, B);
             e3 += rough_error<3, 0>(rg, A, B);
             e2 += rough_error<2, 0>(rg, A, B);
         }
@@ -298,25 +300,8 @@ __device__ __forceinline__ void task_org(const float* fpx, const uint32_t* pix, 
     }
 }
 
-// Stage the texels of the blocks this wavefront's tasks belong to: BPW blocks per wave.
-template<int BPW>
-__device__ __forceinline__ void stage_blocks(const Bc7Args& a, uint32_t nbFirst, int lane, float* sF, uint32_t* sL)
-{
-    for (int t = lane; t < BPW * 16; t += 64)
-    {
-        const uint32_t nb = nbFirst + (uint32_t(t) >> 4);
-        uint32_t ldr = 0;
-        if (nb < a.nblocks)
-        {
-            const BcSeg& sg = seg_of(a.seg, nb);
-            load_block_texel(sg.src, sg.nbw, sg.nb0 + (nb - sg.l0), t & 15, &sF[(t >> 4) * 64 + (t & 15) * 4], ldr);
-        }
-        sL[t] = ldr;
-    }
-    wave_lds_sync();
-}
-
-// The two-subset modes need no float texels once the fits are stored: their 8-bit texels come from the pass's scratch.
+// pre / post need no float texels - every fit they start from is stored by the rough pass or bc7_block_seeds_kernel - and take
+// the 8-bit texels of their blocks from the pass's scratch.
 template<int BPW>
 __device__ __forceinline__ void stage_packed(const Bc7Args& a, uint32_t nbFirst, int lane, uint32_t* sL)
 {
@@ -333,7 +318,6 @@ __global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
 {
     typedef TaskMap<MODE, IM> TM;
     constexpr int BPW = (TM::TPB >= 64) ? 1 : 64 / TM::TPB;       // blocks per wavefront
-    __shared__ float sF[4][BPW * 64];
     __shared__ uint32_t sL[4][BPW * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nbFirst = (blockIdx.x * 4 + wave) * BPW;
@@ -354,14 +338,14 @@ __global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
         }
         return;
     }
-    if constexpr (TM::NS != 3) stage_packed<BPW>(a, nbFirst, lane, sL[wave]);
-    else stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
+    stage_packed<BPW>(a, nbFirst, lane, sL[wave]);
     int lb = 0;
     if (active)
     {
         SubsetResult res; int np; Region rg; Block16 b16;
-        task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
-                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G) : (TM::NS == 1) ? a.seeds1 + uint64_t(nb) * 2 : nullptr);
+        task_org<MODE, IM>(nullptr, &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
+                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G)
+                                         : (TM::NS == 1) ? a.seeds1 + uint64_t(nb) * 2 : a.seeds3 + uint64_t(nb) * 192 + shape * 3 + (r % TM::G));
         rec.A = res.orgA; rec.B = res.orgB; rec.err = res.orgErr;
         rec.np = (res.orgErr != 0) ? uint32_t(np) : 0u;        // error 0: OptimizeOne cannot move the endpoints
         if (a.prune && rec.np)
@@ -557,7 +541,6 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
 {
     typedef TaskMap<MODE, IM> TM;
     constexpr int BPW = (TM::TPB >= 64) ? 1 : 64 / TM::TPB;
-    __shared__ float sF[4][BPW * 64];
     __shared__ uint32_t sL[4][BPW * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nbFirst = (blockIdx.x * 4 + wave) * BPW;
@@ -577,8 +560,7 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
         }
         return;
     }
-    if constexpr (TM::NS != 3) stage_packed<BPW>(a, nbFirst, lane, sL[wave]);
-    else stage_blocks<BPW>(a, nbFirst, lane, sF[wave], sL[wave]);
+    stage_packed<BPW>(a, nbFirst, lane, sL[wave]);
 
     SubsetResult res;
     res.orgErr = 0; res.optErr = 0; res.orgA = res.orgB = res.optA = res.optB = 0;
@@ -586,8 +568,9 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
     if (active)
     {
         int np; Region rg; Block16 b16;
-        task_org<MODE, IM>(&sF[wave][blk * 64], &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
-                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G) : (TM::NS == 1) ? a.seeds1 + uint64_t(nb) * 2 : nullptr);
+        task_org<MODE, IM>(nullptr, &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
+                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G)
+                                         : (TM::NS == 1) ? a.seeds1 + uint64_t(nb) * 2 : a.seeds3 + uint64_t(nb) * 192 + shape * 3 + (r % TM::G));
         const TaskRec rec = a.recs[uint64_t(nb) * TM::TPB + r];
         if (TM::NS == 1) refine_post<MODE, IM>(b16, rec.A, rec.B, 0u, res);
         else refine_post<MODE, IM>(rg, rec.A, rec.B, anchor, res);
@@ -704,7 +687,7 @@ const uint64_t kMaxBlocksPerPass = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::ma
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
 struct ScratchLayout
 {
-    size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, seeds, seeds1, total;
+    size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, seeds, seeds1, seeds3, total;
     explicit ScratchLayout(uint64_t nb, bool threeSubsets)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -721,6 +704,7 @@ struct ScratchLayout
         bestErr = o; o = up(o + nb * sizeof(int));
         seeds = o; o = up(o + nb * 128 * sizeof(uint2));
         seeds1 = o; o = up(o + nb * 2 * sizeof(uint2));
+        seeds3 = o; o = up(o + (threeSubsets ? nb * 192 * sizeof(uint2) : 0));
         total = o;
     }
 };
@@ -814,6 +798,7 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         a.bestErr = reinterpret_cast<int*>(base + L.bestErr);
         a.seeds = reinterpret_cast<uint2*>(base + L.seeds);
         a.seeds1 = reinterpret_cast<uint2*>(base + L.seeds1);
+        a.seeds3 = reinterpret_cast<uint2*>(base + L.seeds3);
         static const bool noPrune = getenv("DXTEX_BC7_NO_PRUNE") != nullptr;
         a.prune = noPrune ? 0 : 1;
         static const int early6 = getenv("DXTEX_BC7_EARLY6_PCT") ? atoi(getenv("DXTEX_BC7_EARLY6_PCT")) : 100;
