@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <cstring>
 #include <vector>
 #include "dxtex_kernels.h"
 
@@ -74,16 +75,37 @@ inline uint64_t build_passes(const BcImage* images, size_t count, uint64_t maxPe
 }
 
 // Uploads the segment table when some pass needs it (more than two segments). Stream-ordered: the previous call's kernels may
-// still be reading the old table. The source is pageable, which HIP stages or waits on before returning; the vector is kept
-// alive until the next call regardless.
+// still be reading the old table. The host copy sits in a pinned buffer owned by the calling thread; an event marks when the
+// last upload from it has been consumed, so the buffer is never rewritten (or reallocated) under a copy in flight.
 inline hipError_t upload_segments(BcSeg* dSegs, std::vector<BcSeg>& segs, const std::vector<BcPass>& passes, hipStream_t stream)
 {
     bool needTable = false;
     for (const BcPass& pass : passes) needTable |= pass.nseg > 2;
     if (!needTable) return hipSuccess;
-    static thread_local std::vector<BcSeg> keep;
-    keep = segs;
-    return hipMemcpyAsync(dSegs, keep.data(), keep.size() * sizeof(BcSeg), hipMemcpyHostToDevice, stream);
+    struct Staging { void* host = nullptr; size_t capacity = 0; hipEvent_t consumed = nullptr; bool pending = false; int device = -1; };
+    static thread_local Staging st;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    if (st.pending) { e = hipEventSynchronize(st.consumed); if (e != hipSuccess) return e; st.pending = false; }
+    const size_t bytes = segs.size() * sizeof(BcSeg);
+    if (st.device != device || st.capacity < bytes)
+    {
+        if (st.host) (void)hipHostFree(st.host);
+        if (st.consumed) (void)hipEventDestroy(st.consumed);
+        st = Staging();
+        e = hipHostMalloc(&st.host, std::max<size_t>(bytes, 4096), hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        e = hipEventCreateWithFlags(&st.consumed, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        st.capacity = std::max<size_t>(bytes, 4096); st.device = device;
+    }
+    std::memcpy(st.host, segs.data(), bytes);
+    e = hipMemcpyAsync(dSegs, st.host, bytes, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(st.consumed, stream);
+    st.pending = (e == hipSuccess);
+    return e;
 }
 
 inline void set_pass(SegTable& t, const BcSeg* dSegs, const std::vector<BcSeg>& segs, const BcPass& pass)
