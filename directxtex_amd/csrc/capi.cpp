@@ -48,6 +48,7 @@ struct dxtex_ctx
     // triangle-filter gather tables (host copies stay alive until the next call: the upload is stream-ordered)
     void* triBuf = nullptr; size_t triBytes = 0;
     std::vector<uint8_t> triHost;
+    void* triPinned = nullptr; size_t triPinnedBytes = 0; hipEvent_t triConsumed = nullptr; bool triPending = false;
     void* mseBuf = nullptr; size_t mseBytes = 0;
     std::string lastError;
     bool profiling = false;
@@ -241,6 +242,8 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
     if (ctx->stageOut) (void)hipFree(ctx->stageOut);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->triBuf) (void)hipFree(ctx->triBuf);
+    if (ctx->triPinned) (void)hipHostFree(ctx->triPinned);
+    if (ctx->triConsumed) (void)hipEventDestroy(ctx->triConsumed);
     if (ctx->mseBuf) (void)hipFree(ctx->mseBuf);
     for (hipEvent_t e : ctx->marks.pool) (void)hipEventDestroy(e);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
@@ -603,6 +606,27 @@ inline bool ispow2(size_t x) { return x != 0 && (x & (x - 1)) == 0; }
 struct LevelPair { const uint8_t* src; size_t srcPitch, sw, sh; uint8_t* dst; size_t dstPitch, dw, dh; };
 
 // Builds the triangle tables of every (src -> dst) pair into one device buffer, then launches the filter per pair.
+// The triangle filter's gather lists go to the device through a pinned buffer of the context; an event marks when the last
+// upload has been consumed, so an asynchronous (_device) call never rewrites host memory under a copy in flight.
+dxtex_hresult upload_tables(dxtex_ctx* ctx, const std::vector<uint8_t>& host)
+{
+    dxtex_hresult hr = ensure(ctx, &ctx->triBuf, &ctx->triBytes, host.size()); if (hr != DXTEX_S_OK) return hr;
+    if (ctx->triPending) { HIP_TRY(ctx, hipEventSynchronize(ctx->triConsumed)); ctx->triPending = false; }
+    if (ctx->triPinnedBytes < host.size())
+    {
+        if (ctx->triPinned) { HIP_TRY(ctx, hipHostFree(ctx->triPinned)); ctx->triPinned = nullptr; ctx->triPinnedBytes = 0; }
+        const size_t bytes = std::max<size_t>(host.size(), 1u << 16);
+        HIP_TRY(ctx, hipHostMalloc(&ctx->triPinned, bytes, hipHostMallocDefault));
+        ctx->triPinnedBytes = bytes;
+    }
+    if (!ctx->triConsumed) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->triConsumed, hipEventDisableTiming));
+    std::memcpy(ctx->triPinned, host.data(), host.size());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->triBuf, ctx->triPinned, host.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->triConsumed, ctx->stream));
+    ctx->triPending = true;
+    return DXTEX_S_OK;
+}
+
 dxtex_hresult submit_resizes(dxtex_ctx* ctx, const std::vector<LevelPair>& pairs, int format, uint32_t mode, uint32_t flags, bool mipAlias)
 {
     std::vector<size_t> base(pairs.size(), 0);
@@ -622,8 +646,7 @@ dxtex_hresult submit_resizes(dxtex_ctx* ctx, const std::vector<LevelPair>& pairs
             slots[i].ofsY = append(ofs.data(), ofs.size() * 4); slots[i].entY = append(ent.data(), std::max<size_t>(1, ent.size()) * 8);
         }
         host.resize(host.size() + 16);
-        dxtex_hresult hr = ensure(ctx, &ctx->triBuf, &ctx->triBytes, host.size()); if (hr != DXTEX_S_OK) return hr;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->triBuf, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+        dxtex_hresult hr = upload_tables(ctx, host); if (hr != DXTEX_S_OK) return hr;
         const uint8_t* d = static_cast<const uint8_t*>(ctx->triBuf);
         for (size_t i = 0; i < pairs.size(); ++i)
         {
@@ -777,8 +800,7 @@ dxtex_hresult submit_mips3d(dxtex_ctx* ctx, const std::vector<VolumeView>& lv, u
             slots[i].ofsZ = append(ofs.data(), ofs.size() * 4); slots[i].entZ = append(ent.data(), std::max<size_t>(1, ent.size()) * 8);
         }
         host.resize(host.size() + 16);
-        dxtex_hresult hr = ensure(ctx, &ctx->triBuf, &ctx->triBytes, host.size()); if (hr != DXTEX_S_OK) return hr;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->triBuf, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+        dxtex_hresult hr = upload_tables(ctx, host); if (hr != DXTEX_S_OK) return hr;
         tri = static_cast<const uint8_t*>(ctx->triBuf);
     }
     const VolumeView* twoHigh = nullptr;     // box: the last SOURCE level that was 2 texels high (what urow1 / vrow1's old buffers hold)
