@@ -247,11 +247,27 @@ __global__ void __launch_bounds__(256) resize_cubic_kernel(ResizeArgs a)
     const Cub ty = cubic_entry(a.src.height, a.dst.height, a.wrapV != 0, a.mirrorV != 0, y);
     const uint32_t ys[4] = { ty.u0, ty.u1, ty.u2, ty.u3 };
     Texel c[4];
+    // RGBA8 away from the left / right border: the four taps of a row are adjacent texels, one 16-byte load instead of four
+    // format-dispatched 4-byte loads (XMLoadUByteN4: byte * (1/255), as load_texel does)
+    const bool rowLoad = a.src.format == FMT_R8G8B8A8_UNORM && !a.srgbIn && tx.u1 == tx.u0 + 1u && tx.u2 == tx.u0 + 2u && tx.u3 == tx.u0 + 3u;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
     {
-        const Texel p0 = load_linear(a.src, tx.u0, ys[r], a.srgbIn), p1 = load_linear(a.src, tx.u1, ys[r], a.srgbIn);
-        const Texel p2 = load_linear(a.src, tx.u2, ys[r], a.srgbIn), p3 = load_linear(a.src, tx.u3, ys[r], a.srgbIn);
+        Texel p0, p1, p2, p3;
+        if (rowLoad)
+        {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(a.src.pixels + uint64_t(ys[r]) * a.src.rowPitch) + tx.u0;
+            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];        // 4-byte aligned: the compiler merges them into one dwordx4 load
+#define DXTEX_UNPACK(P, W) P.r = float(W & 0xFF) * (1.0f / 255.0f); P.g = float((W >> 8) & 0xFF) * (1.0f / 255.0f); \
+                           P.b = float((W >> 16) & 0xFF) * (1.0f / 255.0f); P.a = float(W >> 24) * (1.0f / 255.0f)
+            DXTEX_UNPACK(p0, w0); DXTEX_UNPACK(p1, w1); DXTEX_UNPACK(p2, w2); DXTEX_UNPACK(p3, w3);
+#undef DXTEX_UNPACK
+        }
+        else
+        {
+            p0 = load_linear(a.src, tx.u0, ys[r], a.srgbIn); p1 = load_linear(a.src, tx.u1, ys[r], a.srgbIn);
+            p2 = load_linear(a.src, tx.u2, ys[r], a.srgbIn); p3 = load_linear(a.src, tx.u3, ys[r], a.srgbIn);
+        }
         c[r].r = cubic1(tx.x, p0.r, p1.r, p2.r, p3.r); c[r].g = cubic1(tx.x, p0.g, p1.g, p2.g, p3.g);
         c[r].b = cubic1(tx.x, p0.b, p1.b, p2.b, p3.b); c[r].a = cubic1(tx.x, p0.a, p1.a, p2.a, p3.a);
     }
