@@ -50,6 +50,8 @@ struct Bc7Args
     uint2* seeds;            // per block 64 shapes x 2 subsets: the float-fit endpoints RoughMSE derives (:3526-3552), reused by Refine
     int* bestErr;            // per block: smallest error an already finished mode reached (subset_lower_bound prunes against it)
     int prune;               // 0 = search every candidate like the reference does (DXTEX_BC7_NO_PRUNE, for A/B runs)
+    const uint32_t* flagged; // [0] = number of blocks of this pass the rough kernel flagged for an early mode 6 (bc7_flag_count_kernel)
+    uint32_t early6Min;      // the early phase of mode 6 only exists when at least this many blocks are flagged
     int early6Pct;           // rough kernel: mode 6 goes first where 100 * lower bound <= early6Pct * best 3-bit rough error
     int phase;               // which blocks this launch of a mode owns: PHASE_ALL, or the early / late half of a split mode
 };
@@ -222,7 +224,9 @@ __device__ __forceinline__ bool phase_owns(const Bc7Args& a, uint32_t nb)
 {
     if (a.phase == PHASE_ALL || (MODE != 4 && MODE != 5 && MODE != 6)) return true;
     const uint8_t* lst = a.lists + uint64_t(nb) * LIST_BYTES;
-    const bool early = (MODE == 6) ? (lst[37] != 0) : (lst[32] != 0);
+    // A handful of flagged blocks is not worth a phase of its own: the search kernels of a nearly empty phase still take as long
+    // as their longest task (milliseconds). Below the threshold the flagged blocks simply stay with the late phase.
+    const bool early = (MODE == 6) ? (lst[37] != 0 && a.flagged[0] >= a.early6Min) : (lst[32] != 0);
     return early == (a.phase == PHASE_EARLY);
 }
 
@@ -642,6 +646,16 @@ __global__ void __launch_bounds__(256) bc7_block_seeds_kernel(Bc7Args a)
     a.seeds1[uint64_t(nb) * 2 + (RGBA ? 1 : 0)] = make_uint2(A, B);
 }
 
+// Number of blocks flagged for the early mode-6 phase (lists[37]), into counters[40].
+__global__ void __launch_bounds__(256) bc7_flag_count_kernel(Bc7Args a, uint32_t* out)
+{
+    uint32_t n = 0;
+    for (uint32_t nb = blockIdx.x * 256u + threadIdx.x; nb < a.nblocks; nb += gridDim.x * 256u) n += a.lists[uint64_t(nb) * LIST_BYTES + 37] ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63u) == 0 && n) atomicAdd(out, n);
+}
+
 // BC7_QUICK skips the rough pass; the search kernels still need the packed texels.
 __global__ void __launch_bounds__(256) bc7_texels_kernel(Bc7Args a)
 {
@@ -687,7 +701,7 @@ const uint64_t kMaxBlocksPerPass = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::ma
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
 struct ScratchLayout
 {
-    size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, seeds, seeds1, seeds3, total;
+    size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, seeds, seeds1, seeds3, flagcnt, total;
     explicit ScratchLayout(uint64_t nb, bool threeSubsets)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -705,6 +719,7 @@ struct ScratchLayout
         seeds = o; o = up(o + nb * 128 * sizeof(uint2));
         seeds1 = o; o = up(o + nb * 2 * sizeof(uint2));
         seeds3 = o; o = up(o + (threeSubsets ? nb * 192 * sizeof(uint2) : 0));
+        flagcnt = o; o = up(o + 64);
         total = o;
     }
 };
@@ -805,10 +820,16 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         a.early6Pct = early6;
         uint32_t slotMask = 0;
 
+        uint32_t* flagCount = reinterpret_cast<uint32_t*>(base + L.flagcnt);
+        a.flagged = flagCount;
+        static const int early6MinPct = getenv("DXTEX_BC7_EARLY6_MIN_PCT") ? atoi(getenv("DXTEX_BC7_EARLY6_MIN_PCT")) : 25;
+        a.early6Min = uint32_t(uint64_t(a.nblocks) * uint32_t(early6MinPct) / 100u);
         if (!quick)
         {
             DXTEX_MARK("bc7_rough");
             hipLaunchKernelGGL(bc7_rough_kernel, dim3((a.nblocks + 3) / 4), dim3(256), 0, stream, a);
+            (void)hipMemsetAsync(flagCount, 0, 64, stream);
+            hipLaunchKernelGGL(bc7_flag_count_kernel, dim3(std::min<uint32_t>(1024u, (a.nblocks + 255) / 256)), dim3(256), 0, stream, a, flagCount);
         }
         else
         {
