@@ -50,8 +50,8 @@ struct Bc7Args
     uint2* seeds;            // per block 64 shapes x 2 subsets: the float-fit endpoints RoughMSE derives (:3526-3552), reused by Refine
     int* bestErr;            // per block: smallest error an already finished mode reached (subset_lower_bound prunes against it)
     int prune;               // 0 = search every candidate like the reference does (DXTEX_BC7_NO_PRUNE, for A/B runs)
-    const uint32_t* flagged; // [0] = number of blocks of this pass the rough kernel flagged for an early mode 6 (bc7_flag_count_kernel)
-    uint32_t early6Min;      // the early phase of mode 6 only exists when at least this many blocks are flagged
+    const uint32_t* flagged; // [0] = blocks of this pass flagged for an early mode 6, [1] = blocks with alpha (bc7_flag_count_kernel)
+    uint32_t early6Min;      // an early phase (mode 6; modes 4 / 5) only exists when at least this many blocks would be in it
     int early6Pct;           // rough kernel: mode 6 goes first where 100 * lower bound <= early6Pct * best 3-bit rough error
     int phase;               // which blocks this launch of a mode owns: PHASE_ALL, or the early / late half of a split mode
 };
@@ -226,7 +226,7 @@ __device__ __forceinline__ bool phase_owns(const Bc7Args& a, uint32_t nb)
     const uint8_t* lst = a.lists + uint64_t(nb) * LIST_BYTES;
     // A handful of flagged blocks is not worth a phase of its own: the search kernels of a nearly empty phase still take as long
     // as their longest task (milliseconds). Below the threshold the flagged blocks simply stay with the late phase.
-    const bool early = (MODE == 6) ? (lst[37] != 0 && a.flagged[0] >= a.early6Min) : (lst[32] != 0);
+    const bool early = (MODE == 6) ? (lst[37] != 0 && a.flagged[0] >= a.early6Min) : (lst[32] != 0 && a.flagged[1] >= a.early6Min);
     return early == (a.phase == PHASE_EARLY);
 }
 
@@ -646,14 +646,19 @@ __global__ void __launch_bounds__(256) bc7_block_seeds_kernel(Bc7Args a)
     a.seeds1[uint64_t(nb) * 2 + (RGBA ? 1 : 0)] = make_uint2(A, B);
 }
 
-// Number of blocks flagged for the early mode-6 phase (lists[37]), into counters[40].
+// out[0] = number of blocks flagged for the early mode-6 phase (lists[37]), out[1] = number of blocks that have alpha (lists[32]).
 __global__ void __launch_bounds__(256) bc7_flag_count_kernel(Bc7Args a, uint32_t* out)
 {
-    uint32_t n = 0;
-    for (uint32_t nb = blockIdx.x * 256u + threadIdx.x; nb < a.nblocks; nb += gridDim.x * 256u) n += a.lists[uint64_t(nb) * LIST_BYTES + 37] ? 1u : 0u;
+    uint32_t n = 0, m = 0;
+    for (uint32_t nb = blockIdx.x * 256u + threadIdx.x; nb < a.nblocks; nb += gridDim.x * 256u)
+    {
+        n += a.lists[uint64_t(nb) * LIST_BYTES + 37] ? 1u : 0u;
+        m += a.lists[uint64_t(nb) * LIST_BYTES + 32] ? 1u : 0u;
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    for (int o = 32; o > 0; o >>= 1) { n += __shfl_xor(n, o); m += __shfl_xor(m, o); }
     if ((threadIdx.x & 63u) == 0 && n) atomicAdd(out, n);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(out + 1, m);
 }
 
 // BC7_QUICK skips the rough pass; the search kernels still need the packed texels.
