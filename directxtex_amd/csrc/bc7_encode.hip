@@ -470,6 +470,10 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
     }
 }
 
+// Mode 6's short task lists go to bc7_exhaustive_wave_kernel (below): above this many live tasks the lane-per-task kernel is the
+// efficient one. Both are launched, each returns when it is not its turn.
+constexpr uint32_t kWaveTaskMax = 262144;
+
 // The Exhaustive phase (:2971-3042) for the channels of CHSET.
 template<int MODE, int IM, int CHSET>
 __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop, int kRefillMin, int kTransMin)
@@ -481,6 +485,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
     if (live == 0) return;           // nothing survived pre (a phase that owns no block, everything pruned): skip the queue atomics
+    if (MODE == 6 && live <= kWaveTaskMax) return;      // short list: bc7_exhaustive_wave_kernel has done it
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
 
@@ -536,6 +541,80 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
         {
             exh_step<MODE, IM, CHSET>(rg, st, vp, base);
             exh_settle(st);
+        }
+    }
+}
+
+// Exhaustive for SHORT task lists, one task per wavefront: the <= 11 x 11 candidates of a channel's window are evaluated by the
+// 64 lanes in two rounds and the first minimum in the reference's loop order is taken by a wave reduction - the same candidates,
+// the same winner, but the serial chain of a task shrinks from ~480 evaluations to 8. Mode 6 (one task per block) often leaves
+// fewer tasks than the machine has lanes; with one task per lane the kernel was as slow as its slowest lane and 85 % idle.
+
+template<int MODE, int IM, int CHSET>
+__global__ void __launch_bounds__(64) bc7_exhaustive_wave_kernel(Bc7Args a)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    typedef TaskMap<MODE, IM> TM;
+    static_assert(TM::NS == 1, "whole-block tasks only");
+    __shared__ uint32_t sTex[16 * 64];
+    const int lane = threadIdx.x;
+    const uint32_t live = a.counters[34];
+    if (live == 0 || live > kWaveTaskMax) return;
+    for (uint32_t idx = blockIdx.x; idx < live; idx += gridDim.x)
+    {
+        const uint2 task = a.order[idx];
+        const TaskRec rec = a.recs[task.x];
+        SlotRegion rg;
+        wave_lds_sync();                                  // the previous task's reads are done
+        search_pickup<MODE, IM>(a, task, &sTex[0], rg);   // every lane writes the same 16 texels to column 0: all lanes then read them back
+        wave_lds_sync();
+        const int base = loop_base<MODE, IM, CHSET>(rg, rec.A, rec.B);
+        ExhState st; st.optA = rec.A; st.optB = rec.B; st.optErr = rec.err;
+        st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = rec.err; st.ch = C::CH0;
+        VarPal<C::N> vp;
+#pragma unroll 1
+        for (int ch = C::CH0; ch < C::CH1; ++ch)
+        {
+            st = exh_window<MODE, IM, CHSET>(st, ch);
+            if (st.ch >= C::CH1) break;                   // error already zero: Exhaustive returns at once (:2980)
+            varpal_init<MODE, IM, CHSET>(vp, st.optA, st.optB, ch);
+            // candidate c = (o - oStart) * 11 + (i - lo) over the window's bounding rectangle; the loop nest visits exactly the
+            // cells with o < oEnd, max(o, lo) <= i < iEnd, in increasing c
+            const int oStart = st.o;
+            uint64_t bestKey = ~0ull;
+#pragma unroll 1
+            for (int round = 0; round < 2; ++round)
+            {
+                const int c = lane + 64 * round;
+                const int o = oStart + c / 11, i = st.lo + c % 11;
+                const bool valid = c < 121 && o < st.oEnd && i < st.iEnd && i >= o;
+                int e = 0x7FFFFFFF;
+                if (valid)
+                {
+                    const int av = st.aleb ? o : i, bv = st.aleb ? i : o;
+                    e = eval_var<MODE, IM, CHSET>(rg, vp, ch, unq1<C::PREC>(uint32_t(av)), unq1<C::PREC>(uint32_t(bv)), base);
+                }
+                const uint64_t key = valid ? ((uint64_t(uint32_t(e)) << 8) | uint32_t(c)) : ~0ull;
+                bestKey = key < bestKey ? key : bestKey;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1)
+            {
+                const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(bestKey)), d)), hi = uint32_t(__shfl_xor(int(uint32_t(bestKey >> 32)), d));
+                const uint64_t other = (uint64_t(hi) << 32) | lo;
+                bestKey = other < bestKey ? other : bestKey;
+            }
+            if (bestKey != ~0ull)
+            {
+                const int e = int(uint32_t(bestKey >> 8)), c = int(bestKey & 0xFFu);
+                if (e < st.best) { st.best = e; st.omin = oStart + c / 11; st.imin = st.lo + c % 11; }      // strict: first minimum in loop order (:3006)
+            }
+            st = exh_commit(st);
+        }
+        if (lane == 0)
+        {
+            TaskRec* r = a.recs + task.x;
+            r->A = st.optA; r->B = st.optB; r->err = st.optErr;
         }
     }
 }
@@ -753,6 +832,8 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     {
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
         if (marks) marks->mark(names[4]);
+        if constexpr (MODE == 6)
+            hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_ALL>), dim3(std::min<uint32_t>(kSearchWaves, ntasks)), dim3(64), 0, stream, a);
         hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1, refillMin, transMin);
     }
     else
