@@ -6,9 +6,12 @@
 //             its shape's subsets once, scores them with the 3-bit and the 2-bit palettes (modes 1 / 3,7
 //             share the seed), then the wavefront reproduces the reference's partial selection sort
 //             (:2855-2865) with prefix-min scans and ballots and publishes the best shapes per list. Also
-//             stores the block's 16 texels as packed RGBA8 for the search kernels.
+//             stores the block's 16 texels as packed RGBA8 for the search kernels, the fitted endpoints of every
+//             shape (Refine starts from the same fit) and two scheduling flags (has alpha; mode 6 first).
 //   per mode (1, 3, 7, 4 x 2 index modes, 5, 6; 0 and 2 with BC7_USE_3SUBSETS): pre -> bin -> search -> post,
 //             described further down. The per-mode winners travel through a 24 B slot per mode per block.
+//             pre drops the candidates that provably cannot win (subset_lower_bound, bc7_core.h); the modes run in
+//             an order chosen for that pruning (launch_bc7_encode_many), modes 4 / 5 / 6 possibly in two phases.
 //   pick    : lane = block; minimum over the per-mode winners in the reference's evaluation order.
 #include "dxtex_kernels.h"
 #include "bc67_tables.h"
@@ -27,7 +30,7 @@ using namespace bc7;
 struct Cand { uint32_t err; uint32_t ord; uint64_t lo, hi; };   // ord = evaluation order inside D3DX_BC7::Encode
 
 enum : int { SLOT_M0 = 0, SLOT_M1, SLOT_M2, SLOT_M3, SLOT_M4A, SLOT_M4B, SLOT_M5, SLOT_M6, SLOT_M7, NUM_SLOTS };
-enum : int { LIST_BYTES = 64 };   // per block: [0..15] 3-bit list, [16..31] 2-bit list, [32] hasAlpha, [33..36] mode-0 list, [40..55] mode-2 list
+enum : int { LIST_BYTES = 64 };   // per block: [0..15] 3-bit list, [16..31] 2-bit list, [32] hasAlpha, [33..36] mode-0 list, [37] mode 6 first, [40..55] mode-2 list
 
 enum : int { PHASE_ALL = 0, PHASE_EARLY = 1, PHASE_LATE = 2 };
 

@@ -89,7 +89,7 @@ def test_bc7_special_blocks(ctx, oracle):
 
 
 def test_multi_pass_images(oracle):
-    """Images with more than 2^20 blocks are encoded in passes over block ranges; shrink the pass size to exercise that."""
+    """Images with more than 2^22 blocks are encoded in passes over block ranges; shrink the pass size to exercise that."""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
