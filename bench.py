@@ -96,6 +96,12 @@ def other_workloads(ctx, dev, img):
         dst = torch.empty(sp, dtype=torch.uint8, device=dev)
         dt = timed(lambda: ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), fmt, 0, 0.5), n)
         out[f"{name}_4096"] = {"ms": round(dt * 1e3, 3), "Mtexels_s": round(WIDTH * HEIGHT / dt / 1e6, 1), "algorithmic_GBs": round(WIDTH * HEIGHT * bpt / dt / 1e9, 1)}
+    # the reference's faster / slower BC7 settings on the same image (TEX_COMPRESS_BC7_QUICK: mode 6 only; BC7_USE_3SUBSETS: + modes 0, 2)
+    rp, sp = dx.compute_pitch(dx.DXGI_FORMAT_BC7_UNORM, WIDTH, HEIGHT)
+    dst = torch.empty(sp, dtype=torch.uint8, device=dev)
+    for name, fl, n in (("bc7_quick_4096", dx.TEX_COMPRESS_BC7_QUICK, 5), ("bc7_3subsets_4096", 0x80000, 1)):
+        dt = timed(lambda: ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, fl, 0.5), n)
+        out[name] = {"ms": round(dt * 1e3, 2), "Mtexels_s": round(WIDTH * HEIGHT / dt / 1e6, 1)}
     # cfg3: 4096^2 RGBA16F -> BC6H_UF16
     hdr = torch.from_numpy((img.astype(np.float32) * (8.0 / 255.0)).astype(np.float16)).to(dev)
     rp, sp = dx.compute_pitch(dx.DXGI_FORMAT_BC6H_UF16, WIDTH, HEIGHT)
