@@ -215,7 +215,42 @@ HRESULT Device::Create(int hipDevice) noexcept
 const char* Device::LastError() const noexcept { return m_ctx ? dxtex_ctx_last_error(m_ctx) : "no device"; }
 
 // ---- Compress (CompressEx, DirectXTexCompress.cpp:664-850) --------------------------------------------------------------------
-HRESULT Compress(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_COMPRESS_FLAGS compress, float threshold, ScratchImage& image) noexcept
+namespace
+{
+// Progress and cancellation for one image (the role of the per-row callbacks of CompressBC, DirectXTexCompress.cpp:113-121):
+// blocks are independent, so the image is submitted as bands of whole block rows - large enough to fill the GPU - and the
+// callback is asked between bands. The bytes written are those of the one-submission path.
+// DXTEX_PROGRESS_BAND_BLOCKS / DXTEX_PROGRESS_BAND_TEXELS override the band sizes (the tests use them to get several bands
+// out of a small image).
+size_t BandSize(const char* env, size_t def) noexcept
+{
+    const char* v = std::getenv(env);
+    const long long n = v ? std::atoll(v) : 0;
+    return n > 0 ? size_t(n) : def;
+}
+constexpr size_t kBandBlocks = 262144;
+
+HRESULT CompressBands(Device& device, const Image& src, const Image& dst, const CompressOptions& options, const StatusCallback& statusCallback)
+{
+    const size_t nbW = std::max<size_t>(1, (src.width + 3) / 4), nbH = std::max<size_t>(1, (src.height + 3) / 4);
+    const size_t bandRows = std::max<size_t>(1, BandSize("DXTEX_PROGRESS_BAND_BLOCKS", kBandBlocks) / nbW);          // block rows per band
+    for (size_t by = 0; by < nbH; by += bandRows)
+    {
+        const size_t y = by * 4;
+        if (by && !statusCallback(y, src.height)) return E_ABORT;            // (0, height) was reported by the caller
+        const size_t rows = std::min(src.height - y, bandRows * 4);
+        dxtex_image s = View(src), d = View(dst);
+        s.pixels = src.pixels + y * src.rowPitch; s.height = rows; s.slicePitch = src.rowPitch * rows;
+        d.pixels = dst.pixels + by * dst.rowPitch; d.height = rows; d.slicePitch = dst.rowPitch * ((rows + 3) / 4);
+        const HRESULT hr = dxtex_compress(device.Get(), &s, &d, uint32_t(options.flags), options.threshold);
+        if (FAILED(hr)) return hr;
+    }
+    return S_OK;
+}
+}
+
+HRESULT CompressEx(Device& device, const Image& srcImage, DXGI_FORMAT format, const CompressOptions& options, ScratchImage& image,
+                   StatusCallback statusCallback)
 {
     if (!device) return E_POINTER;
     if (IsCompressed(srcImage.format) || !IsCompressed(format) || srcImage.format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
@@ -224,20 +259,31 @@ HRESULT Compress(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_
     if (FAILED(hr)) return hr;
     const Image* img = image.GetImage(0, 0, 0);
     if (!img) { image.Release(); return E_POINTER; }
+    if (statusCallback)
+    {
+        if (!srcImage.pixels) { image.Release(); return E_POINTER; }
+        if (!statusCallback(0, img->height)) { image.Release(); return E_ABORT; }                    // :690-697
+        hr = CompressBands(device, srcImage, *img, options, statusCallback);
+        if (FAILED(hr)) { image.Release(); return hr; }
+        if (!statusCallback(img->height, img->height)) { image.Release(); return E_ABORT; }          // :719-726
+        return S_OK;
+    }
     const dxtex_image s = View(srcImage), d = View(*img);
-    hr = dxtex_compress(device.Get(), &s, &d, uint32_t(compress), threshold);
+    hr = dxtex_compress(device.Get(), &s, &d, uint32_t(options.flags), options.threshold);
     if (FAILED(hr)) image.Release();
     return hr;
 }
 
-HRESULT Compress(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
-                 TEX_COMPRESS_FLAGS compress, float threshold, ScratchImage& cImages) noexcept
+HRESULT CompressEx(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                   const CompressOptions& options, ScratchImage& cImages, StatusCallback statusCallback)
 {
     if (!device) return E_POINTER;
     if (!srcImages || !nimages) return E_INVALIDARG;
     if (IsCompressed(metadata.format) || !IsCompressed(format)) return E_INVALIDARG;
     if (!IsKnown(metadata.format)) return HRESULT_E_NOT_SUPPORTED;
     cImages.Release();
+    if (statusCallback && nimages == 1 && !metadata.IsVolumemap() && metadata.mipLevels == 1 && metadata.arraySize == 1)
+        return CompressEx(device, srcImages[0], format, options, cImages, statusCallback);         // progress inside the image, :753-764
     TexMetadata m2 = metadata;
     m2.format = format;
     HRESULT hr = cImages.Initialize(m2);
@@ -251,9 +297,41 @@ HRESULT Compress(Device& device, const Image* srcImages, size_t nimages, const T
         if (srcImages[i].width != dest[i].width || srcImages[i].height != dest[i].height) { cImages.Release(); return E_FAIL; }     // :800-804
         s[i] = View(srcImages[i]); d[i] = View(dest[i]);
     }
-    hr = dxtex_compress_many(device.Get(), s.data(), d.data(), nimages, uint32_t(compress), threshold);      // the whole array in one submission
-    if (FAILED(hr)) cImages.Release();
-    return hr;
+    if (!statusCallback)
+    {
+        hr = dxtex_compress_many(device.Get(), s.data(), d.data(), nimages, uint32_t(options.flags), options.threshold);   // the whole array in one submission
+        if (FAILED(hr)) cImages.Release();
+        return hr;
+    }
+    // with a callback the images go one at a time so that a cancel stops the work where the reference's would (:785-843)
+    if (!statusCallback(0, nimages)) { cImages.Release(); return E_ABORT; }
+    for (size_t i = 0; i < nimages; ++i)
+    {
+        hr = dxtex_compress(device.Get(), &s[i], &d[i], uint32_t(options.flags), options.threshold);
+        if (FAILED(hr)) { cImages.Release(); return hr; }
+        if (!statusCallback(i, nimages)) { cImages.Release(); return E_ABORT; }
+    }
+    if (!statusCallback(nimages, nimages)) { cImages.Release(); return E_ABORT; }
+    return S_OK;
+}
+
+// Compress = CompressEx without a callback (DirectXTexCompress.cpp:632-661). The exception barrier is for the noexcept
+// contract only: nothing on the callback-free path throws short of bad_alloc.
+HRESULT Compress(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_COMPRESS_FLAGS compress, float threshold, ScratchImage& image) noexcept
+{
+    CompressOptions options = {};
+    options.flags = compress; options.threshold = threshold;
+    try { return CompressEx(device, srcImage, format, options, image, nullptr); }
+    catch (...) { image.Release(); return E_OUTOFMEMORY; }
+}
+
+HRESULT Compress(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                 TEX_COMPRESS_FLAGS compress, float threshold, ScratchImage& cImages) noexcept
+{
+    CompressOptions options = {};
+    options.flags = compress; options.threshold = threshold;
+    try { return CompressEx(device, srcImages, nimages, metadata, format, options, cImages, nullptr); }
+    catch (...) { cImages.Release(); return E_OUTOFMEMORY; }
 }
 
 // ---- Decompress (DirectXTexCompress.cpp:852-979) -------------------------------------------------------------------------------
@@ -465,7 +543,31 @@ HRESULT Resize(Device& device, const Image* srcImages, size_t nimages, const Tex
 }
 
 // ---- Convert (ConvertEx, DirectXTexConvert.cpp:5107-5176) ---------------------------------------------------------------------------
-HRESULT Convert(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_FILTER_FLAGS filter, float threshold, ScratchImage& image) noexcept
+namespace
+{
+// rows are independent in Convert (dither is out of scope), so progress / cancel works on bands of rows (the per-row
+// callbacks of ConvertCustom, DirectXTexConvert.cpp:4834-4896)
+constexpr size_t kBandTexels = size_t(1) << 24;
+
+HRESULT ConvertBands(Device& device, const Image& src, const Image& dst, const ConvertOptions& options, const StatusCallback& statusCallback)
+{
+    const size_t bandRows = std::max<size_t>(1, BandSize("DXTEX_PROGRESS_BAND_TEXELS", kBandTexels) / std::max<size_t>(1, src.width));
+    for (size_t y = 0; y < src.height; y += bandRows)
+    {
+        if (y && !statusCallback(y, src.height)) return E_ABORT;
+        const size_t rows = std::min(src.height - y, bandRows);
+        dxtex_image s = View(src), d = View(dst);
+        s.pixels = src.pixels + y * src.rowPitch; s.height = rows; s.slicePitch = src.rowPitch * rows;
+        d.pixels = dst.pixels + y * dst.rowPitch; d.height = rows; d.slicePitch = dst.rowPitch * rows;
+        const HRESULT hr = dxtex_convert(device.Get(), &s, &d, uint32_t(options.filter), options.threshold);
+        if (FAILED(hr)) return hr;
+    }
+    return S_OK;
+}
+}
+
+HRESULT ConvertEx(Device& device, const Image& srcImage, DXGI_FORMAT format, const ConvertOptions& options, ScratchImage& image,
+                  StatusCallback statusCallback)
 {
     if (!device) return E_POINTER;
     if (srcImage.format == format || format == DXGI_FORMAT_UNKNOWN || srcImage.format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
@@ -476,21 +578,31 @@ HRESULT Convert(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_F
     if (FAILED(hr)) return hr;
     const Image* rimage = image.GetImage(0, 0, 0);
     if (!rimage) { image.Release(); return E_POINTER; }
+    if (statusCallback)
+    {
+        if (!statusCallback(0, rimage->height)) { image.Release(); return E_ABORT; }                  // :5141-5148
+        hr = ConvertBands(device, srcImage, *rimage, options, statusCallback);
+        if (FAILED(hr)) { image.Release(); return hr; }
+        if (!statusCallback(rimage->height, rimage->height)) { image.Release(); return E_ABORT; }     // :5166-5173
+        return S_OK;
+    }
     const dxtex_image s = View(srcImage), d = View(*rimage);
-    hr = dxtex_convert(device.Get(), &s, &d, uint32_t(filter), threshold);
+    hr = dxtex_convert(device.Get(), &s, &d, uint32_t(options.filter), options.threshold);
     if (FAILED(hr)) image.Release();
     return hr;
 }
 
-// Convert (complex), DirectXTexConvert.cpp:5198-5370: every image of the set (all items, mips, slices) is converted.
-HRESULT Convert(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
-                TEX_FILTER_FLAGS filter, float threshold, ScratchImage& result) noexcept
+// ConvertEx (complex), DirectXTexConvert.cpp:5198-5405: every image of the set (all items, mips, slices) is converted.
+HRESULT ConvertEx(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                  const ConvertOptions& options, ScratchImage& result, StatusCallback statusCallback)
 {
     if (!device) return E_POINTER;
     if (!srcImages || !nimages || metadata.format == format || format == DXGI_FORMAT_UNKNOWN || metadata.format == DXGI_FORMAT_UNKNOWN)
         return E_INVALIDARG;
     if (IsCompressed(metadata.format) || IsCompressed(format) || !IsKnown(metadata.format) || !IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
     if (metadata.width > UINT32_MAX || metadata.height > UINT32_MAX) return E_INVALIDARG;
+    if (statusCallback && nimages == 1 && !metadata.IsVolumemap() && metadata.mipLevels == 1 && metadata.arraySize == 1)
+        return ConvertEx(device, srcImages[0], format, options, result, statusCallback);              // :5224-5235
     TexMetadata mdata2 = metadata;
     mdata2.format = format;
     HRESULT hr = result.Initialize(mdata2);
@@ -498,6 +610,7 @@ HRESULT Convert(Device& device, const Image* srcImages, size_t nimages, const Te
     if (nimages != result.GetImageCount()) { result.Release(); return E_FAIL; }
     const Image* dest = result.GetImages();
     if (!dest) { result.Release(); return E_POINTER; }
+    if (statusCallback && !statusCallback(0, nimages)) { result.Release(); return E_ABORT; }
     for (size_t i = 0; i < nimages; ++i)
     {
         const Image& src = srcImages[i];
@@ -506,10 +619,29 @@ HRESULT Convert(Device& device, const Image* srcImages, size_t nimages, const Te
         if (src.width != dest[i].width || src.height != dest[i].height) { result.Release(); return E_FAIL; }
         if (!src.pixels) { result.Release(); return E_POINTER; }
         const dxtex_image s = View(src), d = View(dest[i]);
-        hr = dxtex_convert(device.Get(), &s, &d, uint32_t(filter), threshold);
+        hr = dxtex_convert(device.Get(), &s, &d, uint32_t(options.filter), options.threshold);
         if (FAILED(hr)) { result.Release(); return hr; }
+        if (statusCallback && !statusCallback(i, nimages)) { result.Release(); return E_ABORT; }
     }
+    if (statusCallback && !statusCallback(nimages, nimages)) { result.Release(); return E_ABORT; }
     return S_OK;
+}
+
+HRESULT Convert(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_FILTER_FLAGS filter, float threshold, ScratchImage& image) noexcept
+{
+    ConvertOptions options = {};
+    options.filter = filter; options.threshold = threshold;
+    try { return ConvertEx(device, srcImage, format, options, image, nullptr); }
+    catch (...) { image.Release(); return E_OUTOFMEMORY; }
+}
+
+HRESULT Convert(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                TEX_FILTER_FLAGS filter, float threshold, ScratchImage& result) noexcept
+{
+    ConvertOptions options = {};
+    options.filter = filter; options.threshold = threshold;
+    try { return ConvertEx(device, srcImages, nimages, metadata, format, options, result, nullptr); }
+    catch (...) { result.Release(); return E_OUTOFMEMORY; }
 }
 
 // ---- PremultiplyAlpha (DirectXTexPMAlpha.cpp:214-341) ----------------------------------------------------------------------------------

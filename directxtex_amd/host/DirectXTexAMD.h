@@ -12,6 +12,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <memory>
 
 struct dxtex_ctx;
@@ -25,6 +26,7 @@ constexpr HRESULT E_INVALIDARG = HRESULT(0x80070057);
 constexpr HRESULT E_OUTOFMEMORY = HRESULT(0x8007000E);
 constexpr HRESULT E_POINTER = HRESULT(0x80004003);
 constexpr HRESULT E_NOTIMPL = HRESULT(0x80004001);
+constexpr HRESULT E_ABORT = HRESULT(0x80004004);
 constexpr HRESULT HRESULT_E_NOT_SUPPORTED = HRESULT(0x80070032);
 constexpr HRESULT HRESULT_E_ARITHMETIC_OVERFLOW = HRESULT(0x80070216);
 inline bool FAILED(HRESULT hr) noexcept { return hr < 0; }
@@ -81,6 +83,7 @@ struct TexMetadata
     TEX_DIMENSION dimension = TEX_DIMENSION_TEXTURE2D;
     // index = item * mipLevels + mip for 1D / 2D textures (DirectXTexUtil.cpp:1695-1740)
     size_t ComputeIndex(size_t mip, size_t item, size_t slice) const noexcept;
+    bool IsVolumemap() const noexcept { return dimension == TEX_DIMENSION_TEXTURE3D; }
 };
 
 struct Image
@@ -142,6 +145,16 @@ private:
 HRESULT Compress(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_COMPRESS_FLAGS compress, float threshold, ScratchImage& cImage) noexcept;
 HRESULT Compress(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
                  TEX_COMPRESS_FLAGS compress, float threshold, ScratchImage& cImages) noexcept;
+// CompressEx (DirectXTex.h:922-944). statusCallBack(done, total) -> false cancels: the result is released and E_ABORT
+// returned. One image reports rows (the image goes to the GPU as bands of block rows, asked between bands); a set
+// reports images. alphaWeight belongs to the reference's DirectCompute BC7 encoder and is not used here either way.
+constexpr float TEX_ALPHA_WEIGHT_DEFAULT = 1.0f;
+using StatusCallback = std::function<bool(size_t, size_t)>;
+struct CompressOptions { TEX_COMPRESS_FLAGS flags; float threshold; float alphaWeight; };
+HRESULT CompressEx(Device& device, const Image& srcImage, DXGI_FORMAT format, const CompressOptions& options, ScratchImage& cImage,
+                   StatusCallback statusCallBack = nullptr);
+HRESULT CompressEx(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                   const CompressOptions& options, ScratchImage& cImages, StatusCallback statusCallBack = nullptr);
 // format == DXGI_FORMAT_UNKNOWN picks the default target (DefaultDecompress, DirectXTexCompress.cpp:377-421)
 HRESULT Decompress(Device& device, const Image& cImage, DXGI_FORMAT format, ScratchImage& image) noexcept;
 HRESULT Decompress(Device& device, const Image* cImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format, ScratchImage& images) noexcept;
@@ -159,6 +172,12 @@ HRESULT Resize(Device& device, const Image* srcImages, size_t nimages, const Tex
 HRESULT Convert(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_FILTER_FLAGS filter, float threshold, ScratchImage& image) noexcept;
 HRESULT Convert(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
                 TEX_FILTER_FLAGS filter, float threshold, ScratchImage& result) noexcept;
+// ConvertEx (DirectXTex.h:812-832), callback as for CompressEx
+struct ConvertOptions { TEX_FILTER_FLAGS filter; float threshold; };
+HRESULT ConvertEx(Device& device, const Image& srcImage, DXGI_FORMAT format, const ConvertOptions& options, ScratchImage& image,
+                  StatusCallback statusCallBack = nullptr);
+HRESULT ConvertEx(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                  const ConvertOptions& options, ScratchImage& result, StatusCallback statusCallBack = nullptr);
 // mse = sum of the per-channel values, mseV[4] the per-channel MSE over [0,1] floats
 // PremultiplyAlpha (DirectXTex.h:864-884). TEX_PMALPHA_FLAGS values as in the reference.
 enum TEX_PMALPHA_FLAGS : uint32_t

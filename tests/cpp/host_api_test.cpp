@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace DirectXTexAMD;
@@ -64,6 +65,14 @@ static int cpu_checks()
     ScratchImage out;
     Image img = *si.GetImage(0, 0, 0);
     CHECK(Compress(none, img, DXGI_FORMAT_BC1_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, out) == E_POINTER);
+    {
+        size_t calls = 0;
+        const CompressOptions co = { TEX_COMPRESS_DEFAULT, TEX_THRESHOLD_DEFAULT, TEX_ALPHA_WEIGHT_DEFAULT };
+        const ConvertOptions cv = { TEX_FILTER_DEFAULT, TEX_THRESHOLD_DEFAULT };
+        auto count = [&](size_t, size_t) { ++calls; return true; };
+        CHECK(CompressEx(none, img, DXGI_FORMAT_BC1_UNORM, co, out, count) == E_POINTER && calls == 0);
+        CHECK(ConvertEx(none, img, DXGI_FORMAT_R16G16B16A16_FLOAT, cv, out, count) == E_POINTER && calls == 0);
+    }
     std::puts("cpu checks OK");
     return 0;
 }
@@ -152,6 +161,63 @@ static int gpu_run(const std::string& outdir)
         CHECK(std::memcmp(volBack.GetPixels(), vol.GetPixels(), vol.GetPixelsSize()) == 0);
         ScratchImage bad3;
         CHECK(GenerateMipMaps3D(dev, slices.data(), 7, TEX_FILTER_BOX, 0, bad3) == E_FAIL);          // 7 slices: not a power of two
+    }
+
+    // CompressEx / ConvertEx: progress and cancel. One image goes to the GPU in bands of rows (forced small here), a set
+    // image by image; either way the bytes are those of the callback-free call (DirectXTexCompress.cpp:664-850).
+    {
+        setenv("DXTEX_PROGRESS_BAND_BLOCKS", "100", 1);         // 24 blocks per row -> 4 block rows per band
+        setenv("DXTEX_PROGRESS_BAND_TEXELS", "1000", 1);        // 96 texels per row -> 10 rows per band
+        const CompressOptions co = { TEX_COMPRESS_DEFAULT, TEX_THRESHOLD_DEFAULT, TEX_ALPHA_WEIGHT_DEFAULT };
+        const ConvertOptions cv = { TEX_FILTER_DEFAULT, TEX_THRESHOLD_DEFAULT };
+        std::vector<std::pair<size_t, size_t>> calls;
+        auto record = [&](size_t a, size_t b) { calls.emplace_back(a, b); return true; };
+        ScratchImage ex;
+        CHECK(CompressEx(dev, src, DXGI_FORMAT_BC7_UNORM, co, ex, record) == S_OK);
+        CHECK(ex.GetPixelsSize() == bc7.GetPixelsSize() && std::memcmp(ex.GetPixels(), bc7.GetPixels(), bc7.GetPixelsSize()) == 0);
+        CHECK(calls.size() == 5 && calls[0] == std::make_pair(size_t(0), H) && calls[1] == std::make_pair(size_t(16), H)
+              && calls[3] == std::make_pair(size_t(48), H) && calls[4] == std::make_pair(H, H));
+        // 62 rows: the last band ends in a partial block row
+        Image cut = src; cut.height = 62; cut.slicePitch = cut.rowPitch * 62;
+        ScratchImage cutA, cutB;
+        calls.clear();
+        CHECK(Compress(dev, cut, DXGI_FORMAT_BC3_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, cutA) == S_OK);
+        CHECK(CompressEx(dev, cut, DXGI_FORMAT_BC3_UNORM, co, cutB, record) == S_OK);
+        CHECK(cutA.GetPixelsSize() == cutB.GetPixelsSize() && std::memcmp(cutA.GetPixels(), cutB.GetPixels(), cutA.GetPixelsSize()) == 0);
+        CHECK(calls.size() == 5 && calls.back() == std::make_pair(size_t(62), size_t(62)));
+        // cancel in the middle: E_ABORT, result released
+        size_t n = 0;
+        CHECK(CompressEx(dev, src, DXGI_FORMAT_BC7_UNORM, co, ex, [&](size_t, size_t) { return ++n < 3; }) == E_ABORT);
+        CHECK(n == 3 && ex.GetPixels() == nullptr && ex.GetImageCount() == 0);
+        // a set reports images: (0,n), then (index,n) after each image, then (n,n)
+        calls.clear();
+        CHECK(CompressEx(dev, mips.GetImages(), mips.GetImageCount(), mips.GetMetadata(), DXGI_FORMAT_BC3_UNORM, co, ex, record) == S_OK);
+        CHECK(ex.GetPixelsSize() == bc3.GetPixelsSize() && std::memcmp(ex.GetPixels(), bc3.GetPixels(), bc3.GetPixelsSize()) == 0);
+        CHECK(calls.size() == 9 && calls[0] == std::make_pair(size_t(0), size_t(7)) && calls[1] == std::make_pair(size_t(0), size_t(7))
+              && calls[7] == std::make_pair(size_t(6), size_t(7)) && calls[8] == std::make_pair(size_t(7), size_t(7)));
+        n = 0;
+        CHECK(CompressEx(dev, mips.GetImages(), mips.GetImageCount(), mips.GetMetadata(), DXGI_FORMAT_BC7_UNORM, co, ex, [&](size_t, size_t) { return ++n < 4; }) == E_ABORT);
+        CHECK(n == 4 && ex.GetPixels() == nullptr);
+        // a set of one plain 2-D image takes the single-image route and reports rows
+        calls.clear();
+        TexMetadata one; one.width = W; one.height = H; one.depth = 1; one.arraySize = 1; one.mipLevels = 1; one.format = src.format;
+        CHECK(CompressEx(dev, &src, 1, one, DXGI_FORMAT_BC7_UNORM, co, ex, record) == S_OK);
+        CHECK(calls.size() == 5 && calls[4] == std::make_pair(H, H) && std::memcmp(ex.GetPixels(), bc7.GetPixels(), bc7.GetPixelsSize()) == 0);
+
+        calls.clear();
+        CHECK(ConvertEx(dev, src, DXGI_FORMAT_R16G16B16A16_FLOAT, cv, ex, record) == S_OK);
+        CHECK(ex.GetPixelsSize() == conv.GetPixelsSize() && std::memcmp(ex.GetPixels(), conv.GetPixels(), conv.GetPixelsSize()) == 0);
+        CHECK(calls.size() == 8 && calls[1] == std::make_pair(size_t(10), H) && calls[6] == std::make_pair(size_t(60), H) && calls[7] == std::make_pair(H, H));
+        calls.clear();
+        CHECK(ConvertEx(dev, mips.GetImages(), mips.GetImageCount(), mips.GetMetadata(), DXGI_FORMAT_B8G8R8A8_UNORM, cv, ex, record) == S_OK);
+        CHECK(ex.GetPixelsSize() == convAll.GetPixelsSize() && std::memcmp(ex.GetPixels(), convAll.GetPixels(), convAll.GetPixelsSize()) == 0);
+        CHECK(calls.size() == 9 && calls[8] == std::make_pair(size_t(7), size_t(7)));
+        n = 0;
+        CHECK(ConvertEx(dev, src, DXGI_FORMAT_R16G16B16A16_FLOAT, cv, ex, [&](size_t, size_t) { return ++n < 2; }) == E_ABORT && ex.GetPixels() == nullptr);
+        unsetenv("DXTEX_PROGRESS_BAND_BLOCKS"); unsetenv("DXTEX_PROGRESS_BAND_TEXELS");
+        // default band sizes: a 96x64 image is one band - start and end only
+        calls.clear();
+        CHECK(CompressEx(dev, src, DXGI_FORMAT_BC1_UNORM, co, ex, record) == S_OK && calls.size() == 2);
     }
 
     float mse = 0, v[4];
