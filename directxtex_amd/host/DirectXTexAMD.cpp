@@ -41,12 +41,162 @@ namespace
     inline bool ispow2(size_t x) noexcept { return x != 0 && (x & (x - 1)) == 0; }
 }
 
-bool IsCompressed(DXGI_FORMAT fmt) noexcept { return dxtex_is_compressed(int32_t(fmt)) != 0; }
-size_t BitsPerPixel(DXGI_FORMAT fmt) noexcept { return dxtex_bits_per_pixel(int32_t(fmt)); }
+// ---- format facts (DirectXTexUtil.cpp:340-1247), for every DXGI format ------------------------------------------------------
+bool IsSupportedOnDevice(DXGI_FORMAT fmt) noexcept { return IsKnown(fmt); }
 
-HRESULT ComputePitch(DXGI_FORMAT fmt, size_t width, size_t height, size_t& rowPitch, size_t& slicePitch) noexcept
+bool IsCompressed(DXGI_FORMAT fmt) noexcept
 {
-    return dxtex_compute_pitch(int32_t(fmt), width, height, &rowPitch, &slicePitch);
+    const uint32_t f = uint32_t(fmt);
+    return (f >= DXGI_FORMAT_BC1_TYPELESS && f <= DXGI_FORMAT_BC5_SNORM) || (f >= DXGI_FORMAT_BC6H_TYPELESS && f <= DXGI_FORMAT_BC7_UNORM_SRGB);
+}
+
+bool IsPacked(DXGI_FORMAT fmt) noexcept
+{
+    return fmt == DXGI_FORMAT_R8G8_B8G8_UNORM || fmt == DXGI_FORMAT_G8R8_G8B8_UNORM || fmt == DXGI_FORMAT_YUY2 || fmt == DXGI_FORMAT_Y210 || fmt == DXGI_FORMAT_Y216;
+}
+
+bool IsPlanar(DXGI_FORMAT fmt) noexcept
+{
+    switch (uint32_t(fmt))
+    {
+    case DXGI_FORMAT_NV12: case DXGI_FORMAT_P010: case DXGI_FORMAT_P016: case DXGI_FORMAT_420_OPAQUE: case DXGI_FORMAT_NV11:
+    case DXGI_FORMAT_P208: case DXGI_FORMAT_V208: case DXGI_FORMAT_V408:
+    case 118: case 119: case 120:            // the Xbox depth-stencil planes (D16_UNORM_S8_UINT and its views)
+        return true;
+    default:
+        return false;
+    }
+}
+
+bool IsPalettized(DXGI_FORMAT fmt) noexcept { return uint32_t(fmt) >= DXGI_FORMAT_AI44 && uint32_t(fmt) <= DXGI_FORMAT_A8P8; }
+
+bool IsSRGB(DXGI_FORMAT fmt) noexcept
+{
+    switch (fmt)
+    {
+    case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB: case DXGI_FORMAT_BC1_UNORM_SRGB: case DXGI_FORMAT_BC2_UNORM_SRGB: case DXGI_FORMAT_BC3_UNORM_SRGB:
+    case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB: case DXGI_FORMAT_B8G8R8X8_UNORM_SRGB: case DXGI_FORMAT_BC7_UNORM_SRGB:
+        return true;
+    default:
+        return false;
+    }
+}
+
+DXGI_FORMAT MakeSRGB(DXGI_FORMAT fmt) noexcept
+{
+    switch (fmt)
+    {
+    case DXGI_FORMAT_R8G8B8A8_UNORM: return DXGI_FORMAT_R8G8B8A8_UNORM_SRGB;
+    case DXGI_FORMAT_BC1_UNORM: return DXGI_FORMAT_BC1_UNORM_SRGB;
+    case DXGI_FORMAT_BC2_UNORM: return DXGI_FORMAT_BC2_UNORM_SRGB;
+    case DXGI_FORMAT_BC3_UNORM: return DXGI_FORMAT_BC3_UNORM_SRGB;
+    case DXGI_FORMAT_B8G8R8A8_UNORM: return DXGI_FORMAT_B8G8R8A8_UNORM_SRGB;
+    case DXGI_FORMAT_B8G8R8X8_UNORM: return DXGI_FORMAT_B8G8R8X8_UNORM_SRGB;
+    case DXGI_FORMAT_BC7_UNORM: return DXGI_FORMAT_BC7_UNORM_SRGB;
+    default: return fmt;
+    }
+}
+
+size_t BitsPerPixel(DXGI_FORMAT fmt) noexcept
+{
+    // runs of the DXGI numbering that share a size
+    static const struct { uint16_t first, last, bits; } runs[] = {
+        { 1, 4, 128 }, { 5, 8, 96 }, { 9, 22, 64 }, { 23, 47, 32 }, { 48, 59, 16 }, { 60, 65, 8 }, { 66, 66, 1 }, { 67, 69, 32 },
+        { 70, 72, 4 }, { 73, 78, 8 }, { 79, 81, 4 }, { 82, 84, 8 }, { 85, 86, 16 }, { 87, 93, 32 }, { 94, 99, 8 },
+        { 100, 101, 32 }, { 102, 102, 64 }, { 103, 103, 12 }, { 104, 105, 24 }, { 106, 106, 12 }, { 107, 107, 32 }, { 108, 109, 64 },
+        { 110, 110, 12 }, { 111, 113, 8 }, { 114, 115, 16 },
+        { 116, 117, 32 }, { 118, 120, 24 },          // Xbox: 10:10:10 float + A2, D16 + S8 planes
+        { 130, 131, 16 }, { 132, 132, 24 },          // P208, V208, V408
+        { 189, 189, 32 }, { 190, 190, 8 }, { 191, 191, 16 },          // (Xbox) R10G10B10_SNORM_A2_UNORM, R4G4_UNORM; A4B4G4R4_UNORM
+    };
+    const uint32_t f = uint32_t(fmt);
+    for (const auto& r : runs)
+        if (f >= r.first && f <= r.last) return r.bits;
+    return 0;
+}
+
+HRESULT ComputePitch(DXGI_FORMAT fmt, size_t width, size_t height, size_t& rowPitch, size_t& slicePitch, CP_FLAGS flags) noexcept
+{
+    const uint64_t w = width, h = height;
+    uint64_t pitch = 0, slice = 0;
+    if (fmt == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
+    if (IsCompressed(fmt))
+    {
+        const uint64_t bytes = (BitsPerPixel(fmt) == 4) ? 8 : 16;
+        if (flags & CP_FLAGS_BAD_DXTN_TAILS)
+        {
+            // files whose writer rounded the block counts down (DirectXTexUtil.cpp:980-986)
+            pitch = std::max<uint64_t>(1, (w >> 2) * bytes);
+            slice = std::max<uint64_t>(1, pitch * (h >> 2));
+        }
+        else
+        {
+            pitch = std::max<uint64_t>(1, (w + 3) / 4) * bytes;
+            slice = pitch * std::max<uint64_t>(1, (h + 3) / 4);
+        }
+    }
+    else if (IsPacked(fmt))
+    {
+        pitch = ((w + 1) >> 1) * ((fmt == DXGI_FORMAT_Y210 || fmt == DXGI_FORMAT_Y216) ? 8 : 4);
+        slice = pitch * h;
+    }
+    else if (IsPlanar(fmt))
+    {
+        switch (uint32_t(fmt))
+        {
+        case DXGI_FORMAT_NV12: case DXGI_FORMAT_420_OPAQUE:
+            if (h % 2) return E_INVALIDARG;
+            pitch = ((w + 1) >> 1) * 2; slice = pitch * (h + ((h + 1) >> 1));
+            break;
+        case DXGI_FORMAT_P010: case DXGI_FORMAT_P016:
+            if (h % 2) return E_INVALIDARG;
+            pitch = ((w + 1) >> 1) * 4; slice = pitch * (h + ((h + 1) >> 1));
+            break;
+        case 118: case 119: case 120:
+            pitch = ((w + 1) >> 1) * 4; slice = pitch * (h + ((h + 1) >> 1));
+            break;
+        case DXGI_FORMAT_NV11:
+            pitch = ((w + 3) >> 2) * 4; slice = pitch * h * 2;
+            break;
+        case DXGI_FORMAT_P208:
+            pitch = ((w + 1) >> 1) * 2; slice = pitch * h * 2;
+            break;
+        case DXGI_FORMAT_V208:
+            if (h % 2) return E_INVALIDARG;
+            pitch = w; slice = pitch * (h + (((h + 1) >> 1) * 2));
+            break;
+        default:        // V408
+            pitch = w; slice = pitch * (h + ((h >> 1) * 4));
+            break;
+        }
+    }
+    else
+    {
+        const uint64_t bpp = (flags & CP_FLAGS_24BPP) ? 24 : (flags & CP_FLAGS_16BPP) ? 16 : (flags & CP_FLAGS_8BPP) ? 8 : BitsPerPixel(fmt);
+        if (!bpp) return E_INVALIDARG;
+        // row alignment in bits: 4 KiB page, zmm, ymm, paragraph, DWORD, else bytes
+        const uint64_t align = (flags & CP_FLAGS_PAGE4K) ? 32768 : (flags & CP_FLAGS_ZMM) ? 512 : (flags & CP_FLAGS_YMM) ? 256
+                             : (flags & CP_FLAGS_PARAGRAPH) ? 128 : (flags & CP_FLAGS_LEGACY_DWORD) ? 32 : 8;
+        pitch = ((w * bpp + align - 1) / align) * (align / 8);
+        slice = pitch * h;
+    }
+    rowPitch = size_t(pitch); slicePitch = size_t(slice);
+    return S_OK;
+}
+
+size_t ComputeScanlines(DXGI_FORMAT fmt, size_t height) noexcept
+{
+    if (fmt == DXGI_FORMAT_UNKNOWN) return 0;
+    if (IsCompressed(fmt)) return std::max<size_t>(1, (height + 3) / 4);
+    switch (uint32_t(fmt))
+    {
+    case DXGI_FORMAT_NV11: case DXGI_FORMAT_P208: return height * 2;
+    case DXGI_FORMAT_V208: return height + (((height + 1) >> 1) * 2);
+    case DXGI_FORMAT_V408: return height + ((height >> 1) * 4);
+    case DXGI_FORMAT_NV12: case DXGI_FORMAT_P010: case DXGI_FORMAT_P016: case DXGI_FORMAT_420_OPAQUE: case 118: case 119: case 120:
+        return height + ((height + 1) >> 1);
+    default: return height;
+    }
 }
 
 bool CalculateMipLevels(size_t width, size_t height, size_t& mipLevels) noexcept
@@ -105,15 +255,30 @@ void ScratchImage::Release() noexcept
     m_metadata = TexMetadata();
 }
 
-HRESULT ScratchImage::Initialize(const TexMetadata& mdata) noexcept
+HRESULT ScratchImage::Initialize(const TexMetadata& mdata, CP_FLAGS flags) noexcept
 {
-    if (!IsKnown(mdata.format)) return E_INVALIDARG;
-    const bool volume = mdata.dimension == TEX_DIMENSION_TEXTURE3D;
-    if (!mdata.width || !mdata.height || !mdata.depth || !mdata.arraySize) return E_INVALIDARG;
-    if (volume ? (mdata.arraySize != 1) : (mdata.depth != 1)) return E_INVALIDARG;          // DirectXTexImage.cpp:312-330
+    if (!IsValid(mdata.format)) return E_INVALIDARG;
+    if (IsPalettized(mdata.format)) return HRESULT_E_NOT_SUPPORTED;
     size_t mipLevels = mdata.mipLevels;
-    if (volume ? !CalculateMipLevels3D(mdata.width, mdata.height, mdata.depth, mipLevels) : !CalculateMipLevels(mdata.width, mdata.height, mipLevels))
-        return E_INVALIDARG;
+    switch (mdata.dimension)              // DirectXTexImage.cpp:310-340
+    {
+    case TEX_DIMENSION_TEXTURE1D:
+        if (!mdata.width || mdata.height != 1 || mdata.depth != 1 || !mdata.arraySize) return E_INVALIDARG;
+        if (!CalculateMipLevels(mdata.width, 1, mipLevels)) return E_INVALIDARG;
+        break;
+    case TEX_DIMENSION_TEXTURE2D:
+        if (!mdata.width || !mdata.height || mdata.depth != 1 || !mdata.arraySize) return E_INVALIDARG;
+        if (mdata.IsCubemap() && (mdata.arraySize % 6) != 0) return E_INVALIDARG;
+        if (!CalculateMipLevels(mdata.width, mdata.height, mipLevels)) return E_INVALIDARG;
+        break;
+    case TEX_DIMENSION_TEXTURE3D:
+        if (!mdata.width || !mdata.height || !mdata.depth || mdata.arraySize != 1) return E_INVALIDARG;
+        if (!CalculateMipLevels3D(mdata.width, mdata.height, mdata.depth, mipLevels)) return E_INVALIDARG;
+        break;
+    default:
+        return HRESULT_E_NOT_SUPPORTED;
+    }
+    const bool volume = mdata.dimension == TEX_DIMENSION_TEXTURE3D;
 
     Release();
     m_metadata = mdata;
@@ -130,7 +295,7 @@ HRESULT ScratchImage::Initialize(const TexMetadata& mdata) noexcept
         for (size_t level = 0; level < mipLevels; ++level)
         {
             size_t rp, sp;
-            const HRESULT hr = ComputePitch(mdata.format, w, h, rp, sp);
+            const HRESULT hr = ComputePitch(mdata.format, w, h, rp, sp, flags);
             if (FAILED(hr)) { Release(); return hr; }
             total += uint64_t(sp) * d;
             nimages += d;
@@ -159,7 +324,7 @@ HRESULT ScratchImage::Initialize(const TexMetadata& mdata) noexcept
             {
                 Image& im = m_images[index];
                 im.width = w; im.height = h; im.format = mdata.format;
-                ComputePitch(mdata.format, w, h, im.rowPitch, im.slicePitch);
+                ComputePitch(mdata.format, w, h, im.rowPitch, im.slicePitch, flags);
                 im.pixels = p;
                 p += im.slicePitch;
             }
@@ -171,20 +336,38 @@ HRESULT ScratchImage::Initialize(const TexMetadata& mdata) noexcept
     return S_OK;
 }
 
-HRESULT ScratchImage::Initialize3D(DXGI_FORMAT fmt, size_t width, size_t height, size_t depth, size_t mipLevels) noexcept
+HRESULT ScratchImage::Initialize3D(DXGI_FORMAT fmt, size_t width, size_t height, size_t depth, size_t mipLevels, CP_FLAGS flags) noexcept
 {
+    if (depth > INT16_MAX) return E_INVALIDARG;                  // DirectXTexImage.cpp:464-465
     TexMetadata m;
     m.width = width; m.height = height; m.depth = depth; m.arraySize = 1; m.mipLevels = mipLevels;
     m.format = fmt; m.dimension = TEX_DIMENSION_TEXTURE3D;
-    return Initialize(m);
+    return Initialize(m, flags);
 }
 
-HRESULT ScratchImage::Initialize2D(DXGI_FORMAT fmt, size_t width, size_t height, size_t arraySize, size_t mipLevels) noexcept
+HRESULT ScratchImage::Initialize2D(DXGI_FORMAT fmt, size_t width, size_t height, size_t arraySize, size_t mipLevels, CP_FLAGS flags) noexcept
 {
     TexMetadata m;
     m.width = width; m.height = height; m.depth = 1; m.arraySize = arraySize; m.mipLevels = mipLevels;
     m.format = fmt; m.dimension = TEX_DIMENSION_TEXTURE2D;
-    return Initialize(m);
+    return Initialize(m, flags);
+}
+
+HRESULT ScratchImage::Initialize1D(DXGI_FORMAT fmt, size_t length, size_t arraySize, size_t mipLevels, CP_FLAGS flags) noexcept
+{
+    TexMetadata m;
+    m.width = length; m.height = 1; m.depth = 1; m.arraySize = arraySize; m.mipLevels = mipLevels;
+    m.format = fmt; m.dimension = TEX_DIMENSION_TEXTURE1D;
+    return Initialize(m, flags);
+}
+
+HRESULT ScratchImage::InitializeCube(DXGI_FORMAT fmt, size_t width, size_t height, size_t nCubes, size_t mipLevels, CP_FLAGS flags) noexcept
+{
+    if (!nCubes) return E_INVALIDARG;
+    TexMetadata m;
+    m.width = width; m.height = height; m.depth = 1; m.arraySize = nCubes * 6; m.mipLevels = mipLevels;
+    m.format = fmt; m.dimension = TEX_DIMENSION_TEXTURE2D; m.miscFlags = TEX_MISC_TEXTURECUBE;
+    return Initialize(m, flags);
 }
 
 HRESULT ScratchImage::InitializeFromImage(const Image& src) noexcept
@@ -254,7 +437,7 @@ HRESULT CompressEx(Device& device, const Image& srcImage, DXGI_FORMAT format, co
 {
     if (!device) return E_POINTER;
     if (IsCompressed(srcImage.format) || !IsCompressed(format) || srcImage.format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
-    if (!IsKnown(srcImage.format)) return HRESULT_E_NOT_SUPPORTED;
+    if (!IsKnown(srcImage.format) || !IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;             // typeless, planar, palettised, ... (:674-676)
     HRESULT hr = image.Initialize2D(format, srcImage.width, srcImage.height, 1, 1);
     if (FAILED(hr)) return hr;
     const Image* img = image.GetImage(0, 0, 0);
@@ -280,7 +463,7 @@ HRESULT CompressEx(Device& device, const Image* srcImages, size_t nimages, const
     if (!device) return E_POINTER;
     if (!srcImages || !nimages) return E_INVALIDARG;
     if (IsCompressed(metadata.format) || !IsCompressed(format)) return E_INVALIDARG;
-    if (!IsKnown(metadata.format)) return HRESULT_E_NOT_SUPPORTED;
+    if (!IsKnown(metadata.format) || !IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
     cImages.Release();
     if (statusCallback && nimages == 1 && !metadata.IsVolumemap() && metadata.mipLevels == 1 && metadata.arraySize == 1)
         return CompressEx(device, srcImages[0], format, options, cImages, statusCallback);         // progress inside the image, :753-764
@@ -339,6 +522,7 @@ HRESULT Decompress(Device& device, const Image& cImage, DXGI_FORMAT format, Scra
 {
     if (!device) return E_POINTER;
     if (!IsCompressed(cImage.format) || IsCompressed(format)) return E_INVALIDARG;
+    if (!IsKnown(cImage.format)) return HRESULT_E_NOT_SUPPORTED;
     if (format == DXGI_FORMAT_UNKNOWN)
     {
         format = DefaultDecompress(cImage.format);
@@ -360,6 +544,7 @@ HRESULT Decompress(Device& device, const Image* cImages, size_t nimages, const T
     if (!device) return E_POINTER;
     if (!cImages || !nimages) return E_INVALIDARG;
     if (!IsCompressed(metadata.format) || IsCompressed(format)) return E_INVALIDARG;
+    if (!IsKnown(metadata.format)) return HRESULT_E_NOT_SUPPORTED;
     if (format == DXGI_FORMAT_UNKNOWN)
     {
         format = DefaultDecompress(cImages[0].format);
@@ -647,7 +832,6 @@ HRESULT Convert(Device& device, const Image* srcImages, size_t nimages, const Te
 // ---- PremultiplyAlpha (DirectXTexPMAlpha.cpp:214-341) ----------------------------------------------------------------------------------
 namespace
 {
-constexpr uint32_t TEX_MISC2_ALPHA_MODE_MASK = 0x7, TEX_ALPHA_MODE_STRAIGHT = 1, TEX_ALPHA_MODE_PREMULTIPLIED = 2;
 bool HasAlphaChannel(DXGI_FORMAT f) noexcept
 {
     switch (int(f))
@@ -682,10 +866,10 @@ HRESULT PremultiplyAlpha(Device& device, const Image* srcImages, size_t nimages,
     if (!srcImages || !nimages) return E_INVALIDARG;
     if (IsCompressed(metadata.format) || !IsKnown(metadata.format) || !HasAlphaChannel(metadata.format)) return HRESULT_E_NOT_SUPPORTED;
     if (metadata.width > UINT32_MAX || metadata.height > UINT32_MAX) return E_INVALIDARG;
-    const bool isPM = (metadata.miscFlags2 & TEX_MISC2_ALPHA_MODE_MASK) == TEX_ALPHA_MODE_PREMULTIPLIED;
+    const bool isPM = metadata.IsPMAlpha();
     if (isPM != ((flags & TEX_PMALPHA_REVERSE) != 0)) return E_FAIL;                      // :283-284
     TexMetadata mdata2 = metadata;
-    mdata2.miscFlags2 = (mdata2.miscFlags2 & ~TEX_MISC2_ALPHA_MODE_MASK) | ((flags & TEX_PMALPHA_REVERSE) ? TEX_ALPHA_MODE_STRAIGHT : TEX_ALPHA_MODE_PREMULTIPLIED);
+    mdata2.SetAlphaMode((flags & TEX_PMALPHA_REVERSE) ? TEX_ALPHA_MODE_STRAIGHT : TEX_ALPHA_MODE_PREMULTIPLIED);
     HRESULT hr = result.Initialize(mdata2);
     if (FAILED(hr)) return hr;
     if (nimages != result.GetImageCount()) { result.Release(); return E_FAIL; }

@@ -33,19 +33,45 @@ inline bool FAILED(HRESULT hr) noexcept { return hr < 0; }
 inline bool SUCCEEDED(HRESULT hr) noexcept { return hr >= 0; }
 
 // DXGI_FORMAT values this layer understands (public DXGI numbering).
+// The public DXGI numbering. The container side of the library (ScratchImage, pitches, DDS) knows every format; the GPU
+// entry points work on the subset IsSupportedOnDevice() names and return HRESULT_E_NOT_SUPPORTED for the rest.
 enum DXGI_FORMAT : uint32_t
 {
     DXGI_FORMAT_UNKNOWN = 0,
-    DXGI_FORMAT_R32G32B32A32_FLOAT = 2, DXGI_FORMAT_R16G16B16A16_FLOAT = 10, DXGI_FORMAT_R16G16B16A16_UNORM = 11,
-    DXGI_FORMAT_R32G32_FLOAT = 16, DXGI_FORMAT_R8G8B8A8_UNORM = 28, DXGI_FORMAT_R8G8B8A8_UNORM_SRGB = 29,
-    DXGI_FORMAT_R8G8B8A8_SNORM = 31, DXGI_FORMAT_R16G16_FLOAT = 34, DXGI_FORMAT_R16G16_UNORM = 35, DXGI_FORMAT_R32_FLOAT = 41,
-    DXGI_FORMAT_R8G8_UNORM = 49, DXGI_FORMAT_R8G8_SNORM = 51, DXGI_FORMAT_R16_FLOAT = 54, DXGI_FORMAT_R16_UNORM = 56,
-    DXGI_FORMAT_R8_UNORM = 61, DXGI_FORMAT_R8_SNORM = 63, DXGI_FORMAT_A8_UNORM = 65,
-    DXGI_FORMAT_BC1_UNORM = 71, DXGI_FORMAT_BC1_UNORM_SRGB = 72, DXGI_FORMAT_BC2_UNORM = 74, DXGI_FORMAT_BC2_UNORM_SRGB = 75,
-    DXGI_FORMAT_BC3_UNORM = 77, DXGI_FORMAT_BC3_UNORM_SRGB = 78, DXGI_FORMAT_BC4_UNORM = 80, DXGI_FORMAT_BC4_SNORM = 81,
-    DXGI_FORMAT_BC5_UNORM = 83, DXGI_FORMAT_BC5_SNORM = 84,
-    DXGI_FORMAT_B8G8R8A8_UNORM = 87, DXGI_FORMAT_B8G8R8X8_UNORM = 88, DXGI_FORMAT_B8G8R8A8_UNORM_SRGB = 91, DXGI_FORMAT_B8G8R8X8_UNORM_SRGB = 93,
-    DXGI_FORMAT_BC6H_UF16 = 95, DXGI_FORMAT_BC6H_SF16 = 96, DXGI_FORMAT_BC7_UNORM = 98, DXGI_FORMAT_BC7_UNORM_SRGB = 99,
+    DXGI_FORMAT_R32G32B32A32_TYPELESS = 1, DXGI_FORMAT_R32G32B32A32_FLOAT = 2, DXGI_FORMAT_R32G32B32A32_UINT = 3, DXGI_FORMAT_R32G32B32A32_SINT = 4,
+    DXGI_FORMAT_R32G32B32_TYPELESS = 5, DXGI_FORMAT_R32G32B32_FLOAT = 6, DXGI_FORMAT_R32G32B32_UINT = 7, DXGI_FORMAT_R32G32B32_SINT = 8,
+    DXGI_FORMAT_R16G16B16A16_TYPELESS = 9, DXGI_FORMAT_R16G16B16A16_FLOAT = 10, DXGI_FORMAT_R16G16B16A16_UNORM = 11, DXGI_FORMAT_R16G16B16A16_UINT = 12,
+    DXGI_FORMAT_R16G16B16A16_SNORM = 13, DXGI_FORMAT_R16G16B16A16_SINT = 14,
+    DXGI_FORMAT_R32G32_TYPELESS = 15, DXGI_FORMAT_R32G32_FLOAT = 16, DXGI_FORMAT_R32G32_UINT = 17, DXGI_FORMAT_R32G32_SINT = 18,
+    DXGI_FORMAT_R32G8X24_TYPELESS = 19, DXGI_FORMAT_D32_FLOAT_S8X24_UINT = 20, DXGI_FORMAT_R32_FLOAT_X8X24_TYPELESS = 21, DXGI_FORMAT_X32_TYPELESS_G8X24_UINT = 22,
+    DXGI_FORMAT_R10G10B10A2_TYPELESS = 23, DXGI_FORMAT_R10G10B10A2_UNORM = 24, DXGI_FORMAT_R10G10B10A2_UINT = 25, DXGI_FORMAT_R11G11B10_FLOAT = 26,
+    DXGI_FORMAT_R8G8B8A8_TYPELESS = 27, DXGI_FORMAT_R8G8B8A8_UNORM = 28, DXGI_FORMAT_R8G8B8A8_UNORM_SRGB = 29, DXGI_FORMAT_R8G8B8A8_UINT = 30,
+    DXGI_FORMAT_R8G8B8A8_SNORM = 31, DXGI_FORMAT_R8G8B8A8_SINT = 32,
+    DXGI_FORMAT_R16G16_TYPELESS = 33, DXGI_FORMAT_R16G16_FLOAT = 34, DXGI_FORMAT_R16G16_UNORM = 35, DXGI_FORMAT_R16G16_UINT = 36,
+    DXGI_FORMAT_R16G16_SNORM = 37, DXGI_FORMAT_R16G16_SINT = 38,
+    DXGI_FORMAT_R32_TYPELESS = 39, DXGI_FORMAT_D32_FLOAT = 40, DXGI_FORMAT_R32_FLOAT = 41, DXGI_FORMAT_R32_UINT = 42, DXGI_FORMAT_R32_SINT = 43,
+    DXGI_FORMAT_R24G8_TYPELESS = 44, DXGI_FORMAT_D24_UNORM_S8_UINT = 45, DXGI_FORMAT_R24_UNORM_X8_TYPELESS = 46, DXGI_FORMAT_X24_TYPELESS_G8_UINT = 47,
+    DXGI_FORMAT_R8G8_TYPELESS = 48, DXGI_FORMAT_R8G8_UNORM = 49, DXGI_FORMAT_R8G8_UINT = 50, DXGI_FORMAT_R8G8_SNORM = 51, DXGI_FORMAT_R8G8_SINT = 52,
+    DXGI_FORMAT_R16_TYPELESS = 53, DXGI_FORMAT_R16_FLOAT = 54, DXGI_FORMAT_D16_UNORM = 55, DXGI_FORMAT_R16_UNORM = 56, DXGI_FORMAT_R16_UINT = 57,
+    DXGI_FORMAT_R16_SNORM = 58, DXGI_FORMAT_R16_SINT = 59,
+    DXGI_FORMAT_R8_TYPELESS = 60, DXGI_FORMAT_R8_UNORM = 61, DXGI_FORMAT_R8_UINT = 62, DXGI_FORMAT_R8_SNORM = 63, DXGI_FORMAT_R8_SINT = 64,
+    DXGI_FORMAT_A8_UNORM = 65, DXGI_FORMAT_R1_UNORM = 66, DXGI_FORMAT_R9G9B9E5_SHAREDEXP = 67,
+    DXGI_FORMAT_R8G8_B8G8_UNORM = 68, DXGI_FORMAT_G8R8_G8B8_UNORM = 69,
+    DXGI_FORMAT_BC1_TYPELESS = 70, DXGI_FORMAT_BC1_UNORM = 71, DXGI_FORMAT_BC1_UNORM_SRGB = 72,
+    DXGI_FORMAT_BC2_TYPELESS = 73, DXGI_FORMAT_BC2_UNORM = 74, DXGI_FORMAT_BC2_UNORM_SRGB = 75,
+    DXGI_FORMAT_BC3_TYPELESS = 76, DXGI_FORMAT_BC3_UNORM = 77, DXGI_FORMAT_BC3_UNORM_SRGB = 78,
+    DXGI_FORMAT_BC4_TYPELESS = 79, DXGI_FORMAT_BC4_UNORM = 80, DXGI_FORMAT_BC4_SNORM = 81,
+    DXGI_FORMAT_BC5_TYPELESS = 82, DXGI_FORMAT_BC5_UNORM = 83, DXGI_FORMAT_BC5_SNORM = 84,
+    DXGI_FORMAT_B5G6R5_UNORM = 85, DXGI_FORMAT_B5G5R5A1_UNORM = 86, DXGI_FORMAT_B8G8R8A8_UNORM = 87, DXGI_FORMAT_B8G8R8X8_UNORM = 88,
+    DXGI_FORMAT_R10G10B10_XR_BIAS_A2_UNORM = 89, DXGI_FORMAT_B8G8R8A8_TYPELESS = 90, DXGI_FORMAT_B8G8R8A8_UNORM_SRGB = 91,
+    DXGI_FORMAT_B8G8R8X8_TYPELESS = 92, DXGI_FORMAT_B8G8R8X8_UNORM_SRGB = 93,
+    DXGI_FORMAT_BC6H_TYPELESS = 94, DXGI_FORMAT_BC6H_UF16 = 95, DXGI_FORMAT_BC6H_SF16 = 96,
+    DXGI_FORMAT_BC7_TYPELESS = 97, DXGI_FORMAT_BC7_UNORM = 98, DXGI_FORMAT_BC7_UNORM_SRGB = 99,
+    DXGI_FORMAT_AYUV = 100, DXGI_FORMAT_Y410 = 101, DXGI_FORMAT_Y416 = 102, DXGI_FORMAT_NV12 = 103, DXGI_FORMAT_P010 = 104, DXGI_FORMAT_P016 = 105,
+    DXGI_FORMAT_420_OPAQUE = 106, DXGI_FORMAT_YUY2 = 107, DXGI_FORMAT_Y210 = 108, DXGI_FORMAT_Y216 = 109, DXGI_FORMAT_NV11 = 110,
+    DXGI_FORMAT_AI44 = 111, DXGI_FORMAT_IA44 = 112, DXGI_FORMAT_P8 = 113, DXGI_FORMAT_A8P8 = 114, DXGI_FORMAT_B4G4R4A4_UNORM = 115,
+    DXGI_FORMAT_P208 = 130, DXGI_FORMAT_V208 = 131, DXGI_FORMAT_V408 = 132,
+    DXGI_FORMAT_SAMPLER_FEEDBACK_MIN_MIP_OPAQUE = 189, DXGI_FORMAT_SAMPLER_FEEDBACK_MIP_REGION_USED_OPAQUE = 190, DXGI_FORMAT_A4B4G4R4_UNORM = 191,
 };
 
 enum TEX_DIMENSION : uint32_t { TEX_DIMENSION_TEXTURE1D = 2, TEX_DIMENSION_TEXTURE2D = 3, TEX_DIMENSION_TEXTURE3D = 4 };
@@ -67,13 +93,35 @@ enum TEX_FILTER_FLAGS : uint32_t
 };
 constexpr float TEX_THRESHOLD_DEFAULT = 0.5f;
 
+// Format facts for every DXGI format (DirectXTex.inl:57-60, DirectXTexUtil.cpp:340-960)
+constexpr bool IsValid(DXGI_FORMAT fmt) noexcept { return uint32_t(fmt) >= 1 && uint32_t(fmt) <= 191; }
 bool IsCompressed(DXGI_FORMAT fmt) noexcept;
+bool IsPacked(DXGI_FORMAT fmt) noexcept;
+bool IsPlanar(DXGI_FORMAT fmt) noexcept;
+bool IsPalettized(DXGI_FORMAT fmt) noexcept;
+bool IsSRGB(DXGI_FORMAT fmt) noexcept;
+DXGI_FORMAT MakeSRGB(DXGI_FORMAT fmt) noexcept;
 size_t BitsPerPixel(DXGI_FORMAT fmt) noexcept;
-// ComputePitch with CP_FLAGS_NONE (DirectXTexUtil.cpp:961-1186)
-HRESULT ComputePitch(DXGI_FORMAT fmt, size_t width, size_t height, size_t& rowPitch, size_t& slicePitch) noexcept;
+// true for the formats the GPU entry points (Compress, Convert, Resize, ...) accept
+bool IsSupportedOnDevice(DXGI_FORMAT fmt) noexcept;
+// ComputePitch / ComputeScanlines (DirectXTexUtil.cpp:961-1247). CP_FLAGS values as in the reference (DirectXTex.h:104-137).
+enum CP_FLAGS : uint32_t
+{
+    CP_FLAGS_NONE = 0, CP_FLAGS_LEGACY_DWORD = 0x1, CP_FLAGS_PARAGRAPH = 0x2, CP_FLAGS_YMM = 0x4, CP_FLAGS_ZMM = 0x8, CP_FLAGS_PAGE4K = 0x200,
+    CP_FLAGS_BAD_DXTN_TAILS = 0x1000, CP_FLAGS_24BPP = 0x10000, CP_FLAGS_16BPP = 0x20000, CP_FLAGS_8BPP = 0x40000,
+};
+HRESULT ComputePitch(DXGI_FORMAT fmt, size_t width, size_t height, size_t& rowPitch, size_t& slicePitch, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
+size_t ComputeScanlines(DXGI_FORMAT fmt, size_t height) noexcept;
 // CalculateMipLevels (DirectXTexMipmaps.cpp:40-69): mipLevels == 0 asks for the full chain
 bool CalculateMipLevels(size_t width, size_t height, size_t& mipLevels) noexcept;
 bool CalculateMipLevels3D(size_t width, size_t height, size_t depth, size_t& mipLevels) noexcept;
+
+enum TEX_MISC_FLAG : uint32_t { TEX_MISC_TEXTURECUBE = 0x4 };
+enum TEX_MISC_FLAG2 : uint32_t { TEX_MISC2_ALPHA_MODE_MASK = 0x7 };
+enum TEX_ALPHA_MODE : uint32_t
+{
+    TEX_ALPHA_MODE_UNKNOWN = 0, TEX_ALPHA_MODE_STRAIGHT = 1, TEX_ALPHA_MODE_PREMULTIPLIED = 2, TEX_ALPHA_MODE_OPAQUE = 3, TEX_ALPHA_MODE_CUSTOM = 4,
+};
 
 struct TexMetadata
 {
@@ -84,6 +132,11 @@ struct TexMetadata
     // index = item * mipLevels + mip for 1D / 2D textures (DirectXTexUtil.cpp:1695-1740)
     size_t ComputeIndex(size_t mip, size_t item, size_t slice) const noexcept;
     bool IsVolumemap() const noexcept { return dimension == TEX_DIMENSION_TEXTURE3D; }
+    bool IsCubemap() const noexcept { return (miscFlags & TEX_MISC_TEXTURECUBE) != 0; }
+    // the alpha mode lives in the low three bits of miscFlags2 (DirectXTex.h:174-207)
+    bool IsPMAlpha() const noexcept { return (miscFlags2 & TEX_MISC2_ALPHA_MODE_MASK) == TEX_ALPHA_MODE_PREMULTIPLIED; }
+    void SetAlphaMode(TEX_ALPHA_MODE mode) noexcept { miscFlags2 = (miscFlags2 & ~uint32_t(TEX_MISC2_ALPHA_MODE_MASK)) | uint32_t(mode); }
+    TEX_ALPHA_MODE GetAlphaMode() const noexcept { return TEX_ALPHA_MODE(miscFlags2 & TEX_MISC2_ALPHA_MODE_MASK); }
 };
 
 struct Image
@@ -105,9 +158,12 @@ public:
     ScratchImage& operator=(const ScratchImage&) = delete;
     ~ScratchImage() { Release(); }
 
-    HRESULT Initialize(const TexMetadata& mdata) noexcept;
-    HRESULT Initialize2D(DXGI_FORMAT fmt, size_t width, size_t height, size_t arraySize, size_t mipLevels) noexcept;
-    HRESULT Initialize3D(DXGI_FORMAT fmt, size_t width, size_t height, size_t depth, size_t mipLevels) noexcept;
+    // any valid, non-palettised DXGI format can be held (DirectXTexImage.cpp:300-505); flags select the pitch rule
+    HRESULT Initialize(const TexMetadata& mdata, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
+    HRESULT Initialize1D(DXGI_FORMAT fmt, size_t length, size_t arraySize, size_t mipLevels, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
+    HRESULT Initialize2D(DXGI_FORMAT fmt, size_t width, size_t height, size_t arraySize, size_t mipLevels, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
+    HRESULT Initialize3D(DXGI_FORMAT fmt, size_t width, size_t height, size_t depth, size_t mipLevels, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
+    HRESULT InitializeCube(DXGI_FORMAT fmt, size_t width, size_t height, size_t nCubes, size_t mipLevels, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
     HRESULT InitializeFromImage(const Image& srcImage) noexcept;      // copies the pixels
     void Release() noexcept;
 
@@ -195,13 +251,32 @@ HRESULT ComputeMSE(Device& device, const Image& image1, const Image& image2, flo
 } // namespace DirectXTexAMD
 
 // ---- DDS container: the on-disk format either side of the path ---------------------------------
-// Subset of DirectXTexDDS.cpp: 1D/2D textures, arrays and cubemaps of the formats this library handles; legacy (DX9)
-// pixel formats are read when they map 1:1 onto one of those formats (no expansion / swizzling), and written exactly
-// where the reference writes them (EncodeDDSHeader, DirectXTexDDS.cpp:711-1033). File names are UTF-8 char strings.
+// DirectXTexDDS.cpp's reader and writer: textures, arrays, cubemaps and volumes of every DXGI format; the whole legacy
+// (Direct3D 9) pixel-format table incl. the expanding / swizzling conversions (24 bpp RGB, 3:3:2, palettes, luminance,
+// bump-map formats, the D3DX 10:10:10:2 reversal), every DDS_FLAGS reader and writer option. File names are UTF-8.
 namespace DirectXTexAMD
 {
-enum DDS_FLAGS : uint32_t { DDS_FLAGS_NONE = 0x0, DDS_FLAGS_FORCE_DX10_EXT = 0x10000, DDS_FLAGS_FORCE_DX10_EXT_MISC2 = 0x20000 };
-enum TEX_MISC_FLAG : uint32_t { TEX_MISC_TEXTURECUBE = 0x4 };
+enum DDS_FLAGS : uint32_t
+{
+    DDS_FLAGS_NONE = 0x0,
+    DDS_FLAGS_LEGACY_DWORD = 0x1,                // rows of a legacy file are DWORD aligned
+    DDS_FLAGS_NO_LEGACY_EXPANSION = 0x2,         // fail instead of expanding a legacy format
+    DDS_FLAGS_NO_R10B10G10A2_FIXUP = 0x4,        // trust the 10:10:10:2 masks instead of assuming D3DX's reversed ones
+    DDS_FLAGS_FORCE_RGB = 0x8,                   // BGRA / BGRX -> RGBA
+    DDS_FLAGS_NO_16BPP = 0x10,                   // 5:6:5, 5:5:5:1, 4:4:4:4 -> RGBA8
+    DDS_FLAGS_EXPAND_LUMINANCE = 0x20,           // L8, A8L8, L16 -> RGBA (replicated) instead of R / RG
+    DDS_FLAGS_BAD_DXTN_TAILS = 0x40,             // mips smaller than a block were not written properly
+    DDS_FLAGS_PERMISSIVE = 0x80,                 // accept known header variants
+    DDS_FLAGS_IGNORE_MIPS = 0x100,               // top level only (non-array files)
+    DDS_FLAGS_FORCE_DX10_EXT = 0x10000, DDS_FLAGS_FORCE_DX10_EXT_MISC2 = 0x20000, DDS_FLAGS_FORCE_DX9_LEGACY = 0x40000,
+    DDS_FLAGS_FORCE_DXT5_RXGB = 0x80000, DDS_FLAGS_FORCE_24BPP_RGB = 0x100000,
+    DDS_FLAGS_ALLOW_LARGE_FILES = 0x1000000,
+};
+constexpr HRESULT HRESULT_E_INVALID_DATA = HRESULT(0x8007000D), HRESULT_E_HANDLE_EOF = HRESULT(0x80070026),
+                  HRESULT_E_CANNOT_MAKE = HRESULT(0x80070052), HRESULT_E_FILE_TOO_LARGE = HRESULT(0x800700DF);
+
+// the file's DDS_PIXELFORMAT as read (DirectXTex.h:297-307)
+struct DDSMetaData { uint32_t size, flags, fourCC, RGBBitCount, RBitMask, GBitMask, BBitMask, ABitMask; };
 
 class Blob
 {
@@ -220,8 +295,17 @@ private:
 };
 
 HRESULT GetMetadataFromDDSMemory(const void* pSource, size_t size, DDS_FLAGS flags, TexMetadata& metadata) noexcept;
+HRESULT GetMetadataFromDDSMemoryEx(const void* pSource, size_t size, DDS_FLAGS flags, TexMetadata& metadata, DDSMetaData* ddPixelFormat) noexcept;
+HRESULT GetMetadataFromDDSFile(const char* szFile, DDS_FLAGS flags, TexMetadata& metadata) noexcept;
+HRESULT GetMetadataFromDDSFileEx(const char* szFile, DDS_FLAGS flags, TexMetadata& metadata, DDSMetaData* ddPixelFormat) noexcept;
 HRESULT LoadFromDDSMemory(const void* pSource, size_t size, DDS_FLAGS flags, TexMetadata* metadata, ScratchImage& image) noexcept;
+HRESULT LoadFromDDSMemoryEx(const void* pSource, size_t size, DDS_FLAGS flags, TexMetadata* metadata, DDSMetaData* ddPixelFormat, ScratchImage& image) noexcept;
 HRESULT LoadFromDDSFile(const char* szFile, DDS_FLAGS flags, TexMetadata* metadata, ScratchImage& image) noexcept;
+HRESULT LoadFromDDSFileEx(const char* szFile, DDS_FLAGS flags, TexMetadata* metadata, DDSMetaData* ddPixelFormat, ScratchImage& image) noexcept;
+// required = header bytes; pDestination may be null to query (DirectXTexDDS.cpp:711-1033)
+HRESULT EncodeDDSHeader(const TexMetadata& metadata, DDS_FLAGS flags, uint8_t* pDestination, size_t maxsize, size_t& required) noexcept;
+HRESULT SaveToDDSMemory(const Image& image, DDS_FLAGS flags, Blob& blob) noexcept;
 HRESULT SaveToDDSMemory(const Image* images, size_t nimages, const TexMetadata& metadata, DDS_FLAGS flags, Blob& blob) noexcept;
+HRESULT SaveToDDSFile(const Image& image, DDS_FLAGS flags, const char* szFile) noexcept;
 HRESULT SaveToDDSFile(const Image* images, size_t nimages, const TexMetadata& metadata, DDS_FLAGS flags, const char* szFile) noexcept;
 } // namespace DirectXTexAMD

@@ -55,6 +55,15 @@ def _load_ref():
         lib.dxtex_ref_save_dds.restype = ctypes.c_int64
         lib.dxtex_ref_load_dds.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64), vp, sz, i32p]
         lib.dxtex_ref_load_dds.restype = ctypes.c_int64
+        lib.dxtex_ref_load_dds_ex.argtypes = [vp, sz, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), vp, sz, i32p]
+        lib.dxtex_ref_load_dds_ex.restype = ctypes.c_int64
+        lib.dxtex_ref_save_dds_ex.argtypes = [vp, sz, sz, sz, ctypes.c_int, sz, sz, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, sz, i32p]
+        lib.dxtex_ref_save_dds_ex.restype = ctypes.c_int64
+        szp = ctypes.POINTER(ctypes.c_size_t)
+        lib.dxtex_ref_format_facts.argtypes = [ctypes.c_int, szp]
+        lib.dxtex_ref_format_facts.restype = ctypes.c_int
+        lib.dxtex_ref_compute_pitch_ex.argtypes = [ctypes.c_int, sz, sz, ctypes.c_uint32, szp, szp, szp]
+        lib.dxtex_ref_compute_pitch_ex.restype = ctypes.c_int
         _ref = lib
     return _ref
 
@@ -418,14 +427,53 @@ def ref_save_dds_volume(pixels, width, height, depth, fmt, mip_levels=1, dds_fla
     return _run(_load_ref().dxtex_ref_save_dds_volume, px.size + 256, px.ctypes.data, width, height, depth, fmt, mip_levels, dds_flags)
 
 
-def ref_load_dds(data):
-    """DirectX::LoadFromDDSMemory (DirectXTexDDS.cpp:2008-2090) -> (metadata dict, tight pixel blob)."""
+def ref_load_dds(data, dds_flags=0):
+    """DirectX::LoadFromDDSMemory (DirectXTexDDS.cpp:2008-2107) -> (metadata dict, pixel blob); raises RefError on failure."""
+    hr, meta, px = ref_load_dds_ex(data, dds_flags)
+    if meta is None:
+        raise RefError(hr - (1 << 32) if hr & 0x80000000 else hr)
+    return meta, px
+
+
+DDS_META_KEYS = ("width", "height", "depth", "format", "arraySize", "mipLevels", "miscFlags", "miscFlags2", "dimension")
+
+
+def ref_load_dds_ex(data, dds_flags=0, capacity=None):
+    """DirectX::LoadFromDDSMemory with DDS_FLAGS -> (hr, metadata dict or None, pixel blob or None). Never raises on a bad
+    file: the HRESULT is the result to compare."""
     d = np.ascontiguousarray(data, np.uint8)
-    meta = (ctypes.c_uint64 * 7)()
-    out = np.zeros(d.size + 64, np.uint8)
+    meta = (ctypes.c_uint64 * 9)()
+    out = np.zeros(capacity if capacity is not None else d.size * 16 + 4096, np.uint8)
     hr = ctypes.c_int32(0)
-    n = _load_ref().dxtex_ref_load_dds(d.ctypes.data, d.size, meta, out.ctypes.data, out.nbytes, ctypes.byref(hr))
+    n = _load_ref().dxtex_ref_load_dds_ex(d.ctypes.data, d.size, dds_flags, meta, out.ctypes.data, out.nbytes, ctypes.byref(hr))
+    if n == -2:
+        raise MemoryError("ref_load_dds_ex: capacity too small")
     if n < 0:
-        raise RefError(hr.value)
-    keys = ("width", "height", "format", "arraySize", "mipLevels", "miscFlags", "miscFlags2")
-    return {k: int(v) for k, v in zip(keys, meta)}, out[:n]
+        return hr.value & 0xFFFFFFFF, None, None
+    return hr.value & 0xFFFFFFFF, {k: int(v) for k, v in zip(DDS_META_KEYS, meta)}, out[:n].copy()
+
+
+def ref_save_dds_ex(pixels, width, height, depth, fmt, array_size, mip_levels, misc_flags, misc_flags2, dimension, dds_flags):
+    """DirectX::SaveToDDSMemory of any texture -> (hr, file bytes or None)."""
+    px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
+    out = np.zeros(px.size + 4096, np.uint8)
+    hr = ctypes.c_int32(0)
+    n = _load_ref().dxtex_ref_save_dds_ex(px.ctypes.data, width, height, depth, fmt, array_size, mip_levels, misc_flags, misc_flags2, dimension, dds_flags,
+                                          out.ctypes.data, out.nbytes, ctypes.byref(hr))
+    if n < 0:
+        return hr.value & 0xFFFFFFFF, None
+    return hr.value & 0xFFFFFFFF, out[:n].copy()
+
+
+def ref_format_facts(fmt):
+    """-> (bits per pixel, predicate bits: 1 compressed, 2 packed, 4 planar, 8 palettised, 16 sRGB, 32 valid)."""
+    bpp = ctypes.c_size_t(0)
+    bits = _load_ref().dxtex_ref_format_facts(fmt, ctypes.byref(bpp))
+    return bpp.value, bits
+
+
+def ref_compute_pitch(fmt, width, height, cp_flags=0):
+    """DirectX::ComputePitch / ComputeScanlines -> (hr, rowPitch, slicePitch, scanlines)."""
+    rp, sp, sl = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    hr = _load_ref().dxtex_ref_compute_pitch_ex(fmt, width, height, cp_flags, ctypes.byref(rp), ctypes.byref(sp), ctypes.byref(sl))
+    return hr & 0xFFFFFFFF, rp.value, sp.value, sl.value

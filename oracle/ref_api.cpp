@@ -286,4 +286,54 @@ extern "C"
         meta[0] = m.width; meta[1] = m.height; meta[2] = uint64_t(m.format); meta[3] = m.arraySize; meta[4] = m.mipLevels; meta[5] = m.miscFlags; meta[6] = m.miscFlags2;
         return copy_out(si, out, capacity);
     }
+
+    // LoadFromDDSMemory with flags. meta[0..8] = width, height, depth, format, arraySize, mipLevels, miscFlags, miscFlags2, dimension.
+    // Returns the number of pixel bytes (ScratchImage order, the result's own pitches), -1 on failure (hrOut), -2 if `out` is too small.
+    int64_t dxtex_ref_load_dds_ex(const uint8_t* file, size_t size, uint32_t ddsFlags, uint64_t* meta, uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        ScratchImage si; TexMetadata m = {};
+        const HRESULT hr = LoadFromDDSMemory(file, size, DDS_FLAGS(ddsFlags), &m, si);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        meta[0] = m.width; meta[1] = m.height; meta[2] = m.depth; meta[3] = uint64_t(m.format); meta[4] = m.arraySize; meta[5] = m.mipLevels;
+        meta[6] = m.miscFlags; meta[7] = m.miscFlags2; meta[8] = uint64_t(m.dimension);
+        if (si.GetPixelsSize() > capacity) return -2;
+        memcpy(out, si.GetPixels(), si.GetPixelsSize());
+        return int64_t(si.GetPixelsSize());
+    }
+
+    // SaveToDDSMemory of any texture: `pixels` in ScratchImage order with default pitches; dimension 2 / 3 / 4 as TEX_DIMENSION.
+    int64_t dxtex_ref_save_dds_ex(const uint8_t* pixels, size_t w, size_t h, size_t d, int fmt, size_t arraySize, size_t mipLevels, uint32_t miscFlags,
+                                  uint32_t miscFlags2, uint32_t dimension, uint32_t ddsFlags, uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        TexMetadata m = {};
+        m.width = w; m.height = h; m.depth = d; m.arraySize = arraySize; m.mipLevels = mipLevels; m.miscFlags = miscFlags; m.miscFlags2 = miscFlags2;
+        m.format = DXGI_FORMAT(fmt); m.dimension = TEX_DIMENSION(dimension);
+        ScratchImage si;
+        HRESULT hr = si.Initialize(m);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        memcpy(si.GetPixels(), pixels, si.GetPixelsSize());
+        Blob blob;
+        hr = SaveToDDSMemory(si.GetImages(), si.GetImageCount(), si.GetMetadata(), DDS_FLAGS(ddsFlags), blob);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        if (blob.GetBufferSize() > capacity) return -2;
+        memcpy(out, blob.GetBufferPointer(), blob.GetBufferSize());
+        return int64_t(blob.GetBufferSize());
+    }
+
+    // format facts (DirectXTexUtil.cpp): bits per pixel, pitches under CP_FLAGS, scanline counts, predicates as a bit set
+    // (1 compressed, 2 packed, 4 planar, 8 palettised, 16 sRGB, 32 valid)
+    int dxtex_ref_format_facts(int fmt, size_t* bpp)
+    {
+        const DXGI_FORMAT f = DXGI_FORMAT(fmt);
+        if (bpp) *bpp = BitsPerPixel(f);
+        return (IsCompressed(f) ? 1 : 0) | (IsPacked(f) ? 2 : 0) | (IsPlanar(f) ? 4 : 0) | (IsPalettized(f) ? 8 : 0) | (IsSRGB(f) ? 16 : 0) | (IsValid(f) ? 32 : 0);
+    }
+    int dxtex_ref_compute_pitch_ex(int fmt, size_t w, size_t h, uint32_t cpFlags, size_t* rowPitch, size_t* slicePitch, size_t* scanlines)
+    {
+        if (scanlines) *scanlines = IsValid(DXGI_FORMAT(fmt)) ? ComputeScanlines(DXGI_FORMAT(fmt), h) : h;       // (asserts on ids past 191)
+        return int(ComputePitch(DXGI_FORMAT(fmt), w, h, *rowPitch, *slicePitch, CP_FLAGS(cpFlags)));
+    }
 }

@@ -449,29 +449,173 @@ void DirectX::Internal::ConvertScanline(XMVECTOR* pBuffer, size_t count, DXGI_FO
         each([](float* v) { for (int c = 0; c < 3; ++c) v[c] = rgb_to_srgb(v[c]); });
 }
 
-// ---- the three scanline helpers the DDS reader links against (DirectXTexConvert.cpp:207-700) ---------------------------------
-// Only what the formats of this library need: a plain copy (optionally forcing 8-bit alpha opaque). Legacy expansion
-// (24 bpp, 16-bit 565 / 5551 / 4444, palettes) and channel swizzles are outside the supported subset and report failure.
+// ---- the three scanline helpers the DDS reader links against (DirectXTexConvert.cpp:207-735) ---------------------------------
+// Integer bit manipulation only (no DirectXMath), restated texel by texel with the reference's own masks and shifts so that
+// DirectXTexDDS.cpp - compiled in place - behaves as it does in the reference. The product's reader
+// (directxtex_amd/host/DirectXTexAMD_DDS.cpp) is written differently (generic bit replication) and is checked against this.
+namespace
+{
+    template<typename T> inline T peek(const void* p, size_t byteOffset) { T v; memcpy(&v, static_cast<const uint8_t*>(p) + byteOffset, sizeof(T)); return v; }
+    template<typename T> inline void poke(void* p, size_t byteOffset, T v) { memcpy(static_cast<uint8_t*>(p) + byteOffset, &v, sizeof(T)); }
+}
+
+// DirectXTexConvert.cpp:207-430. With TEXP_SCANLINE_SETALPHA the alpha channel of the listed formats is overwritten with
+// "opaque"; everything else is a memcpy of min(outSize, inSize) bytes (nothing at all when used in place).
 void DirectX::Internal::CopyScanline(void* pDestination, size_t outSize, const void* pSource, size_t inSize, DXGI_FORMAT format, uint32_t tflags) noexcept
 {
     const size_t n = outSize < inSize ? outSize : inSize;
-    if (pDestination != pSource) memcpy(pDestination, pSource, n);
     if (tflags & TEXP_SCANLINE_SETALPHA)
     {
         switch (int(format))
         {
-        case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB: case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB:
-            for (size_t i = 3; i < n; i += 4) static_cast<uint8_t*>(pDestination)[i] = 0xFF;
-            break;
+        case DXGI_FORMAT_R32G32B32A32_TYPELESS: case DXGI_FORMAT_R32G32B32A32_FLOAT: case DXGI_FORMAT_R32G32B32A32_UINT: case DXGI_FORMAT_R32G32B32A32_SINT:   // :223-260
+            if (inSize >= 16 && outSize >= 16)
+            {
+                const uint32_t alpha = (format == DXGI_FORMAT_R32G32B32A32_FLOAT) ? 0x3f800000u : (format == DXGI_FORMAT_R32G32B32A32_SINT) ? 0x7fffffffu : 0xffffffffu;
+                for (size_t at = 0; at < n - 15; at += 16)
+                {
+                    for (size_t c = 0; c < 12; c += 4) poke<uint32_t>(pDestination, at + c, peek<uint32_t>(pSource, at + c));
+                    poke<uint32_t>(pDestination, at + 12, alpha);
+                }
+            }
+            return;
+        case DXGI_FORMAT_R16G16B16A16_TYPELESS: case DXGI_FORMAT_R16G16B16A16_FLOAT: case DXGI_FORMAT_R16G16B16A16_UNORM: case DXGI_FORMAT_R16G16B16A16_UINT:   // :263-304
+        case DXGI_FORMAT_R16G16B16A16_SNORM: case DXGI_FORMAT_R16G16B16A16_SINT: case DXGI_FORMAT_Y416:
+            if (inSize >= 8 && outSize >= 8)
+            {
+                const uint16_t alpha = (format == DXGI_FORMAT_R16G16B16A16_FLOAT) ? uint16_t(0x3c00)
+                                     : (format == DXGI_FORMAT_R16G16B16A16_SNORM || format == DXGI_FORMAT_R16G16B16A16_SINT) ? uint16_t(0x7fff) : uint16_t(0xffff);
+                for (size_t at = 0; at < n - 7; at += 8)
+                {
+                    for (size_t c = 0; c < 6; c += 2) poke<uint16_t>(pDestination, at + c, peek<uint16_t>(pSource, at + c));
+                    poke<uint16_t>(pDestination, at + 6, alpha);
+                }
+            }
+            return;
+        case DXGI_FORMAT_R10G10B10A2_TYPELESS: case DXGI_FORMAT_R10G10B10A2_UNORM: case DXGI_FORMAT_R10G10B10A2_UINT: case DXGI_FORMAT_R10G10B10_XR_BIAS_A2_UNORM:   // :307-339
+        case DXGI_FORMAT_Y410: case XBOX_DXGI_FORMAT_R10G10B10_7E3_A2_FLOAT: case XBOX_DXGI_FORMAT_R10G10B10_6E4_A2_FLOAT: case XBOX_DXGI_FORMAT_R10G10B10_SNORM_A2_UNORM:
+            if (inSize >= 4 && outSize >= 4)
+                for (size_t at = 0; at < n - 3; at += 4) poke<uint32_t>(pDestination, at, peek<uint32_t>(pSource, at) | 0xC0000000u);
+            return;
+        case DXGI_FORMAT_R8G8B8A8_TYPELESS: case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB: case DXGI_FORMAT_R8G8B8A8_UINT:   // :342-380
+        case DXGI_FORMAT_R8G8B8A8_SNORM: case DXGI_FORMAT_R8G8B8A8_SINT: case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8A8_TYPELESS:
+        case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB: case DXGI_FORMAT_AYUV:
+            if (inSize >= 4 && outSize >= 4)
+            {
+                const uint32_t alpha = (format == DXGI_FORMAT_R8G8B8A8_SNORM || format == DXGI_FORMAT_R8G8B8A8_SINT) ? 0x7f000000u : 0xff000000u;
+                for (size_t at = 0; at < n - 3; at += 4) poke<uint32_t>(pDestination, at, (peek<uint32_t>(pSource, at) & 0xFFFFFFu) | alpha);
+            }
+            return;
+        case DXGI_FORMAT_B5G5R5A1_UNORM: case DXGI_FORMAT_B4G4R4A4_UNORM: case WIN11_DXGI_FORMAT_A4B4G4R4_UNORM:   // :383-415
+            if (inSize >= 2 && outSize >= 2)
+            {
+                const uint16_t alpha = (format == DXGI_FORMAT_B4G4R4A4_UNORM) ? uint16_t(0xF000) : (format == WIN11_DXGI_FORMAT_A4B4G4R4_UNORM) ? uint16_t(0x000F) : uint16_t(0x8000);
+                for (size_t at = 0; at < n - 1; at += 2) poke<uint16_t>(pDestination, at, uint16_t(peek<uint16_t>(pSource, at) | alpha));
+            }
+            return;
+        case DXGI_FORMAT_A8_UNORM:   // :418-420
+            memset(pDestination, 0xff, outSize);
+            return;
         default:
             break;
         }
     }
+    if (pDestination != pSource) memcpy(pDestination, pSource, n);   // :426-430
 }
 
-bool DirectX::Internal::ExpandScanline(void*, size_t, DXGI_FORMAT, const void*, size_t, DXGI_FORMAT, uint32_t) noexcept { return false; }
-void DirectX::Internal::SwizzleScanline(void* pDestination, size_t outSize, const void* pSource, size_t inSize, DXGI_FORMAT, uint32_t) noexcept
+// DirectXTexConvert.cpp:440-605. Red <-> blue for the 10:10:10:2 family (only for legacy sources) and the 8:8:8:8 family,
+// UYVY -> YUY2 for legacy sources; anything else is copied.
+void DirectX::Internal::SwizzleScanline(void* pDestination, size_t outSize, const void* pSource, size_t inSize, DXGI_FORMAT format, uint32_t tflags) noexcept
 {
     const size_t n = outSize < inSize ? outSize : inSize;
-    if (pDestination != pSource) memcpy(pDestination, pSource, n);
+    const bool opaque = (tflags & TEXP_SCANLINE_SETALPHA) != 0, legacy = (tflags & TEXP_SCANLINE_LEGACY) != 0;
+    switch (int(format))
+    {
+    case DXGI_FORMAT_R10G10B10A2_TYPELESS: case DXGI_FORMAT_R10G10B10A2_UNORM: case DXGI_FORMAT_R10G10B10A2_UINT: case DXGI_FORMAT_R10G10B10_XR_BIAS_A2_UNORM:   // :455-497
+    case XBOX_DXGI_FORMAT_R10G10B10_SNORM_A2_UNORM:
+        if (inSize >= 4 && outSize >= 4 && legacy)
+        {
+            for (size_t at = 0; at < n - 3; at += 4)
+            {
+                const uint32_t t = peek<uint32_t>(pSource, at);
+                const uint32_t t1 = (t & 0x3ff00000u) >> 20, t2 = (t & 0x000003ffu) << 20, t3 = t & 0x000ffc00u;
+                poke<uint32_t>(pDestination, at, t1 | t2 | t3 | (opaque ? 0xC0000000u : (t & 0xC0000000u)));
+            }
+            return;
+        }
+        break;
+    case DXGI_FORMAT_R8G8B8A8_TYPELESS: case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB: case DXGI_FORMAT_B8G8R8A8_UNORM:   // :500-545
+    case DXGI_FORMAT_B8G8R8X8_UNORM: case DXGI_FORMAT_B8G8R8A8_TYPELESS: case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB: case DXGI_FORMAT_B8G8R8X8_TYPELESS:
+    case DXGI_FORMAT_B8G8R8X8_UNORM_SRGB:
+        if (inSize >= 4 && outSize >= 4)
+        {
+            for (size_t at = 0; at < n - 3; at += 4)
+            {
+                const uint32_t t = peek<uint32_t>(pSource, at);
+                const uint32_t t1 = (t & 0x00ff0000u) >> 16, t2 = (t & 0x000000ffu) << 16, t3 = t & 0x0000ff00u;
+                poke<uint32_t>(pDestination, at, t1 | t2 | t3 | (opaque ? 0xff000000u : (t & 0xFF000000u)));
+            }
+            return;
+        }
+        break;
+    case DXGI_FORMAT_YUY2:   // :548-594
+        if (inSize >= 4 && outSize >= 4 && legacy)
+        {
+            for (size_t at = 0; at < n - 3; at += 4)
+            {
+                const uint32_t t = peek<uint32_t>(pSource, at);
+                poke<uint32_t>(pDestination, at, ((t & 0x000000ffu) << 8) | ((t & 0x0000ff00u) >> 8) | ((t & 0x00ff0000u) << 8) | ((t & 0xff000000u) >> 8));
+            }
+            return;
+        }
+        break;
+    default:
+        break;
+    }
+    if (pDestination != pSource) memcpy(pDestination, pSource, n);   // :600-605
+}
+
+// DirectXTexConvert.cpp:613-735: the 16-bit formats widened to R8G8B8A8_UNORM (the only target), bits replicated downwards.
+bool DirectX::Internal::ExpandScanline(void* pDestination, size_t outSize, DXGI_FORMAT outFormat, const void* pSource, size_t inSize, DXGI_FORMAT inFormat, uint32_t tflags) noexcept
+{
+    const bool opaque = (tflags & TEXP_SCANLINE_SETALPHA) != 0;
+    const int in = int(inFormat);
+    if (in != DXGI_FORMAT_B5G6R5_UNORM && in != DXGI_FORMAT_B5G5R5A1_UNORM && in != DXGI_FORMAT_B4G4R4A4_UNORM && in != int(WIN11_DXGI_FORMAT_A4B4G4R4_UNORM)) return false;
+    if (outFormat != DXGI_FORMAT_R8G8B8A8_UNORM) return false;
+    if (!(inSize >= 2 && outSize >= 4)) return false;
+    for (size_t ocount = 0, icount = 0; (icount < (inSize - 1)) && (ocount < (outSize - 3)); icount += 2, ocount += 4)
+    {
+        const uint32_t t = peek<uint16_t>(pSource, icount);
+        uint32_t t1, t2, t3, ta;
+        if (in == DXGI_FORMAT_B5G6R5_UNORM)   // :631-652
+        {
+            t1 = ((t & 0xf800u) >> 8) | ((t & 0xe000u) >> 13);
+            t2 = ((t & 0x07e0u) << 5) | ((t & 0x0600u) >> 5);
+            t3 = ((t & 0x001fu) << 19) | ((t & 0x001cu) << 14);
+            ta = 0xff000000u;
+        }
+        else if (in == DXGI_FORMAT_B5G5R5A1_UNORM)   // :654-677
+        {
+            t1 = ((t & 0x7c00u) >> 7) | ((t & 0x7000u) >> 12);
+            t2 = ((t & 0x03e0u) << 6) | ((t & 0x0380u) << 1);
+            t3 = ((t & 0x001fu) << 19) | ((t & 0x001cu) << 14);
+            ta = opaque ? 0xff000000u : ((t & 0x8000u) ? 0xff000000u : 0u);
+        }
+        else if (in == DXGI_FORMAT_B4G4R4A4_UNORM)   // :679-702
+        {
+            t1 = ((t & 0x0f00u) >> 4) | ((t & 0x0f00u) >> 8);
+            t2 = ((t & 0x00f0u) << 8) | ((t & 0x00f0u) << 4);
+            t3 = ((t & 0x000fu) << 20) | ((t & 0x000fu) << 16);
+            ta = opaque ? 0xff000000u : (((t & 0xf000u) << 16) | ((t & 0xf000u) << 12));
+        }
+        else   // A4B4G4R4, :704-727
+        {
+            t1 = ((t & 0xf000u) >> 8) | ((t & 0xf000u) >> 12);
+            t2 = (t & 0x0f00u) | ((t & 0x0f00u) << 4);
+            t3 = ((t & 0x00f0u) << 16) | ((t & 0x00f0u) << 12);
+            ta = opaque ? 0xff000000u : (((t & 0x000fu) << 28) | ((t & 0x000fu) << 24));
+        }
+        poke<uint32_t>(pDestination, ocount, t1 | t2 | t3 | ta);
+    }
+    return true;
 }

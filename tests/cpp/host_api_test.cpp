@@ -60,6 +60,43 @@ static int cpu_checks()
     lv = 7; CHECK(!CalculateMipLevels3D(4, 2, 32, lv));
     CHECK(v3.Initialize3D(DXGI_FORMAT_R8G8B8A8_UNORM, 4, 4, 0, 1) == E_INVALIDARG);
 
+    // the container holds any valid DXGI format (GPU work on it is another matter); 1D textures and cubemaps
+    {
+        ScratchImage any;
+        CHECK(any.Initialize2D(DXGI_FORMAT_B5G6R5_UNORM, 7, 3, 1, 1) == S_OK && any.GetImage(0, 0, 0)->rowPitch == 14);
+        CHECK(any.Initialize2D(DXGI_FORMAT_R1_UNORM, 9, 2, 1, 1) == S_OK && any.GetImage(0, 0, 0)->rowPitch == 2);
+        CHECK(any.Initialize2D(DXGI_FORMAT_P8, 4, 4, 1, 1) == HRESULT_E_NOT_SUPPORTED);
+        CHECK(any.Initialize2D(DXGI_FORMAT(150), 4, 4, 1, 1) == E_INVALIDARG && any.Initialize2D(DXGI_FORMAT(192), 4, 4, 1, 1) == E_INVALIDARG);
+        CHECK(any.Initialize2D(DXGI_FORMAT_R8G8B8A8_UNORM, 5, 3, 1, 1, CP_FLAGS_PARAGRAPH) == S_OK && any.GetImage(0, 0, 0)->rowPitch == 32);
+        CHECK(any.Initialize1D(DXGI_FORMAT_R8_UNORM, 16, 2, 0) == S_OK && any.GetMetadata().dimension == TEX_DIMENSION_TEXTURE1D && any.GetImageCount() == 10);
+        CHECK(any.InitializeCube(DXGI_FORMAT_R8G8B8A8_UNORM, 4, 4, 2, 1) == S_OK && any.GetMetadata().IsCubemap() && any.GetImageCount() == 12);
+        CHECK(any.InitializeCube(DXGI_FORMAT_R8G8B8A8_UNORM, 4, 4, 0, 1) == E_INVALIDARG);
+        TexMetadata odd = any.GetMetadata(); odd.arraySize = 7;
+        CHECK(any.Initialize(odd) == E_INVALIDARG);                     // a cubemap needs a multiple of six
+        CHECK(!IsSupportedOnDevice(DXGI_FORMAT_B5G6R5_UNORM) && IsSupportedOnDevice(DXGI_FORMAT_R8G8B8A8_UNORM) && IsSupportedOnDevice(DXGI_FORMAT_BC7_UNORM));
+    }
+    // DDS: images with padded rows are written with the file's tight pitch; the one-image overloads; the header query
+    {
+        ScratchImage tight;
+        CHECK(tight.Initialize2D(DXGI_FORMAT_R8G8B8A8_UNORM, 5, 3, 1, 1) == S_OK);
+        for (size_t i = 0; i < tight.GetPixelsSize(); ++i) tight.GetPixels()[i] = uint8_t(i * 7 + 1);
+        std::vector<uint8_t> padded(3 * 32, 0xEE);
+        Image wide = *tight.GetImage(0, 0, 0); wide.rowPitch = 32; wide.slicePitch = 96; wide.pixels = padded.data();
+        for (size_t y = 0; y < 3; ++y) std::memcpy(padded.data() + y * 32, tight.GetPixels() + y * 20, 20);
+        Blob b1, b2;
+        CHECK(SaveToDDSMemory(*tight.GetImage(0, 0, 0), DDS_FLAGS_NONE, b1) == S_OK && SaveToDDSMemory(wide, DDS_FLAGS_NONE, b2) == S_OK);
+        CHECK(b1.GetBufferSize() == 128 + 60 && b2.GetBufferSize() == b1.GetBufferSize() && std::memcmp(b1.GetBufferPointer(), b2.GetBufferPointer(), b1.GetBufferSize()) == 0);
+        size_t need = 0;
+        CHECK(EncodeDDSHeader(tight.GetMetadata(), DDS_FLAGS_FORCE_DX10_EXT, nullptr, 0, need) == S_OK && need == 148);
+        uint8_t small[64];
+        CHECK(EncodeDDSHeader(tight.GetMetadata(), DDS_FLAGS_NONE, small, sizeof(small), need) == HRESULT(0x8007007A));
+        TexMetadata q; DDSMetaData pf;
+        CHECK(GetMetadataFromDDSMemoryEx(b1.GetBufferPointer(), b1.GetBufferSize(), DDS_FLAGS_NONE, q, &pf) == S_OK && q.width == 5 && q.format == DXGI_FORMAT_R8G8B8A8_UNORM);
+        CHECK(pf.size == 32 && pf.flags == 0x41 && pf.RGBBitCount == 32 && pf.RBitMask == 0xff && pf.ABitMask == 0xff000000u);
+        CHECK(GetMetadataFromDDSMemory(nullptr, 10, DDS_FLAGS_NONE, q) == E_INVALIDARG && GetMetadataFromDDSMemory(b1.GetBufferPointer(), 0, DDS_FLAGS_NONE, q) == E_INVALIDARG);
+        CHECK(GetMetadataFromDDSFile("/nonexistent/x.dds", DDS_FLAGS_NONE, q) == E_FAIL && LoadFromDDSFile(nullptr, DDS_FLAGS_NONE, nullptr, tight) == E_INVALIDARG);
+    }
+
     // without a device every entry point refuses to work: there is no CPU path
     Device none;
     ScratchImage out;
@@ -236,13 +273,16 @@ static int gpu_run(const std::string& outdir)
     return 0;
 }
 
-// dds_save <tight pixels.bin> <w> <h> <format> <arraySize> <mipLevels> <miscFlags> <ddsFlags> <out.dds>
-static int dds_save(char** a)
+// dds_save <tight pixels.bin> <w> <h> <format> <arraySize> <mipLevels> <miscFlags> <ddsFlags> <out.dds> [depth] [miscFlags2] [dimension]
+// a depth argument > 0 makes it a volume unless a dimension (2, 3, 4) says otherwise
+static int dds_save(int n, char** a)
 {
     const size_t w = std::strtoull(a[1], nullptr, 10), h = std::strtoull(a[2], nullptr, 10);
     TexMetadata m; m.width = w; m.height = h; m.depth = 1; m.format = DXGI_FORMAT(std::atoi(a[3]));
     m.arraySize = std::strtoull(a[4], nullptr, 10); m.mipLevels = std::strtoull(a[5], nullptr, 10); m.miscFlags = uint32_t(std::strtoul(a[6], nullptr, 0));
-    if (a[9]) { m.depth = std::strtoull(a[9], nullptr, 10); m.dimension = TEX_DIMENSION_TEXTURE3D; }      // optional 10th argument: a volume
+    if (n > 9 && std::strtoull(a[9], nullptr, 10) > 0) { m.depth = std::strtoull(a[9], nullptr, 10); m.dimension = TEX_DIMENSION_TEXTURE3D; }
+    if (n > 10) m.miscFlags2 = uint32_t(std::strtoul(a[10], nullptr, 0));
+    if (n > 11) { m.dimension = TEX_DIMENSION(std::atoi(a[11])); if (m.dimension != TEX_DIMENSION_TEXTURE3D) m.depth = 1; }
     ScratchImage si;
     HRESULT hr = si.Initialize(m);
     if (FAILED(hr)) { std::printf("hr %08x\n", unsigned(hr)); return 3; }
@@ -254,22 +294,80 @@ static int dds_save(char** a)
     return FAILED(hr) ? 3 : 0;
 }
 
-// dds_load <in.dds> <out tight pixels.bin>: prints the metadata
-static int dds_load(char** a)
+static void print_meta(const TexMetadata& m)
+{
+    std::printf("meta %zu %zu %zu %u %zu %zu %u %u %u\n", m.width, m.height, m.depth, unsigned(m.format), m.arraySize, m.mipLevels, m.miscFlags, m.miscFlags2, unsigned(m.dimension));
+}
+
+// dds_load <in.dds> <out tight pixels.bin> [ddsFlags]: prints the HRESULT and the metadata
+static int dds_load(int n, char** a)
 {
     ScratchImage si; TexMetadata m;
-    const HRESULT hr = LoadFromDDSFile(a[0], DDS_FLAGS_NONE, &m, si);
+    const HRESULT hr = LoadFromDDSFile(a[0], DDS_FLAGS(n > 2 ? std::strtoul(a[2], nullptr, 0) : 0), &m, si);
     std::printf("hr %08x\n", unsigned(hr));
     if (FAILED(hr)) return 3;
-    std::printf("meta %zu %zu %u %zu %zu %u %u\n", m.width, m.height, unsigned(m.format), m.arraySize, m.mipLevels, m.miscFlags, m.miscFlags2);
+    print_meta(m);
     dump(a[1], si.GetPixels(), si.GetPixelsSize());
+    return 0;
+}
+
+// dds_load_many <list.txt>: every line "<in.dds> <ddsFlags>"; prints "<hr>" or "<hr> meta ..." per line, writes <in.dds>.out
+static int dds_load_many(char** a)
+{
+    FILE* list = std::fopen(a[0], "r");
+    if (!list) return 4;
+    char path[4096]; unsigned long flags;
+    while (std::fscanf(list, "%4095s %lu", path, &flags) == 2)
+    {
+        FILE* f = std::fopen(path, "rb");
+        if (!f) return 4;
+        std::fseek(f, 0, SEEK_END); const long len = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+        std::vector<uint8_t> buf(size_t(len > 0 ? len : 0));
+        if (!buf.empty() && std::fread(buf.data(), 1, buf.size(), f) != buf.size()) return 4;
+        std::fclose(f);
+        ScratchImage si; TexMetadata m;
+        const HRESULT hr = LoadFromDDSMemory(buf.data(), buf.size(), DDS_FLAGS(flags), &m, si);
+        std::printf("hr %08x ", unsigned(hr));
+        if (FAILED(hr)) { std::puts(""); continue; }
+        print_meta(m);
+        // the header-only query must agree with the loader
+        TexMetadata m2;
+        if (GetMetadataFromDDSMemory(buf.data(), buf.size(), DDS_FLAGS(flags), m2) != S_OK || m2.width != m.width || m2.format != m.format || m2.mipLevels != m.mipLevels)
+        { std::fprintf(stderr, "GetMetadataFromDDSMemory disagrees with LoadFromDDSMemory for %s\n", path); return 5; }
+        dump(std::string(path) + ".out", si.GetPixels(), si.GetPixelsSize());
+    }
+    std::fclose(list);
+    return 0;
+}
+
+// formats: the container-side format tables for every format id 0..200, and pitches for a set of sizes and CP_FLAGS
+static int formats()
+{
+    const size_t dims[][2] = { { 1, 1 }, { 5, 3 }, { 16, 16 }, { 31, 7 }, { 256, 2 }, { 1023, 4 } };
+    const uint32_t cps[] = { 0, CP_FLAGS_LEGACY_DWORD, CP_FLAGS_PARAGRAPH, CP_FLAGS_YMM, CP_FLAGS_ZMM, CP_FLAGS_PAGE4K, CP_FLAGS_BAD_DXTN_TAILS,
+                             CP_FLAGS_24BPP, CP_FLAGS_16BPP, CP_FLAGS_8BPP, CP_FLAGS_24BPP | CP_FLAGS_LEGACY_DWORD, CP_FLAGS_8BPP | CP_FLAGS_LEGACY_DWORD };
+    for (uint32_t f = 0; f <= 200; ++f)
+    {
+        const DXGI_FORMAT fmt = DXGI_FORMAT(f);
+        const int bits = (IsCompressed(fmt) ? 1 : 0) | (IsPacked(fmt) ? 2 : 0) | (IsPlanar(fmt) ? 4 : 0) | (IsPalettized(fmt) ? 8 : 0) | (IsSRGB(fmt) ? 16 : 0) | (IsValid(fmt) ? 32 : 0);
+        std::printf("fmt %u %zu %d\n", f, BitsPerPixel(fmt), bits);
+        for (const auto& d : dims)
+            for (uint32_t cp : cps)
+            {
+                size_t rp = 0, sp = 0;
+                const HRESULT hr = ComputePitch(fmt, d[0], d[1], rp, sp, CP_FLAGS(cp));
+                std::printf("pitch %u %zu %zu %u %08x %zu %zu %zu\n", f, d[0], d[1], cp, unsigned(hr), FAILED(hr) ? size_t(0) : rp, FAILED(hr) ? size_t(0) : sp, ComputeScanlines(fmt, d[1]));
+            }
+    }
     return 0;
 }
 
 int main(int argc, char** argv)
 {
-    if (argc >= 11 && !std::strcmp(argv[1], "dds_save")) return dds_save(argv + 2);
-    if (argc >= 4 && !std::strcmp(argv[1], "dds_load")) return dds_load(argv + 2);
+    if (argc >= 11 && !std::strcmp(argv[1], "dds_save")) return dds_save(argc - 2, argv + 2);
+    if (argc >= 4 && !std::strcmp(argv[1], "dds_load")) return dds_load(argc - 2, argv + 2);
+    if (argc >= 3 && !std::strcmp(argv[1], "dds_load_many")) return dds_load_many(argv + 2);
+    if (argc >= 2 && !std::strcmp(argv[1], "formats")) return formats();
     if (argc >= 2 && !std::strcmp(argv[1], "cpu")) return cpu_checks();
     if (argc >= 3 && !std::strcmp(argv[1], "gpu")) return gpu_run(argv[2]);
     std::fprintf(stderr, "usage: host_api_test cpu | gpu <outdir>\n");

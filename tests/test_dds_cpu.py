@@ -28,8 +28,7 @@ def _load(tmp, data):
     r = subprocess.run([EXE, "dds_load", src, out], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     meta = [int(x) for x in [l for l in r.stdout.splitlines() if l.startswith("meta ")][0].split()[1:]]
-    keys = ("width", "height", "format", "arraySize", "mipLevels", "miscFlags", "miscFlags2")
-    return dict(zip(keys, meta)), np.fromfile(out, np.uint8)
+    return dict(zip(oracle.DDS_META_KEYS, meta)), np.fromfile(out, np.uint8)
 
 
 @pytest.mark.parametrize("fmt", FORMATS)
@@ -91,3 +90,56 @@ def test_volume_texture_matches_reference_and_roundtrips(tmp_path, fmt, flags):
     meta, back = _load(str(tmp_path), ref)
     assert (meta["width"], meta["height"], meta["format"], meta["mipLevels"]) == (w, h, fmt, mips)
     assert np.array_equal(back, px)
+
+
+def _save_ex(tmp, px, w, h, d, fmt, array, mips, misc, misc2, dim, flags):
+    """-> (hr, file bytes or None) from the host layer's SaveToDDSFile."""
+    src = os.path.join(tmp, "px.bin"); out = os.path.join(tmp, "out.dds")
+    px.tofile(src)
+    if os.path.exists(out):
+        os.remove(out)
+    r = subprocess.run([EXE, "dds_save", src, str(w), str(h), str(fmt), str(array), str(mips), str(misc), str(flags), out, str(d if dim == 4 else 0), str(misc2), str(dim)],
+                       capture_output=True, text=True, timeout=60)
+    hr = int([l for l in r.stdout.splitlines() if l.startswith("hr ")][0].split()[1], 16)
+    return hr, (np.fromfile(out, np.uint8) if hr == 0 else None)
+
+
+def _tex_bytes(fmt, w, h, d, array, mips, dim):
+    total = 0
+    for _ in range(array if dim != 4 else 1):
+        ww, hh, dd = w, h, (d if dim == 4 else 1)
+        for _ in range(mips):
+            hr, rp, sp, sl = oracle.ref_compute_pitch(fmt, ww, hh, 0)
+            assert hr == 0
+            total += sp * dd
+            ww, hh, dd = max(1, ww >> 1), max(1, hh >> 1), max(1, dd >> 1)
+    return total
+
+
+WRITER_FLAGS = [0, 0x10000, 0x20000, 0x40000, 0x80000, 0x100000, 0x40000 | 0x80000, 0x100000 | 0x10000, 0x40000 | 0x100000]
+# every format EncodeDDSHeader treats specially plus a few it does not (DirectXTexDDS.cpp:744-886)
+WRITER_FORMATS = [28, 29, 35, 49, 56, 61, 65, 68, 69, 71, 72, 74, 75, 77, 78, 80, 81, 83, 84, 85, 86, 51, 31, 37, 87, 88, 91, 93, 115, 107, 2, 10, 11, 13, 16, 34, 41, 54,
+                  24, 26, 67, 95, 98, 99, 6, 30, 42, 66, 191, 103]
+
+
+@pytest.mark.parametrize("flags", WRITER_FLAGS)
+def test_writer_flags_against_the_reference(tmp_path, flags):
+    """SaveToDDSMemory under every writer flag (forced 'DX10' header, miscFlags2, Direct3D 9 only, RXGB, 24 bpp): the same
+    bytes or the same failure as the reference, for 2D, premultiplied-alpha, 1D, array, cubemap and volume textures."""
+    if not oracle.have_ref():
+        pytest.fail("oracle/_ref missing")
+    rng = np.random.default_rng(flags + 1)
+    shapes = [(12, 8, 1, 1, 3, 0, 0, 3), (12, 8, 1, 1, 1, 0, 2, 3), (16, 1, 1, 2, 2, 0, 0, 2), (8, 8, 1, 6, 2, 4, 0, 3), (8, 8, 1, 3, 1, 0, 1, 3), (8, 4, 4, 1, 3, 0, 0, 4)]
+    compared = 0
+    for fmt in WRITER_FORMATS:
+        for (w, h, d, array, mips, misc, misc2, dim) in shapes:
+            if fmt == 103 and (dim != 3 or mips > 1 or array > 1):
+                continue               # NV12 wants even heights on every level
+            px = rng.integers(0, 256, _tex_bytes(fmt, w, h, d, array, mips, dim), dtype=np.uint8)
+            hr, ours = _save_ex(str(tmp_path), px, w, h, d, fmt, array, mips, misc, misc2, dim, flags)
+            rhr, ref = oracle.ref_save_dds_ex(px, w, h, d if dim == 4 else 1, fmt, array, mips, misc, misc2, dim, flags)
+            assert hr == rhr, (fmt, flags, dim, hex(hr), hex(rhr))
+            if ref is not None:
+                assert np.array_equal(ours, ref), (fmt, flags, dim, ours[:148].tolist(), ref[:148].tolist())
+                compared += 1
+    assert compared > 100

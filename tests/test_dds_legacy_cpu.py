@@ -1,0 +1,240 @@
+"""The DDS reader of the C++ host layer on legacy (Direct3D 9) files, header variants and damaged files, differentially
+against the reference's LoadFromDDSMemory (DirectXTexDDS.cpp compiled in place into oracle/_ref): same HRESULT, same
+metadata, same pixels - for every entry of the legacy pixel-format table, under every reader flag, and for a few thousand
+seeded header mutations. Also the container-side format tables (BitsPerPixel, ComputePitch under CP_FLAGS, ...). CPU only."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "directxtex_amd", "lib", "host_api_test")
+
+FOURCC, RGB, RGBA, LUM, LUMA, ALPHA, PAL8, PAL8A, BUMPLUM, BUMPDUDV, BUMPDUDVA = 0x4, 0x40, 0x41, 0x20000, 0x20001, 0x2, 0x20, 0x21, 0x40000, 0x80000, 0x80001
+DDS_FLAGS = {"LEGACY_DWORD": 0x1, "NO_LEGACY_EXPANSION": 0x2, "NO_R10B10G10A2_FIXUP": 0x4, "FORCE_RGB": 0x8, "NO_16BPP": 0x10, "EXPAND_LUMINANCE": 0x20,
+             "BAD_DXTN_TAILS": 0x40, "PERMISSIVE": 0x80, "IGNORE_MIPS": 0x100, "ALLOW_LARGE_FILES": 0x1000000}
+
+
+def cc(s):
+    s = s.encode("latin1") if isinstance(s, str) else s
+    return s[0] | (s[1] << 8) | (s[2] << 16) | (s[3] << 24)
+
+
+def four(code):
+    return (32, FOURCC, cc(code) if not isinstance(code, int) else code, 0, 0, 0, 0, 0)
+
+
+def masks(flags, bits, r, g, b, a):
+    return (32, flags, 0, bits, r, g, b, a)
+
+
+# every pixel format the reference's legacy table knows (DirectXTexDDS.cpp:62-199)
+LEGACY = [four(c) for c in ("DXT1", "DXT2", "DXT3", "DXT4", "DXT5", "A2D5", "xGBR", "RxBG", "RBxG", "xRBG", "RGxB", "xGxR", "GXRB", "GRXB", "RXGB", "BRGX",
+                            "BC4U", "BC4S", "BC5U", "BC5S", "ATI1", "ATI2", "A2XY", "BC6H", "BC7L", b"BC7\0", "RGBG", "GRGB", "YUY2", "UYVY",
+                            36, 110, 111, 112, 113, 114, 115, 116)] + [
+    masks(RGBA, 32, 0x00ff0000, 0x0000ff00, 0x000000ff, 0xff000000), masks(RGB, 32, 0x00ff0000, 0x0000ff00, 0x000000ff, 0),
+    masks(RGBA, 32, 0x000000ff, 0x0000ff00, 0x00ff0000, 0xff000000), masks(RGB, 32, 0x000000ff, 0x0000ff00, 0x00ff0000, 0),
+    masks(RGB, 32, 0x0000ffff, 0xffff0000, 0, 0),
+    masks(RGBA, 32, 0x000003ff, 0x000ffc00, 0x3ff00000, 0xc0000000), masks(RGBA, 32, 0x3ff00000, 0x000ffc00, 0x000003ff, 0xc0000000),
+    masks(RGB, 24, 0xff0000, 0x00ff00, 0x0000ff, 0),
+    masks(RGB, 16, 0xf800, 0x07e0, 0x001f, 0), masks(RGBA, 16, 0x7c00, 0x03e0, 0x001f, 0x8000), masks(RGB, 16, 0x7c00, 0x03e0, 0x001f, 0),
+    masks(RGBA, 16, 0x00e0, 0x001c, 0x0003, 0xff00), masks(RGB, 8, 0xe0, 0x1c, 0x03, 0),
+    masks(LUM, 8, 0xff, 0, 0, 0), masks(LUM, 16, 0xffff, 0, 0, 0), masks(LUMA, 16, 0x00ff, 0, 0, 0xff00), masks(LUMA, 8, 0x00ff, 0, 0, 0xff00),
+    masks(RGB, 8, 0xff, 0, 0, 0), masks(RGB, 16, 0xffff, 0, 0, 0), masks(RGBA, 16, 0x00ff, 0, 0, 0xff00),
+    masks(ALPHA, 8, 0, 0, 0, 0xff), masks(RGB, 32, 0xffffffff, 0, 0, 0),
+    masks(PAL8A, 16, 0, 0, 0, 0xff00), masks(PAL8, 8, 0, 0, 0, 0),
+    masks(RGBA, 16, 0x0f00, 0x00f0, 0x000f, 0xf000), masks(RGB, 16, 0x0f00, 0x00f0, 0x000f, 0), masks(LUMA, 8, 0x0f, 0, 0, 0xf0),
+    masks(BUMPDUDV, 16, 0x00ff, 0xff00, 0, 0), masks(BUMPDUDV, 32, 0x000000ff, 0x0000ff00, 0x00ff0000, 0xff000000), masks(BUMPDUDV, 32, 0x0000ffff, 0xffff0000, 0, 0),
+    masks(BUMPLUM, 16, 0x001f, 0x03e0, 0xfc00, 0), masks(BUMPLUM, 32, 0x000000ff, 0x0000ff00, 0x00ff0000, 0),
+    masks(BUMPDUDVA, 32, 0x3ff00000, 0x000ffc00, 0x000003ff, 0xc0000000),
+    # not in the table: must be refused
+    masks(RGB, 32, 0x00ff0000, 0x0000ff00, 0x0000ff00, 0), masks(RGBA, 16, 0xf000, 0x0f00, 0x00f0, 0x000f), four("ETC1"), masks(0x400, 16, 0, 0, 0, 0),
+]
+
+
+def header(w, h, pf, flags=0x1007, mips=0, depth=0, caps2=0, size=124, reserved9=0, dx10=None, pitch=0):
+    """magic + DDS_HEADER (+ DDS_HEADER_DXT10): DDS.h:262-287."""
+    reserved = [0] * 11
+    reserved[9] = reserved9
+    b = struct.pack("<I", 0x20534444)
+    b += struct.pack("<7I", size, flags, h, w, pitch, depth, mips) + struct.pack("<11I", *reserved) + struct.pack("<8I", *pf)
+    b += struct.pack("<5I", 0x1000, caps2, 0, 0, 0)
+    if dx10 is not None:
+        b += struct.pack("<5I", *dx10)
+    return b
+
+
+def run_ours(tmp, cases):
+    """cases: [(file bytes, ddsFlags)] -> [(hr, meta dict or None, pixels or None)] through one process."""
+    lines = []
+    for i, (data, flags) in enumerate(cases):
+        path = os.path.join(tmp, f"c{i}.dds")
+        with open(path, "wb") as f:
+            f.write(data)
+        lines.append(f"{path} {flags}")
+    lst = os.path.join(tmp, "list.txt")
+    with open(lst, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    r = subprocess.run([EXE, "dds_load_many", lst], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = []
+    rows = r.stdout.splitlines()
+    assert len(rows) == len(cases)
+    for i, row in enumerate(rows):
+        p = row.split()
+        hr = int(p[1], 16)
+        if len(p) > 2:
+            meta = dict(zip(oracle.DDS_META_KEYS, (int(x) for x in p[3:])))
+            out.append((hr, meta, np.fromfile(os.path.join(tmp, f"c{i}.dds.out"), np.uint8)))
+        else:
+            out.append((hr, None, None))
+    return out
+
+
+def compare(tmp, cases, what):
+    ours = run_ours(tmp, cases)
+    loaded = 0
+    for i, ((data, flags), (hr, meta, px)) in enumerate(zip(cases, ours)):
+        rhr, rmeta, rpx = oracle.ref_load_dds_ex(np.frombuffer(data, np.uint8), flags, capacity=1 << 24)
+        where = f"{what} case {i} flags {flags:#x} header {data[:148].hex()}"
+        assert hr == rhr, f"HRESULT {hr:#x} vs the reference's {rhr:#x}: {where}"
+        assert meta == rmeta, f"metadata {meta} vs {rmeta}: {where}"
+        if rpx is not None:
+            loaded += 1
+            assert px.size == rpx.size and np.array_equal(px, rpx), f"pixels differ ({np.flatnonzero(px != rpx)[:8]}): {where}"
+    return loaded
+
+
+FLAG_SETS = [0, 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80, 0x100, 0x10 | 0x1, 0x20 | 0x1, 0x8 | 0x10 | 0x20, 0x4 | 0x8, 0x40 | 0x1, 0x2 | 0x10]
+
+
+def test_container_format_tables_match_the_reference():
+    """BitsPerPixel, the format predicates, ComputePitch under every CP_FLAGS rule and ComputeScanlines for all format ids."""
+    r = subprocess.run([EXE, "formats"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    checked = 0
+    for line in r.stdout.splitlines():
+        p = line.split()
+        if p[0] == "fmt":
+            assert (int(p[2]), int(p[3])) == oracle.ref_format_facts(int(p[1])), line
+        elif int(p[1]) != 0:
+            f, w, h, cp = (int(x) for x in p[1:5])
+            hr, rp, sp, sl = oracle.ref_compute_pitch(f, w, h, cp)
+            assert (int(p[5], 16), int(p[6]), int(p[7]), int(p[8])) == (hr, rp if hr == 0 else 0, sp if hr == 0 else 0, sl), line
+        checked += 1
+    assert checked > 10000
+
+
+@pytest.mark.parametrize("shape", [(7, 5, 3, 0), (16, 16, 5, 0), (1, 1, 1, 0), (6, 4, 2, 3), (9, 9, 0, 0), (4, 4, 1, 0x200 | 0xFC00)])
+def test_every_legacy_pixel_format_under_every_reader_flag(tmp_path, shape):
+    w, h, mips, extra = shape
+    rng = np.random.default_rng(w * 131 + h)
+    payload = rng.integers(0, 256, 1 << 16, dtype=np.uint8).tobytes()
+    cases = []
+    for pf in LEGACY:
+        for fl in FLAG_SETS:
+            if extra == 3:       # a volume
+                data = header(w, h, pf, flags=0x1007 | 0x800000, mips=mips, depth=3, caps2=0x200000)
+            elif extra:          # a cubemap
+                data = header(w, h, pf, mips=mips, caps2=extra)
+            else:
+                data = header(w, h, pf, mips=mips)
+            cases.append((data + payload, fl))
+    loaded = compare(str(tmp_path), cases, f"legacy {shape}")
+    assert loaded > len(cases) // 2
+
+
+def test_header_variants_nvtt_and_dx10(tmp_path):
+    rng = np.random.default_rng(5)
+    payload = rng.integers(0, 256, 1 << 16, dtype=np.uint8).tobytes()
+    a8r8g8b8 = masks(RGBA, 32, 0x00ff0000, 0x0000ff00, 0x000000ff, 0xff000000)
+    cases = []
+    nvtt = cc("NVTT")
+    for fl in (0, 0x80):
+        # NVTT's sRGB / normal-map bits in the pixel format flags, with and without the NVTT tag
+        for pfflags in (RGBA | 0x40000000, RGBA | 0x80000000, RGBA | 0xC0000000):
+            pf = (32, pfflags) + a8r8g8b8[2:]
+            cases.append((header(8, 8, pf, reserved9=nvtt) + payload, fl))
+            cases.append((header(8, 8, pf) + payload, fl))
+        cases.append((header(8, 8, (32, FOURCC | 0x40000000, cc("DXT1"), 0, 0, 0, 0, 0), reserved9=nvtt) + payload, fl))
+        # known variants: header size 24, pixel format size 0 / 24, a blank pixel format with only a FourCC
+        cases.append((header(8, 8, a8r8g8b8, size=24) + payload, fl))
+        cases.append((header(8, 8, (24,) + a8r8g8b8[1:]) + payload, fl))
+        cases.append((header(8, 8, (0,) + a8r8g8b8[1:]) + payload, fl))
+        cases.append((header(8, 8, (0, 0, cc("DXT5"), 0, 0, 0, 0, 0)) + payload, fl))
+        cases.append((header(8, 8, (0, 0, cc("ZZZZ"), 0, 0, 0, 0, 0)) + payload, fl))
+        cases.append((header(8, 8, a8r8g8b8, size=100) + payload, fl))
+        cases.append((header(8, 8, a8r8g8b8, mips=9) + payload, fl))                    # too many mips: permissive clamps
+        cases.append((header(8, 8, a8r8g8b8, mips=9, flags=0x1007 | 0x800000, depth=2) + payload, fl))
+        cases.append((header(8, 8, a8r8g8b8, caps2=0x200 | 0x400) + payload, fl))       # a cubemap with one face
+        # 'DX10' files: every dimension, arrays, cubes, bad dimension, zero array size, palettised / invalid formats
+        dx = four("DX10")
+        for ext in ((28, 3, 0, 1, 0), (28, 3, 0, 0, 0), (28, 3, 0, 3, 2), (28, 3, 4, 1, 0), (28, 3, 4, 2, 3), (28, 2, 0, 2, 0), (28, 4, 0, 1, 0), (28, 4, 0, 2, 0),
+                    (28, 0, 0, 1, 0), (28, 5, 0, 1, 0), (113, 3, 0, 1, 0), (0, 3, 0, 1, 0), (192, 3, 0, 1, 0), (121, 3, 0, 1, 0), (66, 3, 0, 1, 0),
+                    (85, 3, 0, 1, 0), (86, 3, 0, 1, 0), (115, 3, 0, 1, 0), (191, 3, 0, 1, 0), (87, 3, 0, 1, 0), (88, 3, 0, 1, 0), (90, 3, 0, 1, 0),
+                    (91, 3, 0, 1, 0), (92, 3, 0, 1, 0), (93, 3, 0, 1, 0), (103, 3, 0, 1, 0), (104, 3, 0, 1, 0), (107, 3, 0, 1, 0), (68, 3, 0, 2, 0),
+                    (24, 3, 0, 1, 0), (71, 3, 0, 1, 1), (98, 3, 4, 1, 0), (26, 3, 0, 1, 0), (6, 3, 0, 1, 0), (130, 3, 0, 1, 0), (110, 3, 0, 1, 0)):
+            for hflags, h, depth in ((0x1007, 8, 0), (0x1007 | 0x800000, 8, 4), (0x1007, 1, 0), (0x1005, 8, 0)):
+                cases.append((header(8, h, dx, flags=hflags, depth=depth, mips=2, dx10=ext) + payload, fl))
+        for fl2 in (0x8, 0x10, 0x100, 0x8 | 0x10):
+            for fmt in (85, 86, 87, 88, 90, 91, 92, 93, 115, 191):
+                cases.append((header(8, 8, dx, mips=3, dx10=(fmt, 3, 0, 1, 0)) + payload, fl | fl2))
+    # the hardware limits and ALLOW_LARGE_FILES (no payload needed: these fail or succeed in the header)
+    for dims in ((16385, 1, 1, 0), (1, 16385, 1, 0), (4, 4, 16, 0), (4, 4, 1, 2049)):
+        for fl in (0, 0x1000000):
+            w, h, mips, depth = dims
+            cases.append((header(w, h, a8r8g8b8, mips=mips, flags=0x1007 | (0x800000 if depth else 0), depth=depth) + payload[:4096], fl))
+    cases.append((header(4, 4, four("DX10"), dx10=(28, 3, 0, 2049, 0)) + payload[:64], 0))
+    compare(str(tmp_path), cases, "variants")
+
+
+def test_truncated_and_bad_tail_files(tmp_path):
+    rng = np.random.default_rng(6)
+    payload = rng.integers(0, 256, 1 << 14, dtype=np.uint8).tobytes()
+    cases = []
+    for pf in (four("DXT1"), four("DXT5"), four("ATI2"), masks(RGB, 24, 0xff0000, 0x00ff00, 0x0000ff, 0), masks(PAL8, 8, 0, 0, 0, 0), masks(PAL8A, 16, 0, 0, 0, 0xff00),
+               masks(RGBA, 32, 0x00ff0000, 0x0000ff00, 0x000000ff, 0xff000000), masks(LUM, 8, 0xff, 0, 0, 0)):
+        for (w, h, mips) in ((16, 16, 5), (8, 4, 4), (2, 2, 2), (20, 12, 0)):
+            full = header(w, h, pf, mips=mips) + payload
+            for cut in (0, 4, 100, 127, 128, 129, 140, 148, 200, 128 + 1024, 128 + 1025, 128 + 1024 + 37, 128 + 400, len(full)):
+                for fl in (0, 0x40, 0x1, 0x41):
+                    cases.append((full[:cut], fl))
+    # texture arrays and volumes of block-compressed data with the broken tails
+    for ext, hflags, depth in (((71, 3, 0, 3, 0), 0x1007, 0), ((77, 4, 0, 1, 0), 0x1007 | 0x800000, 4), ((98, 3, 4, 1, 0), 0x1007, 0)):
+        for (w, h, mips) in ((16, 16, 5), (2, 2, 2), (8, 8, 0)):
+            for fl in (0, 0x40):
+                cases.append((header(w, h, four("DX10"), flags=hflags, depth=depth, mips=mips, dx10=ext) + payload, fl))
+    compare(str(tmp_path), cases, "truncated")
+
+
+def test_seeded_header_mutations(tmp_path):
+    """Differential fuzzing: valid headers with random fields replaced by interesting values."""
+    rng = np.random.default_rng(7)
+    payload = rng.integers(0, 256, 1 << 15, dtype=np.uint8).tobytes()
+    interesting = [0, 1, 2, 3, 4, 6, 7, 8, 15, 16, 24, 31, 32, 64, 124, 0xff, 0x100, 0xffff, 0x10000, 0x7fffffff, 0x80000000, 0xffffffff,
+                   0x1007, 0x800000, 0x200, 0xFE00, 0x200000, 0x40, 0x41, 0x4, 0x20000, 0x20001, 0x80000, 0x20, 0x21, 0x2, cc("DX10"), cc("DXT1"), cc("NVTT")]
+    cases = []
+    for i in range(3000):
+        pf = LEGACY[int(rng.integers(len(LEGACY)))]
+        w, h = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+        dx10 = None
+        if rng.random() < 0.35:
+            pf = four("DX10")
+            dx10 = (int(rng.integers(0, 120)), int(rng.choice([2, 3, 3, 3, 4])), int(rng.choice([0, 0, 4])), int(rng.integers(0, 4)), int(rng.integers(0, 5)))
+        volume = rng.random() < 0.2
+        words = list(struct.unpack(f"<{(len(header(1, 1, pf, dx10=dx10))) // 4}I",
+                                   header(w, h, pf, flags=0x1007 | (0x800000 if volume else 0), mips=int(rng.integers(0, 6)), depth=int(rng.integers(0, 5)) if volume else 0,
+                                          caps2=int(rng.choice([0, 0, 0xFE00, 0x200000])), dx10=dx10)))
+        for _ in range(int(rng.integers(0, 3))):
+            words[int(rng.integers(1, len(words)))] = int(interesting[int(rng.integers(len(interesting)))])
+        data = struct.pack(f"<{len(words)}I", *words) + payload[:int(rng.choice([0, 64, 2048, 1 << 15]))]
+        fl = 0
+        for bit in (0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80, 0x100):
+            if rng.random() < 0.15:
+                fl |= bit
+        cases.append((data, fl))
+    compare(str(tmp_path), cases, "mutations")
