@@ -82,6 +82,18 @@ bool IsSRGB(DXGI_FORMAT fmt) noexcept
     }
 }
 
+bool HasAlpha(DXGI_FORMAT fmt) noexcept
+{
+    // DirectXTexUtil.cpp:215-276, as runs of the DXGI numbering
+    static const struct { uint16_t first, last; } runs[] = {
+        { 1, 4 }, { 9, 14 }, { 23, 25 }, { 27, 32 }, { 65, 65 }, { 70, 78 }, { 86, 87 }, { 89, 91 }, { 97, 102 }, { 111, 112 }, { 114, 117 }, { 189, 189 }, { 191, 191 },
+    };
+    const uint32_t f = uint32_t(fmt);
+    for (const auto& r : runs)
+        if (f >= r.first && f <= r.last) return true;
+    return false;
+}
+
 DXGI_FORMAT MakeSRGB(DXGI_FORMAT fmt) noexcept
 {
     switch (fmt)
@@ -830,25 +842,11 @@ HRESULT Convert(Device& device, const Image* srcImages, size_t nimages, const Te
 }
 
 // ---- PremultiplyAlpha (DirectXTexPMAlpha.cpp:214-341) ----------------------------------------------------------------------------------
-namespace
-{
-bool HasAlphaChannel(DXGI_FORMAT f) noexcept
-{
-    switch (int(f))
-    {
-    case 2: case 10: case 11: case 13: case 24: case 28: case 29: case 31: case 65: case 87: case 91:       // RGBA32F, RGBA16F/UNORM/SNORM, 10:10:10:2, RGBA8*, A8, BGRA8*
-        return true;
-    default:
-        return false;
-    }
-}
-}
-
 HRESULT PremultiplyAlpha(Device& device, const Image& srcImage, TEX_PMALPHA_FLAGS flags, ScratchImage& image) noexcept
 {
     if (!device) return E_POINTER;
     if (!srcImage.pixels) return E_POINTER;
-    if (IsCompressed(srcImage.format) || !IsKnown(srcImage.format) || !HasAlphaChannel(srcImage.format)) return HRESULT_E_NOT_SUPPORTED;
+    if (IsCompressed(srcImage.format) || !IsKnown(srcImage.format) || !HasAlpha(srcImage.format)) return HRESULT_E_NOT_SUPPORTED;
     if (srcImage.width > UINT32_MAX || srcImage.height > UINT32_MAX) return E_INVALIDARG;
     HRESULT hr = image.Initialize2D(srcImage.format, srcImage.width, srcImage.height, 1, 1);
     if (FAILED(hr)) return hr;
@@ -864,7 +862,7 @@ HRESULT PremultiplyAlpha(Device& device, const Image* srcImages, size_t nimages,
 {
     if (!device) return E_POINTER;
     if (!srcImages || !nimages) return E_INVALIDARG;
-    if (IsCompressed(metadata.format) || !IsKnown(metadata.format) || !HasAlphaChannel(metadata.format)) return HRESULT_E_NOT_SUPPORTED;
+    if (IsCompressed(metadata.format) || !IsKnown(metadata.format) || !HasAlpha(metadata.format)) return HRESULT_E_NOT_SUPPORTED;
     if (metadata.width > UINT32_MAX || metadata.height > UINT32_MAX) return E_INVALIDARG;
     const bool isPM = metadata.IsPMAlpha();
     if (isPM != ((flags & TEX_PMALPHA_REVERSE) != 0)) return E_FAIL;                      // :283-284

@@ -100,6 +100,7 @@ bool IsPacked(DXGI_FORMAT fmt) noexcept;
 bool IsPlanar(DXGI_FORMAT fmt) noexcept;
 bool IsPalettized(DXGI_FORMAT fmt) noexcept;
 bool IsSRGB(DXGI_FORMAT fmt) noexcept;
+bool HasAlpha(DXGI_FORMAT fmt) noexcept;
 DXGI_FORMAT MakeSRGB(DXGI_FORMAT fmt) noexcept;
 size_t BitsPerPixel(DXGI_FORMAT fmt) noexcept;
 // true for the formats the GPU entry points (Compress, Convert, Resize, ...) accept

@@ -1,16 +1,32 @@
-// dxtexconv - a small texconv-style batch converter on top of the MI355X host layer (DirectXTexAMD.h).
-// Same pipeline order as the reference tool (Texconv/texconv.cpp:2609 resize -> :3109 convert -> :3434 mipmaps ->
-// :3711 compress), DDS in, DDS out; every image-processing step runs on the GPU.
+// dxtexconv - a texconv-style batch converter on top of the MI355X host layer (DirectXTexAMD.h): DDS in, DDS out, every
+// image-processing step on the GPU. The pipeline and its order are the reference tool's (Texconv/texconv.cpp): load (:2077-2090)
+// -> decompress (:2325-2480) -> undo premultiplied alpha (:2482-2530) -> resize (:2577-2640) -> convert (:3100-3140) ->
+// mipmaps (:3302-3460) -> alpha-coverage preservation (:3462-3500) -> premultiply alpha (:3502-3545) -> compress (:3547-3735) ->
+// alpha mode (:3738-3766) -> save (:3858-3878). Option names are texconv's; what has no GPU implementation here (flips,
+// swizzles, normal maps, tone mapping, WIC / TGA / HDR codecs, dithered conversion) is refused, not approximated.
 //
-//   dxtexconv [-w <width>] [-h <height>] [-m <miplevels, 0 = full chain>] [-f <DXGI format name or number>]
-//             [-if <POINT|LINEAR|CUBIC|BOX|TRIANGLE>[_WRAP|_MIRROR]] [-bc <q|x|d|u>...] [-srgb] [-gpu <n>] [-dx10]
-//             -o <out.dds> <in.dds>
+//   dxtexconv [options] -o <out.dds | output directory> <in.dds>...
+//     -w <n> -h <n>        target size                         -pow2             fit to a power of two (keeps the aspect ratio)
+//     -m <n>               mip levels, 0 = full chain           -fl <9.1 .. 12.2> feature level: largest texture side allowed
+//     -f <format>          DXGI format name or number           -if <filter>      POINT LINEAR CUBIC FANT BOX TRIANGLE
+//     -wrap -mirror        addressing of the filters            -srgb -srgbi -srgbo   sRGB on both sides / input / output
+//     -pmalpha -alpha      to / from premultiplied alpha        -keepcoverage <ref>   keep alpha-test coverage in the mips
+//     -at <threshold>      alpha threshold (BC1, 1-bit alpha)   -bc <q|x|d|u>...  BC7 quick / 3 subsets, dither, uniform weights
+//     -x2bias              *2 - 1 on conversions to / from SNORM -sepalpha        resize / mip alpha separately (alpha mode custom)
+//     -dword -badtails -permissive -ignoremips -xlum            DDS reader tolerances (DDS_FLAGS)
+//     -dx10 -dx9           force the 'DX10' header (+ alpha mode) / a Direct3D 9 file
+//     -px <s> -sx <s> -l   output name prefix / suffix, lower case    -y   overwrite    -timing -nologo -gpu <n>
 #include "../host/DirectXTexAMD.h"
 
+#include <algorithm>
+#include <cctype>
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <sys/stat.h>
 #include <vector>
 
 using namespace DirectXTexAMD;
@@ -25,6 +41,9 @@ const Name kFormats[] = {
     { "BC1_UNORM", 71 }, { "BC1_UNORM_SRGB", 72 }, { "BC2_UNORM", 74 }, { "BC2_UNORM_SRGB", 75 }, { "BC3_UNORM", 77 }, { "BC3_UNORM_SRGB", 78 },
     { "BC4_UNORM", 80 }, { "BC4_SNORM", 81 }, { "BC5_UNORM", 83 }, { "BC5_SNORM", 84 }, { "B8G8R8A8_UNORM", 87 }, { "B8G8R8X8_UNORM", 88 },
     { "B8G8R8A8_UNORM_SRGB", 91 }, { "B8G8R8X8_UNORM_SRGB", 93 }, { "BC6H_UF16", 95 }, { "BC6H_SF16", 96 }, { "BC7_UNORM", 98 }, { "BC7_UNORM_SRGB", 99 },
+    // texconv's aliases (texconv.cpp:420-440)
+    { "DXT1", 71 }, { "DXT2", 74 }, { "DXT3", 74 }, { "DXT4", 77 }, { "DXT5", 77 }, { "RGBA", 28 }, { "BGRA", 87 }, { "BGR", 88 }, { "FP16", 10 }, { "FP32", 2 },
+    { "BC4", 80 }, { "BC5", 83 }, { "BC6H", 95 }, { "BC7", 98 },
 };
 const Name kFilters[] = {
     { "POINT", TEX_FILTER_POINT }, { "LINEAR", TEX_FILTER_LINEAR }, { "CUBIC", TEX_FILTER_CUBIC }, { "BOX", TEX_FILTER_BOX }, { "FANT", TEX_FILTER_BOX },
@@ -32,156 +51,399 @@ const Name kFilters[] = {
     { "POINT_WRAP", TEX_FILTER_POINT | TEX_FILTER_WRAP }, { "LINEAR_WRAP", TEX_FILTER_LINEAR | TEX_FILTER_WRAP }, { "CUBIC_WRAP", TEX_FILTER_CUBIC | TEX_FILTER_WRAP },
     { "TRIANGLE_WRAP", TEX_FILTER_TRIANGLE | TEX_FILTER_WRAP }, { "LINEAR_MIRROR", TEX_FILTER_LINEAR | TEX_FILTER_MIRROR }, { "CUBIC_MIRROR", TEX_FILTER_CUBIC | TEX_FILTER_MIRROR },
 };
+const Name kFeatureLevels[] = {         // largest 2D texture side (texconv.cpp:880-905)
+    { "9.1", 2048 }, { "9.2", 2048 }, { "9.3", 4096 }, { "10.0", 8192 }, { "10.1", 8192 }, { "11.0", 16384 }, { "11.1", 16384 }, { "12.0", 16384 }, { "12.1", 16384 }, { "12.2", 16384 },
+};
+constexpr uint32_t TEX_FILTER_SEPARATE_ALPHA = 0x100;
 
-bool lookup(const Name* t, size_t n, const char* s, uint32_t& out)
+bool lookup(const Name* t, size_t n, const char* s, uint32_t& out, bool numbers = true)
 {
     for (size_t i = 0; i < n; ++i) if (!strcasecmp(t[i].name, s)) { out = t[i].value; return true; }
+    if (!numbers) return false;
     char* end = nullptr; const unsigned long v = std::strtoul(s, &end, 0);
     if (end && *end == 0 && end != s) { out = uint32_t(v); return true; }
     return false;
 }
 
-int fail(const char* what, HRESULT hr, Device& dev)
+struct Options
 {
-    std::fprintf(stderr, "FAILED [%s] (%08X) %s\n", what, unsigned(hr), dev ? dev.LastError() : "");
-    return 1;
+    size_t width = 0, height = 0, mipLevels = 0, maxSize = 16384;          // mipLevels 0: keep a chain the input has, else build the full one
+    bool pow2 = false, pmalpha = false, demul = false, dx10 = false, dx9 = false, sepalpha = false, lower = false, overwrite = false,
+         timing = false, nologo = false;
+    uint32_t format = 0, filter = 0, filterOpts = 0, srgb = 0, convert = 0, compress = 0, ddsRead = DDS_FLAGS_ALLOW_LARGE_FILES;
+    float alphaThreshold = TEX_THRESHOLD_DEFAULT, keepCoverage = 0.f;
+    int gpu = 0;
+    std::string prefix, suffix, out;
+    std::vector<std::string> inputs;
+};
+
+bool ispow2(size_t x) { return x && !(x & (x - 1)); }
+
+// FitPowerOf2 (texconv.cpp:1019-1057): the larger side snaps down to a power of two, the other takes the power of two that keeps
+// the aspect ratio best
+void FitPowerOf2(size_t origx, size_t origy, size_t& targetx, size_t& targety, size_t maxsize)
+{
+    const float aspect = float(origx) / float(origy);
+    size_t& major = (origx > origy) ? targetx : targety;
+    size_t& minor = (origx > origy) ? targety : targetx;
+    size_t m;
+    for (m = maxsize; m > 1; m >>= 1) if (m <= major) break;
+    major = m;
+    float best = 3.402823466e+38f;
+    for (size_t o = maxsize; o > 0; o >>= 1)
+    {
+        const float score = std::fabs(((origx > origy) ? float(m) / float(o) : float(o) / float(m)) - aspect);
+        if (score < best) { best = score; minor = o; }
+    }
 }
 
-// the level-0 image of every array item as a stand-alone single-mip texture
+// ScratchImage::IsAlphaAllOpaque (DirectXTexImage.cpp:800-852): every alpha >= 0.997. Block-compressed images are decoded on the GPU.
+bool IsAlphaAllOpaque(Device& dev, const ScratchImage& image)
+{
+    const TexMetadata& info = image.GetMetadata();
+    if (!image.GetImageCount()) return false;
+    if (!HasAlpha(info.format)) return true;
+    ScratchImage decoded;
+    const ScratchImage* src = &image;
+    if (IsCompressed(info.format))
+    {
+        // to floats, so that the decoder's own alpha values meet the threshold (IsAlphaAllOpaqueBC, DirectXTexCompress.cpp:537-610)
+        if (FAILED(Decompress(dev, image.GetImages(), image.GetImageCount(), info, DXGI_FORMAT_R32G32B32A32_FLOAT, decoded))) return false;
+        src = &decoded;
+    }
+    const DXGI_FORMAT f = src->GetMetadata().format;
+    auto half = [](uint16_t h) -> float
+    {
+        const uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ff;
+        const float v = (e == 0) ? std::ldexp(float(m), -24) : (e == 31) ? (m ? NAN : INFINITY) : std::ldexp(float(m | 0x400), int(e) - 25);
+        return (h & 0x8000) ? -v : v;
+    };
+    for (size_t i = 0; i < src->GetImageCount(); ++i)
+    {
+        const Image& im = src->GetImages()[i];
+        for (size_t y = 0; y < im.height; ++y)
+        {
+            const uint8_t* row = im.pixels + y * im.rowPitch;
+            for (size_t x = 0; x < im.width; ++x)
+            {
+                float a;
+                switch (f)
+                {
+                case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB: case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB:
+                    a = float(row[x * 4 + 3]) * (1.0f / 255.0f); break;
+                case DXGI_FORMAT_R8G8B8A8_SNORM: a = std::max(float(int8_t(row[x * 4 + 3])) * (1.0f / 127.0f), -1.0f); break;
+                case DXGI_FORMAT_A8_UNORM: a = float(row[x]) / 255.0f; break;
+                case DXGI_FORMAT_R16G16B16A16_UNORM: { uint16_t v; std::memcpy(&v, row + x * 8 + 6, 2); a = float(v) * (1.0f / 65535.0f); break; }
+                case DXGI_FORMAT_R16G16B16A16_FLOAT: { uint16_t v; std::memcpy(&v, row + x * 8 + 6, 2); a = half(v); break; }
+                case DXGI_FORMAT_R32G32B32A32_FLOAT: std::memcpy(&a, row + x * 16 + 12, 4); break;
+                default: return false;
+                }
+                if (a < 0.997f) return false;
+            }
+        }
+    }
+    return true;
+}
+
+// mip level 0 of every array item / depth slice as a texture with one level (texconv.cpp:3324-3380)
 HRESULT TopLevels(const ScratchImage& in, ScratchImage& out)
 {
     TexMetadata m = in.GetMetadata();
     m.mipLevels = 1;
     HRESULT hr = out.Initialize(m);
     if (FAILED(hr)) return hr;
-    for (size_t item = 0; item < m.arraySize; ++item)
+    const bool volume = m.dimension == TEX_DIMENSION_TEXTURE3D;
+    for (size_t i = 0; i < (volume ? m.depth : m.arraySize); ++i)
     {
-        const Image* s = in.GetImage(0, item, 0); const Image* d = out.GetImage(0, item, 0);
+        const Image* s = volume ? in.GetImage(0, 0, i) : in.GetImage(0, i, 0);
+        const Image* d = volume ? out.GetImage(0, 0, i) : out.GetImage(0, i, 0);
+        if (!s || !d) return E_FAIL;
         std::memcpy(d->pixels, s->pixels, d->slicePitch);
     }
     return S_OK;
 }
+
+int usage()
+{
+    std::fprintf(stderr, "usage: dxtexconv [-w W] [-h H] [-pow2] [-fl LEVEL] [-m N] [-f FORMAT] [-if FILTER] [-wrap] [-mirror] [-srgb|-srgbi|-srgbo]\n"
+                         "                 [-pmalpha|-alpha] [-keepcoverage REF] [-at T] [-bc qxdu] [-x2bias] [-sepalpha] [-dword] [-badtails] [-permissive]\n"
+                         "                 [-ignoremips] [-xlum] [-dx10|-dx9] [-px S] [-sx S] [-l] [-y] [-timing] [-nologo] [-gpu N] -o <out.dds | dir> in.dds...\n");
+    return 1;
 }
 
-int main(int argc, char** argv)
+bool Parse(int argc, char** argv, Options& o)
 {
-    size_t width = 0, height = 0, mipLevels = 1;
-    uint32_t format = 0, filter = 0, compress = 0;
-    int gpu = 0; bool dx10 = false, haveMips = false;
-    const char* outFile = nullptr; const char* inFile = nullptr;
     for (int i = 1; i < argc; ++i)
     {
-        const std::string a = argv[i];
-        auto next = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
-        if (a == "-w") width = std::strtoull(next(), nullptr, 10);
-        else if (a == "-h") height = std::strtoull(next(), nullptr, 10);
-        else if (a == "-m") { mipLevels = std::strtoull(next(), nullptr, 10); haveMips = true; }
-        else if (a == "-f") { if (!lookup(kFormats, sizeof(kFormats) / sizeof(Name), next(), format)) { std::fprintf(stderr, "unknown format\n"); return 1; } }
-        else if (a == "-if") { if (!lookup(kFilters, sizeof(kFilters) / sizeof(Name), next(), filter)) { std::fprintf(stderr, "unknown filter\n"); return 1; } }
+        std::string a = argv[i];
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-') a.erase(0, 1);          // --long-form spelled like the short one
+        bool missing = false;
+        auto next = [&]() -> const char* { if (i + 1 < argc) return argv[++i]; missing = true; return ""; };
+        if (a == "-w") o.width = std::strtoull(next(), nullptr, 10);
+        else if (a == "-h") o.height = std::strtoull(next(), nullptr, 10);
+        else if (a == "-m") o.mipLevels = std::strtoull(next(), nullptr, 10);
+        else if (a == "-f") { if (!lookup(kFormats, sizeof(kFormats) / sizeof(Name), next(), o.format)) { std::fprintf(stderr, "unknown format\n"); return false; } }
+        else if (a == "-if") { if (!lookup(kFilters, sizeof(kFilters) / sizeof(Name), next(), o.filter)) { std::fprintf(stderr, "unknown filter (dithered filters have no GPU path)\n"); return false; } }
+        else if (a == "-fl") { uint32_t v; if (!lookup(kFeatureLevels, sizeof(kFeatureLevels) / sizeof(Name), next(), v, false)) { std::fprintf(stderr, "unknown feature level\n"); return false; } o.maxSize = v; }
         else if (a == "-bc")
         {
             for (const char* p = next(); *p; ++p)
                 switch (*p)
                 {
-                case 'q': compress |= TEX_COMPRESS_BC7_QUICK; break;
-                case 'x': compress |= TEX_COMPRESS_BC7_USE_3SUBSETS; break;
-                case 'd': compress |= TEX_COMPRESS_DITHER; break;
-                case 'u': compress |= TEX_COMPRESS_UNIFORM; break;
-                default: std::fprintf(stderr, "unknown -bc flag %c\n", *p); return 1;
+                case 'q': o.compress |= TEX_COMPRESS_BC7_QUICK; break;
+                case 'x': o.compress |= TEX_COMPRESS_BC7_USE_3SUBSETS; break;
+                case 'd': o.compress |= TEX_COMPRESS_DITHER; break;
+                case 'u': o.compress |= TEX_COMPRESS_UNIFORM; break;
+                default: std::fprintf(stderr, "unknown -bc flag %c\n", *p); return false;
                 }
         }
-        else if (a == "-gpu") gpu = std::atoi(next());
-        else if (a == "-dx10") dx10 = true;
-        else if (a == "-o") outFile = next();
-        else if (a[0] == '-') { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
-        else inFile = argv[i];
+        else if (a == "-srgb") o.srgb |= TEX_FILTER_SRGB;
+        else if (a == "-srgbi") o.srgb |= TEX_FILTER_SRGB_IN;
+        else if (a == "-srgbo") o.srgb |= TEX_FILTER_SRGB_OUT;
+        else if (a == "-wrap") { if (o.filterOpts & TEX_FILTER_MIRROR) { std::fprintf(stderr, "-wrap and -mirror exclude each other\n"); return false; } o.filterOpts |= TEX_FILTER_WRAP; }
+        else if (a == "-mirror") { if (o.filterOpts & TEX_FILTER_WRAP) { std::fprintf(stderr, "-wrap and -mirror exclude each other\n"); return false; } o.filterOpts |= TEX_FILTER_MIRROR; }
+        else if (a == "-sepalpha") { o.sepalpha = true; o.filterOpts |= TEX_FILTER_SEPARATE_ALPHA; }
+        else if (a == "-x2bias") o.convert |= TEX_FILTER_FLOAT_X2BIAS;
+        else if (a == "-pow2") o.pow2 = true;
+        else if (a == "-pmalpha") o.pmalpha = true;
+        else if (a == "-alpha") o.demul = true;
+        else if (a == "-keepcoverage") { o.keepCoverage = float(std::atof(next())); if (!(o.keepCoverage >= 0.f && o.keepCoverage <= 1.f)) { std::fprintf(stderr, "-keepcoverage wants a value in [0, 1]\n"); return false; } }
+        else if (a == "-at") { o.alphaThreshold = float(std::atof(next())); if (!(o.alphaThreshold >= 0.f)) { std::fprintf(stderr, "-at wants a non-negative value\n"); return false; } }
+        else if (a == "-aw") next();                                              // the DirectCompute encoder's alpha weight: no meaning here
+        else if (a == "-dword") o.ddsRead |= DDS_FLAGS_LEGACY_DWORD;
+        else if (a == "-badtails") o.ddsRead |= DDS_FLAGS_BAD_DXTN_TAILS;
+        else if (a == "-permissive") o.ddsRead |= DDS_FLAGS_PERMISSIVE;
+        else if (a == "-ignoremips") o.ddsRead |= DDS_FLAGS_IGNORE_MIPS;
+        else if (a == "-xlum") o.ddsRead |= DDS_FLAGS_EXPAND_LUMINANCE;
+        else if (a == "-dx10") o.dx10 = true;
+        else if (a == "-dx9") o.dx9 = true;
+        else if (a == "-px") o.prefix = next();
+        else if (a == "-sx") o.suffix = next();
+        else if (a == "-l") o.lower = true;
+        else if (a == "-y") o.overwrite = true;
+        else if (a == "-timing") o.timing = true;
+        else if (a == "-nologo") o.nologo = true;
+        else if (a == "-gpu") o.gpu = std::atoi(next());
+        else if (a == "-o") o.out = next();
+        else if (a == "-ft") { if (strcasecmp(next(), "dds")) { std::fprintf(stderr, "only DDS output\n"); return false; } }
+        else if (a == "-r" || a == "-nogpu" || a == "-singleproc") { }            // nothing to switch here
+        else if (a[0] == '-') { std::fprintf(stderr, "unknown or unsupported option %s\n", a.c_str()); return false; }
+        else o.inputs.push_back(argv[i]);
+        if (missing) { std::fprintf(stderr, "option %s needs a value\n", a.c_str()); return false; }
     }
-    if (!inFile || !outFile) { std::fprintf(stderr, "usage: dxtexconv [-w W] [-h H] [-m N] [-f FORMAT] [-if FILTER] [-bc qxdu] [-gpu N] [-dx10] -o out.dds in.dds\n"); return 1; }
+    if (o.pmalpha && o.demul) { std::fprintf(stderr, "-pmalpha and -alpha exclude each other\n"); return false; }
+    if (o.dx10 && o.dx9) { std::fprintf(stderr, "-dx10 and -dx9 exclude each other\n"); return false; }
+    return !o.inputs.empty() && !o.out.empty();
+}
 
-    Device dev;
-    HRESULT hr = dev.Create(gpu);
-    if (FAILED(hr)) { std::fprintf(stderr, "no gfx950 device %d (this tool has no CPU path)\n", gpu); return 1; }
+// <out> names a file when it ends in .dds and there is one input; otherwise a directory that receives <px><name><sx>.dds
+std::string OutputName(const Options& o, const std::string& input)
+{
+    auto endsDDS = [](const std::string& s) { return s.size() > 4 && !strcasecmp(s.c_str() + s.size() - 4, ".dds"); };
+    if (o.inputs.size() == 1 && endsDDS(o.out) && o.prefix.empty() && o.suffix.empty()) return o.out;
+    std::string base = input.substr(input.find_last_of('/') == std::string::npos ? 0 : input.find_last_of('/') + 1);
+    if (base.find_last_of('.') != std::string::npos) base.erase(base.find_last_of('.'));
+    std::string name = o.prefix + base + o.suffix + ".dds";
+    if (o.lower) std::transform(name.begin(), name.end(), name.begin(), [](unsigned char c) { return char(std::tolower(c)); });
+    return o.out + "/" + name;
+}
+
+struct StepFailed { const char* what; HRESULT hr; };
+
+// one file through the pipeline; throws StepFailed
+void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const std::string& outFile)
+{
+    auto check = [](const char* what, HRESULT hr) { if (FAILED(hr)) throw StepFailed{ what, hr }; };
+    const TEX_FILTER_FLAGS filter = TEX_FILTER_FLAGS(o.filter | o.filterOpts);
 
     ScratchImage image; TexMetadata info;
-    hr = LoadFromDDSFile(inFile, DDS_FLAGS_NONE, &info, image);
-    if (FAILED(hr)) return fail("load", hr, dev);
-    std::printf("reading %s (%zux%zu, %zu mips, %zu items, format %u)\n", inFile, info.width, info.height, info.mipLevels, info.arraySize, unsigned(info.format));
-    const DXGI_FORMAT tformat = format ? DXGI_FORMAT(format) : info.format;
+    check("load", LoadFromDDSFile(inFile.c_str(), DDS_FLAGS(o.ddsRead), &info, image));
+    std::printf("reading %s (%zux%zu", inFile.c_str(), info.width, info.height);
+    if (info.dimension == TEX_DIMENSION_TEXTURE3D) std::printf("x%zu", info.depth);
+    std::printf(", %zu mips, %zu items, format %u)\n", info.mipLevels, info.arraySize, unsigned(info.format));
+    const DXGI_FORMAT tformat = o.format ? DXGI_FORMAT(o.format) : info.format;
+    size_t tMips = (!o.mipLevels && info.mipLevels > 1) ? info.mipLevels : o.mipLevels;           // texconv.cpp:2270
 
-    // --- decompress a block-compressed source when anything has to be done to its texels (texconv.cpp:2325-2372)
-    if (IsCompressed(info.format) && (width || height || haveMips || tformat != info.format))
+    // --- decompress (texconv.cpp:2325-2480). The compressed original is kept: if no step below changes the texels and the
+    // target is its format, it is written back as it is instead of being encoded again.
+    ScratchImage cimage;
+    bool haveOriginal = false;
+    auto keep = [&](ScratchImage& t)             // a step produced t: it becomes the image, metadata keeps its alpha mode
+    {
+        const uint32_t misc2 = info.miscFlags2;
+        image = std::move(t); info = image.GetMetadata(); info.miscFlags2 = misc2;
+    };
+    if (IsCompressed(info.format))
     {
         ScratchImage t;
-        hr = Decompress(dev, image.GetImages(), image.GetImageCount(), info, DXGI_FORMAT_UNKNOWN, t);
-        if (FAILED(hr)) return fail("decompress", hr, dev);
-        image = std::move(t); info = image.GetMetadata();
+        check("decompress", Decompress(dev, image.GetImages(), image.GetImageCount(), info, DXGI_FORMAT_UNKNOWN, t));
+        cimage = std::move(image); haveOriginal = true;
+        keep(t);
     }
 
-    // --- resize (level 0 of every item; the mip chain is regenerated or dropped like texconv does)
-    const size_t tw = width ? width : info.width, th = height ? height : info.height;
+    // --- undo premultiplied alpha
+    if (o.demul && HasAlpha(info.format) && info.format != DXGI_FORMAT_A8_UNORM)
+    {
+        if (info.GetAlphaMode() == TEX_ALPHA_MODE_STRAIGHT) std::printf("WARNING: image is already using straight alpha\n");
+        else if (!info.IsPMAlpha()) std::printf("WARNING: image is not using premultiplied alpha\n");
+        else
+        {
+            ScratchImage t;
+            check("demultiply alpha", PremultiplyAlpha(dev, image.GetImages(), image.GetImageCount(), info, TEX_PMALPHA_FLAGS(TEX_PMALPHA_REVERSE | o.srgb), t));
+            info.miscFlags2 = t.GetMetadata().miscFlags2;
+            image = std::move(t);
+            haveOriginal = false;
+        }
+    }
+
+    // --- resize: level 0 of every item / slice; the result has one level (DirectXTexResize.cpp:942-1103)
+    size_t tw = o.width ? o.width : info.width, th = o.height ? o.height : info.height;
+    if (tw > o.maxSize) { if (!o.width) tw = o.maxSize; else std::printf("WARNING: width exceeds the feature level's %zu\n", o.maxSize); }
+    if (th > o.maxSize) { if (!o.height) th = o.maxSize; else std::printf("WARNING: height exceeds the feature level's %zu\n", o.maxSize); }
+    if (o.pow2) FitPowerOf2(info.width, info.height, tw, th, o.maxSize);
     if (tw != info.width || th != info.height)
     {
-        TexMetadata m = info; m.width = tw; m.height = th; m.mipLevels = 1;
         ScratchImage t;
-        hr = t.Initialize(m);
-        if (FAILED(hr)) return fail("resize", hr, dev);
-        for (size_t item = 0; item < info.arraySize; ++item)
+        check("resize", Resize(dev, image.GetImages(), image.GetImageCount(), info, tw, th, filter, t));
+        keep(t);
+        haveOriginal = false;
+        if (tMips > 0)
         {
-            ScratchImage one;
-            hr = Resize(dev, *image.GetImage(0, item, 0), tw, th, TEX_FILTER_FLAGS(filter), one);
-            if (FAILED(hr)) return fail("resize", hr, dev);
-            std::memcpy(t.GetImage(0, item, 0)->pixels, one.GetPixels(), one.GetPixelsSize());
+            size_t maxMips = 0;
+            if (info.depth > 1) CalculateMipLevels3D(info.width, info.height, info.depth, maxMips); else CalculateMipLevels(info.width, info.height, maxMips);
+            tMips = std::min(tMips, maxMips);
         }
-        image = std::move(t); info = image.GetMetadata();
     }
 
     // --- convert to the uncompressed target format
     if (!IsCompressed(tformat) && tformat != info.format)
     {
-        TexMetadata m = info; m.format = tformat;
         ScratchImage t;
-        hr = t.Initialize(m);
-        if (FAILED(hr)) return fail("convert", hr, dev);
-        for (size_t i = 0; i < image.GetImageCount(); ++i)
-        {
-            ScratchImage one;
-            hr = Convert(dev, image.GetImages()[i], tformat, TEX_FILTER_FLAGS(filter), TEX_THRESHOLD_DEFAULT, one);
-            if (FAILED(hr)) return fail("convert", hr, dev);
-            std::memcpy(t.GetImages()[i].pixels, one.GetPixels(), one.GetPixelsSize());
-        }
-        image = std::move(t); info = image.GetMetadata();
+        check("convert", Convert(dev, image.GetImages(), image.GetImageCount(), info, tformat, TEX_FILTER_FLAGS(filter | o.srgb | o.convert), o.alphaThreshold, t));
+        keep(t);
+        haveOriginal = false;
     }
 
     // --- mipmaps
-    if (haveMips && mipLevels != 1)
+    const bool keepCoverage = o.keepCoverage > 0.f && HasAlpha(info.format) && !IsAlphaAllOpaque(dev, image);
+    TEX_FILTER_FLAGS filter3D = filter;
+    if (!ispow2(info.width) || !ispow2(info.height) || !ispow2(info.depth))
     {
-        ScratchImage tops;
-        const ScratchImage* base = &image;
-        if (info.mipLevels != 1) { hr = TopLevels(image, tops); if (FAILED(hr)) return fail("mipmaps", hr, dev); base = &tops; }
-        ScratchImage t;
-        hr = GenerateMipMaps(dev, base->GetImages(), base->GetImageCount(), base->GetMetadata(), TEX_FILTER_FLAGS(filter), mipLevels, t);
-        if (FAILED(hr)) return fail("mipmaps", hr, dev);
-        image = std::move(t); info = image.GetMetadata();
+        if (!tMips || info.mipLevels != 1) std::printf("WARNING: not a power-of-two texture with mips\n");
+        if (info.dimension == TEX_DIMENSION_TEXTURE3D) filter3D = TEX_FILTER_FLAGS(TEX_FILTER_TRIANGLE | o.filterOpts);      // the only correct one for such volumes (:3317-3321)
     }
-    else if (haveMips && mipLevels == 1 && info.mipLevels != 1)
+    if ((!tMips || info.mipLevels != tMips || keepCoverage) && info.mipLevels != 1)
+    {
+        // generation starts from a single level: strip the existing chain
+        ScratchImage t;
+        check("copy to single level", TopLevels(image, t));
+        keep(t);
+        if (haveOriginal && tMips == 1)
+        {
+            // only trimming mips off a compressed texture: its top level stays the encoder's original (:3378-3412)
+            ScratchImage c;
+            check("copy compressed to single level", TopLevels(cimage, c));
+            cimage = std::move(c);
+        }
+        else haveOriginal = false;
+    }
+    if ((!tMips || info.mipLevels != tMips) && (info.width > 1 || info.height > 1 || info.depth > 1))
     {
         ScratchImage t;
-        hr = TopLevels(image, t);
-        if (FAILED(hr)) return fail("mipmaps", hr, dev);
-        image = std::move(t); info = image.GetMetadata();
+        if (info.dimension == TEX_DIMENSION_TEXTURE3D) check("mipmaps", GenerateMipMaps3D(dev, image.GetImages(), image.GetImageCount(), info, filter3D, tMips, t));
+        else check("mipmaps", GenerateMipMaps(dev, image.GetImages(), image.GetImageCount(), info, filter, tMips, t));
+        keep(t);
+        haveOriginal = false;
+    }
+
+    // --- keep the alpha-test coverage of level 0 in the smaller levels
+    if (keepCoverage && info.mipLevels != 1)
+    {
+        ScratchImage t;
+        check("keepcoverage", t.Initialize(info));
+        for (size_t item = 0; item < info.arraySize; ++item)
+            check("keepcoverage", ScaleMipMapsAlphaForCoverage(dev, image.GetImage(0, item, 0), info.mipLevels, info, item, o.keepCoverage, t));
+        image = std::move(t);
+        haveOriginal = false;
+    }
+
+    // --- premultiplied alpha
+    if (o.pmalpha && HasAlpha(info.format) && info.format != DXGI_FORMAT_A8_UNORM)
+    {
+        if (info.IsPMAlpha()) std::printf("WARNING: image is already using premultiplied alpha\n");
+        else
+        {
+            ScratchImage t;
+            check("premultiply alpha", PremultiplyAlpha(dev, image.GetImages(), image.GetImageCount(), info, TEX_PMALPHA_FLAGS(TEX_PMALPHA_DEFAULT | o.srgb), t));
+            info.miscFlags2 = t.GetMetadata().miscFlags2;
+            image = std::move(t);
+            haveOriginal = false;
+        }
     }
 
     // --- compress
-    if (IsCompressed(tformat) && tformat != info.format)
+    if (IsCompressed(tformat))
     {
-        ScratchImage t;
-        hr = Compress(dev, image.GetImages(), image.GetImageCount(), info, tformat, TEX_COMPRESS_FLAGS(compress), TEX_THRESHOLD_DEFAULT, t);
-        if (FAILED(hr)) return fail("compress", hr, dev);
-        image = std::move(t); info = image.GetMetadata();
+        if (haveOriginal && cimage.GetMetadata().format == tformat)
+        {
+            // nothing touched the texels and the input already has the target format: hand its blocks through (:3566-3574)
+            keep(cimage);
+        }
+        else
+        {
+            if ((info.width % 4) || (info.height % 4)) std::printf("WARNING: block-compressed texture whose size is not a multiple of 4\n");
+            ScratchImage t;
+            check("compress", Compress(dev, image.GetImages(), image.GetImageCount(), info, tformat, TEX_COMPRESS_FLAGS(o.compress | o.srgb), o.alphaThreshold, t));
+            keep(t);
+        }
     }
 
-    hr = SaveToDDSFile(image.GetImages(), image.GetImageCount(), info, dx10 ? DDS_FLAGS_FORCE_DX10_EXT : DDS_FLAGS_NONE, outFile);
-    if (FAILED(hr)) return fail("save", hr, dev);
-    std::printf("writing %s (%zux%zu, %zu mips, %zu items, format %u)\n", outFile, info.width, info.height, info.mipLevels, info.arraySize, unsigned(info.format));
-    return 0;
+    // --- alpha mode (texconv.cpp:3738-3766)
+    if (HasAlpha(info.format) && info.format != DXGI_FORMAT_A8_UNORM)
+    {
+        if (IsAlphaAllOpaque(dev, image)) info.SetAlphaMode(TEX_ALPHA_MODE_OPAQUE);
+        else if (info.IsPMAlpha()) { }
+        else if (o.sepalpha) info.SetAlphaMode(TEX_ALPHA_MODE_CUSTOM);
+        else if (info.GetAlphaMode() == TEX_ALPHA_MODE_UNKNOWN) info.SetAlphaMode(TEX_ALPHA_MODE_STRAIGHT);
+    }
+    else info.SetAlphaMode(TEX_ALPHA_MODE_UNKNOWN);
+
+    // --- save
+    if (!o.overwrite)
+    {
+        struct stat st;
+        if (::stat(outFile.c_str(), &st) == 0) { std::printf("skipping %s: it exists (use -y to overwrite)\n", outFile.c_str()); return; }
+    }
+    uint32_t ddsFlags = DDS_FLAGS_NONE;
+    if (o.dx10) ddsFlags |= DDS_FLAGS_FORCE_DX10_EXT | DDS_FLAGS_FORCE_DX10_EXT_MISC2;
+    else if (o.dx9) ddsFlags |= DDS_FLAGS_FORCE_DX9_LEGACY;
+    check("save", SaveToDDSFile(image.GetImages(), image.GetImageCount(), info, DDS_FLAGS(ddsFlags), outFile.c_str()));
+    std::printf("writing %s (%zux%zu", outFile.c_str(), info.width, info.height);
+    if (info.dimension == TEX_DIMENSION_TEXTURE3D) std::printf("x%zu", info.depth);
+    std::printf(", %zu mips, %zu items, format %u)\n", info.mipLevels, info.arraySize, unsigned(info.format));
+}
+}
+
+int main(int argc, char** argv)
+{
+    Options o;
+    if (!Parse(argc, argv, o)) return usage();
+    if (!o.nologo) std::printf("dxtexconv: DirectXTex pipeline on MI355X (gfx950)\n");
+
+    Device dev;
+    if (FAILED(dev.Create(o.gpu))) { std::fprintf(stderr, "no gfx950 device %d (this tool has no CPU path)\n", o.gpu); return 1; }
+
+    int failures = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (const std::string& in : o.inputs)
+    {
+        try { ConvertOne(dev, o, in, OutputName(o, in)); }
+        catch (const StepFailed& f)
+        {
+            std::fprintf(stderr, "FAILED [%s] (%08X) %s\n", f.what, unsigned(f.hr), dev.LastError());
+            ++failures;                                   // like texconv: report, go on with the next file, exit code 1
+        }
+    }
+    if (o.timing) std::printf("processing time: %.3f seconds\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return failures ? 1 : 0;
 }

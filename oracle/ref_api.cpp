@@ -324,12 +324,12 @@ extern "C"
     }
 
     // format facts (DirectXTexUtil.cpp): bits per pixel, pitches under CP_FLAGS, scanline counts, predicates as a bit set
-    // (1 compressed, 2 packed, 4 planar, 8 palettised, 16 sRGB, 32 valid)
+    // (1 compressed, 2 packed, 4 planar, 8 palettised, 16 sRGB, 32 valid, 64 has alpha)
     int dxtex_ref_format_facts(int fmt, size_t* bpp)
     {
         const DXGI_FORMAT f = DXGI_FORMAT(fmt);
         if (bpp) *bpp = BitsPerPixel(f);
-        return (IsCompressed(f) ? 1 : 0) | (IsPacked(f) ? 2 : 0) | (IsPlanar(f) ? 4 : 0) | (IsPalettized(f) ? 8 : 0) | (IsSRGB(f) ? 16 : 0) | (IsValid(f) ? 32 : 0);
+        return (IsCompressed(f) ? 1 : 0) | (IsPacked(f) ? 2 : 0) | (IsPlanar(f) ? 4 : 0) | (IsPalettized(f) ? 8 : 0) | (IsSRGB(f) ? 16 : 0) | (IsValid(f) ? 32 : 0) | (HasAlpha(f) ? 64 : 0);
     }
     int dxtex_ref_compute_pitch_ex(int fmt, size_t w, size_t h, uint32_t cpFlags, size_t* rowPitch, size_t* slicePitch, size_t* scanlines)
     {

@@ -349,7 +349,7 @@ static int formats()
     for (uint32_t f = 0; f <= 200; ++f)
     {
         const DXGI_FORMAT fmt = DXGI_FORMAT(f);
-        const int bits = (IsCompressed(fmt) ? 1 : 0) | (IsPacked(fmt) ? 2 : 0) | (IsPlanar(fmt) ? 4 : 0) | (IsPalettized(fmt) ? 8 : 0) | (IsSRGB(fmt) ? 16 : 0) | (IsValid(fmt) ? 32 : 0);
+        const int bits = (IsCompressed(fmt) ? 1 : 0) | (IsPacked(fmt) ? 2 : 0) | (IsPlanar(fmt) ? 4 : 0) | (IsPalettized(fmt) ? 8 : 0) | (IsSRGB(fmt) ? 16 : 0) | (IsValid(fmt) ? 32 : 0) | (HasAlpha(fmt) ? 64 : 0);
         std::printf("fmt %u %zu %d\n", f, BitsPerPixel(fmt), bits);
         for (const auto& d : dims)
             for (uint32_t cp : cps)

@@ -60,6 +60,67 @@ def test_convert_only(tmp_path, oracle):
     img = synth.rgba8(w, h, seed=5, alpha="smooth")
     src = tmp_path / "in.dds"; out = tmp_path / "out.dds"
     oracle.ref_save_dds(img, w, h, RGBA8).tofile(src)
-    _run(["-f", "R16G16B16A16_FLOAT", "-o", str(out), str(src)])
+    _run(["-f", "R16G16B16A16_FLOAT", "-m", "1", "-o", str(out), str(src)])
     want = oracle.ref_save_dds(oracle.ref_convert(img, w, h, RGBA8, 10), w, h, 10)
+    assert np.array_equal(np.fromfile(out, np.uint8), want)
+
+
+def _bc3_chain(oracle, img, w, h, levels):
+    m = oracle.ref_generate_mips(img, w, h, RGBA8, 0x400000, levels)
+    return np.concatenate([oracle.ref_compress_image(x, a, b, RGBA8, 77, 0, 0.5) for x, (a, b) in zip(m, oracle.mip_sizes(w, h, levels))])
+
+
+def test_untouched_blocks_pass_through_and_mips_can_be_trimmed(tmp_path, oracle):
+    """texconv keeps the compressed original when no step changes the texels (texconv.cpp:3378-3412, :3566-3574): same format
+    and mip count -> the file's blocks come back; -m 1 -> the top level's original blocks, not a re-encode."""
+    w = h = 32
+    img = synth.rgba8(w, h, seed=41, alpha="smooth")
+    chain = _bc3_chain(oracle, img, w, h, 6)
+    src = tmp_path / "in.dds"; out = tmp_path / "out.dds"; top = tmp_path / "top.dds"
+    oracle.ref_save_dds(chain, w, h, 77, 1, 6).tofile(src)
+    _run(["-o", str(out), str(src)])
+    assert np.array_equal(np.fromfile(out, np.uint8), np.fromfile(src, np.uint8))
+    _run(["-m", "1", "-o", str(top), str(src)])
+    assert np.array_equal(np.fromfile(top, np.uint8), oracle.ref_save_dds(chain[:oracle.image_bytes(77, w, h)], w, h, 77, 1, 1))
+
+
+def test_default_mips_pow2_and_output_directory(tmp_path, oracle):
+    """without -m a single-level input gets the full chain (texconv.cpp:2270); -pow2 snaps the size (FitPowerOf2, :1019-1057);
+    several inputs go to a directory as <px><name><sx>.dds."""
+    w, h = 100, 60
+    outdir = tmp_path / "cooked"; outdir.mkdir()
+    names = []
+    for i in range(2):
+        img = synth.rgba8(w, h, seed=50 + i, alpha="opaque")
+        src = tmp_path / f"Tex{i}.dds"
+        oracle.ref_save_dds(img, w, h, RGBA8).tofile(src)
+        names.append((src, img))
+    _run(["-pow2", "-px", "p_", "-sx", "_S", "-l", "-y", "-nologo", "-timing", "-o", str(outdir)] + [str(s) for s, _ in names])
+    for i, (src, img) in enumerate(names):
+        small = oracle.ref_resize(img, w, h, RGBA8, 64, 32, 0)
+        mips = oracle.ref_generate_mips(small, 64, 32, RGBA8, 0, 7)
+        want = oracle.ref_save_dds(np.concatenate(mips), 64, 32, RGBA8, 1, 7)
+        assert np.array_equal(np.fromfile(outdir / f"p_tex{i}_s.dds", np.uint8), want)
+
+
+def test_keepcoverage_pmalpha_dx10(tmp_path, oracle):
+    """mips -> ScaleMipMapsAlphaForCoverage -> PremultiplyAlpha -> BC3, written with the 'DX10' header carrying the alpha mode."""
+    w = h = 64
+    img = synth.rgba8(w, h, seed=61, alpha="smooth")
+    src = tmp_path / "in.dds"; out = tmp_path / "out.dds"
+    oracle.ref_save_dds(img, w, h, RGBA8).tofile(src)
+    _run(["-m", "0", "-if", "BOX", "-keepcoverage", "0.5", "-pmalpha", "-f", "BC3_UNORM", "-dx10", "-o", str(out), str(src)])
+    sizes = oracle.mip_sizes(w, h, 7)
+    mips = oracle.ref_generate_mips(img, w, h, RGBA8, 0x400000, 7)
+    cov = oracle.ref_scale_mips_alpha_for_coverage(mips, w, h, RGBA8, 0.5)
+    pm = [oracle.ref_premultiply_alpha(m, a, b, RGBA8, 0) for m, (a, b) in zip(cov, sizes)]
+    bc = np.concatenate([oracle.ref_compress_image(m, a, b, RGBA8, 77, 0, 0.5) for m, (a, b) in zip(pm, sizes)])
+    hr, want = oracle.ref_save_dds_ex(bc, w, h, 1, 77, 1, 7, 0, 2, 3, 0x10000 | 0x20000)            # alpha mode 2 = premultiplied
+    assert hr == 0
+    assert np.array_equal(np.fromfile(out, np.uint8), want)
+    # an opaque texture is tagged opaque (alpha mode 3), whatever was asked for
+    img2 = synth.rgba8(w, h, seed=62, alpha="opaque")
+    oracle.ref_save_dds(img2, w, h, RGBA8).tofile(src)
+    _run(["-m", "1", "-dx10", "-y", "-o", str(out), str(src)])
+    hr, want = oracle.ref_save_dds_ex(img2, w, h, 1, RGBA8, 1, 1, 0, 3, 3, 0x10000 | 0x20000)
     assert np.array_equal(np.fromfile(out, np.uint8), want)
