@@ -36,7 +36,8 @@ def test_resize_mips_bc7(tmp_path, oracle):
 
 
 def test_array_bc3_to_bc1_quick_paths(tmp_path, oracle):
-    """a 3-item array with mips, block-compressed input: decompress -> regenerate mips (box) -> BC1."""
+    """a 3-item array with mips, block-compressed input. Like texconv (texconv.cpp:2270), -m 0 keeps a chain the input already
+    has: every level is decoded and encoded again. Asking for another count (-m 3) rebuilds the chain from the decoded top level."""
     w = h = 32
     imgs = [synth.rgba8(w, h, seed=30 + i, alpha="opaque") for i in range(3)]
     chains = []
@@ -48,10 +49,21 @@ def test_array_bc3_to_bc1_quick_paths(tmp_path, oracle):
     _run(["-m", "0", "-f", "BC1_UNORM", "-if", "BOX", "-o", str(out), str(src)])
     want_chains = []
     for c in chains:
-        top = oracle.ref_decompress_image(c[:oracle.image_bytes(77, w, h)], w, h, 77, RGBA8)
-        m = oracle.ref_generate_mips(top, w, h, RGBA8, 0x400000, 6)
-        want_chains.append(np.concatenate([oracle.ref_compress_image(x, a, b, RGBA8, 71, 0, 0.5) for x, (a, b) in zip(m, oracle.mip_sizes(w, h, 6))]))
+        at = 0
+        for (a, b) in oracle.mip_sizes(w, h, 6):
+            n = oracle.image_bytes(77, a, b)
+            level = oracle.ref_decompress_image(c[at:at + n], a, b, 77, RGBA8)
+            want_chains.append(oracle.ref_compress_image(level, a, b, RGBA8, 71, 0, 0.5))
+            at += n
     want = oracle.ref_save_dds(np.concatenate(want_chains), w, h, 71, 3, 6)
+    assert np.array_equal(np.fromfile(out, np.uint8), want)
+    _run(["-m", "3", "-f", "BC1_UNORM", "-if", "BOX", "-y", "-o", str(out), str(src)])
+    want_chains = []
+    for c in chains:
+        top = oracle.ref_decompress_image(c[:oracle.image_bytes(77, w, h)], w, h, 77, RGBA8)
+        m = oracle.ref_generate_mips(top, w, h, RGBA8, 0x400000, 3)
+        want_chains.append(np.concatenate([oracle.ref_compress_image(x, a, b, RGBA8, 71, 0, 0.5) for x, (a, b) in zip(m, oracle.mip_sizes(w, h, 3))]))
+    want = oracle.ref_save_dds(np.concatenate(want_chains), w, h, 71, 3, 3)
     assert np.array_equal(np.fromfile(out, np.uint8), want)
 
 
