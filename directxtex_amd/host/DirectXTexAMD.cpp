@@ -94,6 +94,101 @@ bool HasAlpha(DXGI_FORMAT fmt) noexcept
     return false;
 }
 
+namespace
+{
+    inline bool InRuns(uint32_t f, const uint16_t (*runs)[2], size_t n) noexcept
+    {
+        for (size_t i = 0; i < n; ++i)
+            if (f >= runs[i][0] && f <= runs[i][1]) return true;
+        return false;
+    }
+
+    // The typeless families of the DXGI numbering: the typeless id, its typed members, and which member "UNORM" / "FLOAT"
+    // means for it (DirectXTexUtil.cpp:1481-1693). 0 = none.
+    struct Family { uint16_t typeless, first, last, extra[3], unorm, flt; };
+    const Family kFamilies[] = {
+        { 1, 2, 4, { 0, 0, 0 }, 0, 2 }, { 5, 6, 8, { 0, 0, 0 }, 0, 6 }, { 9, 10, 14, { 0, 0, 0 }, 11, 10 }, { 15, 16, 18, { 0, 0, 0 }, 0, 16 },
+        { 23, 24, 25, { 116, 117, 189 }, 24, 0 },           // + the Xbox 10:10:10 float / snorm variants
+        { 27, 28, 32, { 0, 0, 0 }, 28, 0 }, { 33, 34, 38, { 0, 0, 0 }, 35, 34 }, { 39, 40, 43, { 0, 0, 0 }, 0, 41 }, { 48, 49, 52, { 0, 0, 0 }, 49, 0 },
+        { 53, 54, 59, { 0, 0, 0 }, 56, 54 }, { 60, 61, 64, { 190, 0, 0 }, 61, 0 },
+        { 70, 71, 72, { 0, 0, 0 }, 71, 0 }, { 73, 74, 75, { 0, 0, 0 }, 74, 0 }, { 76, 77, 78, { 0, 0, 0 }, 77, 0 }, { 79, 80, 81, { 0, 0, 0 }, 80, 0 },
+        { 82, 83, 84, { 0, 0, 0 }, 83, 0 },
+        { 90, 87, 87, { 91, 0, 0 }, 87, 0 }, { 92, 88, 88, { 93, 0, 0 }, 88, 0 },
+        { 94, 95, 96, { 0, 0, 0 }, 0, 0 }, { 97, 98, 99, { 0, 0, 0 }, 98, 0 },
+    };
+}
+
+bool IsVideo(DXGI_FORMAT fmt) noexcept
+{
+    static const uint16_t runs[][2] = { { 100, 114 }, { 130, 132 } };
+    return InRuns(uint32_t(fmt), runs, 2);
+}
+
+bool IsDepthStencil(DXGI_FORMAT fmt) noexcept
+{
+    static const uint16_t runs[][2] = { { 19, 22 }, { 40, 40 }, { 44, 47 }, { 55, 55 }, { 118, 120 } };
+    return InRuns(uint32_t(fmt), runs, 5);
+}
+
+bool IsBGR(DXGI_FORMAT fmt) noexcept
+{
+    static const uint16_t runs[][2] = { { 85, 88 }, { 90, 93 }, { 115, 115 }, { 191, 191 } };
+    return InRuns(uint32_t(fmt), runs, 4);
+}
+
+bool IsTypeless(DXGI_FORMAT fmt, bool partialTypeless) noexcept
+{
+    const uint32_t f = uint32_t(fmt);
+    for (const Family& fam : kFamilies)
+        if (f == fam.typeless) return true;
+    if (f == DXGI_FORMAT_R32G8X24_TYPELESS || f == DXGI_FORMAT_R24G8_TYPELESS) return true;
+    // typed in one plane, typeless in the other
+    if (f == DXGI_FORMAT_R32_FLOAT_X8X24_TYPELESS || f == DXGI_FORMAT_X32_TYPELESS_G8X24_UINT || f == DXGI_FORMAT_R24_UNORM_X8_TYPELESS
+        || f == DXGI_FORMAT_X24_TYPELESS_G8_UINT || f == 119 || f == 120) return partialTypeless;
+    return false;
+}
+
+size_t BitsPerColor(DXGI_FORMAT fmt) noexcept
+{
+    static const struct { uint16_t first, last, bits; } runs[] = {
+        { 1, 8, 32 }, { 9, 14, 16 }, { 15, 22, 32 }, { 23, 25, 10 }, { 26, 26, 11 }, { 27, 32, 8 }, { 33, 38, 16 }, { 39, 43, 32 }, { 44, 47, 24 },
+        { 48, 52, 8 }, { 53, 59, 16 }, { 60, 65, 8 }, { 66, 66, 1 }, { 67, 67, 14 }, { 68, 69, 8 }, { 70, 78, 6 }, { 79, 84, 8 }, { 85, 85, 6 },
+        { 86, 86, 5 }, { 87, 88, 8 }, { 89, 89, 10 }, { 90, 93, 8 }, { 94, 96, 16 }, { 97, 99, 7 }, { 100, 100, 8 }, { 101, 101, 10 }, { 102, 102, 16 },
+        { 103, 103, 8 }, { 104, 104, 10 }, { 105, 105, 16 }, { 106, 107, 8 }, { 108, 108, 10 }, { 109, 109, 16 }, { 110, 110, 8 }, { 115, 115, 4 },
+        { 116, 117, 10 }, { 118, 120, 16 }, { 130, 132, 8 }, { 189, 189, 10 }, { 190, 191, 4 },
+    };
+    const uint32_t f = uint32_t(fmt);
+    for (const auto& r : runs)
+        if (f >= r.first && f <= r.last) return r.bits;
+    return 0;
+}
+
+size_t BytesPerBlock(DXGI_FORMAT fmt) noexcept { return IsCompressed(fmt) ? (BitsPerPixel(fmt) == 4 ? 8 : 16) : 0; }
+
+DXGI_FORMAT MakeLinear(DXGI_FORMAT fmt) noexcept { return IsSRGB(fmt) ? DXGI_FORMAT(uint32_t(fmt) - 1 - (fmt == DXGI_FORMAT_B8G8R8A8_UNORM_SRGB ? 3 : fmt == DXGI_FORMAT_B8G8R8X8_UNORM_SRGB ? 4 : 0)) : fmt; }
+
+DXGI_FORMAT MakeTypeless(DXGI_FORMAT fmt) noexcept
+{
+    const uint32_t f = uint32_t(fmt);
+    for (const Family& fam : kFamilies)
+        if ((f >= fam.first && f <= fam.last) || (f && (f == fam.extra[0] || f == fam.extra[1] || f == fam.extra[2]))) return DXGI_FORMAT(fam.typeless);
+    return fmt;
+}
+
+DXGI_FORMAT MakeTypelessUNORM(DXGI_FORMAT fmt) noexcept
+{
+    for (const Family& fam : kFamilies)
+        if (uint32_t(fmt) == fam.typeless && fam.unorm) return DXGI_FORMAT(fam.unorm);
+    return fmt;
+}
+
+DXGI_FORMAT MakeTypelessFLOAT(DXGI_FORMAT fmt) noexcept
+{
+    for (const Family& fam : kFamilies)
+        if (uint32_t(fmt) == fam.typeless && fam.flt) return DXGI_FORMAT(fam.flt);
+    return fmt;
+}
+
 DXGI_FORMAT MakeSRGB(DXGI_FORMAT fmt) noexcept
 {
     switch (fmt)
@@ -382,16 +477,75 @@ HRESULT ScratchImage::InitializeCube(DXGI_FORMAT fmt, size_t width, size_t heigh
     return Initialize(m, flags);
 }
 
-HRESULT ScratchImage::InitializeFromImage(const Image& src) noexcept
+// the pixels of caller images copied in, row by row over min(pitches) (DirectXTexImage.cpp:534-723)
+namespace
 {
-    if (!src.pixels) return E_POINTER;
-    const HRESULT hr = Initialize2D(src.format, src.width, src.height, 1, 1);
+    HRESULT CopyIn(const Image* src, const Image* dst, size_t count) noexcept
+    {
+        const size_t rows = ComputeScanlines(src[0].format, src[0].height);
+        if (!rows) return HRESULT(0x8000FFFF);           // E_UNEXPECTED
+        for (size_t i = 0; i < count; ++i)
+        {
+            if (!src[i].pixels || !dst[i].pixels) return E_POINTER;
+            const size_t n = std::min(src[i].rowPitch, dst[i].rowPitch);
+            for (size_t y = 0; y < rows; ++y) std::memcpy(dst[i].pixels + y * dst[i].rowPitch, src[i].pixels + y * src[i].rowPitch, n);
+        }
+        return S_OK;
+    }
+    HRESULT SameShape(const Image* images, size_t n) noexcept
+    {
+        for (size_t i = 0; i < n; ++i)
+        {
+            if (!images[i].pixels) return E_POINTER;
+            if (images[i].format != images[0].format || images[i].width != images[0].width || images[i].height != images[0].height) return E_FAIL;
+        }
+        return S_OK;
+    }
+}
+
+HRESULT ScratchImage::InitializeFromImage(const Image& src, bool allow1D, CP_FLAGS flags) noexcept
+{
+    const HRESULT hr = (src.height > 1 || !allow1D) ? Initialize2D(src.format, src.width, src.height, 1, 1, flags) : Initialize1D(src.format, src.width, 1, 1, flags);
     if (FAILED(hr)) return hr;
-    const Image& dst = m_images[0];
-    const size_t rows = IsCompressed(src.format) ? std::max<size_t>(1, (src.height + 3) / 4) : src.height;
-    const size_t n = std::min(src.rowPitch, dst.rowPitch);
-    for (size_t y = 0; y < rows; ++y) std::memcpy(dst.pixels + y * dst.rowPitch, src.pixels + y * src.rowPitch, n);
+    return CopyIn(&src, m_images.get(), 1);
+}
+
+HRESULT ScratchImage::InitializeArrayFromImages(const Image* images, size_t nImages, bool allow1D, CP_FLAGS flags) noexcept
+{
+    if (!images || !nImages) return E_INVALIDARG;
+    HRESULT hr = SameShape(images, nImages);
+    if (FAILED(hr)) return hr;
+    hr = (images[0].height > 1 || !allow1D) ? Initialize2D(images[0].format, images[0].width, images[0].height, nImages, 1, flags)
+                                            : Initialize1D(images[0].format, images[0].width, nImages, 1, flags);
+    if (FAILED(hr)) return hr;
+    return CopyIn(images, m_images.get(), nImages);
+}
+
+HRESULT ScratchImage::InitializeCubeFromImages(const Image* images, size_t nImages, CP_FLAGS flags) noexcept
+{
+    if (!images || !nImages || (nImages % 6) != 0) return E_INVALIDARG;
+    const HRESULT hr = InitializeArrayFromImages(images, nImages, false, flags);
+    if (FAILED(hr)) return hr;
+    m_metadata.miscFlags |= TEX_MISC_TEXTURECUBE;
     return S_OK;
+}
+
+HRESULT ScratchImage::Initialize3DFromImages(const Image* images, size_t depth, CP_FLAGS flags) noexcept
+{
+    if (!images || !depth || depth > INT16_MAX) return E_INVALIDARG;
+    HRESULT hr = SameShape(images, depth);
+    if (FAILED(hr)) return hr;
+    hr = Initialize3D(images[0].format, images[0].width, images[0].height, depth, 1, flags);
+    if (FAILED(hr)) return hr;
+    return CopyIn(images, m_images.get(), depth);
+}
+
+bool ScratchImage::OverrideFormat(DXGI_FORMAT f) noexcept
+{
+    if (!m_images || !IsValid(f) || IsPlanar(f) || IsPalettized(f)) return false;
+    for (size_t i = 0; i < m_nimages; ++i) m_images[i].format = f;
+    m_metadata.format = f;
+    return true;
 }
 
 const Image* ScratchImage::GetImage(size_t mip, size_t item, size_t slice) const noexcept

@@ -101,6 +101,16 @@ bool IsPlanar(DXGI_FORMAT fmt) noexcept;
 bool IsPalettized(DXGI_FORMAT fmt) noexcept;
 bool IsSRGB(DXGI_FORMAT fmt) noexcept;
 bool HasAlpha(DXGI_FORMAT fmt) noexcept;
+bool IsVideo(DXGI_FORMAT fmt) noexcept;
+bool IsDepthStencil(DXGI_FORMAT fmt) noexcept;
+bool IsBGR(DXGI_FORMAT fmt) noexcept;
+bool IsTypeless(DXGI_FORMAT fmt, bool partialTypeless = true) noexcept;
+size_t BitsPerColor(DXGI_FORMAT fmt) noexcept;            // the widest channel; 0 for palettised formats
+size_t BytesPerBlock(DXGI_FORMAT fmt) noexcept;           // 8 / 16 for BC formats, else 0
+DXGI_FORMAT MakeLinear(DXGI_FORMAT fmt) noexcept;
+DXGI_FORMAT MakeTypeless(DXGI_FORMAT fmt) noexcept;
+DXGI_FORMAT MakeTypelessUNORM(DXGI_FORMAT fmt) noexcept;
+DXGI_FORMAT MakeTypelessFLOAT(DXGI_FORMAT fmt) noexcept;
 DXGI_FORMAT MakeSRGB(DXGI_FORMAT fmt) noexcept;
 size_t BitsPerPixel(DXGI_FORMAT fmt) noexcept;
 // true for the formats the GPU entry points (Compress, Convert, Resize, ...) accept
@@ -165,7 +175,12 @@ public:
     HRESULT Initialize2D(DXGI_FORMAT fmt, size_t width, size_t height, size_t arraySize, size_t mipLevels, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
     HRESULT Initialize3D(DXGI_FORMAT fmt, size_t width, size_t height, size_t depth, size_t mipLevels, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
     HRESULT InitializeCube(DXGI_FORMAT fmt, size_t width, size_t height, size_t nCubes, size_t mipLevels, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
-    HRESULT InitializeFromImage(const Image& srcImage) noexcept;      // copies the pixels
+    // copies of caller images (DirectXTexImage.cpp:534-723): one image, an array, cubemaps (a multiple of six), a volume
+    HRESULT InitializeFromImage(const Image& srcImage, bool allow1D = false, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
+    HRESULT InitializeArrayFromImages(const Image* images, size_t nImages, bool allow1D = false, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
+    HRESULT InitializeCubeFromImages(const Image* images, size_t nImages, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
+    HRESULT Initialize3DFromImages(const Image* images, size_t depth, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
+    bool OverrideFormat(DXGI_FORMAT f) noexcept;               // relabels the pixels (same size per texel is the caller's business)
     void Release() noexcept;
 
     const TexMetadata& GetMetadata() const noexcept { return m_metadata; }

@@ -64,6 +64,8 @@ def _load_ref():
         lib.dxtex_ref_format_facts.restype = ctypes.c_int
         lib.dxtex_ref_compute_pitch_ex.argtypes = [ctypes.c_int, sz, sz, ctypes.c_uint32, szp, szp, szp]
         lib.dxtex_ref_compute_pitch_ex.restype = ctypes.c_int
+        lib.dxtex_ref_format_facts2.argtypes = [ctypes.c_int, szp]
+        lib.dxtex_ref_format_facts2.restype = ctypes.c_int
         _ref = lib
     return _ref
 
@@ -477,3 +479,11 @@ def ref_compute_pitch(fmt, width, height, cp_flags=0):
     rp, sp, sl = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
     hr = _load_ref().dxtex_ref_compute_pitch_ex(fmt, width, height, cp_flags, ctypes.byref(rp), ctypes.byref(sp), ctypes.byref(sl))
     return hr & 0xFFFFFFFF, rp.value, sp.value, sl.value
+
+
+def ref_format_facts2(fmt):
+    """-> ([BitsPerColor, BytesPerBlock, MakeSRGB, MakeLinear, MakeTypeless, MakeTypelessUNORM, MakeTypelessFLOAT], predicate bits:
+    1 video, 2 depth-stencil, 4 BGR, 8 typeless incl. partially typeless, 16 fully typeless)."""
+    out = (ctypes.c_size_t * 7)()
+    bits = _load_ref().dxtex_ref_format_facts2(fmt, out)
+    return [int(v) for v in out], bits

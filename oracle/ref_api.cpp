@@ -336,4 +336,14 @@ extern "C"
         if (scanlines) *scanlines = IsValid(DXGI_FORMAT(fmt)) ? ComputeScanlines(DXGI_FORMAT(fmt), h) : h;       // (asserts on ids past 191)
         return int(ComputePitch(DXGI_FORMAT(fmt), w, h, *rowPitch, *slicePitch, CP_FLAGS(cpFlags)));
     }
+
+    // more format facts: out[0..6] = BitsPerColor, BytesPerBlock, MakeSRGB, MakeLinear, MakeTypeless, MakeTypelessUNORM, MakeTypelessFLOAT;
+    // returns predicate bits: 1 video, 2 depth-stencil, 4 BGR, 8 typeless (partial counts), 16 typeless (partial does not count)
+    int dxtex_ref_format_facts2(int fmt, size_t* out)
+    {
+        const DXGI_FORMAT f = DXGI_FORMAT(fmt);
+        out[0] = BitsPerColor(f); out[1] = BytesPerBlock(f); out[2] = size_t(MakeSRGB(f)); out[3] = size_t(MakeLinear(f)); out[4] = size_t(MakeTypeless(f));
+        out[5] = size_t(MakeTypelessUNORM(f)); out[6] = size_t(MakeTypelessFLOAT(f));
+        return (IsVideo(f) ? 1 : 0) | (IsDepthStencil(f) ? 2 : 0) | (IsBGR(f) ? 4 : 0) | (IsTypeless(f, true) ? 8 : 0) | (IsTypeless(f, false) ? 16 : 0);
+    }
 }

@@ -75,6 +75,29 @@ static int cpu_checks()
         CHECK(any.Initialize(odd) == E_INVALIDARG);                     // a cubemap needs a multiple of six
         CHECK(!IsSupportedOnDevice(DXGI_FORMAT_B5G6R5_UNORM) && IsSupportedOnDevice(DXGI_FORMAT_R8G8B8A8_UNORM) && IsSupportedOnDevice(DXGI_FORMAT_BC7_UNORM));
     }
+    // copies of caller images: array, cubemap, volume, relabelling (DirectXTexImage.cpp:534-740)
+    {
+        std::vector<uint8_t> a(6 * 4 * 4 * 4);
+        for (size_t i = 0; i < a.size(); ++i) a[i] = uint8_t(i * 13 + 5);
+        std::vector<Image> six(6);
+        for (size_t i = 0; i < 6; ++i) { six[i].width = 4; six[i].height = 4; six[i].format = DXGI_FORMAT_R8G8B8A8_UNORM; six[i].rowPitch = 16; six[i].slicePitch = 64; six[i].pixels = a.data() + i * 64; }
+        ScratchImage s;
+        CHECK(s.InitializeArrayFromImages(six.data(), 6) == S_OK && s.GetMetadata().arraySize == 6 && !s.GetMetadata().IsCubemap() && std::memcmp(s.GetPixels(), a.data(), a.size()) == 0);
+        CHECK(s.InitializeCubeFromImages(six.data(), 6) == S_OK && s.GetMetadata().IsCubemap() && s.GetImage(0, 5, 0)->pixels[0] == a[5 * 64]);
+        CHECK(s.InitializeCubeFromImages(six.data(), 5) == E_INVALIDARG);
+        CHECK(s.Initialize3DFromImages(six.data(), 4) == S_OK && s.GetMetadata().depth == 4 && s.GetMetadata().dimension == TEX_DIMENSION_TEXTURE3D && s.GetImage(0, 0, 3)->pixels[1] == a[3 * 64 + 1]);
+        six[2].width = 3;
+        CHECK(s.InitializeArrayFromImages(six.data(), 6) == E_FAIL);
+        six[2].width = 4; six[1].pixels = nullptr;
+        CHECK(s.Initialize3DFromImages(six.data(), 4) == E_POINTER);
+        Image line = six[0]; line.width = 16; line.height = 1; line.rowPitch = 64;
+        CHECK(s.InitializeFromImage(line, true) == S_OK && s.GetMetadata().dimension == TEX_DIMENSION_TEXTURE1D);
+        CHECK(s.InitializeFromImage(line) == S_OK && s.GetMetadata().dimension == TEX_DIMENSION_TEXTURE2D);
+        CHECK(s.OverrideFormat(DXGI_FORMAT_R8G8B8A8_UNORM_SRGB) && s.GetMetadata().format == DXGI_FORMAT_R8G8B8A8_UNORM_SRGB && s.GetImage(0, 0, 0)->format == DXGI_FORMAT_R8G8B8A8_UNORM_SRGB);
+        CHECK(!s.OverrideFormat(DXGI_FORMAT_NV12) && !s.OverrideFormat(DXGI_FORMAT_P8) && !s.OverrideFormat(DXGI_FORMAT_UNKNOWN));
+        ScratchImage empty;
+        CHECK(!empty.OverrideFormat(DXGI_FORMAT_R8G8B8A8_UNORM));
+    }
     // DDS: images with padded rows are written with the file's tight pitch; the one-image overloads; the header query
     {
         ScratchImage tight;
@@ -351,6 +374,9 @@ static int formats()
         const DXGI_FORMAT fmt = DXGI_FORMAT(f);
         const int bits = (IsCompressed(fmt) ? 1 : 0) | (IsPacked(fmt) ? 2 : 0) | (IsPlanar(fmt) ? 4 : 0) | (IsPalettized(fmt) ? 8 : 0) | (IsSRGB(fmt) ? 16 : 0) | (IsValid(fmt) ? 32 : 0) | (HasAlpha(fmt) ? 64 : 0);
         std::printf("fmt %u %zu %d\n", f, BitsPerPixel(fmt), bits);
+        std::printf("more %u %zu %zu %u %u %u %u %u %d\n", f, BitsPerColor(fmt), BytesPerBlock(fmt), unsigned(MakeSRGB(fmt)), unsigned(MakeLinear(fmt)), unsigned(MakeTypeless(fmt)),
+                    unsigned(MakeTypelessUNORM(fmt)), unsigned(MakeTypelessFLOAT(fmt)),
+                    (IsVideo(fmt) ? 1 : 0) | (IsDepthStencil(fmt) ? 2 : 0) | (IsBGR(fmt) ? 4 : 0) | (IsTypeless(fmt, true) ? 8 : 0) | (IsTypeless(fmt, false) ? 16 : 0));
         for (const auto& d : dims)
             for (uint32_t cp : cps)
             {
