@@ -224,22 +224,24 @@ size_t BitsPerPixel(DXGI_FORMAT fmt) noexcept
 
 HRESULT ComputePitch(DXGI_FORMAT fmt, size_t width, size_t height, size_t& rowPitch, size_t& slicePitch, CP_FLAGS flags) noexcept
 {
-    const uint64_t w = width, h = height;
-    uint64_t pitch = 0, slice = 0;
+    // 128-bit arithmetic: a hostile header (32-bit width and height, 128 bits per texel) must not wrap the slice size
+    using u128 = unsigned __int128;
+    const u128 w = width, h = height;
+    u128 pitch = 0, slice = 0;
     if (fmt == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
     if (IsCompressed(fmt))
     {
-        const uint64_t bytes = (BitsPerPixel(fmt) == 4) ? 8 : 16;
+        const u128 bytes = (BitsPerPixel(fmt) == 4) ? 8 : 16;
         if (flags & CP_FLAGS_BAD_DXTN_TAILS)
         {
             // files whose writer rounded the block counts down (DirectXTexUtil.cpp:980-986)
-            pitch = std::max<uint64_t>(1, (w >> 2) * bytes);
-            slice = std::max<uint64_t>(1, pitch * (h >> 2));
+            pitch = std::max<u128>(1, (w >> 2) * bytes);
+            slice = std::max<u128>(1, pitch * (h >> 2));
         }
         else
         {
-            pitch = std::max<uint64_t>(1, (w + 3) / 4) * bytes;
-            slice = pitch * std::max<uint64_t>(1, (h + 3) / 4);
+            pitch = std::max<u128>(1, (w + 3) / 4) * bytes;
+            slice = pitch * std::max<u128>(1, (h + 3) / 4);
         }
     }
     else if (IsPacked(fmt))
@@ -279,14 +281,15 @@ HRESULT ComputePitch(DXGI_FORMAT fmt, size_t width, size_t height, size_t& rowPi
     }
     else
     {
-        const uint64_t bpp = (flags & CP_FLAGS_24BPP) ? 24 : (flags & CP_FLAGS_16BPP) ? 16 : (flags & CP_FLAGS_8BPP) ? 8 : BitsPerPixel(fmt);
+        const u128 bpp = (flags & CP_FLAGS_24BPP) ? 24 : (flags & CP_FLAGS_16BPP) ? 16 : (flags & CP_FLAGS_8BPP) ? 8 : BitsPerPixel(fmt);
         if (!bpp) return E_INVALIDARG;
         // row alignment in bits: 4 KiB page, zmm, ymm, paragraph, DWORD, else bytes
-        const uint64_t align = (flags & CP_FLAGS_PAGE4K) ? 32768 : (flags & CP_FLAGS_ZMM) ? 512 : (flags & CP_FLAGS_YMM) ? 256
+        const u128 align = (flags & CP_FLAGS_PAGE4K) ? 32768 : (flags & CP_FLAGS_ZMM) ? 512 : (flags & CP_FLAGS_YMM) ? 256
                              : (flags & CP_FLAGS_PARAGRAPH) ? 128 : (flags & CP_FLAGS_LEGACY_DWORD) ? 32 : 8;
         pitch = ((w * bpp + align - 1) / align) * (align / 8);
         slice = pitch * h;
     }
+    if (pitch > UINT64_MAX || slice > UINT64_MAX) { rowPitch = slicePitch = 0; return HRESULT_E_ARITHMETIC_OVERFLOW; }      // the reference checks this on 32-bit builds only (:1172-1178)
     rowPitch = size_t(pitch); slicePitch = size_t(slice);
     return S_OK;
 }
@@ -404,6 +407,7 @@ HRESULT ScratchImage::Initialize(const TexMetadata& mdata, CP_FLAGS flags) noexc
             size_t rp, sp;
             const HRESULT hr = ComputePitch(mdata.format, w, h, rp, sp, flags);
             if (FAILED(hr)) { Release(); return hr; }
+            if (d && sp > (UINT64_MAX - total) / d) { Release(); return E_OUTOFMEMORY; }          // more than an address space: no wrap-around
             total += uint64_t(sp) * d;
             nimages += d;
             if (h > 1) h >>= 1;

@@ -571,7 +571,11 @@ namespace
                 size_t rp, sp;
                 const HRESULT hr = ComputePitch(m.format, w, h, rp, sp, CP_FLAGS(cp));
                 if (FAILED(hr)) return hr;
-                for (size_t slice = 0; slice < d; ++slice) { src.push_back({ size_t(total), rp, sp }); total += sp; }
+                for (size_t slice = 0; slice < d; ++slice)
+                {
+                    if (sp > UINT64_MAX - total) return HRESULT_E_HANDLE_EOF;          // no file holds that much
+                    src.push_back({ size_t(total), rp, sp }); total += sp;
+                }
                 if (h > 1) h >>= 1;
                 if (w > 1) w >>= 1;
                 if (d > 1) d >>= 1;

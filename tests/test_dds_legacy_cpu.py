@@ -242,3 +242,17 @@ def test_seeded_header_mutations(tmp_path):
                 fl |= bit
         cases.append((data, fl))
     compare(str(tmp_path), cases, "mutations")
+
+
+def test_hostile_sizes_fail_cleanly(tmp_path):
+    """Headers whose image sizes exceed the address space (reachable with DDS_FLAGS_ALLOW_LARGE_FILES, which texconv-style tools
+    pass by default): an error, not a wrapped allocation. Ours only - the reference does its size arithmetic in 64 bits."""
+    payload = bytes(4096)
+    cases = []
+    for (w, h, fmt, arr, mips, depth) in ((0xFFFFFFFF, 0xFFFFFFFF, 2, 1, 1, 0), (0xFFFFFFFF, 0xFFFFFFFF, 2, 0xFFFF, 1, 0), (0x80000000, 0x80000000, 28, 1, 0, 0),
+                                          (0xFFFFFFFF, 0xFFFFFFFF, 98, 1, 1, 0), (0xFFFFFFFF, 0xFFFFFFFF, 28, 1, 1, 0xFFFFFFFF), (1 << 20, 1 << 20, 2, 4096, 1, 0)):
+        hf = 0x1007 | (0x800000 if depth else 0)
+        cases.append((header(w, h, four("DX10"), flags=hf, depth=depth, mips=mips, dx10=(fmt, 4 if depth else 3, 0, arr, 0)) + payload, 0x1000000))
+        cases.append((header(w, h, masks(RGBA, 32, 0x00ff0000, 0x0000ff00, 0x000000ff, 0xff000000), flags=hf, depth=depth, mips=mips) + payload, 0x1000000 | 0x1))
+    for hr, meta, px in run_ours(str(tmp_path), cases):
+        assert hr & 0x80000000 and meta is None, hex(hr)
