@@ -302,6 +302,7 @@ public:
     Blob(const Blob&) = delete;
     Blob& operator=(const Blob&) = delete;
     HRESULT Initialize(size_t size) noexcept;
+    HRESULT Trim(size_t size) noexcept;              // shortens the logical size, keeps the allocation
     void Release() noexcept;
     uint8_t* GetBufferPointer() const noexcept { return m_buffer; }
     size_t GetBufferSize() const noexcept { return m_size; }
@@ -324,4 +325,12 @@ HRESULT SaveToDDSMemory(const Image& image, DDS_FLAGS flags, Blob& blob) noexcep
 HRESULT SaveToDDSMemory(const Image* images, size_t nimages, const TexMetadata& metadata, DDS_FLAGS flags, Blob& blob) noexcept;
 HRESULT SaveToDDSFile(const Image& image, DDS_FLAGS flags, const char* szFile) noexcept;
 HRESULT SaveToDDSFile(const Image* images, size_t nimages, const TexMetadata& metadata, DDS_FLAGS flags, const char* szFile) noexcept;
+
+// ---- Radiance RGBE (.hdr), DirectXTexHDR.cpp: loads to R32G32B32A32_FLOAT; saves RGBA32F / RGB32F / RGBA16F images ---------------
+HRESULT GetMetadataFromHDRMemory(const void* pSource, size_t size, TexMetadata& metadata) noexcept;
+HRESULT GetMetadataFromHDRFile(const char* szFile, TexMetadata& metadata) noexcept;
+HRESULT LoadFromHDRMemory(const void* pSource, size_t size, TexMetadata* metadata, ScratchImage& image) noexcept;
+HRESULT LoadFromHDRFile(const char* szFile, TexMetadata* metadata, ScratchImage& image) noexcept;
+HRESULT SaveToHDRMemory(const Image& image, Blob& blob) noexcept;
+HRESULT SaveToHDRFile(const Image& image, const char* szFile) noexcept;
 } // namespace DirectXTexAMD

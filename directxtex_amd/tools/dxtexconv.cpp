@@ -5,7 +5,7 @@
 // alpha mode (:3738-3766) -> save (:3858-3878). Option names are texconv's; what has no GPU implementation here (flips,
 // swizzles, normal maps, tone mapping, WIC / TGA / HDR codecs, dithered conversion) is refused, not approximated.
 //
-//   dxtexconv [options] -o <out.dds | output directory> <in.dds>...
+//   dxtexconv [options] -o <out.dds | output directory> <in.dds | in.hdr>...        (-ft hdr writes Radiance files from float images)
 //     -w <n> -h <n>        target size                         -pow2             fit to a power of two (keeps the aspect ratio)
 //     -m <n>               mip levels, 0 = full chain           -fl <9.1 .. 12.2> feature level: largest texture side allowed
 //     -f <format>          DXGI format name or number           -if <filter>      POINT LINEAR CUBIC FANT BOX TRIANGLE
@@ -69,7 +69,7 @@ struct Options
 {
     size_t width = 0, height = 0, mipLevels = 0, maxSize = 16384;          // mipLevels 0: keep a chain the input has, else build the full one
     bool pow2 = false, pmalpha = false, demul = false, dx10 = false, dx9 = false, sepalpha = false, lower = false, overwrite = false,
-         timing = false, nologo = false;
+         timing = false, nologo = false, hdrOut = false;
     uint32_t format = 0, filter = 0, filterOpts = 0, srgb = 0, convert = 0, compress = 0, ddsRead = DDS_FLAGS_ALLOW_LARGE_FILES;
     float alphaThreshold = TEX_THRESHOLD_DEFAULT, keepCoverage = 0.f;
     int gpu = 0;
@@ -225,7 +225,12 @@ bool Parse(int argc, char** argv, Options& o)
         else if (a == "-nologo") o.nologo = true;
         else if (a == "-gpu") o.gpu = std::atoi(next());
         else if (a == "-o") o.out = next();
-        else if (a == "-ft") { if (strcasecmp(next(), "dds")) { std::fprintf(stderr, "only DDS output\n"); return false; } }
+        else if (a == "-ft")
+        {
+            const char* ft = next();
+            if (!strcasecmp(ft, "hdr")) o.hdrOut = true;
+            else if (strcasecmp(ft, "dds")) { std::fprintf(stderr, "output file types: dds, hdr\n"); return false; }
+        }
         else if (a == "-r" || a == "-nogpu" || a == "-singleproc") { }            // nothing to switch here
         else if (a[0] == '-') { std::fprintf(stderr, "unknown or unsupported option %s\n", a.c_str()); return false; }
         else o.inputs.push_back(argv[i]);
@@ -239,11 +244,11 @@ bool Parse(int argc, char** argv, Options& o)
 // <out> names a file when it ends in .dds and there is one input; otherwise a directory that receives <px><name><sx>.dds
 std::string OutputName(const Options& o, const std::string& input)
 {
-    auto endsDDS = [](const std::string& s) { return s.size() > 4 && !strcasecmp(s.c_str() + s.size() - 4, ".dds"); };
+    auto endsDDS = [](const std::string& s) { return s.size() > 4 && (!strcasecmp(s.c_str() + s.size() - 4, ".dds") || !strcasecmp(s.c_str() + s.size() - 4, ".hdr")); };
     if (o.inputs.size() == 1 && endsDDS(o.out) && o.prefix.empty() && o.suffix.empty()) return o.out;
     std::string base = input.substr(input.find_last_of('/') == std::string::npos ? 0 : input.find_last_of('/') + 1);
     if (base.find_last_of('.') != std::string::npos) base.erase(base.find_last_of('.'));
-    std::string name = o.prefix + base + o.suffix + ".dds";
+    std::string name = o.prefix + base + o.suffix + (o.hdrOut ? ".hdr" : ".dds");
     if (o.lower) std::transform(name.begin(), name.end(), name.begin(), [](unsigned char c) { return char(std::tolower(c)); });
     return o.out + "/" + name;
 }
@@ -257,7 +262,9 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
     const TEX_FILTER_FLAGS filter = TEX_FILTER_FLAGS(o.filter | o.filterOpts);
 
     ScratchImage image; TexMetadata info;
-    check("load", LoadFromDDSFile(inFile.c_str(), DDS_FLAGS(o.ddsRead), &info, image));
+    auto hasExt = [](const std::string& f, const char* ext) { const size_t n = std::strlen(ext); return f.size() > n && !strcasecmp(f.c_str() + f.size() - n, ext); };
+    if (hasExt(inFile, ".hdr")) check("load", LoadFromHDRFile(inFile.c_str(), &info, image));               // Radiance RGBE -> RGBA32F
+    else check("load", LoadFromDDSFile(inFile.c_str(), DDS_FLAGS(o.ddsRead), &info, image));
     std::printf("reading %s (%zux%zu", inFile.c_str(), info.width, info.height);
     if (info.dimension == TEX_DIMENSION_TEXTURE3D) std::printf("x%zu", info.depth);
     std::printf(", %zu mips, %zu items, format %u)\n", info.mipLevels, info.arraySize, unsigned(info.format));
@@ -417,7 +424,8 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
     uint32_t ddsFlags = DDS_FLAGS_NONE;
     if (o.dx10) ddsFlags |= DDS_FLAGS_FORCE_DX10_EXT | DDS_FLAGS_FORCE_DX10_EXT_MISC2;
     else if (o.dx9) ddsFlags |= DDS_FLAGS_FORCE_DX9_LEGACY;
-    check("save", SaveToDDSFile(image.GetImages(), image.GetImageCount(), info, DDS_FLAGS(ddsFlags), outFile.c_str()));
+    if (o.hdrOut) check("save", SaveToHDRFile(image.GetImages()[0], outFile.c_str()));                     // level 0 of the first item, like texconv's non-DDS codecs
+    else check("save", SaveToDDSFile(image.GetImages(), image.GetImageCount(), info, DDS_FLAGS(ddsFlags), outFile.c_str()));
     std::printf("writing %s (%zux%zu", outFile.c_str(), info.width, info.height);
     if (info.dimension == TEX_DIMENSION_TEXTURE3D) std::printf("x%zu", info.depth);
     std::printf(", %zu mips, %zu items, format %u)\n", info.mipLevels, info.arraySize, unsigned(info.format));

@@ -66,6 +66,10 @@ def _load_ref():
         lib.dxtex_ref_compute_pitch_ex.restype = ctypes.c_int
         lib.dxtex_ref_format_facts2.argtypes = [ctypes.c_int, szp]
         lib.dxtex_ref_format_facts2.restype = ctypes.c_int
+        lib.dxtex_ref_load_hdr.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64), vp, sz, i32p]
+        lib.dxtex_ref_load_hdr.restype = ctypes.c_int64
+        lib.dxtex_ref_save_hdr.argtypes = [vp, sz, sz, ctypes.c_int, sz, vp, sz, i32p]
+        lib.dxtex_ref_save_hdr.restype = ctypes.c_int64
         _ref = lib
     return _ref
 
@@ -487,3 +491,28 @@ def ref_format_facts2(fmt):
     out = (ctypes.c_size_t * 7)()
     bits = _load_ref().dxtex_ref_format_facts2(fmt, out)
     return [int(v) for v in out], bits
+
+
+def ref_load_hdr(data):
+    """DirectX::LoadFromHDRMemory -> (hr, {width, height, format, miscFlags2} or None, RGBA32F bytes or None)."""
+    d = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+    meta = (ctypes.c_uint64 * 4)()
+    out = np.zeros(1 << 22, np.uint8)
+    hr = ctypes.c_int32(0)
+    n = _load_ref().dxtex_ref_load_hdr(d.ctypes.data, d.size, meta, out.ctypes.data, out.nbytes, ctypes.byref(hr))
+    if n == -2:
+        raise MemoryError("ref_load_hdr: capacity")
+    if n < 0:
+        return hr.value & 0xFFFFFFFF, None, None
+    return hr.value & 0xFFFFFFFF, dict(zip(("width", "height", "format", "miscFlags2"), (int(v) for v in meta))), out[:n].copy()
+
+
+def ref_save_hdr(pixels, width, height, fmt, row_pitch):
+    """DirectX::SaveToHDRMemory -> (hr, file bytes or None)."""
+    px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
+    out = np.zeros(width * height * 4 + 4096, np.uint8)
+    hr = ctypes.c_int32(0)
+    n = _load_ref().dxtex_ref_save_hdr(px.ctypes.data, width, height, fmt, row_pitch, out.ctypes.data, out.nbytes, ctypes.byref(hr))
+    if n < 0:
+        return hr.value & 0xFFFFFFFF, None
+    return hr.value & 0xFFFFFFFF, out[:n].copy()

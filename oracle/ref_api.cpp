@@ -346,4 +346,30 @@ extern "C"
         out[5] = size_t(MakeTypelessUNORM(f)); out[6] = size_t(MakeTypelessFLOAT(f));
         return (IsVideo(f) ? 1 : 0) | (IsDepthStencil(f) ? 2 : 0) | (IsBGR(f) ? 4 : 0) | (IsTypeless(f, true) ? 8 : 0) | (IsTypeless(f, false) ? 16 : 0);
     }
+
+    // ---- Radiance .hdr (DirectXTexHDR.cpp compiled in place) --------------------------------------------------------------------
+    // meta[0..3] = width, height, format, miscFlags2; returns the pixel bytes (RGBA32F, tight), -1 on failure
+    int64_t dxtex_ref_load_hdr(const uint8_t* file, size_t size, uint64_t* meta, uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        ScratchImage si; TexMetadata m = {};
+        const HRESULT hr = LoadFromHDRMemory(file, size, &m, si);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        meta[0] = m.width; meta[1] = m.height; meta[2] = uint64_t(m.format); meta[3] = m.miscFlags2;
+        if (si.GetPixelsSize() > capacity) return -2;
+        memcpy(out, si.GetPixels(), si.GetPixelsSize());
+        return int64_t(si.GetPixelsSize());
+    }
+    int64_t dxtex_ref_save_hdr(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t rowPitch, uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        Image img = {};
+        img.width = w; img.height = h; img.format = DXGI_FORMAT(fmt); img.rowPitch = rowPitch; img.slicePitch = rowPitch * h; img.pixels = const_cast<uint8_t*>(pixels);
+        Blob blob;
+        const HRESULT hr = SaveToHDRMemory(img, blob);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        if (blob.GetBufferSize() > capacity) return -2;
+        memcpy(out, blob.GetBufferPointer(), blob.GetBufferSize());
+        return int64_t(blob.GetBufferSize());
+    }
 }

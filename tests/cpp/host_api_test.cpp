@@ -363,6 +363,51 @@ static int dds_load_many(char** a)
     return 0;
 }
 
+// codec_load_many <hdr|tga> <list.txt>: every line "<file> <flags>"; prints "hr <hr>[ meta w h format miscFlags2]", writes <file>.out
+static int codec_load_many(char** a)
+{
+    const bool hdr = !std::strcmp(a[0], "hdr");
+    FILE* list = std::fopen(a[1], "r");
+    if (!list) return 4;
+    char path[4096]; unsigned long flags;
+    while (std::fscanf(list, "%4095s %lu", path, &flags) == 2)
+    {
+        FILE* f = std::fopen(path, "rb");
+        if (!f) return 4;
+        std::fseek(f, 0, SEEK_END); const long len = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+        std::vector<uint8_t> buf(size_t(len > 0 ? len : 0));
+        if (!buf.empty() && std::fread(buf.data(), 1, buf.size(), f) != buf.size()) return 4;
+        std::fclose(f);
+        ScratchImage si; TexMetadata m, m2;
+        const HRESULT hr = hdr ? LoadFromHDRMemory(buf.data(), buf.size(), &m, si) : E_NOTIMPL;
+        std::printf("hr %08x", unsigned(hr));
+        if (FAILED(hr)) { std::puts(""); continue; }
+        std::printf(" meta %zu %zu %u %u\n", m.width, m.height, unsigned(m.format), m.miscFlags2);
+        const HRESULT hr2 = hdr ? GetMetadataFromHDRMemory(buf.data(), buf.size(), m2) : E_NOTIMPL;
+        if (hr2 != S_OK || m2.width != m.width || m2.height != m.height || m2.format != m.format)
+        { std::fprintf(stderr, "the header-only query disagrees with the loader for %s\n", path); return 5; }
+        dump(std::string(path) + ".out", si.GetPixels(), si.GetPixelsSize());
+    }
+    std::fclose(list);
+    return 0;
+}
+
+// codec_save <hdr|tga> <pixels.bin> <w> <h> <format> <rowPitch> <flags> <out>
+static int codec_save(char** a)
+{
+    const bool hdr = !std::strcmp(a[0], "hdr");
+    Image im; im.width = std::strtoull(a[2], nullptr, 10); im.height = std::strtoull(a[3], nullptr, 10); im.format = DXGI_FORMAT(std::atoi(a[4]));
+    im.rowPitch = std::strtoull(a[5], nullptr, 10); im.slicePitch = im.rowPitch * im.height;
+    std::vector<uint8_t> px(im.slicePitch);
+    FILE* f = std::fopen(a[1], "rb");
+    if (!f || std::fread(px.data(), 1, px.size(), f) != px.size()) return 4;
+    std::fclose(f);
+    im.pixels = px.data();
+    const HRESULT hr = hdr ? SaveToHDRFile(im, a[7]) : E_NOTIMPL;
+    std::printf("hr %08x\n", unsigned(hr));
+    return FAILED(hr) ? 3 : 0;
+}
+
 // formats: the container-side format tables for every format id 0..200, and pitches for a set of sizes and CP_FLAGS
 static int formats()
 {
@@ -394,6 +439,8 @@ int main(int argc, char** argv)
     if (argc >= 4 && !std::strcmp(argv[1], "dds_load")) return dds_load(argc - 2, argv + 2);
     if (argc >= 3 && !std::strcmp(argv[1], "dds_load_many")) return dds_load_many(argv + 2);
     if (argc >= 2 && !std::strcmp(argv[1], "formats")) return formats();
+    if (argc >= 4 && !std::strcmp(argv[1], "codec_load_many")) return codec_load_many(argv + 2);
+    if (argc >= 10 && !std::strcmp(argv[1], "codec_save")) return codec_save(argv + 2);
     if (argc >= 2 && !std::strcmp(argv[1], "cpu")) return cpu_checks();
     if (argc >= 3 && !std::strcmp(argv[1], "gpu")) return gpu_run(argv[2]);
     std::fprintf(stderr, "usage: host_api_test cpu | gpu <outdir>\n");

@@ -136,3 +136,25 @@ def test_keepcoverage_pmalpha_dx10(tmp_path, oracle):
     _run(["-m", "1", "-dx10", "-y", "-o", str(out), str(src)])
     hr, want = oracle.ref_save_dds_ex(img2, w, h, 1, RGBA8, 1, 1, 0, 3, 3, 0x10000 | 0x20000)
     assert np.array_equal(np.fromfile(out, np.uint8), want)
+
+
+def test_hdr_to_bc6h(tmp_path, oracle):
+    """a Radiance .hdr file (the reference's own writer) -> full mip chain -> BC6H_UF16, and back out as .hdr from a float DDS."""
+    w, h = 64, 32
+    rng = np.random.default_rng(71)
+    img = (rng.random((h, w, 4), dtype=np.float32) * np.exp2(rng.integers(-3, 5, (h, w, 1))).astype(np.float32)).astype(np.float32)
+    hr, hdr = oracle.ref_save_hdr(img, w, h, 2, w * 16)
+    assert hr == 0
+    src = tmp_path / "sky.hdr"; out = tmp_path / "sky.dds"
+    hdr.tofile(src)
+    _run(["-f", "BC6H_UF16", "-if", "BOX", "-o", str(out), str(src)])
+    hr, meta, px = oracle.ref_load_hdr(hdr)
+    mips = oracle.ref_generate_mips(px, w, h, 2, 0x400000, 7)
+    payload = np.concatenate([oracle.ref_compress_image(m, a, b, 2, 95, 0, 0.5) for m, (a, b) in zip(mips, oracle.mip_sizes(w, h, 7))])
+    want = oracle.ref_save_dds(payload, w, h, 95, 1, 7)
+    assert np.array_equal(np.fromfile(out, np.uint8), want)
+    # float DDS -> .hdr
+    f32 = tmp_path / "f32.dds"; back = tmp_path / "back.hdr"
+    oracle.ref_save_dds(px, w, h, 2).tofile(f32)
+    _run(["-m", "1", "-ft", "hdr", "-o", str(back), str(f32)])
+    assert np.array_equal(np.fromfile(back, np.uint8), oracle.ref_save_hdr(px, w, h, 2, w * 16)[1])
