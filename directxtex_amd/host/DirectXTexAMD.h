@@ -333,4 +333,21 @@ HRESULT LoadFromHDRMemory(const void* pSource, size_t size, TexMetadata* metadat
 HRESULT LoadFromHDRFile(const char* szFile, TexMetadata* metadata, ScratchImage& image) noexcept;
 HRESULT SaveToHDRMemory(const Image& image, Blob& blob) noexcept;
 HRESULT SaveToHDRFile(const Image& image, const char* szFile) noexcept;
+
+// ---- Truevision TGA, DirectXTexTGA.cpp: 8-bit grey -> R8, 16-bit -> B5G5R5A1, 24-bit -> RGBA8 (opaque), 32-bit -> RGBA8, colour-mapped
+// (24-bit palette) -> RGBA8; raw or run-length encoded; TGA 2.0 extension area for alpha mode and gamma ------------------------------
+enum TGA_FLAGS : uint32_t
+{
+    TGA_FLAGS_NONE = 0x0,
+    TGA_FLAGS_BGR = 0x1,                       // keep BGR order: 24-bit -> B8G8R8X8, 32-bit -> B8G8R8A8
+    TGA_FLAGS_ALLOW_ALL_ZERO_ALPHA = 0x2,      // an alpha channel of all zeros is meant (default: treated as opaque)
+    TGA_FLAGS_IGNORE_SRGB = 0x10, TGA_FLAGS_FORCE_SRGB = 0x20, TGA_FLAGS_FORCE_LINEAR = 0x40, TGA_FLAGS_DEFAULT_SRGB = 0x80,
+};
+HRESULT GetMetadataFromTGAMemory(const void* pSource, size_t size, TGA_FLAGS flags, TexMetadata& metadata) noexcept;
+HRESULT GetMetadataFromTGAFile(const char* szFile, TGA_FLAGS flags, TexMetadata& metadata) noexcept;
+HRESULT LoadFromTGAMemory(const void* pSource, size_t size, TGA_FLAGS flags, TexMetadata* metadata, ScratchImage& image) noexcept;
+HRESULT LoadFromTGAFile(const char* szFile, TGA_FLAGS flags, TexMetadata* metadata, ScratchImage& image) noexcept;
+// saves RGBA8 / BGRA8 (32-bit), BGRX8 (24-bit), R8 / A8 (grey), B5G5R5A1 (16-bit); metadata adds the TGA 2.0 extension area
+HRESULT SaveToTGAMemory(const Image& image, TGA_FLAGS flags, Blob& blob, const TexMetadata* metadata = nullptr) noexcept;
+HRESULT SaveToTGAFile(const Image& image, TGA_FLAGS flags, const char* szFile, const TexMetadata* metadata = nullptr) noexcept;
 } // namespace DirectXTexAMD

@@ -3,9 +3,9 @@
 // -> decompress (:2325-2480) -> undo premultiplied alpha (:2482-2530) -> resize (:2577-2640) -> convert (:3100-3140) ->
 // mipmaps (:3302-3460) -> alpha-coverage preservation (:3462-3500) -> premultiply alpha (:3502-3545) -> compress (:3547-3735) ->
 // alpha mode (:3738-3766) -> save (:3858-3878). Option names are texconv's; what has no GPU implementation here (flips,
-// swizzles, normal maps, tone mapping, WIC / TGA / HDR codecs, dithered conversion) is refused, not approximated.
+// swizzles, normal maps, tone mapping, WIC codecs, dithered conversion) is refused, not approximated.
 //
-//   dxtexconv [options] -o <out.dds | output directory> <in.dds | in.hdr>...        (-ft hdr writes Radiance files from float images)
+//   dxtexconv [options] -o <out.dds | output directory> <in.dds | in.hdr | in.tga>...        (-ft hdr | tga: Radiance / TGA output of level 0)
 //     -w <n> -h <n>        target size                         -pow2             fit to a power of two (keeps the aspect ratio)
 //     -m <n>               mip levels, 0 = full chain           -fl <9.1 .. 12.2> feature level: largest texture side allowed
 //     -f <format>          DXGI format name or number           -if <filter>      POINT LINEAR CUBIC FANT BOX TRIANGLE
@@ -69,7 +69,7 @@ struct Options
 {
     size_t width = 0, height = 0, mipLevels = 0, maxSize = 16384;          // mipLevels 0: keep a chain the input has, else build the full one
     bool pow2 = false, pmalpha = false, demul = false, dx10 = false, dx9 = false, sepalpha = false, lower = false, overwrite = false,
-         timing = false, nologo = false, hdrOut = false;
+         timing = false, nologo = false, hdrOut = false, tgaOut = false;
     uint32_t format = 0, filter = 0, filterOpts = 0, srgb = 0, convert = 0, compress = 0, ddsRead = DDS_FLAGS_ALLOW_LARGE_FILES;
     float alphaThreshold = TEX_THRESHOLD_DEFAULT, keepCoverage = 0.f;
     int gpu = 0;
@@ -229,7 +229,8 @@ bool Parse(int argc, char** argv, Options& o)
         {
             const char* ft = next();
             if (!strcasecmp(ft, "hdr")) o.hdrOut = true;
-            else if (strcasecmp(ft, "dds")) { std::fprintf(stderr, "output file types: dds, hdr\n"); return false; }
+            else if (!strcasecmp(ft, "tga")) o.tgaOut = true;
+            else if (strcasecmp(ft, "dds")) { std::fprintf(stderr, "output file types: dds, hdr, tga\n"); return false; }
         }
         else if (a == "-r" || a == "-nogpu" || a == "-singleproc") { }            // nothing to switch here
         else if (a[0] == '-') { std::fprintf(stderr, "unknown or unsupported option %s\n", a.c_str()); return false; }
@@ -244,11 +245,11 @@ bool Parse(int argc, char** argv, Options& o)
 // <out> names a file when it ends in .dds and there is one input; otherwise a directory that receives <px><name><sx>.dds
 std::string OutputName(const Options& o, const std::string& input)
 {
-    auto endsDDS = [](const std::string& s) { return s.size() > 4 && (!strcasecmp(s.c_str() + s.size() - 4, ".dds") || !strcasecmp(s.c_str() + s.size() - 4, ".hdr")); };
+    auto endsDDS = [](const std::string& s) { return s.size() > 4 && (!strcasecmp(s.c_str() + s.size() - 4, ".dds") || !strcasecmp(s.c_str() + s.size() - 4, ".hdr") || !strcasecmp(s.c_str() + s.size() - 4, ".tga")); };
     if (o.inputs.size() == 1 && endsDDS(o.out) && o.prefix.empty() && o.suffix.empty()) return o.out;
     std::string base = input.substr(input.find_last_of('/') == std::string::npos ? 0 : input.find_last_of('/') + 1);
     if (base.find_last_of('.') != std::string::npos) base.erase(base.find_last_of('.'));
-    std::string name = o.prefix + base + o.suffix + (o.hdrOut ? ".hdr" : ".dds");
+    std::string name = o.prefix + base + o.suffix + (o.hdrOut ? ".hdr" : o.tgaOut ? ".tga" : ".dds");
     if (o.lower) std::transform(name.begin(), name.end(), name.begin(), [](unsigned char c) { return char(std::tolower(c)); });
     return o.out + "/" + name;
 }
@@ -264,6 +265,7 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
     ScratchImage image; TexMetadata info;
     auto hasExt = [](const std::string& f, const char* ext) { const size_t n = std::strlen(ext); return f.size() > n && !strcasecmp(f.c_str() + f.size() - n, ext); };
     if (hasExt(inFile, ".hdr")) check("load", LoadFromHDRFile(inFile.c_str(), &info, image));               // Radiance RGBE -> RGBA32F
+    else if (hasExt(inFile, ".tga")) check("load", LoadFromTGAFile(inFile.c_str(), TGA_FLAGS_NONE, &info, image));
     else check("load", LoadFromDDSFile(inFile.c_str(), DDS_FLAGS(o.ddsRead), &info, image));
     std::printf("reading %s (%zux%zu", inFile.c_str(), info.width, info.height);
     if (info.dimension == TEX_DIMENSION_TEXTURE3D) std::printf("x%zu", info.depth);
@@ -425,6 +427,7 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
     if (o.dx10) ddsFlags |= DDS_FLAGS_FORCE_DX10_EXT | DDS_FLAGS_FORCE_DX10_EXT_MISC2;
     else if (o.dx9) ddsFlags |= DDS_FLAGS_FORCE_DX9_LEGACY;
     if (o.hdrOut) check("save", SaveToHDRFile(image.GetImages()[0], outFile.c_str()));                     // level 0 of the first item, like texconv's non-DDS codecs
+    else if (o.tgaOut) check("save", SaveToTGAFile(image.GetImages()[0], TGA_FLAGS_NONE, outFile.c_str(), &info));      // with the TGA 2.0 extension area (texconv -tga20)
     else check("save", SaveToDDSFile(image.GetImages(), image.GetImageCount(), info, DDS_FLAGS(ddsFlags), outFile.c_str()));
     std::printf("writing %s (%zux%zu", outFile.c_str(), info.width, info.height);
     if (info.dimension == TEX_DIMENSION_TEXTURE3D) std::printf("x%zu", info.depth);

@@ -70,6 +70,10 @@ def _load_ref():
         lib.dxtex_ref_load_hdr.restype = ctypes.c_int64
         lib.dxtex_ref_save_hdr.argtypes = [vp, sz, sz, ctypes.c_int, sz, vp, sz, i32p]
         lib.dxtex_ref_save_hdr.restype = ctypes.c_int64
+        lib.dxtex_ref_load_tga.argtypes = [vp, sz, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), vp, sz, i32p]
+        lib.dxtex_ref_load_tga.restype = ctypes.c_int64
+        lib.dxtex_ref_save_tga.argtypes = [vp, sz, sz, ctypes.c_int, sz, ctypes.c_uint32, ctypes.c_int, vp, sz, i32p]
+        lib.dxtex_ref_save_tga.restype = ctypes.c_int64
         _ref = lib
     return _ref
 
@@ -513,6 +517,34 @@ def ref_save_hdr(pixels, width, height, fmt, row_pitch):
     out = np.zeros(width * height * 4 + 4096, np.uint8)
     hr = ctypes.c_int32(0)
     n = _load_ref().dxtex_ref_save_hdr(px.ctypes.data, width, height, fmt, row_pitch, out.ctypes.data, out.nbytes, ctypes.byref(hr))
+    if n < 0:
+        return hr.value & 0xFFFFFFFF, None
+    return hr.value & 0xFFFFFFFF, out[:n].copy()
+
+
+TGA_META_KEYS = ("width", "height", "format", "miscFlags2", "imageFormat", "queryHr", "queryFormat", "queryMiscFlags2")
+
+
+def ref_load_tga(data, flags=0):
+    """DirectX::LoadFromTGAMemory (+ GetMetadataFromTGAMemory) -> (hr, dict of TGA_META_KEYS or None, pixel bytes or None)."""
+    d = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+    meta = (ctypes.c_uint64 * 8)()
+    out = np.zeros(1 << 22, np.uint8)
+    hr = ctypes.c_int32(0)
+    n = _load_ref().dxtex_ref_load_tga(d.ctypes.data, d.size, flags, meta, out.ctypes.data, out.nbytes, ctypes.byref(hr))
+    if n == -2:
+        raise MemoryError("ref_load_tga: capacity")
+    if n < 0:
+        return hr.value & 0xFFFFFFFF, None, None
+    return hr.value & 0xFFFFFFFF, dict(zip(TGA_META_KEYS, (int(v) for v in meta))), out[:n].copy()
+
+
+def ref_save_tga(pixels, width, height, fmt, row_pitch, flags=0, alpha_mode=-1):
+    """DirectX::SaveToTGAMemory -> (hr, file bytes or None); alpha_mode >= 0 passes metadata (TGA 2.0 extension area)."""
+    px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
+    out = np.zeros(width * height * 4 + 4096, np.uint8)
+    hr = ctypes.c_int32(0)
+    n = _load_ref().dxtex_ref_save_tga(px.ctypes.data, width, height, fmt, row_pitch, flags, alpha_mode, out.ctypes.data, out.nbytes, ctypes.byref(hr))
     if n < 0:
         return hr.value & 0xFFFFFFFF, None
     return hr.value & 0xFFFFFFFF, out[:n].copy()

@@ -372,4 +372,37 @@ extern "C"
         memcpy(out, blob.GetBufferPointer(), blob.GetBufferSize());
         return int64_t(blob.GetBufferSize());
     }
+
+    // ---- TGA (DirectXTexTGA.cpp compiled in place) ---------------------------------------------------------------------------------
+    int64_t dxtex_ref_load_tga(const uint8_t* file, size_t size, uint32_t flags, uint64_t* meta, uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        ScratchImage si; TexMetadata m = {};
+        const HRESULT hr = LoadFromTGAMemory(file, size, TGA_FLAGS(flags), &m, si);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        meta[0] = m.width; meta[1] = m.height; meta[2] = uint64_t(m.format); meta[3] = m.miscFlags2;
+        meta[4] = uint64_t(si.GetMetadata().format);           // the image's own label after OverrideFormat
+        TexMetadata q = {};
+        meta[5] = uint64_t(uint32_t(GetMetadataFromTGAMemory(file, size, TGA_FLAGS(flags), q)));
+        meta[6] = uint64_t(q.format); meta[7] = q.miscFlags2;
+        if (si.GetPixelsSize() > capacity) return -2;
+        memcpy(out, si.GetPixels(), si.GetPixelsSize());
+        return int64_t(si.GetPixelsSize());
+    }
+    // alphaMode < 0: no metadata (no extension area)
+    int64_t dxtex_ref_save_tga(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t rowPitch, uint32_t flags, int alphaMode, uint8_t* out, size_t capacity, int32_t* hrOut)
+    {
+        Image img = {};
+        img.width = w; img.height = h; img.format = DXGI_FORMAT(fmt); img.rowPitch = rowPitch; img.slicePitch = rowPitch * h; img.pixels = const_cast<uint8_t*>(pixels);
+        TexMetadata m = {};
+        m.width = w; m.height = h; m.depth = m.arraySize = m.mipLevels = 1; m.format = DXGI_FORMAT(fmt); m.dimension = TEX_DIMENSION_TEXTURE2D;
+        if (alphaMode >= 0) m.SetAlphaMode(TEX_ALPHA_MODE(alphaMode));
+        Blob blob;
+        const HRESULT hr = SaveToTGAMemory(img, TGA_FLAGS(flags), blob, alphaMode >= 0 ? &m : nullptr);
+        if (hrOut) *hrOut = int32_t(hr);
+        if (FAILED(hr)) return -1;
+        if (blob.GetBufferSize() > capacity) return -2;
+        memcpy(out, blob.GetBufferPointer(), blob.GetBufferSize());
+        return int64_t(blob.GetBufferSize());
+    }
 }

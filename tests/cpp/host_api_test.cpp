@@ -379,11 +379,13 @@ static int codec_load_many(char** a)
         if (!buf.empty() && std::fread(buf.data(), 1, buf.size(), f) != buf.size()) return 4;
         std::fclose(f);
         ScratchImage si; TexMetadata m, m2;
-        const HRESULT hr = hdr ? LoadFromHDRMemory(buf.data(), buf.size(), &m, si) : E_NOTIMPL;
+        const HRESULT hr = hdr ? LoadFromHDRMemory(buf.data(), buf.size(), &m, si) : LoadFromTGAMemory(buf.data(), buf.size(), TGA_FLAGS(flags), &m, si);
         std::printf("hr %08x", unsigned(hr));
         if (FAILED(hr)) { std::puts(""); continue; }
-        std::printf(" meta %zu %zu %u %u\n", m.width, m.height, unsigned(m.format), m.miscFlags2);
-        const HRESULT hr2 = hdr ? GetMetadataFromHDRMemory(buf.data(), buf.size(), m2) : E_NOTIMPL;
+        const HRESULT hr2 = hdr ? GetMetadataFromHDRMemory(buf.data(), buf.size(), m2) : GetMetadataFromTGAMemory(buf.data(), buf.size(), TGA_FLAGS(flags), m2);
+        std::printf(" meta %zu %zu %u %u", m.width, m.height, unsigned(m.format), m.miscFlags2);
+        if (!hdr) std::printf(" %u %u %u %u", unsigned(si.GetMetadata().format), unsigned(hr2), unsigned(m2.format), m2.miscFlags2);
+        std::puts("");
         if (hr2 != S_OK || m2.width != m.width || m2.height != m.height || m2.format != m.format)
         { std::fprintf(stderr, "the header-only query disagrees with the loader for %s\n", path); return 5; }
         dump(std::string(path) + ".out", si.GetPixels(), si.GetPixelsSize());
@@ -392,7 +394,7 @@ static int codec_load_many(char** a)
     return 0;
 }
 
-// codec_save <hdr|tga> <pixels.bin> <w> <h> <format> <rowPitch> <flags> <out>
+// codec_save <hdr|tga> <pixels.bin> <w> <h> <format> <rowPitch> <flags> <out> [alphaMode]
 static int codec_save(char** a)
 {
     const bool hdr = !std::strcmp(a[0], "hdr");
@@ -403,7 +405,10 @@ static int codec_save(char** a)
     if (!f || std::fread(px.data(), 1, px.size(), f) != px.size()) return 4;
     std::fclose(f);
     im.pixels = px.data();
-    const HRESULT hr = hdr ? SaveToHDRFile(im, a[7]) : E_NOTIMPL;
+    // TGA: flags, and an optional 9th argument = alpha mode of the metadata to pass (adds the TGA 2.0 extension area)
+    TexMetadata md; md.width = im.width; md.height = im.height; md.depth = md.arraySize = md.mipLevels = 1; md.format = im.format;
+    if (a[8]) md.SetAlphaMode(TEX_ALPHA_MODE(std::atoi(a[8])));
+    const HRESULT hr = hdr ? SaveToHDRFile(im, a[7]) : SaveToTGAFile(im, TGA_FLAGS(std::strtoul(a[6], nullptr, 0)), a[7], a[8] ? &md : nullptr);
     std::printf("hr %08x\n", unsigned(hr));
     return FAILED(hr) ? 3 : 0;
 }

@@ -158,3 +158,27 @@ def test_hdr_to_bc6h(tmp_path, oracle):
     oracle.ref_save_dds(px, w, h, 2).tofile(f32)
     _run(["-m", "1", "-ft", "hdr", "-o", str(back), str(f32)])
     assert np.array_equal(np.fromfile(back, np.uint8), oracle.ref_save_hdr(px, w, h, 2, w * 16)[1])
+
+
+def test_tga_to_bc7_and_back_to_tga(tmp_path, oracle):
+    """a 32-bit run-length-free TGA (the reference's writer) -> BC7 with mips; an RGBA8 DDS -> TGA 2.0 with the alpha mode set."""
+    w, h = 48, 32
+    img = synth.rgba8(w, h, seed=81, alpha="smooth")
+    hr, tga = oracle.ref_save_tga(img, w, h, RGBA8, w * 4)
+    assert hr == 0
+    src = tmp_path / "albedo.tga"; out = tmp_path / "albedo.dds"
+    tga.tofile(src)
+    _run(["-f", "BC7_UNORM", "-if", "CUBIC", "-m", "3", "-o", str(out), str(src)])
+    hr, meta, px = oracle.ref_load_tga(tga)
+    assert np.array_equal(px, img.reshape(-1))
+    mips = oracle.ref_generate_mips(px, w, h, RGBA8, 0x300000, 3)
+    payload = np.concatenate([oracle.ref_compress_image(m, a, b, RGBA8, 98, 0, 0.5) for m, (a, b) in zip(mips, oracle.mip_sizes(w, h, 3))])
+    assert np.array_equal(np.fromfile(out, np.uint8), oracle.ref_save_dds(payload, w, h, 98, 1, 3))
+    dds = tmp_path / "rgba.dds"; back = tmp_path / "back.tga"
+    oracle.ref_save_dds(img, w, h, RGBA8).tofile(dds)
+    _run(["-m", "1", "-ft", "tga", "-o", str(back), str(dds)])
+    ours = np.fromfile(back, np.uint8)
+    hr, want = oracle.ref_save_tga(img, w, h, RGBA8, w * 4, 0, 1)               # alpha mode straight, as texconv tags it
+    at = want.size - 26 - 495
+    ours[at + 367:at + 379] = 0; want = want.copy(); want[at + 367:at + 379] = 0          # the time stamp
+    assert np.array_equal(ours, want)
