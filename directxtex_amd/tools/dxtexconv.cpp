@@ -14,7 +14,7 @@
 //     -at <threshold>      alpha threshold (BC1, 1-bit alpha)   -bc <q|x|d|u>...  BC7 quick / 3 subsets, dither, uniform weights
 //     -x2bias              *2 - 1 on conversions to / from SNORM -sepalpha        resize / mip alpha separately (alpha mode custom)
 //     -dword -badtails -permissive -ignoremips -xlum            DDS reader tolerances (DDS_FLAGS)
-//     -dx10 -dx9           force the 'DX10' header (+ alpha mode) / a Direct3D 9 file
+//     -dx10 -dx9           force the 'DX10' header (+ alpha mode) / a Direct3D 9 file        -tga20   TGA output with the 2.0 extension area
 //     -px <s> -sx <s> -l   output name prefix / suffix, lower case    -y   overwrite    -timing -nologo -gpu <n>
 #include "../host/DirectXTexAMD.h"
 
@@ -69,7 +69,7 @@ struct Options
 {
     size_t width = 0, height = 0, mipLevels = 0, maxSize = 16384;          // mipLevels 0: keep a chain the input has, else build the full one
     bool pow2 = false, pmalpha = false, demul = false, dx10 = false, dx9 = false, sepalpha = false, lower = false, overwrite = false,
-         timing = false, nologo = false, hdrOut = false, tgaOut = false;
+         timing = false, nologo = false, hdrOut = false, tgaOut = false, tga20 = false;
     uint32_t format = 0, filter = 0, filterOpts = 0, srgb = 0, convert = 0, compress = 0, ddsRead = DDS_FLAGS_ALLOW_LARGE_FILES;
     float alphaThreshold = TEX_THRESHOLD_DEFAULT, keepCoverage = 0.f;
     int gpu = 0;
@@ -215,6 +215,7 @@ bool Parse(int argc, char** argv, Options& o)
         else if (a == "-permissive") o.ddsRead |= DDS_FLAGS_PERMISSIVE;
         else if (a == "-ignoremips") o.ddsRead |= DDS_FLAGS_IGNORE_MIPS;
         else if (a == "-xlum") o.ddsRead |= DDS_FLAGS_EXPAND_LUMINANCE;
+        else if (a == "-tga20") o.tga20 = true;
         else if (a == "-dx10") o.dx10 = true;
         else if (a == "-dx9") o.dx9 = true;
         else if (a == "-px") o.prefix = next();
@@ -427,7 +428,7 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
     if (o.dx10) ddsFlags |= DDS_FLAGS_FORCE_DX10_EXT | DDS_FLAGS_FORCE_DX10_EXT_MISC2;
     else if (o.dx9) ddsFlags |= DDS_FLAGS_FORCE_DX9_LEGACY;
     if (o.hdrOut) check("save", SaveToHDRFile(image.GetImages()[0], outFile.c_str()));                     // level 0 of the first item, like texconv's non-DDS codecs
-    else if (o.tgaOut) check("save", SaveToTGAFile(image.GetImages()[0], TGA_FLAGS_NONE, outFile.c_str(), &info));      // with the TGA 2.0 extension area (texconv -tga20)
+    else if (o.tgaOut) check("save", SaveToTGAFile(image.GetImages()[0], TGA_FLAGS_NONE, outFile.c_str(), o.tga20 ? &info : nullptr));      // -tga20: with the TGA 2.0 extension area
     else check("save", SaveToDDSFile(image.GetImages(), image.GetImageCount(), info, DDS_FLAGS(ddsFlags), outFile.c_str()));
     std::printf("writing %s (%zux%zu", outFile.c_str(), info.width, info.height);
     if (info.dimension == TEX_DIMENSION_TEXTURE3D) std::printf("x%zu", info.depth);

@@ -177,6 +177,8 @@ def test_tga_to_bc7_and_back_to_tga(tmp_path, oracle):
     dds = tmp_path / "rgba.dds"; back = tmp_path / "back.tga"
     oracle.ref_save_dds(img, w, h, RGBA8).tofile(dds)
     _run(["-m", "1", "-ft", "tga", "-o", str(back), str(dds)])
+    assert np.array_equal(np.fromfile(back, np.uint8), oracle.ref_save_tga(img, w, h, RGBA8, w * 4)[1])          # plain TGA: no extension area
+    _run(["-m", "1", "-ft", "tga", "-tga20", "-y", "-o", str(back), str(dds)])
     ours = np.fromfile(back, np.uint8)
     hr, want = oracle.ref_save_tga(img, w, h, RGBA8, w * 4, 0, 1)               # alpha mode straight, as texconv tags it
     at = want.size - 26 - 495
