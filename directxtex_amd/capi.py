@@ -58,6 +58,7 @@ _SIGS = {
     "dxtex_is_compressed": (ctypes.c_int, [ctypes.c_int32]),
     "dxtex_bits_per_pixel": (ctypes.c_size_t, [ctypes.c_int32]),
     "dxtex_compute_pitch": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, _P(ctypes.c_size_t), _P(ctypes.c_size_t)]),
+    "dxtex_ctx_prepare": (ctypes.c_int32, [_ctx_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint32, ctypes.c_size_t, _P(ctypes.c_size_t)]),
     "dxtex_compress": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
     "dxtex_compress_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
     "dxtex_compress_many_device": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_size_t, ctypes.c_uint32, ctypes.c_float]),
@@ -186,6 +187,13 @@ class Context:
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(keys)}
 
     # -- Compress -----------------------------------------------------------------------------------
+    def prepare(self, width, height, src_format, dst_format, flags=0, count=1):
+        """GPUCompressBC::Prepare's role: allocate the search scratch and staging for `count` images of this shape now.
+        Returns the bytes of device memory the context holds afterwards."""
+        held = ctypes.c_size_t(0)
+        self._check(_lib.dxtex_ctx_prepare(self._h, width, height, src_format, dst_format, flags, count, ctypes.byref(held)), "prepare")
+        return held.value
+
     def compress(self, pixels, width, height, src_format, dst_format, flags=0, threshold=0.5, src_row_pitch=None):
         """Host image (numpy, any dtype, C-contiguous rows) -> numpy uint8 BC payload (tight pitch)."""
         pixels = np.ascontiguousarray(pixels)

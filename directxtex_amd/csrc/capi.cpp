@@ -417,6 +417,32 @@ dxtex_hresult dxtex_compress_many_device(dxtex_ctx* ctx, const dxtex_image* srcs
     return DXTEX_S_OK;
 }
 
+// GPUCompressBC::Prepare's role (BCDirectCompute.cpp:203-369): size the context for `count` images of one shape up front.
+dxtex_hresult dxtex_ctx_prepare(dxtex_ctx* ctx, size_t width, size_t height, int32_t src_format, int32_t dst_format, uint32_t flags, size_t count,
+                                size_t* device_bytes)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!count) return fail(ctx, DXTEX_E_INVALIDARG, "empty batch");
+    size_t srcRow = 0, srcSlice = 0, dstRow = 0, dstSlice = 0;
+    SrcView v;
+    dxtex_hresult hr = compress_view(ctx, nullptr, width, height, src_format, 0, dst_format, flags, &v);           // the format / size checks of dxtex_compress
+    if (hr != DXTEX_S_OK) return hr;
+    if (dxtex_compute_pitch(src_format, width, height, &srcRow, &srcSlice) != DXTEX_S_OK || dxtex_compute_pitch(dst_format, width, height, &dstRow, &dstSlice) != DXTEX_S_OK)
+        return fail(ctx, DXTEX_E_INVALIDARG, "image too large");
+    ScopedDevice sd(ctx->device);
+    const uint64_t nblocks = uint64_t((width + 3) / 4) * uint64_t((height + 3) / 4) * count;
+    if (dst_format == FMT_BC7_UNORM || dst_format == FMT_BC7_UNORM_SRGB)
+        hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks, flags, count));
+    else if (dst_format == FMT_BC6H_UF16 || dst_format == FMT_BC6H_SF16)
+        hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc6h_scratch_bytes(nblocks, count));
+    if (hr != DXTEX_S_OK) return hr;
+    // staging as dxtex_compress_many lays it out: every image 256-byte aligned
+    hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, ((srcSlice + 255) & ~size_t(255)) * count); if (hr != DXTEX_S_OK) return hr;
+    hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, ((dstSlice + 255) & ~size_t(255)) * count); if (hr != DXTEX_S_OK) return hr;
+    if (device_bytes) *device_bytes = ctx->scratchBytes + ctx->stageInBytes + ctx->stageOutBytes;
+    return DXTEX_S_OK;
+}
+
 // Array form of dxtex_compress with host pointers: every image is staged into one device buffer, the whole array is
 // submitted as one dxtex_compress_many_device, and the payloads come back together.
 dxtex_hresult dxtex_compress_many(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts, size_t count, uint32_t flags, float threshold)
