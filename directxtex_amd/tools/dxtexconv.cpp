@@ -15,7 +15,7 @@
 //     -x2bias              *2 - 1 on conversions to / from SNORM -sepalpha        resize / mip alpha separately (alpha mode custom)
 //     -dword -badtails -permissive -ignoremips -xlum            DDS reader tolerances (DDS_FLAGS)
 //     -dx10 -dx9           force the 'DX10' header (+ alpha mode) / a Direct3D 9 file        -tga20   TGA output with the 2.0 extension area
-//     -px <s> -sx <s> -l   output name prefix / suffix, lower case    -y   overwrite    -timing -nologo -gpu <n>
+//     -px <s> -sx <s> -l   output name prefix / suffix, lower case    -y   overwrite    -timing -nologo -gpu <n> | -gpus <a,b,...> (files dealt out over the GPUs)
 #include "../host/DirectXTexAMD.h"
 
 #include <algorithm>
@@ -27,6 +27,8 @@
 #include <cstring>
 #include <string>
 #include <sys/stat.h>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 using namespace DirectXTexAMD;
@@ -72,7 +74,7 @@ struct Options
          timing = false, nologo = false, hdrOut = false, tgaOut = false, tga20 = false;
     uint32_t format = 0, filter = 0, filterOpts = 0, srgb = 0, convert = 0, compress = 0, ddsRead = DDS_FLAGS_ALLOW_LARGE_FILES;
     float alphaThreshold = TEX_THRESHOLD_DEFAULT, keepCoverage = 0.f;
-    int gpu = 0;
+    std::vector<int> gpus;              // one worker (own Device, own host thread) per entry; input i goes to worker i mod n
     std::string prefix, suffix, out;
     std::vector<std::string> inputs;
 };
@@ -167,7 +169,7 @@ int usage()
 {
     std::fprintf(stderr, "usage: dxtexconv [-w W] [-h H] [-pow2] [-fl LEVEL] [-m N] [-f FORMAT] [-if FILTER] [-wrap] [-mirror] [-srgb|-srgbi|-srgbo]\n"
                          "                 [-pmalpha|-alpha] [-keepcoverage REF] [-at T] [-bc qxdu] [-x2bias] [-sepalpha] [-dword] [-badtails] [-permissive]\n"
-                         "                 [-ignoremips] [-xlum] [-dx10|-dx9] [-px S] [-sx S] [-l] [-y] [-timing] [-nologo] [-gpu N] -o <out.dds | dir> in.dds...\n");
+                         "                 [-ignoremips] [-xlum] [-dx10|-dx9] [-px S] [-sx S] [-l] [-y] [-timing] [-nologo] [-gpu N | -gpus A,B,...] -o <out.dds | dir> in.dds...\n");
     return 1;
 }
 
@@ -224,7 +226,22 @@ bool Parse(int argc, char** argv, Options& o)
         else if (a == "-y") o.overwrite = true;
         else if (a == "-timing") o.timing = true;
         else if (a == "-nologo") o.nologo = true;
-        else if (a == "-gpu") o.gpu = std::atoi(next());
+        else if (a == "-gpu") o.gpus.assign(1, std::atoi(next()));
+        else if (a == "-gpus")
+        {
+            // "0,1,2,3": the files are dealt out over these GPUs, one host thread and one context each (contexts share nothing)
+            o.gpus.clear();
+            for (const char* p = next(); *p;)
+            {
+                char* end = nullptr;
+                const long g = std::strtol(p, &end, 10);
+                if (end == p || g < 0) { std::fprintf(stderr, "-gpus wants a comma-separated list of device ordinals\n"); return false; }
+                o.gpus.push_back(int(g));
+                p = (*end == ',') ? end + 1 : end;
+                if (*end && *end != ',') { std::fprintf(stderr, "-gpus wants a comma-separated list of device ordinals\n"); return false; }
+            }
+            if (o.gpus.empty()) { std::fprintf(stderr, "-gpus wants a comma-separated list of device ordinals\n"); return false; }
+        }
         else if (a == "-o") o.out = next();
         else if (a == "-ft")
         {
@@ -240,6 +257,7 @@ bool Parse(int argc, char** argv, Options& o)
     }
     if (o.pmalpha && o.demul) { std::fprintf(stderr, "-pmalpha and -alpha exclude each other\n"); return false; }
     if (o.dx10 && o.dx9) { std::fprintf(stderr, "-dx10 and -dx9 exclude each other\n"); return false; }
+    if (o.gpus.empty()) o.gpus.assign(1, 0);
     return !o.inputs.empty() && !o.out.empty();
 }
 
@@ -442,20 +460,32 @@ int main(int argc, char** argv)
     if (!Parse(argc, argv, o)) return usage();
     if (!o.nologo) std::printf("dxtexconv: DirectXTex pipeline on MI355X (gfx950)\n");
 
-    Device dev;
-    if (FAILED(dev.Create(o.gpu))) { std::fprintf(stderr, "no gfx950 device %d (this tool has no CPU path)\n", o.gpu); return 1; }
-
-    int failures = 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (const std::string& in : o.inputs)
+    // Image-per-GPU sharding: files are independent, so worker k takes inputs k, k + n, k + 2n, ... on its own
+    // Device; no data moves between GPUs. With one GPU this is a plain loop on the calling thread.
+    std::atomic<int> failures{ 0 };
+    auto work = [&](size_t k, size_t n)
     {
-        try { ConvertOne(dev, o, in, OutputName(o, in)); }
-        catch (const StepFailed& f)
+        Device dev;
+        if (FAILED(dev.Create(o.gpus[k]))) { std::fprintf(stderr, "no gfx950 device %d (this tool has no CPU path)\n", o.gpus[k]); failures += int((o.inputs.size() - k + n - 1) / n); return; }
+        for (size_t i = k; i < o.inputs.size(); i += n)
         {
-            std::fprintf(stderr, "FAILED [%s] (%08X) %s\n", f.what, unsigned(f.hr), dev.LastError());
-            ++failures;                                   // like texconv: report, go on with the next file, exit code 1
+            try { ConvertOne(dev, o, o.inputs[i], OutputName(o, o.inputs[i])); }
+            catch (const StepFailed& f)
+            {
+                std::fprintf(stderr, "FAILED [%s] (%08X) %s: %s\n", f.what, unsigned(f.hr), o.inputs[i].c_str(), dev.LastError());
+                ++failures;                               // like texconv: report, go on with the next file, exit code 1
+            }
         }
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t workers = std::min(o.gpus.size(), o.inputs.size());
+    if (workers <= 1) work(0, 1);
+    else
+    {
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < workers; ++k) pool.emplace_back(work, k, workers);
+        for (std::thread& t : pool) t.join();
     }
     if (o.timing) std::printf("processing time: %.3f seconds\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    return failures ? 1 : 0;
+    return failures.load() ? 1 : 0;
 }

@@ -184,3 +184,20 @@ def test_tga_to_bc7_and_back_to_tga(tmp_path, oracle):
     at = want.size - 26 - 495
     ours[at + 367:at + 379] = 0; want = want.copy(); want[at + 367:at + 379] = 0          # the time stamp
     assert np.array_equal(ours, want)
+
+
+def test_files_dealt_out_over_worker_contexts(tmp_path, oracle):
+    """-gpus a,b,...: one host thread and one context per entry, file i on worker i mod n, nothing shared. On a
+    one-GPU box the two workers are two contexts on the same device - the host-side concurrency is what is tested here."""
+    w = h = 64
+    outdir = tmp_path / "out"; outdir.mkdir()
+    srcs = []
+    for i in range(5):
+        img = synth.rgba8(w, h, seed=100 + i, alpha="smooth")
+        p = tmp_path / f"t{i}.dds"
+        oracle.ref_save_dds(img, w, h, RGBA8).tofile(p)
+        srcs.append((p, img))
+    _run(["-gpus", "0,0", "-f", "BC7_UNORM", "-m", "1", "-nologo", "-o", str(outdir)] + [str(p) for p, _ in srcs])
+    for i, (p, img) in enumerate(srcs):
+        want = oracle.ref_save_dds(oracle.ref_compress_image(img, w, h, RGBA8, 98, 0, 0.5), w, h, 98)
+        assert np.array_equal(np.fromfile(outdir / f"t{i}.dds", np.uint8), want), i
