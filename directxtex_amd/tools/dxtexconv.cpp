@@ -15,7 +15,7 @@
 //     -x2bias              *2 - 1 on conversions to / from SNORM -sepalpha        resize / mip alpha separately (alpha mode custom)
 //     -dword -badtails -permissive -ignoremips -xlum            DDS reader tolerances (DDS_FLAGS)
 //     -dx10 -dx9           force the 'DX10' header (+ alpha mode) / a Direct3D 9 file        -tga20   TGA output with the 2.0 extension area
-//     -px <s> -sx <s> -l   output name prefix / suffix, lower case    -y   overwrite    -timing -nologo -gpu <n> | -gpus <a,b,...> (files dealt out over the GPUs)
+//     -px <s> -sx <s> -l   output name prefix / suffix, lower case    -y   overwrite    -info (print what the files hold, no GPU)    -timing -nologo -gpu <n> | -gpus <a,b,...> (files dealt out over the GPUs)
 #include "../host/DirectXTexAMD.h"
 
 #include <algorithm>
@@ -71,7 +71,7 @@ struct Options
 {
     size_t width = 0, height = 0, mipLevels = 0, maxSize = 16384;          // mipLevels 0: keep a chain the input has, else build the full one
     bool pow2 = false, pmalpha = false, demul = false, dx10 = false, dx9 = false, sepalpha = false, lower = false, overwrite = false,
-         timing = false, nologo = false, hdrOut = false, tgaOut = false, tga20 = false;
+         timing = false, nologo = false, hdrOut = false, tgaOut = false, tga20 = false, info = false;
     uint32_t format = 0, filter = 0, filterOpts = 0, srgb = 0, convert = 0, compress = 0, ddsRead = DDS_FLAGS_ALLOW_LARGE_FILES;
     float alphaThreshold = TEX_THRESHOLD_DEFAULT, keepCoverage = 0.f;
     std::vector<int> gpus;              // one worker (own Device, own host thread) per entry; input i goes to worker i mod n
@@ -218,6 +218,7 @@ bool Parse(int argc, char** argv, Options& o)
         else if (a == "-ignoremips") o.ddsRead |= DDS_FLAGS_IGNORE_MIPS;
         else if (a == "-xlum") o.ddsRead |= DDS_FLAGS_EXPAND_LUMINANCE;
         else if (a == "-tga20") o.tga20 = true;
+        else if (a == "-info") o.info = true;
         else if (a == "-dx10") o.dx10 = true;
         else if (a == "-dx9") o.dx9 = true;
         else if (a == "-px") o.prefix = next();
@@ -258,6 +259,7 @@ bool Parse(int argc, char** argv, Options& o)
     if (o.pmalpha && o.demul) { std::fprintf(stderr, "-pmalpha and -alpha exclude each other\n"); return false; }
     if (o.dx10 && o.dx9) { std::fprintf(stderr, "-dx10 and -dx9 exclude each other\n"); return false; }
     if (o.gpus.empty()) o.gpus.assign(1, 0);
+    if (o.info) return !o.inputs.empty();
     return !o.inputs.empty() && !o.out.empty();
 }
 
@@ -454,10 +456,45 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
 }
 }
 
+// -info: what a file holds (the header only; no GPU involved) - the "info" command of the reference's texdiag in one line per file
+int PrintInfo(const Options& o)
+{
+    int failures = 0;
+    for (const std::string& f : o.inputs)
+    {
+        auto hasExt = [&](const char* ext) { const size_t n = std::strlen(ext); return f.size() > n && !strcasecmp(f.c_str() + f.size() - n, ext); };
+        TexMetadata m;
+        const HRESULT hr = hasExt(".hdr") ? GetMetadataFromHDRFile(f.c_str(), m) : hasExt(".tga") ? GetMetadataFromTGAFile(f.c_str(), TGA_FLAGS_NONE, m)
+                                                                                                   : GetMetadataFromDDSFile(f.c_str(), DDS_FLAGS(o.ddsRead), m);
+        if (FAILED(hr)) { std::printf("%s: FAILED (%08X)\n", f.c_str(), unsigned(hr)); ++failures; continue; }
+        const char* name = "";
+        for (const Name& n : kFormats) if (n.value == uint32_t(m.format)) { name = n.name; break; }
+        static const char* const alpha[] = { "unknown", "straight", "premultiplied", "opaque", "custom" };
+        size_t images = 0, bytes = 0;
+        for (size_t level = 0, w = m.width, h = m.height, d = m.depth; level < m.mipLevels; ++level)
+        {
+            size_t rp = 0, sp = 0;
+            if (SUCCEEDED(ComputePitch(m.format, w, h, rp, sp))) bytes += sp * d * (m.dimension == TEX_DIMENSION_TEXTURE3D ? 1 : m.arraySize);
+            images += d * (m.dimension == TEX_DIMENSION_TEXTURE3D ? 1 : m.arraySize);
+            if (w > 1) w >>= 1;
+            if (h > 1) h >>= 1;
+            if (d > 1) d >>= 1;
+        }
+        std::printf("%s: %zux%zu", f.c_str(), m.width, m.height);
+        if (m.dimension == TEX_DIMENSION_TEXTURE3D) std::printf("x%zu", m.depth);
+        std::printf(" %s mips %zu items %zu format %u %s bpp %zu alpha %s%s images %zu bytes %zu%s\n",
+                    m.dimension == TEX_DIMENSION_TEXTURE1D ? "1D" : m.dimension == TEX_DIMENSION_TEXTURE3D ? "3D" : (m.IsCubemap() ? "cube" : "2D"),
+                    m.mipLevels, m.arraySize, unsigned(m.format), name, BitsPerPixel(m.format), alpha[std::min<uint32_t>(m.GetAlphaMode(), 4)],
+                    IsSRGB(m.format) ? " sRGB" : "", images, bytes, IsSupportedOnDevice(m.format) ? "" : " (container only: no GPU path for this format)");
+    }
+    return failures ? 1 : 0;
+}
+
 int main(int argc, char** argv)
 {
     Options o;
     if (!Parse(argc, argv, o)) return usage();
+    if (o.info) return PrintInfo(o);
     if (!o.nologo) std::printf("dxtexconv: DirectXTex pipeline on MI355X (gfx950)\n");
 
     // Image-per-GPU sharding: files are independent, so worker k takes inputs k, k + n, k + 2n, ... on its own
