@@ -565,6 +565,11 @@ HRESULT Device::Create(int hipDevice) noexcept
     if (m_ctx) { dxtex_ctx_destroy(m_ctx); m_ctx = nullptr; }
     return dxtex_ctx_create(hipDevice, &m_ctx);
 }
+HRESULT Device::Prepare(size_t width, size_t height, DXGI_FORMAT srcFormat, DXGI_FORMAT bcFormat, TEX_COMPRESS_FLAGS flags, size_t count) noexcept
+{
+    if (!m_ctx) return E_POINTER;
+    return dxtex_ctx_prepare(m_ctx, width, height, int32_t(srcFormat), int32_t(bcFormat), uint32_t(flags), count, nullptr);
+}
 const char* Device::LastError() const noexcept { return m_ctx ? dxtex_ctx_last_error(m_ctx) : "no device"; }
 
 // ---- Compress (CompressEx, DirectXTexCompress.cpp:664-850) --------------------------------------------------------------------

@@ -206,6 +206,9 @@ public:
     Device(const Device&) = delete;
     Device& operator=(const Device&) = delete;
     HRESULT Create(int hipDevice) noexcept;          // E_FAIL when no gfx950 device is visible
+    // GPUCompressBC::Prepare's role (BCDirectCompute.h:28): size the encoder's scratch and staging for `count` images of this
+    // shape now, so that the Compress calls that follow allocate nothing. Optional.
+    HRESULT Prepare(size_t width, size_t height, DXGI_FORMAT srcFormat, DXGI_FORMAT bcFormat, TEX_COMPRESS_FLAGS flags, size_t count) noexcept;
     explicit operator bool() const noexcept { return m_ctx != nullptr; }
     dxtex_ctx* Get() const noexcept { return m_ctx; }
     const char* LastError() const noexcept;

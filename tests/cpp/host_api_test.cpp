@@ -77,15 +77,15 @@ static int cpu_checks()
     }
     // copies of caller images: array, cubemap, volume, relabelling (DirectXTexImage.cpp:534-740)
     {
-        std::vector<uint8_t> a(6 * 4 * 4 * 4);
-        for (size_t i = 0; i < a.size(); ++i) a[i] = uint8_t(i * 13 + 5);
+        std::vector<uint8_t> texels(6 * 4 * 4 * 4);
+        for (size_t i = 0; i < texels.size(); ++i) texels[i] = uint8_t(i * 13 + 5);
         std::vector<Image> six(6);
-        for (size_t i = 0; i < 6; ++i) { six[i].width = 4; six[i].height = 4; six[i].format = DXGI_FORMAT_R8G8B8A8_UNORM; six[i].rowPitch = 16; six[i].slicePitch = 64; six[i].pixels = a.data() + i * 64; }
+        for (size_t i = 0; i < 6; ++i) { six[i].width = 4; six[i].height = 4; six[i].format = DXGI_FORMAT_R8G8B8A8_UNORM; six[i].rowPitch = 16; six[i].slicePitch = 64; six[i].pixels = texels.data() + i * 64; }
         ScratchImage s;
-        CHECK(s.InitializeArrayFromImages(six.data(), 6) == S_OK && s.GetMetadata().arraySize == 6 && !s.GetMetadata().IsCubemap() && std::memcmp(s.GetPixels(), a.data(), a.size()) == 0);
-        CHECK(s.InitializeCubeFromImages(six.data(), 6) == S_OK && s.GetMetadata().IsCubemap() && s.GetImage(0, 5, 0)->pixels[0] == a[5 * 64]);
+        CHECK(s.InitializeArrayFromImages(six.data(), 6) == S_OK && s.GetMetadata().arraySize == 6 && !s.GetMetadata().IsCubemap() && std::memcmp(s.GetPixels(), texels.data(), texels.size()) == 0);
+        CHECK(s.InitializeCubeFromImages(six.data(), 6) == S_OK && s.GetMetadata().IsCubemap() && s.GetImage(0, 5, 0)->pixels[0] == texels[5 * 64]);
         CHECK(s.InitializeCubeFromImages(six.data(), 5) == E_INVALIDARG);
-        CHECK(s.Initialize3DFromImages(six.data(), 4) == S_OK && s.GetMetadata().depth == 4 && s.GetMetadata().dimension == TEX_DIMENSION_TEXTURE3D && s.GetImage(0, 0, 3)->pixels[1] == a[3 * 64 + 1]);
+        CHECK(s.Initialize3DFromImages(six.data(), 4) == S_OK && s.GetMetadata().depth == 4 && s.GetMetadata().dimension == TEX_DIMENSION_TEXTURE3D && s.GetImage(0, 0, 3)->pixels[1] == texels[3 * 64 + 1]);
         six[2].width = 3;
         CHECK(s.InitializeArrayFromImages(six.data(), 6) == E_FAIL);
         six[2].width = 4; six[1].pixels = nullptr;
@@ -125,6 +125,7 @@ static int cpu_checks()
     ScratchImage out;
     Image img = *si.GetImage(0, 0, 0);
     CHECK(Compress(none, img, DXGI_FORMAT_BC1_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, out) == E_POINTER);
+    CHECK(none.Prepare(64, 64, DXGI_FORMAT_R8G8B8A8_UNORM, DXGI_FORMAT_BC7_UNORM, TEX_COMPRESS_DEFAULT, 1) == E_POINTER);
     {
         size_t calls = 0;
         const CompressOptions co = { TEX_COMPRESS_DEFAULT, TEX_THRESHOLD_DEFAULT, TEX_ALPHA_WEIGHT_DEFAULT };
