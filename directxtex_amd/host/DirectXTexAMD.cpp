@@ -319,6 +319,46 @@ bool CalculateMipLevels(size_t width, size_t height, size_t& mipLevels) noexcept
     return true;
 }
 
+// A 64 KiB tile holds 2^k texels (or 4x4 blocks); the k doublings go round the dimensions, width first. That reproduces the
+// table of standard tile shapes (DirectXTexUtil.cpp:1259-1405).
+HRESULT ComputeTileShape(DXGI_FORMAT fmt, TEX_DIMENSION dimension, TileShape& tiling) noexcept
+{
+    tiling = TileShape{ 0, 0, 0 };
+    if (IsVideo(fmt) || IsPacked(fmt)) return E_INVALIDARG;
+    const size_t bpp = BitsPerPixel(fmt);
+    if (!bpp || bpp == 1 || bpp == 24 || bpp == 96) return E_INVALIDARG;
+    const bool compressed = IsCompressed(fmt);
+    if (dimension == TEX_DIMENSION_TEXTURE1D)
+    {
+        if (compressed) return E_INVALIDARG;
+        tiling = TileShape{ 65536 * 8 / bpp, 1, 1 };
+        return S_OK;
+    }
+    if (dimension != TEX_DIMENSION_TEXTURE2D && dimension != TEX_DIMENSION_TEXTURE3D) return E_INVALIDARG;
+    size_t unitBytes = compressed ? BytesPerBlock(fmt) : 1;          // a block, or a texel rounded up to a power of two of bytes
+    if (!compressed) { while (unitBytes * 8 < bpp) unitBytes <<= 1; if (unitBytes > 16) return E_INVALIDARG; }
+    unsigned k = 0;
+    while ((size_t(65536) >> (k + 1)) >= unitBytes) ++k;            // 65536 / unitBytes = 2^k
+    const unsigned dims = (dimension == TEX_DIMENSION_TEXTURE3D) ? 3 : 2;
+    size_t e[3] = { 1, 1, 1 };
+    for (unsigned i = 0; i < k; ++i) e[(i % dims)] <<= 1;             // round-robin: width gets the extra doubling first
+    // the doublings were dealt lowest-first; what matters is how many each dimension received
+    const size_t unit = compressed ? 4 : 1;
+    tiling = TileShape{ e[0] * unit, e[1] * unit, e[2] };
+    return S_OK;
+}
+
+uint32_t TexMetadata::CalculateSubresource(size_t mip, size_t item) const noexcept { return CalculateSubresource(mip, item, 0); }
+
+uint32_t TexMetadata::CalculateSubresource(size_t mip, size_t item, size_t plane) const noexcept
+{
+    if (mip >= mipLevels) return uint32_t(-1);
+    if (dimension == TEX_DIMENSION_TEXTURE1D || dimension == TEX_DIMENSION_TEXTURE2D)
+        return (item < arraySize) ? uint32_t(mip + item * mipLevels + plane * mipLevels * arraySize) : uint32_t(-1);
+    if (dimension == TEX_DIMENSION_TEXTURE3D) return (item == 0) ? uint32_t(mip + plane * mipLevels) : uint32_t(-1);       // no arrays of volumes
+    return uint32_t(-1);
+}
+
 size_t TexMetadata::ComputeIndex(size_t mip, size_t item, size_t slice) const noexcept
 {
     if (mip >= mipLevels) return size_t(-1);

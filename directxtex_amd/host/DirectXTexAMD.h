@@ -123,7 +123,10 @@ enum CP_FLAGS : uint32_t
 };
 HRESULT ComputePitch(DXGI_FORMAT fmt, size_t width, size_t height, size_t& rowPitch, size_t& slicePitch, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
 size_t ComputeScanlines(DXGI_FORMAT fmt, size_t height) noexcept;
+// the standard shape of a 64 KiB tile of a tiled resource (DirectXTexUtil.cpp:1251-1405)
+struct TileShape { size_t width, height, depth; };
 // CalculateMipLevels (DirectXTexMipmaps.cpp:40-69): mipLevels == 0 asks for the full chain
+HRESULT ComputeTileShape(DXGI_FORMAT fmt, TEX_DIMENSION dimension, TileShape& tiling) noexcept;
 bool CalculateMipLevels(size_t width, size_t height, size_t& mipLevels) noexcept;
 bool CalculateMipLevels3D(size_t width, size_t height, size_t depth, size_t& mipLevels) noexcept;
 
@@ -142,6 +145,9 @@ struct TexMetadata
     TEX_DIMENSION dimension = TEX_DIMENSION_TEXTURE2D;
     // index = item * mipLevels + mip for 1D / 2D textures (DirectXTexUtil.cpp:1695-1740)
     size_t ComputeIndex(size_t mip, size_t item, size_t slice) const noexcept;
+    // D3D11CalcSubresource / D3D12CalcSubresource (DirectXTexUtil.cpp:1744-1806); uint32_t(-1) when out of range
+    uint32_t CalculateSubresource(size_t mip, size_t item) const noexcept;
+    uint32_t CalculateSubresource(size_t mip, size_t item, size_t plane) const noexcept;
     bool IsVolumemap() const noexcept { return dimension == TEX_DIMENSION_TEXTURE3D; }
     bool IsCubemap() const noexcept { return (miscFlags & TEX_MISC_TEXTURECUBE) != 0; }
     // the alpha mode lives in the low three bits of miscFlags2 (DirectXTex.h:174-207)

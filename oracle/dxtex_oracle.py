@@ -66,6 +66,8 @@ def _load_ref():
         lib.dxtex_ref_compute_pitch_ex.restype = ctypes.c_int
         lib.dxtex_ref_format_facts2.argtypes = [ctypes.c_int, szp]
         lib.dxtex_ref_format_facts2.restype = ctypes.c_int
+        lib.dxtex_ref_tile_shape.argtypes = [ctypes.c_int, ctypes.c_uint32, szp]
+        lib.dxtex_ref_tile_shape.restype = ctypes.c_int
         lib.dxtex_ref_load_hdr.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64), vp, sz, i32p]
         lib.dxtex_ref_load_hdr.restype = ctypes.c_int64
         lib.dxtex_ref_save_hdr.argtypes = [vp, sz, sz, ctypes.c_int, sz, vp, sz, i32p]
@@ -548,3 +550,10 @@ def ref_save_tga(pixels, width, height, fmt, row_pitch, flags=0, alpha_mode=-1):
     if n < 0:
         return hr.value & 0xFFFFFFFF, None
     return hr.value & 0xFFFFFFFF, out[:n].copy()
+
+
+def ref_tile_shape(fmt, dimension):
+    """DirectX::ComputeTileShape -> (hr, width, height, depth)."""
+    out = (ctypes.c_size_t * 3)()
+    hr = _load_ref().dxtex_ref_tile_shape(fmt, dimension, out)
+    return hr & 0xFFFFFFFF, int(out[0]), int(out[1]), int(out[2])

@@ -405,4 +405,12 @@ extern "C"
         memcpy(out, blob.GetBufferPointer(), blob.GetBufferSize());
         return int64_t(blob.GetBufferSize());
     }
+
+    int dxtex_ref_tile_shape(int fmt, uint32_t dimension, size_t* whd)
+    {
+        TileShape t = {};
+        const HRESULT hr = ComputeTileShape(DXGI_FORMAT(fmt), TEX_DIMENSION(dimension), t);
+        whd[0] = t.width; whd[1] = t.height; whd[2] = t.depth;
+        return int(hr);
+    }
 }

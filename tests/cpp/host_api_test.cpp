@@ -56,6 +56,11 @@ static int cpu_checks()
     CHECK(v3.GetImage(0, 0, 3)->pixels == v3.GetPixels() + 3 * 16 * 8 * 4 && v3.GetImage(1, 0, 0)->pixels == v3.GetPixels() + 4 * 16 * 8 * 4);
     CHECK(v3.GetImage(1, 0, 1)->width == 8 && v3.GetImage(1, 0, 2) == nullptr && v3.GetImage(4, 0, 0)->width == 1 && v3.GetImage(0, 1, 0) == nullptr);
     CHECK(v3.GetMetadata().ComputeIndex(2, 0, 0) == 6 && v3.GetMetadata().ComputeIndex(3, 0, 0) == 7);
+    {
+        TexMetadata arr; arr.width = 20; arr.height = 10; arr.depth = 1; arr.arraySize = 3; arr.mipLevels = 5; arr.format = DXGI_FORMAT_R8G8B8A8_UNORM;
+        CHECK(arr.CalculateSubresource(2, 1) == 7 && arr.CalculateSubresource(2, 1, 1) == 7 + 15 && arr.CalculateSubresource(5, 0) == uint32_t(-1) && arr.CalculateSubresource(0, 3) == uint32_t(-1));
+    }
+    CHECK(v3.GetMetadata().CalculateSubresource(3, 0) == 3 && v3.GetMetadata().CalculateSubresource(3, 0, 2) == 13 && v3.GetMetadata().CalculateSubresource(0, 1) == uint32_t(-1));
     lv = 0; CHECK(CalculateMipLevels3D(4, 2, 32, lv) && lv == 6);
     lv = 7; CHECK(!CalculateMipLevels3D(4, 2, 32, lv));
     CHECK(v3.Initialize3D(DXGI_FORMAT_R8G8B8A8_UNORM, 4, 4, 0, 1) == E_INVALIDARG);
@@ -428,6 +433,12 @@ static int formats()
         std::printf("more %u %zu %zu %u %u %u %u %u %d\n", f, BitsPerColor(fmt), BytesPerBlock(fmt), unsigned(MakeSRGB(fmt)), unsigned(MakeLinear(fmt)), unsigned(MakeTypeless(fmt)),
                     unsigned(MakeTypelessUNORM(fmt)), unsigned(MakeTypelessFLOAT(fmt)),
                     (IsVideo(fmt) ? 1 : 0) | (IsDepthStencil(fmt) ? 2 : 0) | (IsBGR(fmt) ? 4 : 0) | (IsTypeless(fmt, true) ? 8 : 0) | (IsTypeless(fmt, false) ? 16 : 0));
+        for (uint32_t dim = 1; dim <= 5; ++dim)
+        {
+            TileShape ts;
+            const HRESULT hr = ComputeTileShape(fmt, TEX_DIMENSION(dim), ts);
+            std::printf("tile %u %u %08x %zu %zu %zu\n", f, dim, unsigned(hr), ts.width, ts.height, ts.depth);
+        }
         for (const auto& d : dims)
             for (uint32_t cp : cps)
             {

@@ -121,6 +121,9 @@ def test_container_format_tables_match_the_reference():
         p = line.split()
         if p[0] == "fmt":
             assert (int(p[2]), int(p[3])) == oracle.ref_format_facts(int(p[1])), line
+        elif p[0] == "tile":
+            if int(p[1]) <= 191:
+                assert (int(p[3], 16), int(p[4]), int(p[5]), int(p[6])) == oracle.ref_tile_shape(int(p[1]), int(p[2])), line
         elif p[0] == "more":
             if int(p[1]) <= 191:           # (the reference's predicates assert on ids past 191)
                 vals, bits = oracle.ref_format_facts2(int(p[1]))
