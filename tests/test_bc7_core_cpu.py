@@ -1,0 +1,32 @@
+"""The BC7 and BC6H encoders' cores on the host. The BC7 encoder's core (directxtex_amd/csrc/bc7_core.h: seeds, RoughMSE, Refine with PerturbOne / Exhaustive, block
+emission, mode choice) compiled for the HOST and run next to the reference's D3DX_BC7::Encode (compiled in place) on random
+tiles - flat, gradients, noise of several amplitudes, opaque and with alpha. It checks the shared logic where there is no GPU;
+the kernels built on it are checked on the GPU (tests/test_bc7_parity.py)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "bc7_core_check")
+
+
+@pytest.mark.parametrize("seed", [7, 11, 12345])
+def test_bc7_core_on_the_host_matches_the_reference(seed):
+    if not os.path.exists(EXE):
+        pytest.fail(f"{EXE} missing: run __graft_entry__.build() where /root/reference exists")
+    r = subprocess.run([EXE, "400", str(seed)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 of 400 tiles differ" in r.stdout, r.stdout[-3000:]
+
+
+BC6H_EXE = os.path.join(ROOT, "oracle", "_ref", "bc6h_core_check")
+
+
+@pytest.mark.parametrize("seed", [5, 99])
+def test_bc6h_core_on_the_host_matches_the_reference(seed):
+    """bc6h_core.h (half -> integer texels, region fits, quantisation per mode, the delta transform and its fit test, PerturbOne,
+    block emission) in the order the kernels use it, against D3DX_BC6H::Encode for unsigned and signed targets."""
+    if not os.path.exists(BC6H_EXE):
+        pytest.fail(f"{BC6H_EXE} missing: run __graft_entry__.build() where /root/reference exists")
+    r = subprocess.run([BC6H_EXE, "150", str(seed)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "0 of 300 encodes differ" in r.stdout, r.stdout[-3000:]

@@ -1,4 +1,5 @@
-// DEVELOPMENT TOOL (not part of the product, not part of the test suite): runs the BC6H core of
+// TEST INFRASTRUCTURE / DEVELOPMENT TOOL (not part of the product; built by oracle/Makefile into oracle/_ref/bc6h_core_check and
+// run by tests/test_bc7_core_cpu.py): runs the BC6H core of
 // directxtex_amd/csrc/bc6h_core.h on the HOST, in the order the kernels of bc6h_encode.hip use it, next to the
 // reference's D3DX_BC6H::Encode compiled in place, and compares the emitted blocks.
 // Build + run:  tools/run_bc6h_debug.sh [ntiles] [seed]

@@ -1,4 +1,5 @@
-// DEVELOPMENT TOOL (not part of the product, not part of the test suite): runs the BC7 core of
+// TEST INFRASTRUCTURE / DEVELOPMENT TOOL (not part of the product; built by oracle/Makefile into oracle/_ref/bc7_core_check and
+// run by tests/test_bc7_core_cpu.py): runs the BC7 core of
 // directxtex_amd/csrc/bc7_core.h on the HOST, next to the reference's D3DX_BC7 class compiled in place
 // with its private members exposed, and compares them stage by stage (seed / RoughMSE / Refine / final
 // block). Build + run:  tools/run_bc7_debug.sh [ntiles] [seed]
