@@ -11,11 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "oracle", "_ref", "bc7_core_check")
 
 
-@pytest.mark.parametrize("seed", [7, 11, 12345])
-def test_bc7_core_on_the_host_matches_the_reference(seed):
+@pytest.mark.parametrize("seed,flags", [(7, 0), (11, 0), (12345, 0), (21, 0x80000), (22, 0x80000), (23, 0x100000), (24, 0x180000)])
+def test_bc7_core_on_the_host_matches_the_reference(seed, flags):
+    """flags: BC_FLAGS (0x80000 BC7_USE_3SUBSETS adds modes 0 and 2, 0x100000 BC7_QUICK leaves mode 6 only)."""
     if not os.path.exists(EXE):
         pytest.fail(f"{EXE} missing: run __graft_entry__.build() where /root/reference exists")
-    r = subprocess.run([EXE, "400", str(seed)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([EXE, "400", str(seed), hex(flags)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 of 400 tiles differ" in r.stdout, r.stdout[-3000:]
 
 

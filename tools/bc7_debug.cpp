@@ -84,6 +84,68 @@ static Cand refine2_one(const HostBlock& b, uint32_t shape, int rank)
     return c;
 }
 
+// modes 0 and 2: three subsets (D3DX_BC7::Encode with BC_FLAGS_USE_3SUBSETS, BC6HBC7.cpp:2805-2815)
+static uint32_t mask3(uint32_t shape, uint32_t region)
+{
+    const uint32_t bits = kPart3Bits[shape];
+    uint32_t m = 0;
+    for (int i = 0; i < 16; ++i) if (((bits >> (2 * i)) & 3u) == region) m |= 1u << i;
+    return m;
+}
+
+static void seeds3(const HostBlock& b, uint32_t shape, uint32_t region, Region& rg, uint32_t& A, uint32_t& B)
+{
+    const uint32_t m = mask3(shape, region);
+    region_init(rg, b.ldr, m);
+    if (rg.np == 1) { A = b.ldr[rg.pos(0)]; B = A; }
+    else if (rg.np == 2) { A = b.ldr[rg.pos(0)]; B = b.ldr[rg.pos(1)]; }
+    else seed_endpoints<true>(b.f, m, A, B);
+}
+
+template<int MODE>
+static Cand refine3_one(const HostBlock& b, uint32_t shape, int rank)
+{
+    SubsetResult r[3];
+    const uint32_t anchor[3] = { 0, uint32_t(kAnchor3[shape] & 15), uint32_t(kAnchor3[shape] >> 4) };
+    int orgTot = 0, optTot = 0;
+    for (uint32_t region = 0; region < 3; ++region)
+    {
+        Region rg; uint32_t A, B;
+        seeds3(b, shape, region, rg, A, B);
+        refine_subset<MODE, 0>(rg, A, B, anchor[region], r[region]);
+        orgTot += r[region].orgErr; optTot += r[region].optErr;
+    }
+    const bool useOpt = optTot < orgTot;
+    Cand c; c.valid = true;
+    c.err = uint32_t(useOpt ? optTot : orgTot);
+    c.ord = MODE * 128 + rank;
+    uint32_t epA[3], epB[3]; uint64_t idx = 0;
+    for (int s = 0; s < 3; ++s) { epA[s] = useOpt ? r[s].optA : r[s].orgA; epB[s] = useOpt ? r[s].optB : r[s].orgB; idx |= useOpt ? r[s].optIdx1 : r[s].orgIdx1; }
+    emit_block<MODE>(shape, 0, 0, epA, epB, idx, 0, anchor, c.lo, c.hi);
+    return c;
+}
+
+// the `count` best of the first `nshapes` 3-subset shapes by rough error with IDXBITS-bit indices (stable: ties keep shape order)
+template<int IDXBITS>
+static void rough_list3(const HostBlock& b, int nshapes, int count, uint32_t* list)
+{
+    int e[64]; uint32_t sh[64];
+    for (int s = 0; s < nshapes; ++s)
+    {
+        e[s] = 0; sh[s] = uint32_t(s);
+        for (uint32_t region = 0; region < 3; ++region)
+        {
+            Region rg; uint32_t A, B;
+            seeds3(b, uint32_t(s), region, rg, A, B);
+            e[s] += rough_error<IDXBITS, 0>(rg, A, B);
+        }
+    }
+    for (int i = 0; i < count; ++i)
+        for (int j = i + 1; j < nshapes; ++j)
+            if (e[i] > e[j]) { std::swap(e[i], e[j]); std::swap(sh[i], sh[j]); }
+    for (int i = 0; i < count; ++i) list[i] = sh[i];
+}
+
 template<int MODE, int IM>
 static Cand refine1_one(const HostBlock& b, uint32_t rot)
 {
@@ -166,6 +228,9 @@ int main(int argc, char** argv)
 {
     const int ntiles = argc > 1 ? atoi(argv[1]) : 200;
     g_rng = argc > 2 ? uint32_t(atoi(argv[2])) : 12345u;
+    // optional third argument: BC_FLAGS (0x80000 BC7_USE_3SUBSETS, 0x100000 BC7_QUICK)
+    const uint32_t bcFlags = argc > 3 ? uint32_t(strtoul(argv[3], nullptr, 0)) : 0u;
+    const bool use3 = (bcFlags & 0x80000u) != 0, quick = (bcFlags & 0x100000u) != 0;
     int nbad = 0;
     for (int t = 0; t < ntiles; ++t)
     {
@@ -186,19 +251,30 @@ int main(int argc, char** argv)
         alignas(16) HDRColorA pIn[16];
         memcpy(pIn, hb.f, sizeof(pIn));
         alignas(16) uint8_t refBlk[16];
-        reinterpret_cast<D3DX_BC7*>(refBlk)->Encode(0, pIn);
+        reinterpret_cast<D3DX_BC7*>(refBlk)->Encode(bcFlags, pIn);
 
         // ours
         int e3[64], e2[64]; uint32_t l3[16], l2[16];
         rough_lists(hb, e3, e2, l3, l2);
         Cand best; best.valid = false;
         Cand perMode[8]; for (auto& c : perMode) c.valid = false;
-        for (int i = 0; i < 16; ++i) better(perMode[1], refine2_one<1>(hb, l3[i], i));
-        for (int i = 0; i < 16; ++i) better(perMode[3], refine2_one<3>(hb, l2[i], i));
-        for (uint32_t r = 0; r < 4; ++r) { better(perMode[4], refine1_one<4, 0>(hb, r)); better(perMode[4], refine1_one<4, 1>(hb, r)); }
-        for (uint32_t r = 0; r < 4; ++r) better(perMode[5], refine1_one<5, 0>(hb, r));
+        if (!quick)
+        {
+            if (use3)
+            {
+                uint32_t m0[4], m2[16];
+                rough_list3<3>(hb, 16, 4, m0);            // mode 0: 16 shapes, 3-bit indices, the best max(1, 16 / 4)
+                rough_list3<2>(hb, 64, 16, m2);           // mode 2: 64 shapes, 2-bit indices, the best 16
+                for (int i = 0; i < 4; ++i) better(perMode[0], refine3_one<0>(hb, m0[i], i));
+                for (int i = 0; i < 16; ++i) better(perMode[2], refine3_one<2>(hb, m2[i], i));
+            }
+            for (int i = 0; i < 16; ++i) better(perMode[1], refine2_one<1>(hb, l3[i], i));
+            for (int i = 0; i < 16; ++i) better(perMode[3], refine2_one<3>(hb, l2[i], i));
+            for (uint32_t r = 0; r < 4; ++r) { better(perMode[4], refine1_one<4, 0>(hb, r)); better(perMode[4], refine1_one<4, 1>(hb, r)); }
+            for (uint32_t r = 0; r < 4; ++r) better(perMode[5], refine1_one<5, 0>(hb, r));
+        }
         better(perMode[6], refine1_one<6, 0>(hb, 0));
-        if (hb.hasAlpha) for (int i = 0; i < 16; ++i) better(perMode[7], refine2_one<7>(hb, l2[i], i));
+        if (!quick && hb.hasAlpha) for (int i = 0; i < 16; ++i) better(perMode[7], refine2_one<7>(hb, l2[i], i));
         for (int m = 0; m < 8; ++m) better(best, perMode[m]);
 
         uint64_t rlo, rhi; memcpy(&rlo, refBlk, 8); memcpy(&rhi, refBlk + 8, 8);
