@@ -18,3 +18,13 @@ def test_lower_bounds_hold_on_random_palettes():
     print(r.stdout)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " 0 violations" in r.stdout
+
+
+def test_pass_and_segment_construction_invariants():
+    """search_common.h: build_passes cuts the block list of an image set into passes and per-image segments, seg_of finds a
+    pass-local block's image again. 3 000 random image lists and pass sizes: every block exactly once, in order, lookups right."""
+    exe = os.path.join(ROOT, "directxtex_amd", "lib", "passes_check")
+    if not os.path.exists(exe):
+        pytest.fail(f"{exe} missing: run __graft_entry__.build()")
+    r = subprocess.run([exe, "3000"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "blocks checked" in r.stdout, r.stdout[-2000:]
