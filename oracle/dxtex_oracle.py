@@ -68,6 +68,8 @@ def _load_ref():
         lib.dxtex_ref_format_facts2.restype = ctypes.c_int
         lib.dxtex_ref_tile_shape.argtypes = [ctypes.c_int, ctypes.c_uint32, szp]
         lib.dxtex_ref_tile_shape.restype = ctypes.c_int
+        lib.dxtex_ref_triangle_filter.argtypes = [sz, sz, ctypes.c_int, vp, vp, vp, sz]
+        lib.dxtex_ref_triangle_filter.restype = ctypes.c_int64
         lib.dxtex_ref_load_hdr.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64), vp, sz, i32p]
         lib.dxtex_ref_load_hdr.restype = ctypes.c_int64
         lib.dxtex_ref_save_hdr.argtypes = [vp, sz, sz, ctypes.c_int, sz, vp, sz, i32p]
@@ -557,3 +559,12 @@ def ref_tile_shape(fmt, dimension):
     out = (ctypes.c_size_t * 3)()
     hr = _load_ref().dxtex_ref_tile_shape(fmt, dimension, out)
     return hr & 0xFFFFFFFF, int(out[0]), int(out[1]), int(out[2])
+
+
+def ref_triangle_filter(source, dest, wrap):
+    """The reference's CreateTriangleFilter (filters.h:249-419) -> arrays (src, dst, weight bits as uint32), source-major."""
+    cap = 4 * (source + dest) + 64
+    s = np.zeros(cap, np.uint32); d = np.zeros(cap, np.uint32); w = np.zeros(cap, np.float32)
+    n = _load_ref().dxtex_ref_triangle_filter(source, dest, 1 if wrap else 0, s.ctypes.data, d.ctypes.data, w.ctypes.data, cap)
+    assert n >= 0, n
+    return s[:n].copy(), d[:n].copy(), w[:n].view(np.uint32).copy()

@@ -4,6 +4,7 @@
 // Never linked into, imported by, or called from the product library.
 #include "DirectXTexP.h"
 #include "BC.h"
+#include "filters.h"
 #include <omp.h>
 #include <vector>
 #include <algorithm>
@@ -412,5 +413,26 @@ extern "C"
         const HRESULT hr = ComputeTileShape(DXGI_FORMAT(fmt), TEX_DIMENSION(dimension), t);
         whd[0] = t.width; whd[1] = t.height; whd[2] = t.depth;
         return int(hr);
+    }
+
+    // The reference's CreateTriangleFilter (filters.h:249-419) flattened: for every source texel, in order, its (destination, weight)
+    // entries. Returns the number of entries (-1 on failure, -2 if the arrays are too small).
+    int64_t dxtex_ref_triangle_filter(size_t source, size_t dest, int wrap, uint32_t* srcOf, uint32_t* dstOf, float* weightOf, size_t capacity)
+    {
+        std::unique_ptr<Filters::Filter> tf;
+        if (FAILED(Filters::CreateTriangleFilter(source, dest, wrap != 0, tf)) || !tf) return -1;
+        size_t n = 0, u = 0;
+        const Filters::FilterFrom* pFrom = tf->from;
+        auto pEnd = reinterpret_cast<const Filters::FilterFrom*>(reinterpret_cast<const uint8_t*>(tf.get()) + tf->sizeInBytes);
+        for (; pFrom < pEnd; ++u)
+        {
+            for (size_t j = 0; j < pFrom->count; ++j, ++n)
+            {
+                if (n >= capacity) return -2;
+                srcOf[n] = uint32_t(u); dstOf[n] = uint32_t(pFrom->to[j].u); weightOf[n] = pFrom->to[j].weight;
+            }
+            pFrom = reinterpret_cast<const Filters::FilterFrom*>(reinterpret_cast<const uint8_t*>(pFrom) + pFrom->sizeInBytes);
+        }
+        return (u == source) ? int64_t(n) : -1;
     }
 }

@@ -5,6 +5,7 @@ mathematics the pruning rests on; that pruning leaves the encoder's OUTPUT uncha
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,3 +29,32 @@ def test_pass_and_segment_construction_invariants():
         pytest.fail(f"{exe} missing: run __graft_entry__.build()")
     r = subprocess.run([exe, "3000"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "blocks checked" in r.stdout, r.stdout[-2000:]
+
+
+def test_triangle_filter_tables_match_the_reference():
+    """The gather lists the host builds for the triangle filter (triangle_filter.h) against the reference's own
+    CreateTriangleFilter (filters.h:249-419, compiled in place): same entries, same fp32 weight bits, in the reference's
+    accumulation order - for mip-chain steps of odd sizes, arbitrary resizes up and down, 1-texel axes, clamp and wrap."""
+    import oracle
+    exe = os.path.join(ROOT, "directxtex_amd", "lib", "triangle_check")
+    if not os.path.exists(exe):
+        pytest.fail(f"{exe} missing: run __graft_entry__.build()")
+    rng = np.random.default_rng(31)
+    triples = [(s, max(1, s >> 1), w) for s in (1, 2, 3, 5, 7, 9, 17, 33, 100, 127, 255, 1000, 4097) for w in (0, 1)]
+    triples += [(int(rng.integers(1, 600)), int(rng.integers(1, 600)), int(rng.integers(0, 2))) for _ in range(300)]
+    triples += [(1, 64, 0), (64, 1, 1), (3, 1000, 0), (1000, 3, 1), (2, 2, 0), (8192, 4096, 0)]
+    args = [str(v) for t in triples for v in t]
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0
+    rows = r.stdout.splitlines()
+    assert len(rows) == len(triples)
+    entries = 0
+    for (source, dest, wrap), row in zip(triples, rows):
+        p = row.split()
+        ours = [tuple(int(x) for x in e.split(":")) for e in p[1:]]                   # (dst, src, weight bits) in gather order
+        s, d, w = oracle.ref_triangle_filter(source, dest, bool(wrap))
+        order = np.argsort(d, kind="stable")                                          # per destination, keeping the source-major order
+        ref = list(zip(d[order].tolist(), s[order].tolist(), w[order].tolist()))
+        assert int(p[0]) == len(ref) and ours == ref, (source, dest, wrap)
+        entries += len(ref)
+    assert entries > 100000
