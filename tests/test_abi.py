@@ -46,3 +46,13 @@ def test_no_context_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(dx.DxtexError):
         dx.Context(0)
+
+
+def test_header_is_plain_c():
+    """include/dxtex_amd.h is the FFI boundary: it must compile as C99 (and as C++11) on its own, warnings as errors."""
+    import subprocess
+    header = os.path.join(ROOT, "include", "dxtex_amd.h")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", header],
+                ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", header]):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
