@@ -56,3 +56,22 @@ def test_header_is_plain_c():
                 ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", header]):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
         assert r.returncode == 0, r.stderr
+
+
+def test_integration_binding_compiles_against_the_reference_headers(tmp_path):
+    """The reference-side binding shown in INTEGRATION.md (DirectXTexCompressMI355X.cpp) is real code: extracted from the document
+    and compiled against the reference's own headers (in place, with the oracle's stand-ins for its un-vendored dependencies)
+    and include/dxtex_amd.h. Needs /root/reference; skipped where it does not exist (the GPU box)."""
+    import subprocess
+    ref = "/root/reference/DirectXTex"
+    if not os.path.isdir(ref):
+        pytest.skip("/root/reference absent")
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```cpp\n(// DirectXTexCompressMI355X.cpp.*?)```", doc, re.S).group(1)
+    decl = ("namespace DirectX { HRESULT CompressMI355X(int hipDevice, const Image& srcImage, DXGI_FORMAT format, TEX_COMPRESS_FLAGS compress, "
+            "float threshold, ScratchImage& image) noexcept; }")
+    src = tmp_path / "binding.cpp"
+    src.write_text(code.replace('#include "DirectXTexP.h"', '#include "DirectXTexP.h"\n' + decl))
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "oracle", "shim"), "-I" + ref, "-I" + os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-3000:]
