@@ -59,19 +59,18 @@ def test_header_is_plain_c():
 
 
 def test_integration_binding_compiles_against_the_reference_headers(tmp_path):
-    """The reference-side binding shown in INTEGRATION.md (DirectXTexCompressMI355X.cpp) is real code: extracted from the document
-    and compiled against the reference's own headers (in place, with the oracle's stand-ins for its un-vendored dependencies)
-    and include/dxtex_amd.h. Needs /root/reference; skipped where it does not exist (the GPU box)."""
+    """The reference-side binding shown in INTEGRATION.md (DirectXTexCompressMI355X.cpp) is real code: the document's snippet is the
+    file oracle/binding/DirectXTexCompressMI355X.cpp character for character, and that file compiles against the reference's own
+    headers (in place, with the oracle's stand-ins for its un-vendored dependencies) and include/dxtex_amd.h. oracle/Makefile
+    links it with the reference and the product into oracle/_ref/binding_demo, which tests/test_zz_binding_gpu.py runs on a GPU."""
     import subprocess
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```cpp\n(// DirectXTexCompressMI355X.cpp.*?)```", doc, re.S).group(1)
+    path = os.path.join(ROOT, "oracle", "binding", "DirectXTexCompressMI355X.cpp")
+    assert open(path).read() == code, "INTEGRATION.md and oracle/binding/DirectXTexCompressMI355X.cpp have drifted apart"
     ref = "/root/reference/DirectXTex"
     if not os.path.isdir(ref):
         pytest.skip("/root/reference absent")
-    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    code = re.search(r"```cpp\n(// DirectXTexCompressMI355X.cpp.*?)```", doc, re.S).group(1)
-    decl = ("namespace DirectX { HRESULT CompressMI355X(int hipDevice, const Image& srcImage, DXGI_FORMAT format, TEX_COMPRESS_FLAGS compress, "
-            "float threshold, ScratchImage& image) noexcept; }")
-    src = tmp_path / "binding.cpp"
-    src.write_text(code.replace('#include "DirectXTexP.h"', '#include "DirectXTexP.h"\n' + decl))
-    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "oracle", "shim"), "-I" + ref, "-I" + os.path.join(ROOT, "include"), str(src)],
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "oracle", "shim"), "-I" + ref, "-I" + os.path.join(ROOT, "include"), path],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-3000:]
