@@ -30,7 +30,7 @@ namespace dxtex
 namespace bc7
 {
 #if defined(DXTEX_COUNT_EVALS)
-static long g_evalCount[8], g_evalTexels[8], g_macroCount[8];
+static long g_evalCount[8], g_evalTexels[8], g_macroCount[8], g_boundCount[8], g_pendCount[8], g_drainCount[8], g_pfTotal[8], g_pfPass[8], g_pfImprove[8];
 #endif
 // ---- per-mode constants (BC6HBC7.cpp:1106-1124) ---------------------------------------------------
 template<int MODE> struct ModeInfo;
@@ -660,6 +660,66 @@ DXTEX_HD int eval_var(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& v
     return total;
 }
 
+// A LOWER BOUND on eval_var's result at well under half its cost. ComputeError's "first local minimum" can only be worse
+// than the nearest palette entry, so the error with the best entry per texel bounds the candidate from below; and with the
+// accumulator of ONE v_dot4_u32_u8 set to floor(-|q_i|^2 / 2) the dot product is t_i = p.q_i - ceil(|q_i|^2 / 2), for which
+// 2 p.q_i - |q_i|^2 <= 2 t_i + 1. So   error >= base - sum_t (2 max_i t_i + 1):   N dot4 + N/2 v_max3 per texel instead of
+// 2N dot4 + (N - 1) compare/select pairs (v_dot4, v_cmp, v_cndmask and v_max3 all issue at 4 cycles per wave64 on gfx950,
+// profiles/r02_valu_rates.md). The alpha loops of modes 4 / 5 need no halving: their bound is the exact nearest-entry error.
+// A candidate whose bound is not below the best error so far can never satisfy Exhaustive's `fErr < fBestErr` (:3006) and
+// needs no exact evaluation; the others are evaluated exactly, in loop order, a little later (ExhPending).
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD int eval_var_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, int ch, uint32_t uaC, uint32_t ubC, int base)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+#if defined(DXTEX_COUNT_EVALS)
+    ++g_boundCount[MODE];
+#endif
+    if (C::kAlpha)
+    {
+        int pa[C::N], npa2[C::N];
+#pragma unroll
+        for (int i = 0; i < C::N; ++i)
+        {
+            pa[i] = int(((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6) & 0xFFu);
+            npa2[i] = -(pa[i] * pa[i]);
+        }
+        int total = base;
+        for_texels(rg, [&](int k)
+        {
+            const int al2 = int((rg.fetch(k) >> 23) & 0x1FEu);
+            int m = al2 * pa[0] + npa2[0];
+#pragma unroll
+            for (int i = 1; i < C::N; ++i) { const int su = al2 * pa[i] + npa2[i]; m = su > m ? su : m; }
+            total -= m;
+        });
+        return total;
+    }
+    else
+    {
+        uint32_t pal[C::N], acc[C::N];
+        const int sh = 8 * ch;
+#pragma unroll
+        for (int i = 0; i < C::N; ++i)
+        {
+            const uint32_t v = ((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6) & 0xFFu;
+            pal[i] = vp.palO[i] | (v << sh);
+            acc[i] = uint32_t(int(vp.nq2O[i] - v * v) >> 1);        // floor(-|q|^2 / 2)
+        }
+        int sum = 0;
+        for_texels(rg, [&](int k)
+        {
+            uint32_t p = rg.fetch(k);
+            if (CHSET == CH_COLOR) p &= 0x00FFFFFFu;
+            int m = int(udot4acc(p, pal[0], acc[0]));
+#pragma unroll
+            for (int i = 1; i < C::N; ++i) { const int t = int(udot4acc(p, pal[i], acc[i])); m = t > m ? t : m; }
+            sum += m;
+        });
+        return base - 2 * sum - rg.count();
+    }
+}
+
 // The two independent error sums of a separate-alpha mode, without the |p|^2 terms folded in.
 template<int MODE, int IM, class RG>
 DXTEX_HD int color_part_error(const RG& rg, uint32_t epA, uint32_t epB)
@@ -769,6 +829,10 @@ DXTEX_HD void perturb_macro(const RG& rg, const PerturbState& s, int base, int& 
             const bool valid = (tmp >= 0) && (tmp < (1 << C::PREC));
             const uint32_t u = unq1<C::PREC>(uint32_t(tmp) & ((1u << C::PREC) - 1u));
             const int e = eval_var<MODE, IM, CHSET>(rg, vp, s.ch, s.do_b ? fixedU : u, s.do_b ? u : fixedU, base);
+#if defined(DXTEX_COUNT_EVALS) && defined(DXTEX_COUNT_PERTURB_FILTER)
+            { const int lb = eval_var_bound<MODE, IM, CHSET>(rg, vp, s.ch, s.do_b ? fixedU : u, s.do_b ? u : fixedU, base); --g_boundCount[MODE];
+              ++g_pfTotal[MODE]; if (valid && lb < minErr) ++g_pfPass[MODE]; if (valid && e < minErr) ++g_pfImprove[MODE]; }
+#endif
             if (valid && e < minErr) { minErr = e; beststep = sign * step; }
         }
         cur += beststep;
@@ -805,6 +869,7 @@ struct ExhState
     int optErr;
     int ch;                 // >= CH1: finished
     int o, i, oEnd, iEnd, lo;
+    int o0;                 // first value of the outer variable in this window
     int aleb;
     int omin, imin, best;
 };
@@ -822,6 +887,7 @@ DXTEX_HD ExhState exh_window(const ExhState& in, int ch)
     const int blow = (cb - delta) > 0 ? (cb - delta) : 0, bhigh = (cb + delta) < hi ? (cb + delta) : hi;
     s.aleb = ca <= cb;
     s.o = s.aleb ? alow : blow;
+    s.o0 = s.o;
     s.oEnd = s.aleb ? ahigh + 1 : bhigh;
     s.lo = s.aleb ? blow : alow;
     s.iEnd = s.aleb ? bhigh : ahigh + 1;
@@ -870,7 +936,7 @@ DXTEX_HD bool exh_begin(ExhState& s, VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, ui
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     s.optA = optA; s.optB = optB; s.optErr = optErr;
-    s.ch = 0; s.o = s.i = s.oEnd = s.iEnd = s.lo = 0; s.aleb = 0; s.omin = s.imin = 0; s.best = optErr;
+    s.ch = 0; s.o = s.i = s.oEnd = s.iEnd = s.lo = 0; s.o0 = 0; s.aleb = 0; s.omin = s.imin = 0; s.best = optErr;
     s = exh_window<MODE, IM, CHSET>(s, C::CH0);
     if (s.ch < C::CH1) varpal_init<MODE, IM, CHSET>(vp, s.optA, s.optB, s.ch);
     return exh_next<MODE, IM, CHSET>(s, vp);
@@ -884,6 +950,49 @@ DXTEX_HD void exh_step(const RG& rg, ExhState& s, const VarPal<LoopCfg<MODE, IM,
     const int e = eval_var<MODE, IM, CHSET>(rg, vp, s.ch, unq1<C::PREC>(uint32_t(a)), unq1<C::PREC>(uint32_t(b)), base);
     if (e < s.best) { s.omin = s.o; s.imin = s.i; s.best = e; }       // strict: the first minimum in loop order wins (:3006)
     ++s.i;
+}
+
+// The same step split in two (see eval_var_bound): visiting a candidate only bounds it; candidates that might beat the best error
+// so far wait, in loop order, for their exact evaluation. The queue is drained before a window is committed, and a stale (too
+// high) `best` in the filter only lets more candidates through, so the window's result is exactly exh_step's.
+// PQ abstracts where the queue lives: ExhPendingRegs (host check) or a per-lane LDS column (search kernel).
+enum : int { kExhPendMax = 16 };
+struct ExhPendingRegs
+{
+    uint8_t slot[kExhPendMax];
+    int head, tail;
+    DXTEX_HD void clear() { head = tail = 0; }
+    DXTEX_HD int count() const { return tail - head; }
+    DXTEX_HD void push(uint32_t v) { slot[tail & (kExhPendMax - 1)] = uint8_t(v); ++tail; }
+    DXTEX_HD uint32_t pop() { const uint32_t v = slot[head & (kExhPendMax - 1)]; ++head; return v; }
+};
+
+// candidate code: (o - o0) | (i - lo) << 4 (a window is at most 11 x 11)
+template<int MODE, int IM, int CHSET, class RG, class PQ>
+DXTEX_HD void exh_filter_step(const RG& rg, ExhState& s, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, int base, PQ& pd)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    const int a = s.aleb ? s.o : s.i, b = s.aleb ? s.i : s.o;
+    const int lb = eval_var_bound<MODE, IM, CHSET>(rg, vp, s.ch, unq1<C::PREC>(uint32_t(a)), unq1<C::PREC>(uint32_t(b)), base);
+    if (lb < s.best)
+    {
+        pd.push(uint32_t(s.o - s.o0) | (uint32_t(s.i - s.lo) << 4));
+#if defined(DXTEX_COUNT_EVALS)
+        ++g_pendCount[MODE];
+#endif
+    }
+    ++s.i;
+}
+
+template<int MODE, int IM, int CHSET, class RG, class PQ>
+DXTEX_HD void exh_exact_pop(const RG& rg, ExhState& s, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, int base, PQ& pd)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    const uint32_t code = pd.pop();
+    const int o = s.o0 + int(code & 0xFu), i = s.lo + int((code >> 4) & 0xFu);
+    const int a = s.aleb ? o : i, b = s.aleb ? i : o;
+    const int e = eval_var<MODE, IM, CHSET>(rg, vp, s.ch, unq1<C::PREC>(uint32_t(a)), unq1<C::PREC>(uint32_t(b)), base);
+    if (e < s.best) { s.omin = o; s.imin = i; s.best = e; }       // strict: the first minimum in loop order wins (:3006)
 }
 
 // optimize_one() through the lockstep pieces, one lane's worth (host-side equivalence check, and the
@@ -912,9 +1021,17 @@ DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& o
     const int base = loop_base<MODE, IM, CHSET>(rg, optA, optB);
     ExhState s; VarPal<C::N> vp;
     bool has = exh_begin<MODE, IM, CHSET>(s, vp, optA, optB, optErr);
+    ExhPendingRegs pd; pd.clear();
     while (has)
     {
-        exh_step<MODE, IM, CHSET>(rg, s, vp, base);
+        exh_filter_step<MODE, IM, CHSET>(rg, s, vp, base, pd);
+        if (pd.count() == kExhPendMax || !exh_settle(s))
+        {
+#if defined(DXTEX_COUNT_EVALS)
+            if (pd.count()) ++g_drainCount[MODE];
+#endif
+            while (pd.count()) exh_exact_pop<MODE, IM, CHSET>(rg, s, vp, base, pd);
+        }
         has = exh_next<MODE, IM, CHSET>(s, vp);
     }
     optA = s.optA; optB = s.optB; optErr = s.optErr;

@@ -477,14 +477,28 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
 // efficient one. Both are launched, each returns when it is not its turn.
 constexpr uint32_t kWaveTaskMax = 262144;
 
-// The Exhaustive phase (:2971-3042) for the channels of CHSET.
+// The Exhaustive phase (:2971-3042) for the channels of CHSET, wave-synchronous by window: every lane holds one task; all lanes
+// walk their current window (one channel's +-5 x +-5 neighbourhood) together, and a lane that needs a new task takes it at a
+// window boundary. Visiting a candidate costs a bound (eval_var_bound: about half an evaluation); the few per cent of candidates
+// whose bound is below the lane's best error so far queue up in the lane's LDS column and are evaluated exactly, in loop order,
+// after the window's last visit, all lanes together; then every lane commits its window. Exactly the result of evaluating every
+// candidate, at about half the instructions.
+struct ExhPendingLds
+{
+    uint8_t* col;        // &sPend[lane]; slot k at col[k * 64]
+    int head, tail;
+    __device__ __forceinline__ void clear() { head = tail = 0; }
+    __device__ __forceinline__ int count() const { return tail - head; }
+    __device__ __forceinline__ void push(uint32_t v) { col[(tail & (kExhPendMax - 1)) * 64] = uint8_t(v); ++tail; }
+    __device__ __forceinline__ uint32_t pop() { const uint32_t v = col[(head & (kExhPendMax - 1)) * 64]; ++head; return v; }
+};
+
 template<int MODE, int IM, int CHSET>
-__global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop, int kRefillMin, int kTransMin)
+__global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
-    // kRefillMin: let a few finished lanes wait so that pickups happen in batches; kTransMin: likewise for lanes
-    // that have to open their next window
     __shared__ uint32_t sSlot[16 * 64];
+    __shared__ uint8_t sPend[kExhPendMax * 64];
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
     if (live == 0) return;           // nothing survived pre (a phase that owns no block, everything pruned): skip the queue atomics
@@ -493,7 +507,8 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
     uint32_t* slotCol = &sSlot[lane];
 
     ExhState st; st.ch = C::CH1; st.optA = st.optB = 0; st.optErr = 0;
-    st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = 0;
+    st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.o0 = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = 0;
+    ExhPendingLds pd; pd.col = &sPend[lane]; pd.clear();
     VarPal<C::N> vp;
 #pragma unroll
     for (int i = 0; i < C::N; ++i) { vp.palO[i] = 0; vp.nq2O[i] = 0; }
@@ -503,9 +518,9 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
     WaveQueue q; q.lo = q.hi = 0; q.drained = false;
     for (;;)
     {
+        // ---- window boundary: lanes without a task take one (its first window opens here)
         const unsigned long long idle = __ballot(myTask == 0xFFFFFFFFu);
-        const int nIdle = __popcll(idle);
-        if (!(q.drained && q.lo >= q.hi) && (nIdle >= kRefillMin))
+        if (idle != 0ull && !(q.drained && q.lo >= q.hi))
         {
             const uint32_t idx = queue_take(q, head, live, idle, lane);
             if (idx != 0xFFFFFFFFu)
@@ -518,32 +533,39 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
                 if (!exh_begin<MODE, IM, CHSET>(st, vp, r.A, r.B, r.err)) myTask = 0xFFFFFFFFu;     // nothing to search: endpoints stay
             }
         }
-        // Lanes whose window is used up wait until kTransMin of them can open their next windows together
-        // (committing a window and rebuilding the palette cache costs about half an evaluation).
-        const unsigned long long busy = __ballot(myTask != 0xFFFFFFFFu);
-        const unsigned long long waiting = __ballot(myTask != 0xFFFFFFFFu && st.o >= st.oEnd);
-        if (busy == 0ull)
+        const bool busyL = myTask != 0xFFFFFFFFu;
+        if (__ballot(busyL) == 0ull)
         {
             if (q.drained && q.lo >= q.hi) break;
             continue;
         }
-        if (__popcll(waiting) >= kTransMin || waiting == busy)
+        pd.clear();
+        // ---- visit every candidate of the window (bounds only)
+        for (;;)
         {
-            if (myTask != 0xFFFFFFFFu && st.o >= st.oEnd)
+            const bool more = busyL && st.o < st.oEnd;
+            if (__ballot(more) == 0ull) break;
+            if (__ballot(busyL && pd.count() == kExhPendMax) != 0ull)
             {
-                if (!exh_next<MODE, IM, CHSET>(st, vp))
-                {
-                    TaskRec* r = a.recs + myTask;
-                    r->A = st.optA; r->B = st.optB; r->err = st.optErr;
-                    myTask = 0xFFFFFFFFu;
-                }
+                // a lane's queue is full (rare): one round of exact evaluations, every lane that has a pending candidate takes part
+                if (busyL && pd.count() > 0) exh_exact_pop<MODE, IM, CHSET>(rg, st, vp, base, pd);
+                continue;
             }
-            continue;
+            if (more)
+            {
+                exh_filter_step<MODE, IM, CHSET>(rg, st, vp, base, pd);
+                exh_settle(st);
+            }
         }
-        if (myTask != 0xFFFFFFFFu && st.o < st.oEnd)
+        // ---- exact evaluation of the candidates that passed the filter, oldest first
+        while (__ballot(busyL && pd.count() > 0) != 0ull)
+            if (busyL && pd.count() > 0) exh_exact_pop<MODE, IM, CHSET>(rg, st, vp, base, pd);
+        // ---- commit the window, open the next one (or finish the task)
+        if (busyL && !exh_next<MODE, IM, CHSET>(st, vp))
         {
-            exh_step<MODE, IM, CHSET>(rg, st, vp, base);
-            exh_settle(st);
+            TaskRec* r = a.recs + myTask;
+            r->A = st.optA; r->B = st.optB; r->err = st.optErr;
+            myTask = 0xFFFFFFFFu;
         }
     }
 }
@@ -573,7 +595,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_wave_kernel(Bc7Args a)
         wave_lds_sync();
         const int base = loop_base<MODE, IM, CHSET>(rg, rec.A, rec.B);
         ExhState st; st.optA = rec.A; st.optB = rec.B; st.optErr = rec.err;
-        st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = rec.err; st.ch = C::CH0;
+        st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.o0 = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = rec.err; st.ch = C::CH0;
         VarPal<C::N> vp;
 #pragma unroll 1
         for (int ch = C::CH0; ch < C::CH1; ++ch)
@@ -829,15 +851,13 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order);
     if (marks) marks->mark(names[2]);
     const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
-    static const int refillMin = getenv("DXTEX_BC7_REFILL_MIN") ? atoi(getenv("DXTEX_BC7_REFILL_MIN")) : 8;
-    static const int transMin = getenv("DXTEX_BC7_TRANS_MIN") ? atoi(getenv("DXTEX_BC7_TRANS_MIN")) : 8;
     if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
         if (marks) marks->mark(names[4]);
         if constexpr (MODE == 6)
             hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_ALL>), dim3(std::min<uint32_t>(kSearchWaves, ntasks)), dim3(64), 0, stream, a);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1, refillMin, transMin);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1);
     }
     else
     {
@@ -845,9 +865,9 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
         if (marks) marks->mark(names[3]);
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 1);
         if (marks) marks->mark(names[4]);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2, refillMin, transMin);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2);
         if (marks) marks->mark(names[5]);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3, refillMin, transMin);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3);
     }
     if (marks) marks->mark(names[6]);
     hipLaunchKernelGGL((bc7_post_kernel<MODE, IM>), dim3(gridPP), dim3(256), 0, stream, a);

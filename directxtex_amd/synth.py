@@ -61,3 +61,68 @@ def rgba16f(width, height, seed=3):
         out[..., c] = np.exp2(e) * g * (0.8 + 0.4 * n)
     out[..., 3] = 1.0
     return np.minimum(out, 60000.0).astype(np.float16)
+
+
+# ---- SURVEY.md section 8d recipes: LCG-driven images of BASELINE.json's configurations ------------------------------------
+# s <- s * 1664525 + 1013904223 (mod 2^32), byte = s >> 24. The n-th state is computed by jump-ahead (doubling), so a plane of
+# any size costs log2(n) numpy passes and the same (seed, index) always gives the same byte.
+_LCG_A, _LCG_C = 1664525, 1013904223
+
+
+def lcg_bytes(seed, n):
+    """First n bytes (s_1 >> 24, s_2 >> 24, ...) of the LCG started at s_0 = seed."""
+    n = int(n)
+    s = np.empty(n + 1, np.uint64)
+    s[0] = seed & 0xFFFFFFFF
+    have, a, c = 1, _LCG_A, _LCG_C            # s[i + have] = a * s[i] + c
+    while have < n + 1:
+        take = min(have, n + 1 - have)
+        s[have:have + take] = (s[:take] * np.uint64(a) + np.uint64(c)) & np.uint64(0xFFFFFFFF)
+        c = (a * c + c) & 0xFFFFFFFF
+        a = (a * a) & 0xFFFFFFFF
+        have += take
+    return (s[1:] >> np.uint64(24)).astype(np.uint8)
+
+
+def _lcg_plane(seed, height, width, cell):
+    """(height, width) bytes: one LCG byte per cell x cell square, replicated."""
+    ch, cw = (height + cell - 1) // cell, (width + cell - 1) // cell
+    p = lcg_bytes(seed, ch * cw).reshape(ch, cw)
+    if cell > 1:
+        p = np.repeat(np.repeat(p, cell, axis=0), cell, axis=1)
+    return p[:height, :width]
+
+
+def survey_rgba8(width, height, seed=2, alpha="opaque"):
+    """SURVEY.md section 8d, cfg1 / cfg2 / cfg4 recipe: R = x-gradient + 4-bit noise, G = y-gradient + 4-bit noise,
+    B = diagonal + 5-bit noise, the noise summed over 4 octaves (cells of 1, 2, 4, 8 texels) and scaled per 64 x 64 region
+    by a gain of 0, 1, 2 or 4 drawn from the same LCG, so that 4 x 4 blocks range from flat (pure gradient) to noisy.
+    alpha: 'opaque' (255) | 'random' (one LCG byte per texel). (H, W, 4) uint8."""
+    ys, xs = np.meshgrid(np.arange(height, dtype=np.int64), np.arange(width, dtype=np.int64), indexing="ij")
+    base = [xs * 255 // max(1, width - 1), ys * 255 // max(1, height - 1), (xs + ys) * 255 // max(1, width + height - 2)]
+    gain = np.array([0, 1, 2, 4], np.int64)[_lcg_plane(seed * 7919 + 5, height, width, 64) >> 6]
+    out = np.empty((height, width, 4), np.uint8)
+    for c in range(3):
+        bits = 5 if c == 2 else 4
+        acc = np.zeros((height, width), np.int64)
+        for octave in range(4):
+            n = _lcg_plane(seed * 7919 + 101 * (octave * 3 + c) + 11, height, width, 1 << octave).astype(np.int64) >> (8 - bits)
+            acc += n - (1 << (bits - 1))
+        out[..., c] = np.clip(base[c] + ((gain * acc) >> 1), 0, 255).astype(np.uint8)
+    out[..., 3] = 255 if alpha == "opaque" else _lcg_plane(seed * 7919 + 977, height, width, 1)
+    return out
+
+
+def survey_rgba16f(width, height, seed=3):
+    """SURVEY.md section 8d, cfg3 recipe: half(exp2(uniform(-8, 6)) * smooth gradient), finite, non-negative, A = 1. The exponent
+    is drawn per 8 x 8 cell (one LCG byte -> [-8, 6]), every texel gets a factor in [0.75, 1.25) from its own LCG byte."""
+    ys, xs = np.meshgrid(np.arange(height, dtype=np.float64), np.arange(width, dtype=np.float64), indexing="ij")
+    fx, fy = xs / max(1, width - 1), ys / max(1, height - 1)
+    e = _lcg_plane(seed * 7919 + 3, height, width, 8).astype(np.float64) * (14.0 / 255.0) - 8.0
+    out = np.empty((height, width, 4), np.float64)
+    for c in range(3):
+        g = 0.25 + 0.75 * (fx if c == 0 else fy if c == 1 else 0.5 * (fx + fy))
+        n = _lcg_plane(seed * 7919 + 31 * (c + 1), height, width, 1).astype(np.float64) / 256.0
+        out[..., c] = np.exp2(e) * g * (0.75 + 0.5 * n)
+    out[..., 3] = 1.0
+    return np.minimum(out, 60000.0).astype(np.float16)

@@ -231,6 +231,17 @@ int main(int argc, char** argv)
     // optional third argument: BC_FLAGS (0x80000 BC7_USE_3SUBSETS, 0x100000 BC7_QUICK)
     const uint32_t bcFlags = argc > 3 ? uint32_t(strtoul(argv[3], nullptr, 0)) : 0u;
     const bool use3 = (bcFlags & 0x80000u) != 0, quick = (bcFlags & 0x100000u) != 0;
+    // optional fourth argument: a file of raw RGBA8 tiles (64 bytes each, row-major 4x4) to use instead of random tiles
+    std::vector<uint8_t> tileFile;
+    if (argc > 4)
+    {
+        FILE* f = fopen(argv[4], "rb");
+        if (!f) { printf("cannot open %s\n", argv[4]); return 2; }
+        tileFile.resize(size_t(ntiles) * 64);
+        const size_t got = fread(tileFile.data(), 1, tileFile.size(), f);
+        fclose(f);
+        if (got != tileFile.size()) { printf("%s: short read\n", argv[4]); return 2; }
+    }
     int nbad = 0;
     for (int t = 0; t < ntiles; ++t)
     {
@@ -245,6 +256,7 @@ int main(int argc, char** argv)
                 v = v < 0 ? 0 : v > 255 ? 255 : v;
                 px[i * 4 + c] = (c == 3 && opaque) ? 255 : uint8_t(v);
             }
+        if (!tileFile.empty()) memcpy(px, tileFile.data() + size_t(t) * 64, 64);
         HostBlock hb; make_block(hb, px);
 
         // reference
@@ -331,7 +343,12 @@ int main(int argc, char** argv)
     }
 #if defined(DXTEX_COUNT_EVALS)
     for (int m = 0; m < 8; ++m)
-        if (g_evalCount[m]) printf("mode %d: %.1f evals/tile, %.1f macro-ops/tile, %.2f texels/eval\n", m, double(g_evalCount[m]) / ntiles, double(g_macroCount[m]) / ntiles, double(g_evalTexels[m]) / g_evalCount[m]);
+        if (g_evalCount[m]) printf("mode %d: %.1f evals/tile, %.1f macro-ops/tile, %.2f texels/eval; exhaustive: %.1f bounds/tile, %.1f passed the filter (%.1f %%), %.1f drains/tile\n", m, double(g_evalCount[m]) / ntiles, double(g_macroCount[m]) / ntiles, double(g_evalTexels[m]) / g_evalCount[m],
+                                    double(g_boundCount[m]) / ntiles, double(g_pendCount[m]) / ntiles, 100.0 * double(g_pendCount[m]) / double(g_boundCount[m] ? g_boundCount[m] : 1), double(g_drainCount[m]) / ntiles);
+#endif
+#if defined(DXTEX_COUNT_PERTURB_FILTER)
+    for (int m = 0; m < 8; ++m)
+        if (g_pfTotal[m]) printf("mode %d perturb: %.1f candidates/tile, %.1f %% pass the bound filter, %.1f %% improve\n", m, double(g_pfTotal[m]) / ntiles, 100.0 * g_pfPass[m] / g_pfTotal[m], 100.0 * g_pfImprove[m] / g_pfTotal[m]);
 #endif
     printf("%d of %d tiles differ\n", nbad, ntiles);
     return nbad ? 1 : 0;
