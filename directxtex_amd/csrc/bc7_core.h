@@ -959,15 +959,16 @@ DXTEX_HD void exh_step(const RG& rg, ExhState& s, const VarPal<LoopCfg<MODE, IM,
 enum : int { kExhPendMax = 16 };
 struct ExhPendingRegs
 {
-    uint8_t slot[kExhPendMax];
+    uint32_t slot[kExhPendMax];
     int head, tail;
     DXTEX_HD void clear() { head = tail = 0; }
     DXTEX_HD int count() const { return tail - head; }
-    DXTEX_HD void push(uint32_t v) { slot[tail & (kExhPendMax - 1)] = uint8_t(v); ++tail; }
-    DXTEX_HD uint32_t pop() { const uint32_t v = slot[head & (kExhPendMax - 1)]; ++head; return v; }
+    DXTEX_HD void push(uint32_t v) { slot[tail & (kExhPendMax - 1)] = v; ++tail; }
+    DXTEX_HD uint32_t front() const { return slot[head & (kExhPendMax - 1)]; }
+    DXTEX_HD void drop() { ++head; }
 };
 
-// candidate code: (o - o0) | (i - lo) << 4 (a window is at most 11 x 11)
+// queue entry: candidate code (o - o0) | (i - lo) << 4 in the low byte (a window is at most 11 x 11), its bound above it
 template<int MODE, int IM, int CHSET, class RG, class PQ>
 DXTEX_HD void exh_filter_step(const RG& rg, ExhState& s, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, int base, PQ& pd)
 {
@@ -976,7 +977,7 @@ DXTEX_HD void exh_filter_step(const RG& rg, ExhState& s, const VarPal<LoopCfg<MO
     const int lb = eval_var_bound<MODE, IM, CHSET>(rg, vp, s.ch, unq1<C::PREC>(uint32_t(a)), unq1<C::PREC>(uint32_t(b)), base);
     if (lb < s.best)
     {
-        pd.push(uint32_t(s.o - s.o0) | (uint32_t(s.i - s.lo) << 4));
+        pd.push(uint32_t(s.o - s.o0) | (uint32_t(s.i - s.lo) << 4) | (uint32_t(lb > 0 ? lb : 0) << 8));     // errors are < 2^23
 #if defined(DXTEX_COUNT_EVALS)
         ++g_pendCount[MODE];
 #endif
@@ -984,15 +985,23 @@ DXTEX_HD void exh_filter_step(const RG& rg, ExhState& s, const VarPal<LoopCfg<MO
     ++s.i;
 }
 
+// Drops the queued candidates that the best error has meanwhile overtaken (their bound is no longer below it).
+template<class PQ>
+DXTEX_HD void exh_skip_beaten(const ExhState& s, PQ& pd)
+{
+    while (pd.count() > 0 && int(pd.front() >> 8) >= s.best) pd.drop();
+}
+
 template<int MODE, int IM, int CHSET, class RG, class PQ>
 DXTEX_HD void exh_exact_pop(const RG& rg, ExhState& s, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, int base, PQ& pd)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
-    const uint32_t code = pd.pop();
+    const uint32_t code = pd.front(); pd.drop();
     const int o = s.o0 + int(code & 0xFu), i = s.lo + int((code >> 4) & 0xFu);
     const int a = s.aleb ? o : i, b = s.aleb ? i : o;
     const int e = eval_var<MODE, IM, CHSET>(rg, vp, s.ch, unq1<C::PREC>(uint32_t(a)), unq1<C::PREC>(uint32_t(b)), base);
     if (e < s.best) { s.omin = o; s.imin = i; s.best = e; }       // strict: the first minimum in loop order wins (:3006)
+    exh_skip_beaten(s, pd);
 }
 
 // optimize_one() through the lockstep pieces, one lane's worth (host-side equivalence check, and the

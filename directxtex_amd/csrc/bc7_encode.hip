@@ -485,20 +485,21 @@ constexpr uint32_t kWaveTaskMax = 262144;
 // candidate, at about half the instructions.
 struct ExhPendingLds
 {
-    uint8_t* col;        // &sPend[lane]; slot k at col[k * 64]
+    uint32_t* col;       // &sPend[lane]; slot k at col[k * 64]
     int head, tail;
     __device__ __forceinline__ void clear() { head = tail = 0; }
     __device__ __forceinline__ int count() const { return tail - head; }
-    __device__ __forceinline__ void push(uint32_t v) { col[(tail & (kExhPendMax - 1)) * 64] = uint8_t(v); ++tail; }
-    __device__ __forceinline__ uint32_t pop() { const uint32_t v = col[(head & (kExhPendMax - 1)) * 64]; ++head; return v; }
+    __device__ __forceinline__ void push(uint32_t v) { col[(tail & (kExhPendMax - 1)) * 64] = v; ++tail; }
+    __device__ __forceinline__ uint32_t front() const { return col[(head & (kExhPendMax - 1)) * 64]; }
+    __device__ __forceinline__ void drop() { ++head; }
 };
 
 template<int MODE, int IM, int CHSET>
-__global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop)
+__global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop, int midDrain)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     __shared__ uint32_t sSlot[16 * 64];
-    __shared__ uint8_t sPend[kExhPendMax * 64];
+    __shared__ uint32_t sPend[kExhPendMax * 64];
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
     if (live == 0) return;           // nothing survived pre (a phase that owns no block, everything pruned): skip the queue atomics
@@ -545,9 +546,11 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop)
         {
             const bool more = busyL && st.o < st.oEnd;
             if (__ballot(more) == 0ull) break;
-            if (__ballot(busyL && pd.count() == kExhPendMax) != 0ull)
+            // One round of exact evaluations in the middle of the window when (nearly) every lane has a candidate waiting - a full
+            // trip, and the lanes' best errors tighten early, so fewer candidates pass the filter - or when a lane's queue is full.
+            const unsigned long long waiting = __ballot(busyL && pd.count() > 0);
+            if (__popcll(waiting) >= midDrain || __ballot(busyL && pd.count() == kExhPendMax) != 0ull)
             {
-                // a lane's queue is full (rare): one round of exact evaluations, every lane that has a pending candidate takes part
                 if (busyL && pd.count() > 0) exh_exact_pop<MODE, IM, CHSET>(rg, st, vp, base, pd);
                 continue;
             }
@@ -851,13 +854,14 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order);
     if (marks) marks->mark(names[2]);
     const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
+    static const int midDrain = getenv("DXTEX_BC7_MID_DRAIN") ? atoi(getenv("DXTEX_BC7_MID_DRAIN")) : 52;
     if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
         if (marks) marks->mark(names[4]);
         if constexpr (MODE == 6)
             hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_ALL>), dim3(std::min<uint32_t>(kSearchWaves, ntasks)), dim3(64), 0, stream, a);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1, midDrain);
     }
     else
     {
@@ -865,9 +869,9 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
         if (marks) marks->mark(names[3]);
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 1);
         if (marks) marks->mark(names[4]);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2, midDrain);
         if (marks) marks->mark(names[5]);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3, midDrain);
     }
     if (marks) marks->mark(names[6]);
     hipLaunchKernelGGL((bc7_post_kernel<MODE, IM>), dim3(gridPP), dim3(256), 0, stream, a);
