@@ -1,26 +1,31 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the MI355X DirectXTex hot path.
 
-Metric (BASELINE.json): Mtexels/s of BC7 encode, 4096x4096 RGBA8, TEX_COMPRESS_DEFAULT.
+Metric (BASELINE.json): Mtexels/s of BC7 encode, 4096x4096 RGBA8, TEX_COMPRESS_DEFAULT (cfg2).
 
   python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of DirectX::Compress' hot path (dxtex_compress_device: source resident in HBM, BC7
-payload written to HBM) over one 4096^2 synthetic image per GPU. N > 1 is launched by the driver through
-torch.distributed.run, one rank per GPU; images are sharded one-per-GPU (the path has no exchange step, so
-there is no data-path collective: the only collectives are the timing barrier and the MAX over ranks).
-Rank 0 prints ONE JSON line.
+One "step" = one pass of DirectX::Compress' hot path (dxtex_compress_device: source resident in HBM, BC7 payload written to
+HBM) over one 4096^2 synthetic image per GPU: SURVEY.md section 8d's cfg2 recipe (directxtex_amd.synth.survey_rgba8, LCG seed
+2 + rank). N > 1 is launched by the driver through torch.distributed.run, one rank per GPU; images are sharded one-per-GPU (the
+path has no exchange step, so there is no data-path collective: the only collectives are the timing barrier and the MAX over
+ranks). Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     - dominant kernel: algorithmic bytes per launch / its mean duration (hipEvents on the launch
-                 stream, recorded inside the timed region through dxtex_ctx_profile_*), against 8 TB/s HBM.
-                 BC7 at the reference's search depth is VALU-bound, so the HBM fraction is small by design;
-                 `all_kernels` lists every kernel of the step.
-  cpu_baseline - the reference's own encoder (oracle/_ref, D3DXEncodeBC7 compiled in place, OpenMP over
-                 blocks as CompressBC_Parallel does) timed on this box's host cores on a bounded sample of
-                 the same image (rank 0, N = 1 only). Reported, not a target.
+  roofline     - dominant kernel: algorithmic bytes per launch / its mean duration (hipEvents on the launch stream, recorded in
+                 a separate, untimed profiling pass through dxtex_ctx_profile_*), against 8 TB/s HBM. BC7 at the reference's
+                 search depth is VALU-bound, so the HBM fraction is small by design; `valu` gives the kernel's VALU issue
+                 utilisation against the measured gfx950 issue rates (profiles/r02_valu_rates.md), `all_kernels_ms` every kernel.
+  parity       - the payload of the timed run against the committed digests of the reference's output for the same image
+                 (tests/golden/fullsize.json: whole 4096^2 image, 1 048 576 blocks) and, live, against the reference run on
+                 this box's host cores on a bounded sample of block rows; PSNR of the whole image (decoded on the GPU).
+  cpu_baseline - the reference's own encoder (oracle/_ref: DirectX::Compress with TEX_COMPRESS_PARALLEL = CompressBC_Parallel,
+                 OpenMP over blocks) timed on this box's host cores on that bounded sample (rank 0, N = 1 only; --cpu-full runs
+                 the whole image, ~3.5 min on 128 threads). Reported, not a target.
+  other_workloads - cfg3, cfg4, a cfg5 shard and the other codecs, each with its own roofline object.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,51 +39,88 @@ sys.path.insert(0, ROOT)
 WIDTH = HEIGHT = 4096
 ALGO_BYTES_PER_TEXEL = 5.0          # 4 B read + 1 B written per texel for RGBA8 -> BC7
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s
+BAND_ROWS = 16                      # block rows per digest band (tests/golden/make_golden_fullsize.py)
+TEX_COMPRESS_PARALLEL = 0x10000000
 
 
-def make_image(seed):
-    """4096^2 RGBA8 synthetic texture (opaque), SURVEY.md section 8d recipe. Built from a 1024^2 hash-noise
-    image generated at 4 different seeds and tiled 4x4, so generation stays a few seconds."""
+def make_image(rank):
+    """4096^2 RGBA8, LCG seed 2 (+ rank: every GPU compresses its own image), opaque."""
     from directxtex_amd import synth
-    tiles = [synth.rgba8(1024, 1024, seed=seed * 16 + i, alpha="opaque") for i in range(4)]
-    rows = []
-    for y in range(4):
-        rows.append(np.concatenate([tiles[(x + y) % 4] for x in range(4)], axis=1))
-    return np.ascontiguousarray(np.concatenate(rows, axis=0))
+    return synth.survey_rgba8(WIDTH, HEIGHT, 2 + rank, "opaque")
 
 
-def cpu_baseline(img, budget_s=15.0):
-    """Reference encoder on the host cores over a bounded crop of the benchmark image."""
+def hbm_roofline(algo_bytes, ms, kernel=None, traffic=None):
+    achieved = algo_bytes / (ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+         "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes), "kernel_ms": round(ms, 4)}
+    if kernel:
+        r["kernel"] = kernel
+    return r
+
+
+def band_sha(payload, width, height):
+    nbw, nbh = (width + 3) // 4, (height + 3) // 4
+    rows = np.ascontiguousarray(payload, np.uint8).reshape(nbh, nbw * 16)
+    return [hashlib.sha256(rows[r:r + BAND_ROWS].tobytes()).hexdigest() for r in range(0, nbh, BAND_ROWS)]
+
+
+def cpu_baseline(img, payload, full, budget_s=20.0):
+    """The reference on the host cores: on bands of 16 block rows of the benchmark image spread over its height (a band is an image of
+    its own for a block codec), sized for ~budget_s of wall time, or on the whole image. Returns (cpu_baseline object, parity dict)."""
     import oracle
     if not oracle.have_ref():
-        return None
-    fmt_src, fmt_bc7 = 28, 98
+        return None, {}
     threads = oracle.ref_num_threads()
-    # calibrate on 8x8 blocks, then size the sample for ~budget_s of wall time
-    crop = np.ascontiguousarray(img[:32, :32])
-    t0 = time.perf_counter()
-    oracle.compress_image(crop, 32, 32, fmt_src, fmt_bc7, 0, 0.5)
-    dt = max(time.perf_counter() - t0, 1e-4)
-    blocks = int(max(64, min(65536, 64 * budget_s / dt)))
-    side = int(np.sqrt(blocks)) * 4
-    side = max(32, min(1024, side // 32 * 32))
-    y0 = x0 = 1024 - side // 2                       # a crop that straddles flat, noisy and edge regions
-    crop = np.ascontiguousarray(img[y0:y0 + side, x0:x0 + side])
-    t0 = time.perf_counter()
-    payload = oracle.compress_image(crop, side, side, fmt_src, fmt_bc7, 0, 0.5)
-    dt = time.perf_counter() - t0
-    src = oracle.load_image(crop, side, side, fmt_src)
-    psnr = oracle.psnr_rgb(oracle.decode_image(payload, side, side, fmt_bc7)[..., :3], src[..., :3])
-    return {"value": round(side * side / dt / 1e6, 5), "unit": "Mtexels/s", "cores": threads, "kind": "reference",
-            "sample": f"{side}x{side} crop at ({x0},{y0}) of the benchmark image, D3DXEncodeBC7 flags=0, "
-                      f"OpenMP over blocks, {dt:.1f} s", "psnr_db": round(psnr, 3)}, (x0, y0, side, payload)
+    rows = BAND_ROWS * 4
+    nbands = HEIGHT // rows
+    got = np.ascontiguousarray(payload, np.uint8).reshape(HEIGHT // 4, (WIDTH // 4) * 16)
+    texels = 0; secs = 0.0; same = 0; blocks = 0
+    done = []
+
+    def run_band(b):
+        nonlocal texels, secs, same, blocks
+        crop = np.ascontiguousarray(img[b * rows:(b + 1) * rows])
+        t0 = time.perf_counter()
+        ref = oracle.ref_compress_image(crop, WIDTH, crop.shape[0], 28, 98, TEX_COMPRESS_PARALLEL, 0.5)
+        secs += time.perf_counter() - t0
+        texels += crop.shape[0] * WIDTH
+        g = got[b * BAND_ROWS:(b + 1) * BAND_ROWS].reshape(-1, 16)
+        same += int((g == ref.reshape(-1, 16)).all(axis=1).sum()); blocks += g.shape[0]
+        done.append(b)
+
+    if full:
+        for b in range(nbands):
+            run_band(b)
+    else:
+        # the first band calibrates: then as many more, spread over the image's height, as fit the budget
+        run_band(nbands // 2)
+        n = int(max(0, min(nbands - 1, budget_s / max(secs, 1e-3) - 1)))
+        for i in range(n):
+            b = int(round(i * (nbands - 1) / max(1, n - 1))) if n > 1 else 0
+            if b not in done:
+                run_band(b)
+    picks = done
+    sample = "the whole 4096x4096 image" if full else f"{len(picks)} bands of {rows} rows x {WIDTH} ({texels} texels) spread over the benchmark image"
+    cpu = {"value": round(texels / secs / 1e6, 5), "unit": "Mtexels/s", "cores": threads, "kind": "reference",
+           "sample": f"{sample}; DirectX::Compress -> CompressBC_Parallel (OpenMP over blocks), D3DXEncodeBC7 flags=0, {secs:.1f} s"}
+    return cpu, {"live_reference_blocks_compared": blocks, "live_reference_blocks_identical": same}
 
 
-def other_workloads(ctx, dev, img):
-    """The other configurations of BASELINE.json, measured once each AFTER the timed region (reported, not the metric):
-    device-resident inputs, per-call wall time with a stream sync, algorithmic GB/s per SURVEY.md section 8d."""
+def gpu_psnr(ctx, dev, src, dst, fmt_src, fmt_bc, width, height):
+    """RGB PSNR (texdiag's formula) of a BC payload against its source, decoded and reduced on the GPU."""
+    import torch
+    back = torch.empty(width * height * 4, dtype=torch.uint8, device=dev)
+    ctx.decompress_device(dst.data_ptr(), width, height, fmt_bc, back.data_ptr(), 28)
+    mse = ctx.compute_mse_device(back.data_ptr(), 28, src.data_ptr(), fmt_src, width, height)
+    return float(10.0 * np.log10(3.0 / max(1e-30, float(mse[0] + mse[1] + mse[2]))))
+
+
+def other_workloads(ctx, dev, img, rank, world):
+    """The other configurations of BASELINE.json, measured AFTER the timed region (reported, not the metric): device-resident
+    inputs, per-call wall time with a stream sync, algorithmic bytes per SURVEY.md section 8d against the 8 TB/s HBM roofline."""
     import torch
     import directxtex_amd as dx
+    from directxtex_amd import synth
     RGBA8, RGBA16F = dx.DXGI_FORMAT_R8G8B8A8_UNORM, dx.DXGI_FORMAT_R16G16B16A16_FLOAT
     out = {}
 
@@ -90,33 +132,54 @@ def other_workloads(ctx, dev, img):
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t0) / n
 
+    def entry(dt, texels, algo_bytes, profile=None, **kw):
+        e = {"ms": round(dt * 1e3, 3), "Mtexels_s": round(texels / dt / 1e6, 1), "roofline": hbm_roofline(algo_bytes, dt * 1e3)}
+        if profile:
+            e["profile"] = profile
+        e.update(kw)
+        return e
+
+    tex = WIDTH * HEIGHT
     src = torch.from_numpy(img).to(dev)
     for name, fmt, bpt, n in (("bc1", dx.DXGI_FORMAT_BC1_UNORM, 4.5, 20), ("bc3", dx.DXGI_FORMAT_BC3_UNORM, 5.0, 20), ("bc5", dx.DXGI_FORMAT_BC5_UNORM, 5.0, 20)):
-        rp, sp = dx.compute_pitch(fmt, WIDTH, HEIGHT)
-        dst = torch.empty(sp, dtype=torch.uint8, device=dev)
+        dst = torch.empty(dx.compute_pitch(fmt, WIDTH, HEIGHT)[1], dtype=torch.uint8, device=dev)
         dt = timed(lambda: ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), fmt, 0, 0.5), n)
-        out[f"{name}_4096"] = {"ms": round(dt * 1e3, 3), "Mtexels_s": round(WIDTH * HEIGHT / dt / 1e6, 1), "algorithmic_GBs": round(WIDTH * HEIGHT * bpt / dt / 1e9, 1)}
+        out[f"{name}_4096"] = entry(dt, tex, tex * bpt, "profiles/r02_kernels.md")
     # the reference's faster / slower BC7 settings on the same image (TEX_COMPRESS_BC7_QUICK: mode 6 only; BC7_USE_3SUBSETS: + modes 0, 2)
-    rp, sp = dx.compute_pitch(dx.DXGI_FORMAT_BC7_UNORM, WIDTH, HEIGHT)
-    dst = torch.empty(sp, dtype=torch.uint8, device=dev)
+    dst = torch.empty(dx.compute_pitch(dx.DXGI_FORMAT_BC7_UNORM, WIDTH, HEIGHT)[1], dtype=torch.uint8, device=dev)
     for name, fl, n in (("bc7_quick_4096", dx.TEX_COMPRESS_BC7_QUICK, 5), ("bc7_3subsets_4096", 0x80000, 1)):
         dt = timed(lambda: ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, fl, 0.5), n)
-        out[name] = {"ms": round(dt * 1e3, 2), "Mtexels_s": round(WIDTH * HEIGHT / dt / 1e6, 1)}
-    # cfg3: 4096^2 RGBA16F -> BC6H_UF16
-    hdr = torch.from_numpy((img.astype(np.float32) * (8.0 / 255.0)).astype(np.float16)).to(dev)
-    rp, sp = dx.compute_pitch(dx.DXGI_FORMAT_BC6H_UF16, WIDTH, HEIGHT)
-    dst = torch.empty(sp, dtype=torch.uint8, device=dev)
-    dt = timed(lambda: ctx.compress_device(hdr.data_ptr(), WIDTH, HEIGHT, RGBA16F, dst.data_ptr(), dx.DXGI_FORMAT_BC6H_UF16, 0, 0.5), 2)
-    out["bc6h_uf16_4096"] = {"ms": round(dt * 1e3, 2), "Mtexels_s": round(WIDTH * HEIGHT / dt / 1e6, 2), "algorithmic_GBs": round(WIDTH * HEIGHT * 9.0 / dt / 1e9, 2)}
-    # decode BC7 4096^2 -> RGBA8 (0.5 + ... 1 B read + 4 B written per texel)
-    rp7, sp7 = dx.compute_pitch(dx.DXGI_FORMAT_BC7_UNORM, WIDTH, HEIGHT)
-    bc7 = torch.empty(sp7, dtype=torch.uint8, device=dev)
-    ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, bc7.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, dx.TEX_COMPRESS_BC7_QUICK, 0.5)
-    back = torch.empty(WIDTH * HEIGHT * 4, dtype=torch.uint8, device=dev)
-    dt = timed(lambda: ctx.decompress_device(bc7.data_ptr(), WIDTH, HEIGHT, dx.DXGI_FORMAT_BC7_UNORM, back.data_ptr(), RGBA8), 20)
-    out["bc7_decode_4096"] = {"ms": round(dt * 1e3, 3), "Mtexels_s": round(WIDTH * HEIGHT / dt / 1e6, 1), "algorithmic_GBs": round(WIDTH * HEIGHT * 5.0 / dt / 1e9, 1)}
-    # cfg4: 8192^2 RGBA8 full mip chain (box, cubic) then BC3 of all 14 levels
-    big = src.reshape(HEIGHT, WIDTH, 4).repeat(2, 2, 1).contiguous()
+        out[name] = entry(dt, tex, tex * 5.0)
+    # the headline codec on other content (the rate depends on what can be pruned): cfg2's variant with random alpha, and round 1's
+    # benchmark image (hash-noise recipe synth.rgba8, four 1024^2 tiles), kept for continuity with BENCH_r01
+    alt = torch.from_numpy(synth.survey_rgba8(WIDTH, HEIGHT, 2, "random")).to(dev)
+    dt = timed(lambda: ctx.compress_device(alt.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, 0, 0.5), 1)
+    out["bc7_4096_cfg2_random_alpha"] = entry(dt, tex, tex * 5.0)
+    tiles = [synth.rgba8(1024, 1024, seed=32 + i, alpha="opaque") for i in range(4)]
+    r01 = np.ascontiguousarray(np.concatenate([np.concatenate([tiles[(x + y) % 4] for x in range(4)], axis=1) for y in range(4)], axis=0))
+    alt = torch.from_numpy(r01).to(dev)
+    dt = timed(lambda: ctx.compress_device(alt.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, 0, 0.5), 2)
+    out["bc7_4096_round1_image"] = entry(dt, tex, tex * 5.0, note="BENCH_r01's image: 86.2 Mtexels/s in round 1")
+    del alt
+    # cfg3: 4096^2 RGBA16F -> BC6H_UF16 (SURVEY 8d seed-3 recipe), 9 B/texel
+    hdr_np = synth.survey_rgba16f(WIDTH, HEIGHT, 3)
+    hdr = torch.from_numpy(hdr_np).to(dev)
+    dst6 = torch.empty(dx.compute_pitch(dx.DXGI_FORMAT_BC6H_UF16, WIDTH, HEIGHT)[1], dtype=torch.uint8, device=dev)
+    dt = timed(lambda: ctx.compress_device(hdr.data_ptr(), WIDTH, HEIGHT, RGBA16F, dst6.data_ptr(), dx.DXGI_FORMAT_BC6H_UF16, 0, 0.5), 2)
+    e = entry(dt, tex, tex * 9.0, "profiles/r02_kernels.md")
+    gold = golden_case("cfg3_bc6h_uf16_4096")
+    if gold:
+        e["identical_to_reference_golden"] = band_sha(dst6.cpu().numpy(), WIDTH, HEIGHT) == gold["bands"]
+    out["cfg3_bc6h_uf16_4096"] = e
+    del hdr, dst6, hdr_np
+    # decode BC7 4096^2 -> RGBA8 (1 B read + 4 B written per texel)
+    back = torch.empty(tex * 4, dtype=torch.uint8, device=dev)
+    ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, dx.TEX_COMPRESS_BC7_QUICK, 0.5)
+    dt = timed(lambda: ctx.decompress_device(dst.data_ptr(), WIDTH, HEIGHT, dx.DXGI_FORMAT_BC7_UNORM, back.data_ptr(), RGBA8), 20)
+    out["bc7_decode_4096"] = entry(dt, tex, tex * 5.0, "profiles/r02_kernels.md")
+    del back
+    # cfg4: 8192^2 RGBA8 (seed 4, random alpha) full mip chain (box, cubic), then BC3 of all 14 levels
+    big = torch.from_numpy(synth.survey_rgba8(8192, 8192, 4, "random")).to(dev)
     w = h = 8192
     sizes = []
     while True:
@@ -126,35 +189,63 @@ def other_workloads(ctx, dev, img):
         w, h = max(1, w >> 1), max(1, h >> 1)
     bufs = [big.reshape(-1)] + [torch.empty(a * b * 4, dtype=torch.uint8, device=dev) for a, b in sizes[1:]]
     levels = [dx.capi.device_image(t.data_ptr(), a, b, RGBA8) for t, (a, b) in zip(bufs, sizes)]
-    chain_bytes = sum(a * b * 4 for a, b in sizes[:-1]) + sum(a * b * 4 for a, b in sizes[1:])
+    chain_bytes = sum(a * b * 4 for a, b in sizes[:-1]) + sum(a * b * 4 for a, b in sizes[1:])          # 447 392 420 B
+    chain_tex = sum(a * b for a, b in sizes[1:])
     for name, flt in (("box", dx.TEX_FILTER_BOX), ("cubic", dx.TEX_FILTER_CUBIC)):
         dt = timed(lambda: ctx.generate_mips_device(levels, flt), 5)
-        out[f"mips_{name}_8192"] = {"ms": round(dt * 1e3, 3), "algorithmic_GBs": round(chain_bytes / dt / 1e9, 1)}
+        e = entry(dt, chain_tex, chain_bytes, "profiles/r02_kernels.md")
+        gold = golden_case(f"cfg4_{name}")
+        if gold:
+            e["identical_to_reference_golden"] = [hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() for t in bufs] == gold["levels"]
+        out[f"cfg4_mips_{name}_8192"] = e
+    ctx.generate_mips_device(levels, dx.TEX_FILTER_BOX)
     bc3 = [torch.empty(dx.compute_pitch(dx.DXGI_FORMAT_BC3_UNORM, a, b)[1], dtype=torch.uint8, device=dev) for a, b in sizes]
     dsts = [dx.capi.device_image(t.data_ptr(), a, b, dx.DXGI_FORMAT_BC3_UNORM) for t, (a, b) in zip(bc3, sizes)]
     dt = timed(lambda: ctx.compress_many_device(levels, dsts, 0, 0.5), 5)
-    tex = sum(a * b for a, b in sizes)
-    out["mipchain_bc3_8192"] = {"ms": round(dt * 1e3, 3), "Mtexels_s": round(tex / dt / 1e6, 1), "algorithmic_GBs": round(tex * 5.0 / dt / 1e9, 1)}
-    # cfg5 (1024 x 2048^2 RGBA8 -> BC7) on a bounded sample: 8 distinct 2048^2 images through the array entry point
-    n5, side5 = 8, 2048
-    imgs5 = [torch.roll(src.reshape(HEIGHT, WIDTH, 4)[:side5, :side5], shifts=(17 * i, 29 * i), dims=(0, 1)).contiguous() for i in range(n5)]
-    sp5 = dx.compute_pitch(dx.DXGI_FORMAT_BC7_UNORM, side5, side5)[1]
-    outs5 = [torch.empty(sp5, dtype=torch.uint8, device=dev) for _ in range(n5)]
-    s5 = [dx.capi.device_image(t.data_ptr(), side5, side5, RGBA8) for t in imgs5]
-    d5 = [dx.capi.device_image(t.data_ptr(), side5, side5, dx.DXGI_FORMAT_BC7_UNORM) for t in outs5]
-    dt = timed(lambda: ctx.compress_many_device(s5, d5, 0, 0.5), 1)
-    out["bc7_batch_8x2048"] = {"ms": round(dt * 1e3, 2), "Mtexels_s": round(n5 * side5 * side5 / dt / 1e6, 2), "sample": "8 of cfg5's 1024 images"}
-    # The host-buffer boundary (dxtex_compress: pageable H2D + kernels + D2H), i.e. the PCIe-inclusive rate of the headline
-    # and of BC1 -- never the metric, reported so the DESIGN.md note has a measured number behind it.
-    for name, fmt, flags, n in (("bc7", dx.DXGI_FORMAT_BC7_UNORM, 0, 1), ("bc1", dx.DXGI_FORMAT_BC1_UNORM, 0, 5)):
-        fn = lambda: ctx.compress(img, WIDTH, HEIGHT, RGBA8, fmt, flags, 0.5)
-        fn()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        dt = (time.perf_counter() - t0) / n
-        out[f"{name}_4096_host_buffers"] = {"ms": round(dt * 1e3, 2), "Mtexels_s": round(WIDTH * HEIGHT / dt / 1e6, 1)}
+    tex4 = sum(a * b for a, b in sizes)
+    e = entry(dt, tex4, 447392452, "profiles/r02_kernels.md")
+    gold = golden_case("cfg4_box")
+    if gold:
+        e["identical_to_reference_golden"] = [hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() for t in bc3] == gold["bc3_levels"]
+    out["cfg4_mipchain_bc3_8192"] = e
+    del big, bufs, bc3
     return out
+
+
+def cfg5_shard(ctx, dev, rank, world, per_rank):
+    """cfg5 (1024 x 2048^2 RGBA8 -> BC7, image i on GPU i mod N): this rank's first `per_rank` images of its shard, host pointers in,
+    host pointers out through dxtex_compress_many (pinned double-buffered H2D / D2H overlapped with the search kernels). 16 distinct
+    host images are cycled. Returns (seconds, texels)."""
+    import directxtex_amd as dx
+    from directxtex_amd import sharding, synth
+    side = 2048
+    distinct = {}
+
+    def load(i):
+        if i % 16 not in distinct:
+            distinct[i % 16] = synth.survey_rgba8(side, side, 1000 + (i % 16), "opaque")
+        return distinct[i % 16]
+
+    mine = sharding.images_for_rank(1024, world, rank)[:per_rank]
+    for i in mine:
+        load(i)                                           # image synthesis is not part of the measurement
+    t0 = time.perf_counter()
+    res = sharding.run_shard(1024, world, rank, load, lambda imgs: ctx.compress_many(imgs, side, side, dx.DXGI_FORMAT_R8G8B8A8_UNORM,
+                                                                                    dx.DXGI_FORMAT_BC7_UNORM, 0, 0.5), batch=128, limit=per_rank)
+    dt = time.perf_counter() - t0
+    assert sorted(res) == mine
+    return dt, float(len(mine)) * side * side
+
+
+_GOLD = None
+
+
+def golden_case(cid):
+    global _GOLD
+    if _GOLD is None:
+        p = os.path.join(ROOT, "tests", "golden", "fullsize.json")
+        _GOLD = json.load(open(p)) if os.path.exists(p) else {"cases": {}}
+    return _GOLD["cases"].get(cid)
 
 
 def main():
@@ -163,7 +254,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (BC1/BC3/BC6H/mips/decode) reported next to the headline")
+    ap.add_argument("--cpu-full", action="store_true", help="run the reference on the whole 4096^2 image (about 3.5 min on 128 threads)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (cfg3 / cfg4 / cfg5 shard / BC1-5 / decode) reported next to the headline")
+    ap.add_argument("--cfg5-images", type=int, default=16, help="images of the cfg5 shard every rank compresses after the timed region (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -183,7 +276,7 @@ def main():
     ctx = dx.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 
-    img = make_image(seed=2 + rank)                       # each GPU compresses its own image
+    img = make_image(rank)                                # each GPU compresses its own image
     src = torch.from_numpy(img).to(dev)
     rp, sp = dx.compute_pitch(dx.DXGI_FORMAT_BC7_UNORM, WIDTH, HEIGHT)
     dst = torch.empty(sp, dtype=torch.uint8, device=dev)
@@ -201,18 +294,38 @@ def main():
 
     barrier()
     torch.cuda.synchronize(dev)
-    ctx.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernels = ctx.profile_end()
 
     # whole-job throughput: texels of all ranks / slowest rank's time (no data-path collective anywhere)
     elapsed, texels = sharding.aggregate(elapsed, float(WIDTH) * HEIGHT * args.steps, world, dev)
     value = texels / elapsed / 1e6
+
+    # per-kernel durations: a separate, untimed pass with hipEvents around every launch on the launch stream
+    ctx.profile_begin()
+    nprof = 2
+    for _ in range(nprof):
+        step()
+    kernels = ctx.profile_end()
+
+    # cfg5 shard: every rank, after the timed region (reported next to the headline; its own max-over-ranks timing)
+    cfg5 = None
+    if args.cfg5_images > 0 and not args.no_extra:
+        barrier()
+        try:
+            dt5, tex5 = cfg5_shard(ctx, dev, rank, world, args.cfg5_images)
+            dt5, tex5 = sharding.aggregate(dt5, tex5, world, dev)
+            cfg5 = {"images": int(round(tex5 / (2048 * 2048))), "seconds": round(dt5, 3), "Mtexels_s": round(tex5 / dt5 / 1e6, 2),
+                    "workload": f"cfg5 shard: images i = rank (mod {world}) of 1024 x 2048^2 RGBA8 -> BC7, the first {args.cfg5_images} per GPU, host buffers in and "
+                                "out through dxtex_compress_many (PCIe-inclusive)", "roofline": hbm_roofline(tex5 * 5.0, dt5 * 1e3)}
+        except Exception as e:
+            cfg5 = {"error": repr(e)}
+            if distributed:
+                raise
 
     if rank == 0:
         # ---- roofline of the dominant kernel -----------------------------------------------------------
@@ -221,14 +334,12 @@ def main():
         algo_bytes = ALGO_BYTES_PER_TEXEL * WIDTH * HEIGHT
         roof = None
         if dom:
-            achieved = algo_bytes / (per_launch[dom] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                    "algorithmic_bytes_per_launch": int(algo_bytes), "kernel_ms": round(per_launch[dom], 4),
-                    "note": "BC7 at the reference's search depth is VALU-bound (integer endpoint search); HBM "
-                            "fraction is reported as the contract asks, VALU utilisation is in profiles/",
-                    "all_kernels_ms": {k: round(v, 4) for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])},
-                    "step_kernel_ms": round(sum(per_launch.values()), 4)}
+            roof = hbm_roofline(algo_bytes, per_launch[dom], dom)
+            roof["note"] = ("BC7 at the reference's search depth is VALU-bound (integer endpoint search); the HBM fraction is reported as the "
+                            "contract asks, the VALU issue utilisation of the same kernel is under `valu`")
+            roof["all_kernels_ms"] = {k: round(v, 4) for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])}
+            roof["step_kernel_ms"] = round(sum(ms for ms, n in kernels.values()) / nprof, 4)
+            roof["step_hbm_frac"] = round(algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6)
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if roof and os.path.exists(pmc):
             try:
@@ -237,45 +348,51 @@ def main():
                     roof["traffic"] = t.get("hbm_bytes_per_launch")
                     roof["traffic_source"] = t.get("source")
                     if t.get("valu"):
-                        roof["valu_from_profile"] = t["valu"]      # SQ counters of the same kernel (profiles/): what actually bounds it
+                        roof["valu"] = t["valu"]               # SQ counters of the same kernel (profiles/): what actually bounds it
             except Exception:
                 pass
 
-        # ---- quality + CPU baseline (N = 1 only) ---------------------------------------------------------
+        # ---- parity + quality + CPU baseline (N = 1 only) --------------------------------------------------
         cpu = None
+        parity = {}
         extra = {}
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1:
             try:
-                res = cpu_baseline(img)
-                if res:
-                    cpu, (x0, y0, side, ref_payload) = res
-                    import oracle
-                    out = dst.cpu().numpy().reshape(HEIGHT // 4, WIDTH // 4, 16)
-                    got = np.ascontiguousarray(out[y0 // 4:(y0 + side) // 4, x0 // 4:(x0 + side) // 4]).reshape(-1, 16)
-                    ref = ref_payload.reshape(-1, 16)
-                    crop = np.ascontiguousarray(img[y0:y0 + side, x0:x0 + side])
-                    srcf = oracle.load_image(crop, side, side, 28)
-                    extra["gpu_psnr_db_on_sample"] = round(oracle.psnr_rgb(oracle.decode_image(got.reshape(-1), side, side, 98)[..., :3], srcf[..., :3]), 3)
-                    extra["blocks_identical_to_reference_on_sample"] = float((got == ref).all(axis=1).mean())
+                payload = dst.cpu().numpy()
+                gold = golden_case("cfg2_bc7_4096")
+                if gold and hashlib.sha256(img.tobytes()).hexdigest() == gold["input_sha256"]:
+                    bands = band_sha(payload, WIDTH, HEIGHT)
+                    parity["golden"] = "tests/golden/fullsize.json: reference output for the whole 4096^2 image (1 048 576 blocks)"
+                    parity["golden_bands_identical"] = sum(1 for a, b in zip(bands, gold["bands"]) if a == b)
+                    parity["golden_bands"] = len(gold["bands"])
+                    parity["full_image_identical_to_reference"] = bands == gold["bands"]
+                    parity["reference_psnr_db_full_image"] = gold["psnr_db"]
+                parity["gpu_psnr_db_full_image"] = round(gpu_psnr(ctx, dev, src, dst, 28, 98, WIDTH, HEIGHT), 4)
+                if not args.no_cpu_baseline:
+                    cpu, live = cpu_baseline(img, payload, args.cpu_full)
+                    parity.update(live)
             except Exception as e:                              # the baseline must never break the bench line
                 extra["cpu_baseline_error"] = repr(e)
 
         if n_gpus == 1 and not args.no_extra:
             try:
-                extra["other_workloads"] = other_workloads(ctx, dev, img)
+                extra["other_workloads"] = other_workloads(ctx, dev, img, rank, world)
             except Exception as e:
                 extra["other_workloads_error"] = repr(e)
+        if cfg5:
+            extra.setdefault("other_workloads", {})["cfg5_shard"] = cfg5
 
         line = {
             "metric": "Mtexels/s BC7 encode (4096^2 RGBA8, TEX_COMPRESS_DEFAULT)",
             "value": round(value, 3), "unit": "Mtexels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "4096x4096 RGBA8 -> BC7_UNORM, TEX_COMPRESS_DEFAULT, one image per GPU, source and "
+            "config": {"workload": "cfg2: 4096x4096 RGBA8 -> BC7_UNORM, TEX_COMPRESS_DEFAULT, one image per GPU, source and "
                                    "payload resident in HBM (dxtex_compress_device)",
-                       "image": "directxtex_amd.synth.rgba8 hash-noise recipe, opaque, seed 2+rank",
+                       "image": "SURVEY.md 8d cfg2 recipe (directxtex_amd.synth.survey_rgba8: LCG gradients + 4-octave noise, flat to noisy blocks), "
+                                "opaque, seed 2+rank",
                        "sharding": f"image-per-GPU x{n_gpus}, no data-path collective"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)

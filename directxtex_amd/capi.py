@@ -215,6 +215,18 @@ class Context:
         b = (Image * n)(*dsts)
         self._check(_lib.dxtex_compress_many_device(self._h, a, b, n, flags, threshold), "compress_many_device")
 
+    def compress_many(self, images, width, height, src_format, dst_format, flags=0, threshold=0.5):
+        """Array of same-sized host images -> list of BC payloads, through dxtex_compress_many (the cfg5 entry point: chunks of the
+        array are staged through pinned memory on copy streams while the previous chunk is searched)."""
+        images = [np.ascontiguousarray(im) for im in images]
+        n = len(images)
+        rp, sp = compute_pitch(dst_format, width, height)
+        outs = [np.zeros(sp, np.uint8) for _ in range(n)]
+        srcs = (Image * n)(*[_host_image(im, width, height, src_format) for im in images])
+        dsts = (Image * n)(*[Image(width, height, dst_format, rp, sp, o.ctypes.data) for o in outs])
+        self._check(_lib.dxtex_compress_many(self._h, srcs, dsts, n, flags, threshold), "compress_many")
+        return outs
+
     def encode_blocks(self, bc_format, rgba, flags=0, threshold=0.5):
         rgba = np.ascontiguousarray(rgba, np.float32).reshape(-1, 16, 4)
         n = rgba.shape[0]

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <cstdint>
 #include <cstring>
 #include <new>
 #include <string>
@@ -50,6 +52,14 @@ struct dxtex_ctx
     std::vector<uint8_t> triHost;
     void* triPinned = nullptr; size_t triPinnedBytes = 0; hipEvent_t triConsumed = nullptr; bool triPending = false;
     void* mseBuf = nullptr; size_t mseBytes = 0;
+    // dxtex_compress_many (host pointers): double-buffered pinned + device staging, copy streams on either side of ctx->stream
+    struct Lane
+    {
+        void* pinIn = nullptr; size_t pinInBytes = 0; void* pinOut = nullptr; size_t pinOutBytes = 0;
+        void* devIn = nullptr; size_t devInBytes = 0; void* devOut = nullptr; size_t devOutBytes = 0;
+        hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
+    } lane[2];
+    hipStream_t h2d = nullptr, d2h = nullptr;
     std::string lastError;
     bool profiling = false;
     Marks marks;
@@ -140,8 +150,12 @@ dxtex_hresult compress_view(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width, s
 {
     const FmtInfo* in = format_info(srcFormat);
     const FmtInfo* out = format_info(dstFormat);
-    if (!out || !(out->cls & FC_BC)) return fail(ctx, in && !(in->cls & FC_BC) ? DXTEX_E_NOT_SUPPORTED : DXTEX_E_INVALIDARG, "destination is not a supported BC format");
-    if (in && (in->cls & FC_BC)) return fail(ctx, DXTEX_E_INVALIDARG, "source image is already compressed");
+    // the reference's order (DirectXTexCompress.cpp:671-676): E_INVALIDARG for a compressed source or an uncompressed target first,
+    // HRESULT_E_NOT_SUPPORTED for formats the path cannot take (typeless / planar / palettised there; anything without kernels here)
+    const auto bcId = [](int f) { return (f >= 70 && f <= 84) || (f >= 94 && f <= 99); };      // IsCompressed: BC1_TYPELESS .. BC5_SNORM, BC6H_TYPELESS .. BC7_UNORM_SRGB
+    if (bcId(srcFormat)) return fail(ctx, DXTEX_E_INVALIDARG, "source image is already compressed");
+    if (!bcId(dstFormat)) return fail(ctx, DXTEX_E_INVALIDARG, "destination is not a BC format");
+    if (!out || !(out->cls & FC_BC)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "destination BC format is not supported (typeless)");
     if (!in) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "source format is not supported by the MI355X path");
     if (!width || !height) return fail(ctx, DXTEX_E_INVALIDARG, "empty image");
     if (width > 0xFFFFFFFCull || height > 0xFFFFFFFCull) return fail(ctx, DXTEX_E_INVALIDARG, "image too large");
@@ -245,6 +259,18 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
     if (ctx->triPinned) (void)hipHostFree(ctx->triPinned);
     if (ctx->triConsumed) (void)hipEventDestroy(ctx->triConsumed);
     if (ctx->mseBuf) (void)hipFree(ctx->mseBuf);
+    if (ctx->h2d) { (void)hipStreamSynchronize(ctx->h2d); (void)hipStreamDestroy(ctx->h2d); }
+    if (ctx->d2h) { (void)hipStreamSynchronize(ctx->d2h); (void)hipStreamDestroy(ctx->d2h); }
+    for (dxtex_ctx::Lane& l : ctx->lane)
+    {
+        if (l.pinIn) (void)hipHostFree(l.pinIn);
+        if (l.pinOut) (void)hipHostFree(l.pinOut);
+        if (l.devIn) (void)hipFree(l.devIn);
+        if (l.devOut) (void)hipFree(l.devOut);
+        if (l.uploaded) (void)hipEventDestroy(l.uploaded);
+        if (l.computed) (void)hipEventDestroy(l.computed);
+        if (l.downloaded) (void)hipEventDestroy(l.downloaded);
+    }
     for (hipEvent_t e : ctx->marks.pool) (void)hipEventDestroy(e);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
@@ -255,7 +281,15 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
 dxtex_hresult dxtex_ctx_set_stream(dxtex_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return DXTEX_E_POINTER;
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->ownStream;
+    hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->ownStream;
+    if (next != ctx->stream)
+    {
+        // the context's scratch, staging and filter tables are ordered by ONE stream: work queued on the old one must be done
+        // before kernels on the new one may reuse them
+        ScopedDevice sd(ctx->device);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->stream = next;
+    }
     return DXTEX_S_OK;
 }
 
@@ -443,36 +477,134 @@ dxtex_hresult dxtex_ctx_prepare(dxtex_ctx* ctx, size_t width, size_t height, int
     return DXTEX_S_OK;
 }
 
-// Array form of dxtex_compress with host pointers: every image is staged into one device buffer, the whole array is
-// submitted as one dxtex_compress_many_device, and the payloads come back together.
+// Array form of dxtex_compress with host pointers (the cfg5 entry point: DirectXTexCompress.cpp:794-833 loops over the images of
+// an array). The array is cut into chunks of about DXTEX_MANY_CHUNK_TEXELS texels (default 32 Mi: eight 2048^2 images, a pass
+// size at which the BC6H / BC7 search pipeline runs at its large-image rate); chunk k+1 is gathered into pinned memory and
+// uploaded on a copy stream while chunk k is searched on the context's stream, and payloads come back on a second copy stream:
+//   host gather -> [h2d] pinIn -> devIn -> [ctx->stream] kernels -> devOut -> [d2h] pinOut -> host scatter
+// with two lanes of buffers, so PCIe traffic in both directions overlaps the kernels (for BC1-BC5, where a 4096^2 image is
+// 0.1-0.5 ms of kernel time and 1.6 ms of PCIe, it is the copies that overlap each other).
+namespace
+{
+dxtex_hresult ensure_pinned(dxtex_ctx* ctx, void** buf, size_t* have, size_t need)
+{
+    if (*have >= need) return DXTEX_S_OK;
+    if (*buf) { HIP_TRY(ctx, hipHostFree(*buf)); *buf = nullptr; *have = 0; }
+    const size_t bytes = std::max<size_t>(need, 1u << 20);
+    HIP_TRY(ctx, hipHostMalloc(buf, bytes, hipHostMallocDefault));
+    *have = bytes;
+    return DXTEX_S_OK;
+}
+
+struct ManyChunk { size_t first, count, inBytes, outBytes; };
+
+// tight size checks for host-pointer images: a pitch below the format's minimum would make the kernels read or write past the staging
+dxtex_hresult check_host_pitches(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, size_t* srcBytes, size_t* dstBytes)
+{
+    size_t minSrcRow = 0, minSrcSlice = 0, minDstRow = 0, minDstSlice = 0;
+    if (dxtex_compute_pitch(src->format, src->width, src->height, &minSrcRow, &minSrcSlice) != DXTEX_S_OK ||
+        dxtex_compute_pitch(dst->format, dst->width, dst->height, &minDstRow, &minDstSlice) != DXTEX_S_OK)
+        return fail(ctx, DXTEX_E_INVALIDARG, "image too large");
+    if (src->rowPitch < minSrcRow || dst->rowPitch < minDstRow) return fail(ctx, DXTEX_E_INVALIDARG, "rowPitch is smaller than the format's minimum (ComputePitch)");
+    const size_t srcRows = (minSrcRow && minSrcSlice) ? minSrcSlice / minSrcRow : src->height;
+    const size_t dstRows = (minDstRow && minDstSlice) ? minDstSlice / minDstRow : dst->height;
+    if (src->rowPitch > SIZE_MAX / std::max<size_t>(1, srcRows) || dst->rowPitch > SIZE_MAX / std::max<size_t>(1, dstRows))
+        return fail(ctx, DXTEX_E_INVALIDARG, "rowPitch x rows overflows");
+    *srcBytes = src->rowPitch * srcRows;
+    *dstBytes = dst->rowPitch * dstRows;
+    return DXTEX_S_OK;
+}
+}
+
 dxtex_hresult dxtex_compress_many(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts, size_t count, uint32_t flags, float threshold)
 {
     if (!ctx) return DXTEX_E_POINTER;
     if (!srcs || !dsts || !count) return fail(ctx, DXTEX_E_INVALIDARG, "empty batch");
     ScopedDevice sd(ctx->device);
-    std::vector<dxtex_image> ds(count), dd(count);
-    std::vector<size_t> atS(count), atD(count), bytesD(count);
-    size_t totalS = 0, totalD = 0;
-    for (size_t i = 0; i < count; ++i)
+    static const uint64_t chunkTexels = getenv("DXTEX_MANY_CHUNK_TEXELS") ? std::max<uint64_t>(1, strtoull(getenv("DXTEX_MANY_CHUNK_TEXELS"), nullptr, 10)) : (32ull << 20);
+    std::vector<size_t> inBytes(count), outBytes(count);
+    std::vector<ManyChunk> chunks;
     {
-        const dxtex_hresult hr = check_pair(ctx, &srcs[i], &dsts[i]);
+        ManyChunk cur = { 0, 0, 0, 0 };
+        uint64_t texels = 0;
+        for (size_t i = 0; i < count; ++i)
+        {
+            dxtex_hresult hr = check_pair(ctx, &srcs[i], &dsts[i]);
+            if (hr == DXTEX_S_OK) { SrcView v; hr = compress_view(ctx, nullptr, srcs[i].width, srcs[i].height, srcs[i].format, srcs[i].rowPitch, dsts[i].format, flags, &v); }
+            if (hr == DXTEX_S_OK) hr = check_host_pitches(ctx, &srcs[i], &dsts[i], &inBytes[i], &outBytes[i]);
+            if (hr != DXTEX_S_OK) return hr;
+            const uint64_t t = uint64_t(srcs[i].width) * srcs[i].height;
+            if (cur.count && texels + t > chunkTexels) { chunks.push_back(cur); cur = { i, 0, 0, 0 }; texels = 0; }
+            ++cur.count; texels += t;
+            cur.inBytes += (inBytes[i] + 255) & ~size_t(255);
+            cur.outBytes += (outBytes[i] + 255) & ~size_t(255);
+        }
+        chunks.push_back(cur);
+    }
+    if (!ctx->h2d) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->h2d, hipStreamNonBlocking));
+    if (!ctx->d2h) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->d2h, hipStreamNonBlocking));
+    for (dxtex_ctx::Lane& l : ctx->lane)
+    {
+        if (!l.uploaded) HIP_TRY(ctx, hipEventCreateWithFlags(&l.uploaded, hipEventDisableTiming));
+        if (!l.computed) HIP_TRY(ctx, hipEventCreateWithFlags(&l.computed, hipEventDisableTiming));
+        if (!l.downloaded) HIP_TRY(ctx, hipEventCreateWithFlags(&l.downloaded, hipEventDisableTiming));
+    }
+
+    // payload of chunk c: pinned -> the caller's images (after its download has finished)
+    auto scatter = [&](size_t c) -> dxtex_hresult
+    {
+        dxtex_ctx::Lane& l = ctx->lane[c & 1];
+        HIP_TRY(ctx, hipEventSynchronize(l.downloaded));
+        size_t at = 0;
+        for (size_t i = chunks[c].first; i < chunks[c].first + chunks[c].count; ++i)
+        {
+            std::memcpy(dsts[i].pixels, static_cast<const uint8_t*>(l.pinOut) + at, outBytes[i]);
+            at += (outBytes[i] + 255) & ~size_t(255);
+        }
+        return DXTEX_S_OK;
+    };
+
+    std::vector<dxtex_image> ds, dd;
+    for (size_t c = 0; c < chunks.size(); ++c)
+    {
+        const ManyChunk& ch = chunks[c];
+        dxtex_ctx::Lane& l = ctx->lane[c & 1];
+        if (c >= 2) { const dxtex_hresult hr = scatter(c - 2); if (hr != DXTEX_S_OK) return hr; }      // frees this lane's pinOut (and, stream-ordered, devOut)
+        dxtex_hresult hr = ensure_pinned(ctx, &l.pinIn, &l.pinInBytes, ch.inBytes); if (hr != DXTEX_S_OK) return hr;
+        hr = ensure_pinned(ctx, &l.pinOut, &l.pinOutBytes, ch.outBytes); if (hr != DXTEX_S_OK) return hr;
+        hr = ensure(ctx, &l.devIn, &l.devInBytes, ch.inBytes); if (hr != DXTEX_S_OK) return hr;
+        hr = ensure(ctx, &l.devOut, &l.devOutBytes, ch.outBytes); if (hr != DXTEX_S_OK) return hr;
+        // gather (pinIn of this lane was last read by the upload of chunk c - 2, which the kernels of c - 2 waited for, which the download
+        // of c - 2 waited for, which scatter(c - 2) has just waited for)
+        ds.assign(srcs + ch.first, srcs + ch.first + ch.count);
+        dd.assign(dsts + ch.first, dsts + ch.first + ch.count);
+        size_t atIn = 0, atOut = 0;
+        for (size_t k = 0; k < ch.count; ++k)
+        {
+            const size_t i = ch.first + k;
+            std::memcpy(static_cast<uint8_t*>(l.pinIn) + atIn, srcs[i].pixels, inBytes[i]);
+            ds[k].pixels = static_cast<uint8_t*>(l.devIn) + atIn;
+            dd[k].pixels = static_cast<uint8_t*>(l.devOut) + atOut;
+            atIn += (inBytes[i] + 255) & ~size_t(255);
+            atOut += (outBytes[i] + 255) & ~size_t(255);
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(l.devIn, l.pinIn, atIn, hipMemcpyHostToDevice, ctx->h2d));
+        HIP_TRY(ctx, hipEventRecord(l.uploaded, ctx->h2d));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, l.uploaded, 0));
+        hr = dxtex_compress_many_device(ctx, ds.data(), dd.data(), ch.count, flags, threshold);
+        if (hr != DXTEX_S_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->d2h); return hr; }
+        HIP_TRY(ctx, hipEventRecord(l.computed, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, l.computed, 0));
+        HIP_TRY(ctx, hipMemcpyAsync(l.pinOut, l.devOut, atOut, hipMemcpyDeviceToHost, ctx->d2h));
+        HIP_TRY(ctx, hipEventRecord(l.downloaded, ctx->d2h));
+        // the next upload into this lane's devIn (chunk c + 2) must not overtake these kernels
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, l.computed, 0));
+    }
+    for (size_t c = chunks.size() >= 2 ? chunks.size() - 2 : 0; c < chunks.size(); ++c)
+    {
+        const dxtex_hresult hr = scatter(c);
         if (hr != DXTEX_S_OK) return hr;
-        atS[i] = totalS; totalS += (srcs[i].rowPitch * srcs[i].height + 255) & ~size_t(255);
-        bytesD[i] = dsts[i].rowPitch * std::max<size_t>(1, (srcs[i].height + 3) / 4);
-        atD[i] = totalD; totalD += (bytesD[i] + 255) & ~size_t(255);
     }
-    dxtex_hresult hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, totalS); if (hr != DXTEX_S_OK) return hr;
-    hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, totalD); if (hr != DXTEX_S_OK) return hr;
-    for (size_t i = 0; i < count; ++i)
-    {
-        ds[i] = srcs[i]; ds[i].pixels = static_cast<uint8_t*>(ctx->stageIn) + atS[i];
-        dd[i] = dsts[i]; dd[i].pixels = static_cast<uint8_t*>(ctx->stageOut) + atD[i];
-        HIP_TRY(ctx, hipMemcpyAsync(ds[i].pixels, srcs[i].pixels, srcs[i].rowPitch * srcs[i].height, hipMemcpyHostToDevice, ctx->stream));
-    }
-    hr = dxtex_compress_many_device(ctx, ds.data(), dd.data(), count, flags, threshold);
-    if (hr != DXTEX_S_OK) return hr;
-    for (size_t i = 0; i < count; ++i)
-        HIP_TRY(ctx, hipMemcpyAsync(dsts[i].pixels, dd[i].pixels, bytesD[i], hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -481,16 +613,10 @@ dxtex_hresult dxtex_compress(dxtex_ctx* ctx, const dxtex_image* src, const dxtex
 {
     dxtex_hresult hr = check_pair(ctx, src, dst);
     if (hr != DXTEX_S_OK) return hr;
-    const FmtInfo* in = format_info(src->format);
-    const FmtInfo* out = format_info(dst->format);
-    if (in && (in->cls & FC_BC)) return fail(ctx, DXTEX_E_INVALIDARG, "source image is already compressed");
-    if (!out || !(out->cls & FC_BC)) return fail(ctx, DXTEX_E_INVALIDARG, "destination is not a BC format");
-    if (!in) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "source format is not supported by the MI355X path");
-
+    { SrcView v; hr = compress_view(ctx, nullptr, src->width, src->height, src->format, src->rowPitch, dst->format, flags, &v); if (hr != DXTEX_S_OK) return hr; }
     ScopedDevice sd(ctx->device);
-    const size_t srcBytes = src->rowPitch * src->height;
-    const size_t nbh = std::max<size_t>(1, (src->height + 3) / 4);
-    const size_t dstBytes = dst->rowPitch * nbh;
+    size_t srcBytes = 0, dstBytes = 0;
+    hr = check_host_pitches(ctx, src, dst, &srcBytes, &dstBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
@@ -585,8 +711,9 @@ dxtex_hresult dxtex_decompress(dxtex_ctx* ctx, const dxtex_image* src, const dxt
     dxtex_hresult hr = check_pair(ctx, src, dst);
     if (hr != DXTEX_S_OK) return hr;
     ScopedDevice sd(ctx->device);
-    const size_t nbh = std::max<size_t>(1, (src->height + 3) / 4);
-    const size_t srcBytes = src->rowPitch * nbh, dstBytes = dst->rowPitch * dst->height;
+    size_t srcBytes = 0, dstBytes = 0;
+    if (format_info(src->format) && format_info(dst->format)) { hr = check_host_pitches(ctx, src, dst, &srcBytes, &dstBytes); if (hr != DXTEX_S_OK) return hr; }
+    else { srcBytes = src->rowPitch * std::max<size_t>(1, (src->height + 3) / 4); dstBytes = dst->rowPitch * dst->height; }      // submit_decompress rejects the formats below
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
@@ -949,7 +1076,8 @@ dxtex_hresult dxtex_resize(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_i
     dxtex_hresult hr = check_resize(ctx, src, dst, filter, &mode);
     if (hr != DXTEX_S_OK) return hr;
     ScopedDevice sd(ctx->device);
-    const size_t srcBytes = src->rowPitch * src->height, dstBytes = dst->rowPitch * dst->height;
+    size_t srcBytes = 0, dstBytes = 0;
+    hr = check_host_pitches(ctx, src, dst, &srcBytes, &dstBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
@@ -1004,7 +1132,8 @@ dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_
     dxtex_hresult hr = check_convert(ctx, src, dst, filter, &plan);
     if (hr != DXTEX_S_OK) return hr;
     ScopedDevice sd(ctx->device);
-    const size_t srcBytes = src->rowPitch * src->height, dstBytes = dst->rowPitch * dst->height;
+    size_t srcBytes = 0, dstBytes = 0;
+    hr = check_host_pitches(ctx, src, dst, &srcBytes, &dstBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
@@ -1113,7 +1242,8 @@ dxtex_hresult dxtex_premultiply_alpha(dxtex_ctx* ctx, const dxtex_image* src, co
     dxtex_hresult hr = check_pmalpha(ctx, src, dst);
     if (hr != DXTEX_S_OK) return hr;
     ScopedDevice sd(ctx->device);
-    const size_t srcBytes = src->rowPitch * src->height, dstBytes = dst->rowPitch * dst->height;
+    size_t srcBytes = 0, dstBytes = 0;
+    hr = check_host_pitches(ctx, src, dst, &srcBytes, &dstBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));

@@ -11,6 +11,35 @@ def images_for_rank(n_images, world, rank):
     return list(range(rank, n_images, world))
 
 
+def run_shard(n_images, world, rank, load, compress_many, batch=128, limit=None):
+    """This rank's part of an image-sharded job: images i = rank (mod world) of n_images, `batch` at a time through
+    compress_many(list of images) -> list of payloads (Context.compress_many: dxtex_compress_many stages each batch's chunks
+    through pinned memory while the previous chunk is searched). load(i) -> image i. Returns {image index: payload}.
+    No rank ever touches another rank's images or results."""
+    mine = images_for_rank(n_images, world, rank)
+    if limit is not None:
+        mine = mine[:limit]
+    out = {}
+    for at in range(0, len(mine), batch):
+        idx = mine[at:at + batch]
+        for i, payload in zip(idx, compress_many([load(i) for i in idx])):
+            out[i] = payload
+    return out
+
+
+def gather_index(results, world):
+    """Bookkeeping only (object all_gather of (index, sha256) pairs - no texture data crosses ranks): every rank learns which image
+    indices were compressed where, and a digest of each payload. Returns a list over ranks of {index: hex digest}."""
+    import hashlib
+    mine = {int(i): hashlib.sha256(bytes(memoryview(p))).hexdigest() for i, p in results.items()}
+    if world <= 1:
+        return [mine]
+    import torch.distributed as dist
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    return got
+
+
 def init_from_env(backend, device=None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1. Returns (rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -98,17 +98,22 @@ def survey_rgba8(width, height, seed=2, alpha="opaque"):
     B = diagonal + 5-bit noise, the noise summed over 4 octaves (cells of 1, 2, 4, 8 texels) and scaled per 64 x 64 region
     by a gain of 0, 1, 2 or 4 drawn from the same LCG, so that 4 x 4 blocks range from flat (pure gradient) to noisy.
     alpha: 'opaque' (255) | 'random' (one LCG byte per texel). (H, W, 4) uint8."""
-    ys, xs = np.meshgrid(np.arange(height, dtype=np.int64), np.arange(width, dtype=np.int64), indexing="ij")
-    base = [xs * 255 // max(1, width - 1), ys * 255 // max(1, height - 1), (xs + ys) * 255 // max(1, width + height - 2)]
-    gain = np.array([0, 1, 2, 4], np.int64)[_lcg_plane(seed * 7919 + 5, height, width, 64) >> 6]
+    xs = np.arange(width, dtype=np.int64)[None, :]
+    ys = np.arange(height, dtype=np.int64)[:, None]
+    base = [(xs * 255 // max(1, width - 1)).astype(np.int16), (ys * 255 // max(1, height - 1)).astype(np.int16),
+            ((xs + ys) * 255 // max(1, width + height - 2)).astype(np.int16)]
+    gain = np.array([0, 1, 2, 4], np.int16)[_lcg_plane(seed * 7919 + 5, height, width, 64) >> 6]
     out = np.empty((height, width, 4), np.uint8)
     for c in range(3):
         bits = 5 if c == 2 else 4
-        acc = np.zeros((height, width), np.int64)
+        acc = np.zeros((height, width), np.int16)
         for octave in range(4):
-            n = _lcg_plane(seed * 7919 + 101 * (octave * 3 + c) + 11, height, width, 1 << octave).astype(np.int64) >> (8 - bits)
-            acc += n - (1 << (bits - 1))
-        out[..., c] = np.clip(base[c] + ((gain * acc) >> 1), 0, 255).astype(np.uint8)
+            acc += (_lcg_plane(seed * 7919 + 101 * (octave * 3 + c) + 11, height, width, 1 << octave) >> (8 - bits)).astype(np.int16)
+        acc -= 4 << (bits - 1)
+        acc *= gain
+        acc >>= 1
+        acc += base[c]
+        out[..., c] = np.clip(acc, 0, 255)
     out[..., 3] = 255 if alpha == "opaque" else _lcg_plane(seed * 7919 + 977, height, width, 1)
     return out
 

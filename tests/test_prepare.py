@@ -30,7 +30,7 @@ def test_prepare_then_compress(oracle):
         assert np.array_equal(got, oracle.ref_compress_image(hdr, w, h, dx.DXGI_FORMAT_R16G16B16A16_FLOAT, dx.DXGI_FORMAT_BC6H_UF16, 0, 0.5))
         # the checks of dxtex_compress
         for args, hr in (((w, h, dx.DXGI_FORMAT_BC1_UNORM, dx.DXGI_FORMAT_BC7_UNORM, 0, 1), 0x80070057),          # compressed source
-                         ((w, h, RGBA8, RGBA8, 0, 1), 0x80070032),                                              # destination not BC
+                         ((w, h, RGBA8, RGBA8, 0, 1), 0x80070057),                                              # destination not BC: E_INVALIDARG, DirectXTexCompress.cpp:671
                          ((w, h, 200, dx.DXGI_FORMAT_BC7_UNORM, 0, 1), 0x80070032),                              # unknown source format
                          ((0, h, RGBA8, dx.DXGI_FORMAT_BC7_UNORM, 0, 1), 0x80070057),
                          ((w, h, RGBA8, dx.DXGI_FORMAT_BC7_UNORM, 0, 0), 0x80070057)):

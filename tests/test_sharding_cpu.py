@@ -50,6 +50,65 @@ def test_two_rank_sharding_and_timing():
     assert outs[0]["total"] == outs[1]["total"] == 11 * 2048 * 2048
 
 
+SHARD_WORKER = r'''
+import os, sys, json, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+from directxtex_amd import sharding
+rank, world = sharding.init_from_env("gloo")
+N = 37
+calls = []
+def load(i):                                   # image i: 8 x 8 RGBA8 that depends on i only
+    return (np.arange(256, dtype=np.uint32).reshape(8, 8, 4) * (i + 1) %% 251).astype(np.uint8)
+def compress_many(imgs):                       # stand-in for Context.compress_many (no GPU here): one "payload" per image, batch-independent
+    calls.append(len(imgs))
+    return [np.frombuffer(hashlib.sha256(im.tobytes()).digest(), np.uint8) for im in imgs]
+res = sharding.run_shard(N, world, rank, load, compress_many, batch=5)
+index = sharding.gather_index(res, world)
+print(json.dumps({"rank": rank, "keys": sorted(res), "calls": calls, "index": [{str(k): v for k, v in d.items()} for d in index]}), flush=True)
+import torch.distributed as dist
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_shard_covers_every_image_once():
+    """cfg5's driver (sharding.run_shard, what bench.py's cfg5 leg and a batch tool call): with two ranks every image index is
+    compressed exactly once, on the rank i mod 2, in batches, and the assembled result does not depend on who did what - it equals
+    the single-process result."""
+    import hashlib
+    import json
+    import numpy as np
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", SHARD_WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("{")][-1]))
+    outs.sort(key=lambda d: d["rank"])
+    assert outs[0]["keys"] == list(range(0, 37, 2)) and outs[1]["keys"] == list(range(1, 37, 2))
+    assert outs[0]["calls"] == [5, 5, 5, 4] and outs[1]["calls"] == [5, 5, 5, 3]          # batches of 5, the last one short
+    # both ranks hold the same bookkeeping; the union has every index exactly once
+    assert outs[0]["index"] == outs[1]["index"]
+    merged = {}
+    for d in outs[0]["index"]:
+        for k, v in d.items():
+            assert k not in merged, f"image {k} compressed twice"
+            merged[k] = v
+    assert sorted(int(k) for k in merged) == list(range(37))
+    # ... and equals what one process computes for the whole array
+    sys.path.insert(0, ROOT)
+    from directxtex_amd import sharding
+
+    def load(i):
+        return (np.arange(256, dtype=np.uint32).reshape(8, 8, 4) * (i + 1) % 251).astype(np.uint8)
+    single = sharding.run_shard(37, 1, 0, load, lambda imgs: [np.frombuffer(hashlib.sha256(im.tobytes()).digest(), np.uint8) for im in imgs], batch=37)
+    assert {str(i): hashlib.sha256(p.tobytes()).hexdigest() for i, p in single.items()} == merged
+
+
 def test_single_rank_is_identity():
     sys.path.insert(0, ROOT)
     from directxtex_amd import sharding

@@ -15,7 +15,7 @@ def emit():
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     yy, xx = np.mgrid[0:2048, 0:2048]
     smooth = np.stack([(xx / 8) % 256, (yy / 8) % 256, ((xx + yy) / 16) % 256, 255 - (xx / 16) % 256], -1).astype(np.uint8)
-    cases = [("bench 4096 opaque", bench.make_image(2), 0),
+    cases = [("bench 4096 opaque", bench.make_image(0), 0),
              ("noise+alpha 2048", np.tile(synth.rgba8(1024, 1024, seed=9, alpha="smooth"), (2, 2, 1)), 0),
              ("random alpha 1024", synth.rgba8(1024, 1024, seed=11, alpha="random"), 0),
              ("gradients 2048", smooth, 0),
@@ -26,7 +26,7 @@ def emit():
         hdr = lambda im, s: (im.astype(np.float32) / 255.0 * s).astype(np.float16)
         spiky = (np.exp2(rng.uniform(-8, 6, (1024, 1024, 1))) * (synth.rgba8(1024, 1024, seed=4).astype(np.float32) / 255.0)).astype(np.float16)
         neg = (synth.rgba8(1024, 1024, seed=6).astype(np.float32) / 255.0 * 4.0 - 2.0).astype(np.float16)
-        cases = [("hdr bench-like 4096", hdr(bench.make_image(2), 8.0), 95), ("hdr smooth 2048", hdr(smooth, 2.0), 95),
+        cases = [("hdr bench-like 4096", hdr(bench.make_image(0), 8.0), 95), ("hdr smooth 2048", hdr(smooth, 2.0), 95),
                  ("hdr spiky 1024", spiky, 95), ("hdr signed 1024", neg, 96), ("hdr noise 1024", hdr(cases[5][1], 16.0), 95)]
     for name, img, flags in cases:
         h, w = img.shape[:2]
