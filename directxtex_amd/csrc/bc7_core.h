@@ -872,6 +872,7 @@ struct ExhState
     int o0;                 // first value of the outer variable in this window
     int aleb;
     int omin, imin, best;
+    int bestCode;           // queue code of (omin, imin) in the current window, -1 while the window has not improved on optErr
 };
 
 template<int MODE, int IM, int CHSET>
@@ -892,7 +893,7 @@ DXTEX_HD ExhState exh_window(const ExhState& in, int ch)
     s.lo = s.aleb ? blow : alow;
     s.iEnd = s.aleb ? bhigh : ahigh + 1;
     s.i = s.o > s.lo ? s.o : s.lo;
-    s.omin = 0; s.imin = 0; s.best = in.optErr;
+    s.omin = 0; s.imin = 0; s.best = in.optErr; s.bestCode = -1;
     return s;
 }
 
@@ -936,7 +937,7 @@ DXTEX_HD bool exh_begin(ExhState& s, VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, ui
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     s.optA = optA; s.optB = optB; s.optErr = optErr;
-    s.ch = 0; s.o = s.i = s.oEnd = s.iEnd = s.lo = 0; s.o0 = 0; s.aleb = 0; s.omin = s.imin = 0; s.best = optErr;
+    s.ch = 0; s.o = s.i = s.oEnd = s.iEnd = s.lo = 0; s.o0 = 0; s.aleb = 0; s.omin = s.imin = 0; s.best = optErr; s.bestCode = -1;
     s = exh_window<MODE, IM, CHSET>(s, C::CH0);
     if (s.ch < C::CH1) varpal_init<MODE, IM, CHSET>(vp, s.optA, s.optB, s.ch);
     return exh_next<MODE, IM, CHSET>(s, vp);
@@ -952,56 +953,56 @@ DXTEX_HD void exh_step(const RG& rg, ExhState& s, const VarPal<LoopCfg<MODE, IM,
     ++s.i;
 }
 
-// The same step split in two (see eval_var_bound): visiting a candidate only bounds it; candidates that might beat the best error
-// so far wait, in loop order, for their exact evaluation. The queue is drained before a window is committed, and a stale (too
-// high) `best` in the filter only lets more candidates through, so the window's result is exactly exh_step's.
-// PQ abstracts where the queue lives: ExhPendingRegs (host check) or a per-lane LDS column (search kernel).
-enum : int { kExhPendMax = 16 };
-struct ExhPendingRegs
-{
-    uint32_t slot[kExhPendMax];
-    int head, tail;
-    DXTEX_HD void clear() { head = tail = 0; }
-    DXTEX_HD int count() const { return tail - head; }
-    DXTEX_HD void push(uint32_t v) { slot[tail & (kExhPendMax - 1)] = v; ++tail; }
-    DXTEX_HD uint32_t front() const { return slot[head & (kExhPendMax - 1)]; }
-    DXTEX_HD void drop() { ++head; }
-};
+// The same step split in two (see eval_var_bound): visiting a candidate only bounds it; the candidates that might still become the
+// window's result are set aside and evaluated exactly later - in the search kernel by ALL lanes of the wavefront together, whoever's
+// candidates they are (bc7_exhaustive_kernel in bc7_encode.hip).
+// Exhaustive's loop keeps the FIRST candidate, in loop order, of those with the smallest error below the starting error (:3006 is a
+// strict '<'), so the result of a window is the minimum of (error, loop position) over its candidates - independent of the order in
+// which they are evaluated - or "no change" if no error is below the start. Both are packed into one key,
+//     key = (error << 8) | (code + 1),  code = ((o - o0) << 4) | (i - lo)   (a window is at most 11 x 11; increasing code = loop order)
+// with key 0 in the low byte for "the starting endpoints" (error optErr): the window's result is the MINIMUM KEY, an unsigned
+// min that lanes can take with LDS atomics, and a candidate is out of the race ("beaten") as soon as the key of its bound is not below
+// the best key known.
+DXTEX_HD uint32_t exh_key(int err, int code) { return (uint32_t(err > 0 ? err : 0) << 8) | uint32_t(code + 1); }     // errors are < 2^23
+DXTEX_HD uint32_t exh_start_key(const ExhState& s) { return uint32_t(s.optErr) << 8; }
+DXTEX_HD int exh_code(const ExhState& s) { return ((s.o - s.o0) << 4) | (s.i - s.lo); }
 
-// queue entry: candidate code (o - o0) | (i - lo) << 4 in the low byte (a window is at most 11 x 11), its bound above it
-template<int MODE, int IM, int CHSET, class RG, class PQ>
-DXTEX_HD void exh_filter_step(const RG& rg, ExhState& s, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, int base, PQ& pd)
+// The window's minimum key -> the state exh_commit expects.
+DXTEX_HD void exh_apply_key(ExhState& s, uint32_t key)
 {
-    typedef LoopCfg<MODE, IM, CHSET> C;
-    const int a = s.aleb ? s.o : s.i, b = s.aleb ? s.i : s.o;
-    const int lb = eval_var_bound<MODE, IM, CHSET>(rg, vp, s.ch, unq1<C::PREC>(uint32_t(a)), unq1<C::PREC>(uint32_t(b)), base);
-    if (lb < s.best)
+    if ((key & 0xFFu) == 0u) return;              // nothing beat the starting endpoints
+    const int code = int(key & 0xFFu) - 1;
+    s.best = int(key >> 8); s.omin = s.o0 + (code >> 4); s.imin = s.lo + (code & 0xF);
+}
+
+// Candidates of the window that are still to be visited, from (s.o, s.i) on.
+DXTEX_HD int exh_remaining(const ExhState& s)
+{
+    int n = 0;
+    for (int o = s.o; o < s.oEnd; ++o)
     {
-        pd.push(uint32_t(s.o - s.o0) | (uint32_t(s.i - s.lo) << 4) | (uint32_t(lb > 0 ? lb : 0) << 8));     // errors are < 2^23
-#if defined(DXTEX_COUNT_EVALS)
-        ++g_pendCount[MODE];
-#endif
+        const int from = (o == s.o) ? s.i : (o > s.lo ? o : s.lo);
+        n += (s.iEnd > from) ? (s.iEnd - from) : 0;
     }
-    ++s.i;
+    return n;
 }
 
-// Drops the queued candidates that the best error has meanwhile overtaken (their bound is no longer below it).
-template<class PQ>
-DXTEX_HD void exh_skip_beaten(const ExhState& s, PQ& pd)
-{
-    while (pd.count() > 0 && int(pd.front() >> 8) >= s.best) pd.drop();
-}
-
-template<int MODE, int IM, int CHSET, class RG, class PQ>
-DXTEX_HD void exh_exact_pop(const RG& rg, ExhState& s, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, int base, PQ& pd)
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD int exh_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, int ch, int aleb, int o0, int lo, int code, int base)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
-    const uint32_t code = pd.front(); pd.drop();
-    const int o = s.o0 + int(code & 0xFu), i = s.lo + int((code >> 4) & 0xFu);
-    const int a = s.aleb ? o : i, b = s.aleb ? i : o;
-    const int e = eval_var<MODE, IM, CHSET>(rg, vp, s.ch, unq1<C::PREC>(uint32_t(a)), unq1<C::PREC>(uint32_t(b)), base);
-    if (e < s.best) { s.omin = o; s.imin = i; s.best = e; }       // strict: the first minimum in loop order wins (:3006)
-    exh_skip_beaten(s, pd);
+    const int o = o0 + (code >> 4), i = lo + (code & 0xF);
+    const int a = aleb ? o : i, b = aleb ? i : o;
+    return eval_var_bound<MODE, IM, CHSET>(rg, vp, ch, unq1<C::PREC>(uint32_t(a)), unq1<C::PREC>(uint32_t(b)), base);
+}
+
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD int exh_exact(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, int ch, int aleb, int o0, int lo, int code, int base)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    const int o = o0 + (code >> 4), i = lo + (code & 0xF);
+    const int a = aleb ? o : i, b = aleb ? i : o;
+    return eval_var<MODE, IM, CHSET>(rg, vp, ch, unq1<C::PREC>(uint32_t(a)), unq1<C::PREC>(uint32_t(b)), base);
 }
 
 // optimize_one() through the lockstep pieces, one lane's worth (host-side equivalence check, and the
@@ -1030,18 +1031,38 @@ DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& o
     const int base = loop_base<MODE, IM, CHSET>(rg, optA, optB);
     ExhState s; VarPal<C::N> vp;
     bool has = exh_begin<MODE, IM, CHSET>(s, vp, optA, optB, optErr);
-    ExhPendingRegs pd; pd.clear();
+    // what the kernel does, one lane's worth: bound every candidate of the window, set the unbeaten ones aside, evaluate those exactly
+    // (here newest first, to exercise the order independence), take the minimum key
+    int queue[128], n = 0;
+    uint32_t bestKey = has ? exh_start_key(s) : 0u;
     while (has)
     {
-        exh_filter_step<MODE, IM, CHSET>(rg, s, vp, base, pd);
-        if (pd.count() == kExhPendMax || !exh_settle(s))
+        const int code = exh_code(s);
+        const int lb = exh_bound<MODE, IM, CHSET>(rg, vp, s.ch, s.aleb, s.o0, s.lo, code, base);
+        if (exh_key(lb, code) < bestKey)
+        {
+            queue[n++] = code;
+#if defined(DXTEX_COUNT_EVALS)
+            ++g_pendCount[MODE];
+#endif
+        }
+        ++s.i;
+        const bool ended = !exh_settle(s);
+        if (n == 8 || ended)
         {
 #if defined(DXTEX_COUNT_EVALS)
-            if (pd.count()) ++g_drainCount[MODE];
+            if (n) ++g_drainCount[MODE];
 #endif
-            while (pd.count()) exh_exact_pop<MODE, IM, CHSET>(rg, s, vp, base, pd);
+            for (int j = n - 1; j >= 0; --j)
+            {
+                const uint32_t k = exh_key(exh_exact<MODE, IM, CHSET>(rg, vp, s.ch, s.aleb, s.o0, s.lo, queue[j], base), queue[j]);
+                bestKey = k < bestKey ? k : bestKey;
+            }
+            n = 0;
         }
+        if (ended) exh_apply_key(s, bestKey);
         has = exh_next<MODE, IM, CHSET>(s, vp);
+        if (ended && has) bestKey = exh_start_key(s);        // a new window has opened
     }
     optA = s.optA; optB = s.optB; optErr = s.optErr;
 }

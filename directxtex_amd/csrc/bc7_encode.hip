@@ -479,28 +479,63 @@ constexpr uint32_t kWaveTaskMax = 262144;
 
 // The Exhaustive phase (:2971-3042) for the channels of CHSET, wave-synchronous by window: every lane holds one task; all lanes
 // walk their current window (one channel's +-5 x +-5 neighbourhood) together, and a lane that needs a new task takes it at a
-// window boundary. Visiting a candidate costs a bound (eval_var_bound: about half an evaluation); the few per cent of candidates
-// whose bound is below the lane's best error so far queue up in the lane's LDS column and are evaluated exactly, in loop order,
-// after the window's last visit, all lanes together; then every lane commits its window. Exactly the result of evaluating every
-// candidate, at about half the instructions.
-struct ExhPendingLds
+// window boundary.
+//   * Visiting a candidate costs a bound (eval_var_bound: about half an evaluation). The few per cent of candidates whose key is
+//     below the lane's best key (bc7_core.h: exh_key) go to a list shared by the wavefront.
+//   * The list is evaluated exactly by ALL lanes, whoever's candidates they are: a helper fetches the owner's palette cache and
+//     window geometry with cross-lane reads, reads the owner's texels from the owner's LDS column, and folds the result into the
+//     owner's best key with an LDS atomic min (the window's result is an order-independent minimum).
+//   * Windows differ in size (55 ... 110 candidates). Once fewer than `tailBelow` lanes still have candidates to visit, the
+//     remaining candidates of all lanes are pooled and bounded by all 64 lanes in the same way, so the tail of a round runs at
+//     full width instead of at the width of its longest window.
+// Exactly the result of evaluating every candidate in the reference's order, at about half the instructions.
+#if defined(DXTEX_EXH_STATS)
+// development instrumentation: trip counts and lane participation of the mode-1 Exhaustive kernel (printed by bc7_stats_print_kernel)
+#define DXTEX_STAT(SLOT, MASK) do { const unsigned long long m_ = (MASK); if (MODE == 1 && lane == 0) { atomicAdd(&stats[2 * (SLOT)], 1ull); atomicAdd(&stats[2 * (SLOT) + 1], (unsigned long long)__popcll(m_)); } } while (0)
+__global__ void bc7_stats_print_kernel(unsigned long long* stats)
 {
-    uint32_t* col;       // &sPend[lane]; slot k at col[k * 64]
-    int head, tail;
-    __device__ __forceinline__ void clear() { head = tail = 0; }
-    __device__ __forceinline__ int count() const { return tail - head; }
-    __device__ __forceinline__ void push(uint32_t v) { col[(tail & (kExhPendMax - 1)) * 64] = v; ++tail; }
-    __device__ __forceinline__ uint32_t front() const { return col[(head & (kExhPendMax - 1)) * 64]; }
-    __device__ __forceinline__ void drop() { ++head; }
-};
+    // 0 round (busy lanes), 1 own-window bound trip, 2 drain (list length), 3 exact trip, 4 pooled bound trip, 5 refill
+    for (int i = 0; i < 6; ++i)
+        printf("exh-stats %d trips %llu lanes %llu\n", i, stats[2 * i], stats[2 * i + 1]);
+}
+#else
+#define DXTEX_STAT(SLOT, MASK) do { } while (0)
+#endif
+
+enum : int { kExhWorkMax = 1024, kExhExactMax = 512 };
+
+// What a helper needs of another lane's window.
+template<int N> struct ExhCtx { VarPal<N> vp; uint32_t geom; int base; };
 
 template<int MODE, int IM, int CHSET>
-__global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop, int midDrain)
+__device__ __forceinline__ ExhCtx<LoopCfg<MODE, IM, CHSET>::N> exh_fetch_ctx(const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, uint32_t geom, int base, int owner)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
-    __shared__ uint32_t sSlot[16 * 64];
-    __shared__ uint32_t sPend[kExhPendMax * 64];
+    ExhCtx<C::N> c;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i)
+    {
+        c.vp.palO[i] = C::kAlpha ? 0u : uint32_t(__shfl(int(vp.palO[i]), owner));
+        c.vp.nq2O[i] = C::kAlpha ? 0u : uint32_t(__shfl(int(vp.nq2O[i]), owner));
+    }
+    c.geom = uint32_t(__shfl(int(geom), owner));
+    c.base = __shfl(base, owner);
+    return c;
+}
+
+template<int MODE, int IM, int CHSET>
+__global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop, int tailBelow)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    __shared__ uint32_t sSlot[16 * 64];             // texel columns, one per lane
+    __shared__ uint32_t sWork[kExhWorkMax];         // pooled candidates to bound: (owner << 8) | code
+    __shared__ uint32_t sExact[kExhExactMax];       // candidates to evaluate exactly: (owner << 8) | code
+    __shared__ uint32_t sBest[64];                  // per lane: best key of its current window
+    __shared__ uint32_t sCount;                     // entries in sExact
     const int lane = threadIdx.x;
+#if defined(DXTEX_EXH_STATS)
+    unsigned long long* stats = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(a.flagged)) + 4;
+#endif
     const uint32_t live = a.counters[34];
     if (live == 0) return;           // nothing survived pre (a phase that owns no block, everything pruned): skip the queue atomics
     if (MODE == 6 && live <= kWaveTaskMax) return;      // short list: bc7_exhaustive_wave_kernel has done it
@@ -508,8 +543,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
     uint32_t* slotCol = &sSlot[lane];
 
     ExhState st; st.ch = C::CH1; st.optA = st.optB = 0; st.optErr = 0;
-    st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.o0 = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = 0;
-    ExhPendingLds pd; pd.col = &sPend[lane]; pd.clear();
+    st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.o0 = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = 0; st.bestCode = -1;
     VarPal<C::N> vp;
 #pragma unroll
     for (int i = 0; i < C::N; ++i) { vp.palO[i] = 0; vp.nq2O[i] = 0; }
@@ -517,6 +551,35 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
     int base = 0;
     uint32_t myTask = 0xFFFFFFFFu;
     WaveQueue q; q.lo = q.hi = 0; q.drained = false;
+    if (lane == 0) sCount = 0;
+
+    // exact evaluation of everything in sExact, by all lanes; afterwards every lane's bestKey is current
+    auto drain = [&](uint32_t geom, uint32_t& bestKey)
+    {
+        wave_lds_sync();
+        const int total = __builtin_amdgcn_readfirstlane(int(*static_cast<volatile uint32_t*>(&sCount)));
+        DXTEX_STAT(2, (total >= 64) ? ~0ull : ((1ull << total) - 1ull));
+        for (int g0 = 0; g0 < total; g0 += 64)
+        {
+            const int g = g0 + lane;
+            const bool valid = g < total;
+            DXTEX_STAT(3, __ballot(valid));
+            const uint32_t ent = valid ? sExact[g] : 0u;
+            const int owner = int(ent >> 8), code = int(ent & 0xFFu);
+            const ExhCtx<C::N> c = exh_fetch_ctx<MODE, IM, CHSET>(vp, geom, base, owner);
+            if (valid)
+            {
+                SlotRegion ro; ro.base = sSlot + owner; ro.np = int((c.geom >> 3) & 31u); ro.p2sum = 0;
+                const int e = exh_exact<MODE, IM, CHSET>(ro, c.vp, int(c.geom & 3u), int((c.geom >> 2) & 1u), int((c.geom >> 8) & 0xFFu), int((c.geom >> 16) & 0xFFu), code, c.base);
+                atomicMin(&sBest[owner], exh_key(e, code));
+            }
+        }
+        wave_lds_sync();
+        if (lane == 0) sCount = 0;
+        bestKey = sBest[lane];
+        wave_lds_sync();
+    };
+
     for (;;)
     {
         // ---- window boundary: lanes without a task take one (its first window opens here)
@@ -524,6 +587,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
         if (idle != 0ull && !(q.drained && q.lo >= q.hi))
         {
             const uint32_t idx = queue_take(q, head, live, idle, lane);
+            DXTEX_STAT(5, __ballot(idx != 0xFFFFFFFFu));
             if (idx != 0xFFFFFFFFu)
             {
                 const uint2 task = a.order[idx];
@@ -535,40 +599,84 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
             }
         }
         const bool busyL = myTask != 0xFFFFFFFFu;
-        if (__ballot(busyL) == 0ull)
+        const unsigned long long busy = __ballot(busyL);
+        DXTEX_STAT(0, busy);
+        if (busy == 0ull)
         {
             if (q.drained && q.lo >= q.hi) break;
             continue;
         }
-        pd.clear();
-        // ---- visit every candidate of the window (bounds only)
+        // what a helper needs of this lane's window: channel, loop orientation, subset size, window origin
+        const uint32_t geom = uint32_t(st.ch & 3) | (uint32_t(st.aleb & 1) << 2) | (uint32_t(rg.np) << 3) | (uint32_t(st.o0 & 0xFF) << 8) | (uint32_t(st.lo & 0xFF) << 16);
+        uint32_t bestKey = busyL ? exh_start_key(st) : 0u;
+        sBest[lane] = bestKey;
+        int rem = busyL ? exh_remaining(st) : 0;
+        wave_lds_sync();             // texel columns and best keys are visible to every lane
+
+        // ---- every lane visits its own window (bounds only) while most lanes have candidates left
         for (;;)
         {
-            const bool more = busyL && st.o < st.oEnd;
-            if (__ballot(more) == 0ull) break;
-            // One round of exact evaluations in the middle of the window when (nearly) every lane has a candidate waiting - a full
-            // trip, and the lanes' best errors tighten early, so fewer candidates pass the filter - or when a lane's queue is full.
-            const unsigned long long waiting = __ballot(busyL && pd.count() > 0);
-            if (__popcll(waiting) >= midDrain || __ballot(busyL && pd.count() == kExhPendMax) != 0ull)
+            const unsigned long long moreMask = __ballot(rem > 0);
+            if (__popcll(moreMask) < tailBelow) break;
+            if (__builtin_amdgcn_readfirstlane(int(*static_cast<volatile uint32_t*>(&sCount))) > kExhExactMax - 64) { drain(geom, bestKey); continue; }
+            DXTEX_STAT(1, moreMask);
+            if (rem > 0)
             {
-                if (busyL && pd.count() > 0) exh_exact_pop<MODE, IM, CHSET>(rg, st, vp, base, pd);
-                continue;
-            }
-            if (more)
-            {
-                exh_filter_step<MODE, IM, CHSET>(rg, st, vp, base, pd);
+                const int code = exh_code(st);
+                const int lb = exh_bound<MODE, IM, CHSET>(rg, vp, st.ch, st.aleb, st.o0, st.lo, code, base);
+                if (exh_key(lb, code) < bestKey) sExact[atomicAdd(&sCount, 1u)] = (uint32_t(lane) << 8) | uint32_t(code);
+                ++st.i; --rem;
                 exh_settle(st);
             }
         }
-        // ---- exact evaluation of the candidates that passed the filter, oldest first
-        while (__ballot(busyL && pd.count() > 0) != 0ull)
-            if (busyL && pd.count() > 0) exh_exact_pop<MODE, IM, CHSET>(rg, st, vp, base, pd);
-        // ---- commit the window, open the next one (or finish the task)
-        if (busyL && !exh_next<MODE, IM, CHSET>(st, vp))
+        // ---- the remaining candidates of all lanes, pooled and bounded by all lanes
+        for (;;)
         {
-            TaskRec* r = a.recs + myTask;
-            r->A = st.optA; r->B = st.optB; r->err = st.optErr;
-            myTask = 0xFFFFFFFFu;
+            const unsigned long long owners = __ballot(rem > 0);
+            if (owners == 0ull) break;
+            const int share = kExhWorkMax / __popcll(owners);            // >= 16
+            const int mine = rem < share ? rem : share;
+            int incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            const int first = incl - mine, total = __shfl(incl, 63);
+            for (int k = 0; k < mine; ++k)
+            {
+                sWork[first + k] = (uint32_t(lane) << 8) | uint32_t(exh_code(st));
+                ++st.i;
+                exh_settle(st);
+            }
+            rem -= mine;
+            wave_lds_sync();
+            for (int g0 = 0; g0 < total; g0 += 64)
+            {
+                if (__builtin_amdgcn_readfirstlane(int(*static_cast<volatile uint32_t*>(&sCount))) > kExhExactMax - 64) drain(geom, bestKey);
+                const int g = g0 + lane;
+                const bool valid = g < total;
+                DXTEX_STAT(4, __ballot(valid));
+                const uint32_t ent = valid ? sWork[g] : 0u;
+                const int owner = int(ent >> 8), code = int(ent & 0xFFu);
+                const ExhCtx<C::N> c = exh_fetch_ctx<MODE, IM, CHSET>(vp, geom, base, owner);
+                if (valid)
+                {
+                    SlotRegion ro; ro.base = sSlot + owner; ro.np = int((c.geom >> 3) & 31u); ro.p2sum = 0;
+                    const int lb = exh_bound<MODE, IM, CHSET>(ro, c.vp, int(c.geom & 3u), int((c.geom >> 2) & 1u), int((c.geom >> 8) & 0xFFu), int((c.geom >> 16) & 0xFFu), code, c.base);
+                    if (exh_key(lb, code) < sBest[owner]) sExact[atomicAdd(&sCount, 1u)] = ent;
+                }
+            }
+            wave_lds_sync();
+        }
+        // ---- exact evaluation of what is left on the list, then every lane commits its window and opens the next (or finishes)
+        drain(geom, bestKey);
+        if (busyL)
+        {
+            exh_apply_key(st, bestKey);
+            if (!exh_next<MODE, IM, CHSET>(st, vp))
+            {
+                TaskRec* r = a.recs + myTask;
+                r->A = st.optA; r->B = st.optB; r->err = st.optErr;
+                myTask = 0xFFFFFFFFu;
+            }
         }
     }
 }
@@ -598,7 +706,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_wave_kernel(Bc7Args a)
         wave_lds_sync();
         const int base = loop_base<MODE, IM, CHSET>(rg, rec.A, rec.B);
         ExhState st; st.optA = rec.A; st.optB = rec.B; st.optErr = rec.err;
-        st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.o0 = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = rec.err; st.ch = C::CH0;
+        st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.o0 = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = rec.err; st.bestCode = -1; st.ch = C::CH0;
         VarPal<C::N> vp;
 #pragma unroll 1
         for (int ch = C::CH0; ch < C::CH1; ++ch)
@@ -831,7 +939,7 @@ struct ScratchLayout
         seeds = o; o = up(o + nb * 128 * sizeof(uint2));
         seeds1 = o; o = up(o + nb * 2 * sizeof(uint2));
         seeds3 = o; o = up(o + (threeSubsets ? nb * 192 * sizeof(uint2) : 0));
-        flagcnt = o; o = up(o + 64);
+        flagcnt = o; o = up(o + 256);
         total = o;
     }
 };
@@ -854,14 +962,14 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order);
     if (marks) marks->mark(names[2]);
     const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
-    static const int midDrain = getenv("DXTEX_BC7_MID_DRAIN") ? atoi(getenv("DXTEX_BC7_MID_DRAIN")) : 52;
+    static const int tailBelow = getenv("DXTEX_BC7_TAIL_BELOW") ? atoi(getenv("DXTEX_BC7_TAIL_BELOW")) : 48;
     if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
         if (marks) marks->mark(names[4]);
         if constexpr (MODE == 6)
             hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_ALL>), dim3(std::min<uint32_t>(kSearchWaves, ntasks)), dim3(64), 0, stream, a);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1, midDrain);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1, tailBelow);
     }
     else
     {
@@ -869,9 +977,9 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
         if (marks) marks->mark(names[3]);
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 1);
         if (marks) marks->mark(names[4]);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2, midDrain);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2, tailBelow);
         if (marks) marks->mark(names[5]);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3, midDrain);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3, tailBelow);
     }
     if (marks) marks->mark(names[6]);
     hipLaunchKernelGGL((bc7_post_kernel<MODE, IM>), dim3(gridPP), dim3(256), 0, stream, a);
@@ -941,7 +1049,7 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         {
             DXTEX_MARK("bc7_rough");
             hipLaunchKernelGGL(bc7_rough_kernel, dim3((a.nblocks + 3) / 4), dim3(256), 0, stream, a);
-            (void)hipMemsetAsync(flagCount, 0, 64, stream);
+            (void)hipMemsetAsync(flagCount, 0, 256, stream);
             hipLaunchKernelGGL(bc7_flag_count_kernel, dim3(std::min<uint32_t>(1024u, (a.nblocks + 255) / 256)), dim3(256), 0, stream, a, flagCount);
         }
         else
@@ -998,6 +1106,9 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
             default: break;
             }
         }
+#if defined(DXTEX_EXH_STATS)
+        hipLaunchKernelGGL(bc7_stats_print_kernel, dim3(1), dim3(1), 0, stream, reinterpret_cast<unsigned long long*>(flagCount) + 4);
+#endif
         DXTEX_MARK("bc7_pick");
         hipLaunchKernelGGL(bc7_pick_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, stream, a, slotMask);
     }
