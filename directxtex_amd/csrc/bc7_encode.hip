@@ -531,7 +531,6 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
     __shared__ uint32_t sWork[kExhWorkMax];         // pooled candidates to bound: (owner << 8) | code
     __shared__ uint32_t sExact[kExhExactMax];       // candidates to evaluate exactly: (owner << 8) | code
     __shared__ uint32_t sBest[64];                  // per lane: best key of its current window
-    __shared__ uint32_t sCount;                     // entries in sExact
     const int lane = threadIdx.x;
 #if defined(DXTEX_EXH_STATS)
     unsigned long long* stats = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(a.flagged)) + 4;
@@ -551,13 +550,13 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
     int base = 0;
     uint32_t myTask = 0xFFFFFFFFu;
     WaveQueue q; q.lo = q.hi = 0; q.drained = false;
-    if (lane == 0) sCount = 0;
+    int nExact = 0;                                 // entries in sExact (wave-uniform)
 
     // exact evaluation of everything in sExact, by all lanes; afterwards every lane's bestKey is current
     auto drain = [&](uint32_t geom, uint32_t& bestKey)
     {
         wave_lds_sync();
-        const int total = __builtin_amdgcn_readfirstlane(int(*static_cast<volatile uint32_t*>(&sCount)));
+        const int total = nExact;
         DXTEX_STAT(2, (total >= 64) ? ~0ull : ((1ull << total) - 1ull));
         for (int g0 = 0; g0 < total; g0 += 64)
         {
@@ -575,9 +574,8 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
             }
         }
         wave_lds_sync();
-        if (lane == 0) sCount = 0;
+        nExact = 0;
         bestKey = sBest[lane];
-        wave_lds_sync();
     };
 
     for (;;)
@@ -618,16 +616,23 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
         {
             const unsigned long long moreMask = __ballot(rem > 0);
             if (__popcll(moreMask) < tailBelow) break;
-            if (__builtin_amdgcn_readfirstlane(int(*static_cast<volatile uint32_t*>(&sCount))) > kExhExactMax - 64) { drain(geom, bestKey); continue; }
+            if (nExact > kExhExactMax - 64) { drain(geom, bestKey); continue; }
             DXTEX_STAT(1, moreMask);
+            bool keep = false;
+            int code = 0;
             if (rem > 0)
             {
-                const int code = exh_code(st);
-                const int lb = exh_bound<MODE, IM, CHSET>(rg, vp, st.ch, st.aleb, st.o0, st.lo, code, base);
-                if (exh_key(lb, code) < bestKey) sExact[atomicAdd(&sCount, 1u)] = (uint32_t(lane) << 8) | uint32_t(code);
+                code = exh_code(st);
+                const int av = st.aleb ? st.o : st.i, bv = st.aleb ? st.i : st.o;
+                const int lb = eval_var_bound<MODE, IM, CHSET>(rg, vp, st.ch, unq1<C::PREC>(uint32_t(av)), unq1<C::PREC>(uint32_t(bv)), base);
+                keep = exh_key(lb, code) < bestKey;
                 ++st.i; --rem;
                 exh_settle(st);
             }
+            // append the unbeaten candidates to the shared list: positions from the ballot, no atomics
+            const unsigned long long keepMask = __ballot(keep);
+            if (keep) sExact[nExact + int(__popcll(keepMask & ((1ull << lane) - 1ull)))] = (uint32_t(lane) << 8) | uint32_t(code);
+            nExact += int(__popcll(keepMask));
         }
         // ---- the remaining candidates of all lanes, pooled and bounded by all lanes
         for (;;)
@@ -650,19 +655,23 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
             wave_lds_sync();
             for (int g0 = 0; g0 < total; g0 += 64)
             {
-                if (__builtin_amdgcn_readfirstlane(int(*static_cast<volatile uint32_t*>(&sCount))) > kExhExactMax - 64) drain(geom, bestKey);
+                if (nExact > kExhExactMax - 64) drain(geom, bestKey);
                 const int g = g0 + lane;
                 const bool valid = g < total;
                 DXTEX_STAT(4, __ballot(valid));
                 const uint32_t ent = valid ? sWork[g] : 0u;
                 const int owner = int(ent >> 8), code = int(ent & 0xFFu);
                 const ExhCtx<C::N> c = exh_fetch_ctx<MODE, IM, CHSET>(vp, geom, base, owner);
+                bool keep = false;
                 if (valid)
                 {
                     SlotRegion ro; ro.base = sSlot + owner; ro.np = int((c.geom >> 3) & 31u); ro.p2sum = 0;
                     const int lb = exh_bound<MODE, IM, CHSET>(ro, c.vp, int(c.geom & 3u), int((c.geom >> 2) & 1u), int((c.geom >> 8) & 0xFFu), int((c.geom >> 16) & 0xFFu), code, c.base);
-                    if (exh_key(lb, code) < sBest[owner]) sExact[atomicAdd(&sCount, 1u)] = ent;
+                    keep = exh_key(lb, code) < sBest[owner];
                 }
+                const unsigned long long keepMask = __ballot(keep);
+                if (keep) sExact[nExact + int(__popcll(keepMask & ((1ull << lane) - 1ull)))] = ent;
+                nExact += int(__popcll(keepMask));
             }
             wave_lds_sync();
         }
