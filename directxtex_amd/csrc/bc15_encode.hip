@@ -46,17 +46,22 @@ __device__ __forceinline__ void decode565(uint32_t w, float& r, float& g, float&
     b = float(w & 31) * (1.0f / 31.0f);
 }
 
-// Interpolation coefficient tables of the Newton fits, selected without indexing memory.
-__device__ __forceinline__ float coefC(uint32_t i, uint32_t cSteps)
+// Interpolation coefficient tables of the Newton fits (pC3 / pD3, pC4 / pD4, BC.cpp:26-31), selected without indexing memory and
+// without control flow: the middle entries are picked once per block from the step count, an entry is three selects.
+struct StepCoef
 {
-    if (cSteps == 3) return (i == 0) ? 1.0f : (i == 1) ? 0.5f : 0.0f;
-    return (i == 0) ? 1.0f : (i == 1) ? (2.0f / 3.0f) : (i == 2) ? (1.0f / 3.0f) : 0.0f;
-}
-__device__ __forceinline__ float coefD(uint32_t i, uint32_t cSteps)
-{
-    if (cSteps == 3) return (i == 0) ? 0.0f : (i == 1) ? 0.5f : 1.0f;
-    return (i == 0) ? 0.0f : (i == 1) ? (1.0f / 3.0f) : (i == 2) ? (2.0f / 3.0f) : 1.0f;
-}
+    float c1, c2, d1, d2;
+    __device__ __forceinline__ explicit StepCoef(uint32_t cSteps)
+    {
+        const bool three = (cSteps == 3);
+        c1 = three ? 0.5f : (2.0f / 3.0f); c2 = three ? 0.0f : (1.0f / 3.0f);
+        d1 = three ? 0.5f : (1.0f / 3.0f); d2 = three ? 1.0f : (2.0f / 3.0f);
+    }
+    // k = the step index as a float (0, 1, 2 or 3): float compares keep these as selects (an integer equality chain is turned into a
+    // switch, i.e. into divergent branches, by the compiler)
+    __device__ __forceinline__ float c(float k) const { return (k < 0.5f) ? 1.0f : (k < 1.5f) ? c1 : (k < 2.5f) ? c2 : 0.0f; }
+    __device__ __forceinline__ float d(float k) const { return (k < 0.5f) ? 0.0f : (k < 1.5f) ? d1 : (k < 2.5f) ? d2 : 1.0f; }
+};
 
 // 6-D Newton endpoint fit over 16 points (BC.cpp:65-314).
 __device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const float (&pg)[16], const float (&pb)[16],
@@ -123,7 +128,9 @@ __device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const floa
     }
 
     const float fSteps = float(cSteps - 1);
+    const StepCoef coef(cSteps);
 
+#pragma unroll 1
     for (int iter = 0; iter < 8; ++iter)
     {
         Dr = Yr - Xr; Dg = Yg - Xg; Db = Yb - Xb;
@@ -142,12 +149,11 @@ __device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const floa
         {
             const float fDot = (pr[i] - Xr) * Dr + (pg[i] - Xg) * Dg + (pb[i] - Xb) * Db;
 
-            uint32_t iStep;
-            if (fDot <= 0.0f) iStep = 0;
-            else if (fDot >= fSteps) iStep = cSteps - 1;
-            else iStep = uint32_t(fDot + 0.5f);
+            // fDot <= 0 -> 0, fDot >= fSteps -> cSteps - 1, else uint32(fDot + 0.5f) (BC.cpp:225-231): the clamp maps the two outer
+            // cases onto the same conversion, so the three-way branch becomes straight-line code (inputs are finite)
+            const float kStep = float(uint32_t(fminf(fmaxf(fDot, 0.0f), fSteps) + 0.5f));
 
-            const float c = coefC(iStep, cSteps), d = coefD(iStep, cSteps);
+            const float c = coef.c(kStep), d = coef.d(kStep);
             // pSteps[iStep] = X * pC[iStep] + Y * pD[iStep], evaluated where it is used
             const float diffR = (Xr * c + Yr * d) - pr[i];
             const float diffG = (Xg * c + Yg * d) - pg[i];
@@ -160,6 +166,7 @@ __device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const floa
             dXr += fC * diffR; dXg += fC * diffG; dXb += fC * diffB;
             d2Y += fD * d;
             dYr += fD * diffR; dYg += fD * diffG; dYb += fD * diffB;
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four texels at a time: keeps the temporaries of an iteration within the register budget
         }
 
         if (d2X > 0.0f)
@@ -181,10 +188,37 @@ __device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const floa
     oXr = Xr; oXg = Xg; oXb = Xb; oYr = Yr; oYg = Yg; oYb = Yb;
 }
 
-// BC1 colour block (BC.cpp:370-685). pa is only read when bColorKey is set.
-template<bool DITHER>
-__device__ __forceinline__ uint2 encode_bc1_color(const float (&sr)[16], const float (&sg)[16], const float (&sb)[16], const float (&pa)[16],
-                                  bool bColorKey, float threshold, uint32_t flags)
+// Two views of a lane's 4x4 tile. TileView: the generic float tile (any source format, partial blocks, conversions). PackedTile: the
+// sixteen RGBA8 texels as loaded - 16 registers instead of 64 - with XMLoadUByteN4's conversion (b * (1 / 255.f), the same expression
+// load_tile uses) applied wherever a component is read; with it the BC1-BC5 kernels fit twice as many waves per SIMD.
+struct TileView
+{
+    const Tile& t; const float (&al)[16];
+    __device__ __forceinline__ void launder() const {}
+    __device__ __forceinline__ float r(int i) const { return t.r[i]; }
+    __device__ __forceinline__ float g(int i) const { return t.g[i]; }
+    __device__ __forceinline__ float b(int i) const { return t.b[i]; }
+    __device__ __forceinline__ float a(int i) const { return al[i]; }
+};
+struct PackedTile
+{
+    uint32_t px[16];
+    __device__ __forceinline__ float r(int i) const { return float(px[i] & 0xFFu) * (1.0f / 255.0f); }
+    __device__ __forceinline__ float g(int i) const { return float((px[i] >> 8) & 0xFFu) * (1.0f / 255.0f); }
+    __device__ __forceinline__ float b(int i) const { return float((px[i] >> 16) & 0xFFu) * (1.0f / 255.0f); }
+    __device__ __forceinline__ float a(int i) const { return float(px[i] >> 24) * (1.0f / 255.0f); }
+    // Makes the texels opaque to the optimiser: conversions after this point are recomputed from the packed words instead of being
+    // kept alive (as 48 floats) from their first use across the Newton fit.
+    __device__ __forceinline__ void launder()
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(px[i]));
+    }
+};
+
+// BC1 colour block (BC.cpp:370-685). Alpha is only read when bColorKey is set.
+template<bool DITHER, class TS>
+__device__ __forceinline__ uint2 encode_bc1_color(TS& s, bool bColorKey, float threshold, uint32_t flags)
 {
     const bool uniform = (flags & BCF_UNIFORM) != 0;
     constexpr float LumR = 0.2125f / 0.7154f, LumB = 0.0721f / 0.7154f;
@@ -196,7 +230,7 @@ __device__ __forceinline__ uint2 encode_bc1_color(const float (&sr)[16], const f
         uint32_t uColorKey = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (pa[i] < threshold) uColorKey++;
+            if (s.a(i) < threshold) uColorKey++;
 
         if (uColorKey == 16)
             return make_uint2(0xffff0000u, 0xffffffffu);   // rgb[0] = 0x0000, rgb[1] = 0xffff
@@ -216,7 +250,7 @@ __device__ __forceinline__ uint2 encode_bc1_color(const float (&sr)[16], const f
 #pragma unroll
     for (int i = 0; i < 16; ++i)
     {
-        float r = sr[i], g = sg[i], b = sb[i];
+        float r = s.r(i), g = s.g(i), b = s.b(i);
         if constexpr (DITHER) { r += er[i]; g += eg[i]; b += eb[i]; }
 
         cr[i] = float(int32_t(r * 31.0f + 0.5f)) * (1.0f / 31.0f);
@@ -236,6 +270,7 @@ __device__ __forceinline__ uint2 encode_bc1_color(const float (&sr)[16], const f
 
     float Ar, Ag, Ab, Br, Bg, Bb;
     optimize_rgb16(cr, cg, cb, uSteps, uniform, Ar, Ag, Ab, Br, Bg, Bb);
+    s.launder();
 
     float Cr, Cg, Cb, Dr, Dg, Db;
     if (uniform) { Cr = Ar; Cg = Ag; Cb = Ab; Dr = Br; Dg = Bg; Db = Bb; }
@@ -302,30 +337,24 @@ __device__ __forceinline__ uint2 encode_bc1_color(const float (&sr)[16], const f
 #pragma unroll
     for (int i = 0; i < 16; ++i)
     {
-        if ((3 == uSteps) && (pa[i] < threshold))
+        if ((3 == uSteps) && (s.a(i) < threshold))
         {
             dw = (3u << 30) | (dw >> 2);
         }
         else
         {
             float r, g, b;
-            if (uniform) { r = sr[i]; g = sg[i]; b = sb[i]; }
-            else { r = sr[i] * LumR; g = sg[i] * 1.0f; b = sb[i] * LumB; }
+            if (uniform) { r = s.r(i); g = s.g(i); b = s.b(i); }
+            else { r = s.r(i) * LumR; g = s.g(i) * 1.0f; b = s.b(i) * LumB; }
 
             if constexpr (DITHER) { r += er[i]; g += eg[i]; b += eb[i]; }
 
             const float fDot = (r - S0r) * dirR + (g - S0g) * dirG + (b - S0b) * dirB;
 
-            uint32_t iStep;
-            if (fDot <= 0.0f) iStep = 0;
-            else if (fDot >= fSteps) iStep = 1;
-            else
-            {
-                const uint32_t k = uint32_t(fDot + 0.5f);
-                // pSteps3 = {0,2,1}; pSteps4 = {0,2,3,1}
-                iStep = (3 == uSteps) ? ((k == 0) ? 0u : (k == 1) ? 2u : 1u)
-                                      : ((k == 0) ? 0u : (k == 1) ? 2u : (k == 2) ? 3u : 1u);
-            }
+            // fDot <= 0 -> 0, fDot >= fSteps -> 1, else pSteps[uint32(fDot + 0.5f)] with pSteps3 = {0,2,1}, pSteps4 = {0,2,3,1}
+            // (BC.cpp:640-647): with the clamp, k = 0 and k = uSteps - 1 are exactly the two outer cases
+            const uint32_t k = uint32_t(fminf(fmaxf(fDot, 0.0f), fSteps) + 0.5f);
+            const uint32_t iStep = (k == 0) ? 0u : (k == uSteps - 1) ? 1u : (k + 1);
 
             dw = (iStep << 30) | (dw >> 2);
 
@@ -342,6 +371,14 @@ __device__ __forceinline__ uint2 encode_bc1_color(const float (&sr)[16], const f
     }
 
     return make_uint2(rgb0 | (rgb1 << 16), dw);
+}
+
+// x / n for small non-negative integers x <= n, n = 5 or 7, rn = float(1 / n): equal to the IEEE quotient (checked for every operand
+// the fits use), at three operations instead of the dozen of a full division.
+__device__ __forceinline__ float small_quotient(float x, float n, float rn)
+{
+    const float q = x * rn;
+    return fmaf(fmaf(-q, n, x), rn, q);
 }
 
 // 1-D Newton endpoint fit for BC3 alpha / BC4 / BC5 (BC.h:187-311).
@@ -375,6 +412,7 @@ __device__ __forceinline__ void optimize_alpha(float& outX, float& outY, const f
 
     const float fSteps = float(cSteps - 1);
     const bool six = (6 == cSteps);
+    const float rSteps = six ? (1.0f / 5.0f) : (1.0f / 7.0f);
 
     for (int iter = 0; iter < 8; ++iter)
     {
@@ -390,26 +428,22 @@ __device__ __forceinline__ void optimize_alpha(float& outX, float& outY, const f
         {
             const float fDot = (p[i] - fX) * fScale;
 
-            uint32_t iStep;
-            if (fDot <= 0.0f)
-                iStep = (six && (p[i] <= (fX + MIN_VALUE) * 0.5f)) ? 6u : 0u;
-            else if (fDot >= fSteps)
-                iStep = (six && (p[i] >= (fY + MAX_VALUE) * 0.5f)) ? 7u : (cSteps - 1);
-            else
-                iStep = uint32_t(fDot + 0.5f);
+            // BC.h:255-283, without control flow: below / above the end points the texel takes step 0 / cSteps - 1 - or, in the 6-step
+            // codec, one of the two fixed values (steps 6 / 7), which take no part in the fit; in between uint32(fDot + 0.5f). The clamp
+            // maps the outer cases onto the same conversion.
+            const bool low = fDot <= 0.0f, high = fDot >= fSteps;
+            const float k = float(uint32_t(fminf(fmaxf(fDot, 0.0f), fSteps) + 0.5f));
+            const bool fixedValue = six && ((low && (p[i] <= (fX + MIN_VALUE) * 0.5f)) || (high && (p[i] >= (fY + MAX_VALUE) * 0.5f)));
 
-            if (iStep < cSteps)
-            {
-                // pC6[i] = (5-i)/5, pD6[i] = i/5; pC8[i] = (7-i)/7, pD8[i] = i/7 (constant-folded divisions)
-                const float c = six ? (float(5 - int(iStep)) / 5.0f) : (float(7 - int(iStep)) / 7.0f);
-                const float d = six ? (float(iStep) / 5.0f) : (float(iStep) / 7.0f);
-                const float fDiff = (c * fX + d * fY) - p[i];
+            // pC6[i] = (5-i)/5, pD6[i] = i/5; pC8[i] = (7-i)/7, pD8[i] = i/7: the correctly rounded quotients, by one Newton step on the
+            // product with the rounded reciprocal (exact for these operands; a plain multiplication is not: 3/7, 6/7)
+            const float c = small_quotient(fSteps - k, fSteps, rSteps), d = small_quotient(k, fSteps, rSteps);
+            const float fDiff = (c * fX + d * fY) - p[i];
 
-                dX += c * fDiff;
-                d2X += c * c;
-                dY += d * fDiff;
-                d2Y += d * d;
-            }
+            dX = fixedValue ? dX : dX + c * fDiff;
+            d2X = fixedValue ? d2X : d2X + c * c;
+            dY = fixedValue ? dY : dY + d * fDiff;
+            d2Y = fixedValue ? d2Y : d2Y + d * d;
         }
 
         if (d2X > 0.0f) fX -= dX / d2X;
@@ -670,32 +704,75 @@ struct EncodeArgs
 
 // KIND: 1..3 = BC1..BC3, 4/5 = BC4/BC5 unsigned, 6/7 = BC4/BC5 signed. One instantiation per format keeps
 // each kernel's register footprint to what that codec needs.
-template<int KIND, bool DITHER>
-__global__ void __launch_bounds__(256) bc15_encode_kernel(EncodeArgs a)
+template<int KIND, bool DITHER, bool PACKED8>
+__global__ void __launch_bounds__(256, PACKED8 ? 3 : 1) bc15_encode_kernel(EncodeArgs a)
 {
     const uint32_t nb = blockIdx.x * 256u + threadIdx.x;
     if (nb >= a.nbw * a.nbh) return;
     const uint32_t by = nb / a.nbw, bx = nb - by * a.nbw;
+    uint8_t* out = a.dst + uint64_t(by) * a.dstRowPitch;
 
+    if constexpr (PACKED8)
+    {
+        // RGBA8 source, whole blocks, no tile conversion (the launcher checks): four coalesced 16-byte row loads, texels stay packed
+        PackedTile t;
+#pragma unroll
+        for (uint32_t y = 0; y < 4; ++y)
+        {
+            const uint4 v = *reinterpret_cast<const uint4*>(a.src.pixels + uint64_t(by * 4 + y) * a.src.rowPitch + uint64_t(bx) * 16);
+            t.px[y * 4 + 0] = v.x; t.px[y * 4 + 1] = v.y; t.px[y * 4 + 2] = v.z; t.px[y * 4 + 3] = v.w;
+        }
+        if constexpr (KIND == 1)
+            reinterpret_cast<uint2*>(out)[bx] = encode_bc1_color<DITHER>(t, true, a.threshold, a.flags);
+        else if constexpr (KIND == 2 || KIND == 3)
+        {
+            uint2 al;
+            {
+                float pa[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pa[i] = t.a(i);
+                al = (KIND == 2) ? encode_bc2_alpha(pa, a.flags) : encode_bc3_alpha(pa, a.flags);
+            }
+            const uint2 c = encode_bc1_color<DITHER>(t, false, 0.0f, a.flags);
+            reinterpret_cast<uint4*>(out)[bx] = make_uint4(al.x, al.y, c.x, c.y);
+        }
+        else
+        {
+            float ch[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ch[i] = t.r(i);
+            const uint2 u = encode_bc4_channel<false>(ch);
+            if constexpr (KIND == 4) reinterpret_cast<uint2*>(out)[bx] = u;
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ch[i] = t.g(i);
+                const uint2 v = encode_bc4_channel<false>(ch);
+                reinterpret_cast<uint4*>(out)[bx] = make_uint4(u.x, u.y, v.x, v.y);
+            }
+        }
+        return;
+    }
+    else
+    {
     Tile t;
     load_tile(a.src, bx, by, t);
-    uint8_t* out = a.dst + uint64_t(by) * a.dstRowPitch;
 
     if constexpr (KIND == 1)
     {
         if (a.flags & BCF_DITHER_A) bc1_dither_alpha(t.a);
-        reinterpret_cast<uint2*>(out)[bx] = encode_bc1_color<DITHER>(t.r, t.g, t.b, t.a, true, a.threshold, a.flags);
+        reinterpret_cast<uint2*>(out)[bx] = [&] { TileView tv{ t, t.a }; return encode_bc1_color<DITHER>(tv, true, a.threshold, a.flags); }();
     }
     else if constexpr (KIND == 2)
     {
         const uint2 al = encode_bc2_alpha(t.a, a.flags);
-        const uint2 c = encode_bc1_color<DITHER>(t.r, t.g, t.b, t.a, false, 0.0f, a.flags);
+        const uint2 c = [&] { TileView tv{ t, t.a }; return encode_bc1_color<DITHER>(tv, false, 0.0f, a.flags); }();
         reinterpret_cast<uint4*>(out)[bx] = make_uint4(al.x, al.y, c.x, c.y);
     }
     else if constexpr (KIND == 3)
     {
         const uint2 al = encode_bc3_alpha(t.a, a.flags);
-        const uint2 c = encode_bc1_color<DITHER>(t.r, t.g, t.b, t.a, false, 0.0f, a.flags);
+        const uint2 c = [&] { TileView tv{ t, t.a }; return encode_bc1_color<DITHER>(tv, false, 0.0f, a.flags); }();
         reinterpret_cast<uint4*>(out)[bx] = make_uint4(al.x, al.y, c.x, c.y);
     }
     else if constexpr (KIND == 4)
@@ -712,6 +789,7 @@ __global__ void __launch_bounds__(256) bc15_encode_kernel(EncodeArgs a)
         const uint2 u = encode_bc4_channel<true>(t.r), v = encode_bc4_channel<true>(t.g);
         reinterpret_cast<uint4*>(out)[bx] = make_uint4(u.x, u.y, v.x, v.y);
     }
+    }
 }
 } // namespace
 
@@ -726,19 +804,26 @@ hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowP
     if (!nblocks) return hipSuccess;
     const dim3 grid(uint32_t((nblocks + 255) / 256)), block(256);
     const bool dither = (flags & BCF_DITHER_RGB) != 0;
-#define DXTEX_LAUNCH(KIND) do { if (dither) hipLaunchKernelGGL((bc15_encode_kernel<KIND, true>), grid, block, 0, stream, a); \
-                                else hipLaunchKernelGGL((bc15_encode_kernel<KIND, false>), grid, block, 0, stream, a); } while (0)
+    // packed-tile kernels: RGBA8 texels need no conversion on their way into the encoder, every block is whole, rows are 16-byte aligned;
+    // BC1's alpha dithering rewrites the tile's alpha and keeps the float tile
+    const bool packed = src.format == FMT_R8G8B8A8_UNORM && src.tcv == TCV_NONE && src.tsw == TSW_NONE && (src.width % 4) == 0 && (src.height % 4) == 0 &&
+                        (src.rowPitch % 16) == 0 && (reinterpret_cast<uintptr_t>(src.pixels) % 16) == 0;
+#define DXTEX_LAUNCH2(KIND, DITHER, PACKED) hipLaunchKernelGGL((bc15_encode_kernel<KIND, DITHER, PACKED>), grid, block, 0, stream, a)
+#define DXTEX_LAUNCH(KIND, PACKOK) do { const bool pk_ = packed && (PACKOK); \
+                                         if (dither) { if (pk_) DXTEX_LAUNCH2(KIND, true, true); else DXTEX_LAUNCH2(KIND, true, false); } \
+                                         else { if (pk_) DXTEX_LAUNCH2(KIND, false, true); else DXTEX_LAUNCH2(KIND, false, false); } } while (0)
     switch (dstFormat)
     {
-    case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: DXTEX_LAUNCH(1); break;
-    case FMT_BC2_UNORM: case FMT_BC2_UNORM_SRGB: DXTEX_LAUNCH(2); break;
-    case FMT_BC3_UNORM: case FMT_BC3_UNORM_SRGB: DXTEX_LAUNCH(3); break;
-    case FMT_BC4_UNORM: hipLaunchKernelGGL((bc15_encode_kernel<4, false>), grid, block, 0, stream, a); break;
-    case FMT_BC5_UNORM: hipLaunchKernelGGL((bc15_encode_kernel<5, false>), grid, block, 0, stream, a); break;
-    case FMT_BC4_SNORM: hipLaunchKernelGGL((bc15_encode_kernel<6, false>), grid, block, 0, stream, a); break;
-    case FMT_BC5_SNORM: hipLaunchKernelGGL((bc15_encode_kernel<7, false>), grid, block, 0, stream, a); break;
+    case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: DXTEX_LAUNCH(1, (flags & BCF_DITHER_A) == 0); break;
+    case FMT_BC2_UNORM: case FMT_BC2_UNORM_SRGB: DXTEX_LAUNCH(2, true); break;
+    case FMT_BC3_UNORM: case FMT_BC3_UNORM_SRGB: DXTEX_LAUNCH(3, true); break;
+    case FMT_BC4_UNORM: if (packed) DXTEX_LAUNCH2(4, false, true); else DXTEX_LAUNCH2(4, false, false); break;
+    case FMT_BC5_UNORM: if (packed) DXTEX_LAUNCH2(5, false, true); else DXTEX_LAUNCH2(5, false, false); break;
+    case FMT_BC4_SNORM: DXTEX_LAUNCH2(6, false, false); break;
+    case FMT_BC5_SNORM: DXTEX_LAUNCH2(7, false, false); break;
     default: return hipErrorInvalidValue;
     }
+#undef DXTEX_LAUNCH2
 #undef DXTEX_LAUNCH
     return hipGetLastError();
 }

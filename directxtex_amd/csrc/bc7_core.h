@@ -1255,13 +1255,12 @@ DXTEX_HD void seed_fit(const float* fpx, uint32_t mask16, float (&X)[4], float (
                         float fDot = (p[0] - X[0]) * Dir[0] + (p[1] - X[1]) * Dir[1] + (p[2] - X[2]) * Dir[2];
                         if (RGBA) fDot = fDot + (p[3] - X[3]) * Dir[3];
 
-                        uint32_t iStep;
-                        if (fDot <= 0.0f) iStep = 0;
-                        else if (fDot >= fSteps) iStep = 3;
-                        else iStep = uint32_t(fDot + 0.5f);
-
-                        const float pc = (iStep == 0) ? 1.0f : (iStep == 1) ? (2.0f / 3.0f) : (iStep == 2) ? (1.0f / 3.0f) : 0.0f;
-                        const float pd = (iStep == 0) ? 0.0f : (iStep == 1) ? (1.0f / 3.0f) : (iStep == 2) ? (2.0f / 3.0f) : 1.0f;
+                        // fDot <= 0 -> step 0, fDot >= fSteps -> step 3, else uint32(fDot + 0.5f) (:1300-1306): the clamp maps the outer cases
+                        // onto the same conversion; float compares keep the table lookups (pC4 / pD4) as selects - an integer equality
+                        // chain is turned into a switch, i.e. divergent branches, by the compiler
+                        const float kStep = float(uint32_t(fminf(fmaxf(fDot, 0.0f), fSteps) + 0.5f));
+                        const float pc = (kStep < 0.5f) ? 1.0f : (kStep < 1.5f) ? (2.0f / 3.0f) : (kStep < 2.5f) ? (1.0f / 3.0f) : 0.0f;
+                        const float pd = (kStep < 0.5f) ? 0.0f : (kStep < 1.5f) ? (1.0f / 3.0f) : (kStep < 2.5f) ? (2.0f / 3.0f) : 1.0f;
                         const float fC = pc * (1.0f / 8.0f);
                         const float fD = pd * (1.0f / 8.0f);
                         d2X += fC * pc;
