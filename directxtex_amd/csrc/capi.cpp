@@ -1112,7 +1112,7 @@ dxtex_hresult check_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_
 }
 } // namespace
 
-dxtex_hresult dxtex_convert_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float)
+dxtex_hresult dxtex_convert_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float threshold)
 {
     ConvertPlan plan;
     dxtex_hresult hr = check_convert(ctx, src, dst, filter, &plan);
@@ -1120,13 +1120,13 @@ dxtex_hresult dxtex_convert_device(dxtex_ctx* ctx, const dxtex_image* src, const
     ScopedDevice sd(ctx->device);
     time_begin(ctx);
     hipError_t e = launch_convert(src->pixels, src->rowPitch, src->format, dst->pixels, dst->rowPitch, dst->format,
-                                  uint32_t(src->width), uint32_t(src->height), plan, ctx->stream);
+                                  uint32_t(src->width), uint32_t(src->height), plan, threshold, ctx->stream);
     time_end(ctx);
     if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
     return DXTEX_S_OK;
 }
 
-dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float)
+dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float threshold)
 {
     ConvertPlan plan;
     dxtex_hresult hr = check_convert(ctx, src, dst, filter, &plan);
@@ -1139,7 +1139,7 @@ dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
     time_begin(ctx);
     hipError_t e = launch_convert(static_cast<const uint8_t*>(ctx->stageIn), src->rowPitch, src->format, static_cast<uint8_t*>(ctx->stageOut),
-                                  dst->rowPitch, dst->format, uint32_t(src->width), uint32_t(src->height), plan, ctx->stream);
+                                  dst->rowPitch, dst->format, uint32_t(src->width), uint32_t(src->height), plan, threshold, ctx->stream);
     time_end(ctx);
     if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
     HIP_TRY(ctx, hipMemcpyAsync(dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -14,31 +14,40 @@ enum : int
 {
     FMT_UNKNOWN = 0,
     FMT_R32G32B32A32_FLOAT = 2,
+    FMT_R32G32B32_FLOAT = 6,
     FMT_R16G16B16A16_FLOAT = 10,
     FMT_R16G16B16A16_UNORM = 11,
+    FMT_R16G16B16A16_SNORM = 13,
     FMT_R32G32_FLOAT = 16,
+    FMT_R10G10B10A2_UNORM = 24,
+    FMT_R11G11B10_FLOAT = 26,
     FMT_R8G8B8A8_UNORM = 28,
     FMT_R8G8B8A8_UNORM_SRGB = 29,
     FMT_R8G8B8A8_SNORM = 31,
     FMT_R16G16_FLOAT = 34,
     FMT_R16G16_UNORM = 35,
+    FMT_R16G16_SNORM = 37,
     FMT_R32_FLOAT = 41,
     FMT_R8G8_UNORM = 49,
     FMT_R8G8_SNORM = 51,
     FMT_R16_FLOAT = 54,
     FMT_R16_UNORM = 56,
+    FMT_R16_SNORM = 58,
     FMT_R8_UNORM = 61,
     FMT_R8_SNORM = 63,
     FMT_A8_UNORM = 65,
+    FMT_R9G9B9E5_SHAREDEXP = 67,
     FMT_BC1_UNORM = 71, FMT_BC1_UNORM_SRGB = 72,
     FMT_BC2_UNORM = 74, FMT_BC2_UNORM_SRGB = 75,
     FMT_BC3_UNORM = 77, FMT_BC3_UNORM_SRGB = 78,
     FMT_BC4_UNORM = 80, FMT_BC4_SNORM = 81,
     FMT_BC5_UNORM = 83, FMT_BC5_SNORM = 84,
+    FMT_B5G6R5_UNORM = 85, FMT_B5G5R5A1_UNORM = 86,
     FMT_B8G8R8A8_UNORM = 87, FMT_B8G8R8X8_UNORM = 88,
     FMT_B8G8R8A8_UNORM_SRGB = 91, FMT_B8G8R8X8_UNORM_SRGB = 93,
     FMT_BC6H_UF16 = 95, FMT_BC6H_SF16 = 96,
     FMT_BC7_UNORM = 98, FMT_BC7_UNORM_SRGB = 99,
+    FMT_B4G4R4A4_UNORM = 115,
 };
 
 // BC_FLAGS == TEX_COMPRESS_FLAGS bit-for-bit (BC.h:30-48, DirectXTex.h:887-917).
@@ -62,6 +71,7 @@ enum : int
     TCV_UNORM_TO_SNORM = 3,  // UNORM -> SNORM  v*2 + -1, unfused (:3495-3501)
     TCV_SNORM_TO_UNORM = 4,  // SNORM -> UNORM  v*0.5 + 0.5 (:3457-3463)
     TCV_X2BIAS_TO_UNORM = 5, // FLOAT -> UNORM with TEX_FILTER_FLOAT_X2BIAS: clamp(v,-1,1)*0.5 + 0.5 (:3469-3477)
+    TCV_SAT_TO_SNORM = 6,    // positive-only FLOAT (x2 bias) -> SNORM / FLOAT: saturate(v)*2 + -1 (:3506-3515, :3549-3561)
 };
 enum : int
 {
@@ -82,6 +92,23 @@ struct SrcView
 };
 
 struct Texel { float r, g, b, a; };
+
+// One component of XMLoadFloat3PK: an unsigned small float (5-bit exponent, MB-bit mantissa) widened to fp32. Infinity and NaN keep
+// their class (exponent 31), denormals are normalised, everything else is re-biased by 127 - 15.
+__device__ __forceinline__ float load_float11(uint32_t bits, int MB)
+{
+    uint32_t mant = bits & ((1u << MB) - 1u);
+    uint32_t expo = bits >> MB;
+    if (expo == 0x1Fu) return __uint_as_float(0x7F800000u | (mant << (23 - MB)));
+    if (expo == 0)
+    {
+        if (mant == 0) return 0.0f;
+        expo = 1;
+        do { --expo; mant <<= 1; } while ((mant & (1u << MB)) == 0);       // normalise
+        mant &= (1u << MB) - 1u;
+    }
+    return __uint_as_float(((expo + 112u) << 23) | (mant << (23 - MB)));
+}
 
 // One texel, LoadScanline semantics for the supported formats.
 __device__ __forceinline__ Texel load_texel(const uint8_t* row, uint32_t x, int format)
@@ -195,6 +222,77 @@ __device__ __forceinline__ Texel load_texel(const uint8_t* row, uint32_t x, int 
     case FMT_A8_UNORM:
         t.r = 0.0f; t.g = 0.0f; t.b = 0.0f; t.a = float(row[x]) / 255.0f;   // :1165
         break;
+    case FMT_R32G32B32_FLOAT:
+    {
+        // XMLoadFloat3, w from g_XMIdentityR3 (LOAD_SCANLINE3, :811-812)
+        const float* v = reinterpret_cast<const float*>(row) + 3 * size_t(x);
+        t.r = v[0]; t.g = v[1]; t.b = v[2]; t.a = 1.0f;
+        break;
+    }
+    case FMT_R16G16B16A16_SNORM:
+    {
+        // XMLoadShortN4 (:829-830): float(int16) * (1/32767), then max with -1 (the -32768 code)
+        const uint2 v = reinterpret_cast<const uint2*>(row)[x];
+        t.r = fmaxf(float(int16_t(v.x & 0xFFFF)) * (1.0f / 32767.0f), -1.0f); t.g = fmaxf(float(int16_t(v.x >> 16)) * (1.0f / 32767.0f), -1.0f);
+        t.b = fmaxf(float(int16_t(v.y & 0xFFFF)) * (1.0f / 32767.0f), -1.0f); t.a = fmaxf(float(int16_t(v.y >> 16)) * (1.0f / 32767.0f), -1.0f);
+        break;
+    }
+    case FMT_R16G16_SNORM:
+    {
+        // XMLoadShortN2 (:931-932), z, w from g_XMIdentityR3
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.r = fmaxf(float(int16_t(v & 0xFFFF)) * (1.0f / 32767.0f), -1.0f); t.g = fmaxf(float(int16_t(v >> 16)) * (1.0f / 32767.0f), -1.0f);
+        t.b = 0.0f; t.a = 1.0f;
+        break;
+    }
+    case FMT_R16_SNORM:
+        t.r = float(int16_t(reinterpret_cast<const uint16_t*>(row)[x])) / 32767.0f; t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;   // true division, no clamp (:1080-1091)
+        break;
+    case FMT_R10G10B10A2_UNORM:
+    {
+        // XMLoadUDecN4 (:897-898): the SSE2 path scales the fields in place by 1/1023, 1/(1023*2^10), 1/(1023*2^20), 1/(3*2^30); the
+        // powers of two are exact, so every channel is float(field) * float(1/1023) (alpha: * float(1/3))
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.r = float(v & 0x3FFu) * (1.0f / 1023.0f); t.g = float((v >> 10) & 0x3FFu) * (1.0f / 1023.0f);
+        t.b = float((v >> 20) & 0x3FFu) * (1.0f / 1023.0f); t.a = float(v >> 30) * (1.0f / 3.0f);
+        break;
+    }
+    case FMT_R11G11B10_FLOAT:
+    {
+        // XMLoadFloat3PK (:906-907): 6-bit mantissa / 5-bit exponent (x, y), 5-bit mantissa (z), no sign; w from g_XMIdentityR3
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.r = load_float11(v & 0x7FFu, 6); t.g = load_float11((v >> 11) & 0x7FFu, 6); t.b = load_float11((v >> 22) & 0x3FFu, 5); t.a = 1.0f;
+        break;
+    }
+    case FMT_R9G9B9E5_SHAREDEXP:
+    {
+        // XMLoadFloat3SE (:1189-1190): mantissa * 2^(e - 24)
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        const float scale = __uint_as_float(0x33800000u + ((v >> 27) << 23));
+        t.r = scale * float(v & 0x1FFu); t.g = scale * float((v >> 9) & 0x1FFu); t.b = scale * float((v >> 18) & 0x1FFu); t.a = 1.0f;
+        break;
+    }
+    case FMT_B5G6R5_UNORM:
+    {
+        // XMLoadU565 -> (b5, g6, r5) as floats, * (1/31, 1/63, 1/31), swizzled to RGB, w = 1 (:1227-1242)
+        const uint32_t v = reinterpret_cast<const uint16_t*>(row)[x];
+        t.b = float(v & 0x1Fu) * (1.0f / 31.0f); t.g = float((v >> 5) & 0x3Fu) * (1.0f / 63.0f); t.r = float((v >> 11) & 0x1Fu) * (1.0f / 31.0f); t.a = 1.0f;
+        break;
+    }
+    case FMT_B5G5R5A1_UNORM:
+    {
+        // XMLoadU555 (:1244-1258)
+        const uint32_t v = reinterpret_cast<const uint16_t*>(row)[x];
+        t.b = float(v & 0x1Fu) * (1.0f / 31.0f); t.g = float((v >> 5) & 0x1Fu) * (1.0f / 31.0f); t.r = float((v >> 10) & 0x1Fu) * (1.0f / 31.0f); t.a = float(v >> 15);
+        break;
+    }
+    case FMT_B4G4R4A4_UNORM:
+    {
+        // XMLoadUNibble4 * 1/15 (:1511-1525)
+        const uint32_t v = reinterpret_cast<const uint16_t*>(row)[x];
+        t.b = float(v & 0xFu) * (1.0f / 15.0f); t.g = float((v >> 4) & 0xFu) * (1.0f / 15.0f); t.r = float((v >> 8) & 0xFu) * (1.0f / 15.0f); t.a = float(v >> 12) * (1.0f / 15.0f);
+        break;
+    }
     default:
         t.r = t.g = t.b = 0.0f; t.a = 1.0f;
         break;
@@ -211,6 +309,7 @@ __device__ __forceinline__ float tcv1(float v, int tcv)
     case TCV_UNORM_TO_SNORM: return v * 2.0f + -1.0f;
     case TCV_SNORM_TO_UNORM: return v * 0.5f + 0.5f;
     case TCV_X2BIAS_TO_UNORM: { float m = (v > -1.0f) ? v : -1.0f; m = (m < 1.0f) ? m : 1.0f; return m * 0.5f + 0.5f; }
+    case TCV_SAT_TO_SNORM: { float m = (v > 0.0f) ? v : 0.0f; m = (m < 1.0f) ? m : 1.0f; return m * 2.0f + -1.0f; }
     default: return v;
     }
 }

@@ -9,6 +9,7 @@ enum FmtClass : uint32_t
 {
     FC_UNORM = 1, FC_SNORM = 2, FC_FLOAT = 4, FC_BC = 8,
     FC_R = 0x10, FC_G = 0x20, FC_B = 0x40, FC_A = 0x80, FC_SRGB = 0x100,
+    FC_POS_ONLY = 0x200,     // CONVF_POS_ONLY: unsigned float formats (R11G11B10_FLOAT, R9G9B9E5_SHAREDEXP)
 };
 
 struct FmtInfo { int format; uint32_t bpp; uint32_t cls; };
@@ -37,6 +38,16 @@ inline const FmtInfo* format_info(int format)
         { FMT_A8_UNORM, 8, FC_UNORM | FC_A },
         { FMT_R32_FLOAT, 32, FC_FLOAT | FC_R },
         { FMT_R16_FLOAT, 16, FC_FLOAT | FC_R },
+        { FMT_R32G32B32_FLOAT, 96, FC_FLOAT | FC_R | FC_G | FC_B },
+        { FMT_R16G16B16A16_SNORM, 64, FC_SNORM | FC_R | FC_G | FC_B | FC_A },
+        { FMT_R16G16_SNORM, 32, FC_SNORM | FC_R | FC_G },
+        { FMT_R16_SNORM, 16, FC_SNORM | FC_R },
+        { FMT_R10G10B10A2_UNORM, 32, FC_UNORM | FC_R | FC_G | FC_B | FC_A },
+        { FMT_R11G11B10_FLOAT, 32, FC_FLOAT | FC_POS_ONLY | FC_R | FC_G | FC_B },
+        { FMT_R9G9B9E5_SHAREDEXP, 32, FC_FLOAT | FC_POS_ONLY | FC_R | FC_G | FC_B },
+        { FMT_B5G6R5_UNORM, 16, FC_UNORM | FC_R | FC_G | FC_B },
+        { FMT_B5G5R5A1_UNORM, 16, FC_UNORM | FC_R | FC_G | FC_B | FC_A },
+        { FMT_B4G4R4A4_UNORM, 16, FC_UNORM | FC_R | FC_G | FC_B | FC_A },
         { FMT_BC1_UNORM, 4, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A },
         { FMT_BC1_UNORM_SRGB, 4, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_SRGB },
         { FMT_BC2_UNORM, 8, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A },

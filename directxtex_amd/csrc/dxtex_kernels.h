@@ -38,7 +38,7 @@ hipError_t launch_bc_decode(const uint8_t* src, uint64_t srcRowPitch, int srcFor
 
 // Convert (ConvertCustom without dithering): same size, different format.
 hipError_t launch_convert(const uint8_t* src, uint64_t srcPitch, int srcFormat, uint8_t* dst, uint64_t dstPitch, int dstFormat,
-                          uint32_t width, uint32_t height, const ConvertPlan& plan, hipStream_t stream);
+                          uint32_t width, uint32_t height, const ConvertPlan& plan, float threshold, hipStream_t stream);
 
 // Resize / one mip level. filterMode = TEX_FILTER_POINT..TRIANGLE (already resolved, never 0); filterFlags carries the
 // wrap / mirror / sRGB bits. `tri` (device pointers) is required for TEX_FILTER_TRIANGLE: per destination column / row

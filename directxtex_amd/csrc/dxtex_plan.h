@@ -28,23 +28,34 @@ inline ConvertPlan resolve_convert_plan(const FmtInfo& in, const FmtInfo& out, u
 
     // the reference compares its CONVF_* words; what can differ among our formats: type class, channel set, BC-ness,
     // BGR order. BGR-only differences reach no branch below, so they can be left out of the test.
-    const uint32_t kDiffMask = FC_UNORM | FC_SNORM | FC_FLOAT | FC_BC | FC_R | FC_G | FC_B | FC_A;
+    const uint32_t kDiffMask = FC_UNORM | FC_SNORM | FC_FLOAT | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_POS_ONLY;
     const uint32_t diff = (in.cls ^ out.cls) & kDiffMask;
     if (!diff) return p;
 
+    const bool x2 = (flags & TF_FLOAT_X2BIAS) != 0;
     if (out.cls & FC_UNORM)
     {
         if (in.cls & FC_SNORM) p.tcv = TCV_SNORM_TO_UNORM;                                            // :3457-3463
-        else if (in.cls & FC_FLOAT) p.tcv = (flags & TF_FLOAT_X2BIAS) ? TCV_X2BIAS_TO_UNORM : TCV_SATURATE;   // :3465-3489
+        else if (in.cls & FC_FLOAT) p.tcv = (!(in.cls & FC_POS_ONLY) && x2) ? TCV_X2BIAS_TO_UNORM : TCV_SATURATE;   // :3465-3489
     }
     else if (out.cls & FC_SNORM)
     {
         if (in.cls & FC_UNORM) p.tcv = TCV_UNORM_TO_SNORM;                                            // :3495-3501
-        else if (in.cls & FC_FLOAT) p.tcv = TCV_CLAMP_SNORM;                                          // :3521-3526
+        else if (in.cls & FC_FLOAT) p.tcv = ((in.cls & FC_POS_ONLY) && x2) ? TCV_SAT_TO_SNORM : TCV_CLAMP_SNORM;     // :3503-3527
     }
     else if (diff & FC_UNORM)
     {
-        if ((out.cls & FC_FLOAT) && (flags & TF_FLOAT_X2BIAS)) p.tcv = TCV_UNORM_TO_SNORM;            // UNORM (x2 bias) -> FLOAT, :3536-3546
+        if ((out.cls & FC_FLOAT) && !(out.cls & FC_POS_ONLY) && x2) p.tcv = TCV_UNORM_TO_SNORM;        // UNORM (x2 bias) -> FLOAT, :3529-3543
+    }
+    else if ((diff & FC_POS_ONLY) && x2)
+    {
+        // :3545-3587
+        if (in.cls & FC_POS_ONLY) { if (out.cls & FC_FLOAT) p.tcv = TCV_SAT_TO_SNORM; }               // FLOAT (positive only, x2 bias) -> FLOAT
+        else if (out.cls & FC_POS_ONLY)
+        {
+            if (in.cls & FC_FLOAT) p.tcv = TCV_X2BIAS_TO_UNORM;                                       // FLOAT -> FLOAT (positive only, x2 bias)
+            else if (in.cls & FC_SNORM) p.tcv = TCV_SNORM_TO_UNORM;                                   // SNORM -> FLOAT (positive only, x2 bias)
+        }
     }
 
     const uint32_t inRGBA = in.cls & (FC_R | FC_G | FC_B | FC_A), outRGBA = out.cls & (FC_R | FC_G | FC_B | FC_A);

@@ -105,6 +105,75 @@ __device__ __forceinline__ uint32_t store_usn(float v)
     return uint32_t(rintf(s * 65535.0f));
 }
 
+// XMStoreShortN4 / XMStoreShortN2: clamp to [-1,1], * 32767, round to nearest even (_mm_cvtps_epi32), saturating pack.
+__device__ __forceinline__ uint32_t store_sn16(float v)
+{
+    float s = (v > -1.0f) ? v : -1.0f; s = (s < 1.0f) ? s : 1.0f;
+    return uint32_t(int32_t(rintf(s * 32767.0f))) & 0xFFFFu;
+}
+
+// XMStoreUDecN4, SSE2 path: saturate, scale, TRUNCATE (_mm_cvttps_epi32), mask. The lanes are pre-scaled by powers of two and masked
+// back, which leaves floor(v * 1023) per colour channel and floor(v * 3) for alpha.
+__device__ __forceinline__ uint32_t store_udecn4(const Texel& t)
+{
+    auto sat = [](float v) { float s = (v > 0.0f) ? v : 0.0f; return (s < 1.0f) ? s : 1.0f; };
+    return (uint32_t(sat(t.r) * 1023.0f) & 0x3FFu) | ((uint32_t(sat(t.g) * 1023.0f) & 0x3FFu) << 10) |
+           ((uint32_t(sat(t.b) * 1023.0f) & 0x3FFu) << 20) | ((uint32_t(sat(t.a) * 3.0f) & 0x3u) << 30);
+}
+
+// One component of XMStoreFloat3PK: fp32 -> unsigned small float with 5 exponent bits and MB mantissa bits, round to nearest even;
+// negative values and values below half the smallest denormal go to 0, values above the largest finite go to it, NaN / +INF keep
+// their class.
+__device__ __forceinline__ uint32_t store_float11(float v, int MB)
+{
+    const uint32_t bits = __float_as_uint(v);
+    const bool sign = (bits & 0x80000000u) != 0;
+    uint32_t I = bits & 0x7FFFFFFFu;
+    const uint32_t expAll = 0x1Fu << MB, all = expAll | ((1u << MB) - 1u);
+    const int shift = 23 - MB;                           // 17 for x / y, 18 for z
+    if ((I & 0x7F800000u) == 0x7F800000u)
+    {
+        if (I & 0x7FFFFFu) return all;                   // NaN
+        return sign ? 0u : expAll;                       // -INF is clamped to 0
+    }
+    if (sign || I < ((MB == 6) ? 0x35800000u : 0x36000000u)) return 0u;      // positive only; below the smallest denormal (2^-20 / 2^-19)
+    if (I > ((MB == 6) ? 0x477E0000u : 0x477C0000u)) return expAll - 1u;     // larger than the largest finite value: clamp to it
+    if (I < 0x38800000u)
+    {
+        const uint32_t Shift = 113u - (I >> 23);         // denormal in the small format
+        I = (0x800000u | (I & 0x7FFFFFu)) >> Shift;
+    }
+    else I += 0xC8000000u;                               // re-bias the exponent
+    return ((I + ((1u << (shift - 1)) - 1u) + ((I >> shift) & 1u)) >> shift) & all;
+}
+
+// XMStoreFloat3SE (DirectXMath >= 3.10; the reference carries the same code for older versions, DirectXTexConvert.cpp:158-191)
+__device__ __forceinline__ uint32_t store_float3se(const Texel& t)
+{
+    const float maxf9 = float(0x1FF << 7), minf9 = 1.0f / float(1 << 16);
+    const float x = (t.r >= 0.0f) ? ((t.r > maxf9) ? maxf9 : t.r) : 0.0f;
+    const float y = (t.g >= 0.0f) ? ((t.g > maxf9) ? maxf9 : t.g) : 0.0f;
+    const float z = (t.b >= 0.0f) ? ((t.b > maxf9) ? maxf9 : t.b) : 0.0f;
+    const float max_xy = (x > y) ? x : y;
+    const float max_xyz = (max_xy > z) ? max_xy : z;
+    const float maxColor = (max_xyz > minf9) ? max_xyz : minf9;
+    const uint32_t fi = __float_as_uint(maxColor) + 0x00004000u;      // round up leaving 9 bits in the fraction (including the assumed 1)
+    const uint32_t e = fi >> 23;
+    const float scaleR = __uint_as_float(0x83000000u - (e << 23));
+    // lroundf: round half away from zero
+    return (uint32_t(int32_t(roundf(x * scaleR))) & 0x1FFu) | ((uint32_t(int32_t(roundf(y * scaleR))) & 0x1FFu) << 9) |
+           ((uint32_t(int32_t(roundf(z * scaleR))) & 0x1FFu) << 18) | (((e - 0x6Fu) & 0x1Fu) << 27);
+}
+
+// XMStoreU565 / XMStoreU555 / XMStoreUNibble4 after the reference's scaling (v * 31 | 63 | 15, no bias on x64): clamp to [0, max], round
+// to nearest even (_mm_cvtps_epi32).
+__device__ __forceinline__ uint32_t store_scaled_rne(float v, float scale)
+{
+    float s = v * scale;
+    s = (s > 0.0f) ? s : 0.0f; s = (s < scale) ? s : scale;
+    return uint32_t(int32_t(rintf(s)));
+}
+
 // The 4-byte formats as one packed word (same expressions as the cases of store_texel below).
 __device__ __forceinline__ bool is_packed32(int format)
 {
@@ -144,7 +213,7 @@ __device__ __forceinline__ uint2 pack_texel_half4(const Texel& t)
 }
 
 // One texel, StoreScanline semantics. Returns false for a format this library cannot write.
-__device__ __forceinline__ void store_texel(uint8_t* row, uint32_t x, int format, const Texel& t)
+__device__ __forceinline__ void store_texel(uint8_t* row, uint32_t x, int format, const Texel& t, float threshold = 0.0f)   // the default of StoreScanline[Linear] (DirectXTexP.h): only Convert passes one
 {
     switch (format)
     {
@@ -211,6 +280,46 @@ __device__ __forceinline__ void store_texel(uint8_t* row, uint32_t x, int format
         row[x] = uint8_t(int8_t(int32_t(roundf(s * 127.0f))));
         break;
     }
+    case FMT_R32G32B32_FLOAT:
+    {
+        float* d = reinterpret_cast<float*>(row) + 3 * size_t(x);             // XMStoreFloat3
+        d[0] = t.r; d[1] = t.g; d[2] = t.b;
+        break;
+    }
+    case FMT_R16G16B16A16_SNORM:
+        reinterpret_cast<uint2*>(row)[x] = make_uint2(store_sn16(t.r) | (store_sn16(t.g) << 16), store_sn16(t.b) | (store_sn16(t.a) << 16));
+        break;
+    case FMT_R16G16_SNORM:
+        reinterpret_cast<uint32_t*>(row)[x] = store_sn16(t.r) | (store_sn16(t.g) << 16);
+        break;
+    case FMT_R16_SNORM:
+    {
+        // clamp to [-1,1]; int16(lroundf(v * 32767)) (:1928-1941)
+        float s = (t.r < 1.0f) ? t.r : 1.0f; s = (s > -1.0f) ? s : -1.0f;
+        reinterpret_cast<uint16_t*>(row)[x] = uint16_t(int16_t(int32_t(roundf(s * 32767.0f))));
+        break;
+    }
+    case FMT_R10G10B10A2_UNORM:
+        reinterpret_cast<uint32_t*>(row)[x] = store_udecn4(t);
+        break;
+    case FMT_R11G11B10_FLOAT:
+        reinterpret_cast<uint32_t*>(row)[x] = store_float11(t.r, 6) | (store_float11(t.g, 6) << 11) | (store_float11(t.b, 5) << 22);
+        break;
+    case FMT_R9G9B9E5_SHAREDEXP:
+        reinterpret_cast<uint32_t*>(row)[x] = store_float3se(t);
+        break;
+    case FMT_B5G6R5_UNORM:
+        reinterpret_cast<uint16_t*>(row)[x] = uint16_t((store_scaled_rne(t.b, 31.0f) & 0x1Fu) | ((store_scaled_rne(t.g, 63.0f) & 0x3Fu) << 5) | ((store_scaled_rne(t.r, 31.0f) & 0x1Fu) << 11));
+        break;
+    case FMT_B5G5R5A1_UNORM:
+        // XMStoreU555, then the alpha bit from the caller's threshold (:2116-2139)
+        reinterpret_cast<uint16_t*>(row)[x] = uint16_t((store_scaled_rne(t.b, 31.0f) & 0x1Fu) | ((store_scaled_rne(t.g, 31.0f) & 0x1Fu) << 5) |
+                                                       ((store_scaled_rne(t.r, 31.0f) & 0x1Fu) << 10) | ((t.a > threshold) ? 0x8000u : 0u));
+        break;
+    case FMT_B4G4R4A4_UNORM:
+        reinterpret_cast<uint16_t*>(row)[x] = uint16_t((store_scaled_rne(t.b, 15.0f) & 0xFu) | ((store_scaled_rne(t.g, 15.0f) & 0xFu) << 4) |
+                                                       ((store_scaled_rne(t.r, 15.0f) & 0xFu) << 8) | ((store_scaled_rne(t.a, 15.0f) & 0xFu) << 12));
+        break;
     default:
         break;
     }

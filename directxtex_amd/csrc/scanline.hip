@@ -56,18 +56,23 @@ __device__ __forceinline__ void store_linear(const ImgView& v, uint32_t x, uint3
 #define DXTEX_PER_CHANNEL(EXPR_R, EXPR_G, EXPR_B, EXPR_A) Texel{ (EXPR_R), (EXPR_G), (EXPR_B), (EXPR_A) }
 
 // ---- Convert -------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) convert_kernel(ImgView src, ImgView dst, ConvertPlan plan)
+// Rows are the grid's y dimension, which HIP limits to 65535: taller images wrap (grid_rows() caps the launch, the kernels stride).
+__host__ __device__ inline uint32_t grid_rows(uint32_t height) { return height < 65535u ? height : 65535u; }
+
+__global__ void __launch_bounds__(256) convert_kernel(ImgView src, ImgView dst, ConvertPlan plan, float threshold)
 {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
     if (x >= src.width) return;
-    const Texel t = load_texel(src.pixels + uint64_t(y) * src.rowPitch, x, src.format);
-    store_texel(dst.pixels + uint64_t(y) * dst.rowPitch, x, dst.format, apply_plan(t, plan));
+    for (uint32_t y = blockIdx.y; y < src.height; y += gridDim.y)
+    {
+        const Texel t = load_texel(src.pixels + uint64_t(y) * src.rowPitch, x, src.format);
+        store_texel(dst.pixels + uint64_t(y) * dst.rowPitch, x, dst.format, apply_plan(t, plan), threshold);
+    }
 }
 
 // ---- PremultiplyAlpha / DemultiplyAlpha (DirectXTexPMAlpha.cpp:30-205): rgb * a, or rgb / a where a > 0, in linear space ------------
-__global__ void __launch_bounds__(256) pmalpha_kernel(ImgView src, ImgView dst, int srgbIn, int srgbOut, int reverse)
+__device__ __forceinline__ void pmalpha_kernel_row(ImgView src, ImgView dst, int srgbIn, int srgbOut, int reverse, const uint32_t x, const uint32_t y)
 {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
     if (x >= src.width) return;
     Texel t = load_linear(src, x, y, srgbIn);
     if (!reverse) { t.r = t.r * t.a; t.g = t.g * t.a; t.b = t.b * t.a; }
@@ -75,24 +80,32 @@ __global__ void __launch_bounds__(256) pmalpha_kernel(ImgView src, ImgView dst, 
     else { t.r = t.g = t.b = t.a; }     // as written (:134-141): with alpha <= 0 the select picks the undivided alpha splat, not the colour
     store_linear(dst, x, y, srgbOut, t);
 }
+__global__ void __launch_bounds__(256) pmalpha_kernel(ImgView src, ImgView dst, int srgbIn, int srgbOut, int reverse)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t y = blockIdx.y; y < src.height; y += gridDim.y) pmalpha_kernel_row(src, dst, srgbIn, srgbOut, reverse, x, y);        // grid_rows(): HIP caps grid.y at 65535
+}
 
 // ---- ScaleMipMapsAlphaForCoverage (DirectXTexMipmaps.cpp:143-352) ---------------------------------------------------------------------
 // ScaleAlpha: alpha * scale, colour untouched.
-__global__ void __launch_bounds__(256) scale_alpha_kernel(ImgView src, ImgView dst, float scale)
+__device__ __forceinline__ void scale_alpha_kernel_row(ImgView src, ImgView dst, float scale, const uint32_t x, const uint32_t y)
 {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
     if (x >= src.width) return;
     Texel t = load_texel(src.pixels + uint64_t(y) * src.rowPitch, x, src.format);
     t.a = t.a * scale;
     store_texel(dst.pixels + uint64_t(y) * dst.rowPitch, x, dst.format, t);
 }
+__global__ void __launch_bounds__(256) scale_alpha_kernel(ImgView src, ImgView dst, float scale)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t y = blockIdx.y; y < src.height; y += gridDim.y) scale_alpha_kernel_row(src, dst, scale, x, y);        // grid_rows(): HIP caps grid.y at 65535
+}
 
 // CalculateAlphaCoverage: every 2x2 quad of scaled, saturated alphas is sampled at 8x8 sub-positions with bilinear weights and
 // the samples above alphaReference are counted. Reproduced as written, including that the running vector `v` is overwritten
 // with the (splatted) sum after every sub-sample (:283), so samples 2..64 of a quad see the previous sum, not the four alphas.
-__global__ void __launch_bounds__(256) alpha_coverage_kernel(ImgView src, float scale, float alphaReference, unsigned long long* count)
+__device__ __forceinline__ void alpha_coverage_kernel_row(ImgView src, float scale, float alphaReference, unsigned long long* count, const uint32_t x, const uint32_t y)
 {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
     uint32_t n = 0;
     if (x + 1 < src.width)
     {
@@ -122,11 +135,15 @@ __global__ void __launch_bounds__(256) alpha_coverage_kernel(ImgView src, float 
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
     if ((threadIdx.x & 63u) == 0 && n) atomicAdd(count, static_cast<unsigned long long>(n));
 }
+__global__ void __launch_bounds__(256) alpha_coverage_kernel(ImgView src, float scale, float alphaReference, unsigned long long* count)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t y = blockIdx.y; y < src.height - 1u; y += gridDim.y) alpha_coverage_kernel_row(src, scale, alphaReference, count, x, y);        // grid_rows(): HIP caps grid.y at 65535
+}
 
 // ---- point (:255-309 / :907-987): 16.16 fixed-point stepping -----------------------------------------------------------------
-__global__ void __launch_bounds__(256) resize_point_kernel(ResizeArgs a)
+__device__ __forceinline__ void resize_point_kernel_row(ResizeArgs a, const uint32_t x, const uint32_t y)
 {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
     if (x >= a.dst.width) return;
     const uint64_t xinc = (uint64_t(a.src.width) << 16) / a.dst.width;
     const uint64_t yinc = (uint64_t(a.src.height) << 16) / a.dst.height;
@@ -134,11 +151,15 @@ __global__ void __launch_bounds__(256) resize_point_kernel(ResizeArgs a)
     const Texel t = load_texel(a.src.pixels + uint64_t(sy) * a.src.rowPitch, sx, a.src.format);
     store_texel(a.dst.pixels + uint64_t(y) * a.dst.rowPitch, x, a.dst.format, t);
 }
+__global__ void __launch_bounds__(256) resize_point_kernel(ResizeArgs a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t y = blockIdx.y; y < a.dst.height; y += gridDim.y) resize_point_kernel_row(a, x, y);        // grid_rows(): HIP caps grid.y at 65535
+}
 
 // ---- box (filters.h:31-37): (((p0 + p1) + p2) + p3) * 0.25 with p0 = (2x, 2y), p1 = (2x, 2y+1), p2 = (2x+1, 2y), p3 = (2x+1, 2y+1)
-__global__ void __launch_bounds__(256) resize_box_kernel(ResizeArgs a)
+__device__ __forceinline__ void resize_box_kernel_row(ResizeArgs a, const uint32_t x, const uint32_t y)
 {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
     if (x >= a.dst.width) return;
     // Generate2DMipsBoxFilter: a 1-high source reads the same row twice, a 1-wide source the same column (:1024-1033)
     const bool oneRow = a.mipAlias && a.src.height <= 1, oneCol = a.mipAlias && a.src.width <= 1;
@@ -158,6 +179,11 @@ __global__ void __launch_bounds__(256) resize_box_kernel(ResizeArgs a)
     r.a = (((p0.a + p1.a) + p2.a) + p3.a) * 0.25f;
     store_linear(a.dst, x, y, a.srgbOut, r);
 }
+__global__ void __launch_bounds__(256) resize_box_kernel(ResizeArgs a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t y = blockIdx.y; y < a.dst.height; y += gridDim.y) resize_box_kernel_row(a, x, y);        // grid_rows(): HIP caps grid.y at 65535
+}
 
 // ---- linear (filters.h:57-104) ---------------------------------------------------------------------------------------------
 struct Lin { uint32_t u0, u1; float w0, w1; };
@@ -174,9 +200,8 @@ __device__ __forceinline__ Lin linear_entry(uint32_t source, uint32_t dest, bool
     return e;
 }
 
-__global__ void __launch_bounds__(256) resize_linear_kernel(ResizeArgs a)
+__device__ __forceinline__ void resize_linear_kernel_row(ResizeArgs a, const uint32_t x, const uint32_t y)
 {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
     if (x >= a.dst.width) return;
     const Lin tx = linear_entry(a.src.width, a.dst.width, a.wrapU != 0, x);
     const Lin ty = linear_entry(a.src.height, a.dst.height, a.wrapV != 0, y);
@@ -188,6 +213,11 @@ __global__ void __launch_bounds__(256) resize_linear_kernel(ResizeArgs a)
     r.r = DXTEX_BILERP(r); r.g = DXTEX_BILERP(g); r.b = DXTEX_BILERP(b); r.a = DXTEX_BILERP(a);
 #undef DXTEX_BILERP
     store_linear(a.dst, x, y, a.srgbOut, r);
+}
+__global__ void __launch_bounds__(256) resize_linear_kernel(ResizeArgs a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t y = blockIdx.y; y < a.dst.height; y += gridDim.y) resize_linear_kernel_row(a, x, y);        // grid_rows(): HIP caps grid.y at 65535
 }
 
 // ---- cubic (filters.h:106-207) -----------------------------------------------------------------------------------------------
@@ -239,9 +269,8 @@ __device__ __forceinline__ float cubic1(float dx, float p0, float p1, float p2, 
     return ((a0 + a1 * dx) + a2 * dx2) + a3 * dx3;
 }
 
-__global__ void __launch_bounds__(256) resize_cubic_kernel(ResizeArgs a)
+__device__ __forceinline__ void resize_cubic_kernel_row(ResizeArgs a, const uint32_t x, const uint32_t y)
 {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
     if (x >= a.dst.width) return;
     const Cub tx = cubic_entry(a.src.width, a.dst.width, a.wrapU != 0, a.mirrorU != 0, x);
     const Cub ty = cubic_entry(a.src.height, a.dst.height, a.wrapV != 0, a.mirrorV != 0, y);
@@ -276,14 +305,18 @@ __global__ void __launch_bounds__(256) resize_cubic_kernel(ResizeArgs a)
     o.b = cubic1(ty.x, c[0].b, c[1].b, c[2].b, c[3].b); o.a = cubic1(ty.x, c[0].a, c[1].a, c[2].a, c[3].a);
     store_linear(a.dst, x, y, a.srgbOut, o);
 }
+__global__ void __launch_bounds__(256) resize_cubic_kernel(ResizeArgs a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t y = blockIdx.y; y < a.dst.height; y += gridDim.y) resize_cubic_kernel_row(a, x, y);        // grid_rows(): HIP caps grid.y at 65535
+}
 
 // ---- triangle (filters.h:209-419; accumulation order of DirectXTexMipmaps.cpp:1517-1542 / DirectXTexResize.cpp:730-760) ----------
 // The reference scatters every source texel into accumulation rows; the sum a destination texel receives is ordered
 // by (source row, source column, row-list entry, column-list entry). The host inverts the filter lists so that a lane
 // can gather its texel's contributions in that same order: acc = acc + src * (wy * wx), unfused.
-__global__ void __launch_bounds__(256) resize_triangle_kernel(ResizeArgs a)
+__device__ __forceinline__ void resize_triangle_kernel_row(ResizeArgs a, const uint32_t x, const uint32_t y)
 {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
     if (x >= a.dst.width) return;
     const uint32_t yb = a.triOfsY[y], ye = a.triOfsY[y + 1];
     const uint32_t xb = a.triOfsX[x], xe = a.triOfsX[x + 1];
@@ -314,7 +347,13 @@ __global__ void __launch_bounds__(256) resize_triangle_kernel(ResizeArgs a)
         }
         i = iEnd;
     }
+    if (a.dst.format == FMT_R10G10B10A2_UNORM) acc.a = acc.a + 0.1f;       // the reference biases 2-bit alpha against accumulation error (DirectXTexMipmaps.cpp:1560-1579, DirectXTexResize.cpp:768-787)
     store_linear(a.dst, x, y, a.srgbOut, acc);
+}
+__global__ void __launch_bounds__(256) resize_triangle_kernel(ResizeArgs a)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t y = blockIdx.y; y < a.dst.height; y += gridDim.y) resize_triangle_kernel_row(a, x, y);        // grid_rows(): HIP caps grid.y at 65535
 }
 
 // ---- volume mips: Generate3DMips{Point,Box,Linear,Cubic,Triangle}Filter (DirectXTexMipmaps.cpp:1666-2826) ----------------------------
@@ -487,6 +526,7 @@ __global__ void __launch_bounds__(256) resize3d_triangle_kernel(Resize3Args a)
         }
         h = hEnd;
     }
+    if (a.dst.format == FMT_R10G10B10A2_UNORM) acc.a = acc.a + 0.1f;       // DirectXTexMipmaps.cpp:2767-2786
     store_linear(slice_of(a.dst, z), x, y, a.srgbOut, acc);
 }
 
@@ -543,11 +583,11 @@ bool can_srgb(int format)
 } // namespace
 
 hipError_t launch_convert(const uint8_t* src, uint64_t srcPitch, int srcFormat, uint8_t* dst, uint64_t dstPitch, int dstFormat,
-                          uint32_t width, uint32_t height, const ConvertPlan& plan, hipStream_t stream)
+                          uint32_t width, uint32_t height, const ConvertPlan& plan, float threshold, hipStream_t stream)
 {
     if (!width || !height) return hipSuccess;
-    hipLaunchKernelGGL(convert_kernel, dim3((width + 255) / 256, height), dim3(256), 0, stream,
-                       make_view(src, srcPitch, width, height, srcFormat), make_view(dst, dstPitch, width, height, dstFormat), plan);
+    hipLaunchKernelGGL(convert_kernel, dim3((width + 255) / 256, grid_rows(height)), dim3(256), 0, stream,
+                       make_view(src, srcPitch, width, height, srcFormat), make_view(dst, dstPitch, width, height, dstFormat), plan, threshold);
     return hipGetLastError();
 }
 
@@ -569,7 +609,7 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
     a.mipAlias = mipAlias ? 1 : 0;
     a.triOfsX = tri ? tri->ofsX : nullptr; a.triX = tri ? reinterpret_cast<const uint2*>(tri->entX) : nullptr;
     a.triOfsY = tri ? tri->ofsY : nullptr; a.triY = tri ? reinterpret_cast<const uint2*>(tri->entY) : nullptr;
-    const dim3 grid((dstW + 255) / 256, dstH), block(256);
+    const dim3 grid((dstW + 255) / 256, grid_rows(dstH)), block(256);
     switch (filterMode)
     {
     case 0x100000u: hipLaunchKernelGGL(resize_point_kernel, grid, block, 0, stream, a); break;
@@ -589,7 +629,7 @@ hipError_t launch_pmalpha(const uint8_t* src, uint64_t srcPitch, uint8_t* dst, u
     // TEX_PMALPHA_IGNORE_SRGB (0x1): plain Load/StoreScanline; otherwise the *Linear wrappers with the SRGB_IN/OUT bits (:68-112)
     const bool linear = !(pmFlags & 0x1u);
     const bool wantIn = linear && (srgb_linear_format(format) || (pmFlags & 0x1000000u)), wantOut = linear && (srgb_linear_format(format) || (pmFlags & 0x2000000u));
-    hipLaunchKernelGGL(pmalpha_kernel, dim3((width + 255) / 256, height), dim3(256), 0, stream,
+    hipLaunchKernelGGL(pmalpha_kernel, dim3((width + 255) / 256, grid_rows(height)), dim3(256), 0, stream,
                        make_view(src, srcPitch, width, height, format), make_view(dst, dstPitch, width, height, format),
                        (can_srgb(format) && wantIn) ? 1 : 0, (can_srgb(format) && wantOut) ? 1 : 0, (pmFlags & 0x2u) ? 1 : 0);
     return hipGetLastError();
@@ -599,7 +639,7 @@ hipError_t launch_scale_alpha(const uint8_t* src, uint64_t srcPitch, uint8_t* ds
                               float scale, hipStream_t stream)
 {
     if (!width || !height) return hipSuccess;
-    hipLaunchKernelGGL(scale_alpha_kernel, dim3((width + 255) / 256, height), dim3(256), 0, stream,
+    hipLaunchKernelGGL(scale_alpha_kernel, dim3((width + 255) / 256, grid_rows(height)), dim3(256), 0, stream,
                        make_view(src, srcPitch, width, height, format), make_view(dst, dstPitch, width, height, format), scale);
     return hipGetLastError();
 }
@@ -610,7 +650,7 @@ hipError_t launch_alpha_coverage(const uint8_t* src, uint64_t srcPitch, int form
     hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
     if (width < 2 || height < 2) return hipSuccess;
-    hipLaunchKernelGGL(alpha_coverage_kernel, dim3((width - 1 + 255) / 256, height - 1), dim3(256), 0, stream,
+    hipLaunchKernelGGL(alpha_coverage_kernel, dim3((width - 1 + 255) / 256, grid_rows(height - 1)), dim3(256), 0, stream,
                        make_view(src, srcPitch, width, height, format), scale, alphaReference, count);
     return hipGetLastError();
 }

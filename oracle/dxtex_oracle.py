@@ -313,7 +313,7 @@ class RefError(RuntimeError):
         super().__init__(f"reference returned HRESULT 0x{self.hresult:08X}")
 
 
-BPP = {2: 128, 10: 64, 11: 64, 16: 64, 28: 32, 29: 32, 31: 32, 34: 32, 35: 32, 41: 32, 49: 16, 51: 16, 54: 16, 56: 16, 61: 8, 63: 8, 65: 8,
+BPP = {2: 128, 6: 96, 13: 64, 24: 32, 26: 32, 37: 32, 58: 16, 67: 32, 85: 16, 86: 16, 115: 16, 10: 64, 11: 64, 16: 64, 28: 32, 29: 32, 31: 32, 34: 32, 35: 32, 41: 32, 49: 16, 51: 16, 54: 16, 56: 16, 61: 8, 63: 8, 65: 8,
        87: 32, 88: 32, 91: 32, 93: 32}
 
 

@@ -50,13 +50,68 @@ namespace
         return (s > 0.0031308f) ? hi : lo;
     }
 
-    enum : uint32_t { C_UNORM = 1, C_SNORM = 2, C_FLOAT = 4, C_R = 0x10, C_G = 0x20, C_B = 0x40, C_A = 0x80, C_BC = 8 };
+    // ---- DirectXMath packed types the long-tail formats go through (DirectXPackedVector.inl, SSE2 / scalar behaviour as published) ----
+    // XMLoadFloat3PK: one unsigned small float (5-bit exponent, `mbits`-bit mantissa) -> fp32
+    inline float load_small_float(uint32_t exponent, uint32_t mantissa, int mbits)
+    {
+        uint32_t result;
+        if (exponent == 0x1f) result = 0x7f800000u | (mantissa << (23 - mbits));          // INF or NAN
+        else
+        {
+            if (exponent != 0) { /* normalised */ }
+            else if (mantissa != 0)
+            {
+                exponent = 1;                                                              // denormal: normalise in the resulting float
+                do { exponent--; mantissa <<= 1; } while ((mantissa & (1u << mbits)) == 0);
+                mantissa &= (1u << mbits) - 1u;
+            }
+            else exponent = uint32_t(-112);
+            result = ((exponent + 112) << 23) | (mantissa << (23 - mbits));
+        }
+        float f; memcpy(&f, &result, 4); return f;
+    }
+    // XMStoreFloat3PK, one channel
+    inline uint32_t store_small_float(float value, int mbits)
+    {
+        uint32_t iv; memcpy(&iv, &value, 4);
+        const bool sign = (iv & 0x80000000u) != 0;
+        uint32_t I = iv & 0x7FFFFFFFu;
+        const uint32_t expMask = 0x1Fu << mbits, allOnes = expMask | ((1u << mbits) - 1u);
+        const uint32_t shift = uint32_t(23 - mbits);
+        if ((I & 0x7F800000u) == 0x7F800000u)
+        {
+            uint32_t r = expMask;                                      // INF
+            if ((I & 0x7FFFFFu) != 0) r = allOnes;                      // NAN
+            else if (sign) r = 0;                                       // -INF is clamped to 0 since 3PK is positive only
+            return r;
+        }
+        if (sign || I < (mbits == 6 ? 0x35800000u : 0x36000000u)) return 0;                 // positive only, or too small
+        if (I > (mbits == 6 ? 0x477E0000u : 0x477C0000u)) return expMask - 1u;              // too large: the largest finite value
+        if (I < 0x38800000u)
+        {
+            const uint32_t Shift = 113u - (I >> 23u);                  // too small for a normalised value: make it a denormal
+            I = (0x800000u | (I & 0x7FFFFFu)) >> Shift;
+        }
+        else I += 0xC8000000u;                                          // rebias the exponent
+        return ((I + ((1u << (shift - 1)) - 1u) + ((I >> shift) & 1u)) >> shift) & allOnes;
+    }
+    inline uint16_t store_snorm16(float v) { const float s = clampf(v, -1.f, 1.f); return uint16_t(int16_t(int32_t(nearbyintf(s * 32767.0f)))); }   // XMStoreShortN4/N2: cvtps, pack
+    inline uint32_t store_scaled(float v, float scale) { return uint32_t(int32_t(nearbyintf(clampf(v * scale, 0.f, scale)))); }                   // XMStoreU565/U555/UNibble4 after the reference's multiply
+
+    enum : uint32_t { C_UNORM = 1, C_SNORM = 2, C_FLOAT = 4, C_R = 0x10, C_G = 0x20, C_B = 0x40, C_A = 0x80, C_BC = 8, C_POS_ONLY = 0x200 };
     // the CONVF_* words of g_ConvertTable (DirectXTexConvert.cpp:2960-3047), reduced to what the supported formats use
     uint32_t conv_flags(DXGI_FORMAT f)
     {
         switch (int(f))
         {
         case DXGI_FORMAT_R32G32B32A32_FLOAT: case DXGI_FORMAT_R16G16B16A16_FLOAT: return C_FLOAT | C_R | C_G | C_B | C_A;
+        case DXGI_FORMAT_R32G32B32_FLOAT: return C_FLOAT | C_R | C_G | C_B;
+        case DXGI_FORMAT_R11G11B10_FLOAT: case DXGI_FORMAT_R9G9B9E5_SHAREDEXP: return C_FLOAT | C_POS_ONLY | C_R | C_G | C_B;       // :2979, :3011
+        case DXGI_FORMAT_R16G16B16A16_SNORM: return C_SNORM | C_R | C_G | C_B | C_A;
+        case DXGI_FORMAT_R16G16_SNORM: return C_SNORM | C_R | C_G;
+        case DXGI_FORMAT_R16_SNORM: return C_SNORM | C_R;
+        case DXGI_FORMAT_R10G10B10A2_UNORM: case DXGI_FORMAT_B5G5R5A1_UNORM: case DXGI_FORMAT_B4G4R4A4_UNORM: return C_UNORM | C_R | C_G | C_B | C_A;
+        case DXGI_FORMAT_B5G6R5_UNORM: return C_UNORM | C_R | C_G | C_B;
         case DXGI_FORMAT_R16G16B16A16_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB:
         case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB: return C_UNORM | C_R | C_G | C_B | C_A;
         case DXGI_FORMAT_B8G8R8X8_UNORM: case DXGI_FORMAT_B8G8R8X8_UNORM_SRGB: return C_UNORM | C_R | C_G | C_B;
@@ -99,6 +154,8 @@ namespace
         case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R16G16_FLOAT: case DXGI_FORMAT_R16G16_UNORM: case DXGI_FORMAT_R32_FLOAT:
         case DXGI_FORMAT_R8G8_UNORM: case DXGI_FORMAT_R16_FLOAT: case DXGI_FORMAT_R16_UNORM: case DXGI_FORMAT_R8_UNORM:
         case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8X8_UNORM: return true;
+        case DXGI_FORMAT_R32G32B32_FLOAT: case DXGI_FORMAT_R10G10B10A2_UNORM: case DXGI_FORMAT_R11G11B10_FLOAT: case DXGI_FORMAT_R9G9B9E5_SHAREDEXP:
+        case DXGI_FORMAT_B5G6R5_UNORM: case DXGI_FORMAT_B5G5R5A1_UNORM: case DXGI_FORMAT_B4G4R4A4_UNORM: return true;     // :2826-2847
         default: return false;
         }
     }
@@ -213,13 +270,90 @@ bool DirectX::Internal::LoadScanline(XMVECTOR* pDestination, size_t count, const
     case DXGI_FORMAT_A8_UNORM:                  // :1158-1169
         for (size_t i = 0, n = texels(1); i < n; ++i) pDestination[i] = XMVectorSet(0.f, 0.f, 0.f, float(s[i]) / 255.f);
         return true;
+    case DXGI_FORMAT_R32G32B32_FLOAT:           // LOAD_SCANLINE3(XMFLOAT3, XMLoadFloat3, g_XMIdentityR3), :811-812
+        for (size_t i = 0, n = texels(12); i < n; ++i)
+        {
+            const float* f = reinterpret_cast<const float*>(s + i * 12);
+            pDestination[i] = XMVectorSet(f[0], f[1], f[2], 1.f);
+        }
+        return true;
+    case DXGI_FORMAT_R16G16B16A16_SNORM:        // XMLoadShortN4, :829-830
+        for (size_t i = 0, n = texels(8); i < n; ++i)
+        {
+            const int16_t* h = reinterpret_cast<const int16_t*>(s + i * 8);
+            float c[4];
+            for (int k = 0; k < 4; ++k) { c[k] = float(h[k]) * (1.0f / 32767.0f); c[k] = (c[k] > -1.0f) ? c[k] : -1.0f; }
+            pDestination[i] = XMVectorSet(c[0], c[1], c[2], c[3]);
+        }
+        return true;
+    case DXGI_FORMAT_R16G16_SNORM:              // XMLoadShortN2, :931-932
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const int16_t* h = reinterpret_cast<const int16_t*>(s + i * 4);
+            float x = float(h[0]) * (1.0f / 32767.0f), y = float(h[1]) * (1.0f / 32767.0f);
+            x = (x > -1.0f) ? x : -1.0f; y = (y > -1.0f) ? y : -1.0f;
+            pDestination[i] = XMVectorSet(x, y, 0.f, 1.f);
+        }
+        return true;
+    case DXGI_FORMAT_R16_SNORM:                 // :1080-1091
+        for (size_t i = 0, n = texels(2); i < n; ++i) pDestination[i] = XMVectorSet(static_cast<float>(reinterpret_cast<const int16_t*>(s)[i]) / 32767.f, 0.f, 0.f, 1.f);
+        return true;
+    case DXGI_FORMAT_R10G10B10A2_UNORM:         // XMLoadUDecN4, :897-898
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const uint32_t v = reinterpret_cast<const uint32_t*>(s)[i];
+            pDestination[i] = XMVectorSet(float(v & 0x3FF) * (1.0f / 1023.0f), float((v >> 10) & 0x3FF) * (1.0f / 1023.0f),
+                                          float((v >> 20) & 0x3FF) * (1.0f / 1023.0f), float(v >> 30) * (1.0f / 3.0f));
+        }
+        return true;
+    case DXGI_FORMAT_R11G11B10_FLOAT:           // XMLoadFloat3PK, :906-907
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const uint32_t v = reinterpret_cast<const uint32_t*>(s)[i];
+            pDestination[i] = XMVectorSet(load_small_float((v >> 6) & 0x1F, v & 0x3F, 6), load_small_float((v >> 17) & 0x1F, (v >> 11) & 0x3F, 6),
+                                          load_small_float((v >> 27) & 0x1F, (v >> 22) & 0x1F, 5), 1.f);
+        }
+        return true;
+    case DXGI_FORMAT_R9G9B9E5_SHAREDEXP:        // XMLoadFloat3SE, :1189-1190
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const uint32_t v = reinterpret_cast<const uint32_t*>(s)[i];
+            union { float f; int32_t i; } fi;
+            fi.i = 0x33800000 + int32_t((v >> 27) << 23);
+            const float Scale = fi.f;
+            pDestination[i] = XMVectorSet(Scale * float(v & 0x1FF), Scale * float((v >> 9) & 0x1FF), Scale * float((v >> 18) & 0x1FF), 1.f);
+        }
+        return true;
+    case DXGI_FORMAT_B5G6R5_UNORM:              // :1227-1242
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            const uint16_t v = reinterpret_cast<const uint16_t*>(s)[i];
+            const float x = float(v & 0x1F) * (1.f / 31.f), y = float((v >> 5) & 0x3F) * (1.f / 63.f), z = float((v >> 11) & 0x1F) * (1.f / 31.f);
+            pDestination[i] = XMVectorSet(z, y, x, 1.f);        // XMVectorSwizzle<2, 1, 0, 3>, w from g_XMIdentityR3
+        }
+        return true;
+    case DXGI_FORMAT_B5G5R5A1_UNORM:            // :1244-1258
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            const uint16_t v = reinterpret_cast<const uint16_t*>(s)[i];
+            const float x = float(v & 0x1F) * (1.f / 31.f), y = float((v >> 5) & 0x1F) * (1.f / 31.f), z = float((v >> 10) & 0x1F) * (1.f / 31.f);
+            pDestination[i] = XMVectorSet(z, y, x, float(v >> 15) * 1.f);
+        }
+        return true;
+    case DXGI_FORMAT_B4G4R4A4_UNORM:            // :1511-1525
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            const uint16_t v = reinterpret_cast<const uint16_t*>(s)[i];
+            pDestination[i] = XMVectorSet(float((v >> 8) & 0xF) * (1.f / 15.f), float((v >> 4) & 0xF) * (1.f / 15.f), float(v & 0xF) * (1.f / 15.f), float(v >> 12) * (1.f / 15.f));
+        }
+        return true;
     default:
         return false;
     }
 }
 
 // ---- StoreScanline (:1629-2533) --------------------------------------------------------------------------------------------------
-bool DirectX::Internal::StoreScanline(void* pDestination, size_t size, DXGI_FORMAT format, const XMVECTOR* pSource, size_t count, float) noexcept
+bool DirectX::Internal::StoreScanline(void* pDestination, size_t size, DXGI_FORMAT format, const XMVECTOR* pSource, size_t count, float threshold) noexcept
 {
     if (!pDestination || !size || !pSource || !count) return false;
     uint8_t* d = static_cast<uint8_t*>(pDestination);
@@ -323,6 +457,87 @@ bool DirectX::Internal::StoreScanline(void* pDestination, size_t size, DXGI_FORM
             d[i] = static_cast<uint8_t>(v * 255.f);
         }
         return true;
+    case DXGI_FORMAT_R32G32B32_FLOAT:           // XMStoreFloat3, :1680-1681
+        for (size_t i = 0, n = texels(12); i < n; ++i) memcpy(d + i * 12, pSource[i].f, 12);
+        return true;
+    case DXGI_FORMAT_R16G16B16A16_SNORM:        // XMStoreShortN4, :1710-1711
+        for (size_t i = 0, n = texels(8); i < n; ++i)
+        {
+            uint16_t* h = reinterpret_cast<uint16_t*>(d + i * 8);
+            for (int c = 0; c < 4; ++c) h[c] = store_snorm16(pSource[i].f[c]);
+        }
+        return true;
+    case DXGI_FORMAT_R16G16_SNORM:              // XMStoreShortN2, :1804-1805
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            uint16_t* h = reinterpret_cast<uint16_t*>(d + i * 4);
+            h[0] = store_snorm16(pSource[i].f[0]); h[1] = store_snorm16(pSource[i].f[1]);
+        }
+        return true;
+    case DXGI_FORMAT_R16_SNORM:                 // :1928-1941
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            float v = pSource[i].f[0];
+            v = std::max<float>(std::min<float>(v, 1.f), -1.f);
+            reinterpret_cast<int16_t*>(d)[i] = static_cast<int16_t>(lroundf(v * 32767.f));
+        }
+        return true;
+    case DXGI_FORMAT_R10G10B10A2_UNORM:         // XMStoreUDecN4 (saturate, scale, truncate), :1747-1748
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const float* v = pSource[i].f;
+            reinterpret_cast<uint32_t*>(d)[i] = (uint32_t(clampf(v[0], 0.f, 1.f) * 1023.0f) & 0x3FF) | ((uint32_t(clampf(v[1], 0.f, 1.f) * 1023.0f) & 0x3FF) << 10) |
+                                                ((uint32_t(clampf(v[2], 0.f, 1.f) * 1023.0f) & 0x3FF) << 20) | ((uint32_t(clampf(v[3], 0.f, 1.f) * 3.0f) & 0x3) << 30);
+        }
+        return true;
+    case DXGI_FORMAT_R11G11B10_FLOAT:           // XMStoreFloat3PK, :1756-1757
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+            reinterpret_cast<uint32_t*>(d)[i] = store_small_float(pSource[i].f[0], 6) | (store_small_float(pSource[i].f[1], 6) << 11) | (store_small_float(pSource[i].f[2], 5) << 22);
+        return true;
+    case DXGI_FORMAT_R9G9B9E5_SHAREDEXP:        // StoreFloat3SE, :158-191 / :2057-2058
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const float* t = pSource[i].f;
+            constexpr float maxf9 = float(0x1FF << 7);
+            constexpr float minf9 = float(1.f / (1 << 16));
+            float x = (t[0] >= 0.f) ? ((t[0] > maxf9) ? maxf9 : t[0]) : 0.f;
+            float y = (t[1] >= 0.f) ? ((t[1] > maxf9) ? maxf9 : t[1]) : 0.f;
+            float z = (t[2] >= 0.f) ? ((t[2] > maxf9) ? maxf9 : t[2]) : 0.f;
+            const float max_xy = (x > y) ? x : y;
+            const float max_xyz = (max_xy > z) ? max_xy : z;
+            const float maxColor = (max_xyz > minf9) ? max_xyz : minf9;
+            union { float f; int32_t i; } fi;
+            fi.f = maxColor;
+            fi.i += 0x00004000;
+            const uint32_t exp = uint32_t(fi.i) >> 23;
+            const uint32_t e = (exp - 0x6f) & 0x1F;
+            fi.i = int32_t(0x83000000u - (exp << 23));
+            const float ScaleR = fi.f;
+            reinterpret_cast<uint32_t*>(d)[i] = (uint32_t(lroundf(x * ScaleR)) & 0x1FF) | ((uint32_t(lroundf(y * ScaleR)) & 0x1FF) << 9) | ((uint32_t(lroundf(z * ScaleR)) & 0x1FF) << 18) | (e << 27);
+        }
+        return true;
+    case DXGI_FORMAT_B5G6R5_UNORM:              // :2096-2114 (x64: multiply, XMStoreU565 rounds to nearest)
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            const float* v = pSource[i].f;
+            reinterpret_cast<uint16_t*>(d)[i] = uint16_t((store_scaled(v[2], 31.f) & 0x1F) | ((store_scaled(v[1], 63.f) & 0x3F) << 5) | ((store_scaled(v[0], 31.f) & 0x1F) << 11));
+        }
+        return true;
+    case DXGI_FORMAT_B5G5R5A1_UNORM:            // :2116-2139
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            const float* v = pSource[i].f;
+            reinterpret_cast<uint16_t*>(d)[i] = uint16_t((store_scaled(v[2], 31.f) & 0x1F) | ((store_scaled(v[1], 31.f) & 0x1F) << 5) | ((store_scaled(v[0], 31.f) & 0x1F) << 10) |
+                                                         ((v[3] > threshold) ? 0x8000u : 0u));
+        }
+        return true;
+    case DXGI_FORMAT_B4G4R4A4_UNORM:            // :2399-2417
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            const float* v = pSource[i].f;
+            reinterpret_cast<uint16_t*>(d)[i] = uint16_t((store_scaled(v[2], 15.f) & 0xF) | ((store_scaled(v[1], 15.f) & 0xF) << 4) | ((store_scaled(v[0], 15.f) & 0xF) << 8) | ((store_scaled(v[3], 15.f) & 0xF) << 12));
+        }
+        return true;
     default:
         return false;
     }
@@ -379,24 +594,42 @@ void DirectX::Internal::ConvertScanline(XMVECTOR* pBuffer, size_t count, DXGI_FO
     const uint32_t diff = in ^ out;
     if (diff != 0)
     {
+        const bool x2bias = (flags & TEX_FILTER_FLOAT_X2BIAS) != 0;
         if (out & C_UNORM)
         {
             if (in & C_SNORM) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = v[c] * 0.5f + 0.5f; });                       // :3457-3463
             else if (in & C_FLOAT)
             {
-                if (flags & TEX_FILTER_FLOAT_X2BIAS) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = clampf(v[c], -1.f, 1.f) * 0.5f + 0.5f; });   // :3469-3477
+                if (!(in & C_POS_ONLY) && x2bias) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = clampf(v[c], -1.f, 1.f) * 0.5f + 0.5f; });   // :3469-3477
                 else each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = clampf(v[c], 0.f, 1.f); });                               // :3481-3486
             }
         }
         else if (out & C_SNORM)
         {
             if (in & C_UNORM) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = v[c] * 2.0f + -1.0f; });                       // :3495-3501
-            else if (in & C_FLOAT) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = clampf(v[c], -1.f, 1.f); });               // :3521-3526
+            else if (in & C_FLOAT)
+            {
+                if ((in & C_POS_ONLY) && x2bias) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = clampf(v[c], 0.f, 1.f) * 2.0f + -1.0f; });    // :3506-3515
+                else each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = clampf(v[c], -1.f, 1.f); });                             // :3519-3526
+            }
         }
         else if (diff & C_UNORM)
         {
-            if ((out & C_FLOAT) && (flags & TEX_FILTER_FLOAT_X2BIAS))
-                each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = v[c] * 2.0f + -1.0f; });                                     // :3536-3546
+            if ((out & C_FLOAT) && !(out & C_POS_ONLY) && x2bias)
+                each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = v[c] * 2.0f + -1.0f; });                                     // :3533-3542
+        }
+        else if ((diff & C_POS_ONLY) && x2bias)
+        {
+            // :3545-3587
+            if (in & C_POS_ONLY)
+            {
+                if (out & C_FLOAT) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = clampf(v[c], 0.f, 1.f) * 2.0f + -1.0f; });
+            }
+            else if (out & C_POS_ONLY)
+            {
+                if (in & C_FLOAT) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = clampf(v[c], -1.f, 1.f) * 0.5f + 0.5f; });
+                else if (in & C_SNORM) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = v[c] * 0.5f + 0.5f; });
+            }
         }
 
         const uint32_t RGBA = C_R | C_G | C_B | C_A, RGB = C_R | C_G | C_B;

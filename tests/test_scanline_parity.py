@@ -100,6 +100,79 @@ def test_convert(ctx, oracle, pair, flags):
     assert np.array_equal(got, ref), (pair, hex(flags), np.nonzero(got != ref)[0][:8])
 
 
+# ---- the packed long tail (LoadScanline :779-1619, StoreScanline :1643-2533) ---------------------------
+RGB32F, RGBA16S, RGB10A2, R11G11B10F, RG16S, R16S, RGB9E5, B5G6R5, B5G5R5A1, B4G4R4A4 = 6, 13, 24, 26, 37, 58, 67, 85, 86, 115
+LONG_TAIL = [RGB32F, RGBA16S, RGB10A2, R11G11B10F, RG16S, R16S, RGB9E5, B5G6R5, B5G5R5A1, B4G4R4A4]
+
+
+def _float_texels(rng, h, w, dtype):
+    """Floats that exercise the packed float stores: negatives, values under / over the small formats' range, exact ties, zero, huge."""
+    v = (rng.random((h, w, 4), dtype=np.float32) * 3 - 1).astype(np.float32)
+    scale = np.exp2(rng.integers(-24, 18, (h, w, 1))).astype(np.float32)
+    v = np.where(rng.random((h, w, 1)) < 0.5, v * scale, v)
+    v[0, :8] = [[0, 65504, 65505, 1e9], [6.1e-5, 6.0e-5, 3.0e-5, 1], [0.5, 0.25, 0.125, 0.5], [1, 1, 1, 1],
+                [-0.0, -1, -65504, -1e9], [9.5e-7, 9.6e-7, 1.9e-6, 0], [65024, 64512, 64000, 0.5000001], [4.7e-7, 4.8e-7, 2.0e-6, 0.4999999]]
+    return v.astype(dtype)
+
+
+@pytest.mark.parametrize("fmt", LONG_TAIL)
+@pytest.mark.parametrize("other", [RGBA32F, RGBA16F, RGBA8, 31])
+@pytest.mark.parametrize("flags", [0, 0x200])
+def test_convert_long_tail(ctx, oracle, fmt, other, flags):
+    """Every long-tail format as source and as destination against float, half, UNORM and SNORM four-channel formats, with and without
+    TEX_FILTER_FLOAT_X2BIAS (the positive-only float formats take different branches there, DirectXTexConvert.cpp:3469-3587)."""
+    w, h = 67, 9
+    rng = np.random.default_rng(fmt * 977 + other * 13 + flags)
+    # as source: every bit pattern of the packed texel is legal input
+    img = rng.integers(0, 256, oracle.image_bytes(fmt, w, h), dtype=np.uint8)
+    if fmt == RGB32F:
+        img = _float_texels(rng, h, w, np.float32)[..., :3].copy()
+    if fmt == R11G11B10F:
+        img = (img.view(np.uint32) & np.uint32(~((1 << 10) | (1 << 21) | (1 << 31)) & 0xFFFFFFFF)).view(np.uint8)   # finite codes (NaN payloads are covered against fp32 below)
+    got = ctx.convert(img, w, h, fmt, other, flags, 0.5)
+    ref = oracle.ref_convert(img, w, h, fmt, other, flags, 0.5)
+    assert np.array_equal(got, ref), ("load", fmt, other, hex(flags), np.nonzero(got != ref)[0][:8])
+    # as destination
+    if other in (RGBA32F, RGBA16F):
+        src = _float_texels(rng, h, w, np.float32 if other == RGBA32F else np.float16)
+    else:
+        src = rng.integers(0, 256, oracle.image_bytes(other, w, h), dtype=np.uint8)
+    for threshold in ((0.5, 0.2) if fmt == B5G5R5A1 else (0.5,)):
+        got = ctx.convert(src, w, h, other, fmt, flags, threshold)
+        ref = oracle.ref_convert(src, w, h, other, fmt, flags, threshold)
+        assert np.array_equal(got, ref), ("store", other, fmt, hex(flags), threshold, np.nonzero(got != ref)[0][:8])
+
+
+def test_convert_long_tail_float11_exhaustive(ctx, oracle):
+    """Every 11-bit and 10-bit small float through load and back through store: the packed float codecs round-trip every finite code."""
+    codes = np.arange(2048, dtype=np.uint32)
+    img = (codes | (codes << 11) | ((codes & 0x3FF) << 22)).astype(np.uint32)
+    w, h = 2048, 1
+    f = ctx.convert(img, w, h, R11G11B10F, RGBA32F, 0, 0.5)
+    assert np.array_equal(f, oracle.ref_convert(img, w, h, R11G11B10F, RGBA32F, 0, 0.5))
+    back = ctx.convert(f.view(np.float32), w, h, RGBA32F, R11G11B10F, 0, 0.5).view(np.uint32)
+    assert np.array_equal(back, oracle.ref_convert(f.view(np.float32), w, h, RGBA32F, R11G11B10F, 0, 0.5).view(np.uint32))
+    finite = ((codes >> 6) & 0x1F) != 0x1F
+    assert np.array_equal(back[finite] & 0x7FF, codes[finite])
+
+
+@pytest.mark.parametrize("fmt", [RGB10A2, R11G11B10F, RGB9E5, B5G6R5, B5G5R5A1, B4G4R4A4, RGBA16S, RGB32F])
+@pytest.mark.parametrize("flt", [BOX, CUBIC, TRIANGLE])
+def test_generate_mips_long_tail(ctx, oracle, fmt, flt):
+    """The filters read and write the packed formats through the same Load / StoreScanline[Linear] code."""
+    w, h = 32, 16
+    rng = np.random.default_rng(fmt)
+    img = rng.integers(0, 256, oracle.image_bytes(fmt, w, h), dtype=np.uint8)
+    if fmt == R11G11B10F:
+        img = (img.view(np.uint32) & np.uint32(~((1 << 10) | (1 << 21) | (1 << 31)) & 0xFFFFFFFF)).view(np.uint8)
+    if fmt == RGB32F:
+        img = rng.random((h, w, 3), dtype=np.float32)
+    got = ctx.generate_mips(img, w, h, fmt, 5, flt)
+    ref = oracle.ref_generate_mips(img, w, h, fmt, flt, 5)
+    for lvl in range(5):
+        assert np.array_equal(got[lvl], ref[lvl]), (fmt, hex(flt), lvl)
+
+
 def test_convert_srgb(ctx, oracle):
     w, h = 64, 16
     img = _image(w, h, RGBA8, 9)
