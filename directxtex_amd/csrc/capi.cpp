@@ -108,8 +108,9 @@ struct ScopedDevice
     ~ScopedDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-void time_begin(dxtex_ctx* ctx) { (void)hipEventRecord(ctx->evStart, ctx->stream); }
-void time_end(dxtex_ctx* ctx) { (void)hipEventRecord(ctx->evStop, ctx->stream); ctx->timing = true; }
+static const bool kNoTiming = getenv("DXTEX_NO_TIMING") != nullptr;
+void time_begin(dxtex_ctx* ctx) { if (!kNoTiming) (void)hipEventRecord(ctx->evStart, ctx->stream); }
+void time_end(dxtex_ctx* ctx) { if (!kNoTiming) { (void)hipEventRecord(ctx->evStop, ctx->stream); ctx->timing = true; } }
 
 // The part of ConvertScanline that Compress reaches (DirectXTexConvert.cpp:3080-3854), resolved once
 // per image on the host into the (tcv, tsw) pair the tile loader applies.

@@ -185,6 +185,36 @@ __global__ void __launch_bounds__(256) resize_box_kernel(ResizeArgs a)
     for (uint32_t y = blockIdx.y; y < a.dst.height; y += gridDim.y) resize_box_kernel_row(a, x, y);        // grid_rows(): HIP caps grid.y at 65535
 }
 
+// Box, exactly 2:1 on RGBA8 (the upper levels of a power-of-two mip chain, where the bytes are): one lane produces two adjacent
+// destination texels from one 16-byte load per source row - consecutive lanes read consecutive 16 bytes - and writes 8 bytes.
+// Same expression as resize_box_kernel: (((p00 + p01) + p10) + p11) * 0.25 with p0x the left column's two rows.
+__global__ void __launch_bounds__(256) resize_box_half_rgba8_kernel(ResizeArgs a)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;              // pair of destination texels
+    if (q * 2u >= a.dst.width) return;
+    for (uint32_t y = blockIdx.y; y < a.dst.height; y += gridDim.y)
+    {
+        const uint4 t = reinterpret_cast<const uint4*>(a.src.pixels + uint64_t(2u * y) * a.src.rowPitch)[q];
+        const uint4 b = reinterpret_cast<const uint4*>(a.src.pixels + uint64_t(2u * y + 1u) * a.src.rowPitch)[q];
+        const uint32_t top[4] = { t.x, t.y, t.z, t.w }, bot[4] = { b.x, b.y, b.z, b.w };
+        uint32_t out[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+        {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                const float p0 = float((top[2 * k] >> (8 * c)) & 0xFFu) * (1.0f / 255.0f), p1 = float((bot[2 * k] >> (8 * c)) & 0xFFu) * (1.0f / 255.0f);
+                const float p2 = float((top[2 * k + 1] >> (8 * c)) & 0xFFu) * (1.0f / 255.0f), p3 = float((bot[2 * k + 1] >> (8 * c)) & 0xFFu) * (1.0f / 255.0f);
+                packed |= store_ubn_biased((((p0 + p1) + p2) + p3) * 0.25f) << (8 * c);
+            }
+            out[k] = packed;
+        }
+        reinterpret_cast<uint2*>(a.dst.pixels + uint64_t(y) * a.dst.rowPitch)[q] = make_uint2(out[0], out[1]);
+    }
+}
+
 // ---- linear (filters.h:57-104) ---------------------------------------------------------------------------------------------
 struct Lin { uint32_t u0, u1; float w0, w1; };
 __device__ __forceinline__ Lin linear_entry(uint32_t source, uint32_t dest, bool wrap, uint32_t u)
@@ -309,6 +339,65 @@ __global__ void __launch_bounds__(256) resize_cubic_kernel(ResizeArgs a)
 {
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
     for (uint32_t y = blockIdx.y; y < a.dst.height; y += gridDim.y) resize_cubic_kernel_row(a, x, y);        // grid_rows(): HIP caps grid.y at 65535
+}
+
+// Cubic, exactly 2:1 in both directions with clamp addressing on RGBA8 (every level of a power-of-two mip chain): srcB = 2u + 0.5, so the
+// four taps are texels 2u-1 .. 2u+2 (clamped) and dx = 0.5 for every destination texel. The filter is separable in the reference too
+// (CUBIC_INTERPOLATE along x for four source rows, then along y, filters.h:192-207), and neighbouring destination rows share two of their
+// four source rows: a workgroup filters the 34 source rows of a 64 x 16 destination tile along x once, into LDS, and then along y -
+// 2.1 row passes per destination texel instead of 4, unpacking each source texel once per row pass. Same expressions, same order,
+// same bits as resize_cubic_kernel.
+constexpr int kCubTileW = 64, kCubTileH = 16, kCubRows = 2 * kCubTileH + 2;
+__global__ void __launch_bounds__(256) resize_cubic_half_rgba8_kernel(ResizeArgs a)
+{
+    __shared__ float4 sRow[kCubRows][kCubTileW];
+    const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * kCubTileW + tx, y0 = blockIdx.y * kCubTileH;
+    const int64_t srcW = a.src.width, srcH = a.src.height;
+    if (x < a.dst.width)
+    {
+        const int64_t u0 = int64_t(2) * x - 1;
+        const bool inside = u0 >= 0 && u0 + 3 < srcW;
+        for (uint32_t r = ty; r < uint32_t(kCubRows); r += 4)
+        {
+            int64_t sy = int64_t(2) * y0 - 1 + r;
+            sy = sy < 0 ? 0 : (sy > srcH - 1 ? srcH - 1 : sy);
+            const uint8_t* row = a.src.pixels + uint64_t(sy) * a.src.rowPitch;
+            uint32_t w0, w1, w2, w3;
+            if (inside)
+            {
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(row) + u0;
+                w0 = q[0]; w1 = q[1]; w2 = q[2]; w3 = q[3];
+            }
+            else
+            {
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(row);
+                auto cl = [&](int64_t u) { return uint32_t(u < 0 ? 0 : (u > srcW - 1 ? srcW - 1 : u)); };
+                w0 = q[cl(u0)]; w1 = q[cl(u0 + 1)]; w2 = q[cl(u0 + 2)]; w3 = q[cl(u0 + 3)];
+            }
+#define DXTEX_CH(W, S) (float(((W) >> (S)) & 0xFFu) * (1.0f / 255.0f))
+            float4 c;
+            c.x = cubic1(0.5f, DXTEX_CH(w0, 0), DXTEX_CH(w1, 0), DXTEX_CH(w2, 0), DXTEX_CH(w3, 0));
+            c.y = cubic1(0.5f, DXTEX_CH(w0, 8), DXTEX_CH(w1, 8), DXTEX_CH(w2, 8), DXTEX_CH(w3, 8));
+            c.z = cubic1(0.5f, DXTEX_CH(w0, 16), DXTEX_CH(w1, 16), DXTEX_CH(w2, 16), DXTEX_CH(w3, 16));
+            c.w = cubic1(0.5f, DXTEX_CH(w0, 24), DXTEX_CH(w1, 24), DXTEX_CH(w2, 24), DXTEX_CH(w3, 24));
+#undef DXTEX_CH
+            sRow[r][tx] = c;
+        }
+    }
+    __syncthreads();
+    if (x >= a.dst.width) return;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+    {
+        const uint32_t yl = ty + 4 * k, y = y0 + yl;
+        if (y >= a.dst.height) break;
+        const float4 c0 = sRow[2 * yl][tx], c1 = sRow[2 * yl + 1][tx], c2 = sRow[2 * yl + 2][tx], c3 = sRow[2 * yl + 3][tx];
+        Texel o;
+        o.r = cubic1(0.5f, c0.x, c1.x, c2.x, c3.x); o.g = cubic1(0.5f, c0.y, c1.y, c2.y, c3.y);
+        o.b = cubic1(0.5f, c0.z, c1.z, c2.z, c3.z); o.a = cubic1(0.5f, c0.w, c1.w, c2.w, c3.w);
+        store_linear(a.dst, x, y, 0, o);
+    }
 }
 
 // ---- triangle (filters.h:209-419; accumulation order of DirectXTexMipmaps.cpp:1517-1542 / DirectXTexResize.cpp:730-760) ----------
@@ -614,8 +703,21 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
     {
     case 0x100000u: hipLaunchKernelGGL(resize_point_kernel, grid, block, 0, stream, a); break;
     case 0x200000u: hipLaunchKernelGGL(resize_linear_kernel, grid, block, 0, stream, a); break;
-    case 0x300000u: hipLaunchKernelGGL(resize_cubic_kernel, grid, block, 0, stream, a); break;
-    case 0x400000u: hipLaunchKernelGGL(resize_box_kernel, grid, block, 0, stream, a); break;
+    case 0x300000u:
+        // the 2:1 RGBA8 case of a power-of-two mip chain has a separable LDS-tiled kernel; levels narrower than a tile gain nothing from it
+        if (format == FMT_R8G8B8A8_UNORM && !a.srgbIn && !a.srgbOut && srcW == 2 * dstW && srcH == 2 * dstH && dstW >= 64 &&
+            !a.wrapU && !a.wrapV && !a.mirrorU && !a.mirrorV && (srcPitch % 4) == 0)
+            hipLaunchKernelGGL(resize_cubic_half_rgba8_kernel, dim3((dstW + kCubTileW - 1) / kCubTileW, (dstH + kCubTileH - 1) / kCubTileH), block, 0, stream, a);
+        else
+            hipLaunchKernelGGL(resize_cubic_kernel, grid, block, 0, stream, a);
+        break;
+    case 0x400000u:
+        if (format == FMT_R8G8B8A8_UNORM && !a.srgbIn && !a.srgbOut && srcW == 2 * dstW && srcH == 2 * dstH && (dstW % 2) == 0 && dstW >= 256 &&
+            (srcPitch % 16) == 0 && (dstPitch % 8) == 0 && (reinterpret_cast<uintptr_t>(src) % 16) == 0 && (reinterpret_cast<uintptr_t>(dst) % 8) == 0)
+            hipLaunchKernelGGL(resize_box_half_rgba8_kernel, dim3((dstW / 2 + 255) / 256, grid_rows(dstH)), block, 0, stream, a);
+        else
+            hipLaunchKernelGGL(resize_box_kernel, grid, block, 0, stream, a);
+        break;
     case 0x500000u: hipLaunchKernelGGL(resize_triangle_kernel, grid, block, 0, stream, a); break;
     default: return hipErrorInvalidValue;
     }

@@ -1080,7 +1080,7 @@ HRESULT PremultiplyAlpha(Device& device, const Image* srcImages, size_t nimages,
     {
         const Image& src = srcImages[i];
         if (src.format != metadata.format) { result.Release(); return E_FAIL; }
-        if (src.width > UINT32_MAX || src.height > UINT32_MAX) return E_FAIL;
+        if (src.width > UINT32_MAX || src.height > UINT32_MAX) { result.Release(); return E_FAIL; }
         if (src.width != dest[i].width || src.height != dest[i].height) { result.Release(); return E_FAIL; }
         const dxtex_image s = View(src), d = View(dest[i]);
         hr = dxtex_premultiply_alpha(device.Get(), &s, &d, uint32_t(flags));

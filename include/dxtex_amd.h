@@ -9,7 +9,9 @@
  *   reference interface                                         replaced by
  *   ----------------------------------------------------------  -----------------------------------------
  *   GPUCompressBC::Initialize(ID3D11Device*)   BCDirectCompute.h:26   dxtex_ctx_create
- *   GPUCompressBC::Prepare(w,h,flags,fmt,aw)   BCDirectCompute.h:28   (folded into compress: no per-size state)
+ *   GPUCompressBC::Prepare(w,h,flags,fmt,aw)   BCDirectCompute.h:28   dxtex_ctx_prepare (optional: sizes the search scratch and the staging now instead of
+ *                                                                     on first use; alphaWeight belongs to the D3D11 BC7 shader and has no counterpart in
+ *                                                                     the CPU-path encoders reproduced here)
  *   GPUCompressBC::Compress(src,dst)           BCDirectCompute.h:30   dxtex_compress / dxtex_compress_device
  *   CompressBC / CompressBC_Parallel           DirectXTexCompress.cpp:72-372   dxtex_compress
  *   DecompressBC                               DirectXTexCompress.cpp:425-535  dxtex_decompress

@@ -50,6 +50,31 @@ def test_generate_mips(ctx, oracle, fmt, size, flt):
         assert np.array_equal(got[lvl], ref[lvl]), (fmt, size, hex(flt), lvl, np.nonzero(got[lvl] != ref[lvl])[0][:8])
 
 
+@pytest.mark.parametrize("size", [(512, 256), (128, 384), (1024, 16), (192, 136)])
+def test_generate_mips_cubic_tiled(ctx, oracle, size):
+    """Levels at least 64 texels wide of an exactly-halving RGBA8 chain take the separable LDS-tiled cubic kernel (partial tiles, image
+    borders, heights that are not a multiple of the tile); narrower or non-halving levels (192 x 136 -> ... -> 3 x 2) the general one."""
+    w, h = size
+    img = _image(w, h, RGBA8, seed=w + h)
+    n = _levels(w, h)
+    got = ctx.generate_mips(img, w, h, RGBA8, n, CUBIC)
+    ref = oracle.ref_generate_mips(img, w, h, RGBA8, CUBIC, n)
+    for lvl in range(n):
+        assert np.array_equal(got[lvl], ref[lvl]), (size, lvl, np.nonzero(got[lvl] != ref[lvl])[0][:8])
+
+
+@pytest.mark.parametrize("size", [(2048, 64), (512, 256), (1024, 4)])
+def test_generate_mips_box_wide(ctx, oracle, size):
+    """Levels at least 256 texels wide of an RGBA8 chain take the four-texels-per-lane box kernel, the rest the general one."""
+    w, h = size
+    img = _image(w, h, RGBA8, seed=w * 3 + h)
+    n = _levels(w, h)
+    got = ctx.generate_mips(img, w, h, RGBA8, n, BOX)
+    ref = oracle.ref_generate_mips(img, w, h, RGBA8, BOX, n)
+    for lvl in range(n):
+        assert np.array_equal(got[lvl], ref[lvl]), (size, lvl, np.nonzero(got[lvl] != ref[lvl])[0][:8])
+
+
 @pytest.mark.parametrize("flt", [BOX, LINEAR, CUBIC, TRIANGLE])
 def test_generate_mips_srgb(ctx, oracle, flt):
     w, h = 64, 64
