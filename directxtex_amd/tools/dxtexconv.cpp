@@ -43,6 +43,8 @@ const Name kFormats[] = {
     { "BC1_UNORM", 71 }, { "BC1_UNORM_SRGB", 72 }, { "BC2_UNORM", 74 }, { "BC2_UNORM_SRGB", 75 }, { "BC3_UNORM", 77 }, { "BC3_UNORM_SRGB", 78 },
     { "BC4_UNORM", 80 }, { "BC4_SNORM", 81 }, { "BC5_UNORM", 83 }, { "BC5_SNORM", 84 }, { "B8G8R8A8_UNORM", 87 }, { "B8G8R8X8_UNORM", 88 },
     { "B8G8R8A8_UNORM_SRGB", 91 }, { "B8G8R8X8_UNORM_SRGB", 93 }, { "BC6H_UF16", 95 }, { "BC6H_SF16", 96 }, { "BC7_UNORM", 98 }, { "BC7_UNORM_SRGB", 99 },
+    { "R32G32B32_FLOAT", 6 }, { "R16G16B16A16_SNORM", 13 }, { "R10G10B10A2_UNORM", 24 }, { "R11G11B10_FLOAT", 26 }, { "R16G16_SNORM", 37 }, { "R16_SNORM", 58 },
+    { "R9G9B9E5_SHAREDEXP", 67 }, { "B5G6R5_UNORM", 85 }, { "B5G5R5A1_UNORM", 86 }, { "B4G4R4A4_UNORM", 115 },
     // texconv's aliases (texconv.cpp:420-440)
     { "DXT1", 71 }, { "DXT2", 74 }, { "DXT3", 74 }, { "DXT4", 77 }, { "DXT5", 77 }, { "RGBA", 28 }, { "BGRA", 87 }, { "BGR", 88 }, { "FP16", 10 }, { "FP32", 2 },
     { "BC4", 80 }, { "BC5", 83 }, { "BC6H", 95 }, { "BC7", 98 },

@@ -104,6 +104,7 @@ L = [f"# {title}\n"]
 L.append("Collected by `tools/profile_r02.sh` (one `rocprofv3 --kernel-trace --stats` run, then separate `--kernel-trace --pmc` passes: SQ instruction counters,")
 L.append("SQ wait counters + GRBM_GUI_ACTIVE, TCC FETCH_SIZE, TCC WRITE_SIZE); summarised by `tools/profile_report_r02.py`.\n")
 L.append("## Kernel trace (`--stats`)\n")
+L.append("(rocprofv3's VGPR column is the kernel descriptor's granulated count read with the wave32 granule: the registers a wave64 lane really holds are twice that, as `hipcc -Rpass-analysis=kernel-resource-usage` / tools/kernel_resources.sh report.)\n")
 L.append("| kernel | calls | total ms | avg ms | % | VGPR | AGPR | SGPR | LDS B | scratch B | grid | wg |")
 L.append("|---|---|---|---|---|---|---|---|---|---|---|---|")
 for r in stats:
@@ -112,6 +113,8 @@ for r in stats:
         continue
     L.append(f"| `{k}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e6:.4f} | {float(r['Percentage']):.2f} | " + " | ".join(m) + " |")
 L.append("\n## VALU issue utilisation per launch (see the header of tools/profile_report_r02.py and profiles/r02_valu_rates.md)\n")
+L.append("The static mix is an estimate (a few per cent either way; the clock is taken at its 2.4 GHz maximum, profiled passes run lower): readings above 1 are shown as 1.00 = the SIMDs' VALU")
+L.append("issue slots are full. The two bracketing columns do not depend on the mix: a kernel whose all-4-cycle reading is below 1 has idle issue slots for certain.\n")
 L.append("| kernel | avg ms | waves | VALU insts / wave | active lanes per VALU inst | G lane-ops/s | fast-opcode share (static, loop-weighted) | mean issue cyc / inst | VALU issue utilisation | if every inst were 2 cyc / 4 cyc | clock GHz |")
 L.append("|---|---|---|---|---|---|---|---|---|---|---|")
 order = [short(r['Name']) for r in stats]
@@ -133,7 +136,7 @@ for k in order:
     u = per_simd * cyc / (secs * clock); u2 = per_simd * 2.15 / (secs * clock); u4 = per_simd * 4.15 / (secs * clock)
     util[k] = (u, lanes, insts, secs)
     L.append("| `%s` | %.4f | %d | %.0f | %.1f | %.0f | %.2f | %.2f | **%.2f** | %.2f / %.2f | %.2f |" % (
-        k, avg_ms[k], v['SQ_WAVES'] / n, insts / max(1, v['SQ_WAVES'] / n), lanes, insts * lanes / secs / 1e9, fast, cyc, min(u, 9.99), u2, u4, clock / 1e9))
+        k, avg_ms[k], v['SQ_WAVES'] / n, insts / max(1, v['SQ_WAVES'] / n), lanes, insts * lanes / secs / 1e9, fast, cyc, min(u, 1.0), u2, u4, clock / 1e9))
 L.append("\n## HBM traffic per launch (TCC `FETCH_SIZE`, `WRITE_SIZE`, separate passes; rocprofv3 reports KiB)\n")
 L.append("gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts the 128-B requests of wide (16 B per lane) streaming reads as 64 B. Kernels marked x2")
 L.append("read their image with 16-byte loads and have FETCH_SIZE doubled; the BC6H / BC7 search kernels read 4 B per lane, where the counter matched a known byte count")
