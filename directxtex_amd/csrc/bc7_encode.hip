@@ -842,8 +842,9 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
             c.ord = uint32_t(MODE) * 128u + sub;
             emit_block<MODE>(shape, rot, IM, epA, epB, idx1, myIdx2, anchors, c.lo, c.hi);
             a.cands[uint64_t(nb) * NUM_SLOTS + TM::SLOT] = c;
-            if (err == 0 && c.ord < a.zeroOrd[nb]) a.zeroOrd[nb] = c.ord;
-            if (err < a.bestErr[nb]) a.bestErr[nb] = err;
+            // (atomics: the single-subset modes of one phase run concurrently on separate streams)
+            if (err == 0) atomicMin(&a.zeroOrd[nb], c.ord);
+            atomicMin(&a.bestErr[nb], err);
         }
         else if (!active && rank == 0 && mine)
         {
@@ -930,7 +931,7 @@ const uint64_t kMaxBlocksPerPass = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::ma
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
 struct ScratchLayout
 {
-    size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, seeds, seeds1, seeds3, flagcnt, total;
+    size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, seeds, seeds1, seeds3, flagcnt, auxRecs, auxOrder, auxTinfo, auxCounters, total;
     explicit ScratchLayout(uint64_t nb, bool threeSubsets)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -949,9 +950,31 @@ struct ScratchLayout
         seeds1 = o; o = up(o + nb * 2 * sizeof(uint2));
         seeds3 = o; o = up(o + (threeSubsets ? nb * 192 * sizeof(uint2) : 0));
         flagcnt = o; o = up(o + 256);
+        // task arrays of the two extra pipelines when modes 4 (both index modes) and 5 run side by side: 4 tasks per block each
+        auxRecs = o; o = up(o + 2 * nb * 4 * sizeof(TaskRec));
+        auxOrder = o; o = up(o + 2 * nb * 4 * sizeof(uint2));
+        auxTinfo = o; o = up(o + 2 * nb * 4 * sizeof(uint32_t));
+        auxCounters = o; o = up(o + 2 * 64 * sizeof(uint32_t));
         total = o;
     }
 };
+
+// Two side streams (per host thread and device) for the pipelines that run next to the caller's stream, with the events that fork and join them.
+struct ForkStreams { hipStream_t side[2] = { nullptr, nullptr }; hipEvent_t forked = nullptr, joined[2] = { nullptr, nullptr }; int device = -1; };
+inline ForkStreams* fork_streams()
+{
+    static thread_local ForkStreams fs;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    if (fs.device == device) return &fs;
+    if (fs.device >= 0) return nullptr;                    // one device per host thread (a context is bound to one GPU)
+    bool ok = hipEventCreateWithFlags(&fs.forked, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+        ok = hipStreamCreateWithFlags(&fs.side[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&fs.joined[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) return nullptr;
+    fs.device = device;
+    return &fs;
+}
 
 template<int MODE, int IM>
 void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const char* const (&names)[7])
@@ -1088,10 +1111,8 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         }();
         a.phase = PHASE_ALL;
         if (quick) { DXTEX_MODE(6, 0, "mode6"); slotMask |= 1u << SLOT_M6; }
-        for (const int step : order)
+        auto run_step = [&](int step, Bc7Args a, hipStream_t stream, KernelMarks* marks)
         {
-            if (quick) break;
-            if (!three && (step == 0 || step == 2)) continue;
             a.phase = (step >= 20) ? PHASE_LATE : (step >= 10) ? PHASE_EARLY : PHASE_ALL;
             switch (step)
             {
@@ -1114,6 +1135,38 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
             case 7: DXTEX_MODE(7, 0, "mode7"); slotMask |= 1u << SLOT_M7; break;
             default: break;
             }
+        };
+        // Modes 4 (index modes 0 and 1) and 5 of one phase have four tasks per block each, long search chains and search kernels that end
+        // with tails of a few busy wavefronts: the three pipelines are independent until `pick` (each has its own candidate slot; the
+        // per-block best error / first-zero key they share are updated with atomics and only ever prune work that cannot matter), so
+        // consecutive steps of that family run side by side on two extra streams, each pipeline on its own slice of the task arrays.
+        // Per-kernel timing (marks) needs one stream and keeps them serial.
+        auto family45 = [](int step) { const int m = step % 10; return m == 4 || m == 8 || m == 5; };
+        static const bool serial45 = getenv("DXTEX_BC7_SERIAL") != nullptr;
+        ForkStreams* fork = (marks || serial45 || quick) ? nullptr : fork_streams();
+        for (size_t at = 0; at < order.size() && !quick; )
+        {
+            const int step = order[at];
+            if (!three && (step == 0 || step == 2)) { ++at; continue; }
+            size_t run = 1;
+            if (fork && family45(step))
+                while (at + run < order.size() && run < 3 && family45(order[at + run]) && order[at + run] / 10 == step / 10) ++run;
+            if (run == 1) { run_step(step, a, stream, marks); ++at; continue; }
+            (void)hipEventRecord(fork->forked, stream);
+            for (size_t k = 1; k < run; ++k)
+            {
+                Bc7Args b = a;
+                b.recs = reinterpret_cast<TaskRec*>(base + L.auxRecs) + (k - 1) * size_t(a.nblocks) * 4;
+                b.order = reinterpret_cast<uint2*>(base + L.auxOrder) + (k - 1) * size_t(a.nblocks) * 4;
+                b.tinfo = reinterpret_cast<uint32_t*>(base + L.auxTinfo) + (k - 1) * size_t(a.nblocks) * 4;
+                b.counters = reinterpret_cast<uint32_t*>(base + L.auxCounters) + (k - 1) * 64;
+                (void)hipStreamWaitEvent(fork->side[k - 1], fork->forked, 0);
+                run_step(order[at + k], b, fork->side[k - 1], nullptr);
+                (void)hipEventRecord(fork->joined[k - 1], fork->side[k - 1]);
+            }
+            run_step(step, a, stream, nullptr);
+            for (size_t k = 1; k < run; ++k) (void)hipStreamWaitEvent(stream, fork->joined[k - 1], 0);
+            at += run;
         }
 #if defined(DXTEX_EXH_STATS)
         hipLaunchKernelGGL(bc7_stats_print_kernel, dim3(1), dim3(1), 0, stream, reinterpret_cast<unsigned long long*>(flagCount) + 4);
