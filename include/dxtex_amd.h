@@ -144,7 +144,10 @@ dxtex_hresult dxtex_compress_device(dxtex_ctx* ctx, const dxtex_image* src, cons
  * search pipeline as one block list, so many small images cost what one image of the same total size costs. */
 dxtex_hresult dxtex_compress_many_device(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts,
                                          size_t count, uint32_t compress_flags, float threshold);
-/* Same with host pointers (staged through one device buffer, returns when the payloads are back). */
+/* Same with host pointers; returns when the payloads are back. The images are cut into chunks of about 32 Mi texels
+ * (DXTEX_MANY_CHUNK_TEXELS overrides); two sets of pinned staging + device buffers alternate so that the upload of chunk k+1
+ * and the download of chunk k-1 run on copy streams while chunk k's kernels run. The bytes written are those of
+ * `count` separate dxtex_compress calls. */
 dxtex_hresult dxtex_compress_many(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts,
                                   size_t count, uint32_t compress_flags, float threshold);
 
