@@ -704,8 +704,11 @@ struct EncodeArgs
 
 // KIND: 1..3 = BC1..BC3, 4/5 = BC4/BC5 unsigned, 6/7 = BC4/BC5 signed. One instantiation per format keeps
 // each kernel's register footprint to what that codec needs.
+#if !defined(DXTEX_BC15_PACKED_WGS)
+#define DXTEX_BC15_PACKED_WGS 3        // workgroups per CU the packed-tile instantiation is compiled for
+#endif
 template<int KIND, bool DITHER, bool PACKED8>
-__global__ void __launch_bounds__(256, PACKED8 ? 3 : 1) bc15_encode_kernel(EncodeArgs a)
+__global__ void __launch_bounds__(256, PACKED8 ? DXTEX_BC15_PACKED_WGS : 1) bc15_encode_kernel(EncodeArgs a)
 {
     const uint32_t nb = blockIdx.x * 256u + threadIdx.x;
     if (nb >= a.nbw * a.nbh) return;

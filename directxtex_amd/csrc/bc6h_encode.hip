@@ -451,13 +451,14 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
 
 // ---- perturb ------------------------------------------------------------------------------------------------------------------
 template<int N>
-__global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a)
+__global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a, uint32_t waveMax)
 {
     __shared__ float sSlot[48 * 64];
     const int lane = threadIdx.x;
     const bool sg = a.isSigned != 0;
     const uint32_t live = a.counters[34];
     if (live == 0) return;
+    if (N == 16 && live <= waveMax) return;        // short one-region lists: bc6h_perturb_wave_kernel's turn
     uint32_t* head = a.counters + kQueueBase;
     float* slot = &sSlot[lane];
     const int TPB = (N == 8) ? 16 : 1;
@@ -510,6 +511,87 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a)
                 for (int c = 0; c < 3; ++c) { r->A[c] = st.ep.A[c]; r->B[c] = st.ep.B[c]; }
                 myTask = 0xFFFFFFFFu;
             }
+        }
+    }
+}
+
+// The one-region modes have one task per block, and after pruning few of them are left (hundreds to a few thousand in a 4096^2
+// image) - but each is long: a PerturbOne call of the 16-bit mode walks 32 candidates of 16 texels x 16 palette entries, and the
+// alternating loop repeats it as long as it improves. With a lane per task the kernel takes as long as its longest chain
+// (8 ms per 4096^2 image, nearly all of the machine idle). Below kWaveTaskMax6 live tasks a WAVEFRONT owns a task instead: lane
+// (half, k) evaluates texel k against candidate `cur - step` (half 0) or `cur + step` (half 1), the per-texel errors are summed
+// in texel order as MapColorsQuantized does (:2044-2077), and every lane takes the same decisions from the two totals. Same
+// functions, same operation order, 1/13 of the chain. Lanes 32..63 mirror lanes 0..31.
+constexpr uint32_t kWaveTaskMax6 = 65536;
+
+__device__ __forceinline__ void perturb6_wave_macro(float tr, float tg, float tb, int lane, const Perturb6& s, int prec, bool isSigned, float& outErr, int& outVal)
+{
+    constexpr int N = 16;
+    float base[3][N];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) palette_channel<N>(s.ep.A[c], s.ep.B[c], prec, isSigned, base[c]);
+    const int fixedQ = (s.ch == 0) ? (s.do_b ? s.ep.A[0] : s.ep.B[0]) : (s.ch == 1) ? (s.do_b ? s.ep.A[1] : s.ep.B[1]) : (s.do_b ? s.ep.A[2] : s.ep.B[2]);
+    int cur = (s.ch == 0) ? (s.do_b ? s.ep.B[0] : s.ep.A[0]) : (s.ch == 1) ? (s.do_b ? s.ep.B[1] : s.ep.A[1]) : (s.do_b ? s.ep.B[2] : s.ep.A[2]);
+    const int half = (lane >> 4) & 1, group = lane & 48;
+    float minErr = s.err;
+#pragma unroll 1
+    for (int step = 1 << (prec - 1); step; step >>= 1)
+    {
+        const int tmp = cur + (half ? step : -step);
+        float var[N];
+        palette_channel<N>(s.do_b ? fixedQ : tmp, s.do_b ? tmp : fixedQ, prec, isSigned, var);
+        float e[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            e[i] = norm3(tr, tg, tb, (s.ch == 0) ? var[i] : base[0][i], (s.ch == 1) ? var[i] : base[1][i], (s.ch == 2) ? var[i] : base[2][i]);
+        const float te = scan_min(e);
+        float tot = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tot += __shfl(te, group | j);
+        const float eMinus = __shfl(tot, 0), ePlus = __shfl(tot, 16);
+        const int tMinus = cur - step, tPlus = cur + step;
+        int beststep = 0;
+        if (tMinus >= 0 && tMinus < (1 << prec) && eMinus < minErr) { minErr = eMinus; beststep = -step; }
+        if (tPlus >= 0 && tPlus < (1 << prec) && ePlus < minErr) { minErr = ePlus; beststep = step; }
+        cur += beststep;
+    }
+    outErr = minErr; outVal = cur;
+}
+
+__global__ void __launch_bounds__(64) bc6h_perturb_wave_kernel(Bc6hArgs a, uint32_t waveMax)
+{
+    const int lane = threadIdx.x;
+    const bool sg = a.isSigned != 0;
+    const uint32_t live = a.counters[34];
+    if (live == 0 || live > waveMax) return;
+    uint32_t* head = a.counters + kQueueBase;
+    for (;;)
+    {
+        uint32_t idx = 0;
+        if (lane == 0) idx = atomicAdd(head, 1u);
+        idx = uint32_t(__builtin_amdgcn_readfirstlane(int(idx)));
+        if (idx >= live) break;
+        const uint32_t myTask = a.order[idx].x;
+        const Rec6 rec = a.recs[myTask];
+        const uint32_t nb = myTask % a.nblocks;
+        const int prec = a.prec1[myTask / a.nblocks];
+        const float* gp = a.fpix + uint64_t(nb) * 48 + (lane & 15);
+        const float tr = gp[0], tg = gp[16], tb = gp[32];
+        EndPts e;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { e.A[c] = rec.A[c]; e.B[c] = rec.B[c]; }
+        Perturb6 st = perturb6_begin(e, rec.err);
+        while (st.ch < 3)
+        {
+            float err; int v;
+            perturb6_wave_macro(tr, tg, tb, lane, st, prec, sg, err, v);
+            st = perturb6_transition(st, err, v);
+        }
+        if (lane == 0)
+        {
+            Rec6* r = a.recs + myTask;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { r->A[c] = st.ep.A[c]; r->B[c] = st.ep.B[c]; }
         }
     }
 }
@@ -647,7 +729,7 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
             DXTEX_MARK("bc6h_bin_2region");
             sort_tasks(ntasks);
             DXTEX_MARK("bc6h_perturb_2region");
-            if (!noSearch) hipLaunchKernelGGL(bc6h_perturb_kernel<8>, dim3(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64)), dim3(64), 0, stream, a);
+            if (!noSearch) hipLaunchKernelGGL(bc6h_perturb_kernel<8>, dim3(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64)), dim3(64), 0, stream, a, 0u);
             DXTEX_MARK("bc6h_post_2region");
             hipLaunchKernelGGL(bc6h_post_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
         }
@@ -670,7 +752,13 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
             DXTEX_MARK("bc6h_bin_1region");
             sort_tasks(ntasks);
             DXTEX_MARK("bc6h_perturb_1region");
-            if (!noSearch) hipLaunchKernelGGL(bc6h_perturb_kernel<16>, dim3(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64)), dim3(64), 0, stream, a);
+            // both are launched; the live count (known on the device only) decides which one works
+            static const uint32_t waveMax = getenv("DXTEX_BC6H_WAVE_MAX") ? uint32_t(strtoul(getenv("DXTEX_BC6H_WAVE_MAX"), nullptr, 0)) : kWaveTaskMax6;
+            if (!noSearch)
+            {
+                hipLaunchKernelGGL(bc6h_perturb_kernel<16>, dim3(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64)), dim3(64), 0, stream, a, waveMax);
+                hipLaunchKernelGGL(bc6h_perturb_wave_kernel, dim3(std::min<uint32_t>(kSearchWaves, ntasks)), dim3(64), 0, stream, a, waveMax);
+            }
             DXTEX_MARK("bc6h_post_1region");
             for (int m = 0; m < 4; ++m)
             {

@@ -30,7 +30,7 @@ namespace dxtex
 namespace bc7
 {
 #if defined(DXTEX_COUNT_EVALS)
-static long g_evalCount[8], g_evalTexels[8], g_macroCount[8], g_boundCount[8], g_pendCount[8], g_drainCount[8], g_pfTotal[8], g_pfPass[8], g_pfImprove[8];
+static long g_evalCount[8], g_evalTexels[8], g_macroCount[8], g_boundCount[8], g_pendCount[8], g_drainCount[8], g_pfTotal[8], g_pfPass[8], g_pfImprove[8], g_pfStepTotal[8][8], g_pfStepPass[8][8];
 #endif
 // ---- per-mode constants (BC6HBC7.cpp:1106-1124) ---------------------------------------------------
 template<int MODE> struct ModeInfo;
@@ -769,7 +769,7 @@ DXTEX_HD int alpha_part_error(const RG& rg, uint32_t epA, uint32_t epB)
 
 // `base` of eval_var for a loop over CHSET, given the endpoints whose other part stays fixed during the loop.
 template<int MODE, int IM, int CHSET, class RG>
-DXTEX_HD int loop_base(const RG& rg, uint32_t epA, uint32_t epB)
+DXTEX_HD int loop_base(const RG& rg, uint32_t epA, uint32_t epB, int* otherPart = nullptr)
 {
     int own = 0;
     for_texels(rg, [&](int k)
@@ -778,10 +778,18 @@ DXTEX_HD int loop_base(const RG& rg, uint32_t epA, uint32_t epB)
         const uint32_t q = (CHSET == CH_COLOR) ? (p & 0x00FFFFFFu) : (CHSET == CH_ALPHA) ? (p >> 24) : p;
         own += int(udot4(q, q));
     });
-    if (CHSET == CH_COLOR) return own + alpha_part_error<MODE, IM>(rg, epA, epB);
-    if (CHSET == CH_ALPHA) return own + color_part_error<MODE, IM>(rg, epA, epB);
-    return own;
+    int other = 0;
+    if (CHSET == CH_COLOR) other = alpha_part_error<MODE, IM>(rg, epA, epB);
+    if (CHSET == CH_ALPHA) other = color_part_error<MODE, IM>(rg, epA, epB);
+    if (otherPart) *otherPart = other;
+    return own + other;
 }
+
+// A loop over the scalar slot of modes 4 / 5 cannot change anything when the slot's error is already 0: every candidate's error is
+// (error of the colour part, constant in this loop) + (scalar error >= 0), and PerturbOne / Exhaustive only accept strictly smaller
+// errors (:2954, :3006). True for the alpha slot of every opaque block. `err` is the task's current total error.
+template<int CHSET>
+DXTEX_HD bool loop_is_settled(int err, int otherPart) { return CHSET == CH_ALPHA && err == otherPart; }
 
 // Where a lane stands inside OptimizeOne's per-channel logic (:3060-3105).
 struct PerturbState
@@ -831,7 +839,8 @@ DXTEX_HD void perturb_macro(const RG& rg, const PerturbState& s, int base, int& 
             const int e = eval_var<MODE, IM, CHSET>(rg, vp, s.ch, s.do_b ? fixedU : u, s.do_b ? u : fixedU, base);
 #if defined(DXTEX_COUNT_EVALS) && defined(DXTEX_COUNT_PERTURB_FILTER)
             { const int lb = eval_var_bound<MODE, IM, CHSET>(rg, vp, s.ch, s.do_b ? fixedU : u, s.do_b ? u : fixedU, base); --g_boundCount[MODE];
-              ++g_pfTotal[MODE]; if (valid && lb < minErr) ++g_pfPass[MODE]; if (valid && e < minErr) ++g_pfImprove[MODE]; }
+              ++g_pfTotal[MODE]; if (valid && lb < minErr) ++g_pfPass[MODE]; if (valid && e < minErr) ++g_pfImprove[MODE];
+              { int si = 0; for (int t = step; t > 1; t >>= 1) ++si; ++g_pfStepTotal[MODE][si]; if (valid && lb < minErr) ++g_pfStepPass[MODE][si]; } }
 #endif
             if (valid && e < minErr) { minErr = e; beststep = sign * step; }
         }
@@ -1012,7 +1021,9 @@ DXTEX_HD void lockstep_perturb_loop(const RG& rg, uint32_t& optA, uint32_t& optB
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     if (C::PREC == 0) return;
-    const int base = loop_base<MODE, IM, CHSET>(rg, optA, optB);
+    int other;
+    const int base = loop_base<MODE, IM, CHSET>(rg, optA, optB, &other);
+    if (loop_is_settled<CHSET>(optErr, other)) return;
     PerturbState s = perturb_begin<MODE, IM, CHSET>(optA, optB, optErr);
     while (s.ch < C::CH1)
     {
@@ -1028,7 +1039,9 @@ DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& o
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     if (C::PREC == 0) return;
-    const int base = loop_base<MODE, IM, CHSET>(rg, optA, optB);
+    int other;
+    const int base = loop_base<MODE, IM, CHSET>(rg, optA, optB, &other);
+    if (loop_is_settled<CHSET>(optErr, other)) return;
     ExhState s; VarPal<C::N> vp;
     bool has = exh_begin<MODE, IM, CHSET>(s, vp, optA, optB, optErr);
     // what the kernel does, one lane's worth: bound every candidate of the window, set the unbeaten ones aside, evaluate those exactly

@@ -450,7 +450,9 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
                 const TaskRec r = a.recs[myTask];
                 search_pickup<MODE, IM>(a, task, slotCol, rg);
                 st = perturb_begin<MODE, IM, CHSET>(r.A, r.B, r.err);
-                base = loop_base<MODE, IM, CHSET>(rg, st.optA, st.optB);
+                int other;
+                base = loop_base<MODE, IM, CHSET>(rg, st.optA, st.optB, &other);
+                if (loop_is_settled<CHSET>(r.err, other)) myTask = 0xFFFFFFFFu;     // scalar slot already exact: the record stays as it is
             }
         }
         if (__ballot(myTask != 0xFFFFFFFFu) == 0ull)
@@ -592,8 +594,9 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
                 myTask = task.x;
                 const TaskRec r = a.recs[myTask];
                 search_pickup<MODE, IM>(a, task, slotCol, rg);
-                base = loop_base<MODE, IM, CHSET>(rg, r.A, r.B);
-                if (!exh_begin<MODE, IM, CHSET>(st, vp, r.A, r.B, r.err)) myTask = 0xFFFFFFFFu;     // nothing to search: endpoints stay
+                int other;
+                base = loop_base<MODE, IM, CHSET>(rg, r.A, r.B, &other);
+                if (loop_is_settled<CHSET>(r.err, other) || !exh_begin<MODE, IM, CHSET>(st, vp, r.A, r.B, r.err)) myTask = 0xFFFFFFFFu;     // nothing to search: endpoints stay
             }
         }
         const bool busyL = myTask != 0xFFFFFFFFu;

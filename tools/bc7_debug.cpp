@@ -348,7 +348,10 @@ int main(int argc, char** argv)
 #endif
 #if defined(DXTEX_COUNT_PERTURB_FILTER)
     for (int m = 0; m < 8; ++m)
+    {
+        if (g_pfTotal[m]) { printf("mode %d perturb pass rate by step (1,2,4,...):", m); for (int si = 0; si < 8; ++si) if (g_pfStepTotal[m][si]) printf(" %.2f%%", 100.0 * g_pfStepPass[m][si] / g_pfStepTotal[m][si]); printf("\n"); }
         if (g_pfTotal[m]) printf("mode %d perturb: %.1f candidates/tile, %.1f %% pass the bound filter, %.1f %% improve\n", m, double(g_pfTotal[m]) / ntiles, 100.0 * g_pfPass[m] / g_pfTotal[m], 100.0 * g_pfImprove[m] / g_pfTotal[m]);
+    }
 #endif
     printf("%d of %d tiles differ\n", nbad, ntiles);
     return nbad ? 1 : 0;
