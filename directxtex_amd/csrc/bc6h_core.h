@@ -288,7 +288,24 @@ DXTEX_HD6 Perturb6 perturb6_begin(const EndPts& ep, float err)
     return s;
 }
 
-// One PerturbOne call (:2081-2141): 2 * prec candidate evaluations, straight-line.
+// Error of the region when channel s.ch of the endpoint being perturbed is `tmp` (the other endpoint's channel is fixedQ).
+template<int N>
+DXTEX_HD6 float perturb6_candidate(const Texels& tx, const Perturb6& s, const float (&base)[3][N], int fixedQ, int tmp, int prec, bool isSigned)
+{
+    float var[N];
+    palette_channel<N>(s.do_b ? fixedQ : tmp, s.do_b ? tmp : fixedQ, prec, isSigned, var);
+    float pr[N], pg[N], pb[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+        pr[i] = (s.ch == 0) ? var[i] : base[0][i];
+        pg[i] = (s.ch == 1) ? var[i] : base[1][i];
+        pb[i] = (s.ch == 2) ? var[i] : base[2][i];
+    }
+    return map_colors_q<N>(tx, pr, pg, pb);
+}
+
+// One PerturbOne call (:2081-2141): 2 * prec - 1 candidate evaluations, straight-line.
 template<int N>
 DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, bool isSigned, float& outErr, int& outVal)
 {
@@ -299,8 +316,17 @@ DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, boo
     const int fixedQ = (s.ch == 0) ? (s.do_b ? s.ep.A[0] : s.ep.B[0]) : (s.ch == 1) ? (s.do_b ? s.ep.A[1] : s.ep.B[1]) : (s.do_b ? s.ep.A[2] : s.ep.B[2]);
     int cur = (s.ch == 0) ? (s.do_b ? s.ep.B[0] : s.ep.A[0]) : (s.ch == 1) ? (s.do_b ? s.ep.B[1] : s.ep.A[1]) : (s.do_b ? s.ep.B[2] : s.ep.A[2]);
     float minErr = s.err;
+    // The first step is half the range: cur - step is legal only for cur >= step, cur + step only for cur < step - never both, and the
+    // reference skips the other one (:2112). One evaluation instead of two.
+    {
+        const int half = 1 << (prec - 1);
+        const int tmp = (cur >= half) ? cur - half : cur + half;
+        const bool valid = (tmp >= 0) && (tmp < (1 << prec));
+        const float e = perturb6_candidate<N>(tx, s, base, fixedQ, tmp, prec, isSigned);
+        if (valid && e < minErr) { minErr = e; cur = tmp; }
+    }
 #pragma unroll 1
-    for (int step = 1 << (prec - 1); step; step >>= 1)
+    for (int step = 1 << (prec - 1) >> 1; step; step >>= 1)
     {
         int beststep = 0;
 #pragma unroll 1
@@ -308,17 +334,7 @@ DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, boo
         {
             const int tmp = cur + sign * step;
             const bool valid = (tmp >= 0) && (tmp < (1 << prec));
-            float var[N];
-            palette_channel<N>(s.do_b ? fixedQ : tmp, s.do_b ? tmp : fixedQ, prec, isSigned, var);
-            float pr[N], pg[N], pb[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-            {
-                pr[i] = (s.ch == 0) ? var[i] : base[0][i];
-                pg[i] = (s.ch == 1) ? var[i] : base[1][i];
-                pb[i] = (s.ch == 2) ? var[i] : base[2][i];
-            }
-            const float e = map_colors_q<N>(tx, pr, pg, pb);
+            const float e = perturb6_candidate<N>(tx, s, base, fixedQ, tmp, prec, isSigned);
             if (valid && e < minErr) { minErr = e; beststep = sign * step; }
         }
         cur += beststep;

@@ -813,7 +813,7 @@ DXTEX_HD PerturbState perturb_begin(uint32_t optA, uint32_t optB, int optErr)
 }
 
 // One PerturbOne call (:2926-2966) on channel s.ch of endpoint A (s.do_b == 0) or B: returns the best error
-// found (fMinErr) and the channel value it belongs to. Straight-line: 2 * PREC evaluations for every lane.
+// found (fMinErr) and the channel value it belongs to. Straight-line: 2 * PREC - 1 evaluations for every lane.
 template<int MODE, int IM, int CHSET, class RG>
 DXTEX_HD void perturb_macro(const RG& rg, const PerturbState& s, int base, int& outErr, uint32_t& outVal)
 {
@@ -826,8 +826,17 @@ DXTEX_HD void perturb_macro(const RG& rg, const PerturbState& s, int base, int& 
     const uint32_t fixedU = unq1<C::PREC>(byte_of(s.do_b ? s.optA : s.optB, s.ch));
     int cur = int(byte_of(s.do_b ? s.optB : s.optA, s.ch));
     int minErr = s.optErr;
+    // The first step is half the range, so exactly one of cur - step / cur + step is a legal endpoint (cur >= step or cur < step)
+    // and the other is skipped by the reference (:2937): one evaluation instead of two.
+    {
+        constexpr int half = 1 << (C::PREC - 1);
+        const int tmp = (cur >= half) ? cur - half : cur + half;
+        const uint32_t u = unq1<C::PREC>(uint32_t(tmp) & ((1u << C::PREC) - 1u));
+        const int e = eval_var<MODE, IM, CHSET>(rg, vp, s.ch, s.do_b ? fixedU : u, s.do_b ? u : fixedU, base);
+        if (e < minErr) { minErr = e; cur = tmp; }
+    }
 #pragma unroll 1
-    for (int step = 1 << (C::PREC - 1); step; step >>= 1)
+    for (int step = 1 << (C::PREC - 2); step; step >>= 1)
     {
         int beststep = 0;
 #pragma unroll 1
