@@ -390,8 +390,21 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     EndPts opt;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { opt.A[c] = rec.A[c]; opt.B[c] = rec.B[c]; }
-    uint64_t optIdx;
-    const float optErr = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, opt, a.mode.prec, sg, o.anchor, optIdx);
+    // A candidate the search never ran for either region (pruned, does not fit, error already 0: subset size 0 in the task list)
+    // still has its unoptimised endpoints: it either cannot win (its lower bound exceeds an error on the table, or it is not
+    // encodable) or wins with its unoptimised half (error 0, which nothing beats), so it stands with those numbers. A wavefront
+    // whose candidates are all of that kind - most wavefronts of the later modes - skips the second AssignIndices.
+    bool searched = (a.tinfo[t] >> 24) != 0u;
+    if (REGIONS2) searched = searched || (__shfl_xor(int(searched), 1) != 0);      // the candidate's other region: Refine scores both (:2401-2410)
+    uint64_t optIdx = o.idx;
+    float optErr = o.err;
+    if (__any(searched))
+    {
+        uint64_t ix;
+        const float e = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, opt, a.mode.prec, sg, o.anchor, ix);
+        if (searched) { optErr = e; optIdx = ix; }
+    }
+    if (!searched) opt = o.ep;
     float orgTot = 0.0f + o.err, optTot = 0.0f + optErr;
     if (REGIONS2)
     {

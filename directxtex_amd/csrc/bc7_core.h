@@ -851,6 +851,9 @@ DXTEX_HD void perturb_macro(const RG& rg, const PerturbState& s, int base, int& 
               ++g_pfTotal[MODE]; if (valid && lb < minErr) ++g_pfPass[MODE]; if (valid && e < minErr) ++g_pfImprove[MODE];
               { int si = 0; for (int t = step; t > 1; t >>= 1) ++si; ++g_pfStepTotal[MODE][si]; if (valid && lb < minErr) ++g_pfStepPass[MODE][si]; } }
 #endif
+#if defined(DXTEX_COUNT_EVALS)
+            ++g_pfStepTotal[MODE][7]; if (!valid) ++g_pfStepPass[MODE][7];
+#endif
             if (valid && e < minErr) { minErr = e; beststep = sign * step; }
         }
         cur += beststep;
@@ -1256,6 +1259,9 @@ DXTEX_HD void seed_fit(const float* fpx, uint32_t mask16, float (&X)[4], float (
             const float fSteps = 3.0f;
             for (int iter = 0; iter < 8; ++iter)
             {
+#if defined(DXTEX_FIT_STATS)
+                ++g_iters;
+#endif
 #pragma unroll
                 for (int c = 0; c < NC; ++c) Dir[c] = Y[c] - X[c];
                 float fLen = Dir[0] * Dir[0] + Dir[1] * Dir[1] + Dir[2] * Dir[2];
