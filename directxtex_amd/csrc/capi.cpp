@@ -517,11 +517,34 @@ dxtex_hresult check_host_pitches(dxtex_ctx* ctx, const dxtex_image* src, const d
 }
 }
 
+namespace
+{
+dxtex_hresult compress_many_pipelined(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts, size_t count, uint32_t flags, float threshold);
+}
+
 dxtex_hresult dxtex_compress_many(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts, size_t count, uint32_t flags, float threshold)
 {
     if (!ctx) return DXTEX_E_POINTER;
     if (!srcs || !dsts || !count) return fail(ctx, DXTEX_E_INVALIDARG, "empty batch");
     ScopedDevice sd(ctx->device);
+    const dxtex_hresult hr = compress_many_pipelined(ctx, srcs, dsts, count, flags, threshold);
+    if (hr != DXTEX_S_OK)
+    {
+        // a failure in the middle leaves copies and kernels of earlier chunks in flight: let them finish before the caller may free
+        // or reuse its images (the staging they touch belongs to the context)
+        const std::string why = ctx->lastError;
+        if (ctx->h2d) (void)hipStreamSynchronize(ctx->h2d);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->d2h) (void)hipStreamSynchronize(ctx->d2h);
+        ctx->lastError = why;
+    }
+    return hr;
+}
+
+namespace
+{
+dxtex_hresult compress_many_pipelined(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts, size_t count, uint32_t flags, float threshold)
+{
     static const uint64_t chunkTexels = getenv("DXTEX_MANY_CHUNK_TEXELS") ? std::max<uint64_t>(1, strtoull(getenv("DXTEX_MANY_CHUNK_TEXELS"), nullptr, 10)) : (32ull << 20);
     std::vector<size_t> inBytes(count), outBytes(count);
     std::vector<ManyChunk> chunks;
@@ -593,7 +616,7 @@ dxtex_hresult dxtex_compress_many(dxtex_ctx* ctx, const dxtex_image* srcs, const
         HIP_TRY(ctx, hipEventRecord(l.uploaded, ctx->h2d));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, l.uploaded, 0));
         hr = dxtex_compress_many_device(ctx, ds.data(), dd.data(), ch.count, flags, threshold);
-        if (hr != DXTEX_S_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->d2h); return hr; }
+        if (hr != DXTEX_S_OK) return hr;
         HIP_TRY(ctx, hipEventRecord(l.computed, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, l.computed, 0));
         HIP_TRY(ctx, hipMemcpyAsync(l.pinOut, l.devOut, atOut, hipMemcpyDeviceToHost, ctx->d2h));
@@ -608,6 +631,7 @@ dxtex_hresult dxtex_compress_many(dxtex_ctx* ctx, const dxtex_image* srcs, const
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
+}
 }
 
 dxtex_hresult dxtex_compress(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t flags, float threshold)
