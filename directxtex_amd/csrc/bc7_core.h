@@ -1169,11 +1169,14 @@ DXTEX_HD void for_masked(uint32_t mask16, F&& f)
     }
 }
 
-// The raw fit: X / Y are the end points OptimizeRGB / OptimizeRGBA return (pX, pY), before any clamping.
+// The raw fit: X / Y are the end points OptimizeRGB / OptimizeRGBA return (pX, pY), before any clamping. In two pieces so that a
+// kernel can schedule the Newton iterations of many fits itself (bc7_rough_kernel): fit_setup = everything up to the iteration
+// loop (:3461-3531 for RGBA: bounding box, choice of the diagonal), fit_iterate = one trip of that loop (:3533-3606).
+
+// Returns true when the loop has to run (false: X / Y are final - a degenerate box, :3478 and :3527).
 template<bool RGBA, bool FULL = false>
-DXTEX_HD void seed_fit(const float* fpx, uint32_t mask16, float (&X)[4], float (&Y)[4])
+DXTEX_HD bool fit_setup(const float* fpx, uint32_t mask16, float (&X)[4], float (&Y)[4])
 {
-    constexpr float fEpsilon = (0.25f / 64.0f) * (0.25f / 64.0f);
     constexpr int NC = RGBA ? 4 : 3;
     if (RGBA) { X[0] = X[1] = X[2] = X[3] = 1.0f; Y[0] = Y[1] = Y[2] = Y[3] = 0.0f; }
     else { X[0] = X[1] = X[2] = 3.402823466e+38f; Y[0] = Y[1] = Y[2] = -3.402823466e+38f; X[3] = 0.0f; Y[3] = 0.0f; }
@@ -1189,157 +1192,157 @@ DXTEX_HD void seed_fit(const float* fpx, uint32_t mask16, float (&X)[4], float (
             }
         });
 
-    bool done = false;
     float AB[4];
 #pragma unroll
     for (int c = 0; c < NC; ++c) AB[c] = Y[c] - X[c];
     float fAB = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
     if (RGBA) fAB = fAB + AB[3] * AB[3];
 
-    if (fAB < 1.175494351e-38f) done = true;
+    if (fAB < 1.175494351e-38f) return false;
 
-    if (!done)
-    {
-        const float fABInv = 1.0f / fAB;
-        float Dir[4], Mid[4];
+    const float fABInv = 1.0f / fAB;
+    float Dir[4], Mid[4];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { Dir[c] = AB[c] * fABInv; Mid[c] = (X[c] + Y[c]) * 0.5f; }
+    for (int c = 0; c < NC; ++c) { Dir[c] = AB[c] * fABInv; Mid[c] = (X[c] + Y[c]) * 0.5f; }
 
-        float fDir[8];
+    float fDir[8];
 #pragma unroll
-        for (int d = 0; d < 8; ++d) fDir[d] = 0.0f;
-        for_masked<FULL>(mask16, [&](int i)
+    for (int d = 0; d < 8; ++d) fDir[d] = 0.0f;
+    for_masked<FULL>(mask16, [&](int i)
+        {
+            float Pt[4];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) Pt[c] = (fpx[i * 4 + c] - Mid[c]) * Dir[c];
+            float f;
+            if (RGBA)
             {
-                float Pt[4];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) Pt[c] = (fpx[i * 4 + c] - Mid[c]) * Dir[c];
-                float f;
-                if (RGBA)
-                {
-                    f = Pt[0] + Pt[1] + Pt[2] + Pt[3]; fDir[0] += f * f;
-                    f = Pt[0] + Pt[1] + Pt[2] - Pt[3]; fDir[1] += f * f;
-                    f = Pt[0] + Pt[1] - Pt[2] + Pt[3]; fDir[2] += f * f;
-                    f = Pt[0] + Pt[1] - Pt[2] - Pt[3]; fDir[3] += f * f;
-                    f = Pt[0] - Pt[1] + Pt[2] + Pt[3]; fDir[4] += f * f;
-                    f = Pt[0] - Pt[1] + Pt[2] - Pt[3]; fDir[5] += f * f;
-                    f = Pt[0] - Pt[1] - Pt[2] + Pt[3]; fDir[6] += f * f;
-                    f = Pt[0] - Pt[1] - Pt[2] - Pt[3]; fDir[7] += f * f;
-                }
-                else
-                {
-                    f = Pt[0] + Pt[1] + Pt[2]; fDir[0] += f * f;
-                    f = Pt[0] + Pt[1] - Pt[2]; fDir[1] += f * f;
-                    f = Pt[0] - Pt[1] + Pt[2]; fDir[2] += f * f;
-                    f = Pt[0] - Pt[1] - Pt[2]; fDir[3] += f * f;
-                }
-            });
-
-        float fDirMax = fDir[0];
-        int iDirMax = 0;
-#pragma unroll
-        for (int d = 1; d < (RGBA ? 8 : 4); ++d)
-            if (fDir[d] > fDirMax) { fDirMax = fDir[d]; iDirMax = d; }
-
-        if (RGBA)
-        {
-            if (iDirMax & 4) { const float t = X[1]; X[1] = Y[1]; Y[1] = t; }
-            if (iDirMax & 2) { const float t = X[2]; X[2] = Y[2]; Y[2] = t; }
-            if (iDirMax & 1) { const float t = X[3]; X[3] = Y[3]; Y[3] = t; }
-        }
-        else
-        {
-            if (iDirMax & 2) { const float t = X[1]; X[1] = Y[1]; Y[1] = t; }
-            if (iDirMax & 1) { const float t = X[2]; X[2] = Y[2]; Y[2] = t; }
-        }
-
-        if (fAB < 1.0f / 4096.0f) done = true;
-
-        if (!done)
-        {
-            const float fSteps = 3.0f;
-            for (int iter = 0; iter < 8; ++iter)
-            {
-#if defined(DXTEX_FIT_STATS)
-                ++g_iters;
-#endif
-#pragma unroll
-                for (int c = 0; c < NC; ++c) Dir[c] = Y[c] - X[c];
-                float fLen = Dir[0] * Dir[0] + Dir[1] * Dir[1] + Dir[2] * Dir[2];
-                if (RGBA) fLen = fLen + Dir[3] * Dir[3];
-                if (fLen < (1.0f / 4096.0f)) break;
-
-                const float fScale = fSteps / fLen;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) Dir[c] *= fScale;
-
-                float d2X = 0.0f, d2Y = 0.0f;
-                float dX[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, dY[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-
-                for_masked<FULL>(mask16, [&](int i)
-                    {
-                        float p[4];
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) p[c] = fpx[i * 4 + c];
-                        float fDot = (p[0] - X[0]) * Dir[0] + (p[1] - X[1]) * Dir[1] + (p[2] - X[2]) * Dir[2];
-                        if (RGBA) fDot = fDot + (p[3] - X[3]) * Dir[3];
-
-                        // fDot <= 0 -> step 0, fDot >= fSteps -> step 3, else uint32(fDot + 0.5f) (:1300-1306): the clamp maps the outer cases
-                        // onto the same conversion; float compares keep the table lookups (pC4 / pD4) as selects - an integer equality
-                        // chain is turned into a switch, i.e. divergent branches, by the compiler
-                        const float kStep = float(uint32_t(fminf(fmaxf(fDot, 0.0f), fSteps) + 0.5f));
-                        const float pc = (kStep < 0.5f) ? 1.0f : (kStep < 1.5f) ? (2.0f / 3.0f) : (kStep < 2.5f) ? (1.0f / 3.0f) : 0.0f;
-                        const float pd = (kStep < 0.5f) ? 0.0f : (kStep < 1.5f) ? (1.0f / 3.0f) : (kStep < 2.5f) ? (2.0f / 3.0f) : 1.0f;
-                        const float fC = pc * (1.0f / 8.0f);
-                        const float fD = pd * (1.0f / 8.0f);
-                        d2X += fC * pc;
-                        d2Y += fD * pd;
-#pragma unroll
-                        for (int c = 0; c < NC; ++c)
-                        {
-                            const float Diff = (X[c] * pc + Y[c] * pd) - p[c];
-                            dX[c] += Diff * fC;
-                            dY[c] += Diff * fD;
-                        }
-                    });
-
-                if (d2X > 0.0f)
-                {
-                    const float f = -1.0f / d2X;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) X[c] += dX[c] * f;
-                }
-                if (d2Y > 0.0f)
-                {
-                    const float f = -1.0f / d2Y;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) Y[c] += dY[c] * f;
-                }
-
-                bool conv;
-                if (RGBA)
-                {
-                    const float ex = dX[0] * dX[0] + dX[1] * dX[1] + dX[2] * dX[2] + dX[3] * dX[3];
-                    const float ey = dY[0] * dY[0] + dY[1] * dY[1] + dY[2] * dY[2] + dY[3] * dY[3];
-                    conv = (ex < fEpsilon) && (ey < fEpsilon);
-                }
-                else
-                {
-                    conv = (dX[0] * dX[0] < fEpsilon) && (dX[1] * dX[1] < fEpsilon) && (dX[2] * dX[2] < fEpsilon) &&
-                           (dY[0] * dY[0] < fEpsilon) && (dY[1] * dY[1] < fEpsilon) && (dY[2] * dY[2] < fEpsilon);
-                }
-                if (conv) break;
+                f = Pt[0] + Pt[1] + Pt[2] + Pt[3]; fDir[0] += f * f;
+                f = Pt[0] + Pt[1] + Pt[2] - Pt[3]; fDir[1] += f * f;
+                f = Pt[0] + Pt[1] - Pt[2] + Pt[3]; fDir[2] += f * f;
+                f = Pt[0] + Pt[1] - Pt[2] - Pt[3]; fDir[3] += f * f;
+                f = Pt[0] - Pt[1] + Pt[2] + Pt[3]; fDir[4] += f * f;
+                f = Pt[0] - Pt[1] + Pt[2] - Pt[3]; fDir[5] += f * f;
+                f = Pt[0] - Pt[1] - Pt[2] + Pt[3]; fDir[6] += f * f;
+                f = Pt[0] - Pt[1] - Pt[2] - Pt[3]; fDir[7] += f * f;
             }
-        }
+            else
+            {
+                f = Pt[0] + Pt[1] + Pt[2]; fDir[0] += f * f;
+                f = Pt[0] + Pt[1] - Pt[2]; fDir[1] += f * f;
+                f = Pt[0] - Pt[1] + Pt[2]; fDir[2] += f * f;
+                f = Pt[0] - Pt[1] - Pt[2]; fDir[3] += f * f;
+            }
+        });
+
+    float fDirMax = fDir[0];
+    int iDirMax = 0;
+#pragma unroll
+    for (int d = 1; d < (RGBA ? 8 : 4); ++d)
+        if (fDir[d] > fDirMax) { fDirMax = fDir[d]; iDirMax = d; }
+
+    if (RGBA)
+    {
+        if (iDirMax & 4) { const float t = X[1]; X[1] = Y[1]; Y[1] = t; }
+        if (iDirMax & 2) { const float t = X[2]; X[2] = Y[2]; Y[2] = t; }
+        if (iDirMax & 1) { const float t = X[3]; X[3] = Y[3]; Y[3] = t; }
+    }
+    else
+    {
+        if (iDirMax & 2) { const float t = X[1]; X[1] = Y[1]; Y[1] = t; }
+        if (iDirMax & 1) { const float t = X[2]; X[2] = Y[2]; Y[2] = t; }
     }
 
+    return !(fAB < 1.0f / 4096.0f);
+}
+
+// One trip of the Newton loop; returns true when the loop ends with this trip (either break). The caller runs at most 8 trips.
+template<bool RGBA, bool FULL = false>
+DXTEX_HD bool fit_iterate(const float* fpx, uint32_t mask16, float (&X)[4], float (&Y)[4])
+{
+    constexpr float fEpsilon = (0.25f / 64.0f) * (0.25f / 64.0f);
+    constexpr int NC = RGBA ? 4 : 3;
+    const float fSteps = 3.0f;
+#if defined(DXTEX_FIT_STATS)
+    ++g_iters;
+#endif
+    float Dir[4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) Dir[c] = Y[c] - X[c];
+    float fLen = Dir[0] * Dir[0] + Dir[1] * Dir[1] + Dir[2] * Dir[2];
+    if (RGBA) fLen = fLen + Dir[3] * Dir[3];
+    if (fLen < (1.0f / 4096.0f)) return true;
+
+    const float fScale = fSteps / fLen;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) Dir[c] *= fScale;
+
+    float d2X = 0.0f, d2Y = 0.0f;
+    float dX[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, dY[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+
+    for_masked<FULL>(mask16, [&](int i)
+        {
+            float p[4];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) p[c] = fpx[i * 4 + c];
+            float fDot = (p[0] - X[0]) * Dir[0] + (p[1] - X[1]) * Dir[1] + (p[2] - X[2]) * Dir[2];
+            if (RGBA) fDot = fDot + (p[3] - X[3]) * Dir[3];
+
+            // fDot <= 0 -> step 0, fDot >= fSteps -> step 3, else uint32(fDot + 0.5f) (:1300-1306): the clamp maps the outer cases
+            // onto the same conversion; float compares keep the table lookups (pC4 / pD4) as selects - an integer equality
+            // chain is turned into a switch, i.e. divergent branches, by the compiler
+            const float kStep = float(uint32_t(fminf(fmaxf(fDot, 0.0f), fSteps) + 0.5f));
+            const float pc = (kStep < 0.5f) ? 1.0f : (kStep < 1.5f) ? (2.0f / 3.0f) : (kStep < 2.5f) ? (1.0f / 3.0f) : 0.0f;
+            const float pd = (kStep < 0.5f) ? 0.0f : (kStep < 1.5f) ? (1.0f / 3.0f) : (kStep < 2.5f) ? (2.0f / 3.0f) : 1.0f;
+            const float fC = pc * (1.0f / 8.0f);
+            const float fD = pd * (1.0f / 8.0f);
+            d2X += fC * pc;
+            d2Y += fD * pd;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+            {
+                const float Diff = (X[c] * pc + Y[c] * pd) - p[c];
+                dX[c] += Diff * fC;
+                dY[c] += Diff * fD;
+            }
+        });
+
+    if (d2X > 0.0f)
+    {
+        const float f = -1.0f / d2X;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) X[c] += dX[c] * f;
+    }
+    if (d2Y > 0.0f)
+    {
+        const float f = -1.0f / d2Y;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) Y[c] += dY[c] * f;
+    }
+
+    if (RGBA)
+    {
+        const float ex = dX[0] * dX[0] + dX[1] * dX[1] + dX[2] * dX[2] + dX[3] * dX[3];
+        const float ey = dY[0] * dY[0] + dY[1] * dY[1] + dY[2] * dY[2] + dY[3] * dY[3];
+        return (ex < fEpsilon) && (ey < fEpsilon);
+    }
+    return (dX[0] * dX[0] < fEpsilon) && (dX[1] * dX[1] < fEpsilon) && (dX[2] * dX[2] < fEpsilon) &&
+           (dY[0] * dY[0] < fEpsilon) && (dY[1] * dY[1] < fEpsilon) && (dY[2] * dY[2] < fEpsilon);
 }
 
 template<bool RGBA, bool FULL = false>
-DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, uint32_t& outB)
+DXTEX_HD void seed_fit(const float* fpx, uint32_t mask16, float (&X)[4], float (&Y)[4])
+{
+    if (!fit_setup<RGBA, FULL>(fpx, mask16, X, Y)) return;
+    for (int iter = 0; iter < 8; ++iter)
+        if (fit_iterate<RGBA, FULL>(fpx, mask16, X, Y)) break;
+}
+
+// X / Y of a fit -> the 8-bit end points Refine and RoughMSE start from: clamped to [0,1], scaled by 255 and truncated with the +0.01
+// bias (:3543-3548).
+template<bool RGBA>
+DXTEX_HD void fit_to_bytes(const float (&X)[4], const float (&Y)[4], uint32_t& outA, uint32_t& outB)
 {
     constexpr int NC = RGBA ? 4 : 3;
-    float X[4], Y[4];
-    seed_fit<RGBA, FULL>(fpx, mask16, X, Y);
     uint32_t a = 0, b = 0;
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -1352,6 +1355,14 @@ DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, 
         b |= (uint32_t(y + 0.01f) & 0xFFu) << (8 * c);
     }
     outA = a; outB = b;
+}
+
+template<bool RGBA, bool FULL = false>
+DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, uint32_t& outB)
+{
+    float X[4], Y[4];
+    seed_fit<RGBA, FULL>(fpx, mask16, X, Y);
+    fit_to_bytes<RGBA>(X, Y, outA, outB);
 }
 
 // RoughMSE's palette error from *unquantised* 8-bit endpoints (:3572-3596) for one region.

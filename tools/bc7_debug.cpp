@@ -346,7 +346,9 @@ int main(int argc, char** argv)
         if (g_evalCount[m]) printf("mode %d: %.1f evals/tile, %.1f macro-ops/tile, %.2f texels/eval; exhaustive: %.1f bounds/tile, %.1f passed the filter (%.1f %%), %.1f drains/tile\n", m, double(g_evalCount[m]) / ntiles, double(g_macroCount[m]) / ntiles, double(g_evalTexels[m]) / g_evalCount[m],
                                     double(g_boundCount[m]) / ntiles, double(g_pendCount[m]) / ntiles, 100.0 * double(g_pendCount[m]) / double(g_boundCount[m] ? g_boundCount[m] : 1), double(g_drainCount[m]) / ntiles);
 #endif
+#if defined(DXTEX_COUNT_EVALS)
     for (int m = 0; m < 8; ++m) if (g_pfStepTotal[m][7]) printf("mode %d perturb: %.1f %% of the candidates below the first step are out of range (skipped by the reference)\n", m, 100.0 * g_pfStepPass[m][7] / g_pfStepTotal[m][7]);
+#endif
 #if defined(DXTEX_COUNT_PERTURB_FILTER)
     for (int m = 0; m < 8; ++m)
     {
