@@ -925,6 +925,18 @@ DXTEX_HD bool exh_settle(ExhState& s)
     return s.o < s.oEnd;
 }
 
+// One candidate forward, branch-free. Rows that hold no candidate (max(o, lo) >= iEnd) only occur at the end of a window - the first
+// value of the inner variable never decreases from row to row - so while candidates remain (exh_remaining) one step lands on the
+// next one; after the last candidate the state is merely "somewhere past it", which exh_settle / exh_next turn into "window used up".
+DXTEX_HD void exh_advance(ExhState& s)
+{
+    ++s.i;
+    const bool wrap = s.i >= s.iEnd;
+    s.o += wrap ? 1 : 0;
+    const int first = s.o > s.lo ? s.o : s.lo;
+    s.i = wrap ? first : s.i;
+}
+
 DXTEX_HD ExhState exh_commit(const ExhState& in)
 {
     ExhState s = in;

@@ -511,6 +511,12 @@ __global__ void bc7_stats_print_kernel(unsigned long long* stats)
 
 enum : int { kExhWorkMax = 1024, kExhExactMax = 512 };
 
+// Set bits of a ballot below this lane (v_mbcnt_lo / v_mbcnt_hi).
+__device__ __forceinline__ int lanes_below(unsigned long long mask)
+{
+    return int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
+}
+
 // What a helper needs of another lane's window.
 template<int N> struct ExhCtx { VarPal<N> vp; uint32_t geom; int base; };
 
@@ -634,12 +640,11 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
                 const int av = st.aleb ? st.o : st.i, bv = st.aleb ? st.i : st.o;
                 const int lb = eval_var_bound<MODE, IM, CHSET>(rg, vp, st.ch, unq1<C::PREC>(uint32_t(av)), unq1<C::PREC>(uint32_t(bv)), base);
                 keep = exh_key(lb, code) < bestKey;
-                ++st.i; --rem;
-                exh_settle(st);
+                exh_advance(st); --rem;
             }
             // append the unbeaten candidates to the shared list: positions from the ballot, no atomics
             const unsigned long long keepMask = __ballot(keep);
-            if (keep) sExact[nExact + int(__popcll(keepMask & ((1ull << lane) - 1ull)))] = (uint32_t(lane) << 8) | uint32_t(code);
+            if (keep) sExact[nExact + lanes_below(keepMask)] = (uint32_t(lane) << 8) | uint32_t(code);
             nExact += int(__popcll(keepMask));
         }
         // ---- the remaining candidates of all lanes, pooled and bounded by all lanes
@@ -656,8 +661,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
             for (int k = 0; k < mine; ++k)
             {
                 sWork[first + k] = (uint32_t(lane) << 8) | uint32_t(exh_code(st));
-                ++st.i;
-                exh_settle(st);
+                exh_advance(st);
             }
             rem -= mine;
             wave_lds_sync();
@@ -678,7 +682,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop,
                     keep = exh_key(lb, code) < sBest[owner];
                 }
                 const unsigned long long keepMask = __ballot(keep);
-                if (keep) sExact[nExact + int(__popcll(keepMask & ((1ull << lane) - 1ull)))] = ent;
+                if (keep) sExact[nExact + lanes_below(keepMask)] = ent;
                 nExact += int(__popcll(keepMask));
             }
             wave_lds_sync();
