@@ -53,6 +53,8 @@ struct Bc6hArgs
     OrgSave* orgs;          // per task: endpoints (after SwapIndices), error and indices of the unoptimised candidate
     uint2* order; uint32_t* tinfo; uint32_t* counters;
     Best6* best;
+    float* bounds;          // nblocks x 17: region_lower_bound6 of the 8 ranked shapes x 2 regions and of the whole block (the same for every mode)
+    int boundsReady;        // 0: this launch computes and stores them, 1: it reads them
     ModeRt mode;
 };
 
@@ -323,7 +325,12 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
     bool prune = false;
     if (a.prune)
     {
-        float lb = region_lower_bound6(planes, o.mask);
+        // the bound depends on the block, the shape and the region only - not on the mode: the first two-region launch (and the first
+        // one-region launch) of a pass computes it (a fp64 power iteration), the others read it back
+        float* bslot = a.bounds + uint64_t(nb) * 17 + (REGIONS2 ? r : 16u);
+        float lb;
+        if (a.boundsReady) lb = *bslot;
+        else { lb = region_lower_bound6(planes, o.mask); if (inRange) *bslot = lb; }
         if (REGIONS2) lb += __shfl_xor(lb, 1);
         // what is already on the table: the running best of the earlier modes and, within this mode, the unoptimised error of
         // every candidate that fits (Refine emits at least that, :2412-2424)
@@ -624,7 +631,7 @@ __global__ void __launch_bounds__(256) bc6h_store_kernel(Bc6hArgs a)
 const uint64_t kMaxBlocksPerPass6 = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(getenv("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 22);
 struct Scratch6
 {
-    size_t fpix, lists, seeds, recs, orgs, order, tinfo, counters, best, total;
+    size_t fpix, lists, seeds, recs, orgs, order, tinfo, counters, best, bounds, total;
     explicit Scratch6(uint64_t nb)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -638,6 +645,7 @@ struct Scratch6
         tinfo = o; o = up(o + nb * 16 * sizeof(uint32_t));
         counters = o; o = up(o + 64 * sizeof(uint32_t));
         best = o; o = up(o + nb * sizeof(Best6));
+        bounds = o; o = up(o + nb * 17 * sizeof(float));
         total = o;
     }
 };
@@ -684,6 +692,8 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         a.tinfo = reinterpret_cast<uint32_t*>(base + L.tinfo);
         a.counters = reinterpret_cast<uint32_t*>(base + L.counters);
         a.best = reinterpret_cast<Best6*>(base + L.best);
+        a.bounds = reinterpret_cast<float*>(base + L.bounds);
+        a.boundsReady = 0;
         a.mode = ModeRt();
 
         DXTEX_MARK("bc6h_rough");
@@ -739,6 +749,7 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
             const uint32_t gridPP = (a.nblocks + 15) / 16;
             DXTEX_MARK("bc6h_pre_2region");
             hipLaunchKernelGGL(bc6h_pre_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
+            a.boundsReady = 1;
             DXTEX_MARK("bc6h_bin_2region");
             sort_tasks(ntasks);
             DXTEX_MARK("bc6h_perturb_2region");
@@ -753,11 +764,13 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         {
             const uint32_t gridPP = (a.nblocks + 255) / 256;
             DXTEX_MARK("bc6h_pre_1region");
+            a.boundsReady = 0;
             for (int m = 0; m < 4; ++m)
             {
                 if (onlyMode >= 0 && 10 + m != onlyMode) continue;
                 set_mode(10 + m); a.taskBase = uint32_t(m) * a.nblocks;
                 hipLaunchKernelGGL(bc6h_pre_kernel<0>, dim3(gridPP), dim3(256), 0, stream, a);
+                a.boundsReady = 1;
             }
             const uint32_t ntasks = a.nblocks * 4u;
             if (onlyMode >= 0)        // development aid: the slots of the modes that did not run hold no tasks
