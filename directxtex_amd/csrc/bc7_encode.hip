@@ -425,6 +425,12 @@ __device__ __forceinline__ void search_pickup(const Bc7Args& a, uint2 task, uint
     rg.base = slotCol; rg.np = np; rg.p2sum = 0;
 }
 
+// Set bits of a ballot below this lane (v_mbcnt_lo / v_mbcnt_hi).
+__device__ __forceinline__ int lanes_below(unsigned long long mask)
+{
+    return int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
+}
+
 // The PERTURB phase of OptimizeOne (:3060-3105) for the channels of CHSET, over every live task of the mode.
 template<int MODE, int IM, int CHSET>
 __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
@@ -480,6 +486,166 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
     }
 }
 
+// PerturbOne through the bound filter (see eval_var_bound). A step of the logarithmic search has to be decided before the next one
+// starts, so the filter cannot postpone a lane's exact evaluations the way Exhaustive's windows do; what it can do is make them rare
+// and share them. Per candidate every lane derives the palette and takes the bound (no second dot product, no compare-select scan);
+// the candidates that could still beat the lane's best error - 10 % on average, 2-4 % at the large steps, a third at step 1 - put
+// their palettes on a list in LDS, and the wavefront evaluates that list exactly TEXEL BY TEXEL: item g = (list entry g / np, texel
+// g % np), so a handful of candidates still fills the 64 lanes; the per-texel first-peak scores are added up with LDS atomics (integer
+// sums: any order) and the owner reads its exact error back. Same candidates, same decisions as perturb_macro (bc7_core.h), which the
+// plain kernel above runs and DXTEX_BC7_PERTURB_PLAIN=1 selects.
+template<int MODE, int IM, int CHSET>
+__global__ void __launch_bounds__(64) bc7_perturb_filter_kernel(Bc7Args a, int loop)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    static_assert(!C::kAlpha && C::N <= 8, "colour loops with up to eight palette entries");
+    constexpr int N = C::N;
+    __shared__ uint32_t sSlot[16 * 64];             // texel columns, one per lane
+    __shared__ uint32_t sCand[64 * 2 * N];          // list entry e: pal[N], then -|q|^2 [N]
+    __shared__ uint32_t sOwner[64];                 // list entry -> owner lane | subset size << 8
+    __shared__ uint32_t sSum[64];                   // list entry -> sum over the subset of the first-peak scores
+    const int lane = threadIdx.x;
+    const uint32_t live = a.counters[34];
+    if (live == 0) return;
+    uint32_t* head = a.counters + kQueueBase + loop;
+    uint32_t* slotCol = &sSlot[lane];
+
+    PerturbState st = perturb_begin<MODE, IM, CHSET>(0, 0, 0);
+    SlotRegion rg; rg.base = slotCol; rg.np = 0; rg.p2sum = 0;
+    int base = 0;
+    uint32_t myTask = 0xFFFFFFFFu;
+    WaveQueue q; q.lo = q.hi = 0; q.drained = false;
+    for (;;)
+    {
+        const unsigned long long idle = __ballot(myTask == 0xFFFFFFFFu);
+        if (idle && !(q.drained && q.lo >= q.hi))
+        {
+            const uint32_t idx = queue_take(q, head, live, idle, lane);
+            if (idx != 0xFFFFFFFFu)
+            {
+                const uint2 task = a.order[idx];
+                myTask = task.x;
+                const TaskRec r = a.recs[myTask];
+                search_pickup<MODE, IM>(a, task, slotCol, rg);
+                st = perturb_begin<MODE, IM, CHSET>(r.A, r.B, r.err);
+                base = loop_base<MODE, IM, CHSET>(rg, st.optA, st.optB);
+            }
+        }
+        const bool busyL = myTask != 0xFFFFFFFFu;
+        if (__ballot(busyL) == 0ull)
+        {
+            if (q.drained && q.lo >= q.hi) break;
+            continue;
+        }
+        wave_lds_sync();             // the texel columns of tasks just taken are visible to every lane
+        // widest subset among the busy lanes (the list is sorted by size: nearly always everybody's)
+        int npMax = busyL ? rg.np : 0;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) npMax = max(npMax, __shfl_xor(npMax, d));
+        npMax = __builtin_amdgcn_readfirstlane(npMax);
+        const uint32_t npMagic = (65536u + uint32_t(npMax) - 1u) / uint32_t(npMax);      // g / npMax == (g * npMagic) >> 16 for g < 4096 (npMax <= 16)
+
+        // ---- one PerturbOne call (:2926-2966) for every busy lane
+        VarPal<N> vp;
+        varpal_init<MODE, IM, CHSET>(vp, st.optA, st.optB, st.ch);
+        const uint32_t fixedU = unq1<C::PREC>(byte_of(st.do_b ? st.optA : st.optB, st.ch));
+        int cur = int(byte_of(st.do_b ? st.optB : st.optA, st.ch));
+        int minErr = st.optErr;
+        const int sh = 8 * st.ch;
+
+        // exact error of the candidate `tmp` if it can still be below minErr, else INT_MAX
+        auto candidate = [&](int tmp, bool valid) -> int
+        {
+            const uint32_t u = unq1<C::PREC>(uint32_t(tmp) & ((1u << C::PREC) - 1u));
+            const uint32_t uaC = st.do_b ? fixedU : u, ubC = st.do_b ? u : fixedU;
+            uint32_t pal[N], nq2[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+            {
+                const uint32_t v = ((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6) & 0xFFu;
+                pal[i] = vp.palO[i] | (v << sh);
+                nq2[i] = vp.nq2O[i] - v * v;
+            }
+            int sum = 0;
+            for_texels(rg, [&](int k)
+            {
+                uint32_t p = rg.fetch(k);
+                if (CHSET == CH_COLOR) p &= 0x00FFFFFFu;
+                int m = int(udot4acc(p, pal[0], uint32_t(int(nq2[0]) >> 1)));
+#pragma unroll
+                for (int i = 1; i < N; ++i) { const int t = int(udot4acc(p, pal[i], uint32_t(int(nq2[i]) >> 1))); m = t > m ? t : m; }
+                sum += m;
+            });
+            const int lb = base - 2 * sum - rg.count();
+            const bool pass = busyL && valid && lb < minErr;
+            const unsigned long long passMask = __ballot(pass);
+            if (passMask == 0ull) return 0x7FFFFFFF;
+            const int n = __popcll(passMask), pos = lanes_below(passMask);
+            if (pass)
+            {
+#pragma unroll
+                for (int i = 0; i < N; ++i) { sCand[pos * 2 * N + i] = pal[i]; sCand[pos * 2 * N + N + i] = nq2[i]; }
+                sOwner[pos] = uint32_t(lane) | (uint32_t(rg.np) << 8);
+                sSum[pos] = 0u;
+            }
+            wave_lds_sync();
+            const int items = n * npMax;
+            for (int g0 = 0; g0 < items; g0 += 64)
+            {
+                const int g = g0 + lane;
+                const int ent = int((uint32_t(g) * npMagic) >> 16), k = g - ent * npMax;
+                if (g < items)
+                {
+                    const uint32_t own = sOwner[ent];
+                    if (k < int(own >> 8))
+                    {
+                        uint32_t p = sSlot[(own & 63u) + uint32_t(k) * 64u];
+                        if (CHSET == CH_COLOR) p &= 0x00FFFFFFu;
+                        int sc[N];
+#pragma unroll
+                        for (int i = 0; i < N; ++i) sc[i] = score(p, sCand[ent * 2 * N + i], sCand[ent * 2 * N + N + i]);
+                        atomicAdd(&sSum[ent], uint32_t(first_peak(sc)));
+                    }
+                }
+            }
+            wave_lds_sync();
+            return pass ? base - int(sSum[pos]) : 0x7FFFFFFF;
+        };
+
+        {
+            // the first step is half the range: exactly one direction is a legal endpoint (see perturb_macro)
+            constexpr int half = 1 << (C::PREC - 1);
+            const int tmp = (cur >= half) ? cur - half : cur + half;
+            const int e = candidate(tmp, true);
+            if (e < minErr) { minErr = e; cur = tmp; }
+        }
+#pragma unroll 1
+        for (int step = 1 << (C::PREC - 2); step; step >>= 1)
+        {
+            int beststep = 0;
+#pragma unroll 1
+            for (int sign = -1; sign <= 1; sign += 2)
+            {
+                const int tmp = cur + sign * step;
+                const bool valid = (tmp >= 0) && (tmp < (1 << C::PREC));
+                const int e = candidate(tmp, valid);
+                if (e < minErr) { minErr = e; beststep = sign * step; }
+            }
+            cur += beststep;
+        }
+        if (busyL)
+        {
+            st = perturb_transition<MODE, IM, CHSET>(st, minErr, uint32_t(cur));
+            if (st.ch >= C::CH1)
+            {
+                TaskRec* r = a.recs + myTask;
+                r->A = st.optA; r->B = st.optB; r->err = st.optErr;
+                myTask = 0xFFFFFFFFu;
+            }
+        }
+    }
+}
+
 // Mode 6's short task lists go to bc7_exhaustive_wave_kernel (below): above this many live tasks the lane-per-task kernel is the
 // efficient one. Both are launched, each returns when it is not its turn.
 constexpr uint32_t kWaveTaskMax = 262144;
@@ -511,11 +677,6 @@ __global__ void bc7_stats_print_kernel(unsigned long long* stats)
 
 enum : int { kExhWorkMax = 1024, kExhExactMax = 512 };
 
-// Set bits of a ballot below this lane (v_mbcnt_lo / v_mbcnt_hi).
-__device__ __forceinline__ int lanes_below(unsigned long long mask)
-{
-    return int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
-}
 
 // What a helper needs of another lane's window.
 template<int N> struct ExhCtx { VarPal<N> vp; uint32_t geom; int base; };
@@ -1007,9 +1168,18 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     if (marks) marks->mark(names[2]);
     const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
     static const int tailBelow = getenv("DXTEX_BC7_TAIL_BELOW") ? atoi(getenv("DXTEX_BC7_TAIL_BELOW")) : 48;
+    static const bool perturbPlain = getenv("DXTEX_BC7_PERTURB_PLAIN") != nullptr;      // A/B: PerturbOne without the bound filter
     if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
-        hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
+        // the filter pays where the exact evaluation is dearest - eight palette entries, subsets of ~8 texels: mode 1 (24.5 -> 22.5 ms
+        // per 4096^2 image); with four entries (modes 3, 5, 7, mode 4's 2-bit colours) its list handling costs more than it saves
+        if constexpr (MODE == 1)
+        {
+            if (perturbPlain) hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
+            else hipLaunchKernelGGL((bc7_perturb_filter_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
+        }
+        else
+            hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
         if (marks) marks->mark(names[4]);
         if constexpr (MODE == 6)
             hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_ALL>), dim3(std::min<uint32_t>(kSearchWaves, ntasks)), dim3(64), 0, stream, a);
