@@ -125,12 +125,18 @@ def other_workloads(ctx, dev, img, rank, world):
     out = {}
 
     def timed(fn, n):
+        # best of three batches: the sub-millisecond kernels are timed through the host's launch path, which a busy host (the CPU
+        # baseline's OpenMP threads winding down, another rank's synthesis) can hold up for a batch
         fn(); torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / n
+        best = None
+        for _ in range(3 if n >= 5 else 1):
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / n
+            best = dt if best is None else min(best, dt)
+        return best
 
     def entry(dt, texels, algo_bytes, profile=None, **kw):
         e = {"ms": round(dt * 1e3, 3), "Mtexels_s": round(texels / dt / 1e6, 1), "roofline": hbm_roofline(algo_bytes, dt * 1e3)}
