@@ -1070,10 +1070,11 @@ DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& o
     if (loop_is_settled<CHSET>(optErr, other)) return;
     ExhState s; VarPal<C::N> vp;
     bool has = exh_begin<MODE, IM, CHSET>(s, vp, optA, optB, optErr);
-    // what the kernel does, one lane's worth: bound every candidate of the window, set the unbeaten ones aside, evaluate those exactly
-    // (here newest first, to exercise the order independence), take the minimum key
+    // what the kernel does, one lane's worth: bound every candidate of the window (counting them down, stepping with exh_advance), set
+    // the unbeaten ones aside, evaluate those exactly (here newest first, to exercise the order independence), take the minimum key
     int queue[128], n = 0;
     uint32_t bestKey = has ? exh_start_key(s) : 0u;
+    int rem = has ? exh_remaining(s) : 0;
     while (has)
     {
         const int code = exh_code(s);
@@ -1085,8 +1086,8 @@ DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& o
             ++g_pendCount[MODE];
 #endif
         }
-        ++s.i;
-        const bool ended = !exh_settle(s);
+        exh_advance(s); --rem;
+        const bool ended = rem == 0;
         if (n == 8 || ended)
         {
 #if defined(DXTEX_COUNT_EVALS)
@@ -1099,9 +1100,12 @@ DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& o
             }
             n = 0;
         }
-        if (ended) exh_apply_key(s, bestKey);
-        has = exh_next<MODE, IM, CHSET>(s, vp);
-        if (ended && has) bestKey = exh_start_key(s);        // a new window has opened
+        if (ended)
+        {
+            exh_apply_key(s, bestKey);
+            has = exh_next<MODE, IM, CHSET>(s, vp);          // the window is used up: commit, open the next one
+            if (has) { bestKey = exh_start_key(s); rem = exh_remaining(s); }
+        }
     }
     optA = s.optA; optB = s.optB; optErr = s.optErr;
 }

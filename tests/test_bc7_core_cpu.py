@@ -20,6 +20,20 @@ def test_bc7_core_on_the_host_matches_the_reference(seed, flags):
     assert r.returncode == 0 and "0 of 400 tiles differ" in r.stdout, r.stdout[-3000:]
 
 
+LOCKSTEP_EXE = os.path.join(ROOT, "oracle", "_ref", "bc7_lockstep_check")
+
+
+@pytest.mark.parametrize("seed,flags", [(31, 0), (32, 0), (33, 0x80000), (34, 0x100000)])
+def test_bc7_lockstep_pieces_match_the_reference(seed, flags):
+    """The same comparison with OptimizeOne taken through the pieces the search kernels run per lane (bc7_core.h: perturb_macro with
+    the merged first step, Exhaustive as bound filter + minimum key + exh_advance, the settled-scalar-slot shortcut) instead of the
+    straight restatement: what bc7_perturb_kernel / bc7_perturb_filter_kernel / bc7_exhaustive_kernel compute, without a GPU."""
+    if not os.path.exists(LOCKSTEP_EXE):
+        pytest.fail(f"{LOCKSTEP_EXE} missing: run __graft_entry__.build() where /root/reference exists")
+    r = subprocess.run([LOCKSTEP_EXE, "200", str(seed), hex(flags)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "0 of 200 tiles differ" in r.stdout, r.stdout[-3000:]
+
+
 BC6H_EXE = os.path.join(ROOT, "oracle", "_ref", "bc6h_core_check")
 
 
