@@ -697,8 +697,12 @@ __device__ __forceinline__ ExhCtx<LoopCfg<MODE, IM, CHSET>::N> exh_fetch_ctx(con
     return c;
 }
 
+// Mode 4 with 2-bit colour indices would take 217 registers (2 waves per SIMD): capped at 3 waves (168 registers + 168 B of spill), 4.6 -> 3.9 ms.
+#if !defined(DXTEX_EXH45_WGS)
+#define DXTEX_EXH45_WGS 3
+#endif
 template<int MODE, int IM, int CHSET>
-__global__ void __launch_bounds__(64) bc7_exhaustive_kernel(Bc7Args a, int loop, int tailBelow)
+__global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS : 1) bc7_exhaustive_kernel(Bc7Args a, int loop, int tailBelow)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     __shared__ uint32_t sSlot[16 * 64];             // texel columns, one per lane
