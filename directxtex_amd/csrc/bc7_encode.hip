@@ -498,7 +498,7 @@ template<int MODE, int IM, int CHSET>
 __global__ void __launch_bounds__(64) bc7_perturb_filter_kernel(Bc7Args a, int loop)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
-    static_assert(!C::kAlpha && C::N <= 8, "colour loops with up to eight palette entries");
+    static_assert(!C::kAlpha, "colour / combined loops only");
     constexpr int N = C::N;
     __shared__ uint32_t sSlot[16 * 64];             // texel columns, one per lane
     __shared__ uint32_t sCand[64 * 2 * N];          // list entry e: pal[N], then -|q|^2 [N]
@@ -1175,9 +1175,10 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     static const bool perturbPlain = getenv("DXTEX_BC7_PERTURB_PLAIN") != nullptr;      // A/B: PerturbOne without the bound filter
     if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
-        // the filter pays where the exact evaluation is dearest - eight palette entries, subsets of ~8 texels: mode 1 (24.5 -> 22.5 ms
-        // per 4096^2 image); with four entries (modes 3, 5, 7, mode 4's 2-bit colours) its list handling costs more than it saves
-        if constexpr (MODE == 1)
+        // the filter pays where the exact evaluation is dearest - eight palette entries on subsets of ~8 texels (mode 1: 24.5 -> 21.7 ms
+        // per 4096^2 image) and sixteen entries on whole blocks (mode 6: 3.8 -> 3.3 ms, BC7_QUICK 12.4 -> 11.6 ms); with four entries
+        // (modes 3, 5, 7, mode 4's 2-bit colours) its list handling costs more than it saves
+        if constexpr (MODE == 1 || MODE == 6)
         {
             if (perturbPlain) hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
             else hipLaunchKernelGGL((bc7_perturb_filter_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
