@@ -1040,6 +1040,52 @@ DXTEX_HD int exh_exact(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& 
     return eval_var<MODE, IM, CHSET>(rg, vp, ch, unq1<C::PREC>(uint32_t(a)), unq1<C::PREC>(uint32_t(b)), base);
 }
 
+// Can ANY candidate of the window that has just been opened beat the error the window starts from? Every palette entry's value on
+// the channel being searched is monotone in both endpoints, so over the window it stays inside [v(lowest a, lowest b), v(highest a,
+// highest b)]; with the entry anywhere in that interval a texel's error against it is at least (error on the other channels) +
+// (distance of the texel's channel value to the interval)^2, and a candidate's error is at least the sum over the texels of the
+// smallest such value (ComputeError's first-local-minimum scan can only do worse than the nearest entry). If that bound is not below
+// the starting error, Exhaustive's strict '<' (:3006) accepts nothing in this window: the ~100 candidates need not be visited.
+// One evaluation of about four candidate bounds. (Measured on the benchmark image, unpruned: 78 % of mode 4's windows, 55 % of mode
+// 5's, 20 % / 14 % / 32 % of the windows of modes 1 / 3 / 6 are of that kind - e.g. every window on a channel that is constant.)
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD bool exh_window_excluded(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, const ExhState& s, int base)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    if (C::kAlpha) return false;                  // the scalar loops of modes 4 / 5 are not filtered
+    const int oLo = s.o, oHi = s.oEnd - 1, iLo = s.i, iHi = s.iEnd - 1;      // at window open: s.o == s.o0, s.i == the first row's first value
+    const uint32_t uoL = unq1<C::PREC>(uint32_t(oLo)), uoH = unq1<C::PREC>(uint32_t(oHi)), uiL = unq1<C::PREC>(uint32_t(iLo)), uiH = unq1<C::PREC>(uint32_t(iHi));
+    const uint32_t aL = s.aleb ? uoL : uiL, bL = s.aleb ? uiL : uoL, aH = s.aleb ? uoH : uiH, bH = s.aleb ? uiH : uoH;
+    int lo[C::N], hi[C::N];
+#pragma unroll
+    for (int i = 0; i < C::N; ++i)
+    {
+        const uint32_t w = uint32_t(weight(C::BITS, i));
+        lo[i] = int(((aL * (64u - w) + bL * w + 32u) >> 6) & 0xFFu);
+        hi[i] = int(((aH * (64u - w) + bH * w + 32u) >> 6) & 0xFFu);
+    }
+    const int sh = 8 * s.ch;
+    int sum = 0;
+    for_texels(rg, [&](int k)
+    {
+        uint32_t p = rg.fetch(k);
+        if (CHSET == CH_COLOR) p &= 0x00FFFFFFu;
+        const int pc = int((p >> sh) & 0xFFu);
+        int m = -0x7FFFFFFF;
+#pragma unroll
+        for (int i = 0; i < C::N; ++i)
+        {
+            // vp.palO has the searched channel blanked, so the score below is the other channels' 2 p.q - |q|^2
+            const int c = pc < lo[i] ? lo[i] : (pc > hi[i] ? hi[i] : pc);
+            const int dc = pc - c;
+            const int t = score(p, vp.palO[i], vp.nq2O[i]) - dc * dc;
+            m = t > m ? t : m;
+        }
+        sum += m + pc * pc;
+    });
+    return (base - sum) >= s.optErr;
+}
+
 // optimize_one() through the lockstep pieces, one lane's worth (host-side equivalence check, and the
 // definition of what the search kernels compute).
 template<int MODE, int IM, int CHSET, class RG>
@@ -1073,6 +1119,16 @@ DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& o
     // what the kernel does, one lane's worth: bound every candidate of the window (counting them down, stepping with exh_advance), set
     // the unbeaten ones aside, evaluate those exactly (here newest first, to exercise the order independence), take the minimum key
     int queue[128], n = 0;
+    // a window that cannot hold an improvement is closed at once (exh_window_excluded): state "past the last row", nothing visited
+    auto skip_excluded = [&]()
+    {
+        while (has && exh_window_excluded<MODE, IM, CHSET>(rg, vp, s, base))
+        {
+            s.o = s.oEnd;
+            has = exh_next<MODE, IM, CHSET>(s, vp);
+        }
+    };
+    skip_excluded();
     uint32_t bestKey = has ? exh_start_key(s) : 0u;
     int rem = has ? exh_remaining(s) : 0;
     while (has)
@@ -1104,6 +1160,7 @@ DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& o
         {
             exh_apply_key(s, bestKey);
             has = exh_next<MODE, IM, CHSET>(s, vp);          // the window is used up: commit, open the next one
+            skip_excluded();
             if (has) { bestKey = exh_start_key(s); rem = exh_remaining(s); }
         }
     }
