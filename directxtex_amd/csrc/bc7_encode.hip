@@ -701,6 +701,9 @@ __device__ __forceinline__ ExhCtx<LoopCfg<MODE, IM, CHSET>::N> exh_fetch_ctx(con
 #if !defined(DXTEX_EXH45_WGS)
 #define DXTEX_EXH45_WGS 3
 #endif
+#if !defined(DXTEX_WIN_TRIES)
+#define DXTEX_WIN_TRIES 2
+#endif
 template<int MODE, int IM, int CHSET>
 __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS : 1) bc7_exhaustive_kernel(Bc7Args a, int loop, int tailBelow)
 {
@@ -780,10 +783,10 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
         // (exh_window_excluded: 78 % / 55 % / 32 % of the windows of modes 4 / 5 / 6 on the benchmark image). Such a window is closed at
         // once and the lane goes on to its next one, twice if need be; lanes that end up without candidates help the others through
         // the pooled phase below.
-        if constexpr (TaskMap<MODE, IM>::NS == 1 && !C::kAlpha)
+        if constexpr (!C::kAlpha)
         {
 #pragma unroll 1
-            for (int tries = 0; tries < 2; ++tries)
+            for (int tries = 0; tries < DXTEX_WIN_TRIES; ++tries)
             {
                 const bool excluded = (myTask != 0xFFFFFFFFu) && exh_window_excluded<MODE, IM, CHSET>(rg, vp, st, base);
                 if (__ballot(excluded) == 0ull) break;
