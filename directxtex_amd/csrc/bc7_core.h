@@ -1052,7 +1052,6 @@ template<int MODE, int IM, int CHSET, class RG>
 DXTEX_HD bool exh_window_excluded(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, const ExhState& s, int base)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
-    if (C::kAlpha) return false;                  // the scalar loops of modes 4 / 5 are not filtered
     const int oLo = s.o, oHi = s.oEnd - 1, iLo = s.i, iHi = s.iEnd - 1;      // at window open: s.o == s.o0, s.i == the first row's first value
     const uint32_t uoL = unq1<C::PREC>(uint32_t(oLo)), uoH = unq1<C::PREC>(uint32_t(oHi)), uiL = unq1<C::PREC>(uint32_t(iLo)), uiH = unq1<C::PREC>(uint32_t(iHi));
     const uint32_t aL = s.aleb ? uoL : uiL, bL = s.aleb ? uiL : uoL, aH = s.aleb ? uoH : uiH, bH = s.aleb ? uiH : uoH;
@@ -1063,6 +1062,25 @@ DXTEX_HD bool exh_window_excluded(const RG& rg, const VarPal<LoopCfg<MODE, IM, C
         const uint32_t w = uint32_t(weight(C::BITS, i));
         lo[i] = int(((aL * (64u - w) + bL * w + 32u) >> 6) & 0xFFu);
         hi[i] = int(((aH * (64u - w) + bH * w + 32u) >> 6) & 0xFFu);
+    }
+    if (C::kAlpha)
+    {
+        // the scalar slot of modes 4 / 5: the same statement in one dimension
+        int sumA = 0;
+        for_texels(rg, [&](int k)
+        {
+            const int al = int(rg.fetch(k) >> 24);
+            int d2 = 0x7FFFFFFF;
+#pragma unroll
+            for (int i = 0; i < C::N; ++i)
+            {
+                const int c = al < lo[i] ? lo[i] : (al > hi[i] ? hi[i] : al);
+                const int d = al - c;
+                d2 = d * d < d2 ? d * d : d2;
+            }
+            sumA += al * al - d2;
+        });
+        return (base - sumA) >= s.optErr;
     }
     const int sh = 8 * s.ch;
     int sum = 0;

@@ -783,7 +783,6 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
         // (exh_window_excluded: 78 % / 55 % / 32 % of the windows of modes 4 / 5 / 6 on the benchmark image). Such a window is closed at
         // once and the lane goes on to its next one, twice if need be; lanes that end up without candidates help the others through
         // the pooled phase below.
-        if constexpr (!C::kAlpha)
         {
 #pragma unroll 1
             for (int tries = 0; tries < DXTEX_WIN_TRIES; ++tries)
