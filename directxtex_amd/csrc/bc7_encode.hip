@@ -702,7 +702,7 @@ __device__ __forceinline__ ExhCtx<LoopCfg<MODE, IM, CHSET>::N> exh_fetch_ctx(con
 #define DXTEX_EXH45_WGS 3
 #endif
 #if !defined(DXTEX_WIN_TRIES)
-#define DXTEX_WIN_TRIES 2
+#define DXTEX_WIN_TRIES 3
 #endif
 template<int MODE, int IM, int CHSET>
 __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS : 1) bc7_exhaustive_kernel(Bc7Args a, int loop, int tailBelow)
@@ -778,11 +778,11 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
                 if (loop_is_settled<CHSET>(r.err, other) || !exh_begin<MODE, IM, CHSET>(st, vp, r.A, r.B, r.err)) myTask = 0xFFFFFFFFu;     // nothing to search: endpoints stay
             }
         }
-        // Whole-block tasks (modes 4, 5, 6): most windows of the colour loops cannot hold an improvement - e.g. every window on a channel
-        // that is constant over the block, as the swapped-in alpha of an opaque block is - and one interval bound says so
-        // (exh_window_excluded: 78 % / 55 % / 32 % of the windows of modes 4 / 5 / 6 on the benchmark image). Such a window is closed at
-        // once and the lane goes on to its next one, twice if need be; lanes that end up without candidates help the others through
-        // the pooled phase below.
+        // Many windows cannot hold an improvement - every window on a channel that is constant over the block, as the swapped-in alpha
+        // of an opaque block is, and many others - and one interval bound says so (exh_window_excluded: 78 % / 55 % / 32 % / 20 % / 14 %
+        // of the windows of modes 4 / 5 / 6 / 1 / 3 on the benchmark image, unpruned). Such a window is closed at once and the lane goes
+        // on to its next one, up to DXTEX_WIN_TRIES times (3: 143.9 ms per 4096^2 image; 1 / 2 / 4 tries: 148.6 / 149.0 / 144.8);
+        // lanes that end up without candidates help the others through the pooled phase below.
         {
 #pragma unroll 1
             for (int tries = 0; tries < DXTEX_WIN_TRIES; ++tries)
