@@ -30,7 +30,8 @@ namespace dxtex
 namespace bc7
 {
 #if defined(DXTEX_COUNT_EVALS)
-static long g_evalCount[8], g_evalTexels[8], g_macroCount[8], g_boundCount[8], g_pendCount[8], g_drainCount[8], g_pfTotal[8], g_pfPass[8], g_pfImprove[8], g_pfStepTotal[8][8], g_pfStepPass[8][8];
+static long g_evalCount[8], g_evalTexels[8], g_macroCount[8], g_boundCount[8], g_pendCount[8], g_drainCount[8], g_pfTotal[8], g_pfPass[8], g_pfImprove[8], g_pfStepTotal[8][8], g_pfStepPass[8][8], g_tabWin[8], g_tabWinOut[8], g_tabWinOutPrev[8];
+static int g_statTable = 0x7FFFFFFF, g_statTablePrev = 0x7FFFFFFF, g_statOther = 0;
 #endif
 // ---- per-mode constants (BC6HBC7.cpp:1106-1124) ---------------------------------------------------
 template<int MODE> struct ModeInfo;
@@ -1049,7 +1050,7 @@ DXTEX_HD int exh_exact(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& 
 // One evaluation of about four candidate bounds. (Measured on the benchmark image, unpruned: 78 % of mode 4's windows, 55 % of mode
 // 5's, 20 % / 14 % / 32 % of the windows of modes 1 / 3 / 6 are of that kind - e.g. every window on a channel that is constant.)
 template<int MODE, int IM, int CHSET, class RG>
-DXTEX_HD bool exh_window_excluded(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, const ExhState& s, int base)
+DXTEX_HD int exh_window_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, const ExhState& s, int base)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     const int oLo = s.o, oHi = s.oEnd - 1, iLo = s.i, iHi = s.iEnd - 1;      // at window open: s.o == s.o0, s.i == the first row's first value
@@ -1080,7 +1081,7 @@ DXTEX_HD bool exh_window_excluded(const RG& rg, const VarPal<LoopCfg<MODE, IM, C
             }
             sumA += al * al - d2;
         });
-        return (base - sumA) >= s.optErr;
+        return base - sumA;
     }
     const int sh = 8 * s.ch;
     int sum = 0;
@@ -1101,7 +1102,13 @@ DXTEX_HD bool exh_window_excluded(const RG& rg, const VarPal<LoopCfg<MODE, IM, C
         }
         sum += m + pc * pc;
     });
-    return (base - sum) >= s.optErr;
+    return base - sum;
+}
+
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD bool exh_window_excluded(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, const ExhState& s, int base)
+{
+    return exh_window_bound<MODE, IM, CHSET>(rg, vp, s, base) >= s.optErr;
 }
 
 // optimize_one() through the lockstep pieces, one lane's worth (host-side equivalence check, and the
@@ -1140,6 +1147,17 @@ DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& o
     // a window that cannot hold an improvement is closed at once (exh_window_excluded): state "past the last row", nothing visited
     auto skip_excluded = [&]()
     {
+#if defined(DXTEX_TABLE_STATS)
+        // development statistics: windows that survive the test above but whose candidate could not win the block even in the best
+        // case (window bound + lower bounds of the candidate's other subsets > an error already achieved for the block)
+        if (has && !exh_window_excluded<MODE, IM, CHSET>(rg, vp, s, base))
+        {
+            const int lbw = exh_window_bound<MODE, IM, CHSET>(rg, vp, s, base);
+            ++g_tabWin[MODE];
+            if (long(lbw) + g_statOther > long(g_statTable)) ++g_tabWinOut[MODE];
+            if (long(lbw) + g_statOther > long(g_statTablePrev)) ++g_tabWinOutPrev[MODE];
+        }
+#endif
         while (has && exh_window_excluded<MODE, IM, CHSET>(rg, vp, s, base))
         {
             s.o = s.oEnd;

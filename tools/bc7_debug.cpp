@@ -69,6 +69,10 @@ static Cand refine2_one(const HostBlock& b, uint32_t shape, int rank)
     {
         Region rg; uint32_t A, B, anchor;
         seeds2(b, shape, region, rg, A, B, anchor);
+#if defined(DXTEX_TABLE_STATS)
+        { const uint32_t m1 = kPart2Mask[shape]; const uint32_t mo = region ? ((~m1) & 0xFFFF) : m1;      // the OTHER region
+          g_statOther = subset_lower_bound(b.ldr, mo, 0u, (MODE >= 6) ? 4 : 3); }
+#endif
         refine_subset<MODE, 0>(rg, A, B, anchor, r[region]);
     }
     const int orgTot = r[0].orgErr + r[1].orgErr, optTot = r[0].optErr + r[1].optErr;
@@ -280,8 +284,27 @@ int main(int argc, char** argv)
                 for (int i = 0; i < 4; ++i) better(perMode[0], refine3_one<0>(hb, m0[i], i));
                 for (int i = 0; i < 16; ++i) better(perMode[2], refine3_one<2>(hb, m2[i], i));
             }
+#if defined(DXTEX_TABLE_STATS)
+            {
+                // first pass without statistics: what the block ends up with (the optimistic table), and mode 6 / mode 1 alone (what is
+                // on the table when mode 1 / mode 3 start in the kernels' order)
+                g_statTable = g_statTablePrev = 0x7FFFFFFF;
+                long sv[3][8]; memcpy(sv[0], g_tabWin, sizeof(g_tabWin)); memcpy(sv[1], g_tabWinOut, sizeof(g_tabWin)); memcpy(sv[2], g_tabWinOutPrev, sizeof(g_tabWin));
+                Cand b6 = refine1_one<6, 0>(hb, 0), b1; b1.valid = false; Cand b3; b3.valid = false;
+                for (int i = 0; i < 16; ++i) better(b1, refine2_one<1>(hb, l3[i], i));
+                for (int i = 0; i < 16; ++i) better(b3, refine2_one<3>(hb, l2[i], i));
+                memcpy(g_tabWin, sv[0], sizeof(g_tabWin)); memcpy(g_tabWinOut, sv[1], sizeof(g_tabWin)); memcpy(g_tabWinOutPrev, sv[2], sizeof(g_tabWin));
+                const int fin = int(std::min(b6.err, std::min(b1.err, b3.err)));
+                g_statTable = fin; g_statTablePrev = int(b6.err);
+                for (int i = 0; i < 16; ++i) better(perMode[1], refine2_one<1>(hb, l3[i], i));
+                g_statTablePrev = int(std::min(b6.err, b1.err));
+                for (int i = 0; i < 16; ++i) better(perMode[3], refine2_one<3>(hb, l2[i], i));
+                g_statTable = g_statTablePrev = 0x7FFFFFFF;
+            }
+#else
             for (int i = 0; i < 16; ++i) better(perMode[1], refine2_one<1>(hb, l3[i], i));
             for (int i = 0; i < 16; ++i) better(perMode[3], refine2_one<3>(hb, l2[i], i));
+#endif
             for (uint32_t r = 0; r < 4; ++r) { better(perMode[4], refine1_one<4, 0>(hb, r)); better(perMode[4], refine1_one<4, 1>(hb, r)); }
             for (uint32_t r = 0; r < 4; ++r) better(perMode[5], refine1_one<5, 0>(hb, r));
         }
@@ -348,6 +371,9 @@ int main(int argc, char** argv)
 #endif
 #if defined(DXTEX_COUNT_EVALS)
     for (int m = 0; m < 8; ++m) if (g_pfStepTotal[m][7]) printf("mode %d perturb: %.1f %% of the candidates below the first step are out of range (skipped by the reference)\n", m, 100.0 * g_pfStepPass[m][7] / g_pfStepTotal[m][7]);
+#endif
+#if defined(DXTEX_TABLE_STATS)
+    for (int m = 0; m < 8; ++m) if (g_tabWin[m]) printf("mode %d: of the windows the interval test leaves, %.1f %% belong to candidates that cannot win against the block's final error (%.1f %% against what earlier modes have put on the table)\n", m, 100.0 * g_tabWinOut[m] / g_tabWin[m], 100.0 * g_tabWinOutPrev[m] / g_tabWin[m]);
 #endif
 #if defined(DXTEX_COUNT_PERTURB_FILTER)
     for (int m = 0; m < 8; ++m)
