@@ -218,13 +218,28 @@ def other_workloads(ctx, dev, img, rank, world):
     return out
 
 
+CFG5_SIDE = 2048
+CFG5_CHUNK_TEXELS = 32 << 20         # dxtex_compress_many's chunk size (csrc/capi.cpp): eight 2048^2 images
+
+
+def kernel_sources_sha256():
+    """Digest of the sources of the BC7 search kernels: profiles/pmc_traffic.json is stamped with it, so counters measured on another
+    build are never republished (see main)."""
+    h = hashlib.sha256()
+    for name in ("bc7_encode.hip", "bc7_core.h", "search_common.h"):
+        h.update(open(os.path.join(ROOT, "directxtex_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
 def cfg5_shard(ctx, dev, rank, world, per_rank):
     """cfg5 (1024 x 2048^2 RGBA8 -> BC7, image i on GPU i mod N): this rank's first `per_rank` images of its shard, host pointers in,
     host pointers out through dxtex_compress_many (pinned double-buffered H2D / D2H overlapped with the search kernels). 16 distinct
-    host images are cycled. One untimed pass first (one-time allocations), then the timed one. Returns (seconds, texels)."""
+    host images are cycled. One untimed pass first (one-time allocations), then the timed one. Every payload of the timed
+    pass is compared (SHA-256) with the reference's output for that image (tests/golden/cfg5.json, no oracle in the loop).
+    Returns (seconds, texels, info)."""
     import directxtex_amd as dx
     from directxtex_amd import sharding, synth
-    side = 2048
+    side = CFG5_SIDE
     distinct = {}
 
     def load(i):
@@ -241,7 +256,70 @@ def cfg5_shard(ctx, dev, rank, world, per_rank):
     res = sharding.run_shard(1024, world, rank, load, many, batch=128, limit=per_rank)
     dt = time.perf_counter() - t0
     assert sorted(res) == mine
-    return dt, float(len(mine)) * side * side
+    per_chunk = max(1, CFG5_CHUNK_TEXELS // (side * side))
+    info = {"indices": mine, "chunks": (len(mine) + per_chunk - 1) // per_chunk}
+    gp = os.path.join(ROOT, "tests", "golden", "cfg5.json")
+    if os.path.exists(gp):
+        gold = json.load(open(gp))["images"]
+        checked = same = 0
+        for i, payload in res.items():
+            g = gold.get(str(i % 16))
+            if g and hashlib.sha256(distinct[i % 16].tobytes()).hexdigest() == g["input_sha256"]:
+                checked += 1
+                same += hashlib.sha256(payload.tobytes()).hexdigest() == g["sha256"]
+        info["payloads_checked"] = checked
+        info["payloads_identical"] = same
+        info["ref_seconds_per_image_golden"] = round(float(np.mean([v["ref_seconds"] for v in gold.values()])), 1)
+    return dt, float(len(mine)) * side * side, info
+
+
+def cfg5_cpu_side(budget_s=8.0):
+    """SURVEY 8d's CPU side of cfg5: the reference on cfg5 image 0 (seed 1000), here on bands of 16 block rows for ~budget_s, the
+    rate extrapolated to the 1024 images and labelled so."""
+    import oracle
+    from directxtex_amd import synth
+    if not oracle.have_ref():
+        return None
+    img = synth.survey_rgba8(CFG5_SIDE, CFG5_SIDE, 1000, "opaque")
+    rows = BAND_ROWS * 4
+    nb = CFG5_SIDE // rows
+    secs = 0.0; texels = 0; k = 0
+    while k < nb and (k == 0 or secs + secs / k < budget_s):
+        b = (k * 7 + nb // 2) % nb                         # bands spread over the image
+        crop = np.ascontiguousarray(img[b * rows:(b + 1) * rows])
+        t0 = time.perf_counter()
+        oracle.ref_compress_image(crop, CFG5_SIDE, rows, 28, 98, TEX_COMPRESS_PARALLEL, 0.5)
+        secs += time.perf_counter() - t0
+        texels += rows * CFG5_SIDE; k += 1
+    rate = texels / secs / 1e6
+    return {"value": round(rate, 5), "unit": "Mtexels/s", "cores": oracle.ref_num_threads(), "kind": "reference",
+            "sample": f"{k} bands of {rows} rows of cfg5 image 0 ({texels} texels, {secs:.1f} s)",
+            "extrapolated_seconds_for_1024_images": round(1024.0 * CFG5_SIDE * CFG5_SIDE / (rate * 1e6), 0)}
+
+
+def end_to_end(ctx, img, gold_sha):
+    """The headline image through dxtex_compress (host pointers: H2D + kernels + D2H, what texconv times around its Compress call,
+    Texconv/texconv.cpp:3692-3712): from pageable numpy memory and from pinned memory, best of two each."""
+    import torch
+    import directxtex_amd as dx
+    out = {}
+    rp, sp = dx.compute_pitch(dx.DXGI_FORMAT_BC7_UNORM, WIDTH, HEIGHT)
+    pin_src = torch.empty(img.nbytes, dtype=torch.uint8).pin_memory()
+    pin_src.numpy()[:] = img.reshape(-1).view(np.uint8)
+    pin_dst = torch.empty(sp, dtype=torch.uint8).pin_memory()
+    for name, src_arr, dst_arr in (("pageable", img, np.zeros(sp, np.uint8)), ("pinned", pin_src.numpy(), pin_dst.numpy())):
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ctx.compress_into(src_arr, WIDTH, HEIGHT, dx.DXGI_FORMAT_R8G8B8A8_UNORM, dst_arr, dx.DXGI_FORMAT_BC7_UNORM, 0, 0.5)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        e = {"ms": round(best * 1e3, 3), "Mtexels_s": round(WIDTH * HEIGHT / best / 1e6, 2)}
+        if gold_sha:
+            e["identical_to_reference_golden"] = hashlib.sha256(dst_arr.tobytes()).hexdigest() == gold_sha
+        out[name] = e
+    out["note"] = "dxtex_compress: 64 MiB host -> device, kernels, 16 MiB device -> host, one image, synchronous call"
+    return out
 
 
 _GOLD = None
@@ -263,16 +341,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="run the reference on the whole 4096^2 image (about 3.5 min on 128 threads)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (cfg3 / cfg4 / cfg5 shard / BC1-5 / decode) reported next to the headline")
-    ap.add_argument("--cfg5-images", type=int, default=16, help="images of the cfg5 shard every rank compresses after the timed region (0 = skip)")
+    ap.add_argument("--cfg5-images", type=int, default=40, help="images of the cfg5 shard every rank compresses after the timed region (0 = skip); "
+                    "40 = five chunks of dxtex_compress_many's double-buffered pipeline")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several "
+                    "ranks share one GPU in the tests)")
     args = ap.parse_args()
 
     import torch
     import directxtex_amd as dx
 
     from directxtex_amd import sharding
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())     # more ranks than GPUs (gloo tests): ranks share a GPU
     torch.cuda.set_device(local_rank)
-    rank, world = sharding.init_from_env("nccl", torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
+    rank, world = sharding.init_from_env(args.backend, torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
     distributed = world > 1
     n_gpus = world if distributed else 1
     if args.gpus != n_gpus and rank == 0:
@@ -324,11 +405,22 @@ def main():
     if args.cfg5_images > 0 and not args.no_extra:
         barrier()
         try:
-            dt5, tex5 = cfg5_shard(ctx, dev, rank, world, args.cfg5_images)
+            dt5, tex5, info5 = cfg5_shard(ctx, dev, rank, world, args.cfg5_images)
             dt5, tex5 = sharding.aggregate(dt5, tex5, world, dev)
+            info5 = sharding.gather_objects(info5, world)          # bookkeeping only: which indices ran where, digests checked
+            checked = sum(i.get("payloads_checked", 0) for i in info5); same = sum(i.get("payloads_identical", 0) for i in info5)
+            all_idx = sorted(j for i in info5 for j in i["indices"])
             cfg5 = {"images": int(round(tex5 / (2048 * 2048))), "seconds": round(dt5, 3), "Mtexels_s": round(tex5 / dt5 / 1e6, 2),
+                    "chunks": min(i["chunks"] for i in info5), "indices_disjoint": len(set(all_idx)) == len(all_idx),
+                    "indices_per_rank": [i["indices"][:4] + (["..."] if len(i["indices"]) > 4 else []) for i in info5],
+                    "payloads_checked": checked, "payloads_identical": same,
+                    "identical_to_reference_golden": bool(checked) and checked == same and checked == int(round(tex5 / (2048 * 2048))),
+                    "golden": "tests/golden/cfg5.json: SHA-256 of the reference's payload for each of the 16 distinct images",
                     "workload": f"cfg5 shard: images i = rank (mod {world}) of 1024 x 2048^2 RGBA8 -> BC7, the first {args.cfg5_images} per GPU, host buffers in and "
-                                "out through dxtex_compress_many (PCIe-inclusive)", "roofline": hbm_roofline(tex5 * 5.0, dt5 * 1e3)}
+                                "out through dxtex_compress_many (PCIe-inclusive), chunks of eight images",
+                    "roofline": hbm_roofline(tex5 * 5.0, dt5 * 1e3)}
+            if info5[0].get("ref_seconds_per_image_golden"):
+                cfg5["reference_seconds_per_image_8_threads"] = info5[0]["ref_seconds_per_image_golden"]
         except Exception as e:
             cfg5 = {"error": repr(e)}
             if distributed:
@@ -347,11 +439,17 @@ def main():
             roof["all_kernels_ms"] = {k: round(v, 4) for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])}
             roof["step_kernel_ms"] = round(sum(ms for ms, n in kernels.values()) / nprof, 4)
             roof["step_hbm_frac"] = round(algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6)
+        # PMC counters cannot be collected inside this process: they come from the committed rocprofv3 --pmc passes, and ONLY if that
+        # file was measured on these kernel sources (stamp) and names this run's dominant kernel; otherwise traffic stays null.
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if roof and os.path.exists(pmc):
             try:
                 t = json.load(open(pmc))
-                if t.get("kernel") == dom:
+                if t.get("kernel") != dom:
+                    roof["traffic_note"] = f"profiles/pmc_traffic.json describes {t.get('kernel')}, not this run's dominant kernel: dropped"
+                elif t.get("sources_sha256") != kernel_sources_sha256():
+                    roof["traffic_note"] = "profiles/pmc_traffic.json was measured on other kernel sources (sources_sha256 differs): dropped"
+                else:
                     roof["traffic"] = t.get("hbm_bytes_per_launch")
                     roof["traffic_source"] = t.get("source")
                     if t.get("valu"):
@@ -378,6 +476,18 @@ def main():
                 if not args.no_cpu_baseline:
                     cpu, live = cpu_baseline(img, payload, args.cpu_full)
                     parity.update(live)
+                    # the whole image on the reference: measured by the live parity test on the GPU box (tests/test_zz_fullsize_gpu.py),
+                    # committed under profiles/ (3+ minutes - not re-run here; --cpu-full does)
+                    for name in ("r03_fullsize_live.json", "r02_fullsize_live.json"):
+                        fp = os.path.join(ROOT, "profiles", name)
+                        if cpu and os.path.exists(fp):
+                            w = json.load(open(fp)).get("cfg2_bc7_4096")
+                            if w:
+                                cpu["whole_image"] = {"seconds": w["ref_seconds"], "cores": w["ref_threads"], "Mtexels_s": w["Mtexels_s"],
+                                                      "identical_to_gpu": w["identical"], "source": f"profiles/{name} (live parity run, same image)"}
+                                break
+                if not args.no_extra:
+                    extra["end_to_end"] = end_to_end(ctx, img, gold["sha256"] if gold else None)
             except Exception as e:                              # the baseline must never break the bench line
                 extra["cpu_baseline_error"] = repr(e)
 
@@ -387,13 +497,18 @@ def main():
             except Exception as e:
                 extra["other_workloads_error"] = repr(e)
         if cfg5:
+            if n_gpus == 1 and not args.no_cpu_baseline and "error" not in cfg5:
+                try:
+                    cfg5["cpu_baseline"] = cfg5_cpu_side()
+                except Exception as e:
+                    cfg5["cpu_baseline_error"] = repr(e)
             extra.setdefault("other_workloads", {})["cfg5_shard"] = cfg5
 
         line = {
             "metric": "Mtexels/s BC7 encode (4096^2 RGBA8, TEX_COMPRESS_DEFAULT)",
             "value": round(value, 3), "unit": "Mtexels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp32 seed fit + i32 exact error sums (u8 texels in, 128-bit blocks out)", "data": "synthetic",
             "config": {"workload": "cfg2: 4096x4096 RGBA8 -> BC7_UNORM, TEX_COMPRESS_DEFAULT, one image per GPU, source and "
                                    "payload resident in HBM (dxtex_compress_device)",
                        "image": "SURVEY.md 8d cfg2 recipe (directxtex_amd.synth.survey_rgba8: LCG gradients + 4-octave noise, flat to noisy blocks), "

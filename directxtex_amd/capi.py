@@ -11,7 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libdxtex_amd.so")
+    """The product library. DXTEX_AMD_LIBRARY=dev (set by the tests and tools that need development knobs, never by bench.py)
+    selects libdxtex_amd_dev.so: the same sources with -DDXTEX_DEV, the only build that reads DXTEX_* environment variables."""
+    name = "libdxtex_amd_dev.so" if os.environ.get("DXTEX_AMD_LIBRARY") == "dev" else "libdxtex_amd.so"
+    return os.path.join(_HERE, "lib", name)
 
 
 def _load():
@@ -204,6 +207,14 @@ class Context:
         self._check(_lib.dxtex_compress(self._h, ctypes.byref(src), ctypes.byref(dst), flags, threshold), "compress")
         return out
 
+    def compress_into(self, pixels, width, height, src_format, out, dst_format, flags=0, threshold=0.5):
+        """dxtex_compress with caller-owned buffers on both sides (e.g. pinned memory): `out` receives the tight BC payload."""
+        src = _host_image(pixels, width, height, src_format)
+        rp, sp = compute_pitch(dst_format, width, height)
+        assert out.flags["C_CONTIGUOUS"] and out.nbytes >= sp
+        dst = Image(width, height, dst_format, rp, sp, out.ctypes.data)
+        self._check(_lib.dxtex_compress(self._h, ctypes.byref(src), ctypes.byref(dst), flags, threshold), "compress")
+
     def compress_device(self, src_ptr, width, height, src_format, dst_ptr, dst_format, flags=0, threshold=0.5, src_row_pitch=None):
         src = device_image(src_ptr, width, height, src_format, src_row_pitch)
         dst = device_image(dst_ptr, width, height, dst_format)
@@ -225,6 +236,21 @@ class Context:
         srcs = (Image * n)(*[_host_image(im, width, height, src_format) for im in images])
         dsts = (Image * n)(*[Image(width, height, dst_format, rp, sp, o.ctypes.data) for o in outs])
         self._check(_lib.dxtex_compress_many(self._h, srcs, dsts, n, flags, threshold), "compress_many")
+        return outs
+
+    def compress_array(self, items, dst_format, flags=0, threshold=0.5):
+        """General form of dxtex_compress_many: items = [(pixels, width, height, src_format, src_row_pitch or None), ...] - any mix
+        of sizes and source formats, as the images of a DirectX::Compress array call may be. Returns the list of tight BC payloads."""
+        keep = [np.ascontiguousarray(it[0]) for it in items]
+        n = len(items)
+        outs, srcs, dsts = [], [], []
+        for arr, (_, w, h, fmt, pitch) in zip(keep, items):
+            srcs.append(_host_image(arr, w, h, fmt, pitch))
+            rp, sp = compute_pitch(dst_format, w, h)
+            o = np.zeros(sp, np.uint8); outs.append(o)
+            dsts.append(Image(w, h, dst_format, rp, sp, o.ctypes.data))
+        a = (Image * n)(*srcs); b = (Image * n)(*dsts)
+        self._check(_lib.dxtex_compress_many(self._h, a, b, n, flags, threshold), "compress_many")
         return outs
 
     def encode_blocks(self, bc_format, rgba, flags=0, threshold=0.5):

@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(256) bc6h_store_kernel(Bc6hArgs a)
     out[0] = b.lo; out[1] = b.hi;
 }
 
-const uint64_t kMaxBlocksPerPass6 = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(getenv("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 22);
+const uint64_t kMaxBlocksPerPass6 = dev_env("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(dev_env("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 22);
 struct Scratch6
 {
     size_t fpix, lists, seeds, recs, orgs, order, tinfo, counters, best, bounds, total;
@@ -681,7 +681,7 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         set_pass(a.seg, dSegs, segs, pass);
         a.nblocks = pass.nblocks;
         a.isSigned = isSigned ? 1 : 0;
-        static const bool noPrune = getenv("DXTEX_BC6H_NO_PRUNE") != nullptr;
+        static const bool noPrune = dev_env("DXTEX_BC6H_NO_PRUNE") != nullptr;
         a.prune = noPrune ? 0 : 1;
         a.fpix = reinterpret_cast<float*>(base + L.fpix);
         a.lists = base + L.lists;
@@ -700,7 +700,7 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         hipLaunchKernelGGL(bc6h_rough_kernel, dim3((a.nblocks + 3) / 4), dim3(256), 0, stream, a);
         DXTEX_MARK("bc6h_block_seed");
         hipLaunchKernelGGL(bc6h_block_seed_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, stream, a);
-        if (getenv("DXTEX_BC6H_DUMP"))     // development aid: rank lists and seeds of the first blocks
+        if (dev_env("DXTEX_BC6H_DUMP"))     // development aid: rank lists and seeds of the first blocks
         {
             (void)hipStreamSynchronize(stream);
             const uint32_t n = std::min<uint32_t>(a.nblocks, 4);
@@ -716,8 +716,8 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
                 fprintf(stderr, "\n");
             }
         }
-        static const int onlyMode = getenv("DXTEX_BC6H_ONLY_MODE") ? atoi(getenv("DXTEX_BC6H_ONLY_MODE")) : -1;     // development aid
-        static const bool noSearch = getenv("DXTEX_BC6H_NO_SEARCH") != nullptr;
+        static const int onlyMode = dev_env("DXTEX_BC6H_ONLY_MODE") ? atoi(dev_env("DXTEX_BC6H_ONLY_MODE")) : -1;     // development aid
+        static const bool noSearch = dev_env("DXTEX_BC6H_NO_SEARCH") != nullptr;
         static const Bc6hMode kModes[14] = {
             { 0x00, 1, 1, 3, { 10, 10, 10 }, { 5, 5, 5 } }, { 0x01, 1, 1, 3, { 7, 7, 7 }, { 6, 6, 6 } }, { 0x02, 1, 1, 3, { 11, 11, 11 }, { 5, 4, 4 } },
             { 0x06, 1, 1, 3, { 11, 11, 11 }, { 4, 5, 4 } }, { 0x0a, 1, 1, 3, { 11, 11, 11 }, { 4, 4, 5 } }, { 0x0e, 1, 1, 3, { 9, 9, 9 }, { 5, 5, 5 } },
@@ -779,7 +779,7 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
             sort_tasks(ntasks);
             DXTEX_MARK("bc6h_perturb_1region");
             // both are launched; the live count (known on the device only) decides which one works
-            static const uint32_t waveMax = getenv("DXTEX_BC6H_WAVE_MAX") ? uint32_t(strtoul(getenv("DXTEX_BC6H_WAVE_MAX"), nullptr, 0)) : kWaveTaskMax6;
+            static const uint32_t waveMax = dev_env("DXTEX_BC6H_WAVE_MAX") ? uint32_t(strtoul(dev_env("DXTEX_BC6H_WAVE_MAX"), nullptr, 0)) : kWaveTaskMax6;
             if (!noSearch)
             {
                 hipLaunchKernelGGL(bc6h_perturb_kernel<16>, dim3(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64)), dim3(64), 0, stream, a, waveMax);

@@ -1130,7 +1130,7 @@ __global__ void __launch_bounds__(256) bc7_pick_kernel(Bc7Args a, uint32_t slotM
 namespace
 {
 // bounds the scratch (about 1.1 KiB per block); DXTEX_MAX_BLOCKS_PER_PASS shrinks it so tests can exercise the pass loop
-const uint64_t kMaxBlocksPerPass = getenv("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(getenv("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 22);
+const uint64_t kMaxBlocksPerPass = dev_env("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(dev_env("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 22);
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
 struct ScratchLayout
 {
@@ -1162,23 +1162,6 @@ struct ScratchLayout
     }
 };
 
-// Two side streams (per host thread and device) for the pipelines that run next to the caller's stream, with the events that fork and join them.
-struct ForkStreams { hipStream_t side[2] = { nullptr, nullptr }; hipEvent_t forked = nullptr, joined[2] = { nullptr, nullptr }; int device = -1; };
-inline ForkStreams* fork_streams()
-{
-    static thread_local ForkStreams fs;
-    int device = 0;
-    if (hipGetDevice(&device) != hipSuccess) return nullptr;
-    if (fs.device == device) return &fs;
-    if (fs.device >= 0) return nullptr;                    // one device per host thread (a context is bound to one GPU)
-    bool ok = hipEventCreateWithFlags(&fs.forked, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < 2 && ok; ++k)
-        ok = hipStreamCreateWithFlags(&fs.side[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&fs.joined[k], hipEventDisableTiming) == hipSuccess;
-    if (!ok) return nullptr;
-    fs.device = device;
-    return &fs;
-}
-
 template<int MODE, int IM>
 void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const char* const (&names)[7])
 {
@@ -1197,8 +1180,8 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order);
     if (marks) marks->mark(names[2]);
     const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
-    static const int tailBelow = getenv("DXTEX_BC7_TAIL_BELOW") ? atoi(getenv("DXTEX_BC7_TAIL_BELOW")) : 48;
-    static const bool perturbPlain = getenv("DXTEX_BC7_PERTURB_PLAIN") != nullptr;      // A/B: PerturbOne without the bound filter
+    static const int tailBelow = dev_env("DXTEX_BC7_TAIL_BELOW") ? atoi(dev_env("DXTEX_BC7_TAIL_BELOW")) : 48;
+    static const bool perturbPlain = dev_env("DXTEX_BC7_PERTURB_PLAIN") != nullptr;      // A/B: PerturbOne without the bound filter
     if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
         // the filter pays where the exact evaluation is dearest - eight palette entries on subsets of ~8 texels (mode 1: 24.5 -> 21.7 ms
@@ -1238,13 +1221,14 @@ size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags, size_t nimages)
 }
 
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
-                             void* scratch, hipStream_t stream, KernelMarks* marks)
+                             void* scratch, hipStream_t stream, KernelMarks* marks, const SideStreams* side)
 {
     BcImage one; one.src = src; one.dst = dst; one.dstRowPitch = dstRowPitch;
-    return launch_bc7_encode_many(&one, 1, flags, scratch, stream, marks);
+    return launch_bc7_encode_many(&one, 1, flags, scratch, stream, marks, side);
 }
 
-hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t flags, void* scratch, hipStream_t stream, KernelMarks* marks)
+hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t flags, void* scratch, hipStream_t stream, KernelMarks* marks,
+                                  const SideStreams* side)
 {
 #define DXTEX_MARK(NAME) do { if (marks) marks->mark(NAME); } while (0)
 #define DXTEX_MODE(MODE, IM, TAG) do { static const char* const n_[7] = { "bc7_pre_" TAG, "bc7_bin_" TAG, "bc7_perturb_" TAG, "bc7_perturb_alpha_" TAG, \
@@ -1280,15 +1264,15 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         a.seeds = reinterpret_cast<uint2*>(base + L.seeds);
         a.seeds1 = reinterpret_cast<uint2*>(base + L.seeds1);
         a.seeds3 = reinterpret_cast<uint2*>(base + L.seeds3);
-        static const bool noPrune = getenv("DXTEX_BC7_NO_PRUNE") != nullptr;
+        static const bool noPrune = dev_env("DXTEX_BC7_NO_PRUNE") != nullptr;
         a.prune = noPrune ? 0 : 1;
-        static const int early6 = getenv("DXTEX_BC7_EARLY6_PCT") ? atoi(getenv("DXTEX_BC7_EARLY6_PCT")) : 100;
+        static const int early6 = dev_env("DXTEX_BC7_EARLY6_PCT") ? atoi(dev_env("DXTEX_BC7_EARLY6_PCT")) : 100;
         a.early6Pct = early6;
         uint32_t slotMask = 0;
 
         uint32_t* flagCount = reinterpret_cast<uint32_t*>(base + L.flagcnt);
         a.flagged = flagCount;
-        static const int early6MinPct = getenv("DXTEX_BC7_EARLY6_MIN_PCT") ? atoi(getenv("DXTEX_BC7_EARLY6_MIN_PCT")) : 25;
+        static const int early6MinPct = dev_env("DXTEX_BC7_EARLY6_MIN_PCT") ? atoi(dev_env("DXTEX_BC7_EARLY6_MIN_PCT")) : 25;
         a.early6Min = uint32_t(uint64_t(a.nblocks) * uint32_t(early6MinPct) / 100u);
         if (!quick)
         {
@@ -1313,7 +1297,7 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         static const std::vector<int> order = []
         {
             std::vector<int> o;
-            const char* e = getenv("DXTEX_BC7_ORDER");
+            const char* e = dev_env("DXTEX_BC7_ORDER");
             const char* p = e ? e : "16,7,14,18,15,0,1,2,3,24,28,25,26";
             while (*p)
             {
@@ -1355,8 +1339,8 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         // consecutive steps of that family run side by side on two extra streams, each pipeline on its own slice of the task arrays.
         // Per-kernel timing (marks) needs one stream and keeps them serial.
         auto family45 = [](int step) { const int m = step % 10; return m == 4 || m == 8 || m == 5; };
-        static const bool serial45 = getenv("DXTEX_BC7_SERIAL") != nullptr;
-        ForkStreams* fork = (marks || serial45 || quick) ? nullptr : fork_streams();
+        static const bool serial45 = dev_env("DXTEX_BC7_SERIAL") != nullptr;
+        const SideStreams* fork = (marks || serial45 || quick) ? nullptr : side;
         for (size_t at = 0; at < order.size() && !quick; )
         {
             const int step = order[at];

@@ -60,6 +60,9 @@ struct dxtex_ctx
         hipEvent_t uploaded = nullptr, computed = nullptr, downloaded = nullptr;
     } lane[2];
     hipStream_t h2d = nullptr, d2h = nullptr;
+    // side streams of the BC7 pipeline (modes 4 / 5 run next to each other): created on first use, destroyed with the context
+    SideStreams side = { { nullptr, nullptr }, nullptr, { nullptr, nullptr } };
+    bool sideTried = false, sideOk = false;
     std::string lastError;
     bool profiling = false;
     Marks marks;
@@ -108,7 +111,22 @@ struct ScopedDevice
     ~ScopedDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-static const bool kNoTiming = getenv("DXTEX_NO_TIMING") != nullptr;
+// lazily creates the context's side streams; nullptr (= serial pipelines) if the runtime refuses
+const SideStreams* side_streams(dxtex_ctx* ctx)
+{
+    if (!ctx->sideTried)
+    {
+        ctx->sideTried = true;
+        bool ok = hipEventCreateWithFlags(&ctx->side.forked, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k)
+            ok = hipStreamCreateWithFlags(&ctx->side.side[k], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&ctx->side.joined[k], hipEventDisableTiming) == hipSuccess;
+        ctx->sideOk = ok;
+    }
+    return ctx->sideOk ? &ctx->side : nullptr;
+}
+
+static const bool kNoTiming = dev_env("DXTEX_NO_TIMING") != nullptr;
 void time_begin(dxtex_ctx* ctx) { if (!kNoTiming) (void)hipEventRecord(ctx->evStart, ctx->stream); }
 void time_end(dxtex_ctx* ctx) { if (!kNoTiming) { (void)hipEventRecord(ctx->evStop, ctx->stream); ctx->timing = true; } }
 
@@ -188,7 +206,7 @@ dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width,
         const uint64_t nblocks = uint64_t((width + 3) / 4) * uint64_t((height + 3) / 4);
         hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc7_scratch_bytes(nblocks, flags));
         if (hr != DXTEX_S_OK) return hr;
-        e = launch_bc7_encode(v, dDst, dstRowPitch, flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
+        e = launch_bc7_encode(v, dDst, dstRowPitch, flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr, side_streams(ctx));
         break;
     }
     case FMT_BC6H_UF16: case FMT_BC6H_SF16:
@@ -272,6 +290,12 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
         if (l.computed) (void)hipEventDestroy(l.computed);
         if (l.downloaded) (void)hipEventDestroy(l.downloaded);
     }
+    for (int k = 0; k < 2; ++k)
+    {
+        if (ctx->side.side[k]) { (void)hipStreamSynchronize(ctx->side.side[k]); (void)hipStreamDestroy(ctx->side.side[k]); }
+        if (ctx->side.joined[k]) (void)hipEventDestroy(ctx->side.joined[k]);
+    }
+    if (ctx->side.forked) (void)hipEventDestroy(ctx->side.forked);
     for (hipEvent_t e : ctx->marks.pool) (void)hipEventDestroy(e);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
@@ -286,9 +310,11 @@ dxtex_hresult dxtex_ctx_set_stream(dxtex_ctx* ctx, void* hip_stream)
     if (next != ctx->stream)
     {
         // the context's scratch, staging and filter tables are ordered by ONE stream: work queued on the old one must be done
-        // before kernels on the new one may reuse them
+        // before kernels on the new one may reuse them. The previous stream must stay alive until this call returns; if the caller
+        // has destroyed it already (invalid handle) there is nothing left to wait for - the context switches either way.
         ScopedDevice sd(ctx->device);
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const hipError_t drained = hipStreamSynchronize(ctx->stream);
+        if (drained != hipSuccess) (void)hipGetLastError();
         ctx->stream = next;
     }
     return DXTEX_S_OK;
@@ -433,7 +459,7 @@ dxtex_hresult dxtex_compress_many_device(dxtex_ctx* ctx, const dxtex_image* srcs
         dxtex_hresult hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, allBc7 ? bc7_scratch_bytes(nblocks, flags, count) : bc6h_scratch_bytes(nblocks, count));
         if (hr != DXTEX_S_OK) return hr;
         time_begin(ctx);
-        const hipError_t e = allBc7 ? launch_bc7_encode_many(batch.data(), count, flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr)
+        const hipError_t e = allBc7 ? launch_bc7_encode_many(batch.data(), count, flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr, side_streams(ctx))
                                     : launch_bc6h_encode_many(batch.data(), count, dsts[0].format == FMT_BC6H_SF16, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
         time_end(ctx);
         if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
@@ -545,7 +571,7 @@ namespace
 {
 dxtex_hresult compress_many_pipelined(dxtex_ctx* ctx, const dxtex_image* srcs, const dxtex_image* dsts, size_t count, uint32_t flags, float threshold)
 {
-    static const uint64_t chunkTexels = getenv("DXTEX_MANY_CHUNK_TEXELS") ? std::max<uint64_t>(1, strtoull(getenv("DXTEX_MANY_CHUNK_TEXELS"), nullptr, 10)) : (32ull << 20);
+    static const uint64_t chunkTexels = dev_env("DXTEX_MANY_CHUNK_TEXELS") ? std::max<uint64_t>(1, strtoull(dev_env("DXTEX_MANY_CHUNK_TEXELS"), nullptr, 10)) : (32ull << 20);
     std::vector<size_t> inBytes(count), outBytes(count);
     std::vector<ManyChunk> chunks;
     {
@@ -621,8 +647,9 @@ dxtex_hresult compress_many_pipelined(dxtex_ctx* ctx, const dxtex_image* srcs, c
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, l.computed, 0));
         HIP_TRY(ctx, hipMemcpyAsync(l.pinOut, l.devOut, atOut, hipMemcpyDeviceToHost, ctx->d2h));
         HIP_TRY(ctx, hipEventRecord(l.downloaded, ctx->d2h));
-        // the next upload into this lane's devIn (chunk c + 2) must not overtake these kernels
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->h2d, l.computed, 0));
+        // (no wait of h2d on `computed`: the next upload into this lane's devIn belongs to chunk c + 2, and iteration c + 2 begins with
+        // scatter(c), a host wait for downloaded(c), which is stream-ordered after computed(c). The upload of chunk c + 1 - the other
+        // lane - therefore runs while these kernels do.)
     }
     for (size_t c = chunks.size() >= 2 ? chunks.size() - 2 : 0; c < chunks.size(); ++c)
     {
@@ -691,7 +718,7 @@ dxtex_hresult dxtex_encode_blocks(dxtex_ctx* ctx, int32_t bc_format, uint32_t bc
         e = launch_bc6h_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_format == FMT_BC6H_SF16, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
         break;
     case FMT_BC7_UNORM: case FMT_BC7_UNORM_SRGB:
-        e = launch_bc7_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
+        e = launch_bc7_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr, side_streams(ctx));
         break;
     default:
         e = launch_bc15_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_format, bc_flags, threshold, ctx->stream);

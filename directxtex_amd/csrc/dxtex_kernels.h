@@ -2,6 +2,7 @@
 // returns the launch status; no launcher synchronises or allocates.
 #pragma once
 #include "dxtex_device.h"
+#include "dxtex_dev.h"
 
 namespace dxtex
 {
@@ -20,10 +21,14 @@ hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowP
 // BC7: `scratch` must hold bc7_scratch_bytes(total number of 4x4 blocks, flags, number of images) bytes of device memory.
 // The _many form runs an array of images (a mip chain, a texture array) through the per-mode pipeline as one block list.
 struct BcImage { SrcView src; uint8_t* dst; uint64_t dstRowPitch; };
+// Two extra streams (and the events that fork / join them) for pipelines that are independent of each other until the last kernel:
+// owned by the context (one set per context and device, destroyed with it); nullptr = everything on `stream`.
+struct SideStreams { hipStream_t side[2]; hipEvent_t forked; hipEvent_t joined[2]; };
 size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags, size_t nimages = 1);
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
-                             void* scratch, hipStream_t stream, KernelMarks* marks);
-hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t flags, void* scratch, hipStream_t stream, KernelMarks* marks);
+                             void* scratch, hipStream_t stream, KernelMarks* marks, const SideStreams* side = nullptr);
+hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t flags, void* scratch, hipStream_t stream, KernelMarks* marks,
+                                  const SideStreams* side = nullptr);
 
 // BC6H (UF16 / SF16): `scratch` must hold bc6h_scratch_bytes(number of 4x4 blocks) bytes of device memory.
 size_t bc6h_scratch_bytes(uint64_t nblocks, size_t nimages = 1);

@@ -618,20 +618,14 @@ namespace
 // Progress and cancellation for one image (the role of the per-row callbacks of CompressBC, DirectXTexCompress.cpp:113-121):
 // blocks are independent, so the image is submitted as bands of whole block rows - large enough to fill the GPU - and the
 // callback is asked between bands. The bytes written are those of the one-submission path.
-// DXTEX_PROGRESS_BAND_BLOCKS / DXTEX_PROGRESS_BAND_TEXELS override the band sizes (the tests use them to get several bands
-// out of a small image).
-size_t BandSize(const char* env, size_t def) noexcept
-{
-    const char* v = std::getenv(env);
-    const long long n = v ? std::atoll(v) : 0;
-    return n > 0 ? size_t(n) : def;
-}
+// Device::SetProgressBands overrides the band sizes (the tests use it to get several bands out of a small image).
+size_t BandSize(size_t chosen, size_t def) noexcept { return chosen ? chosen : def; }
 constexpr size_t kBandBlocks = 262144;
 
 HRESULT CompressBands(Device& device, const Image& src, const Image& dst, const CompressOptions& options, const StatusCallback& statusCallback)
 {
     const size_t nbW = std::max<size_t>(1, (src.width + 3) / 4), nbH = std::max<size_t>(1, (src.height + 3) / 4);
-    const size_t bandRows = std::max<size_t>(1, BandSize("DXTEX_PROGRESS_BAND_BLOCKS", kBandBlocks) / nbW);          // block rows per band
+    const size_t bandRows = std::max<size_t>(1, BandSize(device.ProgressBandBlocks(), kBandBlocks) / nbW);          // block rows per band
     for (size_t by = 0; by < nbH; by += bandRows)
     {
         const size_t y = by * 4;
@@ -951,7 +945,7 @@ constexpr size_t kBandTexels = size_t(1) << 24;
 
 HRESULT ConvertBands(Device& device, const Image& src, const Image& dst, const ConvertOptions& options, const StatusCallback& statusCallback)
 {
-    const size_t bandRows = std::max<size_t>(1, BandSize("DXTEX_PROGRESS_BAND_TEXELS", kBandTexels) / std::max<size_t>(1, src.width));
+    const size_t bandRows = std::max<size_t>(1, BandSize(device.ProgressBandTexels(), kBandTexels) / std::max<size_t>(1, src.width));
     for (size_t y = 0; y < src.height; y += bandRows)
     {
         if (y && !statusCallback(y, src.height)) return E_ABORT;

@@ -218,8 +218,15 @@ public:
     explicit operator bool() const noexcept { return m_ctx != nullptr; }
     dxtex_ctx* Get() const noexcept { return m_ctx; }
     const char* LastError() const noexcept;
+    // Granularity of the progress / cancel callbacks of CompressEx / ConvertEx on ONE image: the image goes to the GPU as bands of
+    // whole (block) rows of about this many blocks / texels, and the callback is asked between bands. 0 keeps the default
+    // (2^18 blocks, 2^24 texels: large enough to fill the GPU). The bytes written never depend on it.
+    void SetProgressBands(size_t compressBlocks, size_t convertTexels) noexcept { m_bandBlocks = compressBlocks; m_bandTexels = convertTexels; }
+    size_t ProgressBandBlocks() const noexcept { return m_bandBlocks; }
+    size_t ProgressBandTexels() const noexcept { return m_bandTexels; }
 private:
     dxtex_ctx* m_ctx = nullptr;
+    size_t m_bandBlocks = 0, m_bandTexels = 0;
 };
 
 // ---- the path's entry points (shapes of DirectXTex.h:799-846, :946-968, :1021) ----------------------------------------

@@ -40,6 +40,16 @@ def gather_index(results, world):
     return got
 
 
+def gather_objects(obj, world):
+    """Bookkeeping only: every rank's small python object (indices, counts) -> list over ranks. No texture data."""
+    if world <= 1:
+        return [obj]
+    import torch.distributed as dist
+    got = [None] * world
+    dist.all_gather_object(got, obj)
+    return got
+
+
 def init_from_env(backend, device=None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1. Returns (rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -65,6 +75,8 @@ def aggregate(elapsed_s, texels_local, world, device="cpu"):
         return float(elapsed_s), float(texels_local)
     import torch
     import torch.distributed as dist
+    if dist.get_backend() == "gloo":
+        device = "cpu"                                   # gloo reduces host tensors
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     n = torch.tensor([texels_local], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

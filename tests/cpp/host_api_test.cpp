@@ -232,8 +232,7 @@ static int gpu_run(const std::string& outdir)
     // CompressEx / ConvertEx: progress and cancel. One image goes to the GPU in bands of rows (forced small here), a set
     // image by image; either way the bytes are those of the callback-free call (DirectXTexCompress.cpp:664-850).
     {
-        setenv("DXTEX_PROGRESS_BAND_BLOCKS", "100", 1);         // 24 blocks per row -> 4 block rows per band
-        setenv("DXTEX_PROGRESS_BAND_TEXELS", "1000", 1);        // 96 texels per row -> 10 rows per band
+        dev.SetProgressBands(100, 1000);                         // 24 blocks per row -> 4 block rows per band; 96 texels per row -> 10 rows per band
         const CompressOptions co = { TEX_COMPRESS_DEFAULT, TEX_THRESHOLD_DEFAULT, TEX_ALPHA_WEIGHT_DEFAULT };
         const ConvertOptions cv = { TEX_FILTER_DEFAULT, TEX_THRESHOLD_DEFAULT };
         std::vector<std::pair<size_t, size_t>> calls;
@@ -280,7 +279,7 @@ static int gpu_run(const std::string& outdir)
         CHECK(calls.size() == 9 && calls[8] == std::make_pair(size_t(7), size_t(7)));
         n = 0;
         CHECK(ConvertEx(dev, src, DXGI_FORMAT_R16G16B16A16_FLOAT, cv, ex, [&](size_t, size_t) { return ++n < 2; }) == E_ABORT && ex.GetPixels() == nullptr);
-        unsetenv("DXTEX_PROGRESS_BAND_BLOCKS"); unsetenv("DXTEX_PROGRESS_BAND_TEXELS");
+        dev.SetProgressBands(0, 0);
         // default band sizes: a 96x64 image is one band - start and end only
         calls.clear();
         CHECK(CompressEx(dev, src, DXGI_FORMAT_BC1_UNORM, co, ex, record) == S_OK && calls.size() == 2);

@@ -74,3 +74,14 @@ def test_integration_binding_compiles_against_the_reference_headers(tmp_path):
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "oracle", "shim"), "-I" + ref, "-I" + os.path.join(ROOT, "include"), path],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_product_library_reads_no_environment():
+    """The shipped libraries must not be steerable from a user's shell: neither libdxtex_amd.so nor the C++ host layer imports getenv /
+    secure_getenv (development knobs exist only in libdxtex_amd_dev.so, the -DDXTEX_DEV build the tests and tools load explicitly)."""
+    import subprocess
+    lib = os.path.join(ROOT, "directxtex_amd", "lib")
+    for name, expect in (("libdxtex_amd.so", False), ("libdxtex_amd_host.so", False), ("libdxtex_amd_dev.so", True)):
+        r = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(lib, name)], capture_output=True, text=True, check=True)
+        has = any("getenv" in l for l in r.stdout.splitlines())
+        assert has == expect, (name, "imports getenv" if has else "does not import getenv")

@@ -104,7 +104,7 @@ def test_multi_pass_images(oracle):
         assert np.array_equal(c.compress(hdr, w, h, 10, 95, 0, 0.5), oracle.ref_compress_image(hdr, w, h, 10, 95, 0, 0.5))
         print("multi-pass OK")
     """ % root)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DXTEX_MAX_BLOCKS_PER_PASS="17"), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DXTEX_AMD_LIBRARY="dev", DXTEX_MAX_BLOCKS_PER_PASS="17"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "multi-pass OK" in r.stdout, r.stdout + r.stderr
 
 
@@ -145,6 +145,7 @@ def test_array_goes_through_one_block_list(oracle, pass_blocks):
     """ % root)
     env = dict(os.environ)
     if pass_blocks:
+        env["DXTEX_AMD_LIBRARY"] = "dev"                     # only the -DDXTEX_DEV build reads knobs
         env["DXTEX_MAX_BLOCKS_PER_PASS"] = pass_blocks
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "array OK" in r.stdout, r.stdout + r.stderr
@@ -177,6 +178,8 @@ def test_pruning_changes_nothing():
     outs = []
     for env in ({}, {"DXTEX_BC7_NO_PRUNE": "1", "DXTEX_BC6H_NO_PRUNE": "1"}, {"DXTEX_BC7_ORDER": "7,6,5,8,4,3,2,1,0", "DXTEX_BC7_PERTURB_PLAIN": "1"},
                 {"DXTEX_BC7_ORDER": "26,25,3,1,16,7,15,14,18,24,28,0,2", "DXTEX_BC6H_WAVE_MAX": "0"}):
+        if env:
+            env = dict(env, DXTEX_AMD_LIBRARY="dev")         # only the -DDXTEX_DEV build reads knobs; the first run is the product library
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.split())

@@ -1,0 +1,99 @@
+"""dxtex_compress_many (host pointers in, host pointers out: the cfg5 entry point, DirectXTexCompress.cpp:794-833) in its steady state.
+
+The array is cut into chunks of about DXTEX_MANY_CHUNK_TEXELS texels; two lanes of pinned + device staging alternate, so lane re-use
+(`scatter(c - 2)`), re-allocation of a lane's buffers when a later chunk is larger, and the H2D / kernels / D2H event chain only
+execute from the third chunk on. The development library (libdxtex_amd_dev.so) honours a small chunk size, so a few dozen KiB of
+images run through >= 6 chunks whose sizes grow and shrink. Every payload byte must equal the reference's per-image Compress."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (width, height, source format, row padding in bytes): uneven sizes, RGBA8 and RGBA16F sources, some rows padded
+SHAPES = [(64, 64, 28, 0), (32, 32, 10, 0), (128, 96, 28, 64), (16, 16, 28, 0), (200, 120, 10, 0), (8, 8, 28, 12), (256, 256, 28, 0),
+          (4, 4, 10, 0), (100, 60, 28, 0), (300, 200, 28, 16), (20, 20, 10, 8), (64, 32, 28, 0), (1, 1, 28, 0), (160, 160, 10, 0),
+          (37, 23, 28, 0), (90, 90, 28, 4)]
+CHUNK_TEXELS = 26000
+
+
+def chunk_plan(shapes, chunk_texels):
+    """The chunking rule of compress_many_pipelined (csrc/capi.cpp): a chunk closes when the next image would exceed the budget."""
+    chunks, cur, tex = [], [], 0
+    for i, (w, h, _, _) in enumerate(shapes):
+        if cur and tex + w * h > chunk_texels:
+            chunks.append(cur); cur = []; tex = 0
+        cur.append(i); tex += w * h
+    chunks.append(cur)
+    return chunks
+
+
+def test_chunk_plan_grows_and_shrinks():
+    chunks = chunk_plan(SHAPES, CHUNK_TEXELS)
+    sizes = [sum(SHAPES[i][0] * SHAPES[i][1] for i in c) for c in chunks]
+    assert len(chunks) >= 6, chunks
+    # lane re-allocation needs a later chunk of the same lane (c, c + 2, ...) to be larger than an earlier one, and the reverse
+    assert any(sizes[c + 2] > sizes[c] for c in range(len(sizes) - 2)) and any(sizes[c + 2] < sizes[c] for c in range(len(sizes) - 2)), sizes
+
+
+CODE = textwrap.dedent("""
+    import sys; sys.path.insert(0, %(root)r)
+    import numpy as np, directxtex_amd as dx, oracle
+    from directxtex_amd import synth
+    from directxtex_amd.capi import DxtexError
+    shapes = %(shapes)r
+    items, tight = [], []
+    for k, (w, h, fmt, pad) in enumerate(shapes):
+        img = synth.rgba8(w, h, seed=100 + k, alpha=("smooth", "opaque", "binary")[k %% 3])
+        if fmt == 10:
+            img = (img.astype(np.float32) / 255.0).astype(np.float16)
+        bpp = 4 if fmt == 28 else 8
+        rows = np.zeros((h, w * bpp + pad), np.uint8)
+        rows[:, :w * bpp] = img.view(np.uint8).reshape(h, w * bpp)
+        rows[:, w * bpp:] = 0xA5                                     # padding must never be read as texels
+        items.append((rows, w, h, fmt, w * bpp + pad))
+        tight.append(img)
+    c = dx.Context(0)
+    for dst_fmt, flags in ((98, 0), (71, 0), (98, 0)):                # BC7, BC1, BC7 again (the lanes now hold BC1-sized buffers)
+        got = c.compress_array(items, dst_fmt, flags, 0.5)
+        for k, ((w, h, fmt, pad), g) in enumerate(zip(shapes, got)):
+            ref = oracle.ref_compress_image(tight[k], w, h, fmt, dst_fmt, flags, 0.5)
+            assert np.array_equal(g, ref), ("payload differs from the reference", dst_fmt, k, w, h, fmt)
+    # a failure in the middle of the array (image 9: rowPitch below the format's minimum) must come back as the reference's HRESULT
+    # without hanging, and leave the context usable
+    bad = list(items)
+    rows, w, h, fmt, pitch = bad[9]
+    bad[9] = (rows, w, h, fmt, w * 4 - 4)
+    try:
+        c.compress_array(bad, 98, 0, 0.5)
+        raise SystemExit("no error for a rowPitch below the minimum")
+    except DxtexError as e:
+        assert e.hresult & 0xFFFFFFFF == 0x80070057, hex(e.hresult)   # E_INVALIDARG
+    bad[9] = (rows, w, h, 71, pitch)                                  # a compressed source (DirectXTexCompress.cpp:671-672)
+    try:
+        c.compress_array(bad, 98, 0, 0.5)
+        raise SystemExit("no error for a compressed source")
+    except DxtexError as e:
+        assert e.hresult & 0xFFFFFFFF == 0x80070057, hex(e.hresult)
+    got = c.compress_array(items[:7], 98, 0, 0.5)
+    for k, g in enumerate(got):
+        w, h, fmt, pad = shapes[k]
+        assert np.array_equal(g, oracle.ref_compress_image(tight[k], w, h, fmt, 98, 0, 0.5)), ("after the failure", k)
+    c.close()
+    print("many OK")
+""")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk_texels", [str(CHUNK_TEXELS), "1", None])
+def test_compress_many_steady_state(oracle, chunk_texels):
+    """>= 6 chunks of growing and shrinking size (lane re-use + re-allocation), one image per chunk (16 chunks), and the product
+    library's default (one chunk): BC7 and BC1 payloads of 16 uneven images in two source formats, byte-identical to the reference."""
+    env = dict(os.environ)
+    if chunk_texels:
+        env.update(DXTEX_AMD_LIBRARY="dev", DXTEX_MANY_CHUNK_TEXELS=chunk_texels)
+    r = subprocess.run([sys.executable, "-c", CODE % {"root": ROOT, "shapes": SHAPES}], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "many OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -22,7 +22,7 @@ for t in range(len(sel)):
 ctx.close()
 for mode in range(14):
     for ns in (0, 1):
-        env = dict(os.environ, DXTEX_BC6H_ONLY_MODE=str(mode))
+        env = dict(os.environ, DXTEX_AMD_LIBRARY="dev", DXTEX_BC6H_ONLY_MODE=str(mode))
         if ns: env["DXTEX_BC6H_NO_SEARCH"] = "1"
         code = ("import sys; sys.path.insert(0, %r); import numpy as np, directxtex_amd as dx; c = dx.Context(0); "
                 "t = np.fromfile(%r, np.float32).reshape(-1,16,4); o = c.encode_blocks(%d, t, 0); "
