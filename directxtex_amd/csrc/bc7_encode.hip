@@ -18,6 +18,7 @@
 #include "bc7_core.h"
 #include "search_common.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -1211,6 +1212,19 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     }
     if (marks) marks->mark(names[6]);
     hipLaunchKernelGGL((bc7_post_kernel<MODE, IM>), dim3(gridPP), dim3(256), 0, stream, a);
+#if defined(DXTEX_DEV)
+    // development statistics (DXTEX_BC7_STATS): how many of the mode's tasks survived pre, by subset size
+    static const bool stats = dev_env("DXTEX_BC7_STATS") != nullptr;
+    if (stats)
+    {
+        uint32_t c[40] = {};
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(c, a.counters, sizeof(c), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "bc7 stats %-22s phase %d: %9u task slots, %9u live; by size 16..1:", names[0], a.phase, ntasks, c[34]);
+        for (int b = 16; b >= 1; --b) std::fprintf(stderr, " %u", c[b]);
+        std::fprintf(stderr, "\n");
+    }
+#endif
 }
 } // namespace
 

@@ -14,6 +14,7 @@
 // bit-identical for the non-sRGB formats; sRGB goes through powf and is within 1 ulp per step.
 #include "dxtex_kernels.h"
 #include "dxtex_store.h"
+#include "dxtex_formats.h"
 #include <algorithm>
 
 namespace dxtex
@@ -67,6 +68,48 @@ __global__ void __launch_bounds__(256) convert_kernel(ImgView src, ImgView dst, 
     {
         const Texel t = load_texel(src.pixels + uint64_t(y) * src.rowPitch, x, src.format);
         store_texel(dst.pixels + uint64_t(y) * dst.rowPitch, x, dst.format, apply_plan(t, plan), threshold);
+    }
+}
+
+// Four consecutive texels of a row per lane: the source quad arrives in 1-4 sixteen-byte loads (a wavefront reads 1-4 KiB of
+// consecutive bytes per instruction), is decoded / converted / encoded texel by texel with the same load_texel / apply_plan /
+// store_texel as above - on a register image of the quad, every index a compile-time constant - and leaves in 1-4 sixteen-byte
+// stores. Used when a texel is a whole number of dwords on both sides (>= 32 bpp) and rows are 16-byte aligned.
+__device__ __forceinline__ void load_quad(uint32_t (&q)[16], const uint8_t* p, uint32_t bytes)
+{
+    const uint4* v = reinterpret_cast<const uint4*>(p);
+    { const uint4 a = v[0]; q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; }
+    if (bytes >= 32u) { const uint4 a = v[1]; q[4] = a.x; q[5] = a.y; q[6] = a.z; q[7] = a.w; }
+    if (bytes >= 48u) { const uint4 a = v[2]; q[8] = a.x; q[9] = a.y; q[10] = a.z; q[11] = a.w; }
+    if (bytes >= 64u) { const uint4 a = v[3]; q[12] = a.x; q[13] = a.y; q[14] = a.z; q[15] = a.w; }
+}
+
+__device__ __forceinline__ void store_quad(uint8_t* p, const uint32_t (&q)[16], uint32_t bytes)
+{
+    uint4* v = reinterpret_cast<uint4*>(p);
+    v[0] = make_uint4(q[0], q[1], q[2], q[3]);
+    if (bytes >= 32u) v[1] = make_uint4(q[4], q[5], q[6], q[7]);
+    if (bytes >= 48u) v[2] = make_uint4(q[8], q[9], q[10], q[11]);
+    if (bytes >= 64u) v[3] = make_uint4(q[12], q[13], q[14], q[15]);
+}
+
+__global__ void __launch_bounds__(256) convert_quad_kernel(ImgView src, ImgView dst, ConvertPlan plan, float threshold, uint32_t srcQuadBytes, uint32_t dstQuadBytes)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q * 4u >= src.width) return;
+    for (uint32_t y = blockIdx.y; y < src.height; y += gridDim.y)
+    {
+        uint32_t in[16], out[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { in[k] = 0u; out[k] = 0u; }
+        load_quad(in, src.pixels + uint64_t(y) * src.rowPitch + uint64_t(q) * srcQuadBytes, srcQuadBytes);
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+        {
+            const Texel t = load_texel(reinterpret_cast<const uint8_t*>(in), k, src.format);
+            store_texel(reinterpret_cast<uint8_t*>(out), k, dst.format, apply_plan(t, plan), threshold);
+        }
+        store_quad(dst.pixels + uint64_t(y) * dst.rowPitch + uint64_t(q) * dstQuadBytes, out, dstQuadBytes);
     }
 }
 
@@ -675,6 +718,21 @@ hipError_t launch_convert(const uint8_t* src, uint64_t srcPitch, int srcFormat, 
                           uint32_t width, uint32_t height, const ConvertPlan& plan, float threshold, hipStream_t stream)
 {
     if (!width || !height) return hipSuccess;
+    const FmtInfo* in = format_info(srcFormat);
+    const FmtInfo* out = format_info(dstFormat);
+    // four texels per lane through 16-byte loads / stores where a texel is a whole number of dwords on both sides and rows are 16-byte aligned
+    if (in && out && in->bpp >= 32 && out->bpp >= 32 && (in->bpp % 32) == 0 && (out->bpp % 32) == 0 && (width % 4u) == 0 &&
+        ((reinterpret_cast<uintptr_t>(src) | srcPitch | reinterpret_cast<uintptr_t>(dst) | dstPitch) & 15u) == 0)
+    {
+        const uint32_t quads = width / 4u;
+        const uint32_t gx = (quads + 255u) / 256u;
+        // rows per workgroup column: enough workgroups to fill 256 CUs several times over, few enough that each lane streams several quads
+        const uint32_t gy = std::min<uint32_t>(height, std::max<uint32_t>(1u, 8192u / gx));
+        hipLaunchKernelGGL(convert_quad_kernel, dim3(gx, gy), dim3(256), 0, stream,
+                           make_view(src, srcPitch, width, height, srcFormat), make_view(dst, dstPitch, width, height, dstFormat), plan, threshold,
+                           uint32_t(in->bpp / 8u) * 4u, uint32_t(out->bpp / 8u) * 4u);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(convert_kernel, dim3((width + 255) / 256, grid_rows(height)), dim3(256), 0, stream,
                        make_view(src, srcPitch, width, height, srcFormat), make_view(dst, dstPitch, width, height, dstFormat), plan, threshold);
     return hipGetLastError();

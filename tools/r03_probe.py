@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""DEVELOPMENT TOOL: per-kernel times of one 4096^2 BC7 encode (the context's hipEvent marks) and wall time of the small kernels, for
+A/B runs of development knobs: `DXTEX_AMD_LIBRARY=dev DXTEX_...=... python tools/r03_probe.py [bc7] [convert] [bc15] [decode]`."""
+import ctypes, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import directxtex_amd as dx
+from directxtex_amd import synth
+
+what = set(sys.argv[1:]) or {"bc7"}
+ctx = dx.Context(0); dev = torch.device("cuda", 0)
+ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+W = H = 4096
+img = synth.survey_rgba8(W, H, 2, "opaque")
+src = torch.from_numpy(img).to(dev)
+
+
+def timed(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(n): fn()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n)
+    return best * 1e3
+
+
+if "bc7" in what:
+    dst = torch.empty(dx.compute_pitch(98, W, H)[1], dtype=torch.uint8, device=dev)
+    f = lambda: ctx.compress_device(src.data_ptr(), W, H, 28, dst.data_ptr(), 98, 0, 0.5)
+    print("bc7 4096^2: %.3f ms per image (wall, 3 images)" % timed(f, 3))
+    ctx.profile_begin(); f(); k = ctx.profile_end()
+    tot = sum(ms for ms, n in k.values())
+    print("  serial kernel sum %.2f ms" % tot)
+    for name, (ms, n) in sorted(k.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("PROBE_TOP", "14"))]:
+        print("  %-40s %8.3f ms x%d" % (name, ms / n, n))
+    import hashlib
+    print("  payload sha256", hashlib.sha256(dst.cpu().numpy().tobytes()).hexdigest()[:16])
+if "convert" in what:
+    for sf, df, sb, db in ((28, 10, 4, 8), (10, 28, 8, 4), (28, 2, 4, 16), (28, 87, 4, 4), (2, 10, 16, 8)):
+        s = torch.zeros(W * H * sb, dtype=torch.uint8, device=dev); s[:W * H * 4] = src.reshape(-1)[:W * H * 4]
+        d = torch.empty(W * H * db, dtype=torch.uint8, device=dev)
+        si = dx.capi.device_image(s.data_ptr(), W, H, sf); di = dx.capi.device_image(d.data_ptr(), W, H, df)
+        ms = timed(lambda: ctx._check(dx.capi._lib.dxtex_convert_device(ctx._h, ctypes.byref(si), ctypes.byref(di), 0, 0.5), "convert"))
+        print("convert %3d -> %3d 4096^2: %.4f ms = %.2f TB/s algorithmic" % (sf, df, ms, W * H * (sb + db) / ms / 1e9))
+if "bc15" in what:
+    for fmt, bpt in ((71, 4.5), (74, 5), (77, 5), (80, 4.5), (83, 5)):
+        dst = torch.empty(dx.compute_pitch(fmt, W, H)[1], dtype=torch.uint8, device=dev)
+        ms = timed(lambda: ctx.compress_device(src.data_ptr(), W, H, 28, dst.data_ptr(), fmt, 0, 0.5))
+        print("bc format %d 4096^2: %.4f ms = %.2f TB/s algorithmic" % (fmt, ms, W * H * bpt / ms / 1e9))
+if "decode" in what:
+    back = torch.empty(W * H * 4, dtype=torch.uint8, device=dev)
+    for fmt in (71, 77, 83, 98):
+        dst = torch.empty(dx.compute_pitch(fmt, W, H)[1], dtype=torch.uint8, device=dev)
+        ctx.compress_device(src.data_ptr(), W, H, 28, dst.data_ptr(), fmt, dx.TEX_COMPRESS_BC7_QUICK if fmt == 98 else 0, 0.5)
+        ms = timed(lambda: ctx.decompress_device(dst.data_ptr(), W, H, fmt, back.data_ptr(), 28))
+        print("decode %d -> RGBA8 4096^2: %.4f ms" % (fmt, ms))
+ctx.close()
