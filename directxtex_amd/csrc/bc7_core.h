@@ -67,6 +67,33 @@ DXTEX_HD uint32_t udot4(uint32_t a, uint32_t b)
 #endif
 }
 
+// 24-bit multiplies. Everything the palette arithmetic multiplies is a byte, a weight <= 64 or two bytes 16 bits apart - but the
+// compiler cannot see that and emits full 32-bit multiplies (v_mul_lo_u32, v_mad_u64_u32: quarter rate on gfx950, ~16 issue cycles
+// per wave64 against 4 for v_mul_u32_u24 / v_mad_i32_i24). Spelling the width out took ~100 cycles off every candidate of the
+// search kernels. Operands must fit 24 bits (signed: 23 bits + sign); the low 32 bits of the product are returned.
+DXTEX_HD uint32_t umul24(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
+DXTEX_HD int mul24(int a, int b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
+// One interpolated byte of LDRColorA::Interpolate (:384-416): (ua (64 - w) + ub w + 32) >> 6 = (64 ua + 32 + w (ub - ua)) >> 6.
+// lerp_base / lerp_delta are per candidate, lerp1 is one v_mad_i32_i24 (w is an inline constant) and a shift per entry; the
+// result is <= 255 without masking.
+DXTEX_HD int lerp_base(uint32_t ua) { return int(ua << 6) + 32; }
+DXTEX_HD int lerp_delta(uint32_t ua, uint32_t ub) { return int(ub) - int(ua); }
+DXTEX_HD uint32_t lerp1(int base64, int delta, int w) { return uint32_t(mul24(delta, w) + base64) >> 6; }
+
 DXTEX_HD uint32_t byte_of(uint32_t v, int ch) { return (v >> (8 * ch)) & 0xFFu; }
 DXTEX_HD uint32_t with_byte(uint32_t v, int ch, uint32_t b) { return (v & ~(0xFFu << (8 * ch))) | (b << (8 * ch)); }
 
@@ -105,8 +132,8 @@ DXTEX_HD uint32_t lerp_bytes(uint32_t a, uint32_t b, int w)
 {
     const uint32_t arb = a & 0x00FF00FFu, aga = (a >> 8) & 0x00FF00FFu;
     const uint32_t brb = b & 0x00FF00FFu, bga = (b >> 8) & 0x00FF00FFu;
-    const uint32_t rb = ((arb * uint32_t(64 - w) + brb * uint32_t(w) + 0x00200020u) >> 6) & 0x00FF00FFu;
-    const uint32_t ga = ((aga * uint32_t(64 - w) + bga * uint32_t(w) + 0x00200020u) >> 6) & 0x00FF00FFu;
+    const uint32_t rb = ((umul24(arb, uint32_t(64 - w)) + umul24(brb, uint32_t(w)) + 0x00200020u) >> 6) & 0x00FF00FFu;
+    const uint32_t ga = ((umul24(aga, uint32_t(64 - w)) + umul24(bga, uint32_t(w)) + 0x00200020u) >> 6) & 0x00FF00FFu;
     return rb | (ga << 8);
 }
 
@@ -286,7 +313,7 @@ DXTEX_HD int map_colors(const RG& rg, uint32_t epA, uint32_t epB)
 #pragma unroll
         for (int i = 0; i < PB::NA; ++i)
         {
-            pa[i] = (a0 * (64 - weight(PB::AB, i)) + a1 * weight(PB::AB, i) + 32) >> 6;
+            pa[i] = int(lerp1(lerp_base(uint32_t(a0)), a1 - a0, weight(PB::AB, i)));
             npa2[i] = -(pa[i] * pa[i]);
         }
         for_texels(rg, [&](int k)
@@ -330,7 +357,7 @@ DXTEX_HD int assign_indices(const RG& rg, uint32_t& epA, uint32_t& epB, uint32_t
         const int a0 = int(ua >> 24), a1 = int(ub >> 24);
 #pragma unroll
         for (int i = 0; i < PB::NA; ++i)
-            pa[i] = (a0 * (64 - weight(PB::AB, i)) + a1 * weight(PB::AB, i) + 32) >> 6;
+            pa[i] = int(lerp1(lerp_base(uint32_t(a0)), a1 - a0, weight(PB::AB, i)));
     }
 
     for_texels(rg, [&](int k)
@@ -624,18 +651,19 @@ DXTEX_HD int eval_var(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& v
     if (C::kAlpha)
     {
         int pa[C::N], npa2[C::N];
+        const int lb64 = lerp_base(uaC), ld = lerp_delta(uaC, ubC);
 #pragma unroll
         for (int i = 0; i < C::N; ++i)
         {
-            pa[i] = int(((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6) & 0xFFu);
-            npa2[i] = -(pa[i] * pa[i]);
+            pa[i] = int(lerp1(lb64, ld, weight(C::BITS, i)));
+            npa2[i] = -mul24(pa[i], pa[i]);
         }
         for_texels(rg, [&](int k)
         {
             const int al2 = int((rg.fetch(k) >> 23) & 0x1FEu);
             int su[C::N];
 #pragma unroll
-            for (int i = 0; i < C::N; ++i) su[i] = al2 * pa[i] + npa2[i];
+            for (int i = 0; i < C::N; ++i) su[i] = mul24(al2, pa[i]) + npa2[i];
             total -= first_peak(su);
         });
     }
@@ -643,12 +671,13 @@ DXTEX_HD int eval_var(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& v
     {
         uint32_t pal[C::N], nq2[C::N];
         const int sh = 8 * ch;
+        const int lb64 = lerp_base(uaC), ld = lerp_delta(uaC, ubC);
 #pragma unroll
         for (int i = 0; i < C::N; ++i)
         {
-            const uint32_t v = ((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6) & 0xFFu;
+            const uint32_t v = lerp1(lb64, ld, weight(C::BITS, i));
             pal[i] = vp.palO[i] | (v << sh);
-            nq2[i] = vp.nq2O[i] - v * v;
+            nq2[i] = vp.nq2O[i] - umul24(v, v);
         }
         for_texels(rg, [&](int k)
         {
@@ -681,19 +710,20 @@ DXTEX_HD int eval_var_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>:
     if (C::kAlpha)
     {
         int pa[C::N], npa2[C::N];
+        const int lb64 = lerp_base(uaC), ld = lerp_delta(uaC, ubC);
 #pragma unroll
         for (int i = 0; i < C::N; ++i)
         {
-            pa[i] = int(((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6) & 0xFFu);
-            npa2[i] = -(pa[i] * pa[i]);
+            pa[i] = int(lerp1(lb64, ld, weight(C::BITS, i)));
+            npa2[i] = -mul24(pa[i], pa[i]);
         }
         int total = base;
         for_texels(rg, [&](int k)
         {
             const int al2 = int((rg.fetch(k) >> 23) & 0x1FEu);
-            int m = al2 * pa[0] + npa2[0];
+            int m = mul24(al2, pa[0]) + npa2[0];
 #pragma unroll
-            for (int i = 1; i < C::N; ++i) { const int su = al2 * pa[i] + npa2[i]; m = su > m ? su : m; }
+            for (int i = 1; i < C::N; ++i) { const int su = mul24(al2, pa[i]) + npa2[i]; m = su > m ? su : m; }
             total -= m;
         });
         return total;
@@ -702,12 +732,13 @@ DXTEX_HD int eval_var_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>:
     {
         uint32_t pal[C::N], acc[C::N];
         const int sh = 8 * ch;
+        const int lb64 = lerp_base(uaC), ld = lerp_delta(uaC, ubC);
 #pragma unroll
         for (int i = 0; i < C::N; ++i)
         {
-            const uint32_t v = ((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6) & 0xFFu;
+            const uint32_t v = lerp1(lb64, ld, weight(C::BITS, i));
             pal[i] = vp.palO[i] | (v << sh);
-            acc[i] = uint32_t(int(vp.nq2O[i] - v * v) >> 1);        // floor(-|q|^2 / 2)
+            acc[i] = uint32_t(int(vp.nq2O[i] - umul24(v, v)) >> 1);        // floor(-|q|^2 / 2)
         }
         int sum = 0;
         for_texels(rg, [&](int k)
@@ -757,7 +788,7 @@ DXTEX_HD int alpha_part_error(const RG& rg, uint32_t epA, uint32_t epB)
     int pa[NA];
     const int a0 = int(ua >> 24), a1 = int(ub >> 24);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) pa[i] = (a0 * (64 - weight(AB, i)) + a1 * weight(AB, i) + 32) >> 6;
+    for (int i = 0; i < NA; ++i) pa[i] = int(lerp1(lerp_base(uint32_t(a0)), a1 - a0, weight(AB, i)));
     int total = 0;
     for_texels(rg, [&](int k)
     {
@@ -1057,12 +1088,12 @@ DXTEX_HD int exh_window_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET
     const uint32_t uoL = unq1<C::PREC>(uint32_t(oLo)), uoH = unq1<C::PREC>(uint32_t(oHi)), uiL = unq1<C::PREC>(uint32_t(iLo)), uiH = unq1<C::PREC>(uint32_t(iHi));
     const uint32_t aL = s.aleb ? uoL : uiL, bL = s.aleb ? uiL : uoL, aH = s.aleb ? uoH : uiH, bH = s.aleb ? uiH : uoH;
     int lo[C::N], hi[C::N];
+    const int lbL = lerp_base(aL), ldL = lerp_delta(aL, bL), lbH = lerp_base(aH), ldH = lerp_delta(aH, bH);
 #pragma unroll
     for (int i = 0; i < C::N; ++i)
     {
-        const uint32_t w = uint32_t(weight(C::BITS, i));
-        lo[i] = int(((aL * (64u - w) + bL * w + 32u) >> 6) & 0xFFu);
-        hi[i] = int(((aH * (64u - w) + bH * w + 32u) >> 6) & 0xFFu);
+        lo[i] = int(lerp1(lbL, ldL, weight(C::BITS, i)));
+        hi[i] = int(lerp1(lbH, ldH, weight(C::BITS, i)));
     }
     if (C::kAlpha)
     {
@@ -1077,9 +1108,10 @@ DXTEX_HD int exh_window_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET
             {
                 const int c = al < lo[i] ? lo[i] : (al > hi[i] ? hi[i] : al);
                 const int d = al - c;
-                d2 = d * d < d2 ? d * d : d2;
+                const int dd = mul24(d, d);
+                d2 = dd < d2 ? dd : d2;
             }
-            sumA += al * al - d2;
+            sumA += mul24(al, al) - d2;
         });
         return base - sumA;
     }
@@ -1097,10 +1129,10 @@ DXTEX_HD int exh_window_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET
             // vp.palO has the searched channel blanked, so the score below is the other channels' 2 p.q - |q|^2
             const int c = pc < lo[i] ? lo[i] : (pc > hi[i] ? hi[i] : pc);
             const int dc = pc - c;
-            const int t = score(p, vp.palO[i], vp.nq2O[i]) - dc * dc;
+            const int t = score(p, vp.palO[i], vp.nq2O[i]) - mul24(dc, dc);
             m = t > m ? t : m;
         }
-        sum += m + pc * pc;
+        sum += m + mul24(pc, pc);
     });
     return base - sum;
 }
@@ -1495,7 +1527,7 @@ DXTEX_HD int rough_error(const RG& rg, uint32_t epA, uint32_t epB)
     {
         const int a0 = int(epA >> 24), a1 = int(epB >> 24);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) pa[i] = (a0 * (64 - weight(AB ? AB : 2, i)) + a1 * weight(AB ? AB : 2, i) + 32) >> 6;
+        for (int i = 0; i < NA; ++i) pa[i] = int(lerp1(lerp_base(uint32_t(a0)), a1 - a0, weight(AB ? AB : 2, i)));
     }
     for_texels(rg, [&](int k)
     {

@@ -560,12 +560,13 @@ __global__ void __launch_bounds__(64) bc7_perturb_filter_kernel(Bc7Args a, int l
             const uint32_t u = unq1<C::PREC>(uint32_t(tmp) & ((1u << C::PREC) - 1u));
             const uint32_t uaC = st.do_b ? fixedU : u, ubC = st.do_b ? u : fixedU;
             uint32_t pal[N], nq2[N];
+            const int lb64 = lerp_base(uaC), ld = lerp_delta(uaC, ubC);
 #pragma unroll
             for (int i = 0; i < N; ++i)
             {
-                const uint32_t v = ((uaC * uint32_t(64 - weight(C::BITS, i)) + ubC * uint32_t(weight(C::BITS, i)) + 32u) >> 6) & 0xFFu;
+                const uint32_t v = lerp1(lb64, ld, weight(C::BITS, i));
                 pal[i] = vp.palO[i] | (v << sh);
-                nq2[i] = vp.nq2O[i] - v * v;
+                nq2[i] = vp.nq2O[i] - umul24(v, v);
             }
             int sum = 0;
             for_texels(rg, [&](int k)

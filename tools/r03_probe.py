@@ -36,7 +36,10 @@ if "bc7" in what:
     for name, (ms, n) in sorted(k.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("PROBE_TOP", "14"))]:
         print("  %-40s %8.3f ms x%d" % (name, ms / n, n))
     import hashlib
-    print("  payload sha256", hashlib.sha256(dst.cpu().numpy().tobytes()).hexdigest()[:16])
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["cases"]["cfg2_bc7_4096"]["sha256"]
+    sha = hashlib.sha256(dst.cpu().numpy().tobytes()).hexdigest()
+    print("  payload sha256", sha[:16], "IDENTICAL to the reference golden" if sha == gold else "DIFFERS from the reference golden")
 if "convert" in what:
     for sf, df, sb, db in ((28, 10, 4, 8), (10, 28, 8, 4), (28, 2, 4, 16), (28, 87, 4, 4), (2, 10, 16, 8)):
         s = torch.zeros(W * H * sb, dtype=torch.uint8, device=dev); s[:W * H * 4] = src.reshape(-1)[:W * H * 4]
