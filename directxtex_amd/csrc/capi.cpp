@@ -866,8 +866,26 @@ dxtex_hresult submit_resizes(dxtex_ctx* ctx, const std::vector<LevelPair>& pairs
         return DXTEX_S_OK;
     }
     const LevelPair* twoHigh = nullptr;      // box mips: the last source level that was 2 texels high (resize_box_kernel's stale tap)
-    for (const LevelPair& p : pairs)
+    for (size_t i = 0; i < pairs.size(); ++i)
     {
+        const LevelPair& p = pairs[i];
+        // a mip chain's last levels (source at most 64 x 64, each level the next one's source) run in one workgroup
+        if (mipAlias && pairs.size() - i >= 2 && resize_tail_applies(uint32_t(p.sw), uint32_t(p.sh), mode))
+        {
+            bool chain = true;
+            for (size_t k = i + 1; k < pairs.size(); ++k) chain = chain && pairs[k].src == pairs[k - 1].dst && pairs[k].srcPitch == pairs[k - 1].dstPitch;
+            if (chain)
+            {
+                std::vector<MipLevel> lv;
+                lv.push_back({ const_cast<uint8_t*>(p.src), p.srcPitch, uint32_t(p.sw), uint32_t(p.sh) });
+                for (size_t k = i; k < pairs.size(); ++k) lv.push_back({ pairs[k].dst, pairs[k].dstPitch, uint32_t(pairs[k].dw), uint32_t(pairs[k].dh) });
+                MipLevel th = { nullptr, 0, 0, 0 };
+                if (twoHigh) th = { const_cast<uint8_t*>(twoHigh->src), twoHigh->srcPitch, uint32_t(twoHigh->sw), uint32_t(twoHigh->sh) };
+                const hipError_t e = launch_resize_tail(lv.data(), int(lv.size()), format, mode, flags, twoHigh ? &th : nullptr, ctx->stream);
+                if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+                return DXTEX_S_OK;
+            }
+        }
         if (mipAlias && p.sh >= 2) twoHigh = &p;
         const bool stale = mipAlias && mode == DXTEX_FILTER_BOX && p.sh == 1 && p.sw > 1 && twoHigh;
         hipError_t e = launch_resize(p.src, p.srcPitch, uint32_t(p.sw), uint32_t(p.sh), p.dst, p.dstPitch, uint32_t(p.dw), uint32_t(p.dh),

@@ -55,6 +55,14 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
                          const TriangleTables* tri, hipStream_t stream,
                          const uint8_t* staleLevel = nullptr, uint64_t stalePitch = 0, uint32_t staleW = 0);
 
+// The tail of a 2-D mip chain (levels[0] = the first source level, at most 64 x 64; levels[1..] = the levels generated from it) in one
+// workgroup: point / linear / cubic / box, the arithmetic of launch_resize with mipAlias. twoHigh = the last level of the chain before
+// levels[0] that was at least 2 texels high (the box filter's stale tap, see resize_box_kernel), or nullptr.
+struct MipLevel { uint8_t* pixels; uint64_t pitch; uint32_t width, height; };
+bool resize_tail_applies(uint32_t srcW, uint32_t srcH, uint32_t filterMode);
+hipError_t launch_resize_tail(const MipLevel* levels, int nlevels, int format, uint32_t filterMode, uint32_t filterFlags,
+                              const MipLevel* twoHigh, hipStream_t stream);
+
 // Volume mips (Generate3DMips*Filter): one level whose source is more than one slice deep. Slices of a level are `slicePitch` apart.
 struct VolumeView { const uint8_t* pixels; uint64_t rowPitch, slicePitch; uint32_t width, height, depth; int format; };
 struct TriangleTables3 { const uint32_t* ofsX; const void* entX; const uint32_t* ofsY; const void* entY; const uint32_t* ofsZ; const void* entZ; };

@@ -75,41 +75,62 @@ __global__ void __launch_bounds__(256) convert_kernel(ImgView src, ImgView dst, 
 // consecutive bytes per instruction), is decoded / converted / encoded texel by texel with the same load_texel / apply_plan /
 // store_texel as above - on a register image of the quad, every index a compile-time constant - and leaves in 1-4 sixteen-byte
 // stores. Used when a texel is a whole number of dwords on both sides (>= 32 bpp) and rows are 16-byte aligned.
-__device__ __forceinline__ void load_quad(uint32_t (&q)[16], const uint8_t* p, uint32_t bytes)
+template<int W>
+__device__ __forceinline__ void load_quad(uint32_t (&q)[W], const uint8_t* p, uint32_t bytes)
 {
     const uint4* v = reinterpret_cast<const uint4*>(p);
     { const uint4 a = v[0]; q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; }
-    if (bytes >= 32u) { const uint4 a = v[1]; q[4] = a.x; q[5] = a.y; q[6] = a.z; q[7] = a.w; }
-    if (bytes >= 48u) { const uint4 a = v[2]; q[8] = a.x; q[9] = a.y; q[10] = a.z; q[11] = a.w; }
-    if (bytes >= 64u) { const uint4 a = v[3]; q[12] = a.x; q[13] = a.y; q[14] = a.z; q[15] = a.w; }
+    if constexpr (W >= 8) if (bytes >= 32u) { const uint4 a = v[1]; q[4] = a.x; q[5] = a.y; q[6] = a.z; q[7] = a.w; }
+    if constexpr (W >= 12) if (bytes >= 48u) { const uint4 a = v[2]; q[8] = a.x; q[9] = a.y; q[10] = a.z; q[11] = a.w; }
+    if constexpr (W >= 16) if (bytes >= 64u) { const uint4 a = v[3]; q[12] = a.x; q[13] = a.y; q[14] = a.z; q[15] = a.w; }
 }
 
-__device__ __forceinline__ void store_quad(uint8_t* p, const uint32_t (&q)[16], uint32_t bytes)
+template<int W>
+__device__ __forceinline__ void store_quad(uint8_t* p, const uint32_t (&q)[W], uint32_t bytes)
 {
     uint4* v = reinterpret_cast<uint4*>(p);
     v[0] = make_uint4(q[0], q[1], q[2], q[3]);
-    if (bytes >= 32u) v[1] = make_uint4(q[4], q[5], q[6], q[7]);
-    if (bytes >= 48u) v[2] = make_uint4(q[8], q[9], q[10], q[11]);
-    if (bytes >= 64u) v[3] = make_uint4(q[12], q[13], q[14], q[15]);
+    if constexpr (W >= 8) if (bytes >= 32u) v[1] = make_uint4(q[4], q[5], q[6], q[7]);
+    if constexpr (W >= 12) if (bytes >= 48u) v[2] = make_uint4(q[8], q[9], q[10], q[11]);
+    if constexpr (W >= 16) if (bytes >= 64u) v[3] = make_uint4(q[12], q[13], q[14], q[15]);
 }
 
+// SQ / DQ = bytes of a source / destination quad (16, 32 or 64; 0 = taken from the arguments: the 48-byte R32G32B32 quads).
+// ROWS quads (of consecutive rows, same columns) are loaded before the first is converted, so that a lane keeps 64 bytes of
+// reads in flight: with one 16-byte load per lane the kernel was bound by latency x occupancy (Little's law), not by HBM.
+template<int SQ, int DQ, int ROWS>
 __global__ void __launch_bounds__(256) convert_quad_kernel(ImgView src, ImgView dst, ConvertPlan plan, float threshold, uint32_t srcQuadBytes, uint32_t dstQuadBytes)
 {
     const uint32_t q = blockIdx.x * 256u + threadIdx.x;
     if (q * 4u >= src.width) return;
-    for (uint32_t y = blockIdx.y; y < src.height; y += gridDim.y)
+    const uint32_t sq = SQ ? uint32_t(SQ) : srcQuadBytes, dq = DQ ? uint32_t(DQ) : dstQuadBytes;
+    constexpr int SW = SQ ? SQ / 4 : 16, DW = DQ ? DQ / 4 : 16;
+    for (uint32_t y0 = blockIdx.y * uint32_t(ROWS); y0 < src.height; y0 += gridDim.y * uint32_t(ROWS))
     {
-        uint32_t in[16], out[16];
+        uint32_t in[ROWS][SW];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { in[k] = 0u; out[k] = 0u; }
-        load_quad(in, src.pixels + uint64_t(y) * src.rowPitch + uint64_t(q) * srcQuadBytes, srcQuadBytes);
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k)
+        for (int r = 0; r < ROWS; ++r)
         {
-            const Texel t = load_texel(reinterpret_cast<const uint8_t*>(in), k, src.format);
-            store_texel(reinterpret_cast<uint8_t*>(out), k, dst.format, apply_plan(t, plan), threshold);
+#pragma unroll
+            for (int k = 0; k < SW; ++k) in[r][k] = 0u;
+            const uint32_t y = min(y0 + uint32_t(r), src.height - 1u);       // a short last group re-reads the last row (and does not store it)
+            load_quad<SW>(in[r], src.pixels + uint64_t(y) * src.rowPitch + uint64_t(q) * sq, sq);
         }
-        store_quad(dst.pixels + uint64_t(y) * dst.rowPitch + uint64_t(q) * dstQuadBytes, out, dstQuadBytes);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+        {
+            uint32_t out[DW];
+#pragma unroll
+            for (int k = 0; k < DW; ++k) out[k] = 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+            {
+                const Texel t = load_texel(reinterpret_cast<const uint8_t*>(in[r]), k, src.format);
+                store_texel(reinterpret_cast<uint8_t*>(out), k, dst.format, apply_plan(t, plan), threshold);
+            }
+            if (y0 + uint32_t(r) < src.height)
+                store_quad<DW>(dst.pixels + uint64_t(y0 + uint32_t(r)) * dst.rowPitch + uint64_t(q) * dq, out, dq);
+        }
     }
 }
 
@@ -510,6 +531,48 @@ struct Resize3Args
     const uint32_t* triOfsZ; const uint2* triZ;
 };
 
+// ---- the tail of a mip chain in ONE workgroup --------------------------------------------------------------------------------
+// The last levels of a chain are a few thousand texels each: a launch per level costs ~5 us of dispatch latency for ~1 us of
+// work (ten such launches were 40 % of the 8192^2 box chain). From the first level whose source is at most kTailSide texels on a
+// side, one workgroup of 1024 lanes walks the remaining levels, a workgroup barrier (with its release / acquire fences on global
+// memory) between levels: level n + 1 reads what the same workgroup stored for level n, exactly as the per-level launches do.
+constexpr uint32_t kTailSide = 64;
+constexpr int kTailMaxLevels = 8;
+struct TailArgs
+{
+    ResizeArgs a;                       // flags; src = the first source level; stale as launch_resize sets it up
+    ImgView level[kTailMaxLevels];      // the destination levels, in order
+    int nlevels;
+    uint32_t mode;                      // TEX_FILTER_POINT / LINEAR / CUBIC / BOX
+    ImgView twoHigh;                    // box: the last level of the whole chain that was 2 texels high BEFORE the tail (or null)
+};
+
+__global__ void __launch_bounds__(1024) resize_tail_kernel(TailArgs t)
+{
+    ResizeArgs a = t.a;
+    ImgView twoHigh = t.twoHigh;
+    for (int l = 0; l < t.nlevels; ++l)
+    {
+        a.dst = t.level[l];
+        if (a.mipAlias && a.src.height >= 2u) twoHigh = a.src;              // submit_resizes' bookkeeping of the stale tap
+        a.stale = (a.mipAlias && t.mode == 0x400000u && a.src.height == 1u && a.src.width > 1u && twoHigh.pixels) ? twoHigh : ImgView{ nullptr, 0, 0, 2, a.src.format };
+        const uint32_t n = a.dst.width * a.dst.height;
+        for (uint32_t i = threadIdx.x; i < n; i += 1024u)
+        {
+            const uint32_t y = i / a.dst.width, x = i - y * a.dst.width;
+            switch (t.mode)
+            {
+            case 0x100000u: resize_point_kernel_row(a, x, y); break;
+            case 0x200000u: resize_linear_kernel_row(a, x, y); break;
+            case 0x300000u: resize_cubic_kernel_row(a, x, y); break;
+            default: resize_box_kernel_row(a, x, y); break;
+            }
+        }
+        __syncthreads();                                                     // level l is complete and visible to the whole workgroup
+        a.src = a.dst;
+    }
+}
+
 __device__ __forceinline__ ImgView slice_of(const Vol& v, uint32_t z)
 {
     ImgView s; s.pixels = v.pixels + uint64_t(z) * v.slicePitch; s.rowPitch = v.rowPitch; s.width = v.width; s.height = v.height; s.format = v.format;
@@ -726,11 +789,22 @@ hipError_t launch_convert(const uint8_t* src, uint64_t srcPitch, int srcFormat, 
     {
         const uint32_t quads = width / 4u;
         const uint32_t gx = (quads + 255u) / 256u;
-        // rows per workgroup column: enough workgroups to fill 256 CUs several times over, few enough that each lane streams several quads
-        const uint32_t gy = std::min<uint32_t>(height, std::max<uint32_t>(1u, 8192u / gx));
-        hipLaunchKernelGGL(convert_quad_kernel, dim3(gx, gy), dim3(256), 0, stream,
-                           make_view(src, srcPitch, width, height, srcFormat), make_view(dst, dstPitch, width, height, dstFormat), plan, threshold,
-                           uint32_t(in->bpp / 8u) * 4u, uint32_t(out->bpp / 8u) * 4u);
+        const uint32_t sq = uint32_t(in->bpp / 8u) * 4u, dq = uint32_t(out->bpp / 8u) * 4u;
+        const ImgView sv = make_view(src, srcPitch, width, height, srcFormat), dv = make_view(dst, dstPitch, width, height, dstFormat);
+        // row groups per workgroup column: enough workgroups to fill 256 CUs several times over, few enough that a lane streams several groups
+#define DXTEX_QUAD(SQ, DQ, ROWS) do { const uint32_t groups = (height + (ROWS) - 1u) / (ROWS); \
+            const uint32_t gy = std::min<uint32_t>(groups, std::max<uint32_t>(1u, 8192u / gx)); \
+            hipLaunchKernelGGL((convert_quad_kernel<SQ, DQ, ROWS>), dim3(gx, gy), dim3(256), 0, stream, sv, dv, plan, threshold, sq, dq); } while (0)
+        if (sq == 16u && dq == 16u) DXTEX_QUAD(16, 16, 4);
+        else if (sq == 16u && dq == 32u) DXTEX_QUAD(16, 32, 4);
+        else if (sq == 16u && dq == 64u) DXTEX_QUAD(16, 64, 4);
+        else if (sq == 32u && dq == 16u) DXTEX_QUAD(32, 16, 2);
+        else if (sq == 32u && dq == 32u) DXTEX_QUAD(32, 32, 2);
+        else if (sq == 32u && dq == 64u) DXTEX_QUAD(32, 64, 2);
+        else if (sq == 64u && dq == 16u) DXTEX_QUAD(64, 16, 1);
+        else if (sq == 64u && dq == 32u) DXTEX_QUAD(64, 32, 1);
+        else DXTEX_QUAD(0, 0, 1);
+#undef DXTEX_QUAD
         return hipGetLastError();
     }
     hipLaunchKernelGGL(convert_kernel, dim3((width + 255) / 256, grid_rows(height)), dim3(256), 0, stream,
@@ -780,6 +854,42 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+hipError_t launch_resize_tail(const MipLevel* levels, int nlevels, int format, uint32_t filterMode, uint32_t filterFlags,
+                              const MipLevel* twoHigh, hipStream_t stream)
+{
+    if (nlevels < 2) return hipSuccess;
+    TailArgs t;
+    ResizeArgs& a = t.a;
+    a.stale = make_view(nullptr, 0, 0, 2, format);
+    a.src = make_view(levels[0].pixels, levels[0].pitch, levels[0].width, levels[0].height, format);
+    a.dst = a.src;
+    const bool wantIn = srgb_linear_format(format) || (filterFlags & 0x1000000u), wantOut = srgb_linear_format(format) || (filterFlags & 0x2000000u);
+    a.srgbIn = (can_srgb(format) && wantIn) ? 1 : 0;
+    a.srgbOut = (can_srgb(format) && wantOut) ? 1 : 0;
+    a.wrapU = (filterFlags & 0x1u) != 0; a.wrapV = (filterFlags & 0x2u) != 0;
+    a.mirrorU = (filterFlags & 0x10u) != 0; a.mirrorV = (filterFlags & 0x20u) != 0;
+    a.mipAlias = 1;
+    a.triOfsX = nullptr; a.triX = nullptr; a.triOfsY = nullptr; a.triY = nullptr;
+    t.mode = filterMode;
+    t.twoHigh = twoHigh ? make_view(twoHigh->pixels, twoHigh->pitch, twoHigh->width, twoHigh->height, format) : make_view(nullptr, 0, 0, 2, format);
+    for (int at = 1; at < nlevels; )
+    {
+        t.nlevels = std::min(kTailMaxLevels, nlevels - at);
+        for (int k = 0; k < t.nlevels; ++k) t.level[k] = make_view(levels[at + k].pixels, levels[at + k].pitch, levels[at + k].width, levels[at + k].height, format);
+        for (int k = t.nlevels; k < kTailMaxLevels; ++k) t.level[k] = t.level[0];
+        hipLaunchKernelGGL(resize_tail_kernel, dim3(1), dim3(1024), 0, stream, t);
+        // a chain with more than kTailMaxLevels tail levels (cannot happen below 64 x 64, kept for safety) continues from the last one written
+        a.src = t.level[t.nlevels - 1];
+        at += t.nlevels;
+    }
+    return hipGetLastError();
+}
+
+bool resize_tail_applies(uint32_t srcW, uint32_t srcH, uint32_t filterMode)
+{
+    return srcW <= kTailSide && srcH <= kTailSide && (filterMode == 0x100000u || filterMode == 0x200000u || filterMode == 0x300000u || filterMode == 0x400000u);
 }
 
 hipError_t launch_pmalpha(const uint8_t* src, uint64_t srcPitch, uint8_t* dst, uint64_t dstPitch, int format, uint32_t width, uint32_t height,
