@@ -85,10 +85,28 @@ DXTEX_HD6 int unquantize(int comp, int bits, bool isSigned)
     return unq;
 }
 
+// 24-bit multiply (operands here are at most 18 bits): v_mul_i32_i24 instead of the quarter-rate v_mul_lo_u32 the compiler emits when
+// it cannot see the operand range.
+DXTEX_HD6 int mul24i(int a, int b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
+
 DXTEX_HD6 int finish_unquantize(int comp, bool isSigned)
 {
-    if (isSigned) return (comp < 0) ? -(((-comp) * 31) >> 5) : (comp * 31) >> 5;
-    return (comp * 31) >> 6;
+    // (:1930-1940) the signed form works on the magnitude; written with selects - a per-lane branch here sat in the innermost
+    // palette loop of the search kernels
+    if (isSigned)
+    {
+        const int a = (comp < 0) ? -comp : comp;
+        const int r = mul24i(a, 31) >> 5;
+        return (comp < 0) ? -r : r;
+    }
+    return mul24i(comp, 31) >> 6;
 }
 
 } // namespace bc6h
@@ -183,11 +201,13 @@ template<int N>
 DXTEX_HD6 void palette_channel(int qa, int qb, int prec, bool isSigned, float (&out)[N])
 {
     const int ua = unquantize(qa, prec, isSigned), ub = unquantize(qb, prec, isSigned);
+    // (ua (64 - w) + ub w + 32) >> 6 as (64 ua + 32 + w (ub - ua)) >> 6: one 24-bit multiply-add per entry (|ub - ua| < 2^17)
+    const int b64 = ua * 64 + 32, d = ub - ua;
 #pragma unroll
     for (int i = 0; i < N; ++i)
     {
         const int w = weight_of<N>(i);
-        out[i] = float(finish_unquantize((ua * (64 - w) + ub * w + 32) >> 6, isSigned));
+        out[i] = float(finish_unquantize((mul24i(d, w) + b64) >> 6, isSigned));
     }
 }
 

@@ -40,6 +40,23 @@ if "bc7" in what:
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["cases"]["cfg2_bc7_4096"]["sha256"]
     sha = hashlib.sha256(dst.cpu().numpy().tobytes()).hexdigest()
     print("  payload sha256", sha[:16], "IDENTICAL to the reference golden" if sha == gold else "DIFFERS from the reference golden")
+if "bc6h" in what:
+    import hashlib, json
+    hdr = torch.from_numpy(synth.survey_rgba16f(W, H, 3)).to(dev)
+    dst6 = torch.empty(dx.compute_pitch(95, W, H)[1], dtype=torch.uint8, device=dev)
+    f6 = lambda: ctx.compress_device(hdr.data_ptr(), W, H, 10, dst6.data_ptr(), 95, 0, 0.5)
+    print("bc6h 4096^2: %.3f ms per image (wall, 2 images)" % timed(f6, 2))
+    ctx.profile_begin(); f6(); k = ctx.profile_end()
+    agg = {}
+    for name, (ms, n) in k.items():
+        key = name.rstrip("0123456789_") if name.startswith("bc6h_") else name
+        agg[key] = agg.get(key, 0.0) + ms
+    for name, ms in sorted(agg.items(), key=lambda kv: -kv[1])[:10]:
+        print("  %-40s %8.3f ms" % (name, ms))
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["cases"]["cfg3_bc6h_uf16_4096"]["sha256"]
+    sha = hashlib.sha256(dst6.cpu().numpy().tobytes()).hexdigest()
+    print("  payload", "IDENTICAL to the reference golden" if sha == gold else "DIFFERS from the reference golden")
+    del hdr, dst6
 if "convert" in what:
     for sf, df, sb, db in ((28, 10, 4, 8), (10, 28, 8, 4), (28, 2, 4, 16), (28, 87, 4, 4), (2, 10, 16, 8)):
         s = torch.zeros(W * H * sb, dtype=torch.uint8, device=dev); s[:W * H * 4] = src.reshape(-1)[:W * H * 4]
