@@ -55,8 +55,12 @@ struct Bc6hArgs
     Best6* best;
     float* bounds;          // nblocks x 17: region_lower_bound6 of the 8 ranked shapes x 2 regions and of the whole block (the same for every mode)
     int boundsReady;        // 0: this launch computes and stores them, 1: it reads them
+    int samePrec;           // two-region modes: the previous mode had the same endpoint precision and its task arrays are still in place
     ModeRt mode;
 };
+
+// tinfo bit 23: the task was searched by an earlier mode of the same precision (see bc6h_pre_kernel); bits 24.. = subset size, 0..15 = texel mask
+constexpr uint32_t kDoneBit6 = 1u << 23;
 
 __device__ __forceinline__ Texels slot_texels(float* slot /* &sSlot[0][0][lane] */, int np)
 {
@@ -354,11 +358,27 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
         sv.err = o.err; sv.pad = 0; sv.idx = o.idx;
         a.orgs[t] = sv;
     }
-    Rec6 rec;
+    // OptimizeOne's search (:2145-2194) depends on the block, the shape, the region and the endpoint PRECISION - not on the mode's delta
+    // bits, which only decide what fits (EndPointsFit). Modes 11:5:4:4 / 11:4:5:4 / 11:4:4:5 and 8:6:5:5 / 8:5:6:5 / 8:5:5:6 follow each
+    // other in the encoder's order, so a task the previous mode of the same precision already searched (or inherited) keeps the
+    // optimised endpoints it left in recs[] and is not searched again; post scores them against this mode's bit budget as Refine would
+    // (:2395-2424). On the cfg3 image 98 % of the tasks of the second and third 8-bit mode are of that kind (2 x 13.5 ms of search).
+    uint32_t done = 0;
+    if (REGIONS2 && a.samePrec)
+    {
+        const uint32_t prev = a.tinfo[t];
+        if ((prev >> 24) != 0u || (prev & kDoneBit6) != 0u) done = kDoneBit6;
+    }
+    if (done)
+        a.recs[t].valid = o.fit ? 1u : 0u;
+    else
+    {
+        Rec6 rec;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { rec.A[c] = o.ep.A[c]; rec.B[c] = o.ep.B[c]; }
-    rec.err = o.err; rec.valid = o.fit ? 1u : 0u;
-    a.recs[t] = rec;
+        for (int c = 0; c < 3; ++c) { rec.A[c] = o.ep.A[c]; rec.B[c] = o.ep.B[c]; }
+        rec.err = o.err; rec.valid = o.fit ? 1u : 0u;
+        a.recs[t] = rec;
+    }
     // OptimizeEndPoints' quirk (:2215): region 0 is optimised against all sixteen texels. Nothing to search when the
     // candidate does not fit or its error is already 0 (PerturbOne only accepts strictly smaller errors).
     const bool region0 = !REGIONS2 || (r & 1u) == 0;
@@ -367,7 +387,8 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
     if (prune) snp = 0;
     // one-region tasks are sorted by mode slot instead (13 + slot: the 16-bit mode, the longest search, goes first); all have 16 texels
     if (!REGIONS2 && snp) snp = 13u + a.taskBase / a.nblocks;
-    a.tinfo[t] = smask | (snp << 24);
+    if (done) snp = 0;
+    a.tinfo[t] = smask | done | (snp << 24);
 }
 
 template<int REGIONS2>
@@ -401,7 +422,7 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     // still has its unoptimised endpoints: it either cannot win (its lower bound exceeds an error on the table, or it is not
     // encodable) or wins with its unoptimised half (error 0, which nothing beats), so it stands with those numbers. A wavefront
     // whose candidates are all of that kind - most wavefronts of the later modes - skips the second AssignIndices.
-    bool searched = (a.tinfo[t] >> 24) != 0u;
+    bool searched = (a.tinfo[t] >> 24) != 0u || (a.tinfo[t] & kDoneBit6) != 0u;      // by this mode, or by an earlier one of the same precision
     if (REGIONS2) searched = searched || (__shfl_xor(int(searched), 1) != 0);      // the candidate's other region: Refine scores both (:2401-2410)
     uint64_t optIdx = o.idx;
     float optErr = o.err;
@@ -741,20 +762,38 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         a.taskBase = 0;
         for (int m = 0; m < 4; ++m) a.prec1[m] = kModes[10 + m].prec[0];
         // the ten two-region modes, one after the other: pre -> sort -> search -> post (post folds the mode into the running best)
+        int prevPrec = -1;
+        a.samePrec = 0;
         for (int mi = 0; mi < 10; ++mi)
         {
             if (onlyMode >= 0 && mi != onlyMode) continue;
             set_mode(mi);
+            static const bool noReuse = dev_env("DXTEX_BC6H_NO_REUSE") != nullptr;      // development A/B: search every mode from scratch
+            a.samePrec = (!noReuse && prevPrec == kModes[mi].prec[0]) ? 1 : 0;
+            prevPrec = kModes[mi].prec[0];
             const uint32_t ntasks = a.nblocks * 16u;
             const uint32_t gridPP = (a.nblocks + 15) / 16;
-            DXTEX_MARK("bc6h_pre_2region");
+            static const char* const kPre[10] = { "bc6h_pre_m0", "bc6h_pre_m1", "bc6h_pre_m2", "bc6h_pre_m3", "bc6h_pre_m4", "bc6h_pre_m5", "bc6h_pre_m6", "bc6h_pre_m7", "bc6h_pre_m8", "bc6h_pre_m9" };
+            static const char* const kPerturb[10] = { "bc6h_perturb_m0", "bc6h_perturb_m1", "bc6h_perturb_m2", "bc6h_perturb_m3", "bc6h_perturb_m4", "bc6h_perturb_m5", "bc6h_perturb_m6", "bc6h_perturb_m7", "bc6h_perturb_m8", "bc6h_perturb_m9" };
+            static const char* const kPost[10] = { "bc6h_post_m0", "bc6h_post_m1", "bc6h_post_m2", "bc6h_post_m3", "bc6h_post_m4", "bc6h_post_m5", "bc6h_post_m6", "bc6h_post_m7", "bc6h_post_m8", "bc6h_post_m9" };
+            DXTEX_MARK(kPre[mi]);
             hipLaunchKernelGGL(bc6h_pre_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
             a.boundsReady = 1;
             DXTEX_MARK("bc6h_bin_2region");
             sort_tasks(ntasks);
-            DXTEX_MARK("bc6h_perturb_2region");
+#if defined(DXTEX_DEV)
+            static const bool stats6 = dev_env("DXTEX_BC6H_STATS") != nullptr;       // development statistics: tasks that survive pre, per mode
+            if (stats6)
+            {
+                uint32_t c[40] = {};
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(c, a.counters, sizeof(c), hipMemcpyDeviceToHost);
+                std::fprintf(stderr, "bc6h stats mode %d (prec %d): %u task slots, %u live (16-texel: %u)\n", mi, a.mode.prec, ntasks, c[34], c[16]);
+            }
+#endif
+            DXTEX_MARK(kPerturb[mi]);
             if (!noSearch) hipLaunchKernelGGL(bc6h_perturb_kernel<8>, dim3(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64)), dim3(64), 0, stream, a, 0u);
-            DXTEX_MARK("bc6h_post_2region");
+            DXTEX_MARK(kPost[mi]);
             hipLaunchKernelGGL(bc6h_post_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
         }
         // The four one-region modes have ONE task per block each - a long serial chain on one lane - so a search kernel per mode would

@@ -47,12 +47,8 @@ if "bc6h" in what:
     f6 = lambda: ctx.compress_device(hdr.data_ptr(), W, H, 10, dst6.data_ptr(), 95, 0, 0.5)
     print("bc6h 4096^2: %.3f ms per image (wall, 2 images)" % timed(f6, 2))
     ctx.profile_begin(); f6(); k = ctx.profile_end()
-    agg = {}
-    for name, (ms, n) in k.items():
-        key = name.rstrip("0123456789_") if name.startswith("bc6h_") else name
-        agg[key] = agg.get(key, 0.0) + ms
-    for name, ms in sorted(agg.items(), key=lambda kv: -kv[1])[:10]:
-        print("  %-40s %8.3f ms" % (name, ms))
+    for name, (ms, n) in sorted(k.items(), key=lambda kv: kv[0]):
+        print("  %-40s %8.3f ms x%d" % (name, ms, n))
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["cases"]["cfg3_bc6h_uf16_4096"]["sha256"]
     sha = hashlib.sha256(dst6.cpu().numpy().tobytes()).hexdigest()
     print("  payload", "IDENTICAL to the reference golden" if sha == gold else "DIFFERS from the reference golden")
