@@ -10,6 +10,24 @@
 namespace DirectX
 {
     HRESULT CompressMI355X(int hipDevice, const Image& srcImage, DXGI_FORMAT format, TEX_COMPRESS_FLAGS compress, float threshold, ScratchImage& image) noexcept;
+    // DirectXTexMI355X.cpp: the array overload (one Prepare per mip size, then one dxtex_compress_many) and the other entry points of the path
+    HRESULT CompressMI355X(int hipDevice, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                           TEX_COMPRESS_FLAGS compress, float threshold, ScratchImage& cImages) noexcept;
+    HRESULT DecompressMI355X(int hipDevice, const Image& cImage, DXGI_FORMAT format, ScratchImage& image) noexcept;
+    HRESULT GenerateMipMapsMI355X(int hipDevice, const Image& baseImage, TEX_FILTER_FLAGS filter, size_t levels, ScratchImage& mipChain) noexcept;
+    HRESULT ResizeMI355X(int hipDevice, const Image& srcImage, size_t width, size_t height, TEX_FILTER_FLAGS filter, ScratchImage& image) noexcept;
+    HRESULT ConvertMI355X(int hipDevice, const Image& srcImage, DXGI_FORMAT format, TEX_FILTER_FLAGS filter, float threshold, ScratchImage& image) noexcept;
+}
+
+namespace
+{
+    bool SameScratch(const DirectX::ScratchImage& a, const DirectX::ScratchImage& b)
+    {
+        const DirectX::TexMetadata &ma = a.GetMetadata(), &mb = b.GetMetadata();
+        return a.GetPixels() && b.GetPixels() && a.GetImageCount() == b.GetImageCount() && a.GetPixelsSize() == b.GetPixelsSize() &&
+               ma.width == mb.width && ma.height == mb.height && ma.format == mb.format && ma.mipLevels == mb.mipLevels && ma.arraySize == mb.arraySize &&
+               std::memcmp(a.GetPixels(), b.GetPixels(), a.GetPixelsSize()) == 0;
+    }
 }
 
 using namespace DirectX;
@@ -47,6 +65,77 @@ int main()
         // the reference's argument checks come back through the binding unchanged
         ScratchImage bad;
         if (CompressMI355X(0, src, DXGI_FORMAT_R8G8B8A8_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, bad) != E_INVALIDARG) { std::puts("expected E_INVALIDARG for an uncompressed target"); ++failures; }
+    }
+    // ---- the other entry points, each against the reference's own CPU function on the reference's own ScratchImage ---------------------
+    {
+        auto report = [&](const char* what, HRESULT hrCpu, HRESULT hrGpu, bool same)
+        {
+            std::printf("%s: reference CPU %08X, binding over libdxtex_amd.so %08X, %s\n", what, unsigned(hrCpu), unsigned(hrGpu), same ? "identical ScratchImages" : "DIFFERENT");
+            if (!same) ++failures;
+        };
+        // a texture array with mips: 2 items x 3 levels of 44 x 28 (levels 22 x 14 and 11 x 7 have partial blocks)
+        ScratchImage arr;
+        if (FAILED(arr.Initialize2D(DXGI_FORMAT_R8G8B8A8_UNORM, 44, 28, 2, 3))) { std::puts("Initialize2D failed"); return 1; }
+        uint32_t s = 77u;
+        for (size_t i = 0; i < arr.GetPixelsSize(); ++i) { s = s * 1664525u + 1013904223u; arr.GetPixels()[i] = uint8_t((i * 7u) / 5u + ((s >> 24) & 31u)); }
+        for (DXGI_FORMAT fmt : { DXGI_FORMAT_BC1_UNORM, DXGI_FORMAT_BC7_UNORM })
+        {
+            ScratchImage cpu, gpu;
+            const HRESULT hrCpu = Compress(arr.GetImages(), arr.GetImageCount(), arr.GetMetadata(), fmt, TEX_COMPRESS_DEFAULT, TEX_THRESHOLD_DEFAULT, cpu);
+            const HRESULT hrGpu = CompressMI355X(0, arr.GetImages(), arr.GetImageCount(), arr.GetMetadata(), fmt, TEX_COMPRESS_DEFAULT, TEX_THRESHOLD_DEFAULT, gpu);
+            report(fmt == DXGI_FORMAT_BC1_UNORM ? "Compress (array 2 x 3 mips) -> BC1" : "Compress (array 2 x 3 mips) -> BC7", hrCpu, hrGpu,
+                   SUCCEEDED(hrCpu) && SUCCEEDED(hrGpu) && SameScratch(cpu, gpu));
+            if (fmt == DXGI_FORMAT_BC7_UNORM && SUCCEEDED(hrCpu))
+            {
+                ScratchImage dcpu, dgpu;
+                const Image& c = *cpu.GetImage(0, 1, 0);
+                const HRESULT h1 = Decompress(c, DXGI_FORMAT_R8G8B8A8_UNORM, dcpu);
+                const HRESULT h2 = DecompressMI355X(0, c, DXGI_FORMAT_R8G8B8A8_UNORM, dgpu);
+                report("Decompress BC7 -> RGBA8", h1, h2, SUCCEEDED(h1) && SUCCEEDED(h2) && SameScratch(dcpu, dgpu));
+            }
+        }
+        {
+            ScratchImage bad;
+            TexMetadata m = arr.GetMetadata();
+            if (CompressMI355X(0, arr.GetImages(), arr.GetImageCount() - 1, m, DXGI_FORMAT_BC1_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, bad) != E_FAIL || bad.GetPixels())
+            { std::puts("expected E_FAIL and a released result for a short image array"); ++failures; }                     // DirectXTexCompressGPU.cpp:360-364
+        }
+        const Image& base = *arr.GetImage(0, 0, 0);
+        for (TEX_FILTER_FLAGS flt : { TEX_FILTER_LINEAR, TEX_FILTER_CUBIC, TEX_FILTER_TRIANGLE })
+        {
+            ScratchImage cpu, gpu;
+            const HRESULT h1 = GenerateMipMaps(base, flt, 0, cpu);
+            const HRESULT h2 = GenerateMipMapsMI355X(0, base, flt, 0, gpu);
+            report(flt == TEX_FILTER_LINEAR ? "GenerateMipMaps 44 x 28 linear, full chain" : flt == TEX_FILTER_CUBIC ? "GenerateMipMaps 44 x 28 cubic, full chain" : "GenerateMipMaps 44 x 28 triangle, full chain",
+                   h1, h2, SUCCEEDED(h1) && SUCCEEDED(h2) && SameScratch(cpu, gpu));
+        }
+        {
+            ScratchImage cpu, gpu;
+            const HRESULT h1 = Resize(base, 61, 17, TEX_FILTER_CUBIC, cpu);
+            const HRESULT h2 = ResizeMI355X(0, base, 61, 17, TEX_FILTER_CUBIC, gpu);
+            report("Resize 44 x 28 -> 61 x 17 cubic", h1, h2, SUCCEEDED(h1) && SUCCEEDED(h2) && SameScratch(cpu, gpu));
+        }
+        {
+            // DirectX::Convert lives in DirectXTexConvert.cpp, which cannot be compiled here (DirectXMath is absent): the CPU side is the loop of
+            // ConvertCustom's plain branch (:4887-4909) over the scanline layer libdxtex_ref.so carries (oracle/restate/scanline.cpp, restated)
+            ScratchImage cpu, gpu;
+            HRESULT h1 = cpu.Initialize2D(DXGI_FORMAT_R16G16B16A16_FLOAT, base.width, base.height, 1, 1);
+            if (SUCCEEDED(h1))
+            {
+                std::vector<XMVECTOR> row(base.width);
+                const Image& d = *cpu.GetImage(0, 0, 0);
+                for (size_t y = 0; y < base.height && SUCCEEDED(h1); ++y)
+                {
+                    if (!Internal::LoadScanline(row.data(), base.width, base.pixels + y * base.rowPitch, base.rowPitch, base.format)) h1 = E_FAIL;
+                    Internal::ConvertScanline(row.data(), base.width, d.format, base.format, TEX_FILTER_DEFAULT);
+                    if (!Internal::StoreScanline(d.pixels + y * d.rowPitch, d.rowPitch, d.format, row.data(), base.width, TEX_THRESHOLD_DEFAULT)) h1 = E_FAIL;
+                }
+            }
+            const HRESULT h2 = ConvertMI355X(0, base, DXGI_FORMAT_R16G16B16A16_FLOAT, TEX_FILTER_DEFAULT, TEX_THRESHOLD_DEFAULT, gpu);
+            report("Convert RGBA8 -> RGBA16F (CPU side: restated scanline layer)", h1, h2, SUCCEEDED(h1) && SUCCEEDED(h2) && SameScratch(cpu, gpu));
+            ScratchImage bad;
+            if (ConvertMI355X(0, base, DXGI_FORMAT_R8G8B8A8_UNORM, TEX_FILTER_DEFAULT, 0.5f, bad) != E_INVALIDARG) { std::puts("expected E_INVALIDARG for Convert to the same format"); ++failures; }
+        }
     }
     std::puts(failures ? "binding demo FAILED" : "binding demo OK");
     return failures ? 1 : 0;
