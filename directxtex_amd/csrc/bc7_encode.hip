@@ -60,6 +60,13 @@ struct Bc7Args
     int phase;               // which blocks this launch of a mode owns: PHASE_ALL, or the early / late half of a split mode
 };
 
+// Whole-block tasks (modes 4, 5, 6: one subset of 16 texels) on SHORT lists - a small image, the late phase of mode 6 - are searched by
+// groups of lanes instead of a lane each: with fewer tasks than lanes a kernel is as slow as its longest serial chain, and a chain of
+// PerturbOne / Exhaustive evaluations on one lane is 0.1 - 0.5 ms. Exhaustive: a wavefront per task (the <= 121 candidates of a window
+// on its 64 lanes). PerturbOne: half a wavefront per task (16 texels x the step's two candidates).
+constexpr uint32_t kWaveTaskMax = 262144;
+constexpr uint32_t kPerturbWaveMax = 65536;
+
 // One texel of block `nb` (texel t = y*4+x), with the reference's partial-block replication, as float4
 // plus the 8-bit value D3DX_BC7::Encode derives from it (:2792-2799).
 __device__ __forceinline__ void load_block_texel(const SrcView& src, uint32_t nbw, uint32_t nb, uint32_t t, float* f4, uint32_t& ldr)
@@ -441,6 +448,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
     if (live == 0) return;           // nothing survived pre (a phase that owns no block, everything pruned): skip the queue atomics
+    if (TaskMap<MODE, IM>::NS == 1 && live <= kPerturbWaveMax) return;      // short list of whole-block tasks: bc7_perturb_wave_kernel's turn
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
 
@@ -487,6 +495,77 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
     }
 }
 
+// PerturbOne (:2926-2966) for SHORT lists of whole-block tasks, half a wavefront per task: lane (cand, k) of a half scores texel k
+// against candidate `cur - step` (cand 0) or `cur + step` (cand 1); the sixteen per-texel results are added up inside the group
+// (integers: any order) and every lane of the half takes the same decisions from the two totals - perturb_macro's candidates and
+// decisions, a chain of 2 * PREC - 1 single-texel evaluations instead of that many sixteen-texel ones. Two tasks per wavefront.
+template<int MODE, int IM, int CHSET>
+__global__ void __launch_bounds__(64) bc7_perturb_wave_kernel(Bc7Args a)
+{
+    typedef LoopCfg<MODE, IM, CHSET> C;
+    typedef TaskMap<MODE, IM> TM;
+    static_assert(TM::NS == 1, "whole-block tasks only");
+    __shared__ uint32_t sTex[16 * 64];              // column `slot` holds the slot's sixteen texels (SlotRegion's layout)
+    const int lane = threadIdx.x, slot = lane >> 5, k = lane & 15, cand = (lane >> 4) & 1;
+    const uint32_t live = a.counters[34];
+    if (live == 0 || live > kPerturbWaveMax) return;
+    for (uint32_t idx0 = blockIdx.x * 2u; idx0 < live; idx0 += gridDim.x * 2u)
+    {
+        const uint32_t idx = min(idx0 + uint32_t(slot), live - 1u);      // an odd tail: the second half shadows the last task and does not store
+        const bool mine = (idx0 + uint32_t(slot)) < live;
+        const uint2 task = a.order[idx];
+        const TaskRec rec = a.recs[task.x];
+        SlotRegion rg;
+        wave_lds_sync();                                  // the previous tasks' reads are done
+        search_pickup<MODE, IM>(a, task, &sTex[slot], rg);      // every lane of the half writes the same 16 texels
+        wave_lds_sync();
+        int other;
+        const int base = loop_base<MODE, IM, CHSET>(rg, rec.A, rec.B, &other);
+        PerturbState st = perturb_begin<MODE, IM, CHSET>(rec.A, rec.B, rec.err);
+        if (loop_is_settled<CHSET>(rec.err, other)) st.ch = C::CH1;       // scalar slot already exact: the record stays as it is
+        SlotRegion one; one.base = &sTex[slot] + k * 64; one.np = 1; one.p2sum = 0;      // this lane's texel
+        // sum over the sixteen texel lanes of a candidate group
+        auto group_sum = [](int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; };
+        while (__ballot(st.ch < C::CH1) != 0ull)
+        {
+            const bool busy = st.ch < C::CH1;
+            const int ch = busy ? st.ch : int(C::CH0);
+            VarPal<C::N> vp;
+            varpal_init<MODE, IM, CHSET>(vp, st.optA, st.optB, ch);
+            const uint32_t fixedU = unq1<C::PREC>(byte_of(st.do_b ? st.optA : st.optB, ch));
+            int cur = int(byte_of(st.do_b ? st.optB : st.optA, ch));
+            int minErr = st.optErr;
+            {
+                // the first step is half the range: one legal candidate (perturb_macro), both groups score it
+                constexpr int half = 1 << (C::PREC - 1);
+                const int tmp = (cur >= half) ? cur - half : cur + half;
+                const uint32_t u = unq1<C::PREC>(uint32_t(tmp) & ((1u << C::PREC) - 1u));
+                const int e = base + group_sum(eval_var<MODE, IM, CHSET>(one, vp, ch, st.do_b ? fixedU : u, st.do_b ? u : fixedU, 0));
+                if (e < minErr) { minErr = e; cur = tmp; }
+            }
+#pragma unroll 1
+            for (int step = 1 << (C::PREC - 2); step; step >>= 1)
+            {
+                const int tmp = cur + (cand ? step : -step);
+                const uint32_t u = unq1<C::PREC>(uint32_t(tmp) & ((1u << C::PREC) - 1u));
+                const int tot = base + group_sum(eval_var<MODE, IM, CHSET>(one, vp, ch, st.do_b ? fixedU : u, st.do_b ? u : fixedU, 0));
+                const int eMinus = __shfl(tot, slot * 32), ePlus = __shfl(tot, slot * 32 + 16);
+                const int tMinus = cur - step, tPlus = cur + step;
+                int beststep = 0;
+                if (tMinus >= 0 && tMinus < (1 << C::PREC) && eMinus < minErr) { minErr = eMinus; beststep = -step; }
+                if (tPlus >= 0 && tPlus < (1 << C::PREC) && ePlus < minErr) { minErr = ePlus; beststep = step; }
+                cur += beststep;
+            }
+            if (busy) st = perturb_transition<MODE, IM, CHSET>(st, minErr, uint32_t(cur));
+        }
+        if (mine && (lane & 31) == 0 && !loop_is_settled<CHSET>(rec.err, other))
+        {
+            TaskRec* r = a.recs + task.x;
+            r->A = st.optA; r->B = st.optB; r->err = st.optErr;
+        }
+    }
+}
+
 // PerturbOne through the bound filter (see eval_var_bound). A step of the logarithmic search has to be decided before the next one
 // starts, so the filter cannot postpone a lane's exact evaluations the way Exhaustive's windows do; what it can do is make them rare
 // and share them. Per candidate every lane derives the palette and takes the bound (no second dot product, no compare-select scan);
@@ -508,6 +587,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_filter_kernel(Bc7Args a, int l
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
     if (live == 0) return;
+    if (TaskMap<MODE, IM>::NS == 1 && live <= kPerturbWaveMax) return;      // short list of whole-block tasks: bc7_perturb_wave_kernel's turn
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
 
@@ -650,7 +730,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_filter_kernel(Bc7Args a, int l
 
 // Mode 6's short task lists go to bc7_exhaustive_wave_kernel (below): above this many live tasks the lane-per-task kernel is the
 // efficient one. Both are launched, each returns when it is not its turn.
-constexpr uint32_t kWaveTaskMax = 262144;
+
 
 // The Exhaustive phase (:2971-3042) for the channels of CHSET, wave-synchronous by window: every lane holds one task; all lanes
 // walk their current window (one channel's +-5 x +-5 neighbourhood) together, and a lane that needs a new task takes it at a
@@ -720,7 +800,7 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
 #endif
     const uint32_t live = a.counters[34];
     if (live == 0) return;           // nothing survived pre (a phase that owns no block, everything pruned): skip the queue atomics
-    if (MODE == 6 && live <= kWaveTaskMax) return;      // short list: bc7_exhaustive_wave_kernel has done it
+    if (TaskMap<MODE, IM>::NS == 1 && live <= kWaveTaskMax) return;      // short list of whole-block tasks: bc7_exhaustive_wave_kernel has done it
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
 
@@ -918,7 +998,9 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_wave_kernel(Bc7Args a)
         wave_lds_sync();                                  // the previous task's reads are done
         search_pickup<MODE, IM>(a, task, &sTex[0], rg);   // every lane writes the same 16 texels to column 0: all lanes then read them back
         wave_lds_sync();
-        const int base = loop_base<MODE, IM, CHSET>(rg, rec.A, rec.B);
+        int other;
+        const int base = loop_base<MODE, IM, CHSET>(rg, rec.A, rec.B, &other);
+        if (loop_is_settled<CHSET>(rec.err, other)) continue;      // scalar slot already exact (wave-uniform: one task per wavefront)
         ExhState st; st.optA = rec.A; st.optB = rec.B; st.optErr = rec.err;
         st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.o0 = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = rec.err; st.bestCode = -1; st.ch = C::CH0;
         VarPal<C::N> vp;
@@ -1184,6 +1266,11 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
     static const int tailBelow = dev_env("DXTEX_BC7_TAIL_BELOW") ? atoi(dev_env("DXTEX_BC7_TAIL_BELOW")) : 48;
     static const bool perturbPlain = dev_env("DXTEX_BC7_PERTURB_PLAIN") != nullptr;      // A/B: PerturbOne without the bound filter
+    // whole-block modes: the group-of-lanes kernels for short lists are launched next to the lane-per-task ones and the live count
+    // (known on the device only) decides which of the two works; on lists that cannot be short they are not launched at all
+    constexpr bool kWhole = TM::NS == 1;
+    const bool maybeShortP = kWhole && ntasks <= 4u * kPerturbWaveMax, maybeShortE = kWhole && ntasks <= 4u * kWaveTaskMax;
+    const uint32_t wavesP = std::min<uint32_t>(kSearchWaves, (ntasks + 1) / 2), wavesE = std::min<uint32_t>(kSearchWaves, ntasks);
     if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
         // the filter pays where the exact evaluation is dearest - eight palette entries on subsets of ~8 texels (mode 1: 24.5 -> 21.7 ms
@@ -1196,19 +1283,23 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
         }
         else
             hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 0);
+        if constexpr (kWhole) { if (maybeShortP) hipLaunchKernelGGL((bc7_perturb_wave_kernel<MODE, IM, CH_ALL>), dim3(wavesP), dim3(64), 0, stream, a); }
         if (marks) marks->mark(names[4]);
-        if constexpr (MODE == 6)
-            hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_ALL>), dim3(std::min<uint32_t>(kSearchWaves, ntasks)), dim3(64), 0, stream, a);
+        if constexpr (kWhole) { if (maybeShortE) hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_ALL>), dim3(wavesE), dim3(64), 0, stream, a); }
         hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1, tailBelow);
     }
     else
     {
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 0);
+        if (maybeShortP) hipLaunchKernelGGL((bc7_perturb_wave_kernel<MODE, IM, CH_COLOR>), dim3(wavesP), dim3(64), 0, stream, a);
         if (marks) marks->mark(names[3]);
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 1);
+        if (maybeShortP) hipLaunchKernelGGL((bc7_perturb_wave_kernel<MODE, IM, CH_ALPHA>), dim3(wavesP), dim3(64), 0, stream, a);
         if (marks) marks->mark(names[4]);
+        if (maybeShortE) hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_COLOR>), dim3(wavesE), dim3(64), 0, stream, a);
         hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2, tailBelow);
         if (marks) marks->mark(names[5]);
+        if (maybeShortE) hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_ALPHA>), dim3(wavesE), dim3(64), 0, stream, a);
         hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3, tailBelow);
     }
     if (marks) marks->mark(names[6]);

@@ -10,7 +10,7 @@ from directxtex_amd import synth
 what = set(sys.argv[1:]) or {"bc7"}
 ctx = dx.Context(0); dev = torch.device("cuda", 0)
 ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-W = H = 4096
+W = H = int(os.environ.get("PROBE_SIZE", "4096"))
 img = synth.survey_rgba8(W, H, 2, "opaque")
 src = torch.from_numpy(img).to(dev)
 
@@ -29,7 +29,7 @@ def timed(fn, n=20):
 if "bc7" in what:
     dst = torch.empty(dx.compute_pitch(98, W, H)[1], dtype=torch.uint8, device=dev)
     f = lambda: ctx.compress_device(src.data_ptr(), W, H, 28, dst.data_ptr(), 98, 0, 0.5)
-    print("bc7 4096^2: %.3f ms per image (wall, 3 images)" % timed(f, 3))
+    print("bc7 %d^2: %.3f ms per image (wall, 3 images)" % (W, timed(f, 3)))
     ctx.profile_begin(); f(); k = ctx.profile_end()
     tot = sum(ms for ms, n in k.values())
     print("  serial kernel sum %.2f ms" % tot)
@@ -39,7 +39,7 @@ if "bc7" in what:
     import json
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["cases"]["cfg2_bc7_4096"]["sha256"]
     sha = hashlib.sha256(dst.cpu().numpy().tobytes()).hexdigest()
-    print("  payload sha256", sha[:16], "IDENTICAL to the reference golden" if sha == gold else "DIFFERS from the reference golden")
+    print("  payload sha256", sha[:16], ("IDENTICAL to the reference golden" if sha == gold else "DIFFERS from the reference golden") if W == 4096 else "")
 if "bc6h" in what:
     import hashlib, json
     hdr = torch.from_numpy(synth.survey_rgba16f(W, H, 3)).to(dev)
