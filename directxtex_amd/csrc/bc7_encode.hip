@@ -58,14 +58,21 @@ struct Bc7Args
     uint32_t early6Min;      // an early phase (mode 6; modes 4 / 5) only exists when at least this many blocks would be in it
     int early6Pct;           // rough kernel: mode 6 goes first where 100 * lower bound <= early6Pct * best 3-bit rough error
     int phase;               // which blocks this launch of a mode owns: PHASE_ALL, or the early / late half of a split mode
+    uint32_t perturbWaveMax; // whole-block modes: lists of at most this many live tasks are searched by bc7_perturb_wave_kernel (0 = never)
+    uint32_t exhWaveMax;     // ... and by bc7_exhaustive_wave_kernel
 };
 
 // Whole-block tasks (modes 4, 5, 6: one subset of 16 texels) on SHORT lists - a small image, the late phase of mode 6 - are searched by
 // groups of lanes instead of a lane each: with fewer tasks than lanes a kernel is as slow as its longest serial chain, and a chain of
 // PerturbOne / Exhaustive evaluations on one lane is 0.1 - 0.5 ms. Exhaustive: a wavefront per task (the <= 121 candidates of a window
 // on its 64 lanes). PerturbOne: half a wavefront per task (16 texels x the step's two candidates).
+// The live count is known on the device only: the launcher passes each kernel pair the limit below which the group kernel works and the
+// lane-per-task kernel stands down (0 when the group kernel was not launched because the list cannot be short). Measured on MI355X:
+// mode 6's Exhaustive pays up to 2^18 tasks (its sixteen-entry evaluations are dear and its lists are pruned hard); modes 4 / 5 break
+// even near 25 K tasks; the half-wave PerturbOne near 32 K (2 x 8192 tasks in flight).
 constexpr uint32_t kWaveTaskMax = 262144;
-constexpr uint32_t kPerturbWaveMax = 65536;
+constexpr uint32_t kWaveTaskMax45 = 24576;
+constexpr uint32_t kPerturbWaveMax = 32768;
 
 // One texel of block `nb` (texel t = y*4+x), with the reference's partial-block replication, as float4
 // plus the 8-bit value D3DX_BC7::Encode derives from it (:2792-2799).
@@ -448,7 +455,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
     if (live == 0) return;           // nothing survived pre (a phase that owns no block, everything pruned): skip the queue atomics
-    if (TaskMap<MODE, IM>::NS == 1 && live <= kPerturbWaveMax) return;      // short list of whole-block tasks: bc7_perturb_wave_kernel's turn
+    if (TaskMap<MODE, IM>::NS == 1 && live <= a.perturbWaveMax) return;      // short list of whole-block tasks: bc7_perturb_wave_kernel's turn
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
 
@@ -508,7 +515,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_wave_kernel(Bc7Args a)
     __shared__ uint32_t sTex[16 * 64];              // column `slot` holds the slot's sixteen texels (SlotRegion's layout)
     const int lane = threadIdx.x, slot = lane >> 5, k = lane & 15, cand = (lane >> 4) & 1;
     const uint32_t live = a.counters[34];
-    if (live == 0 || live > kPerturbWaveMax) return;
+    if (live == 0 || live > a.perturbWaveMax) return;
     for (uint32_t idx0 = blockIdx.x * 2u; idx0 < live; idx0 += gridDim.x * 2u)
     {
         const uint32_t idx = min(idx0 + uint32_t(slot), live - 1u);      // an odd tail: the second half shadows the last task and does not store
@@ -587,7 +594,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_filter_kernel(Bc7Args a, int l
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
     if (live == 0) return;
-    if (TaskMap<MODE, IM>::NS == 1 && live <= kPerturbWaveMax) return;      // short list of whole-block tasks: bc7_perturb_wave_kernel's turn
+    if (TaskMap<MODE, IM>::NS == 1 && live <= a.perturbWaveMax) return;      // short list of whole-block tasks: bc7_perturb_wave_kernel's turn
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
 
@@ -800,7 +807,7 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
 #endif
     const uint32_t live = a.counters[34];
     if (live == 0) return;           // nothing survived pre (a phase that owns no block, everything pruned): skip the queue atomics
-    if (TaskMap<MODE, IM>::NS == 1 && live <= kWaveTaskMax) return;      // short list of whole-block tasks: bc7_exhaustive_wave_kernel has done it
+    if (TaskMap<MODE, IM>::NS == 1 && live <= a.exhWaveMax) return;      // short list of whole-block tasks: bc7_exhaustive_wave_kernel has done it
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
 
@@ -989,7 +996,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_wave_kernel(Bc7Args a)
     __shared__ uint32_t sTex[16 * 64];
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
-    if (live == 0 || live > kWaveTaskMax) return;
+    if (live == 0 || live > a.exhWaveMax) return;
     for (uint32_t idx = blockIdx.x; idx < live; idx += gridDim.x)
     {
         const uint2 task = a.order[idx];
@@ -1247,13 +1254,24 @@ struct ScratchLayout
 };
 
 template<int MODE, int IM>
-void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const char* const (&names)[7])
+void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, const char* const (&names)[7])
 {
     typedef TaskMap<MODE, IM> TM;
     constexpr int BPW = (TM::TPB >= 64) ? 1 : 64 / TM::TPB;
-    const uint32_t nb = a.nblocks;
+    const uint32_t nb = a0.nblocks;
     const uint32_t ntasks = nb * uint32_t(TM::TPB);
     const uint32_t gridPP = (nb + 4 * BPW - 1) / (4 * BPW);
+    // whole-block modes: the group-of-lanes kernels for short lists are launched next to the lane-per-task ones and the live count
+    // (known on the device only) decides which of the two works; on lists that cannot be short they are not launched at all
+    // (a list of n slots holds at most n live tasks and typically at least a quarter of them; mode 6's lists are pruned to a few per
+    // cent on large images, so its pair is always launched: an empty launch costs ~5 us)
+    constexpr bool kWhole = TM::NS == 1;
+    constexpr uint32_t kExhMax = (MODE == 6) ? kWaveTaskMax : kWaveTaskMax45;
+    const bool maybeShortP = kWhole && (MODE == 6 || ntasks <= 4u * kPerturbWaveMax), maybeShortE = kWhole && (MODE == 6 || ntasks <= 4u * kExhMax);
+    const uint32_t wavesP = std::min<uint32_t>(kSearchWaves, (ntasks + 1) / 2), wavesE = std::min<uint32_t>(kSearchWaves, ntasks);
+    Bc7Args a = a0;
+    a.perturbWaveMax = maybeShortP ? kPerturbWaveMax : 0u;
+    a.exhWaveMax = maybeShortE ? kExhMax : 0u;
     if (marks) marks->mark(names[0]);
     hipLaunchKernelGGL((bc7_pre_kernel<MODE, IM>), dim3(gridPP), dim3(256), 0, stream, a);
     if (marks) marks->mark(names[1]);
@@ -1266,11 +1284,6 @@ void launch_mode(const Bc7Args& a, hipStream_t stream, KernelMarks* marks, const
     const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
     static const int tailBelow = dev_env("DXTEX_BC7_TAIL_BELOW") ? atoi(dev_env("DXTEX_BC7_TAIL_BELOW")) : 48;
     static const bool perturbPlain = dev_env("DXTEX_BC7_PERTURB_PLAIN") != nullptr;      // A/B: PerturbOne without the bound filter
-    // whole-block modes: the group-of-lanes kernels for short lists are launched next to the lane-per-task ones and the live count
-    // (known on the device only) decides which of the two works; on lists that cannot be short they are not launched at all
-    constexpr bool kWhole = TM::NS == 1;
-    const bool maybeShortP = kWhole && ntasks <= 4u * kPerturbWaveMax, maybeShortE = kWhole && ntasks <= 4u * kWaveTaskMax;
-    const uint32_t wavesP = std::min<uint32_t>(kSearchWaves, (ntasks + 1) / 2), wavesE = std::min<uint32_t>(kSearchWaves, ntasks);
     if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
         // the filter pays where the exact evaluation is dearest - eight palette entries on subsets of ~8 texels (mode 1: 24.5 -> 21.7 ms
@@ -1358,6 +1371,7 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         set_pass(a.seg, dSegs, segs, pass);
         a.nblocks = pass.nblocks;
         a.flags = flags;
+        a.perturbWaveMax = 0; a.exhWaveMax = 0;       // set per mode by launch_mode
         a.lists = base + L.lists;
         a.cands = reinterpret_cast<Cand*>(base + L.cands);
         a.px = reinterpret_cast<uint32_t*>(base + L.px);
