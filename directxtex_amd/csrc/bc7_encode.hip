@@ -1267,7 +1267,9 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
     // cent on large images, so its pair is always launched: an empty launch costs ~5 us)
     constexpr bool kWhole = TM::NS == 1;
     constexpr uint32_t kExhMax = (MODE == 6) ? kWaveTaskMax : kWaveTaskMax45;
-    const bool maybeShortP = kWhole && (MODE == 6 || ntasks <= 4u * kPerturbWaveMax), maybeShortE = kWhole && (MODE == 6 || ntasks <= 4u * kExhMax);
+    static const bool noGroup = dev_env("DXTEX_BC7_NO_GROUP") != nullptr;      // development A/B: every list through the lane-per-task kernels
+    const bool maybeShortP = kWhole && !noGroup && (MODE == 6 || ntasks <= 4u * kPerturbWaveMax);
+    const bool maybeShortE = kWhole && !noGroup && (MODE == 6 || ntasks <= 4u * kExhMax);
     const uint32_t wavesP = std::min<uint32_t>(kSearchWaves, (ntasks + 1) / 2), wavesE = std::min<uint32_t>(kSearchWaves, ntasks);
     Bc7Args a = a0;
     a.perturbWaveMax = maybeShortP ? kPerturbWaveMax : 0u;

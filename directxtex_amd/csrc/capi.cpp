@@ -136,7 +136,7 @@ dxtex_hresult tile_conversion(const FmtInfo& in, const FmtInfo& out, uint32_t co
 {
     bool srgbIn = (compressFlags & DXTEX_COMPRESS_SRGB_IN) != 0 || (in.cls & FC_SRGB);
     bool srgbOut = (compressFlags & DXTEX_COMPRESS_SRGB_OUT) != 0 || (out.cls & FC_SRGB);
-    if (in.format == FMT_A8_UNORM) srgbIn = false;
+    if (in.format == FMT_A8_UNORM || in.format == FMT_R10G10B10_XR_BIAS_A2_UNORM) srgbIn = false;      // :3136-3139
     if (srgbIn && srgbOut) srgbIn = srgbOut = false;       // :3164-3167
 
     *tcv = TCV_NONE; *tsw = TSW_NONE;

@@ -13,28 +13,28 @@ namespace dxtex
 enum : int
 {
     FMT_UNKNOWN = 0,
-    FMT_R32G32B32A32_FLOAT = 2,
-    FMT_R32G32B32_FLOAT = 6,
+    FMT_R32G32B32A32_FLOAT = 2, FMT_R32G32B32A32_UINT = 3, FMT_R32G32B32A32_SINT = 4,
+    FMT_R32G32B32_FLOAT = 6, FMT_R32G32B32_UINT = 7, FMT_R32G32B32_SINT = 8,
     FMT_R16G16B16A16_FLOAT = 10,
-    FMT_R16G16B16A16_UNORM = 11,
-    FMT_R16G16B16A16_SNORM = 13,
-    FMT_R32G32_FLOAT = 16,
-    FMT_R10G10B10A2_UNORM = 24,
+    FMT_R16G16B16A16_UNORM = 11, FMT_R16G16B16A16_UINT = 12,
+    FMT_R16G16B16A16_SNORM = 13, FMT_R16G16B16A16_SINT = 14,
+    FMT_R32G32_FLOAT = 16, FMT_R32G32_UINT = 17, FMT_R32G32_SINT = 18,
+    FMT_R10G10B10A2_UNORM = 24, FMT_R10G10B10A2_UINT = 25,
     FMT_R11G11B10_FLOAT = 26,
     FMT_R8G8B8A8_UNORM = 28,
-    FMT_R8G8B8A8_UNORM_SRGB = 29,
-    FMT_R8G8B8A8_SNORM = 31,
+    FMT_R8G8B8A8_UNORM_SRGB = 29, FMT_R8G8B8A8_UINT = 30,
+    FMT_R8G8B8A8_SNORM = 31, FMT_R8G8B8A8_SINT = 32,
     FMT_R16G16_FLOAT = 34,
-    FMT_R16G16_UNORM = 35,
-    FMT_R16G16_SNORM = 37,
-    FMT_R32_FLOAT = 41,
-    FMT_R8G8_UNORM = 49,
-    FMT_R8G8_SNORM = 51,
+    FMT_R16G16_UNORM = 35, FMT_R16G16_UINT = 36,
+    FMT_R16G16_SNORM = 37, FMT_R16G16_SINT = 38,
+    FMT_R32_FLOAT = 41, FMT_R32_UINT = 42, FMT_R32_SINT = 43,
+    FMT_R8G8_UNORM = 49, FMT_R8G8_UINT = 50,
+    FMT_R8G8_SNORM = 51, FMT_R8G8_SINT = 52,
     FMT_R16_FLOAT = 54,
-    FMT_R16_UNORM = 56,
-    FMT_R16_SNORM = 58,
-    FMT_R8_UNORM = 61,
-    FMT_R8_SNORM = 63,
+    FMT_R16_UNORM = 56, FMT_R16_UINT = 57,
+    FMT_R16_SNORM = 58, FMT_R16_SINT = 59,
+    FMT_R8_UNORM = 61, FMT_R8_UINT = 62,
+    FMT_R8_SNORM = 63, FMT_R8_SINT = 64,
     FMT_A8_UNORM = 65,
     FMT_R9G9B9E5_SHAREDEXP = 67,
     FMT_BC1_UNORM = 71, FMT_BC1_UNORM_SRGB = 72,
@@ -43,10 +43,11 @@ enum : int
     FMT_BC4_UNORM = 80, FMT_BC4_SNORM = 81,
     FMT_BC5_UNORM = 83, FMT_BC5_SNORM = 84,
     FMT_B5G6R5_UNORM = 85, FMT_B5G5R5A1_UNORM = 86,
-    FMT_B8G8R8A8_UNORM = 87, FMT_B8G8R8X8_UNORM = 88,
+    FMT_B8G8R8A8_UNORM = 87, FMT_B8G8R8X8_UNORM = 88, FMT_R10G10B10_XR_BIAS_A2_UNORM = 89,
     FMT_B8G8R8A8_UNORM_SRGB = 91, FMT_B8G8R8X8_UNORM_SRGB = 93,
     FMT_BC6H_UF16 = 95, FMT_BC6H_SF16 = 96,
     FMT_BC7_UNORM = 98, FMT_BC7_UNORM_SRGB = 99,
+    FMT_AYUV = 100, FMT_Y410 = 101, FMT_Y416 = 102,
     FMT_B4G4R4A4_UNORM = 115,
 };
 
@@ -108,6 +109,13 @@ __device__ __forceinline__ float load_float11(uint32_t bits, int MB)
         mant &= (1u << MB) - 1u;
     }
     return __uint_as_float(((expo + 112u) << 23) | (mant << (23 - MB)));
+}
+
+// XMLoadUInt4 / XMConvertVectorUIntToFloat, SSE2 path: cvtdq2ps of the low 31 bits, + 2^31 if the top bit was set
+__device__ __forceinline__ float load_u32f(uint32_t v)
+{
+    const float lo = float(int32_t(v & 0x7FFFFFFFu));
+    return (v & 0x80000000u) ? lo + 2147483648.0f : lo;
 }
 
 // One texel, LoadScanline semantics for the supported formats.
@@ -291,6 +299,91 @@ __device__ __forceinline__ Texel load_texel(const uint8_t* row, uint32_t x, int 
         // XMLoadUNibble4 * 1/15 (:1511-1525)
         const uint32_t v = reinterpret_cast<const uint16_t*>(row)[x];
         t.b = float(v & 0xFu) * (1.0f / 15.0f); t.g = float((v >> 4) & 0xFu) * (1.0f / 15.0f); t.r = float((v >> 8) & 0xFu) * (1.0f / 15.0f); t.a = float(v >> 12) * (1.0f / 15.0f);
+        break;
+    }
+    // ---- integer formats: the VALUE as a float, not normalised. XMLoadUInt* (SSE2): the low 31 bits through cvtdq2ps (round to
+    // nearest even), plus 2^31 when the top bit is set - two roundings above 2^31, as there. XMLoadSInt*: cvtdq2ps. The 8- / 16-bit
+    // loads are exact. Missing channels come from g_XMIdentityR3 = (0, 0, 0, 1) (LOAD_SCANLINE2 / 3, :750-776).
+    case FMT_R32G32B32A32_UINT: { const uint4 v = reinterpret_cast<const uint4*>(row)[x]; t.r = load_u32f(v.x); t.g = load_u32f(v.y); t.b = load_u32f(v.z); t.a = load_u32f(v.w); break; }   // :805-806
+    case FMT_R32G32B32A32_SINT: { const int4 v = reinterpret_cast<const int4*>(row)[x]; t.r = float(v.x); t.g = float(v.y); t.b = float(v.z); t.a = float(v.w); break; }                      // :808-809
+    case FMT_R32G32B32_UINT: { const uint32_t* v = reinterpret_cast<const uint32_t*>(row) + 3 * size_t(x); t.r = load_u32f(v[0]); t.g = load_u32f(v[1]); t.b = load_u32f(v[2]); t.a = 1.0f; break; }   // :814-815
+    case FMT_R32G32B32_SINT: { const int32_t* v = reinterpret_cast<const int32_t*>(row) + 3 * size_t(x); t.r = float(v[0]); t.g = float(v[1]); t.b = float(v[2]); t.a = 1.0f; break; }              // :817-818
+    case FMT_R16G16B16A16_UINT:     // XMLoadUShort4, :826-827
+    {
+        const uint2 v = reinterpret_cast<const uint2*>(row)[x];
+        t.r = float(v.x & 0xFFFFu); t.g = float(v.x >> 16); t.b = float(v.y & 0xFFFFu); t.a = float(v.y >> 16);
+        break;
+    }
+    case FMT_R16G16B16A16_SINT:     // XMLoadShort4, :832-833
+    {
+        const uint2 v = reinterpret_cast<const uint2*>(row)[x];
+        t.r = float(int16_t(v.x & 0xFFFFu)); t.g = float(int16_t(v.x >> 16)); t.b = float(int16_t(v.y & 0xFFFFu)); t.a = float(int16_t(v.y >> 16));
+        break;
+    }
+    case FMT_R32G32_UINT: { const uint2 v = reinterpret_cast<const uint2*>(row)[x]; t.r = load_u32f(v.x); t.g = load_u32f(v.y); t.b = 0.0f; t.a = 1.0f; break; }       // :838-839
+    case FMT_R32G32_SINT: { const int2 v = reinterpret_cast<const int2*>(row)[x]; t.r = float(v.x); t.g = float(v.y); t.b = 0.0f; t.a = 1.0f; break; }                   // :841-842
+    case FMT_R10G10B10A2_UINT:      // XMLoadUDec4, :903-904
+    {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.r = float(v & 0x3FFu); t.g = float((v >> 10) & 0x3FFu); t.b = float((v >> 20) & 0x3FFu); t.a = float(v >> 30);
+        break;
+    }
+    case FMT_R10G10B10_XR_BIAS_A2_UNORM:    // XMLoadUDecN4_XR, :900-901: (field - 0x180) / 510, alpha / 3 (true divisions)
+    {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.r = float(int32_t(v & 0x3FFu) - 0x180) / 510.0f; t.g = float(int32_t((v >> 10) & 0x3FFu) - 0x180) / 510.0f;
+        t.b = float(int32_t((v >> 20) & 0x3FFu) - 0x180) / 510.0f; t.a = float(v >> 30) / 3.0f;
+        break;
+    }
+    case FMT_R8G8B8A8_UINT:         // XMLoadUByte4, :913-914
+    {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.r = float(v & 0xFFu); t.g = float((v >> 8) & 0xFFu); t.b = float((v >> 16) & 0xFFu); t.a = float(v >> 24);
+        break;
+    }
+    case FMT_R8G8B8A8_SINT:         // XMLoadByte4, :919-920
+    {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.r = float(int8_t(v & 0xFFu)); t.g = float(int8_t((v >> 8) & 0xFFu)); t.b = float(int8_t((v >> 16) & 0xFFu)); t.a = float(int8_t(v >> 24));
+        break;
+    }
+    case FMT_R16G16_UINT: { const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x]; t.r = float(v & 0xFFFFu); t.g = float(v >> 16); t.b = 0.0f; t.a = 1.0f; break; }                        // :928-929
+    case FMT_R16G16_SINT: { const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x]; t.r = float(int16_t(v & 0xFFFFu)); t.g = float(int16_t(v >> 16)); t.b = 0.0f; t.a = 1.0f; break; }      // :934-935
+    case FMT_R32_UINT: t.r = load_u32f(reinterpret_cast<const uint32_t*>(row)[x]); t.g = 0.0f; t.b = 0.0f; t.a = 1.0f; break;      // XMConvertVectorUIntToFloat(v, 0), :952-966
+    case FMT_R32_SINT: t.r = float(reinterpret_cast<const int32_t*>(row)[x]); t.g = 0.0f; t.b = 0.0f; t.a = 1.0f; break;           // :968-981
+    case FMT_R8G8_UINT: { const uint32_t v = reinterpret_cast<const uint16_t*>(row)[x]; t.r = float(v & 0xFFu); t.g = float(v >> 8); t.b = 0.0f; t.a = 1.0f; break; }                            // :1031-1032
+    case FMT_R8G8_SINT: { const uint32_t v = reinterpret_cast<const uint16_t*>(row)[x]; t.r = float(int8_t(v & 0xFFu)); t.g = float(int8_t(v >> 8)); t.b = 0.0f; t.a = 1.0f; break; }            // :1037-1038
+    case FMT_R16_UINT: t.r = float(reinterpret_cast<const uint16_t*>(row)[x]); t.g = 0.0f; t.b = 0.0f; t.a = 1.0f; break;          // :1067-1078
+    case FMT_R16_SINT: t.r = float(reinterpret_cast<const int16_t*>(row)[x]); t.g = 0.0f; t.b = 0.0f; t.a = 1.0f; break;           // :1093-1104
+    case FMT_R8_UINT: t.r = float(row[x]); t.g = 0.0f; t.b = 0.0f; t.a = 1.0f; break;                                              // :1119-1130
+    case FMT_R8_SINT: t.r = float(int8_t(row[x])); t.g = 0.0f; t.b = 0.0f; t.a = 1.0f; break;                                      // :1145-1156
+    // ---- 4:4:4 video formats: the reference's own fixed-point BT.601 matrices (:1291-1392), clamp, true division by the channel maximum
+    case FMT_AYUV:
+    {
+        const uint32_t w = reinterpret_cast<const uint32_t*>(row)[x];
+        const int v = int(w & 0xFFu) - 128, u = int((w >> 8) & 0xFFu) - 128, y = int((w >> 16) & 0xFFu) - 16;
+        const int r = (298 * y + 409 * v + 128) >> 8, g = (298 * y - 100 * u - 208 * v + 128) >> 8, b = (298 * y + 516 * u + 128) >> 8;
+        t.r = float(min(max(r, 0), 255)) / 255.0f; t.g = float(min(max(g, 0), 255)) / 255.0f; t.b = float(min(max(b, 0), 255)) / 255.0f;
+        t.a = float(w >> 24) / 255.0f;
+        break;
+    }
+    case FMT_Y410:
+    {
+        const uint32_t w = reinterpret_cast<const uint32_t*>(row)[x];
+        const long long u = int(w & 0x3FFu) - 512, y = int((w >> 10) & 0x3FFu) - 64, v = int((w >> 20) & 0x3FFu) - 512;
+        const int r = int((76533 * y + 104905 * v + 32768) >> 16), g = int((76533 * y - 25747 * u - 53425 * v + 32768) >> 16), b = int((76533 * y + 132590 * u + 32768) >> 16);
+        t.r = float(min(max(r, 0), 1023)) / 1023.0f; t.g = float(min(max(g, 0), 1023)) / 1023.0f; t.b = float(min(max(b, 0), 1023)) / 1023.0f;
+        t.a = float(w >> 30) / 3.0f;
+        break;
+    }
+    case FMT_Y416:
+    {
+        const uint2 w = reinterpret_cast<const uint2*>(row)[x];
+        const long long u = (long long)(w.x & 0xFFFFu) - 32768, y = (long long)(w.x >> 16) - 4096, v = (long long)(w.y & 0xFFFFu) - 32768;
+        const int a = int(w.y >> 16);
+        const int r = int((76607 * y + 105006 * v + 32768) >> 16), g = int((76607 * y - 25772 * u - 53477 * v + 32768) >> 16), b = int((76607 * y + 132718 * u + 32768) >> 16);
+        t.r = float(min(max(r, 0), 65535)) / 65535.0f; t.g = float(min(max(g, 0), 65535)) / 65535.0f; t.b = float(min(max(b, 0), 65535)) / 65535.0f;
+        t.a = float(min(max(a, 0), 65535)) / 65535.0f;
         break;
     }
     default:

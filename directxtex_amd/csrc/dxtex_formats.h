@@ -10,6 +10,9 @@ enum FmtClass : uint32_t
     FC_UNORM = 1, FC_SNORM = 2, FC_FLOAT = 4, FC_BC = 8,
     FC_R = 0x10, FC_G = 0x20, FC_B = 0x40, FC_A = 0x80, FC_SRGB = 0x100,
     FC_POS_ONLY = 0x200,     // CONVF_POS_ONLY: unsigned float formats (R11G11B10_FLOAT, R9G9B9E5_SHAREDEXP)
+    FC_UINT = 0x400, FC_SINT = 0x800,      // CONVF_UINT / CONVF_SINT: the value itself travels through the float row
+    FC_XR = 0x1000,          // CONVF_XR (R10G10B10_XR_BIAS_A2_UNORM)
+    FC_YUV = 0x2000,         // CONVF_YUV: converted to / from RGB inside LoadScanline / StoreScanline
 };
 
 struct FmtInfo { int format; uint32_t bpp; uint32_t cls; };
@@ -48,6 +51,21 @@ inline const FmtInfo* format_info(int format)
         { FMT_B5G6R5_UNORM, 16, FC_UNORM | FC_R | FC_G | FC_B },
         { FMT_B5G5R5A1_UNORM, 16, FC_UNORM | FC_R | FC_G | FC_B | FC_A },
         { FMT_B4G4R4A4_UNORM, 16, FC_UNORM | FC_R | FC_G | FC_B | FC_A },
+        // g_ConvertTable (DirectXTexConvert.cpp:2960-3047): integer, extended-range and 4:4:4 video formats
+        { FMT_R32G32B32A32_UINT, 128, FC_UINT | FC_R | FC_G | FC_B | FC_A }, { FMT_R32G32B32A32_SINT, 128, FC_SINT | FC_R | FC_G | FC_B | FC_A },
+        { FMT_R32G32B32_UINT, 96, FC_UINT | FC_R | FC_G | FC_B }, { FMT_R32G32B32_SINT, 96, FC_SINT | FC_R | FC_G | FC_B },
+        { FMT_R16G16B16A16_UINT, 64, FC_UINT | FC_R | FC_G | FC_B | FC_A }, { FMT_R16G16B16A16_SINT, 64, FC_SINT | FC_R | FC_G | FC_B | FC_A },
+        { FMT_R32G32_UINT, 64, FC_UINT | FC_R | FC_G }, { FMT_R32G32_SINT, 64, FC_SINT | FC_R | FC_G },
+        { FMT_R10G10B10A2_UINT, 32, FC_UINT | FC_R | FC_G | FC_B | FC_A },
+        { FMT_R8G8B8A8_UINT, 32, FC_UINT | FC_R | FC_G | FC_B | FC_A }, { FMT_R8G8B8A8_SINT, 32, FC_SINT | FC_R | FC_G | FC_B | FC_A },
+        { FMT_R16G16_UINT, 32, FC_UINT | FC_R | FC_G }, { FMT_R16G16_SINT, 32, FC_SINT | FC_R | FC_G },
+        { FMT_R32_UINT, 32, FC_UINT | FC_R }, { FMT_R32_SINT, 32, FC_SINT | FC_R },
+        { FMT_R8G8_UINT, 16, FC_UINT | FC_R | FC_G }, { FMT_R8G8_SINT, 16, FC_SINT | FC_R | FC_G },
+        { FMT_R16_UINT, 16, FC_UINT | FC_R }, { FMT_R16_SINT, 16, FC_SINT | FC_R },
+        { FMT_R8_UINT, 8, FC_UINT | FC_R }, { FMT_R8_SINT, 8, FC_SINT | FC_R },
+        { FMT_R10G10B10_XR_BIAS_A2_UNORM, 32, FC_UNORM | FC_XR | FC_R | FC_G | FC_B | FC_A },
+        { FMT_AYUV, 32, FC_UNORM | FC_YUV | FC_R | FC_G | FC_B | FC_A }, { FMT_Y410, 32, FC_UNORM | FC_YUV | FC_R | FC_G | FC_B | FC_A },
+        { FMT_Y416, 64, FC_UNORM | FC_YUV | FC_R | FC_G | FC_B | FC_A },
         { FMT_BC1_UNORM, 4, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A },
         { FMT_BC1_UNORM_SRGB, 4, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_SRGB },
         { FMT_BC2_UNORM, 8, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A },

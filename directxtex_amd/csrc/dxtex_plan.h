@@ -19,16 +19,16 @@ inline ConvertPlan resolve_convert_plan(const FmtInfo& in, const FmtInfo& out, u
 
     // :3123-3167
     if (in.cls & FC_SRGB) flags |= TF_SRGB_IN;
-    if (in.format == FMT_A8_UNORM) flags &= ~TF_SRGB_IN;
+    if (in.format == FMT_A8_UNORM || in.format == FMT_R10G10B10_XR_BIAS_A2_UNORM) flags &= ~TF_SRGB_IN;       // :3136-3139
     if (out.cls & FC_SRGB) flags |= TF_SRGB_OUT;
-    if (out.format == FMT_A8_UNORM) flags &= ~TF_SRGB_OUT;
+    if (out.format == FMT_A8_UNORM || out.format == FMT_R10G10B10_XR_BIAS_A2_UNORM) flags &= ~TF_SRGB_OUT;    // :3156-3159
     if ((flags & (TF_SRGB_IN | TF_SRGB_OUT)) == (TF_SRGB_IN | TF_SRGB_OUT)) flags &= ~(TF_SRGB_IN | TF_SRGB_OUT);
     if ((flags & TF_SRGB_IN) && (in.cls & (FC_FLOAT | FC_UNORM))) p.srgbIn = 1;
     if ((flags & TF_SRGB_OUT) && (out.cls & (FC_FLOAT | FC_UNORM))) p.srgbOut = 1;
 
     // the reference compares its CONVF_* words; what can differ among our formats: type class, channel set, BC-ness,
     // BGR order. BGR-only differences reach no branch below, so they can be left out of the test.
-    const uint32_t kDiffMask = FC_UNORM | FC_SNORM | FC_FLOAT | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_POS_ONLY;
+    const uint32_t kDiffMask = FC_UNORM | FC_SNORM | FC_FLOAT | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_POS_ONLY | FC_UINT | FC_SINT | FC_XR | FC_YUV;
     const uint32_t diff = (in.cls ^ out.cls) & kDiffMask;
     if (!diff) return p;
 

@@ -174,6 +174,59 @@ __device__ __forceinline__ uint32_t store_scaled_rne(float v, float scale)
     return uint32_t(int32_t(rintf(s)));
 }
 
+
+// ---- integer stores --------------------------------------------------------------------------------------------------------
+// XMStoreUInt4/3/2 and XMConvertVectorFloatToUInt(v, 0), SSE2 path: max(v, 0) (a NaN becomes 0: maxps returns its second operand),
+// values above 4294967295.0f (which is 2^32 in fp32) give 0xFFFFFFFF, everything else is TRUNCATED (cvttps2dq, with the usual
+// subtract-2^31 detour above 2^31, which is exact).
+__device__ __forceinline__ uint32_t store_u32(float v)
+{
+    const float s = (v > 0.0f) ? v : 0.0f;
+    if (s > 4294967295.0f) return 0xFFFFFFFFu;
+    return (s >= 2147483648.0f) ? (uint32_t(int32_t(s - 2147483648.0f)) ^ 0x80000000u) : uint32_t(int32_t(s));
+}
+// XMStoreSInt4/3/2 and XMConvertVectorFloatToInt(v, 0): truncation; above 2147483520.0f (65536 * 32768 - 128) the result is
+// 0x7FFFFFFF; below -2^31 and for NaN cvttps2dq's "integer indefinite" 0x80000000.
+__device__ __forceinline__ uint32_t store_s32(float v)
+{
+    if (v > 2147483520.0f) return 0x7FFFFFFFu;
+    if (!(v >= -2147483648.0f)) return 0x80000000u;
+    return uint32_t(int32_t(v));
+}
+// XMStoreUShort4/2, XMStoreShort4/2, XMStoreUByte4/2, XMStoreByte4/2: clamp to [lo, hi] (maxps then minps: a NaN becomes lo), round to
+// nearest even (cvtps2dq). lo is -32767 / -127 for the signed ones (g_ShortMin / g_ByteMin).
+__device__ __forceinline__ int32_t store_clamp_rne(float v, float lo, float hi)
+{
+    float s = (v > lo) ? v : lo; s = (s < hi) ? s : hi;
+    return int32_t(rintf(s));
+}
+// The single-channel integer formats are the reference's own scalar code (:1913-2016): std::min / std::max, then a C++ cast (truncation)
+__device__ __forceinline__ int32_t store_clamp_trunc(float v, float lo, float hi)
+{
+    float s = (hi < v) ? hi : v;        // std::min<float>(v, hi)
+    s = (s < lo) ? lo : s;              // std::max<float>(., lo); a NaN passes through both and converts to 0 here (the reference's cast
+    return int32_t(s);                  // of a NaN is undefined; x86-64 stores 0 in the 8- and 16-bit fields)
+}
+// XMStoreUDec4: maxps / minps (a NaN becomes lo), then cvttps2dq
+__device__ __forceinline__ int32_t store_clamp_trunc_sse(float v, float lo, float hi)
+{
+    float s = (v > lo) ? v : lo; s = (s < hi) ? s : hi;
+    return int32_t(s);
+}
+// XMStoreUDecN4_XR: v * (510, 510, 510, 3) + (384, 384, 384, 0), clamp to [0, (1023, 1023, 1023, 3)], truncate
+__device__ __forceinline__ uint32_t store_xr(const Texel& t)
+{
+    auto one = [](float v, float scale, float bias, float hi) { float s = v * scale + bias; s = (s > 0.0f) ? s : 0.0f; s = (s < hi) ? s : hi; return uint32_t(s); };
+    return (one(t.r, 510.0f, 384.0f, 1023.0f) & 0x3FFu) | ((one(t.g, 510.0f, 384.0f, 1023.0f) & 0x3FFu) << 10) |
+           ((one(t.b, 510.0f, 384.0f, 1023.0f) & 0x3FFu) << 20) | (one(t.a, 3.0f, 0.0f, 3.0f) << 30);
+}
+// XMStoreUByteN4 WITHOUT the reference's bias (the AYUV store calls it on the raw vector, :2184): saturate, * 255, truncate
+__device__ __forceinline__ uint32_t store_ubn_plain(float v)
+{
+    float s = (v > 0.0f) ? v : 0.0f; s = (s < 1.0f) ? s : 1.0f;
+    return uint32_t(s * 255.0f);
+}
+
 // The 4-byte formats as one packed word (same expressions as the cases of store_texel below).
 __device__ __forceinline__ bool is_packed32(int format)
 {
@@ -320,6 +373,70 @@ __device__ __forceinline__ void store_texel(uint8_t* row, uint32_t x, int format
         reinterpret_cast<uint16_t*>(row)[x] = uint16_t((store_scaled_rne(t.b, 15.0f) & 0xFu) | ((store_scaled_rne(t.g, 15.0f) & 0xFu) << 4) |
                                                        ((store_scaled_rne(t.r, 15.0f) & 0xFu) << 8) | ((store_scaled_rne(t.a, 15.0f) & 0xFu) << 12));
         break;
+    // ---- integer formats (see store_u32 / store_s32 / store_clamp_rne / store_clamp_trunc above)
+    case FMT_R32G32B32A32_UINT: reinterpret_cast<uint4*>(row)[x] = make_uint4(store_u32(t.r), store_u32(t.g), store_u32(t.b), store_u32(t.a)); break;     // :1674-1675
+    case FMT_R32G32B32A32_SINT: reinterpret_cast<uint4*>(row)[x] = make_uint4(store_s32(t.r), store_s32(t.g), store_s32(t.b), store_s32(t.a)); break;     // :1677-1678
+    case FMT_R32G32B32_UINT: { uint32_t* d = reinterpret_cast<uint32_t*>(row) + 3 * size_t(x); d[0] = store_u32(t.r); d[1] = store_u32(t.g); d[2] = store_u32(t.b); break; }      // :1683-1684
+    case FMT_R32G32B32_SINT: { uint32_t* d = reinterpret_cast<uint32_t*>(row) + 3 * size_t(x); d[0] = store_s32(t.r); d[1] = store_s32(t.g); d[2] = store_s32(t.b); break; }      // :1686-1687
+    case FMT_R16G16B16A16_UINT:     // XMStoreUShort4, :1707-1708
+        reinterpret_cast<uint2*>(row)[x] = make_uint2(uint32_t(store_clamp_rne(t.r, 0.0f, 65535.0f)) | (uint32_t(store_clamp_rne(t.g, 0.0f, 65535.0f)) << 16),
+                                                      uint32_t(store_clamp_rne(t.b, 0.0f, 65535.0f)) | (uint32_t(store_clamp_rne(t.a, 0.0f, 65535.0f)) << 16));
+        break;
+    case FMT_R16G16B16A16_SINT:     // XMStoreShort4, :1713-1714
+        reinterpret_cast<uint2*>(row)[x] = make_uint2((uint32_t(store_clamp_rne(t.r, -32767.0f, 32767.0f)) & 0xFFFFu) | (uint32_t(store_clamp_rne(t.g, -32767.0f, 32767.0f)) << 16),
+                                                      (uint32_t(store_clamp_rne(t.b, -32767.0f, 32767.0f)) & 0xFFFFu) | (uint32_t(store_clamp_rne(t.a, -32767.0f, 32767.0f)) << 16));
+        break;
+    case FMT_R32G32_UINT: reinterpret_cast<uint2*>(row)[x] = make_uint2(store_u32(t.r), store_u32(t.g)); break;      // :1719-1720
+    case FMT_R32G32_SINT: reinterpret_cast<uint2*>(row)[x] = make_uint2(store_s32(t.r), store_s32(t.g)); break;      // :1722-1723
+    case FMT_R10G10B10A2_UINT:      // XMStoreUDec4 (:1753-1754): clamp to [0, (1023, 1023, 1023, 3)], truncate
+        reinterpret_cast<uint32_t*>(row)[x] = uint32_t(store_clamp_trunc_sse(t.r, 0.0f, 1023.0f)) | (uint32_t(store_clamp_trunc_sse(t.g, 0.0f, 1023.0f)) << 10) |
+                                              (uint32_t(store_clamp_trunc_sse(t.b, 0.0f, 1023.0f)) << 20) | (uint32_t(store_clamp_trunc_sse(t.a, 0.0f, 3.0f)) << 30);
+        break;
+    case FMT_R10G10B10_XR_BIAS_A2_UNORM: reinterpret_cast<uint32_t*>(row)[x] = store_xr(t); break;      // :1750-1751
+    case FMT_R8G8B8A8_UINT:         // XMStoreUByte4, :1774-1775
+        reinterpret_cast<uint32_t*>(row)[x] = uint32_t(store_clamp_rne(t.r, 0.0f, 255.0f)) | (uint32_t(store_clamp_rne(t.g, 0.0f, 255.0f)) << 8) |
+                                              (uint32_t(store_clamp_rne(t.b, 0.0f, 255.0f)) << 16) | (uint32_t(store_clamp_rne(t.a, 0.0f, 255.0f)) << 24);
+        break;
+    case FMT_R8G8B8A8_SINT:         // XMStoreByte4, :1780-1781
+        reinterpret_cast<uint32_t*>(row)[x] = (uint32_t(store_clamp_rne(t.r, -127.0f, 127.0f)) & 0xFFu) | ((uint32_t(store_clamp_rne(t.g, -127.0f, 127.0f)) & 0xFFu) << 8) |
+                                              ((uint32_t(store_clamp_rne(t.b, -127.0f, 127.0f)) & 0xFFu) << 16) | (uint32_t(store_clamp_rne(t.a, -127.0f, 127.0f)) << 24);
+        break;
+    case FMT_R16G16_UINT: reinterpret_cast<uint32_t*>(row)[x] = uint32_t(store_clamp_rne(t.r, 0.0f, 65535.0f)) | (uint32_t(store_clamp_rne(t.g, 0.0f, 65535.0f)) << 16); break;      // :1801-1802
+    case FMT_R16G16_SINT: reinterpret_cast<uint32_t*>(row)[x] = (uint32_t(store_clamp_rne(t.r, -32767.0f, 32767.0f)) & 0xFFFFu) | (uint32_t(store_clamp_rne(t.g, -32767.0f, 32767.0f)) << 16); break;   // :1807-1808
+    case FMT_R32_UINT: reinterpret_cast<uint32_t*>(row)[x] = store_u32(t.r); break;      // XMConvertVectorFloatToUInt(v, 0), :1824-1836
+    case FMT_R32_SINT: reinterpret_cast<uint32_t*>(row)[x] = store_s32(t.r); break;      // :1838-1850
+    case FMT_R8G8_UINT: reinterpret_cast<uint16_t*>(row)[x] = uint16_t(uint32_t(store_clamp_rne(t.r, 0.0f, 255.0f)) | (uint32_t(store_clamp_rne(t.g, 0.0f, 255.0f)) << 8)); break;     // :1873-1874
+    case FMT_R8G8_SINT: reinterpret_cast<uint16_t*>(row)[x] = uint16_t((uint32_t(store_clamp_rne(t.r, -127.0f, 127.0f)) & 0xFFu) | ((uint32_t(store_clamp_rne(t.g, -127.0f, 127.0f)) & 0xFFu) << 8)); break;   // :1879-1880
+    case FMT_R16_UINT: reinterpret_cast<uint16_t*>(row)[x] = uint16_t(store_clamp_trunc(t.r, 0.0f, 65535.0f)); break;                  // :1913-1926
+    case FMT_R16_SINT: reinterpret_cast<uint16_t*>(row)[x] = uint16_t(int16_t(store_clamp_trunc(t.r, -32767.0f, 32767.0f))); break;    // :1943-1956
+    case FMT_R8_UINT: row[x] = uint8_t(store_clamp_trunc(t.r, 0.0f, 255.0f)); break;                                                   // :1973-1986
+    case FMT_R8_SINT: row[x] = uint8_t(int8_t(store_clamp_trunc(t.r, -127.0f, 127.0f))); break;                                        // :2003-2016
+    // ---- 4:4:4 video formats: quantise with the format's RGB store, then the reference's fixed-point matrices (:2173-2268)
+    case FMT_AYUV:
+    {
+        const int r = int(store_ubn_plain(t.r)), g = int(store_ubn_plain(t.g)), b = int(store_ubn_plain(t.b));
+        const int y = ((66 * r + 129 * g + 25 * b + 128) >> 8) + 16, u = ((-38 * r - 74 * g + 112 * b + 128) >> 8) + 128, v = ((112 * r - 94 * g - 18 * b + 128) >> 8) + 128;
+        reinterpret_cast<uint32_t*>(row)[x] = uint32_t(min(max(v, 0), 255)) | (uint32_t(min(max(u, 0), 255)) << 8) | (uint32_t(min(max(y, 0), 255)) << 16) | (store_ubn_plain(t.a) << 24);
+        break;
+    }
+    case FMT_Y410:
+    {
+        const uint32_t q = store_udecn4(t);
+        const long long r = q & 0x3FFu, g = (q >> 10) & 0x3FFu, b = (q >> 20) & 0x3FFu;
+        const int y = int((16780 * r + 32942 * g + 6544 * b + 32768) >> 16) + 64, u = int((-9683 * r - 19017 * g + 28700 * b + 32768) >> 16) + 512,
+                  v = int((28700 * r - 24033 * g - 4667 * b + 32768) >> 16) + 512;
+        reinterpret_cast<uint32_t*>(row)[x] = uint32_t(min(max(u, 0), 1023)) | (uint32_t(min(max(y, 0), 1023)) << 10) | (uint32_t(min(max(v, 0), 1023)) << 20) | (q & 0xC0000000u);
+        break;
+    }
+    case FMT_Y416:
+    {
+        const long long r = store_usn(t.r), g = store_usn(t.g), b = store_usn(t.b);
+        const int y = int((16763 * r + 32910 * g + 6537 * b + 32768) >> 16) + 4096, u = int((-9674 * r - 18998 * g + 28672 * b + 32768) >> 16) + 32768,
+                  v = int((28672 * r - 24010 * g - 4662 * b + 32768) >> 16) + 32768;
+        reinterpret_cast<uint2*>(row)[x] = make_uint2(uint32_t(min(max(u, 0), 65535)) | (uint32_t(min(max(y, 0), 65535)) << 16),
+                                                      uint32_t(min(max(v, 0), 65535)) | (store_usn(t.a) << 16));
+        break;
+    }
     default:
         break;
     }

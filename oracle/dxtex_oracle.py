@@ -314,7 +314,10 @@ class RefError(RuntimeError):
 
 
 BPP = {2: 128, 6: 96, 13: 64, 24: 32, 26: 32, 37: 32, 58: 16, 67: 32, 85: 16, 86: 16, 115: 16, 10: 64, 11: 64, 16: 64, 28: 32, 29: 32, 31: 32, 34: 32, 35: 32, 41: 32, 49: 16, 51: 16, 54: 16, 56: 16, 61: 8, 63: 8, 65: 8,
-       87: 32, 88: 32, 91: 32, 93: 32}
+       87: 32, 88: 32, 91: 32, 93: 32,
+       # integer, extended-range and 4:4:4 video formats
+       3: 128, 4: 128, 7: 96, 8: 96, 12: 64, 14: 64, 17: 64, 18: 64, 25: 32, 30: 32, 32: 32, 36: 32, 38: 32, 42: 32, 43: 32, 50: 16, 52: 16, 57: 16, 59: 16, 62: 8, 64: 8,
+       89: 32, 100: 32, 101: 32, 102: 64}
 
 
 def image_bytes(fmt, w, h):

@@ -98,7 +98,54 @@ namespace
     inline uint16_t store_snorm16(float v) { const float s = clampf(v, -1.f, 1.f); return uint16_t(int16_t(int32_t(nearbyintf(s * 32767.0f)))); }   // XMStoreShortN4/N2: cvtps, pack
     inline uint32_t store_scaled(float v, float scale) { return uint32_t(int32_t(nearbyintf(clampf(v * scale, 0.f, scale)))); }                   // XMStoreU565/U555/UNibble4 after the reference's multiply
 
-    enum : uint32_t { C_UNORM = 1, C_SNORM = 2, C_FLOAT = 4, C_R = 0x10, C_G = 0x20, C_B = 0x40, C_A = 0x80, C_BC = 8, C_POS_ONLY = 0x200 };
+    enum : uint32_t { C_UNORM = 1, C_SNORM = 2, C_FLOAT = 4, C_R = 0x10, C_G = 0x20, C_B = 0x40, C_A = 0x80, C_BC = 8, C_POS_ONLY = 0x200,
+                      C_UINT = 0x400, C_SINT = 0x800, C_XR = 0x1000, C_YUV = 0x2000 };
+
+    // The integer formats (value = the integer itself), as a table: channels, bits per channel, signedness. `scalar` marks the single-channel
+    // 8- / 16-bit formats, which the reference loads and stores with its own scalar code (C++ casts: truncation, :1067-1156, :1913-2016); the
+    // others go through DirectXMath's XMLoad* / XMStore* (restated from its SSE2 paths: 32-bit stores truncate, 8- / 16-bit stores round to
+    // nearest even after a clamp to [0, max] or [-max, max]).
+    struct IntFormat { int format; int channels; int bits; bool isSigned; bool scalar; };
+    const IntFormat* int_format(DXGI_FORMAT f)
+    {
+        static const IntFormat table[] = {
+            { DXGI_FORMAT_R32G32B32A32_UINT, 4, 32, false, false }, { DXGI_FORMAT_R32G32B32A32_SINT, 4, 32, true, false },
+            { DXGI_FORMAT_R32G32B32_UINT, 3, 32, false, false }, { DXGI_FORMAT_R32G32B32_SINT, 3, 32, true, false },
+            { DXGI_FORMAT_R16G16B16A16_UINT, 4, 16, false, false }, { DXGI_FORMAT_R16G16B16A16_SINT, 4, 16, true, false },
+            { DXGI_FORMAT_R32G32_UINT, 2, 32, false, false }, { DXGI_FORMAT_R32G32_SINT, 2, 32, true, false },
+            { DXGI_FORMAT_R8G8B8A8_UINT, 4, 8, false, false }, { DXGI_FORMAT_R8G8B8A8_SINT, 4, 8, true, false },
+            { DXGI_FORMAT_R16G16_UINT, 2, 16, false, false }, { DXGI_FORMAT_R16G16_SINT, 2, 16, true, false },
+            { DXGI_FORMAT_R32_UINT, 1, 32, false, false }, { DXGI_FORMAT_R32_SINT, 1, 32, true, false },
+            { DXGI_FORMAT_R8G8_UINT, 2, 8, false, false }, { DXGI_FORMAT_R8G8_SINT, 2, 8, true, false },
+            { DXGI_FORMAT_R16_UINT, 1, 16, false, true }, { DXGI_FORMAT_R16_SINT, 1, 16, true, true },
+            { DXGI_FORMAT_R8_UINT, 1, 8, false, true }, { DXGI_FORMAT_R8_SINT, 1, 8, true, true },
+        };
+        for (const IntFormat& e : table) if (e.format == int(f)) return &e;
+        return nullptr;
+    }
+    // XMLoadUInt* / XMConvertVectorUIntToFloat: cvtdq2ps of (v & 0x7FFFFFFF), + 2^31 if the top bit was set
+    inline float uint_to_float(uint32_t v) { const float lo = float(int32_t(v & 0x7FFFFFFFu)); return (v & 0x80000000u) ? lo + 2147483648.0f : lo; }
+    // XMStoreUInt* / XMConvertVectorFloatToUInt
+    inline uint32_t float_to_uint(float v)
+    {
+        const float s = (v > 0.0f) ? v : 0.0f;                                  // maxps(v, 0): NaN -> 0
+        if (s > 4294967295.0f) return 0xFFFFFFFFu;
+        if (s >= 2147483648.0f) return uint32_t(int32_t(s - 2147483648.0f)) ^ 0x80000000u;
+        return uint32_t(int32_t(s));
+    }
+    // XMStoreSInt* / XMConvertVectorFloatToInt
+    inline uint32_t float_to_sint(float v)
+    {
+        if (v > 2147483520.0f) return 0x7FFFFFFFu;
+        if (!(v >= -2147483648.0f)) return 0x80000000u;                         // cvttps2dq's integer indefinite (also for NaN)
+        return uint32_t(int32_t(v));
+    }
+    inline int32_t clamp_round_even(float v, float lo, float hi) { float s = (v > lo) ? v : lo; s = (s < hi) ? s : hi; return int32_t(nearbyintf(s)); }
+    inline int32_t clamp_truncate_std(float v, float lo, float hi)
+    {
+        const float s = std::max<float>(std::min<float>(v, hi), lo);
+        return (s != s) ? 0 : int32_t(s);                                       // the reference's cast of a NaN is undefined; x86-64 leaves 0 in the narrow field
+    }
     // the CONVF_* words of g_ConvertTable (DirectXTexConvert.cpp:2960-3047), reduced to what the supported formats use
     uint32_t conv_flags(DXGI_FORMAT f)
     {
@@ -131,7 +178,13 @@ namespace
         case DXGI_FORMAT_BC5_UNORM: return C_UNORM | C_BC | C_R | C_G;
         case DXGI_FORMAT_BC5_SNORM: return C_SNORM | C_BC | C_R | C_G;
         case DXGI_FORMAT_BC6H_UF16: case DXGI_FORMAT_BC6H_SF16: return C_FLOAT | C_BC | C_R | C_G | C_B | C_A;
-        default: return 0;
+        case DXGI_FORMAT_R10G10B10_XR_BIAS_A2_UNORM: return C_UNORM | C_XR | C_R | C_G | C_B | C_A;                                        // :3030
+        case DXGI_FORMAT_AYUV: case DXGI_FORMAT_Y410: case DXGI_FORMAT_Y416: return C_UNORM | C_YUV | C_R | C_G | C_B | C_A;                  // :3037-3039
+        case DXGI_FORMAT_R10G10B10A2_UINT: return C_UINT | C_R | C_G | C_B | C_A;                                                         // :2978
+        default:
+            if (const IntFormat* e = int_format(f))
+                return (e->isSigned ? C_SINT : C_UINT) | C_R | (e->channels > 1 ? C_G : 0) | (e->channels > 2 ? C_B : 0) | (e->channels > 3 ? C_A : 0);
+            return 0;
         }
     }
 
@@ -167,8 +220,72 @@ bool DirectX::Internal::LoadScanline(XMVECTOR* pDestination, size_t count, const
     if (!pDestination || !count || !pSource || !size) return false;
     const uint8_t* s = static_cast<const uint8_t*>(pSource);
     auto texels = [&](size_t bytes) { const size_t n = size / bytes; return n < count ? n : count; };
+    if (const IntFormat* e = int_format(format))
+    {
+        // :805-809, :814-818, :826-833, :838-842, :913-920, :928-935, :952-981, :1031-1038, :1067-1156; absent channels from (0, 0, 0, 1)
+        const size_t bytes = size_t(e->channels * e->bits / 8);
+        for (size_t i = 0, n = texels(bytes); i < n; ++i)
+        {
+            float v[4] = { 0.f, 0.f, 0.f, 1.f };
+            for (int c = 0; c < e->channels; ++c)
+            {
+                const uint8_t* p = s + i * bytes + size_t(c * e->bits / 8);
+                if (e->bits == 32) { uint32_t u; memcpy(&u, p, 4); v[c] = e->isSigned ? float(int32_t(u)) : uint_to_float(u); }
+                else if (e->bits == 16) { uint16_t u; memcpy(&u, p, 2); v[c] = e->isSigned ? float(int16_t(u)) : float(u); }
+                else v[c] = e->isSigned ? float(int8_t(*p)) : float(*p);
+            }
+            pDestination[i] = XMVectorSet(v[0], v[1], v[2], v[3]);
+        }
+        return true;
+    }
     switch (int(format))
     {
+    case DXGI_FORMAT_R10G10B10A2_UINT:          // XMLoadUDec4, :903-904
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            uint32_t u; memcpy(&u, s + i * 4, 4);
+            pDestination[i] = XMVectorSet(float(u & 0x3FF), float((u >> 10) & 0x3FF), float((u >> 20) & 0x3FF), float(u >> 30));
+        }
+        return true;
+    case DXGI_FORMAT_R10G10B10_XR_BIAS_A2_UNORM:    // XMLoadUDecN4_XR, :900-901
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            uint32_t u; memcpy(&u, s + i * 4, 4);
+            pDestination[i] = XMVectorSet(float(int32_t(u & 0x3FF) - 0x180) / 510.0f, float(int32_t((u >> 10) & 0x3FF) - 0x180) / 510.0f,
+                                          float(int32_t((u >> 20) & 0x3FF) - 0x180) / 510.0f, float(u >> 30) / 3.0f);
+        }
+        return true;
+    case DXGI_FORMAT_AYUV:                      // :1291-1326
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const uint8_t* b = s + i * 4;
+            const int v = int(b[0]) - 128, u = int(b[1]) - 128, y = int(b[2]) - 16;
+            const int r = (298 * y + 409 * v + 128) >> 8, g = (298 * y - 100 * u - 208 * v + 128) >> 8, bl = (298 * y + 516 * u + 128) >> 8;
+            pDestination[i] = XMVectorSet(float(std::min<int>(std::max<int>(r, 0), 255)) / 255.f, float(std::min<int>(std::max<int>(g, 0), 255)) / 255.f,
+                                          float(std::min<int>(std::max<int>(bl, 0), 255)) / 255.f, float(b[3]) / 255.f);
+        }
+        return true;
+    case DXGI_FORMAT_Y410:                      // :1328-1360
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            uint32_t w; memcpy(&w, s + i * 4, 4);
+            const int64_t u = int(w & 0x3FF) - 512, y = int((w >> 10) & 0x3FF) - 64, v = int((w >> 20) & 0x3FF) - 512;
+            const int r = int((76533 * y + 104905 * v + 32768) >> 16), g = int((76533 * y - 25747 * u - 53425 * v + 32768) >> 16), bl = int((76533 * y + 132590 * u + 32768) >> 16);
+            pDestination[i] = XMVectorSet(float(std::min<int>(std::max<int>(r, 0), 1023)) / 1023.f, float(std::min<int>(std::max<int>(g, 0), 1023)) / 1023.f,
+                                          float(std::min<int>(std::max<int>(bl, 0), 1023)) / 1023.f, float(w >> 30) / 3.f);
+        }
+        return true;
+    case DXGI_FORMAT_Y416:                      // :1362-1394
+        for (size_t i = 0, n = texels(8); i < n; ++i)
+        {
+            uint16_t h[4]; memcpy(h, s + i * 8, 8);
+            const int64_t u = int64_t(h[0]) - 32768, y = int64_t(h[1]) - 4096, v = int64_t(h[2]) - 32768;
+            const int a = int(h[3]);
+            const int r = int((76607 * y + 105006 * v + 32768) >> 16), g = int((76607 * y - 25772 * u - 53477 * v + 32768) >> 16), bl = int((76607 * y + 132718 * u + 32768) >> 16);
+            pDestination[i] = XMVectorSet(float(std::min<int>(std::max<int>(r, 0), 65535)) / 65535.f, float(std::min<int>(std::max<int>(g, 0), 65535)) / 65535.f,
+                                          float(std::min<int>(std::max<int>(bl, 0), 65535)) / 65535.f, float(std::min<int>(std::max<int>(a, 0), 65535)) / 65535.f);
+        }
+        return true;
     case DXGI_FORMAT_R32G32B32A32_FLOAT:        // :798-803
     {
         const size_t n = texels(16);
@@ -358,8 +475,77 @@ bool DirectX::Internal::StoreScanline(void* pDestination, size_t size, DXGI_FORM
     if (!pDestination || !size || !pSource || !count) return false;
     uint8_t* d = static_cast<uint8_t*>(pDestination);
     auto texels = [&](size_t bytes) { const size_t n = size / bytes; return n < count ? n : count; };
+    if (const IntFormat* e = int_format(format))
+    {
+        // :1674-1687, :1707-1714, :1719-1723, :1774-1781, :1801-1808, :1824-1850, :1873-1880, :1913-2016
+        const size_t bytes = size_t(e->channels * e->bits / 8);
+        for (size_t i = 0, n = texels(bytes); i < n; ++i)
+            for (int c = 0; c < e->channels; ++c)
+            {
+                const float v = pSource[i].f[c];
+                uint8_t* p = d + i * bytes + size_t(c * e->bits / 8);
+                if (e->bits == 32) { const uint32_t u = e->isSigned ? float_to_sint(v) : float_to_uint(v); memcpy(p, &u, 4); }
+                else
+                {
+                    const float hi = e->isSigned ? (e->bits == 16 ? 32767.f : 127.f) : (e->bits == 16 ? 65535.f : 255.f), lo = e->isSigned ? -hi : 0.f;
+                    const int32_t q = e->scalar ? clamp_truncate_std(v, lo, hi) : clamp_round_even(v, lo, hi);
+                    if (e->bits == 16) { const uint16_t u = uint16_t(q); memcpy(p, &u, 2); } else *p = uint8_t(q);
+                }
+            }
+        return true;
+    }
     switch (int(format))
     {
+    case DXGI_FORMAT_R10G10B10A2_UINT:          // XMStoreUDec4, :1753-1754: clamp (maxps / minps), truncate
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            auto q = [](float v, float hi) { float t = (v > 0.f) ? v : 0.f; t = (t < hi) ? t : hi; return uint32_t(int32_t(t)); };
+            const uint32_t u = q(pSource[i].f[0], 1023.f) | (q(pSource[i].f[1], 1023.f) << 10) | (q(pSource[i].f[2], 1023.f) << 20) | (q(pSource[i].f[3], 3.f) << 30);
+            memcpy(d + i * 4, &u, 4);
+        }
+        return true;
+    case DXGI_FORMAT_R10G10B10_XR_BIAS_A2_UNORM:    // XMStoreUDecN4_XR, :1750-1751
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            auto q = [](float v, float scale, float bias, float hi) { float t = v * scale + bias; t = (t > 0.f) ? t : 0.f; t = (t < hi) ? t : hi; return uint32_t(t); };
+            const uint32_t u = (q(pSource[i].f[0], 510.f, 384.f, 1023.f) & 0x3FF) | ((q(pSource[i].f[1], 510.f, 384.f, 1023.f) & 0x3FF) << 10) |
+                               ((q(pSource[i].f[2], 510.f, 384.f, 1023.f) & 0x3FF) << 20) | (q(pSource[i].f[3], 3.f, 0.f, 3.f) << 30);
+            memcpy(d + i * 4, &u, 4);
+        }
+        return true;
+    case DXGI_FORMAT_AYUV:                      // :2173-2202 (XMStoreUByteN4 on the raw vector: no bias here)
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            auto ubn = [](float v) { const float t = clampf(v, 0.f, 1.f); return int(uint32_t(t * 255.0f)); };
+            const int r = ubn(pSource[i].f[0]), g = ubn(pSource[i].f[1]), b = ubn(pSource[i].f[2]);
+            const int y = ((66 * r + 129 * g + 25 * b + 128) >> 8) + 16, u = ((-38 * r - 74 * g + 112 * b + 128) >> 8) + 128, v = ((112 * r - 94 * g - 18 * b + 128) >> 8) + 128;
+            d[i * 4 + 0] = uint8_t(std::min<int>(std::max<int>(v, 0), 255)); d[i * 4 + 1] = uint8_t(std::min<int>(std::max<int>(u, 0), 255));
+            d[i * 4 + 2] = uint8_t(std::min<int>(std::max<int>(y, 0), 255)); d[i * 4 + 3] = uint8_t(ubn(pSource[i].f[3]));
+        }
+        return true;
+    case DXGI_FORMAT_Y410:                      // :2204-2237 (XMStoreUDecN4: saturate, scale, truncate)
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            auto dec = [](float v, float scale) { const float t = clampf(v, 0.f, 1.f); return int64_t(uint32_t(t * scale)); };
+            const int64_t r = dec(pSource[i].f[0], 1023.f), g = dec(pSource[i].f[1], 1023.f), b = dec(pSource[i].f[2], 1023.f), a = dec(pSource[i].f[3], 3.f);
+            const int y = int((16780 * r + 32942 * g + 6544 * b + 32768) >> 16) + 64, u = int((-9683 * r - 19017 * g + 28700 * b + 32768) >> 16) + 512,
+                      v = int((28700 * r - 24033 * g - 4667 * b + 32768) >> 16) + 512;
+            const uint32_t w = uint32_t(std::min<int>(std::max<int>(u, 0), 1023)) | (uint32_t(std::min<int>(std::max<int>(y, 0), 1023)) << 10) |
+                               (uint32_t(std::min<int>(std::max<int>(v, 0), 1023)) << 20) | (uint32_t(a) << 30);
+            memcpy(d + i * 4, &w, 4);
+        }
+        return true;
+    case DXGI_FORMAT_Y416:                      // :2239-2272 (XMStoreUShortN4)
+        for (size_t i = 0, n = texels(8); i < n; ++i)
+        {
+            const int64_t r = store_usn(pSource[i].f[0]), g = store_usn(pSource[i].f[1]), b = store_usn(pSource[i].f[2]);
+            const int y = int((16763 * r + 32910 * g + 6537 * b + 32768) >> 16) + 4096, u = int((-9674 * r - 18998 * g + 28672 * b + 32768) >> 16) + 32768,
+                      v = int((28672 * r - 24010 * g - 4662 * b + 32768) >> 16) + 32768;
+            uint16_t h[4] = { uint16_t(std::min<int>(std::max<int>(u, 0), 65535)), uint16_t(std::min<int>(std::max<int>(y, 0), 65535)),
+                              uint16_t(std::min<int>(std::max<int>(v, 0), 65535)), store_usn(pSource[i].f[3]) };
+            memcpy(d + i * 8, h, 8);
+        }
+        return true;
     case DXGI_FORMAT_R32G32B32A32_FLOAT:
         memcpy(d, pSource, texels(16) * 16);
         return true;
@@ -581,9 +767,9 @@ void DirectX::Internal::ConvertScanline(XMVECTOR* pBuffer, size_t count, DXGI_FO
     if (!in || !out) return;
     uint32_t flags = uint32_t(tflags);
     if (is_srgb_format(inFormat)) flags |= TEX_FILTER_SRGB_IN;
-    if (inFormat == DXGI_FORMAT_A8_UNORM) flags &= ~uint32_t(TEX_FILTER_SRGB_IN);
+    if (inFormat == DXGI_FORMAT_A8_UNORM || inFormat == DXGI_FORMAT_R10G10B10_XR_BIAS_A2_UNORM) flags &= ~uint32_t(TEX_FILTER_SRGB_IN);        // :3136-3139
     if (is_srgb_format(outFormat)) flags |= TEX_FILTER_SRGB_OUT;
-    if (outFormat == DXGI_FORMAT_A8_UNORM) flags &= ~uint32_t(TEX_FILTER_SRGB_OUT);
+    if (outFormat == DXGI_FORMAT_A8_UNORM || outFormat == DXGI_FORMAT_R10G10B10_XR_BIAS_A2_UNORM) flags &= ~uint32_t(TEX_FILTER_SRGB_OUT);     // :3156-3159
     if ((flags & TEX_FILTER_SRGB) == TEX_FILTER_SRGB) flags &= ~uint32_t(TEX_FILTER_SRGB);
 
     auto each = [&](auto&& fn) { for (size_t i = 0; i < count; ++i) fn(pBuffer[i].f); };

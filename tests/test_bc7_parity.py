@@ -156,7 +156,8 @@ def test_pruning_changes_nothing():
     without (DXTEX_BC7_NO_PRUNE / DXTEX_BC6H_NO_PRUNE) must be the same bytes, and so must any legal order of the modes - and
     BC6H's one-region modes searched by a lane per task (DXTEX_BC6H_WAVE_MAX=0) or by a wavefront per task (the default for lists this
     short) are the same search, as is mode 1's PerturbOne with (default) and without (DXTEX_BC7_PERTURB_PLAIN) the bound filter, and BC6H's
-    modes of equal endpoint precision sharing one search (default) or searching each from scratch (DXTEX_BC6H_NO_REUSE)."""
+    modes of equal endpoint precision sharing one search (default) or searching each from scratch (DXTEX_BC6H_NO_REUSE), and BC7's
+    whole-block tasks (modes 4 / 5 / 6) searched by groups of lanes (default on lists this short) or a lane each (DXTEX_BC7_NO_GROUP)."""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
@@ -177,7 +178,7 @@ def test_pruning_changes_nothing():
                 print(hashlib.sha256(c.compress(hdr, w, h, 10, fmt, 0, 0.5).tobytes()).hexdigest())
     """ % root)
     outs = []
-    for env in ({}, {"DXTEX_BC7_NO_PRUNE": "1", "DXTEX_BC6H_NO_PRUNE": "1"}, {"DXTEX_BC7_ORDER": "7,6,5,8,4,3,2,1,0", "DXTEX_BC7_PERTURB_PLAIN": "1"},
+    for env in ({}, {"DXTEX_BC7_NO_PRUNE": "1", "DXTEX_BC6H_NO_PRUNE": "1"}, {"DXTEX_BC7_ORDER": "7,6,5,8,4,3,2,1,0", "DXTEX_BC7_PERTURB_PLAIN": "1", "DXTEX_BC7_NO_GROUP": "1"},
                 {"DXTEX_BC7_ORDER": "26,25,3,1,16,7,15,14,18,24,28,0,2", "DXTEX_BC6H_WAVE_MAX": "0", "DXTEX_BC6H_NO_REUSE": "1"}):
         if env:
             env = dict(env, DXTEX_AMD_LIBRARY="dev")         # only the -DDXTEX_DEV build reads knobs; the first run is the product library
