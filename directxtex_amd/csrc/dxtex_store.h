@@ -182,8 +182,11 @@ __device__ __forceinline__ uint32_t store_scaled_rne(float v, float scale)
 __device__ __forceinline__ uint32_t store_u32(float v)
 {
     const float s = (v > 0.0f) ? v : 0.0f;
-    if (s > 4294967295.0f) return 0xFFFFFFFFu;
-    return (s >= 2147483648.0f) ? (uint32_t(int32_t(s - 2147483648.0f)) ^ 0x80000000u) : uint32_t(int32_t(s));
+    if (s > 4294967295.0f) return 0xFFFFFFFFu;             // (the constant IS 2^32 in fp32, so exactly 2^32 is not an overflow there ...)
+    if (s < 2147483648.0f) return uint32_t(int32_t(s));
+    const float t = s - 2147483648.0f;
+    // ... and its detour value 2^31 converts to cvttps2dq's 0x80000000, which the final XOR turns into 0: reproduced
+    return ((t >= 2147483648.0f) ? 0x80000000u : uint32_t(int32_t(t))) ^ 0x80000000u;
 }
 // XMStoreSInt4/3/2 and XMConvertVectorFloatToInt(v, 0): truncation; above 2147483520.0f (65536 * 32768 - 128) the result is
 // 0x7FFFFFFF; below -2^31 and for NaN cvttps2dq's "integer indefinite" 0x80000000.

@@ -500,7 +500,7 @@ __device__ __forceinline__ void resize_triangle_kernel_row(ResizeArgs a, const u
         }
         i = iEnd;
     }
-    if (a.dst.format == FMT_R10G10B10A2_UNORM) acc.a = acc.a + 0.1f;       // the reference biases 2-bit alpha against accumulation error (DirectXTexMipmaps.cpp:1560-1579, DirectXTexResize.cpp:768-787)
+    if (a.dst.format == FMT_R10G10B10A2_UNORM || a.dst.format == FMT_R10G10B10A2_UINT) acc.a = acc.a + 0.1f;       // the reference biases 2-bit alpha against accumulation error (DirectXTexMipmaps.cpp:1560-1579, DirectXTexResize.cpp:768-787)
     store_linear(a.dst, x, y, a.srgbOut, acc);
 }
 __global__ void __launch_bounds__(256) resize_triangle_kernel(ResizeArgs a)
@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(256) resize3d_triangle_kernel(Resize3Args a)
         }
         h = hEnd;
     }
-    if (a.dst.format == FMT_R10G10B10A2_UNORM) acc.a = acc.a + 0.1f;       // DirectXTexMipmaps.cpp:2767-2786
+    if (a.dst.format == FMT_R10G10B10A2_UNORM || a.dst.format == FMT_R10G10B10A2_UINT) acc.a = acc.a + 0.1f;       // DirectXTexMipmaps.cpp:2767-2786
     store_linear(slice_of(a.dst, z), x, y, a.srgbOut, acc);
 }
 

@@ -130,8 +130,9 @@ namespace
     {
         const float s = (v > 0.0f) ? v : 0.0f;                                  // maxps(v, 0): NaN -> 0
         if (s > 4294967295.0f) return 0xFFFFFFFFu;
-        if (s >= 2147483648.0f) return uint32_t(int32_t(s - 2147483648.0f)) ^ 0x80000000u;
-        return uint32_t(int32_t(s));
+        if (s < 2147483648.0f) return uint32_t(int32_t(s));
+        const float t = s - 2147483648.0f;                                      // exactly 2^32 passes the overflow test (MaxUInt rounds to 2^32): t = 2^31
+        return ((t >= 2147483648.0f) ? 0x80000000u : uint32_t(int32_t(t))) ^ 0x80000000u;       // -> cvttps2dq's 0x80000000 -> 0 after the XOR
     }
     // XMStoreSInt* / XMConvertVectorFloatToInt
     inline uint32_t float_to_sint(float v)
