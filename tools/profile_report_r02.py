@@ -166,7 +166,13 @@ open(out_md, 'w').write("\n".join(L) + "\n")
 if json_out:
     dom = order[0]
     u = util.get(dom, (0, 0, 0, 0))
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("bc7_encode.hip", "bc7_core.h", "search_common.h"):       # the stamp bench.py checks (kernel_sources_sha256)
+        h.update(open(os.path.join(ROOT, "directxtex_amd", "csrc", name), "rb").read())
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     json.dump({"kernel": dominant_mark or dom, "rocprof_kernel": dom, "hbm_bytes_per_launch": int(traffic.get(dom, 0)),
+               "sources_sha256": h.hexdigest(), "git_head_at_report": head,
                "valu": {"issue_utilisation": round(min(u[0], 1.0), 3), "active_lanes_per_valu_inst": round(u[1], 1), "valu_insts_per_launch": int(u[2]),
                         "kernel_avg_ms_profiled": round(u[3] * 1e3, 3), "mean_issue_cycles_per_inst": round(mix.get(dom, (4.15, 0))[0], 2),
                         "lane_ops_per_s": round(u[2] * u[1] / max(u[3], 1e-9), 0),
