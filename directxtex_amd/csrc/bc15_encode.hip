@@ -51,17 +51,20 @@ __device__ __forceinline__ void decode565(uint32_t w, float& r, float& g, float&
 // without control flow: the middle entries are picked once per block from the step count, an entry is three selects.
 struct StepCoef
 {
-    float c1, c2, d1, d2;
+    // pC3 = {1, 1/2, 0}, pD3 = {0, 1/2, 1}; pC4 = {1, 2/3, 1/3, 0}, pD4 = {0, 1/3, 2/3, 1} (BC.cpp:26-31) as ONE multiplication each:
+    // pD[k] = k * r and pC[k] = (steps - 1 - k) * r with r = 1/2 or float(1/3). Exact for every entry: k * 0.5f is exact, and with
+    // r = 0x3EAAAAAB (1/3 rounded up) 2 r is the table's 2.0f/3.0f (a power-of-two scaling) and 3 r = 1.00000003 rounds to 1.0f.
+    // (Round 2 picked the entries with three float compare-selects per coefficient: 12 of the ~45 operations per texel and trip.)
+    float r, last;
     __device__ __forceinline__ explicit StepCoef(uint32_t cSteps)
     {
         const bool three = (cSteps == 3);
-        c1 = three ? 0.5f : (2.0f / 3.0f); c2 = three ? 0.0f : (1.0f / 3.0f);
-        d1 = three ? 0.5f : (1.0f / 3.0f); d2 = three ? 1.0f : (2.0f / 3.0f);
+        r = three ? 0.5f : (1.0f / 3.0f);
+        last = three ? 2.0f : 3.0f;
     }
-    // k = the step index as a float (0, 1, 2 or 3): float compares keep these as selects (an integer equality chain is turned into a
-    // switch, i.e. into divergent branches, by the compiler)
-    __device__ __forceinline__ float c(float k) const { return (k < 0.5f) ? 1.0f : (k < 1.5f) ? c1 : (k < 2.5f) ? c2 : 0.0f; }
-    __device__ __forceinline__ float d(float k) const { return (k < 0.5f) ? 0.0f : (k < 1.5f) ? d1 : (k < 2.5f) ? d2 : 1.0f; }
+    // k = the step index as a float (0, 1, 2 or 3)
+    __device__ __forceinline__ float c(float k) const { return (last - k) * r; }
+    __device__ __forceinline__ float d(float k) const { return k * r; }
 };
 
 // 6-D Newton endpoint fit over 16 points (BC.cpp:65-314).
