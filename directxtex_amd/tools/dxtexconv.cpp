@@ -45,6 +45,10 @@ const Name kFormats[] = {
     { "B8G8R8A8_UNORM_SRGB", 91 }, { "B8G8R8X8_UNORM_SRGB", 93 }, { "BC6H_UF16", 95 }, { "BC6H_SF16", 96 }, { "BC7_UNORM", 98 }, { "BC7_UNORM_SRGB", 99 },
     { "R32G32B32_FLOAT", 6 }, { "R16G16B16A16_SNORM", 13 }, { "R10G10B10A2_UNORM", 24 }, { "R11G11B10_FLOAT", 26 }, { "R16G16_SNORM", 37 }, { "R16_SNORM", 58 },
     { "R9G9B9E5_SHAREDEXP", 67 }, { "B5G6R5_UNORM", 85 }, { "B5G5R5A1_UNORM", 86 }, { "B4G4R4A4_UNORM", 115 },
+    { "R32G32B32A32_UINT", 3 }, { "R32G32B32A32_SINT", 4 }, { "R32G32B32_UINT", 7 }, { "R32G32B32_SINT", 8 }, { "R16G16B16A16_UINT", 12 }, { "R16G16B16A16_SINT", 14 },
+    { "R32G32_UINT", 17 }, { "R32G32_SINT", 18 }, { "R10G10B10A2_UINT", 25 }, { "R8G8B8A8_UINT", 30 }, { "R8G8B8A8_SINT", 32 }, { "R16G16_UINT", 36 }, { "R16G16_SINT", 38 },
+    { "R32_UINT", 42 }, { "R32_SINT", 43 }, { "R8G8_UINT", 50 }, { "R8G8_SINT", 52 }, { "R16_UINT", 57 }, { "R16_SINT", 59 }, { "R8_UINT", 62 }, { "R8_SINT", 64 },
+    { "R10G10B10_XR_BIAS_A2_UNORM", 89 }, { "AYUV", 100 }, { "Y410", 101 }, { "Y416", 102 },
     // texconv's aliases (texconv.cpp:420-440)
     { "DXT1", 71 }, { "DXT2", 74 }, { "DXT3", 74 }, { "DXT4", 77 }, { "DXT5", 77 }, { "RGBA", 28 }, { "BGRA", 87 }, { "BGR", 88 }, { "FP16", 10 }, { "FP32", 2 },
     { "BC4", 80 }, { "BC5", 83 }, { "BC6H", 95 }, { "BC7", 98 },
