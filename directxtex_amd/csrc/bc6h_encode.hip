@@ -33,7 +33,7 @@ namespace
 using namespace bc6h;
 
 struct Rec6 { int A[3], B[3]; float err; uint32_t valid; };        // 32 bytes per task
-struct Best6 { float err; uint32_t pad; uint64_t lo, hi; };        // 24 bytes per block
+struct Best6 { float err; uint32_t mode; uint64_t lo, hi; };       // 24 bytes per block; mode = position of the winner's mode in the encoder's order
 struct OrgSave { int A[3], B[3]; float err; uint32_t pad; uint64_t idx; };      // 40 bytes per task: Refine's unoptimised half, pre -> post
 
 enum : int { SEED_INTS = 17 * 6 + 2 };      // 8 shapes x 2 regions + the one-region seed, 6 ints each (+ pad)
@@ -61,6 +61,11 @@ struct Bc6hArgs
 
 // tinfo bit 23: the task was searched by an earlier mode of the same precision (see bc6h_pre_kernel); bits 24.. = subset size, 0..15 = texel mask
 constexpr uint32_t kDoneBit6 = 1u << 23;
+
+// Running order of the two-region modes (positions in the encoder's order, ms_aInfo :1051-1067)
+#if !defined(DXTEX_BC6H_DEFAULT_ORDER)
+#define DXTEX_BC6H_DEFAULT_ORDER "0,1,2,3,4,5,6,7,8,9"
+#endif
 
 __device__ __forceinline__ Texels slot_texels(float* slot /* &sSlot[0][0][lane] */, int np)
 {
@@ -111,7 +116,7 @@ __global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
         float* gp = a.fpix + uint64_t(nb) * 48;
         gp[lane] = ir; gp[16 + lane] = ig; gp[32 + lane] = ib;
     }
-    if (lane == 0) { Best6 b; b.err = 3.402823466e+38f; b.pad = 0; b.lo = 0; b.hi = 0; a.best[nb] = b; }
+    if (lane == 0) { Best6 b; b.err = 3.402823466e+38f; b.mode = 0xFFFFFFFFu; b.lo = 0; b.hi = 0; a.best[nb] = b; }
     wave_lds_sync();
     const float* fpx = sF[wave];
     const float* planes = sP[wave];
@@ -302,7 +307,10 @@ __device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, ui
     bool fit = endpoints_fit(o.epT, int(region), a.mode, sg);
     if (REGIONS2) { const int partner = __shfl_xor(int(fit), 1); fit = fit && (partner != 0); }     // no short-circuit around the shuffle
     // Encode() stops at the first candidate that reaches error 0 (:1823, :1851): nothing later can be strictly better
-    o.fit = fit && (a.best[nb].err > 0.0f);
+    // ... from an EARLIER mode of the encoder's order that is: the modes may run in another order here (see launch_bc6h_encode_many), and a
+    // zero reached by a later mode does not stop an earlier one, which could reach zero too and would then come first
+    const Best6 cur = a.best[nb];
+    o.fit = fit && (cur.err > 0.0f || cur.mode > uint32_t(a.mode.index));
 }
 
 template<int REGIONS2>
@@ -481,9 +489,11 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     if (valid && region == 0 && key == bestKey)
     {
         Best6* b = a.best + nb;
-        if (err < b->err)         // Refine only emits when it beats fBestErr (:2412-2424)
+        // Refine only emits when it beats fBestErr (:2412-2424): the block ends up with the FIRST minimum in the encoder's mode order. The modes
+        // of a pass run one after the other on one stream, in any order: ties go to the mode that comes first in the encoder's order.
+        if (err < b->err || (err == b->err && uint32_t(a.mode.index) < b->mode))
         {
-            Best6 n; n.err = err; n.pad = 0;
+            Best6 n; n.err = err; n.mode = uint32_t(a.mode.index);
             emit_block6(a.mode, o.shape, ep, idx, REGIONS2 ? uint32_t(kAnchor2[o.shape]) : 0u, n.lo, n.hi);
             *b = n;
         }
@@ -761,11 +771,22 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         };
         a.taskBase = 0;
         for (int m = 0; m < 4; ++m) a.prec1[m] = kModes[10 + m].prec[0];
-        // the ten two-region modes, one after the other: pre -> sort -> search -> post (post folds the mode into the running best)
+        // the ten two-region modes, one after the other: pre -> sort -> search -> post (post folds the mode into the running best, keyed by
+        // (error, position in the encoder's order), so the order they RUN in is free). What the running order changes is how good an error is
+        // on the table when a mode's pre prunes; modes of equal precision stay next to each other (they share one search).
+        static const std::vector<int> order6 = []
+        {
+            std::vector<int> o;
+            const char* e = dev_env("DXTEX_BC6H_ORDER");
+            const char* p = e ? e : DXTEX_BC6H_DEFAULT_ORDER;
+            while (*p) { if (*p >= '0' && *p <= '9') o.push_back(int(strtol(p, const_cast<char**>(&p), 10))); else ++p; }
+            return o;
+        }();
         int prevPrec = -1;
         a.samePrec = 0;
-        for (int mi = 0; mi < 10; ++mi)
+        for (int mi : order6)
         {
+            if (mi < 0 || mi > 9) continue;
             if (onlyMode >= 0 && mi != onlyMode) continue;
             set_mode(mi);
             static const bool noReuse = dev_env("DXTEX_BC6H_NO_REUSE") != nullptr;      // development A/B: search every mode from scratch

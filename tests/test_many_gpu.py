@@ -45,6 +45,7 @@ CODE = textwrap.dedent("""
     from directxtex_amd import synth
     from directxtex_amd.capi import DxtexError
     shapes = %(shapes)r
+    PARALLEL = 0x10000000              # TEX_COMPRESS_PARALLEL for the reference side only: CompressBC_Parallel, the same bytes on all host cores
     items, tight = [], []
     for k, (w, h, fmt, pad) in enumerate(shapes):
         img = synth.rgba8(w, h, seed=100 + k, alpha=("smooth", "opaque", "binary")[k %% 3])
@@ -60,7 +61,7 @@ CODE = textwrap.dedent("""
     for dst_fmt, flags in ((98, 0), (71, 0), (98, 0)):                # BC7, BC1, BC7 again (the lanes now hold BC1-sized buffers)
         got = c.compress_array(items, dst_fmt, flags, 0.5)
         for k, ((w, h, fmt, pad), g) in enumerate(zip(shapes, got)):
-            ref = oracle.ref_compress_image(tight[k], w, h, fmt, dst_fmt, flags, 0.5)
+            ref = oracle.ref_compress_image(tight[k], w, h, fmt, dst_fmt, flags | PARALLEL, 0.5)
             assert np.array_equal(g, ref), ("payload differs from the reference", dst_fmt, k, w, h, fmt)
     # a failure in the middle of the array (image 9: rowPitch below the format's minimum) must come back as the reference's HRESULT
     # without hanging, and leave the context usable
@@ -81,7 +82,7 @@ CODE = textwrap.dedent("""
     got = c.compress_array(items[:7], 98, 0, 0.5)
     for k, g in enumerate(got):
         w, h, fmt, pad = shapes[k]
-        assert np.array_equal(g, oracle.ref_compress_image(tight[k], w, h, fmt, 98, 0, 0.5)), ("after the failure", k)
+        assert np.array_equal(g, oracle.ref_compress_image(tight[k], w, h, fmt, 98, PARALLEL, 0.5)), ("after the failure", k)
     c.close()
     print("many OK")
 """)
