@@ -22,6 +22,7 @@ struct DecodeArgs
     uint8_t* dst; uint64_t dstRowPitch; int dstFormat;
     uint32_t width, height, nbw, nbh;
     int vec16;       // dst and dstRowPitch are 16-byte aligned
+    int direct8;     // BC7 -> R8G8B8A8_UNORM(_SRGB) with an empty plan: the decoder's bytes are the texels
     ConvertPlan plan;
 };
 
@@ -182,7 +183,37 @@ __device__ __forceinline__ uint32_t bc7_unq(uint32_t c, uint32_t prec)
     return s | (s >> prec);
 }
 
-__device__ __forceinline__ void decode_bc7(const uint8_t* p, Texel (&out)[16])
+// b >>= s, s < 32
+__device__ __forceinline__ void shr128(Bits128& b, uint32_t s)
+{
+    b.w0 = __builtin_amdgcn_alignbit(b.w1, b.w0, s);
+    b.w1 = __builtin_amdgcn_alignbit(b.w2, b.w1, s);
+    b.w2 = __builtin_amdgcn_alignbit(b.w3, b.w2, s);
+    b.w3 = __builtin_amdgcn_alignbit(0u, b.w3, s);
+}
+
+// v with a zero bit inserted at position p (the implicit top bit of an anchor index, :2663-2700); `on` false: v unchanged
+__device__ __forceinline__ uint64_t insert_zero(uint64_t v, uint32_t p, bool on)
+{
+    const uint64_t keep = on ? ((1ull << p) - 1ull) : ~0ull;
+    return v + (v & ~keep);
+}
+
+// 16 mask bits -> 16 two-bit fields
+__device__ __forceinline__ uint32_t spread16(uint32_t x)
+{
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// D3DX_BC7::Decode (:2566-2780) in integers: out[i] = texel i as packed R8G8B8A8 (the LDRColorA the reference converts to floats with
+// * 1/255). The block is consumed as a 128-bit shift register: the header fields, then one shift per endpoint channel (the nEnd fields
+// of a channel are at most 30 bits), then the p-bits; what remains is the first index stream. Index streams get their anchors' implicit
+// zero bits inserted once, so the 16 texels read fixed-width fields; endpoints are unquantized three colour channels at a time.
+__device__ __forceinline__ void decode_bc7_packed(const uint8_t* p, uint32_t (&out)[16])
 {
     const uint4 raw = *reinterpret_cast<const uint4*>(p);
     Bits128 b; b.w0 = raw.x; b.w1 = raw.y; b.w2 = raw.z; b.w3 = raw.w;
@@ -191,7 +222,7 @@ __device__ __forceinline__ void decode_bc7(const uint8_t* p, Texel (&out)[16])
     {
         // reserved mode 8 (or no mode bit in the first byte): transparent black (:2771-2778)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { out[i].r = out[i].g = out[i].b = out[i].a = 0.0f; }
+        for (int i = 0; i < 16; ++i) out[i] = 0u;
         return;
     }
     const uint32_t mode = uint32_t(__ffs(int(low8))) - 1u;
@@ -199,80 +230,93 @@ __device__ __forceinline__ void decode_bc7(const uint8_t* p, Texel (&out)[16])
     const uint32_t parts = mw & 3u, partBits = (mw >> 2) & 7u, pBits = (mw >> 5) & 7u, rotBits = (mw >> 8) & 3u, imBits = (mw >> 10) & 1u;
     const uint32_t ib = (mw >> 11) & 7u, ib2 = (mw >> 14) & 3u, cp = (mw >> 16) & 15u, ap = (mw >> 20) & 15u;
     const uint32_t nEnd = (parts + 1u) << 1;
-    uint32_t pos = mode + 1u;
-    const uint32_t shape = peek_bits(b, pos, partBits); pos += partBits;
-    const uint32_t rot = peek_bits(b, pos, rotBits); pos += rotBits;
-    const uint32_t im = peek_bits(b, pos, imBits); pos += imBits;
+    uint32_t pos = mode + 1u;                                    // at most 14 header bits, all in the first word
+    const uint32_t shape = __builtin_amdgcn_ubfe(b.w0, pos, partBits); pos += partBits;
+    const uint32_t rot = __builtin_amdgcn_ubfe(b.w0, pos, rotBits); pos += rotBits;
+    const uint32_t im = __builtin_amdgcn_ubfe(b.w0, pos, imBits); pos += imBits;
+    shr128(b, pos);
 
-    // endpoints, channel-major in the stream (:2618-2640); e[i] = packed RGBA of endpoint i
+    // endpoints, channel-major in the stream (:2618-2640); e[i] = packed RGBA of endpoint i. Fields of endpoints the mode does not have
+    // (i >= nEnd) read as garbage below 2^prec; no texel ever selects them.
     uint32_t e[6] = { 0, 0, 0, 0, 0, 0 };
 #pragma unroll
-    for (uint32_t ch = 0; ch < 4; ++ch)
+    for (uint32_t ch = 0; ch < 3; ++ch)
     {
-        const uint32_t prec = (ch == 3) ? ap : cp;
 #pragma unroll
-        for (uint32_t i = 0; i < 6; ++i)
-            if (i < nEnd) { e[i] |= peek_bits(b, pos, prec) << (8u * ch); pos += prec; }
+        for (uint32_t i = 0; i < 6; ++i) e[i] |= __builtin_amdgcn_ubfe(b.w0, i * cp, cp) << (8u * ch);
+        shr128(b, nEnd * cp);
     }
+#pragma unroll
+    for (uint32_t i = 0; i < 6; ++i) e[i] |= __builtin_amdgcn_ubfe(b.w0, i * ap, ap) << 24;
+    shr128(b, nEnd * ap);
     // p-bits (:2643-2660): one per endpoint, or one per endpoint pair (mode 1)
-    const uint32_t pb = peek_bits(b, pos, pBits); pos += pBits;
+    const uint32_t pb = __builtin_amdgcn_ubfe(b.w0, 0u, pBits);
+    shr128(b, pBits);
+    const uint32_t hasP = pBits ? 1u : 0u;
     const bool perPair = pBits != 0 && pBits != nEnd;
-    const uint32_t cpp = cp + (pBits ? 1u : 0u), app = (ap && pBits) ? ap + 1u : ap;
+    const uint32_t cpp = cp + hasP, app = ap ? ap + hasP : 0u;
+    const uint32_t cmask = (0xFFu >> cpp) * 0x010101u;           // the bits of (s >> cpp) that stay inside their own byte
 #pragma unroll
     for (uint32_t i = 0; i < 6; ++i)
     {
-        const uint32_t pbit = pBits ? (pb >> (perPair ? (i >> 1) : i)) & 1u : 0u;
-        uint32_t v = 0;
-#pragma unroll
-        for (uint32_t ch = 0; ch < 4; ++ch)
-        {
-            uint32_t c = (e[i] >> (8u * ch)) & 0xFFu;
-            const uint32_t pr = (ch == 3) ? ap : cp, prp = (ch == 3) ? app : cpp;
-            if (pr != prp) c = ((c << 1) | pbit) & 0xFFu;
-            c = (ch == 3 && ap == 0) ? 255u : bc7_unq(c, prp);            // colour-only modes: alpha = 255
-            v |= c << (8u * ch);
-        }
-        e[i] = v;
+        const uint32_t pbit = (pb >> (perPair ? (i >> 1) : i)) & 1u;                   // pb == 0 without p-bits
+        // D3DX_BC7::Unquantize (:826-831) of the three colour channels at once: every channel is below 2^cpp, so the left shift
+        // cannot cross a byte and the right shift's spill into the byte below is masked
+        uint32_t c3 = ((e[i] & 0xFFFFFFu) << hasP) | (pbit ? 0x010101u : 0u);
+        c3 <<= 8u - cpp;
+        c3 |= (c3 >> cpp) & cmask;
+        uint32_t al = ((e[i] >> 24) << (ap ? hasP : 0u)) | (ap ? pbit : 0u);
+        al <<= 8u - app;
+        al = ap ? (al | (al >> app)) : 255u;                                               // colour-only modes: alpha = 255
+        e[i] = c3 | (al << 24);
     }
 
-    // partition row and anchors, read once
-    const uint32_t reg2 = (parts == 1) ? uint32_t(kPart2Mask[shape]) : 0u;          // 1 bit per texel
-    const uint32_t reg3 = (parts == 2) ? kPart3Bits[shape] : 0u;                    // 2 bits per texel
-    const uint32_t an3 = (parts == 2) ? uint32_t(kAnchor3[shape]) : 0u;
-    const uint32_t anchorA = (parts == 1) ? uint32_t(kAnchor2[shape]) : (parts == 2) ? (an3 & 15u) : 0u;   // 0 == "texel 0", always an anchor
-    const uint32_t anchorB = (parts == 2) ? (an3 >> 4) : 0u;
+    // partition (2 bits per texel) and anchors, read once
+    const uint32_t reg = (parts == 2) ? kPart3Bits[shape] : (parts == 1) ? spread16(uint32_t(kPart2Mask[shape])) : 0u;
+    const uint32_t an3 = uint32_t(kAnchor3[shape]);
+    const uint32_t anchorA = (parts == 2) ? (an3 & 15u) : uint32_t(kAnchor2[shape]), anchorB = an3 >> 4;
+    const uint32_t pA = (anchorA + 1u) * ib - 1u, pB = (anchorB + 1u) * ib - 1u;
+    const uint32_t pLo = (parts == 2) ? min(pA, pB) : pA, pHi = max(pA, pB);
 
-    uint32_t pos1 = pos;                                         // first index set: 16 ib-bit fields minus one bit per anchor
-    uint32_t pos2 = pos + 16u * ib - (parts + 1u);               // second index set (modes 4 and 5)
-    const uint32_t wcBits = (ib2 && im) ? ib2 : ib, waBits = ib2 ? (im ? ib : ib2) : ib;
-    const uint32_t mc = weight_magic(wcBits), ma = weight_magic(waBits);
+    // index streams: the first is what is left in the register; the second (modes 4 and 5, ib == 2) starts 16 * ib - 1 = 31 bits later
+    uint64_t s1 = uint64_t(b.w0) | (uint64_t(b.w1) << 32);
+    uint64_t s2 = uint64_t(__builtin_amdgcn_alignbit(b.w1, b.w0, 31u)) | (uint64_t(__builtin_amdgcn_alignbit(b.w2, b.w1, 31u)) << 32);
+    s1 = insert_zero(s1, ib - 1u, true);
+    s1 = insert_zero(s1, pLo, parts >= 1);
+    s1 = insert_zero(s1, pHi, parts == 2);
+    s2 = ib2 ? insert_zero(s2, ib2 - 1u, true) : s1;
+    const uint32_t nb2 = ib2 ? ib2 : ib;
+    uint64_t sc = im ? s2 : s1, sa = im ? s1 : s2;               // colour and alpha streams (:2703-2720)
+    const uint32_t bC = im ? nb2 : ib, bA = im ? ib : nb2;
+    const uint32_t mC = (1u << bC) - 1u, mA = (1u << bA) - 1u, hC = mC >> 1, hA = mA >> 1;
+    const uint32_t magC = weight_magic(bC), magA = weight_magic(bA);
+    // rotation (:2745-2753) swaps alpha with channel rot - 1: a byte permute of the packed texel
+    const uint32_t rsel = (rot == 1) ? 0x00020103u : (rot == 2) ? 0x01020300u : (rot == 3) ? 0x02030100u : 0x03020100u;
 #pragma unroll
     for (uint32_t i = 0; i < 16; ++i)
     {
-        const bool anchor = (i == 0) || (i == anchorA) || (i == anchorB);
-        const uint32_t n1 = ib - (anchor ? 1u : 0u);
-        const uint32_t i1 = peek_bits(b, pos1, n1); pos1 += n1;
-        uint32_t i2 = 0;
-        if (ib2) { const uint32_t n2 = ib2 - (i == 0 ? 1u : 0u); i2 = peek_bits(b, pos2, n2); pos2 += n2; }
-        const uint32_t rg = ((reg2 >> i) & 1u) | ((reg3 >> (2u * i)) & 3u);
+        const uint32_t wc = uint32_t(sc) & mC, wa = uint32_t(sa) & mA;
+        sc >>= bC; sa >>= bA;
+        const uint32_t kc = __umul24(wc * 64u + hC, magC) >> 16, ka = __umul24(wa * 64u + hA, magA) >> 16;
+        const uint32_t rg = (reg >> (2u * i)) & 3u;
         const uint32_t e0 = (rg == 0) ? e[0] : (rg == 1) ? e[2] : e[4];
         const uint32_t e1 = (rg == 0) ? e[1] : (rg == 1) ? e[3] : e[5];
-        const uint32_t wc = ib2 ? (im ? i2 : i1) : i1, wa = ib2 ? (im ? i1 : i2) : i1;
-        const uint32_t kc = bc67_weight(wcBits, mc, wc), ka = bc67_weight(waBits, ma, wa);
-        uint32_t px[4];
+        const uint32_t rb = ((__umul24(e0 & 0x00FF00FFu, 64u - kc) + __umul24(e1 & 0x00FF00FFu, kc) + 0x00200020u) >> 6) & 0x00FF00FFu;
+        const uint32_t g = (__umul24((e0 >> 8) & 0xFFu, 64u - kc) + __umul24((e1 >> 8) & 0xFFu, kc) + 32u) >> 6;
+        const uint32_t al = (__umul24(e0 >> 24, 64u - ka) + __umul24(e1 >> 24, ka) + 32u) >> 6;
+        out[i] = __builtin_amdgcn_perm(0u, rb | (g << 8) | (al << 24), rsel);
+    }
+}
+
+__device__ __forceinline__ void decode_bc7(const uint8_t* p, Texel (&out)[16])
+{
+    uint32_t pk[16];
+    decode_bc7_packed(p, pk);
 #pragma unroll
-        for (uint32_t ch = 0; ch < 4; ++ch)
-        {
-            const uint32_t k = (ch == 3) ? ka : kc;
-            px[ch] = (((e0 >> (8u * ch)) & 0xFFu) * (64u - k) + ((e1 >> (8u * ch)) & 0xFFu) * k + 32u) >> 6;
-        }
-        // rotation (:2745-2753): swap alpha with channel rot-1
-        const uint32_t al = px[3];
-        if (rot == 1) { px[3] = px[0]; px[0] = al; }
-        else if (rot == 2) { px[3] = px[1]; px[1] = al; }
-        else if (rot == 3) { px[3] = px[2]; px[2] = al; }
-        out[i].r = float(px[0]) * (1.0f / 255.0f); out[i].g = float(px[1]) * (1.0f / 255.0f);
-        out[i].b = float(px[2]) * (1.0f / 255.0f); out[i].a = float(px[3]) * (1.0f / 255.0f);
+    for (int i = 0; i < 16; ++i)
+    {
+        out[i].r = float(pk[i] & 0xFFu) * (1.0f / 255.0f); out[i].g = float((pk[i] >> 8) & 0xFFu) * (1.0f / 255.0f);
+        out[i].b = float((pk[i] >> 16) & 0xFFu) * (1.0f / 255.0f); out[i].a = float(pk[i] >> 24) * (1.0f / 255.0f);
     }
 }
 
@@ -415,7 +459,35 @@ __global__ void __launch_bounds__(256) bc_decode_kernel(DecodeArgs a)
         decode_bc6h(p, a.srcFormat == FMT_BC6H_SF16, t, epLds);
     }
     else
+    {
+        if (a.direct8)
+        {
+            // float(c) * (1/255) stored with XMStoreUByteN4's bias / scale / truncate gives c back for every byte c, so the
+            // round trip through fp32 texels is skipped
+            uint32_t pk[16];
+            decode_bc7_packed(p, pk);
+            const uint32_t x0 = bx * 4, y0 = by * 4;
+            const uint32_t pw = min(4u, a.width - x0), ph = min(4u, a.height - y0);
+#pragma unroll
+            for (uint32_t y = 0; y < 4; ++y)
+            {
+                if (y < ph)
+                {
+                    uint8_t* row = a.dst + uint64_t(y0 + y) * a.dstRowPitch;
+                    if (a.vec16 && pw == 4)
+                        reinterpret_cast<uint4*>(row)[bx] = make_uint4(pk[y * 4], pk[y * 4 + 1], pk[y * 4 + 2], pk[y * 4 + 3]);
+                    else
+                    {
+#pragma unroll
+                        for (uint32_t x = 0; x < 4; ++x)
+                            if (x < pw) reinterpret_cast<uint32_t*>(row)[x0 + x] = pk[y * 4 + x];
+                    }
+                }
+            }
+            return;
+        }
         decode_bc7(p, t);
+    }
 
     const uint32_t x0 = bx * 4, y0 = by * 4;
     const uint32_t pw = min(4u, a.width - x0), ph = min(4u, a.height - y0);
@@ -459,6 +531,8 @@ hipError_t launch_bc_decode(const uint8_t* src, uint64_t srcRowPitch, int srcFor
     a.width = width; a.height = height; a.nbw = (width + 3) / 4; a.nbh = (height + 3) / 4;
     a.plan = plan;
     a.vec16 = ((reinterpret_cast<uintptr_t>(dst) | dstRowPitch) & 15u) == 0;
+    a.direct8 = (srcFormat == FMT_BC7_UNORM || srcFormat == FMT_BC7_UNORM_SRGB) && (dstFormat == FMT_R8G8B8A8_UNORM || dstFormat == FMT_R8G8B8A8_UNORM_SRGB) &&
+                !plan.srgbIn && !plan.srgbOut && plan.tcv == TCV_NONE && plan.tsw == TSW_NONE;
     const uint64_t n = uint64_t(a.nbw) * a.nbh;
     if (!n) return hipSuccess;
     const dim3 grid(uint32_t((n + 255) / 256)), wg(256);

@@ -55,3 +55,21 @@ def test_decompress_image(ctx, oracle, fmt, dst, size):
     got = ctx.decompress(payload, w, h, fmt, dst)
     ref = oracle.decompress_image(payload, w, h, fmt, dst)
     assert np.array_equal(got, ref), (fmt, dst, np.nonzero(got != ref)[0][:8])
+
+
+@pytest.mark.parametrize("fmt,dst", [(98, 28), (99, 29), (98, 29), (98, 87)])
+@pytest.mark.parametrize("size", [(256, 128), (61, 35)])
+def test_decompress_bc7_arbitrary_blocks(ctx, oracle, fmt, dst, size):
+    """BC7 -> RGBA8 leaves the decoder as bytes (no fp32 round trip) when formats and sRGB-ness agree; every mode, rotation, index
+    selector, partition and reserved pattern of arbitrary 16-byte blocks must still give DecompressBC's bytes, as must the targets
+    that keep the fp32 route (sRGB mismatch, BGRA)."""
+    w, h = size
+    nb = ((w + 3) // 4) * ((h + 3) // 4)
+    rng = np.random.default_rng(fmt * 1000 + dst + w)
+    payload = rng.integers(0, 256, (nb, 16), dtype=np.uint8)
+    payload[::9, 0] = (1 << rng.integers(0, 8, payload[::9].shape[0])).astype(np.uint8)      # every mode well represented
+    payload[5] = 0
+    payload = payload.reshape(-1)
+    got = ctx.decompress(payload, w, h, fmt, dst)
+    ref = oracle.ref_decompress_image(payload, w, h, fmt, dst)                                   # the reference's own Decompress
+    assert np.array_equal(np.asarray(got).reshape(-1).view(np.uint8), np.asarray(ref).reshape(-1).view(np.uint8)), (fmt, dst)

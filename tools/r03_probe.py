@@ -71,7 +71,18 @@ if "decode" in what:
         dst = torch.empty(dx.compute_pitch(fmt, W, H)[1], dtype=torch.uint8, device=dev)
         ctx.compress_device(src.data_ptr(), W, H, 28, dst.data_ptr(), fmt, dx.TEX_COMPRESS_BC7_QUICK if fmt == 98 else 0, 0.5)
         ms = timed(lambda: ctx.decompress_device(dst.data_ptr(), W, H, fmt, back.data_ptr(), 28))
-        print("decode %d -> RGBA8 4096^2: %.4f ms" % (fmt, ms))
+        print("decode %d -> RGBA8 4096^2: %.4f ms = %.2f TB/s algorithmic" % (fmt, ms, (dst.numel() + W * H * 4) / ms / 1e9))
+    # every BC7 mode / partition / rotation (arbitrary blocks), and BC6H of the encoder's output to RGBA16F
+    rnd = torch.randint(0, 256, (W * H,), dtype=torch.uint8, device=dev)
+    ms = timed(lambda: ctx.decompress_device(rnd.data_ptr(), W, H, 98, back.data_ptr(), 28))
+    print("decode 98 (arbitrary blocks) -> RGBA8 4096^2: %.4f ms = %.2f TB/s algorithmic" % (ms, (W * H * 5) / ms / 1e9))
+    srch = (src.view(H, W, 4).float() / 255.0).half().contiguous()
+    b6 = torch.empty(W * H, dtype=torch.uint8, device=dev); back16 = torch.empty(W * H * 8, dtype=torch.uint8, device=dev)
+    ctx.compress_device(srch.data_ptr(), W, H, 10, b6.data_ptr(), 95, 0, 0.5)
+    ms = timed(lambda: ctx.decompress_device(b6.data_ptr(), W, H, 95, back16.data_ptr(), 10))
+    print("decode 95 -> RGBA16F 4096^2: %.4f ms = %.2f TB/s algorithmic" % (ms, (W * H * 9) / ms / 1e9))
+    ms = timed(lambda: ctx.decompress_device(rnd.data_ptr(), W, H, 95, back16.data_ptr(), 10))
+    print("decode 95 (arbitrary blocks) -> RGBA16F 4096^2: %.4f ms = %.2f TB/s algorithmic" % (ms, (W * H * 9) / ms / 1e9))
 if "mips" in what:
     big = torch.from_numpy(synth.survey_rgba8(8192, 8192, 4, "random")).to(dev)
     sizes = []; w = h = 8192
