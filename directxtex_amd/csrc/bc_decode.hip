@@ -5,7 +5,7 @@
 // One lane decodes one 4x4 block to 16 fp32 texels (what the reference's BC_DECODE hooks produce), runs the
 // ConvertScanline plan and stores the texels that fall inside the image with StoreScanline semantics. Lanes of a
 // wavefront own consecutive blocks of a block row, so every one of the four row stores of a wave is contiguous.
-// The decoders keep everything in registers (BC6H: its scattered header goes through LDS); no scratch.
+// The decoders keep everything in registers; no scratch, no LDS.
 // HBM-bound: 0.5 or 1 byte read + bytes-per-texel of the target written per texel.
 #include "dxtex_kernels.h"
 #include "dxtex_store.h"
@@ -23,6 +23,7 @@ struct DecodeArgs
     uint32_t width, height, nbw, nbh;
     int vec16;       // dst and dstRowPitch are 16-byte aligned
     int direct8;     // BC7 -> R8G8B8A8_UNORM(_SRGB) with an empty plan: the decoder's bytes are the texels
+    int direct16;    // BC6H -> R16G16B16A16_FLOAT with an empty plan: the decoder's halves are the texels
     ConvertPlan plan;
 };
 
@@ -320,39 +321,66 @@ __device__ __forceinline__ void decode_bc7(const uint8_t* p, Texel (&out)[16])
     }
 }
 
-// ep: [field][lane] in LDS, field = endpoint * 3 + channel (A0, B0, A1, B1). The header is scattered bit by bit
-// (ms_aDesc, :879-1048), which needs a store whose target depends on the lane's mode: LDS takes that in one ds_or.
-__device__ __forceinline__ void decode_bc6h(const uint8_t* p, bool isSigned, Texel (&out)[16], int (*epLds)[256])
+// n <= 16 bits at a position the caller knows at compile time (the word selects fold away)
+__device__ __forceinline__ uint32_t take_bits(const Bits128& b, uint32_t pos, uint32_t n)
+{
+    const uint32_t k = pos >> 5;
+    const uint32_t lo = (k == 0) ? b.w0 : (k == 1) ? b.w1 : (k == 2) ? b.w2 : b.w3;
+    const uint32_t hi = (k == 0) ? b.w1 : (k == 1) ? b.w2 : (k == 2) ? b.w3 : 0u;
+    return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(hi, lo, pos & 31u), 0u, n);
+}
+
+// One run of the gather list (bc67_tables.h): the header bits [pos, pos + len) of a field, shifted to their place in the field
+// (the words by value: a select between loads through a reference becomes a load through a selected pointer, which pins the block
+// to scratch memory)
+__device__ __forceinline__ uint32_t bc6h_extra_run(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t d)
+{
+    const uint32_t pos = d & 127u, len = (d >> 7) & 7u, lo = (d >> 10) & 15u;
+    const uint32_t k = pos >> 5;                                 // header bits end at 82: words 0..2
+    const uint32_t wl = (k == 0) ? w0 : (k == 1) ? w1 : w2;
+    const uint32_t wh = (k == 0) ? w1 : (k == 1) ? w2 : w3;
+    uint32_t v = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(wh, wl, pos & 31u), 0u, len);      // len == 0 (no run): 0
+    const uint32_t r = __brev(v) >> ((32u - len) & 31u);                                            // stored high bit first
+    v = (d & 0x4000u) ? r : v;
+    return v << lo;
+}
+
+// D3DX_BC6H::Decode (:1658-1813): out[i] = texel i as halves, (r | g << 16, b | 1.0h << 16). The header (ms_aDesc, :879-1048) is read as
+// a gather: twelve fields at fixed positions whose lengths depend on the mode, plus up to fourteen short runs listed per mode, each with
+// a compile-time destination field - so endpoints stay in registers. `false` = reserved mode: FillWithErrorColors (:1805-1811).
+__device__ __forceinline__ bool decode_bc6h_half(const uint8_t* p, bool isSigned, uint2 (&out)[16])
 {
     const uint4 raw = *reinterpret_cast<const uint4*>(p);
     Bits128 b; b.w0 = raw.x; b.w1 = raw.y; b.w2 = raw.z; b.w3 = raw.w;
-    const uint32_t lane = threadIdx.x;
-    uint32_t mode = b.w0 & 3u, pos = 2;
-    if (mode != 0 && mode != 1) { mode = (b.w0 & 31u); pos = 5; }
+    uint32_t mode = b.w0 & 3u;
+    if (mode != 0 && mode != 1) mode = b.w0 & 31u;
     const int mi = kBc6hModeIndex[mode];
-    if (mi < 0) { fill_error(out); return; }      // reserved modes decode to opaque black (:1805-1811)
+    if (mi < 0) return false;
     const Bc6hMode info = kBc6hModes[mi];
-    const uint8_t* desc = kBc6hHeader[mi];
+    const uint64_t lens = kBc6hMainLen[mi];
+    const uint4 x0 = reinterpret_cast<const uint4*>(kBc6hExtra[mi])[0], x1 = reinterpret_cast<const uint4*>(kBc6hExtra[mi])[1];
+    const uint32_t xw[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
 
-#pragma unroll
-    for (int f = 0; f < 12; ++f) epLds[f][lane] = 0;
-    uint32_t shape = 0;
-    const uint32_t headerBits = info.regions2 ? 82u : 65u;
-    bool bad = false;
-    for (; pos < headerBits; ++pos)
-    {
-        if (!peek_bits(b, pos, 1)) continue;
-        const uint32_t f = desc[pos] >> 4, bit = desc[pos] & 15u;
-        if (f == 2) shape |= 1u << bit;
-        else if (f >= 3) { const uint32_t k = f - 3u; atomicOr(&epLds[(k & 3u) * 3u + (k >> 2)][lane], 1 << bit); }
-        else if (f == 0) bad = true;               // a set bit in an unused header position (:1703-1711)
-    }
-    if (bad) { fill_error(out); return; }
+    // (a set bit in an unused header position, :1703-1711, cannot occur: no mode has one below its header length - checked by the
+    // table generator)
+    const uint32_t shape = take_bits(b, kBc6hMainPos[0], uint32_t(lens) & 15u);
     int ep[4][3];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) ep[e][ch] = epLds[e * 3 + ch][lane];
+        for (int e = 0; e < 4; ++e)
+        {
+            const int q = 1 + 4 * ch + e;                        // field 3 + 4 * channel + endpoint, minus 2
+            if (q < 12) ep[e][ch] = int(take_bits(b, kBc6hMainPos[q], uint32_t(lens >> (4 * q)) & 15u));
+            else ep[e][ch] = 0;                                  // B1.b has no fixed position
+        }
+#pragma unroll
+    for (int sl = 0; sl < 14; ++sl)
+    {
+        const int f = kBc6hExtraField[sl] - 3;
+        const uint32_t d = (sl & 1) ? (xw[sl >> 1] >> 16) : (xw[sl >> 1] & 0xFFFFu);
+        ep[f & 3][f >> 2] |= int(bc6h_extra_run(raw.x, raw.y, raw.z, raw.w, d));
+    }
 
     // sign extension and inverse delta transform (:1735-1767)
 #pragma unroll
@@ -382,27 +410,42 @@ __device__ __forceinline__ void decode_bc6h(const uint8_t* p, bool isSigned, Tex
 
     const uint32_t sh = shape & 31u;
     const uint32_t reg2 = info.regions2 ? uint32_t(kPart2Mask[sh]) : 0u;
-    const uint32_t anchorA = info.regions2 ? uint32_t(kAnchor2[sh]) : 0u;
-    const uint32_t ibits = info.indexBits, magic = weight_magic(ibits);
-    pos = headerBits;
+    const uint32_t ibits = info.indexBits, magic = weight_magic(ibits), imask = (1u << ibits) - 1u, half = imask >> 1;
+    // indices: 46 bits from header bit 82 (two regions) or 63 bits from bit 65, the anchors' implicit zero bits inserted once
+    uint64_t st = info.regions2 ? (uint64_t(__builtin_amdgcn_alignbit(b.w3, b.w2, 18u)) | (uint64_t(b.w3 >> 18) << 32))
+                                : (uint64_t(__builtin_amdgcn_alignbit(b.w3, b.w2, 1u)) | (uint64_t(b.w3 >> 1) << 32));
+    st = insert_zero(st, ibits - 1u, true);
+    st = insert_zero(st, (uint32_t(kAnchor2[sh]) + 1u) * ibits - 1u, info.regions2 != 0);
 #pragma unroll
     for (uint32_t i = 0; i < 16; ++i)
     {
-        const uint32_t nb = ibits - ((i == 0 || i == anchorA) ? 1u : 0u);
-        const uint32_t idx = peek_bits(b, pos, nb); pos += nb;
+        const uint32_t idx = uint32_t(st) & imask;
+        st >>= ibits;
         const bool r1 = ((reg2 >> i) & 1u) != 0;
-        const int w = int(bc67_weight(ibits, magic, idx));
+        const int w = int(__umul24(idx * 64u + half, magic) >> 16);
         uint32_t h[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
         {
             const int a = r1 ? ep[2][ch] : ep[0][ch], bq = r1 ? ep[3][ch] : ep[1][ch];
             const int v = bc6h::finish_unquantize((a * (64 - w) + bq * w + 32) >> 6, isSigned);
-            h[ch] = bc6h::int_to_f16(v, isSigned);
+            h[ch] = bc6h::int_to_f16(v, isSigned) & 0xFFFFu;
         }
-        out[i].r = __half2float(__ushort_as_half(uint16_t(h[0])));
-        out[i].g = __half2float(__ushort_as_half(uint16_t(h[1])));
-        out[i].b = __half2float(__ushort_as_half(uint16_t(h[2])));
+        out[i] = make_uint2(h[0] | (h[1] << 16), h[2] | 0x3C000000u);
+    }
+    return true;
+}
+
+__device__ __forceinline__ void decode_bc6h(const uint8_t* p, bool isSigned, Texel (&out)[16])
+{
+    uint2 hv[16];
+    if (!decode_bc6h_half(p, isSigned, hv)) { fill_error(out); return; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        out[i].r = __half2float(__ushort_as_half(uint16_t(hv[i].x & 0xFFFFu)));
+        out[i].g = __half2float(__ushort_as_half(uint16_t(hv[i].x >> 16)));
+        out[i].b = __half2float(__ushort_as_half(uint16_t(hv[i].y & 0xFFFFu)));
         out[i].a = 1.0f;
     }
 }
@@ -455,8 +498,55 @@ __global__ void __launch_bounds__(256) bc_decode_kernel(DecodeArgs a)
     }
     else if constexpr (FAM == FAM_BC6H)
     {
-        __shared__ int epLds[12][256];
-        decode_bc6h(p, a.srcFormat == FMT_BC6H_SF16, t, epLds);
+        if (a.direct16)
+        {
+            // half -> float -> StoreScanline's half (clamped to +-65504) gives the decoder's bits back, except for the one infinity the
+            // signed format can produce (-32768 * 31 >> 5 = 0x7C00, the 16-bit mode), which the clamp turns into -65504
+            uint2 hv[16];
+            const bool sf = a.srcFormat == FMT_BC6H_SF16;
+            if (!decode_bc6h_half(p, sf, hv))
+            {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) hv[i] = make_uint2(0u, 0x3C000000u);                  // opaque black
+            }
+            else if (sf)
+            {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                {
+                    // magnitudes never exceed 0x7C00, so "bit 10..14 all set" is exactly the infinity
+                    const uint32_t ix = hv[i].x & 0x7C007C00u, iy = hv[i].y & 0x00007C00u;
+                    uint32_t fx = 0u;
+                    if ((ix & 0xFFFFu) == 0x7C00u) fx |= 0x00000001u;
+                    if ((ix >> 16) == 0x7C00u) fx |= 0x00010000u;
+                    hv[i].x -= fx;                                                                  // 0x7C00 -> 0x7BFF, sign kept
+                    hv[i].y -= (iy == 0x7C00u) ? 1u : 0u;
+                }
+            }
+            const uint32_t x0 = bx * 4, y0 = by * 4;
+            const uint32_t pw = min(4u, a.width - x0), ph = min(4u, a.height - y0);
+#pragma unroll
+            for (uint32_t y = 0; y < 4; ++y)
+            {
+                if (y < ph)
+                {
+                    uint8_t* row = a.dst + uint64_t(y0 + y) * a.dstRowPitch;
+                    if (a.vec16 && pw == 4)
+                    {
+                        reinterpret_cast<uint4*>(row)[bx * 2] = make_uint4(hv[y * 4].x, hv[y * 4].y, hv[y * 4 + 1].x, hv[y * 4 + 1].y);
+                        reinterpret_cast<uint4*>(row)[bx * 2 + 1] = make_uint4(hv[y * 4 + 2].x, hv[y * 4 + 2].y, hv[y * 4 + 3].x, hv[y * 4 + 3].y);
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (uint32_t x = 0; x < 4; ++x)
+                            if (x < pw) reinterpret_cast<uint2*>(row)[x0 + x] = hv[y * 4 + x];
+                    }
+                }
+            }
+            return;
+        }
+        decode_bc6h(p, a.srcFormat == FMT_BC6H_SF16, t);
     }
     else
     {
@@ -533,6 +623,8 @@ hipError_t launch_bc_decode(const uint8_t* src, uint64_t srcRowPitch, int srcFor
     a.vec16 = ((reinterpret_cast<uintptr_t>(dst) | dstRowPitch) & 15u) == 0;
     a.direct8 = (srcFormat == FMT_BC7_UNORM || srcFormat == FMT_BC7_UNORM_SRGB) && (dstFormat == FMT_R8G8B8A8_UNORM || dstFormat == FMT_R8G8B8A8_UNORM_SRGB) &&
                 !plan.srgbIn && !plan.srgbOut && plan.tcv == TCV_NONE && plan.tsw == TSW_NONE;
+    a.direct16 = (srcFormat == FMT_BC6H_UF16 || srcFormat == FMT_BC6H_SF16) && dstFormat == FMT_R16G16B16A16_FLOAT &&
+                 !plan.srgbIn && !plan.srgbOut && plan.tcv == TCV_NONE && plan.tsw == TSW_NONE;
     const uint64_t n = uint64_t(a.nbw) * a.nbh;
     if (!n) return hipSuccess;
     const dim3 grid(uint32_t((n + 255) / 256)), wg(256);

@@ -73,3 +73,30 @@ def test_decompress_bc7_arbitrary_blocks(ctx, oracle, fmt, dst, size):
     got = ctx.decompress(payload, w, h, fmt, dst)
     ref = oracle.ref_decompress_image(payload, w, h, fmt, dst)                                   # the reference's own Decompress
     assert np.array_equal(np.asarray(got).reshape(-1).view(np.uint8), np.asarray(ref).reshape(-1).view(np.uint8)), (fmt, dst)
+
+
+@pytest.mark.parametrize("fmt,dst", [(95, 10), (96, 10), (96, 2), (95, 2)])
+@pytest.mark.parametrize("size", [(256, 128), (61, 35)])
+def test_decompress_bc6h_arbitrary_blocks(ctx, oracle, fmt, dst, size):
+    """BC6H -> RGBA16F stores the decoder's halves directly; arbitrary 16-byte blocks (all 14 modes, reserved modes, every header bit)
+    must give the reference's Decompress bytes - including the one infinity the signed format can decode to (a 16-bit endpoint of
+    -32768), which StoreScanline's half clamp turns into -65504 but an fp32 target keeps."""
+    w, h = size
+    nb = ((w + 3) // 4) * ((h + 3) // 4)
+    rng = np.random.default_rng(fmt * 1000 + dst + w)
+    payload = rng.integers(0, 256, (nb, 16), dtype=np.uint8)
+    inf = np.zeros(16, np.uint8)
+    inf[0] = 0x0F                      # mode 0x0f (16:4), one region
+    inf[4] = 0x80                      # header bit 39 = bit 15 of the red base endpoint: -32768 when signed
+    payload[3] = inf
+    payload[7, 1:] = 0                 # mode bits only
+    payload = payload.reshape(-1)
+    got = ctx.decompress(payload, w, h, fmt, dst)
+    ref = oracle.ref_decompress_image(payload, w, h, fmt, dst)
+    g = np.asarray(got).reshape(-1).view(np.uint8); r = np.asarray(ref).reshape(-1).view(np.uint8)
+    assert np.array_equal(g, r), (fmt, dst, np.nonzero(g != r)[0][:8])
+    if fmt == 96:
+        bpt = 8 if dst == 10 else 16
+        texel = r.reshape(h, w, bpt)[0, 12]                                                  # block 3, row 0
+        red = texel[:2].view(np.float16)[0] if dst == 10 else texel[:4].view(np.float32)[0]
+        assert (red == -65504.0) if dst == 10 else np.isneginf(red), red
