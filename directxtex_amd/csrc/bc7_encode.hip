@@ -51,7 +51,8 @@ struct Bc7Args
                              // Encode() returns there (:2803, :2835, :2845), so later candidates are never looked at
     uint2* seeds1;           // per block: the whole-block RGB fit (modes 4, 5) and RGBA fit (mode 6), :3541-3568
     uint2* seeds3;           // BC7_USE_3SUBSETS only: per block 64 shapes x 3 subsets (modes 0 and 2)
-    uint2* seeds;            // per block 64 shapes x 2 subsets: the float-fit endpoints RoughMSE derives (:3526-3552), reused by Refine
+    uint2* seeds;            // per block 2 lists (3-bit, 2-bit rough error) x 16 ranked shapes x 2 subsets: the float-fit endpoints RoughMSE
+                             // derives (:3526-3552) for the shapes Refine will look at (the fits of the other shapes are never read again)
     int* bestErr;            // per block: smallest error an already finished mode reached (subset_lower_bound prunes against it)
     int prune;               // 0 = search every candidate like the reference does (DXTEX_BC7_NO_PRUNE, for A/B runs)
     const uint32_t* flagged; // [0] = blocks of this pass flagged for an early mode 6, [1] = blocks with alpha (bc7_flag_count_kernel)
@@ -105,6 +106,7 @@ __global__ void __launch_bounds__(256, DXTEX_ROUGH_WGS) bc7_rough_kernel(Bc7Args
 {
     __shared__ float sF[4][64];
     __shared__ uint32_t sL[4][16];
+    __shared__ uint2 sSeed[4][128];    // the fits of all 64 shapes x 2 subsets; only the ranked ones leave the kernel
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nb = blockIdx.x * 4 + wave;
     if (nb >= a.nblocks) return;       // whole wave exits together
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(256, DXTEX_ROUGH_WGS) bc7_rough_kernel(Bc7Args
             if (rg.np == 1) { A = pix[rg.pos(0)]; B = A; }
             else if (rg.np == 2) { A = pix[rg.pos(0)]; B = pix[rg.pos(1)]; }
             else seed_endpoints<true>(fpx, m, A, B);
-            a.seeds[uint64_t(nb) * 128 + shape * 2 + r] = make_uint2(A, B);      // Refine starts from the same fit (:3411-3417)
+            sSeed[wave][shape * 2 + r] = make_uint2(A, B);                        // Refine starts from the same fit (:3411-3417)
             e3 += rough_error<3, 0>(rg, A, B);
             e2 += rough_error<2, 0>(rg, A, B);
         }
@@ -157,6 +159,18 @@ __global__ void __launch_bounds__(256, DXTEX_ROUGH_WGS) bc7_rough_kernel(Bc7Args
             selection_pass(eb, sb, lane, i);
         }
         if (lane < 16) { lst[lane] = uint8_t(sa); lst[16 + lane] = uint8_t(sb); }
+        {
+            // lanes 0-15: the shapes ranked by 3-bit error (mode 1), lanes 16-31: by 2-bit error (modes 3, 7); 16 bytes per lane, 512 per block
+            wave_lds_sync();
+            uint32_t ranked2 = uint32_t(__shfl(int(sb), lane & 15));
+            asm volatile("" : "+v"(ranked2));      // keeps the exchange out of the lanes >= 16 branch, where its source lanes would be off
+            const uint32_t mine = (lane < 16) ? sa : ranked2;
+            if (lane < 32)
+            {
+                const uint2 s0 = sSeed[wave][mine * 2], s1 = sSeed[wave][mine * 2 + 1];
+                reinterpret_cast<uint4*>(a.seeds + uint64_t(nb) * 64)[lane] = make_uint4(s0.x, s0.y, s1.x, s1.y);
+            }
+        }
         if (lane == 0)
         {
             lst[32] = hasAlpha ? 1 : 0;
@@ -371,7 +385,7 @@ __global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
     {
         SubsetResult res; int np; Region rg; Block16 b16;
         task_org<MODE, IM>(nullptr, &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
-                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G)
+                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 64 + (TM::LIST ? 32 : 0) + r
                                          : (TM::NS == 1) ? a.seeds1 + uint64_t(nb) * 2 : a.seeds3 + uint64_t(nb) * 192 + shape * 3 + (r % TM::G));
         rec.A = res.orgA; rec.B = res.orgB; rec.err = res.orgErr;
         rec.np = (res.orgErr != 0) ? uint32_t(np) : 0u;        // error 0: OptimizeOne cannot move the endpoints
@@ -1091,7 +1105,7 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
     {
         int np; Region rg; Block16 b16;
         task_org<MODE, IM>(nullptr, &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
-                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 128 + shape * 2 + (r % TM::G)
+                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 64 + (TM::LIST ? 32 : 0) + r
                                          : (TM::NS == 1) ? a.seeds1 + uint64_t(nb) * 2 : a.seeds3 + uint64_t(nb) * 192 + shape * 3 + (r % TM::G));
         const TaskRec rec = a.recs[uint64_t(nb) * TM::TPB + r];
         if (TM::NS == 1) refine_post<MODE, IM>(b16, rec.A, rec.B, 0u, res);
@@ -1240,7 +1254,7 @@ struct ScratchLayout
         counters = o; o = up(o + 64 * sizeof(uint32_t));
         zeroOrd = o; o = up(o + nb * sizeof(uint32_t));
         bestErr = o; o = up(o + nb * sizeof(int));
-        seeds = o; o = up(o + nb * 128 * sizeof(uint2));
+        seeds = o; o = up(o + nb * 64 * sizeof(uint2));
         seeds1 = o; o = up(o + nb * 2 * sizeof(uint2));
         seeds3 = o; o = up(o + (threeSubsets ? nb * 192 * sizeof(uint2) : 0));
         flagcnt = o; o = up(o + 256);
