@@ -13,6 +13,7 @@
 // This translation unit must be compiled with -ffp-contract=off (see csrc/Makefile).
 #include "dxtex_device.h"
 #include "dxtex_dev.h"
+#include "dxtex_kernels.h"
 
 namespace dxtex
 {
@@ -982,6 +983,48 @@ __global__ void __launch_bounds__(kPoolLanes) bc13_pooled_kernel(EncodeArgs a)
 
 // KIND: 1..3 = BC1..BC3, 4/5 = BC4/BC5 unsigned, 6/7 = BC4/BC5 signed. One instantiation per format keeps
 // each kernel's register footprint to what that codec needs.
+// One block from a tile of floats (any source format, partial blocks, conversions): block `nb` of the image behind `a`
+template<int KIND, bool DITHER>
+__device__ __forceinline__ void encode_block_generic(const EncodeArgs& a, uint32_t nb)
+{
+    const uint32_t by = nb / a.nbw, bx = nb - by * a.nbw;
+    uint8_t* out = a.dst + uint64_t(by) * a.dstRowPitch;
+    Tile t;
+    load_tile(a.src, bx, by, t);
+
+    if constexpr (KIND == 1)
+    {
+        if (a.flags & BCF_DITHER_A) bc1_dither_alpha(t.a);
+        reinterpret_cast<uint2*>(out)[bx] = [&] { TileView tv{ t, t.a }; return encode_bc1_color<DITHER>(tv, true, a.threshold, a.flags); }();
+    }
+    else if constexpr (KIND == 2)
+    {
+        const uint2 al = encode_bc2_alpha(t.a, a.flags);
+        const uint2 c = [&] { TileView tv{ t, t.a }; return encode_bc1_color<DITHER>(tv, false, 0.0f, a.flags); }();
+        reinterpret_cast<uint4*>(out)[bx] = make_uint4(al.x, al.y, c.x, c.y);
+    }
+    else if constexpr (KIND == 3)
+    {
+        const uint2 al = encode_bc3_alpha(t.a, a.flags);
+        const uint2 c = [&] { TileView tv{ t, t.a }; return encode_bc1_color<DITHER>(tv, false, 0.0f, a.flags); }();
+        reinterpret_cast<uint4*>(out)[bx] = make_uint4(al.x, al.y, c.x, c.y);
+    }
+    else if constexpr (KIND == 4)
+        reinterpret_cast<uint2*>(out)[bx] = encode_bc4_channel<false>(t.r);
+    else if constexpr (KIND == 6)
+        reinterpret_cast<uint2*>(out)[bx] = encode_bc4_channel<true>(t.r);
+    else if constexpr (KIND == 5)
+    {
+        const uint2 u = encode_bc4_channel<false>(t.r), v = encode_bc4_channel<false>(t.g);
+        reinterpret_cast<uint4*>(out)[bx] = make_uint4(u.x, u.y, v.x, v.y);
+    }
+    else
+    {
+        const uint2 u = encode_bc4_channel<true>(t.r), v = encode_bc4_channel<true>(t.g);
+        reinterpret_cast<uint4*>(out)[bx] = make_uint4(u.x, u.y, v.x, v.y);
+    }
+}
+
 #if !defined(DXTEX_BC15_PACKED_WGS)
 #define DXTEX_BC15_PACKED_WGS 3        // workgroups per CU the packed-tile instantiation is compiled for
 #endif
@@ -1035,42 +1078,26 @@ __global__ void __launch_bounds__(256, PACKED8 ? DXTEX_BC15_PACKED_WGS : 1) bc15
         return;
     }
     else
-    {
-    Tile t;
-    load_tile(a.src, bx, by, t);
+        encode_block_generic<KIND, DITHER>(a, nb);
+}
 
-    if constexpr (KIND == 1)
-    {
-        if (a.flags & BCF_DITHER_A) bc1_dither_alpha(t.a);
-        reinterpret_cast<uint2*>(out)[bx] = [&] { TileView tv{ t, t.a }; return encode_bc1_color<DITHER>(tv, true, a.threshold, a.flags); }();
-    }
-    else if constexpr (KIND == 2)
-    {
-        const uint2 al = encode_bc2_alpha(t.a, a.flags);
-        const uint2 c = [&] { TileView tv{ t, t.a }; return encode_bc1_color<DITHER>(tv, false, 0.0f, a.flags); }();
-        reinterpret_cast<uint4*>(out)[bx] = make_uint4(al.x, al.y, c.x, c.y);
-    }
-    else if constexpr (KIND == 3)
-    {
-        const uint2 al = encode_bc3_alpha(t.a, a.flags);
-        const uint2 c = [&] { TileView tv{ t, t.a }; return encode_bc1_color<DITHER>(tv, false, 0.0f, a.flags); }();
-        reinterpret_cast<uint4*>(out)[bx] = make_uint4(al.x, al.y, c.x, c.y);
-    }
-    else if constexpr (KIND == 4)
-        reinterpret_cast<uint2*>(out)[bx] = encode_bc4_channel<false>(t.r);
-    else if constexpr (KIND == 6)
-        reinterpret_cast<uint2*>(out)[bx] = encode_bc4_channel<true>(t.r);
-    else if constexpr (KIND == 5)
-    {
-        const uint2 u = encode_bc4_channel<false>(t.r), v = encode_bc4_channel<false>(t.g);
-        reinterpret_cast<uint4*>(out)[bx] = make_uint4(u.x, u.y, v.x, v.y);
-    }
-    else
-    {
-        const uint2 u = encode_bc4_channel<true>(t.r), v = encode_bc4_channel<true>(t.g);
-        reinterpret_cast<uint4*>(out)[bx] = make_uint4(u.x, u.y, v.x, v.y);
-    }
-    }
+// Several SMALL images in one launch (the tail of a mip chain, a set of icons): a kernel over one of them lasts as long as its slowest
+// block - about 15 us, whatever the size below 256^2 - so a launch each is a serial chain of latencies; together they are one.
+constexpr int kMultiMax = 12;
+constexpr uint32_t kMultiMaxBlocks = 4096;           // images of at most 256 x 256 texels
+struct MultiImage { SrcView src; uint8_t* dst; uint64_t dstRowPitch; uint32_t nbw, nbh, first, pad; };
+struct MultiArgs { MultiImage img[kMultiMax]; uint32_t n, total; int dstFormat; uint32_t flags; float threshold; };
+template<int KIND, bool DITHER>
+__global__ void __launch_bounds__(256) bc15_encode_multi_kernel(MultiArgs m)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= m.total) return;
+    uint32_t i = 0;
+    for (uint32_t k = 1; k < m.n; ++k) if (m.img[k].first <= g) i = k;
+    EncodeArgs a;
+    a.src = m.img[i].src; a.dst = m.img[i].dst; a.dstRowPitch = m.img[i].dstRowPitch; a.nbw = m.img[i].nbw; a.nbh = m.img[i].nbh;
+    a.dstFormat = m.dstFormat; a.flags = m.flags; a.threshold = m.threshold;
+    encode_block_generic<KIND, DITHER>(a, g - m.img[i].first);
 }
 } // namespace
 
@@ -1122,6 +1149,43 @@ hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowP
     }
 #undef DXTEX_LAUNCH2
 #undef DXTEX_LAUNCH
+    return hipGetLastError();
+}
+bool bc15_small_image(uint32_t width, uint32_t height) { return uint64_t((width + 3) / 4) * ((height + 3) / 4) <= kMultiMaxBlocks; }
+int bc15_small_batch_max() { return kMultiMax; }
+
+hipError_t launch_bc15_encode_small(const BcImage* images, int count, int dstFormat, uint32_t flags, float threshold, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    if (count > kMultiMax) return hipErrorInvalidValue;
+    MultiArgs m;
+    uint32_t total = 0;
+    for (int i = 0; i < count; ++i)
+    {
+        MultiImage& g = m.img[i];
+        g.src = images[i].src; g.dst = images[i].dst; g.dstRowPitch = images[i].dstRowPitch;
+        g.nbw = (images[i].src.width + 3) / 4; g.nbh = (images[i].src.height + 3) / 4; g.first = total; g.pad = 0;
+        total += g.nbw * g.nbh;
+    }
+    for (int i = count; i < kMultiMax; ++i) m.img[i] = m.img[0];
+    m.n = uint32_t(count); m.total = total; m.dstFormat = dstFormat; m.flags = flags; m.threshold = threshold;
+    if (!total) return hipSuccess;
+    const dim3 grid((total + 255) / 256), block(256);
+    const bool dither = (flags & BCF_DITHER_RGB) != 0;
+#define DXTEX_MULTI(KIND) do { if (dither) hipLaunchKernelGGL((bc15_encode_multi_kernel<KIND, true>), grid, block, 0, stream, m); \
+                               else hipLaunchKernelGGL((bc15_encode_multi_kernel<KIND, false>), grid, block, 0, stream, m); } while (0)
+    switch (dstFormat)
+    {
+    case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: DXTEX_MULTI(1); break;
+    case FMT_BC2_UNORM: case FMT_BC2_UNORM_SRGB: DXTEX_MULTI(2); break;
+    case FMT_BC3_UNORM: case FMT_BC3_UNORM_SRGB: DXTEX_MULTI(3); break;
+    case FMT_BC4_UNORM: hipLaunchKernelGGL((bc15_encode_multi_kernel<4, false>), grid, block, 0, stream, m); break;
+    case FMT_BC5_UNORM: hipLaunchKernelGGL((bc15_encode_multi_kernel<5, false>), grid, block, 0, stream, m); break;
+    case FMT_BC4_SNORM: hipLaunchKernelGGL((bc15_encode_multi_kernel<6, false>), grid, block, 0, stream, m); break;
+    case FMT_BC5_SNORM: hipLaunchKernelGGL((bc15_encode_multi_kernel<7, false>), grid, block, 0, stream, m); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef DXTEX_MULTI
     return hipGetLastError();
 }
 } // namespace dxtex

@@ -22,7 +22,7 @@ struct DecodeArgs
     uint8_t* dst; uint64_t dstRowPitch; int dstFormat;
     uint32_t width, height, nbw, nbh;
     int vec16;       // dst and dstRowPitch are 16-byte aligned
-    int direct8;     // BC7 -> R8G8B8A8_UNORM(_SRGB) with an empty plan: the decoder's bytes are the texels
+    int direct8;     // BC1-3 / BC7 -> R8G8B8A8_UNORM(_SRGB), BC4 -> R8, BC5 -> R8G8 with an empty plan: texels are picked from stored palette bytes
     int direct16;    // BC6H -> R16G16B16A16_FLOAT with an empty plan: the decoder's halves are the texels
     ConvertPlan plan;
 };
@@ -30,13 +30,13 @@ struct DecodeArgs
 // XMVectorLerp(a, b, t) = a + (b - a) * t, unfused (DirectXMath, SSE2 shape)
 __device__ __forceinline__ float lerp1(float a, float b, float t) { return a + (b - a) * t; }
 
-__device__ __forceinline__ void decode_bc1(const uint8_t* p, bool isbc1, Texel (&out)[16])
+// The four colours of a BC1-style colour block (D3DXDecodeBC1's clr[], BC.cpp:318-364) and its 2-bit index word
+__device__ __forceinline__ void bc1_palette(const uint8_t* p, bool isbc1, Texel (&clr)[4], uint32_t& bitmap)
 {
     const uint32_t c01 = *reinterpret_cast<const uint32_t*>(p);
-    const uint32_t bitmap = *reinterpret_cast<const uint32_t*>(p + 4);
+    bitmap = *reinterpret_cast<const uint32_t*>(p + 4);
     const uint32_t w0 = c01 & 0xFFFF, w1 = c01 >> 16;
     // XMLoadU565 -> (x = bits 0-4, y = bits 5-10, z = bits 11-15) * (1/31, 1/63, 1/31), swizzled to (z, y, x)
-    Texel clr[4];
     const uint32_t ws[2] = { w0, w1 };
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -59,6 +59,12 @@ __device__ __forceinline__ void decode_bc1(const uint8_t* p, bool isbc1, Texel (
         clr[3].r = lerp1(clr[0].r, clr[1].r, 2.0f / 3.0f); clr[3].g = lerp1(clr[0].g, clr[1].g, 2.0f / 3.0f);
         clr[3].b = lerp1(clr[0].b, clr[1].b, 2.0f / 3.0f); clr[3].a = lerp1(clr[0].a, clr[1].a, 2.0f / 3.0f);
     }
+}
+
+__device__ __forceinline__ void decode_bc1(const uint8_t* p, bool isbc1, Texel (&out)[16])
+{
+    Texel clr[4]; uint32_t bitmap;
+    bc1_palette(p, isbc1, clr, bitmap);
 #pragma unroll
     for (int i = 0; i < 16; ++i)
     {
@@ -70,40 +76,54 @@ __device__ __forceinline__ void decode_bc1(const uint8_t* p, bool isbc1, Texel (
     }
 }
 
-__device__ __forceinline__ void decode_bc3_alpha(const uint8_t* p, Texel (&out)[16])
+// Eight-entry palettes are kept in eight separate scalars, not an array: the optimiser rewrites a select chain over the elements of
+// one array into a load with a per-lane index, which pins the array to scratch or LDS.
+#define DXTEX_PAL8(n) float n##0, n##1, n##2, n##3, n##4, n##5, n##6, n##7
+#define DXTEX_PAL8_ARGS(n) n##0, n##1, n##2, n##3, n##4, n##5, n##6, n##7
+#define DXTEX_PAL8_REFS(n) float& n##0, float& n##1, float& n##2, float& n##3, float& n##4, float& n##5, float& n##6, float& n##7
+
+// The eight alpha values of a BC3 alpha block (D3DXDecodeBC3, BC.cpp:902-941: multiplications by 1/7 and 1/5)
+__device__ __forceinline__ void bc3_alpha_palette(uint64_t d, DXTEX_PAL8_REFS(f))
 {
-    const uint64_t d = *reinterpret_cast<const uint64_t*>(p);
     const uint32_t a0 = uint32_t(d & 0xFF), a1 = uint32_t((d >> 8) & 0xFF);
-    float f[8];
-    f[0] = float(a0) * (1.0f / 255.0f);
-    f[1] = float(a1) * (1.0f / 255.0f);
+    f0 = float(a0) * (1.0f / 255.0f);
+    f1 = float(a1) * (1.0f / 255.0f);
     if (a0 > a1)
     {
-#pragma unroll
-        for (int i = 1; i < 7; ++i) f[i + 1] = (f[0] * float(7 - i) + f[1] * float(i)) * (1.0f / 7.0f);
+        f2 = (f0 * 6.0f + f1 * 1.0f) * (1.0f / 7.0f); f3 = (f0 * 5.0f + f1 * 2.0f) * (1.0f / 7.0f); f4 = (f0 * 4.0f + f1 * 3.0f) * (1.0f / 7.0f);
+        f5 = (f0 * 3.0f + f1 * 4.0f) * (1.0f / 7.0f); f6 = (f0 * 2.0f + f1 * 5.0f) * (1.0f / 7.0f); f7 = (f0 * 1.0f + f1 * 6.0f) * (1.0f / 7.0f);
     }
     else
     {
-#pragma unroll
-        for (int i = 1; i < 5; ++i) f[i + 1] = (f[0] * float(5 - i) + f[1] * float(i)) * (1.0f / 5.0f);
-        f[6] = 0.0f; f[7] = 1.0f;
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-    {
-        const uint32_t s = uint32_t(d >> (16 + 3 * i)) & 7u;
-        float v = f[0];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) v = (s == uint32_t(k)) ? f[k] : v;
-        out[i].a = v;
+        f2 = (f0 * 4.0f + f1 * 1.0f) * (1.0f / 5.0f); f3 = (f0 * 3.0f + f1 * 2.0f) * (1.0f / 5.0f);
+        f4 = (f0 * 2.0f + f1 * 3.0f) * (1.0f / 5.0f); f5 = (f0 * 1.0f + f1 * 4.0f) * (1.0f / 5.0f);
+        f6 = 0.0f; f7 = 1.0f;
     }
 }
 
-// BC4_UNORM::R / BC4_SNORM::R (BC4BC5.cpp:36-151): true divisions, unlike BC3's alpha
-__device__ __forceinline__ float bc4_value(uint64_t d, int i, bool isSigned)
+#define DXTEX_PAL8_VALS(n) float n##0, float n##1, float n##2, float n##3, float n##4, float n##5, float n##6, float n##7
+__device__ __forceinline__ float select8(uint32_t s, DXTEX_PAL8_VALS(f))
 {
-    const uint32_t idx = uint32_t(d >> (16 + 3 * i)) & 7u;
-    float f0, f1; bool gt;
+    float v = f0;
+    v = (s == 1u) ? f1 : v; v = (s == 2u) ? f2 : v; v = (s == 3u) ? f3 : v; v = (s == 4u) ? f4 : v;
+    v = (s == 5u) ? f5 : v; v = (s == 6u) ? f6 : v; v = (s == 7u) ? f7 : v;
+    return v;
+}
+
+__device__ __forceinline__ void decode_bc3_alpha(const uint8_t* p, Texel (&out)[16])
+{
+    const uint64_t d = *reinterpret_cast<const uint64_t*>(p);
+    DXTEX_PAL8(f);
+    bc3_alpha_palette(d, DXTEX_PAL8_ARGS(f));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i].a = select8(uint32_t(d >> (16 + 3 * i)) & 7u, DXTEX_PAL8_ARGS(f));
+}
+
+// The eight values of a BC4 / BC5 channel block: BC4_UNORM::R / BC4_SNORM::R (BC4BC5.cpp:36-151) for index 0..7 - true divisions,
+// unlike BC3's alpha
+__device__ __forceinline__ void bc4_palette(uint64_t d, bool isSigned, DXTEX_PAL8_REFS(f))
+{
+    bool gt;
     if (isSigned)
     {
         int r0 = int(int8_t(d & 0xFF)), r1 = int(int8_t((d >> 8) & 0xFF));
@@ -118,14 +138,27 @@ __device__ __forceinline__ float bc4_value(uint64_t d, int i, bool isSigned)
         gt = r0 > r1;
         f0 = float(r0) / 255.0f; f1 = float(r1) / 255.0f;
     }
-    if (idx == 0) return f0;
-    if (idx == 1) return f1;
-    if (gt) { const uint32_t k = idx - 1; return (f0 * float(7u - k) + f1 * float(k)) / 7.0f; }
-    if (idx == 6) return isSigned ? -1.0f : 0.0f;
-    if (idx == 7) return 1.0f;
-    const uint32_t k = idx - 1;
-    return (f0 * float(5u - k) + f1 * float(k)) / 5.0f;
+    if (gt)
+    {
+        f2 = (f0 * 6.0f + f1 * 1.0f) / 7.0f; f3 = (f0 * 5.0f + f1 * 2.0f) / 7.0f; f4 = (f0 * 4.0f + f1 * 3.0f) / 7.0f;
+        f5 = (f0 * 3.0f + f1 * 4.0f) / 7.0f; f6 = (f0 * 2.0f + f1 * 5.0f) / 7.0f; f7 = (f0 * 1.0f + f1 * 6.0f) / 7.0f;
+    }
+    else
+    {
+        f2 = (f0 * 4.0f + f1 * 1.0f) / 5.0f; f3 = (f0 * 3.0f + f1 * 2.0f) / 5.0f;
+        f4 = (f0 * 2.0f + f1 * 3.0f) / 5.0f; f5 = (f0 * 1.0f + f1 * 4.0f) / 5.0f;
+        f6 = isSigned ? -1.0f : 0.0f; f7 = 1.0f;
+    }
 }
+
+// Byte selectors (v_perm_b32) for the four texels of row y of a 3-bit index block: byte k of the result = index of texel 4y + k
+__device__ __forceinline__ uint32_t row_selector3(uint64_t d, uint32_t y)
+{
+    const uint32_t x = uint32_t(d >> (16u + 12u * y)) & 0xFFFu;
+    return (x & 7u) | ((x & 0x38u) << 5) | ((x & 0x1C0u) << 10) | ((x & 0xE00u) << 15);
+}
+// eight palette bytes (lo = entries 0-3, hi = 4-7) -> the four bytes of a row
+__device__ __forceinline__ uint32_t row_bytes3(uint32_t lo, uint32_t hi, uint64_t d, uint32_t y) { return __builtin_amdgcn_perm(hi, lo, row_selector3(d, y)); }
 
 // ---- BC6H / BC7 -------------------------------------------------------------------------------------------------------
 // Everything below is written so that no array is ever indexed by a per-lane value: endpoints live in constant-indexed
@@ -465,12 +498,71 @@ __global__ void __launch_bounds__(256) bc_decode_kernel(DecodeArgs a)
     Texel t[16];
     if constexpr (FAM == FAM_BC123)
     {
-        if (a.srcFormat == FMT_BC1_UNORM || a.srcFormat == FMT_BC1_UNORM_SRGB)
+        const bool isbc1 = a.srcFormat == FMT_BC1_UNORM || a.srcFormat == FMT_BC1_UNORM_SRGB;
+        const bool isbc2 = a.srcFormat == FMT_BC2_UNORM || a.srcFormat == FMT_BC2_UNORM_SRGB;
+        if (a.direct8)
+        {
+            // RGBA8 target, empty plan: the four colours (and BC3's eight alphas) are stored once per block with StoreScanline's
+            // arithmetic, the texels pick bytes
+            Texel clr[4]; uint32_t bitmap;
+            bc1_palette(isbc1 ? p : p + 8, isbc1, clr, bitmap);
+            uint32_t c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c[k] = pack_texel32(FMT_R8G8B8A8_UNORM, clr[k]);
+            const uint64_t ad = isbc1 ? 0ull : *reinterpret_cast<const uint64_t*>(p);
+            uint32_t alo = 0, ahi = 0;
+            if (!isbc1 && !isbc2)
+            {
+                DXTEX_PAL8(f);
+                bc3_alpha_palette(ad, DXTEX_PAL8_ARGS(f));
+                alo = store_ubn_biased(f0) | (store_ubn_biased(f1) << 8) | (store_ubn_biased(f2) << 16) | (store_ubn_biased(f3) << 24);
+                ahi = store_ubn_biased(f4) | (store_ubn_biased(f5) << 8) | (store_ubn_biased(f6) << 16) | (store_ubn_biased(f7) << 24);
+            }
+            const uint32_t x0 = bx * 4, y0 = by * 4;
+            const uint32_t pw = min(4u, a.width - x0), ph = min(4u, a.height - y0);
+#pragma unroll
+            for (uint32_t y = 0; y < 4; ++y)
+            {
+                if (y < ph)
+                {
+                    uint32_t a4 = 0;
+                    if (isbc2)
+                    {
+                        // float(n) * (1 / 15.f) stores as 17 n for every nibble n
+                        uint32_t n = uint32_t(ad >> (16u * y)) & 0xFFFFu;
+                        n = (n | (n << 8)) & 0x00FF00FFu;
+                        n = (n | (n << 4)) & 0x0F0F0F0Fu;
+                        a4 = n | (n << 4);
+                    }
+                    else if (!isbc1)
+                        a4 = row_bytes3(alo, ahi, ad, y);
+                    uint32_t px[4];
+#pragma unroll
+                    for (uint32_t x = 0; x < 4; ++x)
+                    {
+                        const uint32_t sidx = (bitmap >> (2u * (4u * y + x))) & 3u;
+                        const uint32_t v = (sidx == 0) ? c[0] : (sidx == 1) ? c[1] : (sidx == 2) ? c[2] : c[3];
+                        px[x] = isbc1 ? v : __builtin_amdgcn_perm(a4, v, 0x04020100u + (x << 24));
+                    }
+                    uint8_t* row = a.dst + uint64_t(y0 + y) * a.dstRowPitch;
+                    if (a.vec16 && pw == 4)
+                        reinterpret_cast<uint4*>(row)[bx] = make_uint4(px[0], px[1], px[2], px[3]);
+                    else
+                    {
+#pragma unroll
+                        for (uint32_t x = 0; x < 4; ++x)
+                            if (x < pw) reinterpret_cast<uint32_t*>(row)[x0 + x] = px[x];
+                    }
+                }
+            }
+            return;
+        }
+        if (isbc1)
             decode_bc1(p, true, t);
         else
         {
             decode_bc1(p + 8, false, t);
-            if (a.srcFormat == FMT_BC2_UNORM || a.srcFormat == FMT_BC2_UNORM_SRGB)
+            if (isbc2)
             {
                 const uint64_t al = *reinterpret_cast<const uint64_t*>(p);
 #pragma unroll
@@ -483,17 +575,76 @@ __global__ void __launch_bounds__(256) bc_decode_kernel(DecodeArgs a)
     else if constexpr (FAM == FAM_BC45)
     {
         const bool sg = a.srcFormat == FMT_BC4_SNORM || a.srcFormat == FMT_BC5_SNORM;
-        if (a.srcFormat == FMT_BC4_UNORM || a.srcFormat == FMT_BC4_SNORM)
+        const bool one = a.srcFormat == FMT_BC4_UNORM || a.srcFormat == FMT_BC4_SNORM;
+        const uint64_t d0 = reinterpret_cast<const uint64_t*>(p)[0], d1 = one ? 0ull : reinterpret_cast<const uint64_t*>(p)[1];
+        DXTEX_PAL8(f); DXTEX_PAL8(g);
+        bc4_palette(d0, sg, DXTEX_PAL8_ARGS(f));
+        g0 = g1 = g2 = g3 = g4 = g5 = g6 = g7 = 0.0f;
+        if (!one) bc4_palette(d1, sg, DXTEX_PAL8_ARGS(g));
+        if (a.direct8)
         {
-            const uint64_t d = *reinterpret_cast<const uint64_t*>(p);
+            // R8 / R8G8 target of the block's own kind (UNORM or SNORM), empty plan: eight stored bytes per channel, texels pick.
+            // StoreScanline R8_UNORM: biased truncation; R8_SNORM: round half away from zero; R8G8: XMStoreUByteN2 / XMStoreByteN2
+            // (dxtex_store.h)
+            auto byte_of = [&](float v) -> uint32_t
+            {
+                if (one)
+                {
+                    if (!sg) return store_ubn_biased(v);
+                    float c = (v < 1.0f) ? v : 1.0f; c = (c > -1.0f) ? c : -1.0f;
+                    return uint32_t(int32_t(roundf(c * 127.0f))) & 0xFFu;
+                }
+                return sg ? (uint32_t(store_bn(v)) & 0xFFu) : store_ubn2(v);
+            };
+            const uint32_t lo0 = byte_of(f0) | (byte_of(f1) << 8) | (byte_of(f2) << 16) | (byte_of(f3) << 24);
+            const uint32_t hi0 = byte_of(f4) | (byte_of(f5) << 8) | (byte_of(f6) << 16) | (byte_of(f7) << 24);
+            uint32_t lo1 = 0, hi1 = 0;
+            if (!one)
+            {
+                lo1 = byte_of(g0) | (byte_of(g1) << 8) | (byte_of(g2) << 16) | (byte_of(g3) << 24);
+                hi1 = byte_of(g4) | (byte_of(g5) << 8) | (byte_of(g6) << 16) | (byte_of(g7) << 24);
+            }
+            const uint32_t x0 = bx * 4, y0 = by * 4;
+            const uint32_t pw = min(4u, a.width - x0), ph = min(4u, a.height - y0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { t[i].r = bc4_value(d, i, sg); t[i].g = 0.0f; t[i].b = 0.0f; t[i].a = 1.0f; }
+            for (uint32_t y = 0; y < 4; ++y)
+            {
+                if (y < ph)
+                {
+                    uint8_t* row = a.dst + uint64_t(y0 + y) * a.dstRowPitch;
+                    const uint32_t r4 = row_bytes3(lo0, hi0, d0, y);
+                    if (one)
+                    {
+                        if (a.vec16 && pw == 4) reinterpret_cast<uint32_t*>(row)[bx] = r4;
+                        else
+                        {
+#pragma unroll
+                            for (uint32_t x = 0; x < 4; ++x)
+                                if (x < pw) row[x0 + x] = uint8_t(r4 >> (8 * x));
+                        }
+                    }
+                    else
+                    {
+                        const uint32_t g4 = row_bytes3(lo1, hi1, d1, y);
+                        const uint32_t w0 = __builtin_amdgcn_perm(g4, r4, 0x05010400u), w1 = __builtin_amdgcn_perm(g4, r4, 0x07030602u);
+                        if (a.vec16 && pw == 4) reinterpret_cast<uint2*>(row)[bx] = make_uint2(w0, w1);
+                        else
+                        {
+#pragma unroll
+                            for (uint32_t x = 0; x < 4; ++x)
+                                if (x < pw) reinterpret_cast<uint16_t*>(row)[x0 + x] = uint16_t(((x < 2) ? w0 : w1) >> (16 * (x & 1)));
+                        }
+                    }
+                }
+            }
+            return;
         }
-        else
-        {
-            const uint64_t d0 = reinterpret_cast<const uint64_t*>(p)[0], d1 = reinterpret_cast<const uint64_t*>(p)[1];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { t[i].r = bc4_value(d0, i, sg); t[i].g = bc4_value(d1, i, sg); t[i].b = 0.0f; t[i].a = 1.0f; }
+        for (int i = 0; i < 16; ++i)
+        {
+            t[i].r = select8(uint32_t(d0 >> (16 + 3 * i)) & 7u, DXTEX_PAL8_ARGS(f));
+            t[i].g = one ? 0.0f : select8(uint32_t(d1 >> (16 + 3 * i)) & 7u, DXTEX_PAL8_ARGS(g));
+            t[i].b = 0.0f; t[i].a = 1.0f;
         }
     }
     else if constexpr (FAM == FAM_BC6H)
@@ -621,8 +772,19 @@ hipError_t launch_bc_decode(const uint8_t* src, uint64_t srcRowPitch, int srcFor
     a.width = width; a.height = height; a.nbw = (width + 3) / 4; a.nbh = (height + 3) / 4;
     a.plan = plan;
     a.vec16 = ((reinterpret_cast<uintptr_t>(dst) | dstRowPitch) & 15u) == 0;
-    a.direct8 = (srcFormat == FMT_BC7_UNORM || srcFormat == FMT_BC7_UNORM_SRGB) && (dstFormat == FMT_R8G8B8A8_UNORM || dstFormat == FMT_R8G8B8A8_UNORM_SRGB) &&
-                !plan.srgbIn && !plan.srgbOut && plan.tcv == TCV_NONE && plan.tsw == TSW_NONE;
+    const bool emptyPlan = !plan.srgbIn && !plan.srgbOut && plan.tcv == TCV_NONE && plan.tsw == TSW_NONE;
+    const bool rgba8 = dstFormat == FMT_R8G8B8A8_UNORM || dstFormat == FMT_R8G8B8A8_UNORM_SRGB;
+    switch (srcFormat)
+    {
+    case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: case FMT_BC2_UNORM: case FMT_BC2_UNORM_SRGB: case FMT_BC3_UNORM: case FMT_BC3_UNORM_SRGB:
+    case FMT_BC7_UNORM: case FMT_BC7_UNORM_SRGB:
+        a.direct8 = rgba8 && emptyPlan; break;
+    case FMT_BC4_UNORM: a.direct8 = dstFormat == FMT_R8_UNORM && emptyPlan; break;
+    case FMT_BC4_SNORM: a.direct8 = dstFormat == FMT_R8_SNORM && emptyPlan; break;
+    case FMT_BC5_UNORM: a.direct8 = dstFormat == FMT_R8G8_UNORM && emptyPlan; break;
+    case FMT_BC5_SNORM: a.direct8 = dstFormat == FMT_R8G8_SNORM && emptyPlan; break;
+    default: a.direct8 = 0; break;
+    }
     a.direct16 = (srcFormat == FMT_BC6H_UF16 || srcFormat == FMT_BC6H_SF16) && dstFormat == FMT_R16G16B16A16_FLOAT &&
                  !plan.srgbIn && !plan.srgbOut && plan.tcv == TCV_NONE && plan.tsw == TSW_NONE;
     const uint64_t n = uint64_t(a.nbw) * a.nbh;

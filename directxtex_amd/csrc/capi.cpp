@@ -466,16 +466,42 @@ dxtex_hresult dxtex_compress_many_device(dxtex_ctx* ctx, const dxtex_image* srcs
         return DXTEX_S_OK;
     }
     time_begin(ctx);
+    // BC1-BC5: runs of small images of one target format (the tail of a mip chain) share a launch; everything else goes image by image
+    std::vector<BcImage> small;
+    int smallFormat = 0;
+    auto flush_small = [&]() -> dxtex_hresult
+    {
+        if (small.empty()) return DXTEX_S_OK;
+        const hipError_t e = launch_bc15_encode_small(small.data(), int(small.size()), smallFormat, flags, threshold, ctx->stream);
+        small.clear();
+        return e == hipSuccess ? DXTEX_S_OK : fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    };
     for (size_t i = 0; i < count; ++i)
     {
         dxtex_hresult hr = check_pair(ctx, &srcs[i], &dsts[i]);
-        if (hr == DXTEX_S_OK)
-            hr = submit_compress(ctx, srcs[i].pixels, srcs[i].width, srcs[i].height, srcs[i].format, srcs[i].rowPitch,
-                                 dsts[i].pixels, dsts[i].format, dsts[i].rowPitch, flags, threshold);
+        const FmtInfo* out = (hr == DXTEX_S_OK) ? format_info(dsts[i].format) : nullptr;
+        const bool bc15 = out && (out->cls & FC_BC) && bc_block_bytes(dsts[i].format) && dsts[i].format != FMT_BC7_UNORM && dsts[i].format != FMT_BC7_UNORM_SRGB &&
+                          dsts[i].format != FMT_BC6H_UF16 && dsts[i].format != FMT_BC6H_SF16;
+        if (hr == DXTEX_S_OK && bc15 && bc15_small_image(uint32_t(srcs[i].width), uint32_t(srcs[i].height)) && srcs[i].width <= 0xFFFFFFFFull && srcs[i].height <= 0xFFFFFFFFull)
+        {
+            if (!small.empty() && (smallFormat != dsts[i].format || int(small.size()) == bc15_small_batch_max())) hr = flush_small();
+            BcImage im;
+            if (hr == DXTEX_S_OK)
+                hr = compress_view(ctx, srcs[i].pixels, srcs[i].width, srcs[i].height, srcs[i].format, srcs[i].rowPitch, dsts[i].format, flags, &im.src);
+            if (hr == DXTEX_S_OK) { im.dst = dsts[i].pixels; im.dstRowPitch = dsts[i].rowPitch; small.push_back(im); smallFormat = dsts[i].format; }
+        }
+        else if (hr == DXTEX_S_OK)
+        {
+            hr = flush_small();                        // keeps the images in submission order on the stream
+            if (hr == DXTEX_S_OK)
+                hr = submit_compress(ctx, srcs[i].pixels, srcs[i].width, srcs[i].height, srcs[i].format, srcs[i].rowPitch,
+                                     dsts[i].pixels, dsts[i].format, dsts[i].rowPitch, flags, threshold);
+        }
         if (hr != DXTEX_S_OK) { time_end(ctx); return hr; }
     }
+    const dxtex_hresult hrSmall = flush_small();
     time_end(ctx);
-    return DXTEX_S_OK;
+    return hrSmall;
 }
 
 // GPUCompressBC::Prepare's role (BCDirectCompute.cpp:203-369): size the context for `count` images of one shape up front.

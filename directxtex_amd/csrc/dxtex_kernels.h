@@ -21,6 +21,11 @@ hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowP
 // BC7: `scratch` must hold bc7_scratch_bytes(total number of 4x4 blocks, flags, number of images) bytes of device memory.
 // The _many form runs an array of images (a mip chain, a texture array) through the per-mode pipeline as one block list.
 struct BcImage { SrcView src; uint8_t* dst; uint64_t dstRowPitch; };
+// BC1-BC5: up to bc15_small_batch_max() images that satisfy bc15_small_image() (at most 256 x 256 texels) in ONE launch - the tail
+// of a mip chain, whose levels would otherwise each cost the latency of a kernel's slowest block.
+bool bc15_small_image(uint32_t width, uint32_t height);
+int bc15_small_batch_max();
+hipError_t launch_bc15_encode_small(const BcImage* images, int count, int dstFormat, uint32_t flags, float threshold, hipStream_t stream);
 // Two extra streams (and the events that fork / join them) for pipelines that are independent of each other until the last kernel:
 // owned by the context (one set per context and device, destroyed with it); nullptr = everything on `stream`.
 struct SideStreams { hipStream_t side[2]; hipEvent_t forked; hipEvent_t joined[2]; };

@@ -408,59 +408,50 @@ __global__ void __launch_bounds__(256) resize_cubic_kernel(ResizeArgs a)
 // Cubic, exactly 2:1 in both directions with clamp addressing on RGBA8 (every level of a power-of-two mip chain): srcB = 2u + 0.5, so the
 // four taps are texels 2u-1 .. 2u+2 (clamped) and dx = 0.5 for every destination texel. The filter is separable in the reference too
 // (CUBIC_INTERPOLATE along x for four source rows, then along y, filters.h:192-207), and neighbouring destination rows share two of their
-// four source rows: a workgroup filters the 34 source rows of a 64 x 16 destination tile along x once, into LDS, and then along y -
-// 2.1 row passes per destination texel instead of 4, unpacking each source texel once per row pass. Same expressions, same order,
-// same bits as resize_cubic_kernel.
-constexpr int kCubTileW = 64, kCubTileH = 16, kCubRows = 2 * kCubTileH + 2;
-__global__ void __launch_bounds__(256) resize_cubic_half_rgba8_kernel(ResizeArgs a)
+// four source rows: a lane owns one destination column of a strip of rows and walks down it with the x-filtered values of the last four
+// source rows in registers - two row passes per destination texel instead of four (plus two at the top of the strip), every source texel
+// unpacked once per row pass, no LDS and no barrier (a tile in LDS held 35 KiB per workgroup and left the kernel waiting on it at four
+// waves per SIMD). Same expressions, same order, same bits as resize_cubic_kernel.
+__global__ void __launch_bounds__(256) resize_cubic_half_rgba8_kernel(ResizeArgs a, uint32_t stripRows)
 {
-    __shared__ float4 sRow[kCubRows][kCubTileW];
-    const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * kCubTileW + tx, y0 = blockIdx.y * kCubTileH;
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t y0 = blockIdx.y * stripRows;
+    if (x >= a.dst.width || y0 >= a.dst.height) return;
+    const uint32_t y1 = min(y0 + stripRows, a.dst.height);
     const int64_t srcW = a.src.width, srcH = a.src.height;
-    if (x < a.dst.width)
+    const int64_t u0 = int64_t(2) * x - 1;
+    const bool inside = u0 >= 0 && u0 + 3 < srcW;
+    const uint32_t i0 = uint32_t(u0 < 0 ? 0 : u0), i1 = uint32_t(u0 + 1 > srcW - 1 ? srcW - 1 : u0 + 1),
+                   i2 = uint32_t(u0 + 2 > srcW - 1 ? srcW - 1 : u0 + 2), i3 = uint32_t(u0 + 3 > srcW - 1 ? srcW - 1 : u0 + 3);
+    // the x-filtered texel of source row sy (clamped) at this column
+    auto xpass = [&](int64_t sy) -> float4
     {
-        const int64_t u0 = int64_t(2) * x - 1;
-        const bool inside = u0 >= 0 && u0 + 3 < srcW;
-        for (uint32_t r = ty; r < uint32_t(kCubRows); r += 4)
-        {
-            int64_t sy = int64_t(2) * y0 - 1 + r;
-            sy = sy < 0 ? 0 : (sy > srcH - 1 ? srcH - 1 : sy);
-            const uint8_t* row = a.src.pixels + uint64_t(sy) * a.src.rowPitch;
-            uint32_t w0, w1, w2, w3;
-            if (inside)
-            {
-                const uint32_t* q = reinterpret_cast<const uint32_t*>(row) + u0;
-                w0 = q[0]; w1 = q[1]; w2 = q[2]; w3 = q[3];
-            }
-            else
-            {
-                const uint32_t* q = reinterpret_cast<const uint32_t*>(row);
-                auto cl = [&](int64_t u) { return uint32_t(u < 0 ? 0 : (u > srcW - 1 ? srcW - 1 : u)); };
-                w0 = q[cl(u0)]; w1 = q[cl(u0 + 1)]; w2 = q[cl(u0 + 2)]; w3 = q[cl(u0 + 3)];
-            }
+        sy = sy < 0 ? 0 : (sy > srcH - 1 ? srcH - 1 : sy);
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(a.src.pixels + uint64_t(sy) * a.src.rowPitch);
+        uint32_t w0, w1, w2, w3;
+        if (inside) { w0 = q[u0]; w1 = q[u0 + 1]; w2 = q[u0 + 2]; w3 = q[u0 + 3]; }
+        else { w0 = q[i0]; w1 = q[i1]; w2 = q[i2]; w3 = q[i3]; }
 #define DXTEX_CH(W, S) (float(((W) >> (S)) & 0xFFu) * (1.0f / 255.0f))
-            float4 c;
-            c.x = cubic1(0.5f, DXTEX_CH(w0, 0), DXTEX_CH(w1, 0), DXTEX_CH(w2, 0), DXTEX_CH(w3, 0));
-            c.y = cubic1(0.5f, DXTEX_CH(w0, 8), DXTEX_CH(w1, 8), DXTEX_CH(w2, 8), DXTEX_CH(w3, 8));
-            c.z = cubic1(0.5f, DXTEX_CH(w0, 16), DXTEX_CH(w1, 16), DXTEX_CH(w2, 16), DXTEX_CH(w3, 16));
-            c.w = cubic1(0.5f, DXTEX_CH(w0, 24), DXTEX_CH(w1, 24), DXTEX_CH(w2, 24), DXTEX_CH(w3, 24));
+        float4 c;
+        c.x = cubic1(0.5f, DXTEX_CH(w0, 0), DXTEX_CH(w1, 0), DXTEX_CH(w2, 0), DXTEX_CH(w3, 0));
+        c.y = cubic1(0.5f, DXTEX_CH(w0, 8), DXTEX_CH(w1, 8), DXTEX_CH(w2, 8), DXTEX_CH(w3, 8));
+        c.z = cubic1(0.5f, DXTEX_CH(w0, 16), DXTEX_CH(w1, 16), DXTEX_CH(w2, 16), DXTEX_CH(w3, 16));
+        c.w = cubic1(0.5f, DXTEX_CH(w0, 24), DXTEX_CH(w1, 24), DXTEX_CH(w2, 24), DXTEX_CH(w3, 24));
 #undef DXTEX_CH
-            sRow[r][tx] = c;
-        }
-    }
-    __syncthreads();
-    if (x >= a.dst.width) return;
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k)
+        return c;
+    };
+    // destination row y takes source rows 2y - 1 .. 2y + 2
+    float4 c0 = xpass(int64_t(2) * y0 - 1), c1 = xpass(int64_t(2) * y0), c2 = xpass(int64_t(2) * y0 + 1);
+#pragma unroll 2
+    for (uint32_t y = y0; y < y1; ++y)
     {
-        const uint32_t yl = ty + 4 * k, y = y0 + yl;
-        if (y >= a.dst.height) break;
-        const float4 c0 = sRow[2 * yl][tx], c1 = sRow[2 * yl + 1][tx], c2 = sRow[2 * yl + 2][tx], c3 = sRow[2 * yl + 3][tx];
+        const float4 c3 = xpass(int64_t(2) * y + 2);
+        const float4 n2 = xpass(int64_t(2) * y + 3);             // row 2(y+1) + 1 of the next trip, loaded before this trip's store
         Texel o;
         o.r = cubic1(0.5f, c0.x, c1.x, c2.x, c3.x); o.g = cubic1(0.5f, c0.y, c1.y, c2.y, c3.y);
         o.b = cubic1(0.5f, c0.z, c1.z, c2.z, c3.z); o.a = cubic1(0.5f, c0.w, c1.w, c2.w, c3.w);
-        store_linear(a.dst, x, y, 0, o);
+        reinterpret_cast<uint32_t*>(a.dst.pixels + uint64_t(y) * a.dst.rowPitch)[x] = pack_texel32(FMT_R8G8B8A8_UNORM, o);
+        c0 = c2; c1 = c3; c2 = n2;
     }
 }
 
@@ -836,10 +827,17 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
     case 0x100000u: hipLaunchKernelGGL(resize_point_kernel, grid, block, 0, stream, a); break;
     case 0x200000u: hipLaunchKernelGGL(resize_linear_kernel, grid, block, 0, stream, a); break;
     case 0x300000u:
-        // the 2:1 RGBA8 case of a power-of-two mip chain has a separable LDS-tiled kernel; levels narrower than a tile gain nothing from it
+        // the 2:1 RGBA8 case of a power-of-two mip chain has a separable kernel (a column strip per lane); levels narrower than a wavefront gain nothing from it
         if (format == FMT_R8G8B8A8_UNORM && !a.srgbIn && !a.srgbOut && srcW == 2 * dstW && srcH == 2 * dstH && dstW >= 64 &&
-            !a.wrapU && !a.wrapV && !a.mirrorU && !a.mirrorV && (srcPitch % 4) == 0)
-            hipLaunchKernelGGL(resize_cubic_half_rgba8_kernel, dim3((dstW + kCubTileW - 1) / kCubTileW, (dstH + kCubTileH - 1) / kCubTileH), block, 0, stream, a);
+            !a.wrapU && !a.wrapV && !a.mirrorU && !a.mirrorV && (srcPitch % 4) == 0 && (dstPitch % 4) == 0 &&
+            (reinterpret_cast<uintptr_t>(src) % 4) == 0 && (reinterpret_cast<uintptr_t>(dst) % 4) == 0)
+        {
+            // rows per lane: long strips amortise the two extra row passes at their top; short ones keep a small level spread over the chip
+            // (at least ~4096 wavefronts while that leaves 4 rows or more per strip)
+            uint32_t strip = 32;
+            while (strip > 4 && uint64_t((dstW + 63) / 64) * ((dstH + strip - 1) / strip) < 4096) strip >>= 1;
+            hipLaunchKernelGGL(resize_cubic_half_rgba8_kernel, dim3((dstW + 255) / 256, (dstH + strip - 1) / strip), block, 0, stream, a, strip);
+        }
         else
             hipLaunchKernelGGL(resize_cubic_kernel, grid, block, 0, stream, a);
         break;

@@ -100,3 +100,25 @@ def test_decompress_bc6h_arbitrary_blocks(ctx, oracle, fmt, dst, size):
         texel = r.reshape(h, w, bpt)[0, 12]                                                  # block 3, row 0
         red = texel[:2].view(np.float16)[0] if dst == 10 else texel[:4].view(np.float32)[0]
         assert (red == -65504.0) if dst == 10 else np.isneginf(red), red
+
+
+@pytest.mark.parametrize("fmt,dst", [(71, 28), (72, 29), (74, 28), (77, 28), (78, 29), (80, 61), (81, 63), (83, 49), (84, 51), (80, 28), (84, 49)])
+@pytest.mark.parametrize("size", [(256, 128), (61, 35)])
+def test_decompress_bc15_arbitrary_blocks(ctx, oracle, fmt, dst, size):
+    """BC1-BC5 to their default targets store a block's palette once and let the texels pick bytes; arbitrary blocks (both BC1 colour
+    orders, both BC3 / BC4 alpha layouts, SNORM -128 endpoints) must give the reference's Decompress bytes, as must targets that keep
+    the fp32 route."""
+    w, h = size
+    nb = ((w + 3) // 4) * ((h + 3) // 4)
+    bb = dx.BC_BLOCK_BYTES[fmt]
+    rng = np.random.default_rng(fmt * 1000 + dst + w)
+    payload = rng.integers(0, 256, (nb, bb), dtype=np.uint8)
+    payload[2] = 0
+    payload[4] = 255
+    payload[6, :2] = (0x80, 0x7F)      # SNORM endpoints -128 / 127
+    payload[8, :2] = (0x7F, 0x80)
+    payload = payload.reshape(-1)
+    got = ctx.decompress(payload, w, h, fmt, dst)
+    ref = oracle.ref_decompress_image(payload, w, h, fmt, dst)
+    g = np.asarray(got).reshape(-1).view(np.uint8); r = np.asarray(ref).reshape(-1).view(np.uint8)
+    assert np.array_equal(g, r), (fmt, dst, np.nonzero(g != r)[0][:8])

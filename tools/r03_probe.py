@@ -72,6 +72,11 @@ if "decode" in what:
         ctx.compress_device(src.data_ptr(), W, H, 28, dst.data_ptr(), fmt, dx.TEX_COMPRESS_BC7_QUICK if fmt == 98 else 0, 0.5)
         ms = timed(lambda: ctx.decompress_device(dst.data_ptr(), W, H, fmt, back.data_ptr(), 28))
         print("decode %d -> RGBA8 4096^2: %.4f ms = %.2f TB/s algorithmic" % (fmt, ms, (dst.numel() + W * H * 4) / ms / 1e9))
+    for fmt, tgt, bpt, bb in ((80, 61, 1, 0.5), (83, 49, 2, 1.0)):                      # BC4 -> R8, BC5 -> R8G8: the default targets
+        dst = torch.empty(dx.compute_pitch(fmt, W, H)[1], dtype=torch.uint8, device=dev)
+        ctx.compress_device(src.data_ptr(), W, H, 28, dst.data_ptr(), fmt, 0, 0.5)
+        ms = timed(lambda: ctx.decompress_device(dst.data_ptr(), W, H, fmt, back.data_ptr(), tgt))
+        print("decode %d -> %d 4096^2: %.4f ms = %.2f TB/s algorithmic" % (fmt, tgt, ms, W * H * (bpt + bb) / ms / 1e9))
     # every BC7 mode / partition / rotation (arbitrary blocks), and BC6H of the encoder's output to RGBA16F
     rnd = torch.randint(0, 256, (W * H,), dtype=torch.uint8, device=dev)
     ms = timed(lambda: ctx.decompress_device(rnd.data_ptr(), W, H, 98, back.data_ptr(), 28))
