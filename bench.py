@@ -150,7 +150,7 @@ def other_workloads(ctx, dev, img, rank, world):
     for name, fmt, bpt, n in (("bc1", dx.DXGI_FORMAT_BC1_UNORM, 4.5, 20), ("bc3", dx.DXGI_FORMAT_BC3_UNORM, 5.0, 20), ("bc5", dx.DXGI_FORMAT_BC5_UNORM, 5.0, 20)):
         dst = torch.empty(dx.compute_pitch(fmt, WIDTH, HEIGHT)[1], dtype=torch.uint8, device=dev)
         dt = timed(lambda: ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), fmt, 0, 0.5), n)
-        out[f"{name}_4096"] = entry(dt, tex, tex * bpt, "profiles/r02_kernels.md")
+        out[f"{name}_4096"] = entry(dt, tex, tex * bpt, "profiles/r03_kernels.md")
     # the reference's faster / slower BC7 settings on the same image (TEX_COMPRESS_BC7_QUICK: mode 6 only; BC7_USE_3SUBSETS: + modes 0, 2)
     dst = torch.empty(dx.compute_pitch(dx.DXGI_FORMAT_BC7_UNORM, WIDTH, HEIGHT)[1], dtype=torch.uint8, device=dev)
     for name, fl, n in (("bc7_quick_4096", dx.TEX_COMPRESS_BC7_QUICK, 5), ("bc7_3subsets_4096", 0x80000, 1)):
@@ -172,18 +172,25 @@ def other_workloads(ctx, dev, img, rank, world):
     hdr = torch.from_numpy(hdr_np).to(dev)
     dst6 = torch.empty(dx.compute_pitch(dx.DXGI_FORMAT_BC6H_UF16, WIDTH, HEIGHT)[1], dtype=torch.uint8, device=dev)
     dt = timed(lambda: ctx.compress_device(hdr.data_ptr(), WIDTH, HEIGHT, RGBA16F, dst6.data_ptr(), dx.DXGI_FORMAT_BC6H_UF16, 0, 0.5), 2)
-    e = entry(dt, tex, tex * 9.0, "profiles/r02_kernels.md")
+    e = entry(dt, tex, tex * 9.0, "profiles/r03_kernels.md")
     gold = golden_case("cfg3_bc6h_uf16_4096")
     if gold:
         e["identical_to_reference_golden"] = band_sha(dst6.cpu().numpy(), WIDTH, HEIGHT) == gold["bands"]
     out["cfg3_bc6h_uf16_4096"] = e
-    del hdr, dst6, hdr_np
-    # decode BC7 4096^2 -> RGBA8 (1 B read + 4 B written per texel)
-    back = torch.empty(tex * 4, dtype=torch.uint8, device=dev)
-    ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, dx.TEX_COMPRESS_BC7_QUICK, 0.5)
+    del hdr, hdr_np
+    # decoders, 4096^2 to their default targets (block bytes read + target bytes written per texel): BC7 of the headline's own payload
+    # (all modes), BC1 / BC3 of this image, BC6H of cfg3's payload
+    back = torch.empty(tex * 8, dtype=torch.uint8, device=dev)
+    ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, 0, 0.5)
     dt = timed(lambda: ctx.decompress_device(dst.data_ptr(), WIDTH, HEIGHT, dx.DXGI_FORMAT_BC7_UNORM, back.data_ptr(), RGBA8), 20)
-    out["bc7_decode_4096"] = entry(dt, tex, tex * 5.0, "profiles/r02_kernels.md")
-    del back
+    out["bc7_decode_4096"] = entry(dt, tex, tex * 5.0, "profiles/r03_kernels.md")
+    for name, fmt, bpt in (("bc1", dx.DXGI_FORMAT_BC1_UNORM, 4.5), ("bc3", dx.DXGI_FORMAT_BC3_UNORM, 5.0)):
+        ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), fmt, 0, 0.5)
+        dt = timed(lambda: ctx.decompress_device(dst.data_ptr(), WIDTH, HEIGHT, fmt, back.data_ptr(), RGBA8), 20)
+        out[f"{name}_decode_4096"] = entry(dt, tex, tex * bpt, "profiles/r03_kernels.md")
+    dt = timed(lambda: ctx.decompress_device(dst6.data_ptr(), WIDTH, HEIGHT, dx.DXGI_FORMAT_BC6H_UF16, back.data_ptr(), RGBA16F), 20)
+    out["bc6h_decode_4096"] = entry(dt, tex, tex * 9.0, "profiles/r03_kernels.md")
+    del back, dst6
     # cfg4: 8192^2 RGBA8 (seed 4, random alpha) full mip chain (box, cubic), then BC3 of all 14 levels
     big = torch.from_numpy(synth.survey_rgba8(8192, 8192, 4, "random")).to(dev)
     w = h = 8192
@@ -199,7 +206,7 @@ def other_workloads(ctx, dev, img, rank, world):
     chain_tex = sum(a * b for a, b in sizes[1:])
     for name, flt in (("box", dx.TEX_FILTER_BOX), ("cubic", dx.TEX_FILTER_CUBIC)):
         dt = timed(lambda: ctx.generate_mips_device(levels, flt), 5)
-        e = entry(dt, chain_tex, chain_bytes, "profiles/r02_kernels.md")
+        e = entry(dt, chain_tex, chain_bytes, "profiles/r03_kernels.md")
         gold = golden_case(f"cfg4_{name}")
         if gold:
             e["identical_to_reference_golden"] = [hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() for t in bufs] == gold["levels"]
@@ -209,7 +216,7 @@ def other_workloads(ctx, dev, img, rank, world):
     dsts = [dx.capi.device_image(t.data_ptr(), a, b, dx.DXGI_FORMAT_BC3_UNORM) for t, (a, b) in zip(bc3, sizes)]
     dt = timed(lambda: ctx.compress_many_device(levels, dsts, 0, 0.5), 5)
     tex4 = sum(a * b for a, b in sizes)
-    e = entry(dt, tex4, 447392452, "profiles/r02_kernels.md")
+    e = entry(dt, tex4, 447392452, "profiles/r03_kernels.md")
     gold = golden_case("cfg4_box")
     if gold:
         e["identical_to_reference_golden"] = [hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() for t in bc3] == gold["bc3_levels"]

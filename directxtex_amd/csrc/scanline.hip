@@ -75,6 +75,16 @@ __global__ void __launch_bounds__(256) convert_kernel(ImgView src, ImgView dst, 
 // consecutive bytes per instruction), is decoded / converted / encoded texel by texel with the same load_texel / apply_plan /
 // store_texel as above - on a register image of the quad, every index a compile-time constant - and leaves in 1-4 sixteen-byte
 // stores. Used when a texel is a whole number of dwords on both sides (>= 32 bpp) and rows are 16-byte aligned.
+// every format whose texel is a whole number of dwords (the quad kernel's domain; launch_convert admits no other)
+#define DXTEX_QUAD_FORMATS(X) \
+    X(FMT_R32G32B32A32_FLOAT) X(FMT_R32G32B32A32_UINT) X(FMT_R32G32B32A32_SINT) X(FMT_R32G32B32_FLOAT) X(FMT_R32G32B32_UINT) X(FMT_R32G32B32_SINT) \
+    X(FMT_R16G16B16A16_FLOAT) X(FMT_R16G16B16A16_UNORM) X(FMT_R16G16B16A16_UINT) X(FMT_R16G16B16A16_SNORM) X(FMT_R16G16B16A16_SINT) \
+    X(FMT_R32G32_FLOAT) X(FMT_R32G32_UINT) X(FMT_R32G32_SINT) X(FMT_Y416) \
+    X(FMT_R10G10B10A2_UNORM) X(FMT_R10G10B10A2_UINT) X(FMT_R11G11B10_FLOAT) X(FMT_R8G8B8A8_UNORM) X(FMT_R8G8B8A8_UNORM_SRGB) X(FMT_R8G8B8A8_UINT) \
+    X(FMT_R8G8B8A8_SNORM) X(FMT_R8G8B8A8_SINT) X(FMT_R16G16_FLOAT) X(FMT_R16G16_UNORM) X(FMT_R16G16_UINT) X(FMT_R16G16_SNORM) X(FMT_R16G16_SINT) \
+    X(FMT_R32_FLOAT) X(FMT_R32_UINT) X(FMT_R32_SINT) X(FMT_R9G9B9E5_SHAREDEXP) X(FMT_B8G8R8A8_UNORM) X(FMT_B8G8R8X8_UNORM) \
+    X(FMT_R10G10B10_XR_BIAS_A2_UNORM) X(FMT_B8G8R8A8_UNORM_SRGB) X(FMT_B8G8R8X8_UNORM_SRGB) X(FMT_AYUV) X(FMT_Y410)
+
 template<int W>
 __device__ __forceinline__ void load_quad(uint32_t (&q)[W], const uint8_t* p, uint32_t bytes)
 {
@@ -122,11 +132,28 @@ __global__ void __launch_bounds__(256) convert_quad_kernel(ImgView src, ImgView 
             uint32_t out[DW];
 #pragma unroll
             for (int k = 0; k < DW; ++k) out[k] = 0u;
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k)
+            // load_texel / store_texel are called with the format as a compile-time constant (one case per whole-dword format):
+            // with a run-time format their switch also holds the byte- and word-addressed formats, whose accesses would force the
+            // register image of the quad into memory
+            Texel tx[4];
+            switch (src.format)
             {
-                const Texel t = load_texel(reinterpret_cast<const uint8_t*>(in[r]), k, src.format);
-                store_texel(reinterpret_cast<uint8_t*>(out), k, dst.format, apply_plan(t, plan), threshold);
+#define DXTEX_QCASE(F) case F: _Pragma("unroll") for (uint32_t k = 0; k < 4u; ++k) tx[k] = load_texel(reinterpret_cast<const uint8_t*>(in[r]), k, F); break;
+                DXTEX_QUAD_FORMATS(DXTEX_QCASE)
+#undef DXTEX_QCASE
+            default:
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) tx[k].r = tx[k].g = tx[k].b = tx[k].a = 0.0f;
+                break;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) tx[k] = apply_plan(tx[k], plan);
+            switch (dst.format)
+            {
+#define DXTEX_QCASE(F) case F: _Pragma("unroll") for (uint32_t k = 0; k < 4u; ++k) store_texel(reinterpret_cast<uint8_t*>(out), k, F, tx[k], threshold); break;
+                DXTEX_QUAD_FORMATS(DXTEX_QCASE)
+#undef DXTEX_QCASE
+            default: break;
             }
             if (y0 + uint32_t(r) < src.height)
                 store_quad<DW>(dst.pixels + uint64_t(y0 + uint32_t(r)) * dst.rowPitch + uint64_t(q) * dq, out, dq);
@@ -827,8 +854,9 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
     case 0x100000u: hipLaunchKernelGGL(resize_point_kernel, grid, block, 0, stream, a); break;
     case 0x200000u: hipLaunchKernelGGL(resize_linear_kernel, grid, block, 0, stream, a); break;
     case 0x300000u:
-        // the 2:1 RGBA8 case of a power-of-two mip chain has a separable kernel (a column strip per lane); levels narrower than a wavefront gain nothing from it
-        if (format == FMT_R8G8B8A8_UNORM && !a.srgbIn && !a.srgbOut && srcW == 2 * dstW && srcH == 2 * dstH && dstW >= 64 &&
+        // the 2:1 RGBA8 case of a power-of-two mip chain has a separable kernel (a column strip per lane); the small levels take it too (6 us a
+        // launch against 10 - 30 us of the general kernel's sixteen dependent taps)
+        if (format == FMT_R8G8B8A8_UNORM && !a.srgbIn && !a.srgbOut && srcW == 2 * dstW && srcH == 2 * dstH &&
             !a.wrapU && !a.wrapV && !a.mirrorU && !a.mirrorV && (srcPitch % 4) == 0 && (dstPitch % 4) == 0 &&
             (reinterpret_cast<uintptr_t>(src) % 4) == 0 && (reinterpret_cast<uintptr_t>(dst) % 4) == 0)
         {

@@ -8,7 +8,7 @@ f = glob.glob('/tmp/mt/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 # last occurrence of each (kernel, grid) in order: print the final 60 dispatches
 out = []
-for r in rows[-80:]:
+for r in [r for r in rows if 'resize' in r['Kernel_Name']][-60:]:
     n = r['Kernel_Name'].replace('dxtex::(anonymous namespace)::', '').split('(')[0]
     out.append("%-44s grid %8s x %5s  %8.2f us" % (n, r['Grid_Size_X'], r['Grid_Size_Y'], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
 print("\n".join(out))

@@ -36,11 +36,16 @@ else:
     dst = out_for(95)
     for _ in range(reps):
         ctx.compress_device(hdr.data_ptr(), W, H, RGBA16F, dst.data_ptr(), 95, 0, 0.5)
-    bc7 = out_for(98)                                              # decode
-    ctx.compress_device(src.data_ptr(), W, H, RGBA8, bc7.data_ptr(), 98, dx.TEX_COMPRESS_BC7_QUICK, 0.5)
+    bc7 = out_for(98)                                              # decode: BC7 (arbitrary blocks: every mode), BC1, BC3, BC6H
+    bc7.copy_(torch.randint(0, 256, (bc7.numel(),), dtype=torch.uint8, device=dev))
+    bc1 = out_for(71); bc3_ = out_for(77)
+    ctx.compress_device(src.data_ptr(), W, H, RGBA8, bc1.data_ptr(), 71, 0, 0.5)
+    ctx.compress_device(src.data_ptr(), W, H, RGBA8, bc3_.data_ptr(), 77, 0, 0.5)
     back = torch.empty(W * H * 4, dtype=torch.uint8, device=dev)
     for _ in range(reps):
         ctx.decompress_device(bc7.data_ptr(), W, H, 98, back.data_ptr(), RGBA8)
+        ctx.decompress_device(bc1.data_ptr(), W, H, 71, back.data_ptr(), RGBA8)
+        ctx.decompress_device(bc3_.data_ptr(), W, H, 77, back.data_ptr(), RGBA8)
         ctx.decompress_device(dst.data_ptr(), W, H, 95, hdr.data_ptr(), RGBA16F)
     cv = torch.empty(W * H * 8, dtype=torch.uint8, device=dev)     # convert RGBA8 -> RGBA16F
     s_im = dx.capi.device_image(src.data_ptr(), W, H, RGBA8); d_im = dx.capi.device_image(cv.data_ptr(), W, H, RGBA16F)
