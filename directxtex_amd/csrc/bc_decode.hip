@@ -772,7 +772,7 @@ hipError_t launch_bc_decode(const uint8_t* src, uint64_t srcRowPitch, int srcFor
     a.width = width; a.height = height; a.nbw = (width + 3) / 4; a.nbh = (height + 3) / 4;
     a.plan = plan;
     a.vec16 = ((reinterpret_cast<uintptr_t>(dst) | dstRowPitch) & 15u) == 0;
-    const bool emptyPlan = !plan.srgbIn && !plan.srgbOut && plan.tcv == TCV_NONE && plan.tsw == TSW_NONE;
+    const bool emptyPlan = !plan.srgbIn && !plan.srgbOut && plan.tcv == TCV_NONE && plan.tsw == TSW_NONE && !plan.depth;
     const bool rgba8 = dstFormat == FMT_R8G8B8A8_UNORM || dstFormat == FMT_R8G8B8A8_UNORM_SRGB;
     switch (srcFormat)
     {
@@ -786,7 +786,7 @@ hipError_t launch_bc_decode(const uint8_t* src, uint64_t srcRowPitch, int srcFor
     default: a.direct8 = 0; break;
     }
     a.direct16 = (srcFormat == FMT_BC6H_UF16 || srcFormat == FMT_BC6H_SF16) && dstFormat == FMT_R16G16B16A16_FLOAT &&
-                 !plan.srgbIn && !plan.srgbOut && plan.tcv == TCV_NONE && plan.tsw == TSW_NONE;
+                 emptyPlan;
     const uint64_t n = uint64_t(a.nbw) * a.nbh;
     if (!n) return hipSuccess;
     const dim3 grid(uint32_t((n + 255) / 256)), wg(256);

@@ -52,6 +52,8 @@ struct dxtex_ctx
     std::vector<uint8_t> triHost;
     void* triPinned = nullptr; size_t triPinnedBytes = 0; hipEvent_t triConsumed = nullptr; bool triPending = false;
     void* mseBuf = nullptr; size_t mseBytes = 0;
+    // R32G32B32A32_FLOAT rows on their way into a format whose element holds several texels (launch_pack_group)
+    void* groupRows = nullptr; size_t groupRowsBytes = 0;
     // dxtex_compress_many (host pointers): double-buffered pinned + device staging, copy streams on either side of ctx->stream
     struct Lane
     {
@@ -140,7 +142,14 @@ dxtex_hresult tile_conversion(const FmtInfo& in, const FmtInfo& out, uint32_t co
     if (srgbIn && srgbOut) srgbIn = srgbOut = false;       // :3164-3167
 
     *tcv = TCV_NONE; *tsw = TSW_NONE;
-    if (out.cls & FC_UNORM)
+    if (in.cls & FC_DEPTH)
+    {
+        // a depth source: ConvertScanline's depth branch instead of the range conversion (:3186-3291); sRGB does not apply (:3172, :3845 ask
+        // for a non-depth format on the side they convert - the BC side still gets its encode step below)
+        *tsw = resolve_depth_steps(in, out, 0) << 8;
+        srgbIn = false;
+    }
+    else if (out.cls & FC_UNORM)
     {
         if (in.cls & FC_SNORM) *tcv = TCV_SNORM_TO_UNORM;
         else if (in.cls & FC_FLOAT) *tcv = TCV_SATURATE;
@@ -176,6 +185,11 @@ dxtex_hresult compress_view(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width, s
     if (!bcId(dstFormat)) return fail(ctx, DXTEX_E_INVALIDARG, "destination is not a BC format");
     if (!out || !(out->cls & FC_BC)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "destination BC format is not supported (typeless)");
     if (!in) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "source format is not supported by the MI355X path");
+    // R1_UNORM: the reference refuses it (DirectXTexCompress.cpp:228-232, "we don't support compressing from monochrome"). The packed
+    // two-texel formats: CompressBC steps through a row with BitsPerPixel / 8 bytes per texel (:224-235, :279), which for them is the
+    // size of an ELEMENT of two texels (DirectXTexUtil.cpp:625-670) - block column k reads texels 8k.. instead of 4k.. and the right half
+    // of the image reads past its rows (past the image on the last block row). Nothing defined to reproduce: refused here.
+    if (in->cls & FC_GROUP) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "Compress does not take R1_UNORM or the packed two-texel formats as a source");
     if (!width || !height) return fail(ctx, DXTEX_E_INVALIDARG, "empty image");
     if (width > 0xFFFFFFFCull || height > 0xFFFFFFFCull) return fail(ctx, DXTEX_E_INVALIDARG, "image too large");
     SrcView v;
@@ -274,6 +288,7 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
     if (ctx->stageIn) (void)hipFree(ctx->stageIn);
     if (ctx->stageOut) (void)hipFree(ctx->stageOut);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->groupRows) (void)hipFree(ctx->groupRows);
     if (ctx->triBuf) (void)hipFree(ctx->triBuf);
     if (ctx->triPinned) (void)hipHostFree(ctx->triPinned);
     if (ctx->triConsumed) (void)hipEventDestroy(ctx->triConsumed);
@@ -407,6 +422,12 @@ dxtex_hresult dxtex_compute_pitch(int32_t format, size_t width, size_t height, s
         const uint64_t nbh = std::max<uint64_t>(1u, (uint64_t(height) + 3u) / 4u);
         pitch = nbw * bc_block_bytes(format);
         slice = pitch * nbh;
+    }
+    else if (f->cls & FC_PACKED)
+    {
+        // two texels per element: ((width + 1) >> 1) elements of 4 (R8G8_B8G8, G8R8_G8B8, YUY2) or 8 (Y210, Y216) bytes (DirectXTexUtil.cpp:1031-1052)
+        pitch = ((uint64_t(width) + 1u) >> 1) * ((f->bpp == 32) ? 8u : 4u);
+        slice = pitch * uint64_t(height);
     }
     else
     {
@@ -765,7 +786,7 @@ static dxtex_hresult submit_decompress(dxtex_ctx* ctx, const uint8_t* dSrc, int 
     const FmtInfo* out = format_info(dstFormat);
     if (!in || !(in->cls & FC_BC)) return fail(ctx, DXTEX_E_INVALIDARG, "source image is not block compressed");
     if (out && (out->cls & FC_BC)) return fail(ctx, DXTEX_E_INVALIDARG, "destination format is block compressed");
-    if (!out) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "destination format is not supported by the MI355X path");
+    if (!out || (out->cls & FC_GROUP)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "destination format is not supported by the MI355X path");
     if (!width || !height) return fail(ctx, DXTEX_E_INVALIDARG, "empty image");
     const ConvertPlan plan = resolve_convert_plan(*in, *out, 0);
     hipError_t e = launch_bc_decode(dSrc, srcRowPitch, srcFormat, dDst, dstRowPitch, dstFormat, uint32_t(width), uint32_t(height), plan, ctx->stream);
@@ -818,7 +839,7 @@ dxtex_hresult dxtex_decode_blocks(dxtex_ctx* ctx, int32_t bc_format, const uint8
     dxtex_hresult hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, bc, srcBytes, hipMemcpyHostToDevice, ctx->stream));
-    ConvertPlan plan; plan.srgbIn = 0; plan.tcv = TCV_NONE; plan.tsw = TSW_NONE; plan.srgbOut = 0;
+    ConvertPlan plan; plan.srgbIn = 0; plan.tcv = TCV_NONE; plan.tsw = TSW_NONE; plan.srgbOut = 0; plan.depth = 0;
     time_begin(ctx);
     hipError_t e = launch_bc_decode(static_cast<const uint8_t*>(ctx->stageIn), bb, bc_format, static_cast<uint8_t*>(ctx->stageOut), 64,
                                     FMT_R32G32B32A32_FLOAT, 4, uint32_t(nblocks * 4), plan, ctx->stream);
@@ -858,9 +879,32 @@ dxtex_hresult upload_tables(dxtex_ctx* ctx, const std::vector<uint8_t>& host)
     return DXTEX_S_OK;
 }
 
+// A destination whose element holds several texels (FC_GROUP) is written in two steps: the operation leaves R32G32B32A32_FLOAT rows in
+// ctx->groupRows (what the reference hands to StoreScanline), launch_pack_group stores them. The stream orders the steps, so one
+// buffer serves every level of a chain.
+bool is_group_format(int format) { const FmtInfo* f = format_info(format); return f && (f->cls & FC_GROUP); }
+dxtex_hresult group_rows(dxtex_ctx* ctx, size_t width, size_t height, uint8_t** rows, size_t* pitch)
+{
+    *pitch = width * 16;
+    const dxtex_hresult hr = ensure(ctx, &ctx->groupRows, &ctx->groupRowsBytes, *pitch * height);
+    *rows = static_cast<uint8_t*>(ctx->groupRows);
+    return hr;
+}
+
 dxtex_hresult submit_resizes(dxtex_ctx* ctx, const std::vector<LevelPair>& pairs, int format, uint32_t mode, uint32_t flags, bool mipAlias)
 {
     std::vector<size_t> base(pairs.size(), 0);
+    const bool grouped = is_group_format(format);
+    // one resize: straight into the destination, or through float rows and the pack kernel
+    auto resize_one = [&](const LevelPair& p, const TriangleTables* t, const uint8_t* staleSrc, uint64_t stalePitch, uint32_t staleW) -> dxtex_hresult
+    {
+        uint8_t* out = p.dst; size_t outPitch = p.dstPitch;
+        if (grouped) { const dxtex_hresult hr = group_rows(ctx, p.dw, p.dh, &out, &outPitch); if (hr != DXTEX_S_OK) return hr; }
+        hipError_t e = launch_resize(p.src, p.srcPitch, uint32_t(p.sw), uint32_t(p.sh), out, outPitch, uint32_t(p.dw), uint32_t(p.dh),
+                                     format, mode, flags, mipAlias, t, ctx->stream, staleSrc, stalePitch, staleW, grouped ? FMT_R32G32B32A32_FLOAT : -1);
+        if (e == hipSuccess && grouped) e = launch_pack_group(out, outPitch, p.dst, p.dstPitch, format, uint32_t(p.dw), uint32_t(p.dh), ctx->stream);
+        return e == hipSuccess ? DXTEX_S_OK : fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    };
     if (mode == DXTEX_FILTER_TRIANGLE)
     {
         std::vector<uint8_t>& host = ctx->triHost;
@@ -884,10 +928,8 @@ dxtex_hresult submit_resizes(dxtex_ctx* ctx, const std::vector<LevelPair>& pairs
             TriangleTables t;
             t.ofsX = reinterpret_cast<const uint32_t*>(d + slots[i].ofsX); t.entX = d + slots[i].entX;
             t.ofsY = reinterpret_cast<const uint32_t*>(d + slots[i].ofsY); t.entY = d + slots[i].entY;
-            const LevelPair& p = pairs[i];
-            hipError_t e = launch_resize(p.src, p.srcPitch, uint32_t(p.sw), uint32_t(p.sh), p.dst, p.dstPitch, uint32_t(p.dw), uint32_t(p.dh),
-                                         format, mode, flags, mipAlias, &t, ctx->stream);
-            if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+            const dxtex_hresult hr1 = resize_one(pairs[i], &t, nullptr, 0, 0);
+            if (hr1 != DXTEX_S_OK) return hr1;
         }
         return DXTEX_S_OK;
     }
@@ -896,7 +938,7 @@ dxtex_hresult submit_resizes(dxtex_ctx* ctx, const std::vector<LevelPair>& pairs
     {
         const LevelPair& p = pairs[i];
         // a mip chain's last levels (source at most 64 x 64, each level the next one's source) run in one workgroup
-        if (mipAlias && pairs.size() - i >= 2 && resize_tail_applies(uint32_t(p.sw), uint32_t(p.sh), mode))
+        if (mipAlias && !grouped && pairs.size() - i >= 2 && resize_tail_applies(uint32_t(p.sw), uint32_t(p.sh), mode))
         {
             bool chain = true;
             for (size_t k = i + 1; k < pairs.size(); ++k) chain = chain && pairs[k].src == pairs[k - 1].dst && pairs[k].srcPitch == pairs[k - 1].dstPitch;
@@ -914,10 +956,8 @@ dxtex_hresult submit_resizes(dxtex_ctx* ctx, const std::vector<LevelPair>& pairs
         }
         if (mipAlias && p.sh >= 2) twoHigh = &p;
         const bool stale = mipAlias && mode == DXTEX_FILTER_BOX && p.sh == 1 && p.sw > 1 && twoHigh;
-        hipError_t e = launch_resize(p.src, p.srcPitch, uint32_t(p.sw), uint32_t(p.sh), p.dst, p.dstPitch, uint32_t(p.dw), uint32_t(p.dh),
-                                     format, mode, flags, mipAlias, nullptr, ctx->stream,
-                                     stale ? twoHigh->src : nullptr, stale ? twoHigh->srcPitch : 0, stale ? uint32_t(twoHigh->sw) : 0u);
-        if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+        const dxtex_hresult hr1 = resize_one(p, nullptr, stale ? twoHigh->src : nullptr, stale ? twoHigh->srcPitch : 0, stale ? uint32_t(twoHigh->sw) : 0u);
+        if (hr1 != DXTEX_S_OK) return hr1;
     }
     return DXTEX_S_OK;
 }
@@ -1003,7 +1043,7 @@ dxtex_hresult check_mips3d(dxtex_ctx* ctx, const dxtex_volume* levels, size_t nl
     if (!levels || nlevels <= 1) return fail(ctx, DXTEX_E_INVALIDARG, "need at least two levels");
     const FmtInfo* f = format_info(levels[0].format);
     if (f && (f->cls & FC_BC)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "cannot filter a block-compressed volume");
-    if (!f) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "format is not supported by the MI355X path");
+    if (!f || (f->cls & FC_GROUP)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "format is not supported by the MI355X path");
     size_t w = levels[0].width, h = levels[0].height, d = levels[0].depth;
     if (!w || !h || !d || d > 32767) return fail(ctx, DXTEX_E_INVALIDARG, "bad volume dimensions");           // depth > INT16_MAX, :3264
     if (filter & 0x20000000u) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "TEX_FILTER_FORCE_WIC");
@@ -1206,6 +1246,23 @@ dxtex_hresult check_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_
     *plan = resolve_convert_plan(*in, *out, filter);
     return DXTEX_S_OK;
 }
+
+// the conversion kernel, through float rows + the pack kernel when the destination's element holds several texels
+dxtex_hresult submit_convert(dxtex_ctx* ctx, const uint8_t* dSrc, size_t srcPitch, int srcFormat, uint8_t* dDst, size_t dstPitch, int dstFormat,
+                             size_t width, size_t height, const ConvertPlan& plan, float threshold)
+{
+    uint8_t* out = dDst; size_t outPitch = dstPitch; int outFormat = dstFormat;
+    const bool grouped = is_group_format(dstFormat);
+    if (grouped)
+    {
+        const dxtex_hresult hr = group_rows(ctx, width, height, &out, &outPitch);
+        if (hr != DXTEX_S_OK) return hr;
+        outFormat = FMT_R32G32B32A32_FLOAT;
+    }
+    hipError_t e = launch_convert(dSrc, srcPitch, srcFormat, out, outPitch, outFormat, uint32_t(width), uint32_t(height), plan, threshold, ctx->stream);
+    if (e == hipSuccess && grouped) e = launch_pack_group(out, outPitch, dDst, dstPitch, dstFormat, uint32_t(width), uint32_t(height), ctx->stream);
+    return e == hipSuccess ? DXTEX_S_OK : fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+}
 } // namespace
 
 dxtex_hresult dxtex_convert_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float threshold)
@@ -1215,11 +1272,9 @@ dxtex_hresult dxtex_convert_device(dxtex_ctx* ctx, const dxtex_image* src, const
     if (hr != DXTEX_S_OK) return hr;
     ScopedDevice sd(ctx->device);
     time_begin(ctx);
-    hipError_t e = launch_convert(src->pixels, src->rowPitch, src->format, dst->pixels, dst->rowPitch, dst->format,
-                                  uint32_t(src->width), uint32_t(src->height), plan, threshold, ctx->stream);
+    hr = submit_convert(ctx, src->pixels, src->rowPitch, src->format, dst->pixels, dst->rowPitch, dst->format, src->width, src->height, plan, threshold);
     time_end(ctx);
-    if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
-    return DXTEX_S_OK;
+    return hr;
 }
 
 dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter, float threshold)
@@ -1234,10 +1289,10 @@ dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
     time_begin(ctx);
-    hipError_t e = launch_convert(static_cast<const uint8_t*>(ctx->stageIn), src->rowPitch, src->format, static_cast<uint8_t*>(ctx->stageOut),
-                                  dst->rowPitch, dst->format, uint32_t(src->width), uint32_t(src->height), plan, threshold, ctx->stream);
+    hr = submit_convert(ctx, static_cast<const uint8_t*>(ctx->stageIn), src->rowPitch, src->format, static_cast<uint8_t*>(ctx->stageOut),
+                        dst->rowPitch, dst->format, src->width, src->height, plan, threshold);
     time_end(ctx);
-    if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    if (hr != DXTEX_S_OK) return hr;
     HIP_TRY(ctx, hipMemcpyAsync(dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
@@ -1279,7 +1334,7 @@ dxtex_hresult check_coverage_chain(dxtex_ctx* ctx, const dxtex_image* src, const
     if (!src || !dst || !nlevels) return fail(ctx, DXTEX_E_INVALIDARG, "empty mip chain");
     const FmtInfo* f = format_info(src[0].format);
     if (f && (f->cls & FC_BC)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "ScaleMipMapsAlphaForCoverage does not take block-compressed formats");
-    if (!f) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "format is not supported by the MI355X path");
+    if (!f || (f->cls & FC_GROUP)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "format is not supported by the MI355X path");
     for (size_t i = 0; i < nlevels; ++i)
     {
         if (!src[i].pixels || !dst[i].pixels) return fail(ctx, DXTEX_E_POINTER, "null pixels");

@@ -19,6 +19,7 @@ enum : int
     FMT_R16G16B16A16_UNORM = 11, FMT_R16G16B16A16_UINT = 12,
     FMT_R16G16B16A16_SNORM = 13, FMT_R16G16B16A16_SINT = 14,
     FMT_R32G32_FLOAT = 16, FMT_R32G32_UINT = 17, FMT_R32G32_SINT = 18,
+    FMT_D32_FLOAT_S8X24_UINT = 20,
     FMT_R10G10B10A2_UNORM = 24, FMT_R10G10B10A2_UINT = 25,
     FMT_R11G11B10_FLOAT = 26,
     FMT_R8G8B8A8_UNORM = 28,
@@ -27,16 +28,17 @@ enum : int
     FMT_R16G16_FLOAT = 34,
     FMT_R16G16_UNORM = 35, FMT_R16G16_UINT = 36,
     FMT_R16G16_SNORM = 37, FMT_R16G16_SINT = 38,
-    FMT_R32_FLOAT = 41, FMT_R32_UINT = 42, FMT_R32_SINT = 43,
+    FMT_D32_FLOAT = 40, FMT_R32_FLOAT = 41, FMT_R32_UINT = 42, FMT_R32_SINT = 43,
+    FMT_D24_UNORM_S8_UINT = 45,
     FMT_R8G8_UNORM = 49, FMT_R8G8_UINT = 50,
     FMT_R8G8_SNORM = 51, FMT_R8G8_SINT = 52,
-    FMT_R16_FLOAT = 54,
+    FMT_R16_FLOAT = 54, FMT_D16_UNORM = 55,
     FMT_R16_UNORM = 56, FMT_R16_UINT = 57,
     FMT_R16_SNORM = 58, FMT_R16_SINT = 59,
     FMT_R8_UNORM = 61, FMT_R8_UINT = 62,
     FMT_R8_SNORM = 63, FMT_R8_SINT = 64,
-    FMT_A8_UNORM = 65,
-    FMT_R9G9B9E5_SHAREDEXP = 67,
+    FMT_A8_UNORM = 65, FMT_R1_UNORM = 66,
+    FMT_R9G9B9E5_SHAREDEXP = 67, FMT_R8G8_B8G8_UNORM = 68, FMT_G8R8_G8B8_UNORM = 69,
     FMT_BC1_UNORM = 71, FMT_BC1_UNORM_SRGB = 72,
     FMT_BC2_UNORM = 74, FMT_BC2_UNORM_SRGB = 75,
     FMT_BC3_UNORM = 77, FMT_BC3_UNORM_SRGB = 78,
@@ -47,7 +49,7 @@ enum : int
     FMT_B8G8R8A8_UNORM_SRGB = 91, FMT_B8G8R8X8_UNORM_SRGB = 93,
     FMT_BC6H_UF16 = 95, FMT_BC6H_SF16 = 96,
     FMT_BC7_UNORM = 98, FMT_BC7_UNORM_SRGB = 99,
-    FMT_AYUV = 100, FMT_Y410 = 101, FMT_Y416 = 102,
+    FMT_AYUV = 100, FMT_Y410 = 101, FMT_Y416 = 102, FMT_YUY2 = 107, FMT_Y210 = 108, FMT_Y216 = 109,
     FMT_B4G4R4A4_UNORM = 115,
 };
 
@@ -205,6 +207,7 @@ __device__ __forceinline__ Texel load_texel(const uint8_t* row, uint32_t x, int 
         t.b = 0.0f; t.a = 1.0f;
         break;
     }
+    case FMT_D16_UNORM:              // :1053, shares R16_UNORM's case
     case FMT_R16_UNORM:
         t.r = float(reinterpret_cast<const uint16_t*>(row)[x]) / 65535.0f; t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;   // :1054-1065
         break;
@@ -221,9 +224,22 @@ __device__ __forceinline__ Texel load_texel(const uint8_t* row, uint32_t x, int 
     case FMT_R8_SNORM:
         t.r = float(int8_t(row[x])) / 127.0f; t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;   // :1139, no clamp
         break;
+    case FMT_D32_FLOAT:              // :937-950, shares R32_FLOAT's case
     case FMT_R32_FLOAT:
         t.r = reinterpret_cast<const float*>(row)[x]; t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;
         break;
+    case FMT_D32_FLOAT_S8X24_UINT:   // (depth, stencil byte, 0, 1), :844-860
+    {
+        const uint2 v = reinterpret_cast<const uint2*>(row)[x];
+        t.r = __uint_as_float(v.x); t.g = float(v.y & 0xFFu); t.b = 0.0f; t.a = 1.0f;
+        break;
+    }
+    case FMT_D24_UNORM_S8_UINT:      // (d / 16777215.f, s, 0, 1): a true division, :982-997
+    {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
+        t.r = float(v & 0xFFFFFFu) / 16777215.0f; t.g = float(v >> 24); t.b = 0.0f; t.a = 1.0f;
+        break;
+    }
     case FMT_R16_FLOAT:
         t.r = __half2float(__ushort_as_half(reinterpret_cast<const uint16_t*>(row)[x])); t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;
         break;
@@ -358,6 +374,52 @@ __device__ __forceinline__ Texel load_texel(const uint8_t* row, uint32_t x, int 
     case FMT_R8_UINT: t.r = float(row[x]); t.g = 0.0f; t.b = 0.0f; t.a = 1.0f; break;                                              // :1119-1130
     case FMT_R8_SINT: t.r = float(int8_t(row[x])); t.g = 0.0f; t.b = 0.0f; t.a = 1.0f; break;                                      // :1145-1156
     // ---- 4:4:4 video formats: the reference's own fixed-point BT.601 matrices (:1291-1392), clamp, true division by the channel maximum
+    // ---- formats whose memory element holds more than one texel: texel x of its element ----
+    case FMT_R1_UNORM:               // eight texels a byte, most significant bit first (:1171-1188)
+        t.r = ((row[x >> 3] >> (7u - (x & 7u))) & 1u) ? 1.0f : 0.0f; t.g = 0.0f; t.b = 0.0f; t.a = 1.0f;
+        break;
+    case FMT_R8G8_B8G8_UNORM:        // XMLoadUByteN4 (x * (1/255.f)) of (R, G0, B, G1): texel 0 = (R, G0, B), texel 1 = (R, G1, B) (:1192-1207)
+    {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x >> 1];
+        t.r = float(v & 0xFFu) * (1.0f / 255.0f); t.g = float((v >> ((x & 1u) ? 24 : 8)) & 0xFFu) * (1.0f / 255.0f);
+        t.b = float((v >> 16) & 0xFFu) * (1.0f / 255.0f); t.a = 1.0f;
+        break;
+    }
+    case FMT_G8R8_G8B8_UNORM:        // (G0, R, G1, B): texel 0 = (R, G0, B), texel 1 = (R, G1, B) (:1209-1225)
+    {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x >> 1];
+        t.r = float((v >> 8) & 0xFFu) * (1.0f / 255.0f); t.g = float((v >> ((x & 1u) ? 16 : 0)) & 0xFFu) * (1.0f / 255.0f);
+        t.b = float(v >> 24) * (1.0f / 255.0f); t.a = 1.0f;
+        break;
+    }
+    case FMT_YUY2:                   // (Y0, U, Y1, V) bytes, BT.601 integer matrix, true divisions by 255 (:1399-1434)
+    {
+        const uint32_t w = reinterpret_cast<const uint32_t*>(row)[x >> 1];
+        const int y = int((w >> ((x & 1u) ? 16 : 0)) & 0xFFu) - 16, u = int((w >> 8) & 0xFFu) - 128, v = int(w >> 24) - 128;
+        const int r = (298 * y + 409 * v + 128) >> 8, g = (298 * y - 100 * u - 208 * v + 128) >> 8, b = (298 * y + 516 * u + 128) >> 8;
+        t.r = float(min(max(r, 0), 255)) / 255.0f; t.g = float(min(max(g, 0), 255)) / 255.0f; t.b = float(min(max(b, 0), 255)) / 255.0f; t.a = 1.0f;
+        break;
+    }
+    case FMT_Y210:                   // Y216's layout with the low six bits of every word unused (:1436-1472)
+    case FMT_Y216:                   // (Y0, U, Y1, V) words (:1474-1510)
+    {
+        const uint2 w = reinterpret_cast<const uint2*>(row)[x >> 1];
+        const uint32_t wy = (x & 1u) ? (w.y & 0xFFFFu) : (w.x & 0xFFFFu), wu = w.x >> 16, wv = w.y >> 16;
+        if (format == FMT_Y210)
+        {
+            const long long y = (long long)(wy >> 6) - 64, u = (long long)(wu >> 6) - 512, v = (long long)(wv >> 6) - 512;
+            const int r = int((76533 * y + 104905 * v + 32768) >> 16), g = int((76533 * y - 25747 * u - 53425 * v + 32768) >> 16), b = int((76533 * y + 132590 * u + 32768) >> 16);
+            t.r = float(min(max(r, 0), 1023)) / 1023.0f; t.g = float(min(max(g, 0), 1023)) / 1023.0f; t.b = float(min(max(b, 0), 1023)) / 1023.0f;
+        }
+        else
+        {
+            const long long y = (long long)wy - 4096, u = (long long)wu - 32768, v = (long long)wv - 32768;
+            const int r = int((76607 * y + 105006 * v + 32768) >> 16), g = int((76607 * y - 25772 * u - 53477 * v + 32768) >> 16), b = int((76607 * y + 132718 * u + 32768) >> 16);
+            t.r = float(min(max(r, 0), 65535)) / 65535.0f; t.g = float(min(max(g, 0), 65535)) / 65535.0f; t.b = float(min(max(b, 0), 65535)) / 65535.0f;
+        }
+        t.a = 1.0f;
+        break;
+    }
     case FMT_AYUV:
     {
         const uint32_t w = reinterpret_cast<const uint32_t*>(row)[x];
@@ -432,11 +494,65 @@ __device__ __forceinline__ float linear_to_srgb1(float v)
 
 enum : int { TCV_SRGB_TO_LINEAR = 0x100, TCV_LINEAR_TO_SRGB = 0x200 };   // or-ed into SrcView::tcv by the compress path
 
+// ConvertScanline's depth conversions (:3186-3451), one code per step, packed TDP_A | TDP_B << 4 | TDP_C << 8 (0 = none). Depth
+// travels in x and stencil in y of the float row (LoadScanline); the steps run in the reference's order: stencil -> alpha, depth ->
+// RGB (depth source), or channel -> depth, its range conversion, alpha -> stencil (depth target).
+enum : int
+{
+    TDP_S2A_UNORM = 1,   // w = clamp(y, 0, 255) / 255 (:3196-3209)
+    TDP_S2A_SNORM = 2,   // w = clamp(y, 0, 255) / 255 * 2 - 1 (:3210-3224)
+    TDP_S2A_RAW = 3,     // w = y (:3225-3235)
+    TDP_A2S_UNORM = 4,   // y = w * 255 (:3396-3408)
+    TDP_A2S_SNORM = 5,   // y = (w * 0.5 + 0.5) * 255 (:3409-3422)
+    TDP_A2S_RAW = 6,     // y = w (:3423-3433)
+    TDP_D2RGB_SAT = 1,   // xyz = saturate(x): float depth -> UNORM (:3239-3250)
+    TDP_D2RGB_U2S = 2,   // xyz = x * 2 - 1: UNORM depth -> SNORM (:3253-3265)
+    TDP_D2RGB_CLAMPS = 3,// xyz = clamp(x, -1, 1): float depth -> SNORM (:3266-3278)
+    TDP_D2RGB_RAW = 4,   // xyz = x (:3280-3290)
+    TDP_X_FROM_Y = 5, TDP_X_FROM_Z = 6, TDP_X_FROM_W = 7,    // TEX_FILTER_RGB_COPY_GREEN / BLUE / ALPHA -> depth (:3295-3328)
+    TDP_X_GRAY = 8,      // x = dot3(v, g_Grayscale): UNORM RGB source without a copy flag (:3330-3343)
+    TDP_X_S2U = 1,       // x = x * 0.5 + 0.5 (:3368-3379)
+    TDP_X_SAT = 2,       // x = saturate(x) (:3380-3391, :3440-3449)
+};
+
+__device__ __forceinline__ Texel apply_depth(Texel t, int op)
+{
+    const int a = op & 15, b = (op >> 4) & 15, c = (op >> 8) & 15;
+    if (a == TDP_S2A_UNORM || a == TDP_S2A_SNORM)
+    {
+        float s = (t.g > 0.0f) ? t.g : 0.0f; s = (s < 255.0f) ? s : 255.0f;      // XMVectorClamp: max with the lower bound, then min
+        s = s / 255.0f;
+        t.a = (a == TDP_S2A_SNORM) ? (s * 2.0f + -1.0f) : s;
+    }
+    else if (a == TDP_S2A_RAW) t.a = t.g;
+    switch (b)
+    {
+    case TDP_D2RGB_SAT: { float v = (t.r > 0.0f) ? t.r : 0.0f; v = (v < 1.0f) ? v : 1.0f; t.r = t.g = t.b = v; break; }
+    case TDP_D2RGB_U2S: { const float v = t.r * 2.0f + -1.0f; t.r = t.g = t.b = v; break; }
+    case TDP_D2RGB_CLAMPS: { float v = (t.r > -1.0f) ? t.r : -1.0f; v = (v < 1.0f) ? v : 1.0f; t.r = t.g = t.b = v; break; }
+    case TDP_D2RGB_RAW: t.g = t.b = t.r; break;
+    case TDP_X_FROM_Y: t.r = t.g; break;
+    case TDP_X_FROM_Z: t.r = t.b; break;
+    case TDP_X_FROM_W: t.r = t.a; break;
+    case TDP_X_GRAY: t.r = (t.r * 0.2125f + t.g * 0.7154f) + t.b * 0.0721f; break;
+    default: break;
+    }
+    if (c == TDP_X_S2U) t.r = t.r * 0.5f + 0.5f;
+    else if (c == TDP_X_SAT) { float v = (t.r > 0.0f) ? t.r : 0.0f; t.r = (v < 1.0f) ? v : 1.0f; }
+    if (a == TDP_A2S_UNORM) t.g = t.a * 255.0f;
+    else if (a == TDP_A2S_SNORM) t.g = (t.a * 0.5f + 0.5f) * 255.0f;
+    else if (a == TDP_A2S_RAW) t.g = t.a;
+    return t;
+}
+
+// tsw carries the depth steps of a depth source in its upper bits (tsw = TSW_* | TDP word << 8): Compress from a depth format
 __device__ __forceinline__ Texel convert_texel(Texel t, int tcv, int tsw)
 {
     if (tcv & TCV_SRGB_TO_LINEAR) { t.r = srgb_to_linear1(t.r); t.g = srgb_to_linear1(t.g); t.b = srgb_to_linear1(t.b); }   // first, :3170-3180
     const int srgbOut = tcv & TCV_LINEAR_TO_SRGB;
     tcv &= 0xFF;
+    if (tsw >> 8) t = apply_depth(t, tsw >> 8);
+    tsw &= 0xFF;
     if (tcv != TCV_NONE)
     {
         t.r = tcv1(t.r, tcv); t.g = tcv1(t.g, tcv); t.b = tcv1(t.b, tcv); t.a = tcv1(t.a, tcv);

@@ -13,6 +13,9 @@ enum FmtClass : uint32_t
     FC_UINT = 0x400, FC_SINT = 0x800,      // CONVF_UINT / CONVF_SINT: the value itself travels through the float row
     FC_XR = 0x1000,          // CONVF_XR (R10G10B10_XR_BIAS_A2_UNORM)
     FC_YUV = 0x2000,         // CONVF_YUV: converted to / from RGB inside LoadScanline / StoreScanline
+    FC_PACKED = 0x10000,     // CONVF_PACKED: two texels share an element (LoadScanline / StoreScanline unpack / pack)
+    FC_GROUP = 0x20000,      // ours: an element holds several texels (the packed formats and R1_UNORM) - stores go through store_group()
+    FC_DEPTH = 0x4000, FC_STENCIL = 0x8000,    // CONVF_DEPTH / CONVF_STENCIL: depth in x, stencil in y of the float row; no R / G / B / A bits
 };
 
 struct FmtInfo { int format; uint32_t bpp; uint32_t cls; };
@@ -66,6 +69,14 @@ inline const FmtInfo* format_info(int format)
         { FMT_R10G10B10_XR_BIAS_A2_UNORM, 32, FC_UNORM | FC_XR | FC_R | FC_G | FC_B | FC_A },
         { FMT_AYUV, 32, FC_UNORM | FC_YUV | FC_R | FC_G | FC_B | FC_A }, { FMT_Y410, 32, FC_UNORM | FC_YUV | FC_R | FC_G | FC_B | FC_A },
         { FMT_Y416, 64, FC_UNORM | FC_YUV | FC_R | FC_G | FC_B | FC_A },
+        // several texels per element (:3010, :3012-3013, :3038-3040); bpp = bits of an element / texels in it
+        { FMT_R1_UNORM, 1, FC_UNORM | FC_R | FC_GROUP },
+        { FMT_R8G8_B8G8_UNORM, 16, FC_UNORM | FC_PACKED | FC_GROUP | FC_R | FC_G | FC_B }, { FMT_G8R8_G8B8_UNORM, 16, FC_UNORM | FC_PACKED | FC_GROUP | FC_R | FC_G | FC_B },
+        { FMT_YUY2, 16, FC_UNORM | FC_YUV | FC_PACKED | FC_GROUP | FC_R | FC_G | FC_B },
+        { FMT_Y210, 32, FC_UNORM | FC_YUV | FC_PACKED | FC_GROUP | FC_R | FC_G | FC_B }, { FMT_Y216, 32, FC_UNORM | FC_YUV | FC_PACKED | FC_GROUP | FC_R | FC_G | FC_B },
+        // depth / stencil (:2976, :2990, :2994, :3000)
+        { FMT_D32_FLOAT_S8X24_UINT, 64, FC_FLOAT | FC_DEPTH | FC_STENCIL }, { FMT_D32_FLOAT, 32, FC_FLOAT | FC_DEPTH },
+        { FMT_D24_UNORM_S8_UINT, 32, FC_UNORM | FC_DEPTH | FC_STENCIL }, { FMT_D16_UNORM, 16, FC_UNORM | FC_DEPTH },
         { FMT_BC1_UNORM, 4, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A },
         { FMT_BC1_UNORM_SRGB, 4, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_SRGB },
         { FMT_BC2_UNORM, 8, FC_UNORM | FC_BC | FC_R | FC_G | FC_B | FC_A },

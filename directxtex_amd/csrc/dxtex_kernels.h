@@ -58,7 +58,11 @@ struct TriangleTables { const uint32_t* ofsX; const void* entX; const uint32_t* 
 hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, uint32_t srcH, uint8_t* dst, uint64_t dstPitch,
                          uint32_t dstW, uint32_t dstH, int format, uint32_t filterMode, uint32_t filterFlags, bool mipAlias,
                          const TriangleTables* tri, hipStream_t stream,
-                         const uint8_t* staleLevel = nullptr, uint64_t stalePitch = 0, uint32_t staleW = 0);
+                         const uint8_t* staleLevel = nullptr, uint64_t stalePitch = 0, uint32_t staleW = 0, int dstFormat = -1);
+// dstFormat >= 0: the destination rows are written in that format instead of `format` (R32G32B32A32_FLOAT rows for launch_pack_group).
+
+// Formats whose element holds several texels (FC_GROUP): R32G32B32A32_FLOAT rows -> the format, with StoreScanline's pair / bit packing.
+hipError_t launch_pack_group(const uint8_t* rows, uint64_t rowsPitch, uint8_t* dst, uint64_t dstPitch, int dstFormat, uint32_t width, uint32_t height, hipStream_t stream);
 
 // The tail of a 2-D mip chain (levels[0] = the first source level, at most 64 x 64; levels[1..] = the levels generated from it) in one
 // workgroup: point / linear / cubic / box, the arithmetic of launch_resize with mipAlias. twoHigh = the last level of the chain before

@@ -13,9 +13,36 @@ enum : uint32_t
     TF_SRGB_IN = 0x1000000, TF_SRGB_OUT = 0x2000000,
 };
 
+// The depth branch of ConvertScanline (:3186-3434) as a TDP word (dxtex_device.h); in / out differ in FC_DEPTH
+inline int resolve_depth_steps(const FmtInfo& in, const FmtInfo& out, uint32_t flags)
+{
+    int a = 0, b = 0, c = 0;
+    if (in.cls & FC_DEPTH)
+    {
+        if (in.cls & FC_STENCIL) a = (out.cls & FC_UNORM) ? TDP_S2A_UNORM : (out.cls & FC_SNORM) ? TDP_S2A_SNORM : TDP_S2A_RAW;
+        if ((out.cls & FC_UNORM) && (in.cls & FC_FLOAT)) b = TDP_D2RGB_SAT;
+        else if (out.cls & FC_SNORM) b = (in.cls & FC_UNORM) ? TDP_D2RGB_U2S : TDP_D2RGB_CLAMPS;
+        else b = TDP_D2RGB_RAW;
+    }
+    else
+    {
+        switch (flags & (TF_COPY_RED | TF_COPY_GREEN | TF_COPY_BLUE | TF_COPY_ALPHA))
+        {
+        case TF_COPY_GREEN: b = TDP_X_FROM_Y; break;
+        case TF_COPY_BLUE: b = TDP_X_FROM_Z; break;
+        case TF_COPY_ALPHA: b = TDP_X_FROM_W; break;
+        case TF_COPY_RED: break;
+        default: if ((in.cls & FC_UNORM) && (in.cls & (FC_R | FC_G | FC_B)) == (FC_R | FC_G | FC_B)) b = TDP_X_GRAY; break;
+        }
+        if (out.cls & FC_UNORM) c = (in.cls & FC_SNORM) ? TDP_X_S2U : (in.cls & FC_FLOAT) ? TDP_X_SAT : 0;
+        if (out.cls & FC_STENCIL) a = (in.cls & FC_UNORM) ? TDP_A2S_UNORM : (in.cls & FC_SNORM) ? TDP_A2S_SNORM : TDP_A2S_RAW;
+    }
+    return a | (b << 4) | (c << 8);
+}
+
 inline ConvertPlan resolve_convert_plan(const FmtInfo& in, const FmtInfo& out, uint32_t flags)
 {
-    ConvertPlan p; p.srgbIn = 0; p.tcv = TCV_NONE; p.tsw = TSW_NONE; p.srgbOut = 0;
+    ConvertPlan p; p.srgbIn = 0; p.tcv = TCV_NONE; p.tsw = TSW_NONE; p.srgbOut = 0; p.depth = 0;
 
     // :3123-3167
     if (in.cls & FC_SRGB) flags |= TF_SRGB_IN;
@@ -23,17 +50,19 @@ inline ConvertPlan resolve_convert_plan(const FmtInfo& in, const FmtInfo& out, u
     if (out.cls & FC_SRGB) flags |= TF_SRGB_OUT;
     if (out.format == FMT_A8_UNORM || out.format == FMT_R10G10B10_XR_BIAS_A2_UNORM) flags &= ~TF_SRGB_OUT;    // :3156-3159
     if ((flags & (TF_SRGB_IN | TF_SRGB_OUT)) == (TF_SRGB_IN | TF_SRGB_OUT)) flags &= ~(TF_SRGB_IN | TF_SRGB_OUT);
-    if ((flags & TF_SRGB_IN) && (in.cls & (FC_FLOAT | FC_UNORM))) p.srgbIn = 1;
-    if ((flags & TF_SRGB_OUT) && (out.cls & (FC_FLOAT | FC_UNORM))) p.srgbOut = 1;
+    if ((flags & TF_SRGB_IN) && !(in.cls & FC_DEPTH) && (in.cls & (FC_FLOAT | FC_UNORM))) p.srgbIn = 1;        // :3170-3180
+    if ((flags & TF_SRGB_OUT) && !(out.cls & FC_DEPTH) && (out.cls & (FC_FLOAT | FC_UNORM))) p.srgbOut = 1;    // :3843-3853
 
     // the reference compares its CONVF_* words; what can differ among our formats: type class, channel set, BC-ness,
     // BGR order. BGR-only differences reach no branch below, so they can be left out of the test.
-    const uint32_t kDiffMask = FC_UNORM | FC_SNORM | FC_FLOAT | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_POS_ONLY | FC_UINT | FC_SINT | FC_XR | FC_YUV;
+    const uint32_t kDiffMask = FC_UNORM | FC_SNORM | FC_FLOAT | FC_BC | FC_R | FC_G | FC_B | FC_A | FC_POS_ONLY | FC_UINT | FC_SINT | FC_XR | FC_YUV | FC_DEPTH | FC_STENCIL | FC_PACKED;
     const uint32_t diff = (in.cls ^ out.cls) & kDiffMask;
     if (!diff) return p;
 
     const bool x2 = (flags & TF_FLOAT_X2BIAS) != 0;
-    if (out.cls & FC_UNORM)
+    if (diff & FC_DEPTH) p.depth = resolve_depth_steps(in, out, flags);                                // :3186-3434
+    else if (out.cls & FC_DEPTH) { if ((diff & FC_FLOAT) && (in.cls & FC_FLOAT)) p.depth = TDP_X_SAT << 8; }   // depth -> depth, :3435-3451
+    else if (out.cls & FC_UNORM)
     {
         if (in.cls & FC_SNORM) p.tcv = TCV_SNORM_TO_UNORM;                                            // :3457-3463
         else if (in.cls & FC_FLOAT) p.tcv = (!(in.cls & FC_POS_ONLY) && x2) ? TCV_X2BIAS_TO_UNORM : TCV_SATURATE;   // :3465-3489

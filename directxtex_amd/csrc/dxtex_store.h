@@ -37,11 +37,13 @@ struct ConvertPlan
     int tcv;         // TCV_*
     int tsw;         // TSW_*
     int srgbOut;     // XMColorRGBToSRGB last
+    int depth;       // TDP_* word (dxtex_device.h): the depth conversions, in place of the range conversion
 };
 
 __device__ __forceinline__ Texel apply_plan(Texel t, const ConvertPlan& p)
 {
     if (p.srgbIn) { t.r = srgb_to_linear1(t.r); t.g = srgb_to_linear1(t.g); t.b = srgb_to_linear1(t.b); }
+    if (p.depth) t = apply_depth(t, p.depth);
     if (p.tcv != TCV_NONE)
     {
         t.r = tcv1(t.r, p.tcv); t.g = tcv1(t.g, p.tcv); t.b = tcv1(t.b, p.tcv); t.a = tcv1(t.a, p.tcv);
@@ -295,9 +297,24 @@ __device__ __forceinline__ void store_texel(uint8_t* row, uint32_t x, int format
     case FMT_R16G16_UNORM:
         reinterpret_cast<uint32_t*>(row)[x] = store_usn(t.r) | (store_usn(t.g) << 16);
         break;
+    case FMT_D32_FLOAT:              // :1810-1822, shares R32_FLOAT's case
     case FMT_R32_FLOAT:
         reinterpret_cast<float*>(row)[x] = t.r;
         break;
+    case FMT_D32_FLOAT_S8X24_UINT:   // depth as it is, stencil = uint8(min(255, max(0, y))), the other three bytes zero (:1725-1744)
+    {
+        float sv = (0.0f < t.g) ? t.g : 0.0f;            // std::max<float>(0.f, y): NaN -> 0
+        sv = (sv < 255.0f) ? sv : 255.0f;
+        reinterpret_cast<uint2*>(row)[x] = make_uint2(__float_as_uint(t.r), uint32_t(sv) & 0xFFu);
+        break;
+    }
+    case FMT_D24_UNORM_S8_UINT:      // XMVectorClamp(v, 0, (1, 255)); uint32(x * 16777215.f) & 0xFFFFFF | (uint32(y) & 0xFF) << 24 (:1852-1869)
+    {
+        float d = (t.r > 0.0f) ? t.r : 0.0f; d = (d < 1.0f) ? d : 1.0f;
+        float sv = (t.g > 0.0f) ? t.g : 0.0f; sv = (sv < 255.0f) ? sv : 255.0f;
+        reinterpret_cast<uint32_t*>(row)[x] = (uint32_t(d * 16777215.0f) & 0xFFFFFFu) | ((uint32_t(sv) & 0xFFu) << 24);
+        break;
+    }
     case FMT_R8G8_UNORM:
         reinterpret_cast<uint16_t*>(row)[x] = uint16_t(store_ubn2(t.r) | (store_ubn2(t.g) << 8));
         break;
@@ -307,6 +324,7 @@ __device__ __forceinline__ void store_texel(uint8_t* row, uint32_t x, int format
     case FMT_R16_FLOAT:
         reinterpret_cast<uint16_t*>(row)[x] = store_half(t.r);       // std::max(std::min(v, 65504), -65504) (:1891)
         break;
+    case FMT_D16_UNORM:              // :1897, shares R16_UNORM's case
     case FMT_R16_UNORM:
     {
         // v = clamp(x, 0, 1); uint16(v * 65535 + 0.5) (:1898-1912)
@@ -438,6 +456,79 @@ __device__ __forceinline__ void store_texel(uint8_t* row, uint32_t x, int format
                   v = int((28672 * r - 24010 * g - 4662 * b + 32768) >> 16) + 32768;
         reinterpret_cast<uint2*>(row)[x] = make_uint2(uint32_t(min(max(u, 0), 65535)) | (uint32_t(min(max(y, 0), 65535)) << 16),
                                                       uint32_t(min(max(v, 0), 65535)) | (store_usn(t.a) << 16));
+        break;
+    }
+    default:
+        break;
+    }
+}
+
+// ---- formats whose memory element holds more than one texel (FC_GROUP): one element from its texels ------------------------------
+// texels per element
+__host__ __device__ inline uint32_t group_texels(int format) { return format == FMT_R1_UNORM ? 8u : 2u; }
+__host__ __device__ inline uint32_t group_bytes(int format) { return format == FMT_R1_UNORM ? 1u : (format == FMT_Y210 || format == FMT_Y216) ? 8u : 4u; }
+
+// Element `g` of a row from texels t[0 .. n) (n = the texels of the element that exist: the last element of an odd-width row is
+// short; StoreScanline's missing second texel is a zero vector - which still goes through the colour matrix of the video formats).
+__device__ __forceinline__ void store_group(uint8_t* row, uint32_t g, int format, const Texel* t, uint32_t n)
+{
+    const Texel zero = { 0.0f, 0.0f, 0.0f, 0.0f };
+    const Texel t0 = t[0], t1 = (n > 1) ? t[1] : zero;
+    switch (format)
+    {
+    case FMT_R1_UNORM:               // bit set where x > 0.25, first texel in the most significant bit (:2033-2055)
+    {
+        uint32_t bits = 0;
+        for (uint32_t k = 0; k < n; ++k) if (t[k].r > 0.25f) bits |= 0x80u >> k;
+        row[g] = uint8_t(bits);
+        break;
+    }
+    case FMT_R8G8_B8G8_UNORM:        // (R0, G0, B0, G1) + g_8BitBias through XMStoreUByteN4 (:2060-2075)
+        reinterpret_cast<uint32_t*>(row)[g] = store_ubn_biased(t0.r) | (store_ubn_biased(t0.g) << 8) | (store_ubn_biased(t0.b) << 16) | (store_ubn_biased(t1.g) << 24);
+        break;
+    case FMT_G8R8_G8B8_UNORM:        // (G0, R0, G1, B0) (:2077-2094)
+        reinterpret_cast<uint32_t*>(row)[g] = store_ubn_biased(t0.g) | (store_ubn_biased(t0.r) << 8) | (store_ubn_biased(t1.g) << 16) | (store_ubn_biased(t0.b) << 24);
+        break;
+    case FMT_YUY2:                   // XMStoreUByteN4 (no bias) of both texels, BT.601 matrix each, chroma averaged (:2274-2308)
+    {
+        int yy[2], uu[2], vv[2];
+        const Texel* src[2] = { &t0, &t1 };
+        for (int k = 0; k < 2; ++k)
+        {
+            const int r = int(store_ubn_plain(src[k]->r)), gr = int(store_ubn_plain(src[k]->g)), b = int(store_ubn_plain(src[k]->b));
+            yy[k] = ((66 * r + 129 * gr + 25 * b + 128) >> 8) + 16; uu[k] = ((-38 * r - 74 * gr + 112 * b + 128) >> 8) + 128; vv[k] = ((112 * r - 94 * gr - 18 * b + 128) >> 8) + 128;
+        }
+        reinterpret_cast<uint32_t*>(row)[g] = uint32_t(min(max(yy[0], 0), 255)) | (uint32_t(min(max((uu[0] + uu[1]) >> 1, 0), 255)) << 8) |
+                                              (uint32_t(min(max(yy[1], 0), 255)) << 16) | (uint32_t(min(max((vv[0] + vv[1]) >> 1, 0), 255)) << 24);
+        break;
+    }
+    case FMT_Y210:                   // XMStoreUDecN4 of both texels, the 10-bit matrix, results shifted up six bits (:2310-2353)
+    {
+        int yy[2], uu[2], vv[2];
+        const Texel* src[2] = { &t0, &t1 };
+        for (int k = 0; k < 2; ++k)
+        {
+            const uint32_t q = store_udecn4(*src[k]);
+            const long long r = q & 0x3FFu, gr = (q >> 10) & 0x3FFu, b = (q >> 20) & 0x3FFu;
+            yy[k] = int((16780 * r + 32942 * gr + 6544 * b + 32768) >> 16) + 64; uu[k] = int((-9683 * r - 19017 * gr + 28700 * b + 32768) >> 16) + 512;
+            vv[k] = int((28700 * r - 24033 * gr - 4667 * b + 32768) >> 16) + 512;
+        }
+        reinterpret_cast<uint2*>(row)[g] = make_uint2((uint32_t(min(max(yy[0], 0), 1023)) << 6) | (uint32_t(min(max((uu[0] + uu[1]) >> 1, 0), 1023)) << 22),
+                                                      (uint32_t(min(max(yy[1], 0), 1023)) << 6) | (uint32_t(min(max((vv[0] + vv[1]) >> 1, 0), 1023)) << 22));
+        break;
+    }
+    case FMT_Y216:                   // XMStoreUShortN4 of both texels, the 16-bit matrix (:2355-2397)
+    {
+        int yy[2], uu[2], vv[2];
+        const Texel* src[2] = { &t0, &t1 };
+        for (int k = 0; k < 2; ++k)
+        {
+            const long long r = store_usn(src[k]->r), gr = store_usn(src[k]->g), b = store_usn(src[k]->b);
+            yy[k] = int((16763 * r + 32910 * gr + 6537 * b + 32768) >> 16) + 4096; uu[k] = int((-9674 * r - 18998 * gr + 28672 * b + 32768) >> 16) + 32768;
+            vv[k] = int((28672 * r - 24010 * gr - 4662 * b + 32768) >> 16) + 32768;
+        }
+        reinterpret_cast<uint2*>(row)[g] = make_uint2(uint32_t(min(max(yy[0], 0), 65535)) | (uint32_t(min(max((uu[0] + uu[1]) >> 1, 0), 65535)) << 16),
+                                                      uint32_t(min(max(yy[1], 0), 65535)) | (uint32_t(min(max((vv[0] + vv[1]) >> 1, 0), 65535)) << 16));
         break;
     }
     default:

@@ -71,19 +71,44 @@ __global__ void __launch_bounds__(256) convert_kernel(ImgView src, ImgView dst, 
     }
 }
 
+// Formats whose element holds several texels (FC_GROUP: R8G8_B8G8, G8R8_G8B8, YUY2, Y210, Y216, R1): every operation that writes
+// one produces R32G32B32A32_FLOAT rows first - exactly the XMVECTOR row the reference hands to StoreScanline - and this kernel
+// stores them, an element per lane.
+__global__ void __launch_bounds__(256) pack_group_kernel(ImgView rows, ImgView dst)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t per = group_texels(dst.format);
+    if (uint64_t(g) * per >= dst.width) return;
+    const uint32_t n = min(per, dst.width - g * per);
+    for (uint32_t y = blockIdx.y; y < dst.height; y += gridDim.y)
+    {
+        const float4* in = reinterpret_cast<const float4*>(rows.pixels + uint64_t(y) * rows.rowPitch) + uint64_t(g) * per;
+        Texel t[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+        {
+            t[k].r = t[k].g = t[k].b = t[k].a = 0.0f;
+            if (k < n) { const float4 v = in[k]; t[k].r = v.x; t[k].g = v.y; t[k].b = v.z; t[k].a = v.w; }
+        }
+        store_group(dst.pixels + uint64_t(y) * dst.rowPitch, g, dst.format, t, n);
+    }
+}
+
 // Four consecutive texels of a row per lane: the source quad arrives in 1-4 sixteen-byte loads (a wavefront reads 1-4 KiB of
 // consecutive bytes per instruction), is decoded / converted / encoded texel by texel with the same load_texel / apply_plan /
 // store_texel as above - on a register image of the quad, every index a compile-time constant - and leaves in 1-4 sixteen-byte
 // stores. Used when a texel is a whole number of dwords on both sides (>= 32 bpp) and rows are 16-byte aligned.
-// every format whose texel is a whole number of dwords (the quad kernel's domain; launch_convert admits no other)
+// every format whose texel is a whole number of dwords (the quad kernel's domain; launch_convert admits no other), with the bytes of a quad
 #define DXTEX_QUAD_FORMATS(X) \
-    X(FMT_R32G32B32A32_FLOAT) X(FMT_R32G32B32A32_UINT) X(FMT_R32G32B32A32_SINT) X(FMT_R32G32B32_FLOAT) X(FMT_R32G32B32_UINT) X(FMT_R32G32B32_SINT) \
-    X(FMT_R16G16B16A16_FLOAT) X(FMT_R16G16B16A16_UNORM) X(FMT_R16G16B16A16_UINT) X(FMT_R16G16B16A16_SNORM) X(FMT_R16G16B16A16_SINT) \
-    X(FMT_R32G32_FLOAT) X(FMT_R32G32_UINT) X(FMT_R32G32_SINT) X(FMT_Y416) \
-    X(FMT_R10G10B10A2_UNORM) X(FMT_R10G10B10A2_UINT) X(FMT_R11G11B10_FLOAT) X(FMT_R8G8B8A8_UNORM) X(FMT_R8G8B8A8_UNORM_SRGB) X(FMT_R8G8B8A8_UINT) \
-    X(FMT_R8G8B8A8_SNORM) X(FMT_R8G8B8A8_SINT) X(FMT_R16G16_FLOAT) X(FMT_R16G16_UNORM) X(FMT_R16G16_UINT) X(FMT_R16G16_SNORM) X(FMT_R16G16_SINT) \
-    X(FMT_R32_FLOAT) X(FMT_R32_UINT) X(FMT_R32_SINT) X(FMT_R9G9B9E5_SHAREDEXP) X(FMT_B8G8R8A8_UNORM) X(FMT_B8G8R8X8_UNORM) \
-    X(FMT_R10G10B10_XR_BIAS_A2_UNORM) X(FMT_B8G8R8A8_UNORM_SRGB) X(FMT_B8G8R8X8_UNORM_SRGB) X(FMT_AYUV) X(FMT_Y410)
+    X(FMT_R32G32B32A32_FLOAT, 64) X(FMT_R32G32B32A32_UINT, 64) X(FMT_R32G32B32A32_SINT, 64) X(FMT_R32G32B32_FLOAT, 48) X(FMT_R32G32B32_UINT, 48) \
+    X(FMT_R32G32B32_SINT, 48) X(FMT_R16G16B16A16_FLOAT, 32) X(FMT_R16G16B16A16_UNORM, 32) X(FMT_R16G16B16A16_UINT, 32) X(FMT_R16G16B16A16_SNORM, 32) \
+    X(FMT_R16G16B16A16_SINT, 32) X(FMT_R32G32_FLOAT, 32) X(FMT_R32G32_UINT, 32) X(FMT_R32G32_SINT, 32) X(FMT_Y416, 32) \
+    X(FMT_R10G10B10A2_UNORM, 16) X(FMT_R10G10B10A2_UINT, 16) X(FMT_R11G11B10_FLOAT, 16) X(FMT_R8G8B8A8_UNORM, 16) X(FMT_R8G8B8A8_UNORM_SRGB, 16) \
+    X(FMT_R8G8B8A8_UINT, 16) X(FMT_R8G8B8A8_SNORM, 16) X(FMT_R8G8B8A8_SINT, 16) X(FMT_R16G16_FLOAT, 16) X(FMT_R16G16_UNORM, 16) \
+    X(FMT_R16G16_UINT, 16) X(FMT_R16G16_SNORM, 16) X(FMT_R16G16_SINT, 16) X(FMT_R32_FLOAT, 16) X(FMT_R32_UINT, 16) \
+    X(FMT_R32_SINT, 16) X(FMT_R9G9B9E5_SHAREDEXP, 16) X(FMT_B8G8R8A8_UNORM, 16) X(FMT_B8G8R8X8_UNORM, 16) X(FMT_R10G10B10_XR_BIAS_A2_UNORM, 16) \
+    X(FMT_B8G8R8A8_UNORM_SRGB, 16) X(FMT_B8G8R8X8_UNORM_SRGB, 16) X(FMT_AYUV, 16) X(FMT_Y410, 16) X(FMT_D32_FLOAT_S8X24_UINT, 32) \
+    X(FMT_D32_FLOAT, 16) X(FMT_D24_UNORM_S8_UINT, 16)
 
 template<int W>
 __device__ __forceinline__ void load_quad(uint32_t (&q)[W], const uint8_t* p, uint32_t bytes)
@@ -136,21 +161,20 @@ __global__ void __launch_bounds__(256) convert_quad_kernel(ImgView src, ImgView 
             // with a run-time format their switch also holds the byte- and word-addressed formats, whose accesses would force the
             // register image of the quad into memory
             Texel tx[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) tx[k].r = tx[k].g = tx[k].b = tx[k].a = 0.0f;
             switch (src.format)
             {
-#define DXTEX_QCASE(F) case F: _Pragma("unroll") for (uint32_t k = 0; k < 4u; ++k) tx[k] = load_texel(reinterpret_cast<const uint8_t*>(in[r]), k, F); break;
+#define DXTEX_QCASE(F, QB) case F: if constexpr (SQ == QB || (SQ == 0 && QB > 0)) { _Pragma("unroll") for (uint32_t k = 0; k < 4u; ++k) tx[k] = load_texel(reinterpret_cast<const uint8_t*>(in[r]), k, F); } break;
                 DXTEX_QUAD_FORMATS(DXTEX_QCASE)
 #undef DXTEX_QCASE
-            default:
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) tx[k].r = tx[k].g = tx[k].b = tx[k].a = 0.0f;
-                break;
+            default: break;
             }
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) tx[k] = apply_plan(tx[k], plan);
             switch (dst.format)
             {
-#define DXTEX_QCASE(F) case F: _Pragma("unroll") for (uint32_t k = 0; k < 4u; ++k) store_texel(reinterpret_cast<uint8_t*>(out), k, F, tx[k], threshold); break;
+#define DXTEX_QCASE(F, QB) case F: if constexpr (DQ == QB || (DQ == 0 && QB > 0)) { _Pragma("unroll") for (uint32_t k = 0; k < 4u; ++k) store_texel(reinterpret_cast<uint8_t*>(out), k, F, tx[k], threshold); } break;
                 DXTEX_QUAD_FORMATS(DXTEX_QCASE)
 #undef DXTEX_QCASE
             default: break;
@@ -795,6 +819,15 @@ bool can_srgb(int format)
 }
 } // namespace
 
+hipError_t launch_pack_group(const uint8_t* rows, uint64_t rowsPitch, uint8_t* dst, uint64_t dstPitch, int dstFormat, uint32_t width, uint32_t height, hipStream_t stream)
+{
+    if (!width || !height) return hipSuccess;
+    const uint32_t per = group_texels(dstFormat), groups = (width + per - 1) / per;
+    hipLaunchKernelGGL(pack_group_kernel, dim3((groups + 255) / 256, grid_rows(height)), dim3(256), 0, stream,
+                       make_view(rows, rowsPitch, width, height, FMT_R32G32B32A32_FLOAT), make_view(dst, dstPitch, width, height, dstFormat));
+    return hipGetLastError();
+}
+
 hipError_t launch_convert(const uint8_t* src, uint64_t srcPitch, int srcFormat, uint8_t* dst, uint64_t dstPitch, int dstFormat,
                           uint32_t width, uint32_t height, const ConvertPlan& plan, float threshold, hipStream_t stream)
 {
@@ -802,7 +835,7 @@ hipError_t launch_convert(const uint8_t* src, uint64_t srcPitch, int srcFormat, 
     const FmtInfo* in = format_info(srcFormat);
     const FmtInfo* out = format_info(dstFormat);
     // four texels per lane through 16-byte loads / stores where a texel is a whole number of dwords on both sides and rows are 16-byte aligned
-    if (in && out && in->bpp >= 32 && out->bpp >= 32 && (in->bpp % 32) == 0 && (out->bpp % 32) == 0 && (width % 4u) == 0 &&
+    if (in && out && !((in->cls | out->cls) & FC_GROUP) && in->bpp >= 32 && out->bpp >= 32 && (in->bpp % 32) == 0 && (out->bpp % 32) == 0 && (width % 4u) == 0 &&
         ((reinterpret_cast<uintptr_t>(src) | srcPitch | reinterpret_cast<uintptr_t>(dst) | dstPitch) & 15u) == 0)
     {
         const uint32_t quads = width / 4u;
@@ -832,13 +865,13 @@ hipError_t launch_convert(const uint8_t* src, uint64_t srcPitch, int srcFormat, 
 
 hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, uint32_t srcH, uint8_t* dst, uint64_t dstPitch,
                          uint32_t dstW, uint32_t dstH, int format, uint32_t filterMode, uint32_t filterFlags, bool mipAlias,
-                         const TriangleTables* tri, hipStream_t stream, const uint8_t* staleLevel, uint64_t stalePitch, uint32_t staleW)
+                         const TriangleTables* tri, hipStream_t stream, const uint8_t* staleLevel, uint64_t stalePitch, uint32_t staleW, int dstFormat)
 {
     if (!dstW || !dstH) return hipSuccess;
     ResizeArgs a;
     a.stale = make_view(staleLevel, stalePitch, staleW, 2, format);
     a.src = make_view(src, srcPitch, srcW, srcH, format);
-    a.dst = make_view(dst, dstPitch, dstW, dstH, format);
+    a.dst = make_view(dst, dstPitch, dstW, dstH, dstFormat >= 0 ? dstFormat : format);
     // sRGB formats filter in linear space; TEX_FILTER_SRGB forces it for the other colour formats (:2803-2945)
     const bool wantIn = srgb_linear_format(format) || (filterFlags & 0x1000000u), wantOut = srgb_linear_format(format) || (filterFlags & 0x2000000u);
     a.srgbIn = (can_srgb(format) && wantIn) ? 1 : 0;

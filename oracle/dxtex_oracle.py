@@ -317,12 +317,19 @@ BPP = {2: 128, 6: 96, 13: 64, 24: 32, 26: 32, 37: 32, 58: 16, 67: 32, 85: 16, 86
        87: 32, 88: 32, 91: 32, 93: 32,
        # integer, extended-range and 4:4:4 video formats
        3: 128, 4: 128, 7: 96, 8: 96, 12: 64, 14: 64, 17: 64, 18: 64, 25: 32, 30: 32, 32: 32, 36: 32, 38: 32, 42: 32, 43: 32, 50: 16, 52: 16, 57: 16, 59: 16, 62: 8, 64: 8,
-       89: 32, 100: 32, 101: 32, 102: 64}
+       89: 32, 100: 32, 101: 32, 102: 64,
+       # depth / stencil
+       20: 64, 40: 32, 45: 32, 55: 16,
+       # several texels per element: R1 (8 per byte); R8G8_B8G8 / G8R8_G8B8 / YUY2 (2 per dword); Y210 / Y216 (2 per qword)
+       66: 1, 68: 16, 69: 16, 107: 16, 108: 32, 109: 32}
+PAIRED = {68: 4, 69: 4, 107: 4, 108: 8, 109: 8}      # bytes of an element of two texels: rows are ((w + 1) >> 1) elements (ComputePitch)
 
 
 def image_bytes(fmt, w, h):
     if fmt in BC_BLOCK_BYTES:
         return max(1, (w + 3) // 4) * max(1, (h + 3) // 4) * BC_BLOCK_BYTES[fmt]
+    if fmt in PAIRED:
+        return ((w + 1) >> 1) * PAIRED[fmt] * h
     return (w * BPP[fmt] + 7) // 8 * h
 
 

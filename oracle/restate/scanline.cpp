@@ -99,7 +99,7 @@ namespace
     inline uint32_t store_scaled(float v, float scale) { return uint32_t(int32_t(nearbyintf(clampf(v * scale, 0.f, scale)))); }                   // XMStoreU565/U555/UNibble4 after the reference's multiply
 
     enum : uint32_t { C_UNORM = 1, C_SNORM = 2, C_FLOAT = 4, C_R = 0x10, C_G = 0x20, C_B = 0x40, C_A = 0x80, C_BC = 8, C_POS_ONLY = 0x200,
-                      C_UINT = 0x400, C_SINT = 0x800, C_XR = 0x1000, C_YUV = 0x2000 };
+                      C_UINT = 0x400, C_SINT = 0x800, C_XR = 0x1000, C_YUV = 0x2000, C_DEPTH = 0x4000, C_STENCIL = 0x8000, C_PACKED = 0x10000 };
 
     // The integer formats (value = the integer itself), as a table: channels, bits per channel, signedness. `scalar` marks the single-channel
     // 8- / 16-bit formats, which the reference loads and stores with its own scalar code (C++ casts: truncation, :1067-1156, :1913-2016); the
@@ -182,6 +182,13 @@ namespace
         case DXGI_FORMAT_R10G10B10_XR_BIAS_A2_UNORM: return C_UNORM | C_XR | C_R | C_G | C_B | C_A;                                        // :3030
         case DXGI_FORMAT_AYUV: case DXGI_FORMAT_Y410: case DXGI_FORMAT_Y416: return C_UNORM | C_YUV | C_R | C_G | C_B | C_A;                  // :3037-3039
         case DXGI_FORMAT_R10G10B10A2_UINT: return C_UINT | C_R | C_G | C_B | C_A;                                                         // :2978
+        case DXGI_FORMAT_D32_FLOAT_S8X24_UINT: return C_FLOAT | C_DEPTH | C_STENCIL;                                                      // :2976
+        case DXGI_FORMAT_D32_FLOAT: return C_FLOAT | C_DEPTH;                                                                           // :2990
+        case DXGI_FORMAT_D24_UNORM_S8_UINT: return C_UNORM | C_DEPTH | C_STENCIL;                                                         // :2994
+        case DXGI_FORMAT_D16_UNORM: return C_UNORM | C_DEPTH;                                                                           // :3000
+        case DXGI_FORMAT_R1_UNORM: return C_UNORM | C_R;                                                                                 // :3010
+        case DXGI_FORMAT_R8G8_B8G8_UNORM: case DXGI_FORMAT_G8R8_G8B8_UNORM: return C_UNORM | C_PACKED | C_R | C_G | C_B;                   // :3012-3013
+        case DXGI_FORMAT_YUY2: case DXGI_FORMAT_Y210: case DXGI_FORMAT_Y216: return C_UNORM | C_YUV | C_PACKED | C_R | C_G | C_B;          // :3038-3040
         default:
             if (const IntFormat* e = int_format(f))
                 return (e->isSigned ? C_SINT : C_UINT) | C_R | (e->channels > 1 ? C_G : 0) | (e->channels > 2 ? C_B : 0) | (e->channels > 3 ? C_A : 0);
@@ -287,6 +294,76 @@ bool DirectX::Internal::LoadScanline(XMVECTOR* pDestination, size_t count, const
                                           float(std::min<int>(std::max<int>(bl, 0), 65535)) / 65535.f, float(std::min<int>(std::max<int>(a, 0), 65535)) / 65535.f);
         }
         return true;
+    // ---- formats whose element holds several texels: the reference's element loops, two (eight) destinations per element ----
+    case DXGI_FORMAT_R1_UNORM:                  // :1171-1188
+    {
+        size_t o = 0;
+        for (size_t icount = 0; icount < size; ++icount)
+            for (size_t bcount = 8; bcount > 0; --bcount)
+            {
+                if (o >= count) break;
+                pDestination[o++] = XMVectorSet(((s[icount] >> (bcount - 1)) & 0x1) ? 1.f : 0.f, 0.f, 0.f, 1.f);
+            }
+        return true;
+    }
+    case DXGI_FORMAT_R8G8_B8G8_UNORM:           // :1192-1207: XMLoadUByteN4, then (x, y, z, 1) and (x, w, z, 1)
+    case DXGI_FORMAT_G8R8_G8B8_UNORM:           // :1209-1225: (y, x, w, 1) and (y, z, w, 1)
+    {
+        if (size < 4) return false;
+        size_t o = 0;
+        for (size_t icount = 0; icount < (size - 4 + 1); icount += 4)
+        {
+            const float v[4] = { float(s[icount]) * (1.0f / 255.0f), float(s[icount + 1]) * (1.0f / 255.0f), float(s[icount + 2]) * (1.0f / 255.0f), float(s[icount + 3]) * (1.0f / 255.0f) };
+            const bool rg = format == DXGI_FORMAT_R8G8_B8G8_UNORM;
+            if (o >= count) break;
+            pDestination[o++] = rg ? XMVectorSet(v[0], v[1], v[2], 1.f) : XMVectorSet(v[1], v[0], v[3], 1.f);
+            if (o >= count) break;
+            pDestination[o++] = rg ? XMVectorSet(v[0], v[3], v[2], 1.f) : XMVectorSet(v[1], v[2], v[3], 1.f);
+        }
+        return true;
+    }
+    case DXGI_FORMAT_YUY2:                      // :1399-1434
+    {
+        if (size < 4) return false;
+        size_t o = 0;
+        for (size_t icount = 0; icount < (size - 4 + 1); icount += 4)
+        {
+            const int y0 = int(s[icount]) - 16, u = int(s[icount + 1]) - 128, y1 = int(s[icount + 2]) - 16, v = int(s[icount + 3]) - 128;
+            for (int half = 0; half < 2; ++half)
+            {
+                const int y = half ? y1 : y0;
+                const int r = (298 * y + 409 * v + 128) >> 8, g = (298 * y - 100 * u - 208 * v + 128) >> 8, b = (298 * y + 516 * u + 128) >> 8;
+                if (o >= count) break;
+                pDestination[o++] = XMVectorSet(float(std::min<int>(std::max<int>(r, 0), 255)) / 255.f, float(std::min<int>(std::max<int>(g, 0), 255)) / 255.f,
+                                                float(std::min<int>(std::max<int>(b, 0), 255)) / 255.f, 1.f);
+            }
+        }
+        return true;
+    }
+    case DXGI_FORMAT_Y210:                      // :1436-1472
+    case DXGI_FORMAT_Y216:                      // :1474-1510
+    {
+        if (size < 8) return false;
+        const bool ten = format == DXGI_FORMAT_Y210;
+        size_t o = 0;
+        for (size_t icount = 0; icount < (size - 8 + 1); icount += 8)
+        {
+            uint16_t h[4]; memcpy(h, s + icount, 8);
+            const int64_t y0 = ten ? int64_t(h[0] >> 6) - 64 : int64_t(h[0]) - 4096, u = ten ? int64_t(h[1] >> 6) - 512 : int64_t(h[1]) - 32768;
+            const int64_t y1 = ten ? int64_t(h[2] >> 6) - 64 : int64_t(h[2]) - 4096, v = ten ? int64_t(h[3] >> 6) - 512 : int64_t(h[3]) - 32768;
+            for (int half = 0; half < 2; ++half)
+            {
+                const int64_t y = half ? y1 : y0;
+                int r, g, b; float top;
+                if (ten) { r = int((76533 * y + 104905 * v + 32768) >> 16); g = int((76533 * y - 25747 * u - 53425 * v + 32768) >> 16); b = int((76533 * y + 132590 * u + 32768) >> 16); top = 1023.f; }
+                else { r = int((76607 * y + 105006 * v + 32768) >> 16); g = int((76607 * y - 25772 * u - 53477 * v + 32768) >> 16); b = int((76607 * y + 132718 * u + 32768) >> 16); top = 65535.f; }
+                if (o >= count) break;
+                pDestination[o++] = XMVectorSet(float(std::min<int>(std::max<int>(r, 0), int(top))) / top, float(std::min<int>(std::max<int>(g, 0), int(top))) / top,
+                                                float(std::min<int>(std::max<int>(b, 0), int(top))) / top, 1.f);
+            }
+        }
+        return true;
+    }
     case DXGI_FORMAT_R32G32B32A32_FLOAT:        // :798-803
     {
         const size_t n = texels(16);
@@ -358,8 +435,21 @@ bool DirectX::Internal::LoadScanline(XMVECTOR* pDestination, size_t count, const
             pDestination[i] = XMVectorSet(float(h[0]) * (1.0f / 65535.0f), float(h[1]) * (1.0f / 65535.0f), 0.f, 1.f);
         }
         return true;
+    case DXGI_FORMAT_D32_FLOAT:                 // :937
     case DXGI_FORMAT_R32_FLOAT:                 // :938-950
         for (size_t i = 0, n = texels(4); i < n; ++i) pDestination[i] = XMVectorSet(reinterpret_cast<const float*>(s)[i], 0.f, 0.f, 1.f);
+        return true;
+    case DXGI_FORMAT_D32_FLOAT_S8X24_UINT:      // :844-860: (depth, float(stencil byte), 0, 1)
+        for (size_t i = 0, n = texels(8); i < n; ++i) pDestination[i] = XMVectorSet(reinterpret_cast<const float*>(s)[i * 2], float(s[i * 8 + 4]), 0.f, 1.f);
+        return true;
+    case DXGI_FORMAT_D24_UNORM_S8_UINT:         // :982-997
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const uint32_t v = reinterpret_cast<const uint32_t*>(s)[i];
+            const auto dd = static_cast<float>(v & 0xFFFFFF) / 16777215.f;
+            const auto ss = static_cast<float>((v & 0xFF000000) >> 24);
+            pDestination[i] = XMVectorSet(dd, ss, 0.f, 1.f);
+        }
         return true;
     case DXGI_FORMAT_R8G8_UNORM:                // XMLoadUByteN2, :1028-1029
         for (size_t i = 0, n = texels(2); i < n; ++i)
@@ -376,6 +466,7 @@ bool DirectX::Internal::LoadScanline(XMVECTOR* pDestination, size_t count, const
     case DXGI_FORMAT_R16_FLOAT:                 // :1040-1051
         for (size_t i = 0, n = texels(2); i < n; ++i) pDestination[i] = XMVectorSet(loadh(reinterpret_cast<const uint16_t*>(s)[i]), 0.f, 0.f, 1.f);
         return true;
+    case DXGI_FORMAT_D16_UNORM:                 // :1053
     case DXGI_FORMAT_R16_UNORM:                 // :1054-1065
         for (size_t i = 0, n = texels(2); i < n; ++i) pDestination[i] = XMVectorSet(float(reinterpret_cast<const uint16_t*>(s)[i]) / 65535.f, 0.f, 0.f, 1.f);
         return true;
@@ -547,6 +638,89 @@ bool DirectX::Internal::StoreScanline(void* pDestination, size_t size, DXGI_FORM
             memcpy(d + i * 8, h, 8);
         }
         return true;
+    // ---- formats whose element holds several texels: the reference's element loops, two (eight) sources per element ----
+    case DXGI_FORMAT_R1_UNORM:                  // :2033-2055
+    {
+        size_t i = 0;
+        for (size_t icount = 0; icount < size; ++icount)
+        {
+            uint8_t pixels = 0;
+            for (size_t bcount = 8; bcount > 0; --bcount)
+            {
+                if (i >= count) break;
+                if (pSource[i++].f[0] > 0.25f) pixels |= uint8_t(1 << (bcount - 1));
+            }
+            d[icount] = pixels;
+        }
+        return true;
+    }
+    case DXGI_FORMAT_R8G8_B8G8_UNORM:           // :2060-2075
+    case DXGI_FORMAT_G8R8_G8B8_UNORM:           // :2077-2094
+    {
+        if (size < 4) return false;
+        size_t i = 0;
+        for (size_t icount = 0; icount < (size - 4 + 1); icount += 4)
+        {
+            if (i >= count) break;
+            const float* v0 = pSource[i++].f;
+            const float g1 = (i < count) ? pSource[i++].f[1] : 0.f;          // XMVectorSplatY of the second texel, or zero
+            if (format == DXGI_FORMAT_R8G8_B8G8_UNORM) { d[icount] = store_ubn_biased(v0[0]); d[icount + 1] = store_ubn_biased(v0[1]); d[icount + 2] = store_ubn_biased(v0[2]); d[icount + 3] = store_ubn_biased(g1); }
+            else { d[icount] = store_ubn_biased(v0[1]); d[icount + 1] = store_ubn_biased(v0[0]); d[icount + 2] = store_ubn_biased(g1); d[icount + 3] = store_ubn_biased(v0[2]); }
+        }
+        return true;
+    }
+    case DXGI_FORMAT_YUY2:                      // :2274-2308 (XMStoreUByteN4 on the raw vectors: no bias)
+    {
+        if (size < 4) return false;
+        auto ubn = [](float v) { const float t = clampf(v, 0.f, 1.f); return int(uint32_t(t * 255.0f)); };
+        size_t i = 0;
+        for (size_t icount = 0; icount < (size - 4 + 1); icount += 4)
+        {
+            if (i >= count) break;
+            int rgb[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };
+            for (int c = 0; c < 3; ++c) rgb[0][c] = ubn(pSource[i].f[c]);
+            ++i;
+            if (i < count) { for (int c = 0; c < 3; ++c) rgb[1][c] = ubn(pSource[i].f[c]); ++i; }
+            int y[2], u[2], v[2];
+            for (int k = 0; k < 2; ++k)
+            {
+                y[k] = ((66 * rgb[k][0] + 129 * rgb[k][1] + 25 * rgb[k][2] + 128) >> 8) + 16;
+                u[k] = ((-38 * rgb[k][0] - 74 * rgb[k][1] + 112 * rgb[k][2] + 128) >> 8) + 128;
+                v[k] = ((112 * rgb[k][0] - 94 * rgb[k][1] - 18 * rgb[k][2] + 128) >> 8) + 128;
+            }
+            d[icount] = uint8_t(std::min<int>(std::max<int>(y[0], 0), 255)); d[icount + 1] = uint8_t(std::min<int>(std::max<int>((u[0] + u[1]) >> 1, 0), 255));
+            d[icount + 2] = uint8_t(std::min<int>(std::max<int>(y[1], 0), 255)); d[icount + 3] = uint8_t(std::min<int>(std::max<int>((v[0] + v[1]) >> 1, 0), 255));
+        }
+        return true;
+    }
+    case DXGI_FORMAT_Y210:                      // :2310-2353 (XMStoreUDecN4: saturate, * 1023, truncate)
+    case DXGI_FORMAT_Y216:                      // :2355-2397 (XMStoreUShortN4)
+    {
+        if (size < 8) return false;
+        const bool ten = format == DXGI_FORMAT_Y210;
+        auto q = [&](float v) -> int64_t { return ten ? int64_t(uint32_t(clampf(v, 0.f, 1.f) * 1023.0f)) : int64_t(store_usn(v)); };
+        size_t i = 0;
+        for (size_t icount = 0; icount < (size - 8 + 1); icount += 8)
+        {
+            if (i >= count) break;
+            int64_t rgb[2][3] = { { 0, 0, 0 }, { 0, 0, 0 } };
+            for (int c = 0; c < 3; ++c) rgb[0][c] = q(pSource[i].f[c]);
+            ++i;
+            if (i < count) { for (int c = 0; c < 3; ++c) rgb[1][c] = q(pSource[i].f[c]); ++i; }
+            int y[2], u[2], v[2];
+            for (int k = 0; k < 2; ++k)
+            {
+                const int64_t r = rgb[k][0], g = rgb[k][1], b = rgb[k][2];
+                if (ten) { y[k] = int((16780 * r + 32942 * g + 6544 * b + 32768) >> 16) + 64; u[k] = int((-9683 * r - 19017 * g + 28700 * b + 32768) >> 16) + 512; v[k] = int((28700 * r - 24033 * g - 4667 * b + 32768) >> 16) + 512; }
+                else { y[k] = int((16763 * r + 32910 * g + 6537 * b + 32768) >> 16) + 4096; u[k] = int((-9674 * r - 18998 * g + 28672 * b + 32768) >> 16) + 32768; v[k] = int((28672 * r - 24010 * g - 4662 * b + 32768) >> 16) + 32768; }
+            }
+            const int top = ten ? 1023 : 65535, sh = ten ? 6 : 0;
+            uint16_t h[4] = { uint16_t(std::min<int>(std::max<int>(y[0], 0), top) << sh), uint16_t(std::min<int>(std::max<int>((u[0] + u[1]) >> 1, 0), top) << sh),
+                              uint16_t(std::min<int>(std::max<int>(y[1], 0), top) << sh), uint16_t(std::min<int>(std::max<int>((v[0] + v[1]) >> 1, 0), top) << sh) };
+            memcpy(d + icount, h, 8);
+        }
+        return true;
+    }
     case DXGI_FORMAT_R32G32B32A32_FLOAT:
         memcpy(d, pSource, texels(16) * 16);
         return true;
@@ -595,8 +769,24 @@ bool DirectX::Internal::StoreScanline(void* pDestination, size_t size, DXGI_FORM
     case DXGI_FORMAT_R16G16_UNORM:
         for (size_t i = 0, n = texels(4); i < n; ++i) { uint16_t* h = reinterpret_cast<uint16_t*>(d + i * 4); h[0] = store_usn(pSource[i].f[0]); h[1] = store_usn(pSource[i].f[1]); }
         return true;
+    case DXGI_FORMAT_D32_FLOAT:                 // :1810
     case DXGI_FORMAT_R32_FLOAT:                 // :1811-1823
         for (size_t i = 0, n = texels(4); i < n; ++i) reinterpret_cast<float*>(d)[i] = pSource[i].f[0];
+        return true;
+    case DXGI_FORMAT_D32_FLOAT_S8X24_UINT:      // :1725-1744
+        for (size_t i = 0, n = texels(8); i < n; ++i)
+        {
+            reinterpret_cast<float*>(d)[i * 2] = pSource[i].f[0];
+            d[i * 8 + 4] = static_cast<uint8_t>(std::min<float>(255.f, std::max<float>(0.f, pSource[i].f[1])));
+            d[i * 8 + 5] = d[i * 8 + 6] = d[i * 8 + 7] = 0;
+        }
+        return true;
+    case DXGI_FORMAT_D24_UNORM_S8_UINT:         // :1852-1869: XMVectorClamp(v, 0, (1, 255, 0, 0))
+        for (size_t i = 0, n = texels(4); i < n; ++i)
+        {
+            const float fx = clampf(pSource[i].f[0], 0.f, 1.f), fy = clampf(pSource[i].f[1], 0.f, 255.f);
+            reinterpret_cast<uint32_t*>(d)[i] = (static_cast<uint32_t>(fx * 16777215.f) & 0xFFFFFF) | ((static_cast<uint32_t>(fy) & 0xFF) << 24);
+        }
         return true;
     case DXGI_FORMAT_R8G8_UNORM:                // XMStoreUByteN2, :1870-1871
         for (size_t i = 0, n = texels(2); i < n; ++i) { d[i * 2] = store_ubn2(pSource[i].f[0]); d[i * 2 + 1] = store_ubn2(pSource[i].f[1]); }
@@ -612,6 +802,7 @@ bool DirectX::Internal::StoreScanline(void* pDestination, size_t size, DXGI_FORM
             reinterpret_cast<uint16_t*>(d)[i] = PackedVector::XMConvertFloatToHalf(v);
         }
         return true;
+    case DXGI_FORMAT_D16_UNORM:                 // :1897
     case DXGI_FORMAT_R16_UNORM:                 // :1898-1912
         for (size_t i = 0, n = texels(2); i < n; ++i)
         {
@@ -760,7 +951,7 @@ bool DirectX::Internal::StoreScanlineLinear(void* pDestination, size_t size, DXG
     return StoreScanline(pDestination, size, format, pSource, count, threshold);
 }
 
-// ---- ConvertScanline (:3080-3854), non-depth formats -----------------------------------------------------------------------------
+// ---- ConvertScanline (:3080-3854) -----------------------------------------------------------------------------
 void DirectX::Internal::ConvertScanline(XMVECTOR* pBuffer, size_t count, DXGI_FORMAT outFormat, DXGI_FORMAT inFormat, TEX_FILTER_FLAGS tflags) noexcept
 {
     if (!pBuffer) return;
@@ -775,14 +966,59 @@ void DirectX::Internal::ConvertScanline(XMVECTOR* pBuffer, size_t count, DXGI_FO
 
     auto each = [&](auto&& fn) { for (size_t i = 0; i < count; ++i) fn(pBuffer[i].f); };
 
-    if ((flags & TEX_FILTER_SRGB_IN) && (in & (C_FLOAT | C_UNORM)))
+    if ((flags & TEX_FILTER_SRGB_IN) && !(in & C_DEPTH) && (in & (C_FLOAT | C_UNORM)))                                              // :3170-3180
         each([](float* v) { for (int c = 0; c < 3; ++c) v[c] = srgb_to_rgb(v[c]); });
 
     const uint32_t diff = in ^ out;
     if (diff != 0)
     {
         const bool x2bias = (flags & TEX_FILTER_FLOAT_X2BIAS) != 0;
-        if (out & C_UNORM)
+        const uint32_t copyAny = flags & (TEX_FILTER_RGB_COPY_RED | TEX_FILTER_RGB_COPY_GREEN | TEX_FILTER_RGB_COPY_BLUE | TEX_FILTER_RGB_COPY_ALPHA);
+        if (diff & C_DEPTH)
+        {
+            if (in & C_DEPTH)
+            {
+                // depth -> colour (:3189-3291): stencil to alpha, then depth to RGB
+                if (in & C_STENCIL)
+                {
+                    if (out & C_UNORM) each([](float* v) { v[3] = clampf(v[1], 0.f, 255.f) / 255.f; });                              // :3196-3209
+                    else if (out & C_SNORM) each([](float* v) { v[3] = (clampf(v[1], 0.f, 255.f) / 255.f) * 2.0f + -1.0f; });         // :3210-3224
+                    else each([](float* v) { v[3] = v[1]; });                                                                     // :3225-3235
+                }
+                if ((out & C_UNORM) && (in & C_FLOAT)) each([](float* v) { v[0] = v[1] = v[2] = clampf(v[0], 0.f, 1.f); });          // :3239-3250
+                else if (out & C_SNORM)
+                {
+                    if (in & C_UNORM) each([](float* v) { v[0] = v[1] = v[2] = v[0] * 2.0f + -1.0f; });                             // :3253-3265
+                    else each([](float* v) { v[0] = v[1] = v[2] = clampf(v[0], -1.f, 1.f); });                                      // :3266-3278
+                }
+                else each([](float* v) { v[1] = v[2] = v[0]; });                                                                  // :3280-3290
+            }
+            else
+            {
+                // colour -> depth (:3293-3434): one channel to x, its range conversion, alpha to stencil
+                if (copyAny == TEX_FILTER_RGB_COPY_GREEN) each([](float* v) { v[0] = v[1]; });
+                else if (copyAny == TEX_FILTER_RGB_COPY_BLUE) each([](float* v) { v[0] = v[2]; });
+                else if (copyAny == TEX_FILTER_RGB_COPY_ALPHA) each([](float* v) { v[0] = v[3]; });
+                else if (copyAny != TEX_FILTER_RGB_COPY_RED && (in & C_UNORM) && ((in & (C_R | C_G | C_B)) == (C_R | C_G | C_B)))
+                    each([](float* v) { v[0] = (v[0] * 0.2125f + v[1] * 0.7154f) + v[2] * 0.0721f; });                               // :3330-3343
+                if (out & C_UNORM)
+                {
+                    if (in & C_SNORM) each([](float* v) { v[0] = v[0] * 0.5f + 0.5f; });                                             // :3368-3379
+                    else if (in & C_FLOAT) each([](float* v) { v[0] = clampf(v[0], 0.f, 1.f); });                                    // :3380-3391
+                }
+                if (out & C_STENCIL)
+                {
+                    if (in & C_UNORM) each([](float* v) { v[1] = v[3] * 255.f; });                                                   // :3396-3408
+                    else if (in & C_SNORM) each([](float* v) { v[1] = (v[3] * 0.5f + 0.5f) * 255.f; });                              // :3409-3422
+                    else each([](float* v) { v[1] = v[3]; });                                                                      // :3423-3433
+                }
+            }
+        }
+        else if (out & C_DEPTH)
+        {
+            if ((diff & C_FLOAT) && (in & C_FLOAT)) each([](float* v) { v[0] = clampf(v[0], 0.f, 1.f); });                             // :3435-3451
+        }
+        else if (out & C_UNORM)
         {
             if (in & C_SNORM) each([](float* v) { for (int c = 0; c < 4; ++c) v[c] = v[c] * 0.5f + 0.5f; });                       // :3457-3463
             else if (in & C_FLOAT)
@@ -865,7 +1101,7 @@ void DirectX::Internal::ConvertScanline(XMVECTOR* pBuffer, size_t count, DXGI_FO
         }
     }
 
-    if ((flags & TEX_FILTER_SRGB_OUT) && (out & (C_FLOAT | C_UNORM)))
+    if ((flags & TEX_FILTER_SRGB_OUT) && !(out & C_DEPTH) && (out & (C_FLOAT | C_UNORM)))                                           // :3843-3853
         each([](float* v) { for (int c = 0; c < 3; ++c) v[c] = rgb_to_srgb(v[c]); });
 }
 

@@ -78,7 +78,7 @@ static int cpu_checks()
         CHECK(any.InitializeCube(DXGI_FORMAT_R8G8B8A8_UNORM, 4, 4, 0, 1) == E_INVALIDARG);
         TexMetadata odd = any.GetMetadata(); odd.arraySize = 7;
         CHECK(any.Initialize(odd) == E_INVALIDARG);                     // a cubemap needs a multiple of six
-        CHECK(!IsSupportedOnDevice(DXGI_FORMAT_D16_UNORM) && IsSupportedOnDevice(DXGI_FORMAT_R16_UINT) && IsSupportedOnDevice(DXGI_FORMAT_B5G6R5_UNORM) && IsSupportedOnDevice(DXGI_FORMAT_R8G8B8A8_UNORM) && IsSupportedOnDevice(DXGI_FORMAT_BC7_UNORM));
+        CHECK(!IsSupportedOnDevice(DXGI_FORMAT_A8P8) && IsSupportedOnDevice(DXGI_FORMAT_D16_UNORM) && IsSupportedOnDevice(DXGI_FORMAT_R16_UINT) && IsSupportedOnDevice(DXGI_FORMAT_B5G6R5_UNORM) && IsSupportedOnDevice(DXGI_FORMAT_R8G8B8A8_UNORM) && IsSupportedOnDevice(DXGI_FORMAT_BC7_UNORM));
     }
     // copies of caller images: array, cubemap, volume, relabelling (DirectXTexImage.cpp:534-740)
     {

@@ -21,7 +21,7 @@ def test_info_reads_headers_of_all_three_containers(tmp_path):
     oracle.ref_save_dds(rng.integers(0, 256, oracle.texture_bytes(77, 20, 12, 6, 3), dtype=np.uint8), 20, 12, 77, 6, 3, 4).tofile(d + "/cube.dds")
     oracle.ref_save_hdr(rng.random((4, 16, 4), dtype=np.float32), 16, 4, 2, 256)[1].tofile(d + "/sky.hdr")
     oracle.ref_save_tga(rng.integers(0, 256, (3, 5, 4), dtype=np.uint8), 5, 3, 28, 20, 0x20, 2)[1].tofile(d + "/a.tga")
-    oracle.ref_save_dds_ex(rng.integers(0, 256, 8 * 4 * 2 * 2 + 4 * 2 * 2, dtype=np.uint8), 8, 4, 2, 55, 1, 2, 0, 0, 4, 0)[1].tofile(d + "/vol565.dds")      # D16_UNORM: held by the container, no kernels
+    oracle.ref_save_dds_ex(rng.integers(0, 256, 8 * 4 * 2 * 2 + 4 * 2 * 2, dtype=np.uint8), 8, 4, 2, 53, 1, 2, 0, 0, 4, 0)[1].tofile(d + "/vol565.dds")      # R16_TYPELESS: held by the container, no kernels
     with open(d + "/bad.dds", "wb") as f:
         f.write(b"nope")
     r = run(["-info", d + "/cube.dds", d + "/sky.hdr", d + "/a.tga", d + "/vol565.dds", d + "/bad.dds"])
@@ -30,7 +30,7 @@ def test_info_reads_headers_of_all_three_containers(tmp_path):
     assert out[0] == "./cube.dds: 20x12 cube mips 3 items 6 format 77 BC3_UNORM bpp 8 alpha unknown images 18 bytes 2208"
     assert out[1] == "./sky.hdr: 16x4 2D mips 1 items 1 format 2 R32G32B32A32_FLOAT bpp 128 alpha opaque images 1 bytes 1024"
     assert out[2] == "./a.tga: 5x3 2D mips 1 items 1 format 29 R8G8B8A8_UNORM_SRGB bpp 32 alpha premultiplied sRGB images 1 bytes 60"
-    assert out[3].startswith("./vol565.dds: 8x4x2 3D mips 2 items 1 format 55") and out[3].endswith("(container only: no GPU path for this format)")
+    assert out[3].startswith("./vol565.dds: 8x4x2 3D mips 2 items 1 format 53") and out[3].endswith("(container only: no GPU path for this format)")
     assert out[4] == "./bad.dds: FAILED (80004005)"
     assert run(["-info", d + "/cube.dds"]).returncode == 0
 
