@@ -51,6 +51,7 @@ enum : int
     FMT_BC7_UNORM = 98, FMT_BC7_UNORM_SRGB = 99,
     FMT_AYUV = 100, FMT_Y410 = 101, FMT_Y416 = 102, FMT_YUY2 = 107, FMT_Y210 = 108, FMT_Y216 = 109,
     FMT_B4G4R4A4_UNORM = 115,
+    FMT_A4B4G4R4_UNORM = 191,
 };
 
 // BC_FLAGS == TEX_COMPRESS_FLAGS bit-for-bit (BC.h:30-48, DirectXTex.h:887-917).
@@ -315,6 +316,13 @@ __device__ __forceinline__ Texel load_texel(const uint8_t* row, uint32_t x, int 
         // XMLoadUNibble4 * 1/15 (:1511-1525)
         const uint32_t v = reinterpret_cast<const uint16_t*>(row)[x];
         t.b = float(v & 0xFu) * (1.0f / 15.0f); t.g = float((v >> 4) & 0xFu) * (1.0f / 15.0f); t.r = float((v >> 8) & 0xFu) * (1.0f / 15.0f); t.a = float(v >> 12) * (1.0f / 15.0f);
+        break;
+    }
+    case FMT_A4B4G4R4_UNORM:
+    {
+        // XMLoadUNibble4 * 1/15, swizzled <3, 2, 1, 0> (:1527-1541)
+        const uint32_t v = reinterpret_cast<const uint16_t*>(row)[x];
+        t.a = float(v & 0xFu) * (1.0f / 15.0f); t.b = float((v >> 4) & 0xFu) * (1.0f / 15.0f); t.g = float((v >> 8) & 0xFu) * (1.0f / 15.0f); t.r = float(v >> 12) * (1.0f / 15.0f);
         break;
     }
     // ---- integer formats: the VALUE as a float, not normalised. XMLoadUInt* (SSE2): the low 31 bits through cvtdq2ps (round to

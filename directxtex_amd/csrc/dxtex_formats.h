@@ -54,6 +54,7 @@ inline const FmtInfo* format_info(int format)
         { FMT_B5G6R5_UNORM, 16, FC_UNORM | FC_R | FC_G | FC_B },
         { FMT_B5G5R5A1_UNORM, 16, FC_UNORM | FC_R | FC_G | FC_B | FC_A },
         { FMT_B4G4R4A4_UNORM, 16, FC_UNORM | FC_R | FC_G | FC_B | FC_A },
+        { FMT_A4B4G4R4_UNORM, 16, FC_UNORM | FC_R | FC_G | FC_B | FC_A },        // WIN11_DXGI_FORMAT_A4B4G4R4_UNORM = 191 (:3046)
         // g_ConvertTable (DirectXTexConvert.cpp:2960-3047): integer, extended-range and 4:4:4 video formats
         { FMT_R32G32B32A32_UINT, 128, FC_UINT | FC_R | FC_G | FC_B | FC_A }, { FMT_R32G32B32A32_SINT, 128, FC_SINT | FC_R | FC_G | FC_B | FC_A },
         { FMT_R32G32B32_UINT, 96, FC_UINT | FC_R | FC_G | FC_B }, { FMT_R32G32B32_SINT, 96, FC_SINT | FC_R | FC_G | FC_B },

@@ -394,6 +394,10 @@ __device__ __forceinline__ void store_texel(uint8_t* row, uint32_t x, int format
         reinterpret_cast<uint16_t*>(row)[x] = uint16_t((store_scaled_rne(t.b, 15.0f) & 0xFu) | ((store_scaled_rne(t.g, 15.0f) & 0xFu) << 4) |
                                                        ((store_scaled_rne(t.r, 15.0f) & 0xFu) << 8) | ((store_scaled_rne(t.a, 15.0f) & 0xFu) << 12));
         break;
+    case FMT_A4B4G4R4_UNORM:         // (a, b, g, r) * 15 through XMStoreUNibble4 (:2419-2437)
+        reinterpret_cast<uint16_t*>(row)[x] = uint16_t((store_scaled_rne(t.a, 15.0f) & 0xFu) | ((store_scaled_rne(t.b, 15.0f) & 0xFu) << 4) |
+                                                       ((store_scaled_rne(t.g, 15.0f) & 0xFu) << 8) | ((store_scaled_rne(t.r, 15.0f) & 0xFu) << 12));
+        break;
     // ---- integer formats (see store_u32 / store_s32 / store_clamp_rne / store_clamp_trunc above)
     case FMT_R32G32B32A32_UINT: reinterpret_cast<uint4*>(row)[x] = make_uint4(store_u32(t.r), store_u32(t.g), store_u32(t.b), store_u32(t.a)); break;     // :1674-1675
     case FMT_R32G32B32A32_SINT: reinterpret_cast<uint4*>(row)[x] = make_uint4(store_s32(t.r), store_s32(t.g), store_s32(t.b), store_s32(t.a)); break;     // :1677-1678

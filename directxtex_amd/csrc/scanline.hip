@@ -812,6 +812,9 @@ bool can_srgb(int format)
     case FMT_R32G32B32A32_FLOAT: case FMT_R16G16B16A16_FLOAT: case FMT_R16G16B16A16_UNORM: case FMT_R32G32_FLOAT:
     case FMT_R8G8B8A8_UNORM: case FMT_R16G16_FLOAT: case FMT_R16G16_UNORM: case FMT_R32_FLOAT: case FMT_R8G8_UNORM:
     case FMT_R16_FLOAT: case FMT_R16_UNORM: case FMT_R8_UNORM: case FMT_B8G8R8A8_UNORM: case FMT_B8G8R8X8_UNORM:
+    case FMT_R32G32B32_FLOAT: case FMT_R10G10B10A2_UNORM: case FMT_R11G11B10_FLOAT: case FMT_R9G9B9E5_SHAREDEXP:
+    case FMT_R8G8_B8G8_UNORM: case FMT_G8R8_G8B8_UNORM: case FMT_B5G6R5_UNORM: case FMT_B5G5R5A1_UNORM: case FMT_B4G4R4A4_UNORM:
+    case FMT_A4B4G4R4_UNORM:         // the whole list of :2825-2849
         return true;
     default:
         return srgb_linear_format(format);

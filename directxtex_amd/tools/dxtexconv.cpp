@@ -50,7 +50,7 @@ const Name kFormats[] = {
     { "R32_UINT", 42 }, { "R32_SINT", 43 }, { "R8G8_UINT", 50 }, { "R8G8_SINT", 52 }, { "R16_UINT", 57 }, { "R16_SINT", 59 }, { "R8_UINT", 62 }, { "R8_SINT", 64 },
     { "R10G10B10_XR_BIAS_A2_UNORM", 89 }, { "AYUV", 100 }, { "Y410", 101 }, { "Y416", 102 },
     { "D32_FLOAT_S8X24_UINT", 20 }, { "D32_FLOAT", 40 }, { "D24_UNORM_S8_UINT", 45 }, { "D16_UNORM", 55 },
-    { "R1_UNORM", 66 }, { "R8G8_B8G8_UNORM", 68 }, { "G8R8_G8B8_UNORM", 69 }, { "YUY2", 107 }, { "Y210", 108 }, { "Y216", 109 },
+    { "R1_UNORM", 66 }, { "R8G8_B8G8_UNORM", 68 }, { "G8R8_G8B8_UNORM", 69 }, { "YUY2", 107 }, { "Y210", 108 }, { "Y216", 109 }, { "A4B4G4R4_UNORM", 191 },
     // texconv's aliases (texconv.cpp:420-440)
     { "DXT1", 71 }, { "DXT2", 74 }, { "DXT3", 74 }, { "DXT4", 77 }, { "DXT5", 77 }, { "RGBA", 28 }, { "BGRA", 87 }, { "BGR", 88 }, { "FP16", 10 }, { "FP32", 2 },
     { "BC4", 80 }, { "BC5", 83 }, { "BC6H", 95 }, { "BC7", 98 },

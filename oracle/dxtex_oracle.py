@@ -321,7 +321,7 @@ BPP = {2: 128, 6: 96, 13: 64, 24: 32, 26: 32, 37: 32, 58: 16, 67: 32, 85: 16, 86
        # depth / stencil
        20: 64, 40: 32, 45: 32, 55: 16,
        # several texels per element: R1 (8 per byte); R8G8_B8G8 / G8R8_G8B8 / YUY2 (2 per dword); Y210 / Y216 (2 per qword)
-       66: 1, 68: 16, 69: 16, 107: 16, 108: 32, 109: 32}
+       66: 1, 68: 16, 69: 16, 107: 16, 108: 32, 109: 32, 191: 16}
 PAIRED = {68: 4, 69: 4, 107: 4, 108: 8, 109: 8}      # bytes of an element of two texels: rows are ((w + 1) >> 1) elements (ComputePitch)
 
 

@@ -158,7 +158,7 @@ namespace
         case DXGI_FORMAT_R16G16B16A16_SNORM: return C_SNORM | C_R | C_G | C_B | C_A;
         case DXGI_FORMAT_R16G16_SNORM: return C_SNORM | C_R | C_G;
         case DXGI_FORMAT_R16_SNORM: return C_SNORM | C_R;
-        case DXGI_FORMAT_R10G10B10A2_UNORM: case DXGI_FORMAT_B5G5R5A1_UNORM: case DXGI_FORMAT_B4G4R4A4_UNORM: return C_UNORM | C_R | C_G | C_B | C_A;
+        case DXGI_FORMAT_R10G10B10A2_UNORM: case DXGI_FORMAT_B5G5R5A1_UNORM: case DXGI_FORMAT_B4G4R4A4_UNORM: case WIN11_DXGI_FORMAT_A4B4G4R4_UNORM: return C_UNORM | C_R | C_G | C_B | C_A;
         case DXGI_FORMAT_B5G6R5_UNORM: return C_UNORM | C_R | C_G | C_B;
         case DXGI_FORMAT_R16G16B16A16_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB:
         case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB: return C_UNORM | C_R | C_G | C_B | C_A;
@@ -217,6 +217,7 @@ namespace
         case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8X8_UNORM: return true;
         case DXGI_FORMAT_R32G32B32_FLOAT: case DXGI_FORMAT_R10G10B10A2_UNORM: case DXGI_FORMAT_R11G11B10_FLOAT: case DXGI_FORMAT_R9G9B9E5_SHAREDEXP:
         case DXGI_FORMAT_B5G6R5_UNORM: case DXGI_FORMAT_B5G5R5A1_UNORM: case DXGI_FORMAT_B4G4R4A4_UNORM: return true;     // :2826-2847
+        case DXGI_FORMAT_R8G8_B8G8_UNORM: case DXGI_FORMAT_G8R8_G8B8_UNORM: case WIN11_DXGI_FORMAT_A4B4G4R4_UNORM: return true;   // :2841-2842, :2848
         default: return false;
         }
     }
@@ -554,6 +555,14 @@ bool DirectX::Internal::LoadScanline(XMVECTOR* pDestination, size_t count, const
         {
             const uint16_t v = reinterpret_cast<const uint16_t*>(s)[i];
             pDestination[i] = XMVectorSet(float((v >> 8) & 0xF) * (1.f / 15.f), float((v >> 4) & 0xF) * (1.f / 15.f), float(v & 0xF) * (1.f / 15.f), float(v >> 12) * (1.f / 15.f));
+        }
+        return true;
+    case WIN11_DXGI_FORMAT_A4B4G4R4_UNORM:      // :1527-1541: XMLoadUNibble4 * 1/15, swizzle <3, 2, 1, 0>
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            const uint16_t v = reinterpret_cast<const uint16_t*>(s)[i];
+            const float nib[4] = { float(v & 0xF) * (1.f / 15.f), float((v >> 4) & 0xF) * (1.f / 15.f), float((v >> 8) & 0xF) * (1.f / 15.f), float(v >> 12) * (1.f / 15.f) };
+            pDestination[i] = XMVectorSet(nib[3], nib[2], nib[1], nib[0]);
         }
         return true;
     default:
@@ -914,6 +923,13 @@ bool DirectX::Internal::StoreScanline(void* pDestination, size_t size, DXGI_FORM
         {
             const float* v = pSource[i].f;
             reinterpret_cast<uint16_t*>(d)[i] = uint16_t((store_scaled(v[2], 15.f) & 0xF) | ((store_scaled(v[1], 15.f) & 0xF) << 4) | ((store_scaled(v[0], 15.f) & 0xF) << 8) | ((store_scaled(v[3], 15.f) & 0xF) << 12));
+        }
+        return true;
+    case WIN11_DXGI_FORMAT_A4B4G4R4_UNORM:      // :2419-2437: swizzle <3, 2, 1, 0>, * 15, XMStoreUNibble4
+        for (size_t i = 0, n = texels(2); i < n; ++i)
+        {
+            const float sw[4] = { pSource[i].f[3], pSource[i].f[2], pSource[i].f[1], pSource[i].f[0] };
+            reinterpret_cast<uint16_t*>(d)[i] = uint16_t((store_scaled(sw[0], 15.f) & 0xF) | ((store_scaled(sw[1], 15.f) & 0xF) << 4) | ((store_scaled(sw[2], 15.f) & 0xF) << 8) | ((store_scaled(sw[3], 15.f) & 0xF) << 12));
         }
         return true;
     default:

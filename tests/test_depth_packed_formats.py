@@ -332,3 +332,45 @@ def test_compress_refuses_grouped_sources(ctx, oracle, fmt, bc):
         with pytest.raises(oracle.RefError) as r:
             oracle.ref_compress_image(img, w, h, fmt, bc, 0, 0.5)
         assert r.value.hresult == 0x80070032
+
+
+# ---- WIN11_DXGI_FORMAT_A4B4G4R4_UNORM (191; :1527-1541, :2419-2437) and the full list of formats the filters may treat as sRGB (:2825-2849) ----
+A4B4G4R4 = 191
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("other", [RGBA32F, RGBA8, 115])
+def test_convert_a4b4g4r4(ctx, oracle, other):
+    w, h = 67, 9
+    rng = np.random.default_rng(other)
+    raw = rng.integers(0, 256, oracle.image_bytes(A4B4G4R4, w, h), dtype=np.uint8)
+    got = ctx.convert(raw, w, h, A4B4G4R4, other, 0, 0.5)
+    assert np.array_equal(got, oracle.ref_convert(raw, w, h, A4B4G4R4, other, 0, 0.5))
+    src = rng.random((h, w, 4), dtype=F) if other == RGBA32F else rng.integers(0, 256, oracle.image_bytes(other, w, h), dtype=np.uint8)
+    got = ctx.convert(src, w, h, other, A4B4G4R4, 0, 0.5)
+    assert np.array_equal(got, oracle.ref_convert(src, w, h, other, A4B4G4R4, 0, 0.5))
+    if other == RGBA32F:
+        nib = raw.view(np.uint16).astype(np.uint32)
+        want = np.stack([(nib >> 12) & 15, (nib >> 8) & 15, (nib >> 4) & 15, nib & 15], -1).astype(F) * F(1.0 / 15.0)      # third statement of the load
+        assert np.array_equal(ctx.convert(raw, w, h, A4B4G4R4, RGBA32F, 0, 0.5).view(F).reshape(-1, 4), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [6, 24, 26, 67, RGBG, GRGB, 85, 86, 115, A4B4G4R4])
+@pytest.mark.parametrize("flt", [0x400000, 0x200000])
+def test_filters_in_linear_space_for_the_whole_srgb_list(ctx, oracle, fmt, flt):
+    """TEX_FILTER_SRGB makes the filters convert to linear and back for every format of LoadScanlineLinear's list (:2825-2849), not only
+    the common ones: the result must differ from the plain filter and follow the reference (pow() on the device and libm's powf differ
+    in the last bit for a few values, as in test_premultiply_alpha)."""
+    w, h = 32, 16
+    rng = np.random.default_rng(fmt + flt)
+    img = rng.integers(0, 256, oracle.image_bytes(fmt, w, h), dtype=np.uint8)
+    if fmt in (6, 26, 67):
+        img = rng.random(w * h * 3, dtype=F) if fmt == 6 else img
+    plain = ctx.generate_mips(img, w, h, fmt, 3, flt)
+    got = ctx.generate_mips(img, w, h, fmt, 3, flt | 0x3000000)
+    ref = oracle.ref_generate_mips(img, w, h, fmt, flt | 0x3000000, 3)
+    assert any((g != p).any() for g, p in zip(got[1:], plain[1:])), "the sRGB flag did nothing"
+    for lvl in range(1, 3):
+        g, r = np.asarray(got[lvl]).view(np.uint8), np.asarray(ref[lvl]).view(np.uint8)
+        assert (g != r).mean() < 0.02, (fmt, hex(flt), lvl, (g != r).mean())
