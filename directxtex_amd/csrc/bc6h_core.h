@@ -194,6 +194,16 @@ struct Texels
     const float* r; const float* g; const float* b;     // r[k * stride] etc.
     int stride;
     int np;
+    DXTEX_HD6 void fetch(int k, uint32_t /*blockPos*/, float& pr, float& pg, float& pb) const { pr = r[k * stride]; pg = g[k * stride]; pb = b[k * stride]; }
+};
+
+// The same texels read in place from the block's planes (r[16], g[16], b[16], one copy per block shared by the lanes that work on
+// it): texel k of the region is at its block position. No per-lane copy - what pre / post of the two-region modes use.
+struct TileTexels
+{
+    const float* planes;
+    int np;
+    DXTEX_HD6 void fetch(int /*k*/, uint32_t blockPos, float& pr, float& pg, float& pb) const { pr = planes[blockPos]; pg = planes[16 + blockPos]; pb = planes[32 + blockPos]; }
 };
 
 // Palette of quantised endpoints (GeneratePaletteQuantized, :1990-2040) for one channel
@@ -214,13 +224,16 @@ DXTEX_HD6 void palette_channel(int qa, int qb, int prec, bool isSigned, float (&
 struct EndPts { int A[3], B[3]; };
 
 // MapColorsQuantized (:2044-2077): total fp32 error of the texels against the palette of `ep`
-template<int N>
-DXTEX_HD6 float map_colors_q(const Texels& tx, const float (&pr)[N], const float (&pg)[N], const float (&pb)[N])
+template<int N, class TX>
+DXTEX_HD6 float map_colors_q(const TX& tx, const float (&pr)[N], const float (&pg)[N], const float (&pb)[N], uint64_t pos = 0)
 {
     float tot = 0.0f;
+    uint64_t rest = pos;            // block positions (TileTexels only)
     for (int k = 0; k < tx.np; ++k)
     {
-        const float r = tx.r[k * tx.stride], g = tx.g[k * tx.stride], b = tx.b[k * tx.stride];
+        float r, g, b;
+        tx.fetch(k, uint32_t(rest) & 15u, r, g, b);
+        rest >>= 4;
         float e[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) e[i] = norm3(r, g, b, pr[i], pg[i], pb[i]);
@@ -231,8 +244,8 @@ DXTEX_HD6 float map_colors_q(const Texels& tx, const float (&pr)[N], const float
 
 // AssignIndices for one region (:2260-2301) + SwapIndices (:2228-2255). `pos` = 4-bit block positions of the region's
 // texels; indices come back as 4 bits per block position.
-template<int N>
-DXTEX_HD6 float assign_indices6(const Texels& tx, uint64_t pos, EndPts& ep, int prec, bool isSigned, uint32_t anchorPos, uint64_t& idxOut)
+template<int N, class TX>
+DXTEX_HD6 float assign_indices6(const TX& tx, uint64_t pos, EndPts& ep, int prec, bool isSigned, uint32_t anchorPos, uint64_t& idxOut)
 {
     float pr[N], pg[N], pb[N];
     palette_channel<N>(ep.A[0], ep.B[0], prec, isSigned, pr);
@@ -240,15 +253,18 @@ DXTEX_HD6 float assign_indices6(const Texels& tx, uint64_t pos, EndPts& ep, int 
     palette_channel<N>(ep.A[2], ep.B[2], prec, isSigned, pb);
     float tot = 0.0f;
     uint64_t idx = 0, member = 0;
+    uint64_t rest = pos;            // block positions of the texels still to come, 4 bits each
     for (int k = 0; k < tx.np; ++k)
     {
-        const float r = tx.r[k * tx.stride], g = tx.g[k * tx.stride], b = tx.b[k * tx.stride];
+        const uint32_t p = uint32_t(rest) & 15u;
+        rest >>= 4;
+        float r, g, b;
+        tx.fetch(k, p, r, g, b);
         float e[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) e[i] = norm3(r, g, b, pr[i], pg[i], pb[i]);
         uint32_t ix;
         tot += scan_min_idx(e, ix);
-        const uint32_t p = uint32_t(pos >> (4 * k)) & 15u;
         idx |= uint64_t(ix) << (4 * p);
         member |= uint64_t(0xF) << (4 * p);
     }
@@ -427,8 +443,8 @@ DXTEX_HD6 int clamp_seed(int v, bool isSigned)
 }
 
 // MapColors (:2467-2494): rough error of a region against the UNQUANTISED palette of the seed (:2430-2464)
-template<int N>
-DXTEX_HD6 float rough_error6(const Texels& tx, const EndPts& seed)
+template<int N, class TX>
+DXTEX_HD6 float rough_error6(const TX& tx, const EndPts& seed, uint64_t pos = 0)
 {
     float pr[N], pg[N], pb[N];
 #pragma unroll
@@ -439,7 +455,7 @@ DXTEX_HD6 float rough_error6(const Texels& tx, const EndPts& seed)
         pg[i] = float((seed.A[1] * (64 - w) + seed.B[1] * w + 32) >> 6);
         pb[i] = float((seed.A[2] * (64 - w) + seed.B[2] * w + 32) >> 6);
     }
-    return map_colors_q<N>(tx, pr, pg, pb);
+    return map_colors_q<N>(tx, pr, pg, pb, pos);
 }
 
 // ---- EmitBlock (:2330-2373) --------------------------------------------------------------------------------------------------

@@ -92,12 +92,37 @@ __device__ __forceinline__ int gather_texels(const float* planes, uint32_t mask,
     return np;
 }
 
+// The packed block positions of the texels selected by `mask` (no copy: pre / post of the two-region modes read the block's planes in place).
+__device__ __forceinline__ int region_positions(uint32_t mask, uint64_t& pos)
+{
+    int np = 0; pos = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if ((mask >> i) & 1u) { pos |= uint64_t(i) << (4 * np); ++np; }
+    return np;
+}
+
+// Stages the planes of the BPW blocks a wavefront of pre / post works on (48 floats each) in LDS: one 16-byte load per lane instead
+// of twelve, and no per-lane copy of the block in registers or LDS columns - the two-region kernels were held at three waves per SIMD
+// by 48 KiB of columns per workgroup and 136 registers, and waited (issue utilisation 0.37 / 0.59).
+template<int BPW>
+__device__ __forceinline__ void stage_planes(const Bc6hArgs& a, uint32_t nbFirst, int lane, float* tile)
+{
+    static_assert(BPW * 12 <= 64, "one float4 per lane");
+    if (lane < BPW * 12)
+    {
+        const uint32_t nb = min(nbFirst + uint32_t(lane) / 12u, a.nblocks - 1);
+        const float4 v = reinterpret_cast<const float4*>(a.fpix + uint64_t(nb) * 48)[uint32_t(lane) % 12u];
+        reinterpret_cast<float4*>(tile)[lane] = v;
+    }
+    wave_lds_sync();
+}
+
 // ---- rough ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
 {
     __shared__ float sF[4][64];
     __shared__ float sP[4][48];
-    __shared__ float sSlot[4][48 * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nb = blockIdx.x * 4 + wave;
     if (nb >= a.nblocks) return;
@@ -122,8 +147,7 @@ __global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
     if (lane == 0) { Best6 b; b.err = 3.402823466e+38f; b.mode = 0xFFFFFFFFu; b.lo = 0; b.hi = 0; a.best[nb] = b; }
     wave_lds_sync();
     const float* fpx = sF[wave];
-    const float* planes = sP[wave];
-    float* slot = &sSlot[wave][lane];
+    const float* planes = sP[wave];         // the subsets are read in place (no per-lane columns: 50 KiB of LDS held the kernel at 3 waves per SIMD)
 
     // lane = shape + 32 * region: every lane fits ONE subset of a two-region shape (the one-region fit has a kernel of its own,
     // bc6h_block_seed_kernel, so that it does not cost this wavefront a second full pass with one lane active)
@@ -135,15 +159,16 @@ __global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
     bool ranked = false;
     {
         uint64_t pos;
-        const int np = gather_texels(planes, mask, slot, pos);
+        const int np = region_positions(mask, pos);
+        const uint32_t p0 = uint32_t(pos) & 15u, p1 = uint32_t(pos >> 4) & 15u;
         if (np == 1)
         {
-            seed.A[0] = seed.B[0] = int(slot[0]); seed.A[1] = seed.B[1] = int(slot[16 * 64]); seed.A[2] = seed.B[2] = int(slot[32 * 64]);
+            seed.A[0] = seed.B[0] = int(planes[p0]); seed.A[1] = seed.B[1] = int(planes[16 + p0]); seed.A[2] = seed.B[2] = int(planes[32 + p0]);
         }
         else if (np == 2)
         {
-            seed.A[0] = int(slot[0]); seed.A[1] = int(slot[16 * 64]); seed.A[2] = int(slot[32 * 64]);
-            seed.B[0] = int(slot[64]); seed.B[1] = int(slot[17 * 64]); seed.B[2] = int(slot[33 * 64]);
+            seed.A[0] = int(planes[p0]); seed.A[1] = int(planes[16 + p0]); seed.A[2] = int(planes[32 + p0]);
+            seed.B[0] = int(planes[p1]); seed.B[1] = int(planes[16 + p1]); seed.B[2] = int(planes[32 + p1]);
         }
         else
         {
@@ -155,7 +180,8 @@ __global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
                 seed.A[c] = clamp_seed(float_to_int16f(X[c], sg), sg);
                 seed.B[c] = clamp_seed(float_to_int16f(Y[c], sg), sg);
             }
-            part = rough_error6<8>(slot_texels(slot, np), seed);
+            const TileTexels tx = { planes, np };
+            part = rough_error6<8>(tx, seed, pos);
             ranked = true;
         }
     }
@@ -284,7 +310,8 @@ __device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, ui
     o.mask = REGIONS2 ? (region ? m1 : ((~m1) & 0xFFFFu)) : 0xFFFFu;
     o.anchor = (REGIONS2 && region) ? uint32_t(kAnchor2[o.shape]) : 0u;
     const int* sd = a.seeds + uint64_t(nb) * SEED_INTS + (REGIONS2 ? (rank * 2 + region) * 6 : 16 * 6);
-    o.np = gather_texels(planes, o.mask, slot, o.pos);
+    if constexpr (REGIONS2) o.np = region_positions(o.mask, o.pos);            // `planes` is the block's tile in LDS, read in place
+    else o.np = gather_texels(planes, o.mask, slot, o.pos);
     if (saved)
     {
         // post: the pre kernel of this mode already quantised the seeds and assigned the indices
@@ -301,7 +328,8 @@ __device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, ui
             o.ep.A[c] = quantize(sd[c], a.mode.prec, sg);
             o.ep.B[c] = quantize(sd[3 + c], a.mode.prec, sg);
         }
-        o.err = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, o.ep, a.mode.prec, sg, o.anchor, o.idx);
+        if constexpr (REGIONS2) { const TileTexels tx = { planes, o.np }; o.err = assign_indices6<L::N>(tx, o.pos, o.ep, a.mode.prec, sg, o.anchor, o.idx); }
+        else o.err = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, o.ep, a.mode.prec, sg, o.anchor, o.idx);
     }
     int a0[3];
 #pragma unroll
@@ -320,19 +348,29 @@ template<int REGIONS2>
 __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
 {
     typedef Lay6<REGIONS2> L;
-    __shared__ float sSlot[4][48 * 64];
+    __shared__ float sSlot[4][REGIONS2 ? L::BPW * 48 : 48 * 64];        // two regions: the blocks' planes; one region: a column per lane
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nbFirst = (blockIdx.x * 4 + wave) * L::BPW;
     if (nbFirst >= a.nblocks) return;
     const uint32_t blk = uint32_t(lane) / L::TPB, r = uint32_t(lane) % L::TPB;
     const uint32_t nb = min(nbFirst + blk, a.nblocks - 1);       // out-of-range lanes shadow the last block (shuffles stay defined)
     const bool inRange = (nbFirst + blk) < a.nblocks;
-    float planes[48];
-    const float4* gp = reinterpret_cast<const float4*>(a.fpix + uint64_t(nb) * 48);
+    float regs[REGIONS2 ? 1 : 48];
+    const float* planes = regs;
+    float* slot = &sSlot[wave][REGIONS2 ? 0 : lane];
+    if constexpr (REGIONS2)
+    {
+        stage_planes<L::BPW>(a, nbFirst, lane, sSlot[wave]);
+        planes = &sSlot[wave][blk * 48];
+    }
+    else
+    {
+        const float4* gp = reinterpret_cast<const float4*>(a.fpix + uint64_t(nb) * 48);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { const float4 v = gp[i]; planes[4 * i] = v.x; planes[4 * i + 1] = v.y; planes[4 * i + 2] = v.z; planes[4 * i + 3] = v.w; }
+        for (int i = 0; i < 12; ++i) { const float4 v = gp[i]; regs[4 * i] = v.x; regs[4 * i + 1] = v.y; regs[4 * i + 2] = v.z; regs[4 * i + 3] = v.w; }
+    }
     Org6 o;
-    org_candidate<REGIONS2>(a, nb, r, planes, &sSlot[wave][lane], o);
+    org_candidate<REGIONS2>(a, nb, r, planes, slot, o);
 #if defined(DXTEX_BC6H_TRACE)
     if (nb == 0 && a.mode.index == 0) printf("pre r %u shape %u fit %d A %d %d %d B %d %d %d | T A %d %d %d B %d %d %d err %.9g np %d tr %d delta %d %d %d\n", r, o.shape, int(o.fit), o.ep.A[0], o.ep.A[1], o.ep.A[2], o.ep.B[0], o.ep.B[1], o.ep.B[2], o.epT.A[0], o.epT.A[1], o.epT.A[2], o.epT.B[0], o.epT.B[1], o.epT.B[2], o.err, o.np, a.mode.transformed, a.mode.delta[0], a.mode.delta[1], a.mode.delta[2]);
 #endif
@@ -406,7 +444,7 @@ template<int REGIONS2>
 __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
 {
     typedef Lay6<REGIONS2> L;
-    __shared__ float sSlot[4][48 * 64];
+    __shared__ float sSlot[4][REGIONS2 ? L::BPW * 48 : 48 * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nbFirst = (blockIdx.x * 4 + wave) * L::BPW;
     if (nbFirst >= a.nblocks) return;
@@ -415,11 +453,20 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     const uint32_t nb = min(nbFirst + blk, a.nblocks - 1);
     const bool inRange = (nbFirst + blk) < a.nblocks;
     const uint32_t rank = REGIONS2 ? (r >> 1) : 0u, region = REGIONS2 ? (r & 1u) : 0u;
-    float planes[48];
-    const float4* gp = reinterpret_cast<const float4*>(a.fpix + uint64_t(nb) * 48);
+    float regs[REGIONS2 ? 1 : 48];
+    const float* planes = regs;
+    float* slot = &sSlot[wave][REGIONS2 ? 0 : lane];
+    if constexpr (REGIONS2)
+    {
+        stage_planes<L::BPW>(a, nbFirst, lane, sSlot[wave]);
+        planes = &sSlot[wave][blk * 48];
+    }
+    else
+    {
+        const float4* gp = reinterpret_cast<const float4*>(a.fpix + uint64_t(nb) * 48);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { const float4 v = gp[i]; planes[4 * i] = v.x; planes[4 * i + 1] = v.y; planes[4 * i + 2] = v.z; planes[4 * i + 3] = v.w; }
-    float* slot = &sSlot[wave][lane];
+        for (int i = 0; i < 12; ++i) { const float4 v = gp[i]; regs[4 * i] = v.x; regs[4 * i + 1] = v.y; regs[4 * i + 2] = v.z; regs[4 * i + 3] = v.w; }
+    }
     Org6 o;
     const uint64_t t = REGIONS2 ? uint64_t(nb) * L::TPB + r : uint64_t(a.taskBase) + nb;
     org_candidate<REGIONS2>(a, nb, r, planes, slot, o, a.orgs + t);
@@ -440,7 +487,9 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     if (__any(searched))
     {
         uint64_t ix;
-        const float e = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, opt, a.mode.prec, sg, o.anchor, ix);
+        float e;
+        if constexpr (REGIONS2) { const TileTexels tx = { planes, o.np }; e = assign_indices6<L::N>(tx, o.pos, opt, a.mode.prec, sg, o.anchor, ix); }
+        else e = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, opt, a.mode.prec, sg, o.anchor, ix);
         if (searched) { optErr = e; optIdx = ix; }
     }
     if (!searched) opt = o.ep;
