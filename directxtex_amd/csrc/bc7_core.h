@@ -1317,12 +1317,20 @@ DXTEX_HD void for_masked(uint32_t mask16, F&& f)
 // loop (:3461-3531 for RGBA: bounding box, choice of the diagonal), fit_iterate = one trip of that loop (:3533-3606).
 
 // Returns true when the loop has to run (false: X / Y are final - a degenerate box, :3478 and :3527).
-template<bool RGBA, bool FULL = false>
+// A1 (with RGBA): the caller has checked that the alpha of every texel of the block is exactly 1.0f (an opaque block - the common
+// case). Then X[3] = Y[3] = 1 from the bounding box on, and every alpha term of the RGBA formulas is an exact zero: Dir[3] = 0,
+// (p[3] - X[3]) * Dir[3] = 0, Diff[3] = (X[3] pc + Y[3] pd) - p[3] = (pc + pd) - 1 = 0 (float(2/3) + float(1/3) rounds to 1.0f), so
+// dX[3] = dY[3] = 0 and the end points' alpha never moves; x + 0.0f = x. The A1 instantiation drops those terms (a quarter of the
+// Newton loop) and keeps everything else of the RGBA path - the eight-direction choice (directions 2j and 2j + 1 tie, the strict
+// compare keeps 2j, so bit 0 of iDirMax is clear) and the summed convergence test - bit for bit.
+template<bool RGBA, bool FULL = false, bool A1 = false>
 DXTEX_HD bool fit_setup(const float* fpx, uint32_t mask16, float (&X)[4], float (&Y)[4])
 {
-    constexpr int NC = RGBA ? 4 : 3;
+    static_assert(RGBA || !A1, "A1 is a variant of the RGBA fit");
+    constexpr int NC = (RGBA && !A1) ? 4 : 3;
     if (RGBA) { X[0] = X[1] = X[2] = X[3] = 1.0f; Y[0] = Y[1] = Y[2] = Y[3] = 0.0f; }
     else { X[0] = X[1] = X[2] = 3.402823466e+38f; Y[0] = Y[1] = Y[2] = -3.402823466e+38f; X[3] = 0.0f; Y[3] = 0.0f; }
+    if (A1) Y[3] = 1.0f;
 
     for_masked<FULL>(mask16, [&](int i)
         {
@@ -1339,7 +1347,7 @@ DXTEX_HD bool fit_setup(const float* fpx, uint32_t mask16, float (&X)[4], float 
 #pragma unroll
     for (int c = 0; c < NC; ++c) AB[c] = Y[c] - X[c];
     float fAB = AB[0] * AB[0] + AB[1] * AB[1] + AB[2] * AB[2];
-    if (RGBA) fAB = fAB + AB[3] * AB[3];
+    if (RGBA && !A1) fAB = fAB + AB[3] * AB[3];
 
     if (fAB < 1.175494351e-38f) return false;
 
@@ -1357,7 +1365,15 @@ DXTEX_HD bool fit_setup(const float* fpx, uint32_t mask16, float (&X)[4], float 
 #pragma unroll
             for (int c = 0; c < NC; ++c) Pt[c] = (fpx[i * 4 + c] - Mid[c]) * Dir[c];
             float f;
-            if (RGBA)
+            if (RGBA && A1)
+            {
+                // Pt[3] = 0: directions 2j and 2j + 1 of the RGBA list coincide; j in the order (+,+) (+,-) (-,+) (-,-)
+                f = Pt[0] + Pt[1] + Pt[2]; fDir[0] += f * f;
+                f = Pt[0] + Pt[1] - Pt[2]; fDir[1] += f * f;
+                f = Pt[0] - Pt[1] + Pt[2]; fDir[2] += f * f;
+                f = Pt[0] - Pt[1] - Pt[2]; fDir[3] += f * f;
+            }
+            else if (RGBA)
             {
                 f = Pt[0] + Pt[1] + Pt[2] + Pt[3]; fDir[0] += f * f;
                 f = Pt[0] + Pt[1] + Pt[2] - Pt[3]; fDir[1] += f * f;
@@ -1380,10 +1396,15 @@ DXTEX_HD bool fit_setup(const float* fpx, uint32_t mask16, float (&X)[4], float 
     float fDirMax = fDir[0];
     int iDirMax = 0;
 #pragma unroll
-    for (int d = 1; d < (RGBA ? 8 : 4); ++d)
+    for (int d = 1; d < ((RGBA && !A1) ? 8 : 4); ++d)
         if (fDir[d] > fDirMax) { fDirMax = fDir[d]; iDirMax = d; }
 
-    if (RGBA)
+    if (RGBA && A1)
+    {
+        if (iDirMax & 2) { const float t = X[1]; X[1] = Y[1]; Y[1] = t; }
+        if (iDirMax & 1) { const float t = X[2]; X[2] = Y[2]; Y[2] = t; }
+    }
+    else if (RGBA)
     {
         if (iDirMax & 4) { const float t = X[1]; X[1] = Y[1]; Y[1] = t; }
         if (iDirMax & 2) { const float t = X[2]; X[2] = Y[2]; Y[2] = t; }
@@ -1399,11 +1420,11 @@ DXTEX_HD bool fit_setup(const float* fpx, uint32_t mask16, float (&X)[4], float 
 }
 
 // One trip of the Newton loop; returns true when the loop ends with this trip (either break). The caller runs at most 8 trips.
-template<bool RGBA, bool FULL = false>
+template<bool RGBA, bool FULL = false, bool A1 = false>
 DXTEX_HD bool fit_iterate(const float* fpx, uint32_t mask16, float (&X)[4], float (&Y)[4])
 {
     constexpr float fEpsilon = (0.25f / 64.0f) * (0.25f / 64.0f);
-    constexpr int NC = RGBA ? 4 : 3;
+    constexpr int NC = (RGBA && !A1) ? 4 : 3;
     const float fSteps = 3.0f;
 #if defined(DXTEX_FIT_STATS)
     ++g_iters;
@@ -1412,7 +1433,7 @@ DXTEX_HD bool fit_iterate(const float* fpx, uint32_t mask16, float (&X)[4], floa
 #pragma unroll
     for (int c = 0; c < NC; ++c) Dir[c] = Y[c] - X[c];
     float fLen = Dir[0] * Dir[0] + Dir[1] * Dir[1] + Dir[2] * Dir[2];
-    if (RGBA) fLen = fLen + Dir[3] * Dir[3];
+    if (RGBA && !A1) fLen = fLen + Dir[3] * Dir[3];
     if (fLen < (1.0f / 4096.0f)) return true;
 
     const float fScale = fSteps / fLen;
@@ -1428,7 +1449,7 @@ DXTEX_HD bool fit_iterate(const float* fpx, uint32_t mask16, float (&X)[4], floa
 #pragma unroll
             for (int c = 0; c < NC; ++c) p[c] = fpx[i * 4 + c];
             float fDot = (p[0] - X[0]) * Dir[0] + (p[1] - X[1]) * Dir[1] + (p[2] - X[2]) * Dir[2];
-            if (RGBA) fDot = fDot + (p[3] - X[3]) * Dir[3];
+            if (RGBA && !A1) fDot = fDot + (p[3] - X[3]) * Dir[3];
 
             // fDot <= 0 -> step 0, fDot >= fSteps -> step 3, else uint32(fDot + 0.5f) (:1300-1306): the clamp maps the outer cases
             // onto the same conversion; float compares keep the table lookups (pC4 / pD4) as selects - an integer equality
@@ -1462,6 +1483,12 @@ DXTEX_HD bool fit_iterate(const float* fpx, uint32_t mask16, float (&X)[4], floa
         for (int c = 0; c < NC; ++c) Y[c] += dY[c] * f;
     }
 
+    if (RGBA && A1)
+    {
+        const float ex = dX[0] * dX[0] + dX[1] * dX[1] + dX[2] * dX[2];
+        const float ey = dY[0] * dY[0] + dY[1] * dY[1] + dY[2] * dY[2];
+        return (ex < fEpsilon) && (ey < fEpsilon);
+    }
     if (RGBA)
     {
         const float ex = dX[0] * dX[0] + dX[1] * dX[1] + dX[2] * dX[2] + dX[3] * dX[3];
@@ -1472,12 +1499,12 @@ DXTEX_HD bool fit_iterate(const float* fpx, uint32_t mask16, float (&X)[4], floa
            (dY[0] * dY[0] < fEpsilon) && (dY[1] * dY[1] < fEpsilon) && (dY[2] * dY[2] < fEpsilon);
 }
 
-template<bool RGBA, bool FULL = false>
+template<bool RGBA, bool FULL = false, bool A1 = false>
 DXTEX_HD void seed_fit(const float* fpx, uint32_t mask16, float (&X)[4], float (&Y)[4])
 {
-    if (!fit_setup<RGBA, FULL>(fpx, mask16, X, Y)) return;
+    if (!fit_setup<RGBA, FULL, A1>(fpx, mask16, X, Y)) return;
     for (int iter = 0; iter < 8; ++iter)
-        if (fit_iterate<RGBA, FULL>(fpx, mask16, X, Y)) break;
+        if (fit_iterate<RGBA, FULL, A1>(fpx, mask16, X, Y)) break;
 }
 
 // X / Y of a fit -> the 8-bit end points Refine and RoughMSE start from: clamped to [0,1], scaled by 255 and truncated with the +0.01
@@ -1500,11 +1527,11 @@ DXTEX_HD void fit_to_bytes(const float (&X)[4], const float (&Y)[4], uint32_t& o
     outA = a; outB = b;
 }
 
-template<bool RGBA, bool FULL = false>
+template<bool RGBA, bool FULL = false, bool A1 = false>
 DXTEX_HD void seed_endpoints(const float* fpx, uint32_t mask16, uint32_t& outA, uint32_t& outB)
 {
     float X[4], Y[4];
-    seed_fit<RGBA, FULL>(fpx, mask16, X, Y);
+    seed_fit<RGBA, FULL, A1>(fpx, mask16, X, Y);
     fit_to_bytes<RGBA>(X, Y, outA, outB);
 }
 

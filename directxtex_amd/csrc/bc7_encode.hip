@@ -107,11 +107,13 @@ __global__ void __launch_bounds__(256, DXTEX_ROUGH_WGS) bc7_rough_kernel(Bc7Args
     __shared__ float sF[4][64];
     __shared__ uint32_t sL[4][16];
     __shared__ uint2 sSeed[4][128];    // the fits of all 64 shapes x 2 subsets; only the ranked ones leave the kernel
+    __shared__ int2 sErr[4][128];      // their rough errors with 3-bit / 2-bit indices
+    __shared__ uint32_t sOpaque[4];    // every alpha of the block is exactly 1.0f: the fits take the A1 variant (bc7_core.h, fit_setup)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nb = blockIdx.x * 4 + wave;
-    if (nb >= a.nblocks) return;       // whole wave exits together
+    const bool inRange = nb < a.nblocks;
 
-    if (lane < 16)
+    if (inRange && lane < 16)
     {
         uint32_t ldr;
         const BcSeg& sg = seg_of(a.seg, nb);
@@ -120,7 +122,47 @@ __global__ void __launch_bounds__(256, DXTEX_ROUGH_WGS) bc7_rough_kernel(Bc7Args
         a.px[uint64_t(nb) * 16 + lane] = ldr;
         if (lane == 0) { a.zeroOrd[nb] = 0xFFFFFFFFu; a.bestErr[nb] = 0x7FFFFFFF; }
     }
-    wave_lds_sync();
+    {
+        const bool one = !inRange || lane >= 16 || sF[wave][(lane & 15) * 4 + 3] == 1.0f;       // own write, same lane
+        const unsigned long long all = __ballot(one);
+        if (lane == 0) sOpaque[wave] = (all == ~0ull) ? 1u : 0u;
+    }
+    __syncthreads();
+
+    // ---- 2-subset shapes: modes 1, 3, 7 ----
+    // The 4 x 128 fits of the workgroup's four blocks are dealt to the wavefronts BY SUBSET SIZE (kFit2Order: 128 subsets, largest
+    // first, in eight groups of sixteen): a wavefront takes one group for all four blocks (lane = block * 16 + entry), twice - group
+    // w, then group 7 - w. The texel loops of a wavefront then run max-of-group trips (13, 12, 8, 8, 8, 8, 8, 4: 69 per four blocks)
+    // instead of max(larger subset) + max(smaller subset) = 13 + 8 per block with a lane per shape: the same fits, 18 % fewer trips.
+    // Every fit is independent and the error sums are integers, so who computes what is free.
+    {
+        const uint32_t blk = uint32_t(lane) >> 4, ent = uint32_t(lane) & 15u;
+        const uint32_t nbk = blockIdx.x * 4 + blk;
+        const float* fpxk = sF[blk];
+        const uint32_t* pixk = sL[blk];
+        const bool opaque = sOpaque[blk] != 0u;
+#pragma unroll 1
+        for (int k = 0; k < 2; ++k)
+        {
+            const uint32_t group = k ? uint32_t(7 - wave) : uint32_t(wave);
+            const uint32_t code = kFit2Order[group * 16 + ent];
+            if (nbk < a.nblocks)
+            {
+                const uint32_t m1 = kPart2Mask[code >> 1];
+                const uint32_t m = (code & 1u) ? m1 : ((~m1) & 0xFFFFu);
+                Region rg; region_init(rg, pixk, m);
+                uint32_t A, B;
+                if (rg.np == 1) { A = pixk[rg.pos(0)]; B = A; }
+                else if (rg.np == 2) { A = pixk[rg.pos(0)]; B = pixk[rg.pos(1)]; }
+                else if (opaque) seed_endpoints<true, false, true>(fpxk, m, A, B);
+                else seed_endpoints<true>(fpxk, m, A, B);
+                sSeed[blk][code] = make_uint2(A, B);                              // Refine starts from the same fit (:3411-3417)
+                sErr[blk][code] = make_int2(rough_error<3, 0>(rg, A, B), rough_error<2, 0>(rg, A, B));
+            }
+        }
+    }
+    __syncthreads();
+    if (!inRange) return;              // whole wave exits together
     const float* fpx = sF[wave];
     const uint32_t* pix = sL[wave];
 
@@ -129,28 +171,10 @@ __global__ void __launch_bounds__(256, DXTEX_ROUGH_WGS) bc7_rough_kernel(Bc7Args
 
     uint8_t* lst = a.lists + uint64_t(nb) * LIST_BYTES;
 
-    // ---- 2-subset shapes: modes 1, 3, 7 ----
     {
         const uint32_t shape = lane;
-        const uint32_t m1 = kPart2Mask[shape], m0 = (~m1) & 0xFFFFu;
-        int e3 = 0, e2 = 0;
-        // every lane takes its LARGER subset first: the trip counts of a wavefront are then max(larger) + max(smaller) <= 15 + 8
-        // instead of max(subset 0) + max(subset 1) ~ 29 (the error sums are integers, their order is free)
-        const int big = (__popc(m1) > __popc(m0)) ? 1 : 0;
-#pragma unroll 1
-        for (int k = 0; k < 2; ++k)
-        {
-            const int r = k ^ big;
-            const uint32_t m = r ? m1 : m0;
-            Region rg; region_init(rg, pix, m);
-            uint32_t A, B;
-            if (rg.np == 1) { A = pix[rg.pos(0)]; B = A; }
-            else if (rg.np == 2) { A = pix[rg.pos(0)]; B = pix[rg.pos(1)]; }
-            else seed_endpoints<true>(fpx, m, A, B);
-            sSeed[wave][shape * 2 + r] = make_uint2(A, B);                        // Refine starts from the same fit (:3411-3417)
-            e3 += rough_error<3, 0>(rg, A, B);
-            e2 += rough_error<2, 0>(rg, A, B);
-        }
+        const int2 er0 = sErr[wave][shape * 2], er1 = sErr[wave][shape * 2 + 1];
+        const int e3 = er0.x + er1.x, e2 = er0.y + er1.y;
         int ea = e3, eb = e2;
         uint32_t sa = shape, sb = shape;
         for (int i = 0; i < 16; ++i)

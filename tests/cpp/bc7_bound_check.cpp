@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cmath>
 #include <algorithm>
+#include <cstring>
 #include "../../directxtex_amd/csrc/bc67_tables.h"
 #include "../../directxtex_amd/csrc/bc7_core.h"
 
@@ -125,6 +126,48 @@ int main(int argc, char** argv)
             if (e < ((K == 4) ? lb4 : lb8)) { ++violations; std::printf("VIOLATION: scalar error %ld < k-means bound %d (K=%d)\n", e, (K == 4) ? lb4 : lb8, K); }
         }
     }
+    // The opaque-block variant of the RGBA fit (fit_setup / fit_iterate with A1): bit-identical end points to the plain RGBA fit on
+    // blocks whose alpha is exactly 1.0f, for every subset mask - flat, two-colour, gradient and noisy blocks, texels as LoadScanline
+    // makes them (byte * float(1 / 255)).
+    long fits = 0, fitDiff = 0;
+    for (int t = 0; t < trials; ++t)
+    {
+        float f[64];
+        const int kind = rnd() % 5;
+        int a[3], b[3];
+        for (int c = 0; c < 3; ++c) { a[c] = rnd() % 256; b[c] = rnd() % 256; }
+        for (int i = 0; i < 16; ++i)
+        {
+            for (int c = 0; c < 3; ++c)
+            {
+                int v;
+                if (kind == 0) v = rnd() % 256;
+                else if (kind == 1) { const int sgrad = rnd() % 65; v = (a[c] * (64 - sgrad) + b[c] * sgrad) / 64 + int(rnd() % 9) - 4; }
+                else if (kind == 2) v = (rnd() & 1) ? a[c] : b[c];
+                else if (kind == 3) v = a[c] + int(rnd() % 6) - 3;
+                else v = a[c];
+                v = std::min(255, std::max(0, v));
+                f[i * 4 + c] = float(v) * (1.0f / 255.0f);
+            }
+            f[i * 4 + 3] = 255.0f * (1.0f / 255.0f);
+            if (f[i * 4 + 3] != 1.0f) { std::printf("alpha 255 does not load as 1.0f\n"); return 1; }
+        }
+        const uint32_t masks[3] = { 0xFFFFu, uint32_t(kPart2Mask[rnd() % 64]), uint32_t(~kPart2Mask[rnd() % 64]) & 0xFFFFu };
+        for (uint32_t mask : masks)
+        {
+            if (__builtin_popcount(mask) < 3) continue;
+            float X0[4], Y0[4], X1[4], Y1[4];
+            seed_fit<true, false, false>(f, mask, X0, Y0);
+            seed_fit<true, false, true>(f, mask, X1, Y1);
+            ++fits;
+            if (std::memcmp(X0, X1, sizeof(X0)) != 0 || std::memcmp(Y0, Y1, sizeof(Y0)) != 0)
+            {
+                ++fitDiff;
+                if (fitDiff < 4) std::printf("A1 FIT DIFFERS (trial %d, mask %04x): X %g %g %g %g | %g %g %g %g\n", t, mask, X0[0], X0[1], X0[2], X0[3], X1[0], X1[1], X1[2], X1[3]);
+            }
+        }
+    }
     std::printf("%ld palettes checked, %ld violations, best found error / bound >= %.3f\n", checked, violations, tightest);
-    return violations ? 1 : 0;
+    std::printf("%ld opaque fits, %ld differ between the RGBA fit and its opaque-block variant\n", fits, fitDiff);
+    return (violations || fitDiff) ? 1 : 0;
 }
