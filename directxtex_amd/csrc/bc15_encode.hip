@@ -985,9 +985,8 @@ __global__ void __launch_bounds__(kPoolLanes) bc13_pooled_kernel(EncodeArgs a)
 // each kernel's register footprint to what that codec needs.
 // One block from a tile of floats (any source format, partial blocks, conversions): block `nb` of the image behind `a`
 template<int KIND, bool DITHER>
-__device__ __forceinline__ void encode_block_generic(const EncodeArgs& a, uint32_t nb)
+__device__ __forceinline__ void encode_block_generic(const EncodeArgs& a, uint32_t bx, uint32_t by)
 {
-    const uint32_t by = nb / a.nbw, bx = nb - by * a.nbw;
     uint8_t* out = a.dst + uint64_t(by) * a.dstRowPitch;
     Tile t;
     load_tile(a.src, bx, by, t);
@@ -1031,9 +1030,26 @@ __device__ __forceinline__ void encode_block_generic(const EncodeArgs& a, uint32
 template<int KIND, bool DITHER, bool PACKED8>
 __global__ void __launch_bounds__(256, PACKED8 ? DXTEX_BC15_PACKED_WGS : 1) bc15_encode_kernel(EncodeArgs a)
 {
-    const uint32_t nb = blockIdx.x * 256u + threadIdx.x;
-    if (nb >= a.nbw * a.nbh) return;
-    const uint32_t by = nb / a.nbw, bx = nb - by * a.nbw;
+    // A wavefront takes an 8 x 8 tile of blocks (32 x 32 texels), not 64 blocks of one block row: what the lanes of a wavefront do
+    // differs by content - flat blocks leave the fit at once, noisy ones run its eight Newton trips - and content is coherent in two
+    // dimensions, so a square tile keeps more lanes in step than a 256-texel strip (36 -> of 64 lanes active on the benchmark image
+    // with strips). Loads stay 128-byte runs (8 blocks x 16 bytes per row), stores 64 / 128-byte runs. Images narrower or lower than
+    // 8 blocks keep the linear order.
+    uint32_t bx, by;
+    if (KIND <= 3 && a.nbw >= 8 && a.nbh >= 8)          // BC4 / BC5 have no content-dependent paths: linear order, 1 KiB runs
+    {
+        const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+        const uint32_t tilesX = (a.nbw + 7u) >> 3;
+        const uint32_t ty = wave / tilesX, tx = wave - ty * tilesX;
+        bx = tx * 8u + (lane & 7u); by = ty * 8u + (lane >> 3);
+        if (bx >= a.nbw || by >= a.nbh) return;
+    }
+    else
+    {
+        const uint32_t nb = blockIdx.x * 256u + threadIdx.x;
+        if (nb >= a.nbw * a.nbh) return;
+        by = nb / a.nbw; bx = nb - by * a.nbw;
+    }
     uint8_t* out = a.dst + uint64_t(by) * a.dstRowPitch;
 
     if constexpr (PACKED8)
@@ -1078,7 +1094,7 @@ __global__ void __launch_bounds__(256, PACKED8 ? DXTEX_BC15_PACKED_WGS : 1) bc15
         return;
     }
     else
-        encode_block_generic<KIND, DITHER>(a, nb);
+        encode_block_generic<KIND, DITHER>(a, bx, by);
 }
 
 // Several SMALL images in one launch (the tail of a mip chain, a set of icons): a kernel over one of them lasts as long as its slowest
@@ -1097,7 +1113,8 @@ __global__ void __launch_bounds__(256) bc15_encode_multi_kernel(MultiArgs m)
     EncodeArgs a;
     a.src = m.img[i].src; a.dst = m.img[i].dst; a.dstRowPitch = m.img[i].dstRowPitch; a.nbw = m.img[i].nbw; a.nbh = m.img[i].nbh;
     a.dstFormat = m.dstFormat; a.flags = m.flags; a.threshold = m.threshold;
-    encode_block_generic<KIND, DITHER>(a, g - m.img[i].first);
+    const uint32_t nb = g - m.img[i].first, by = nb / a.nbw;
+    encode_block_generic<KIND, DITHER>(a, nb - by * a.nbw, by);
 }
 } // namespace
 
@@ -1110,7 +1127,11 @@ hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowP
     a.dstFormat = dstFormat; a.flags = flags; a.threshold = threshold;
     const uint64_t nblocks = uint64_t(a.nbw) * a.nbh;
     if (!nblocks) return hipSuccess;
-    const dim3 grid(uint32_t((nblocks + 255) / 256)), block(256);
+    // bc15_encode_kernel: a wavefront per 8 x 8 tile of blocks when the image has at least 8 x 8 of them, else blocks in linear order
+    const uint64_t tiles = uint64_t((a.nbw + 7) / 8) * ((a.nbh + 7) / 8);
+    const bool colourFit = dstFormat == FMT_BC1_UNORM || dstFormat == FMT_BC1_UNORM_SRGB || dstFormat == FMT_BC2_UNORM || dstFormat == FMT_BC2_UNORM_SRGB ||
+                           dstFormat == FMT_BC3_UNORM || dstFormat == FMT_BC3_UNORM_SRGB;         // kernel KIND <= 3
+    const dim3 grid((colourFit && a.nbw >= 8 && a.nbh >= 8) ? uint32_t((tiles + 3) / 4) : uint32_t((nblocks + 255) / 256)), block(256);
     const bool dither = (flags & BCF_DITHER_RGB) != 0;
     // packed-tile kernels: RGBA8 texels need no conversion on their way into the encoder, every block is whole, rows are 16-byte aligned;
     // BC1's alpha dithering rewrites the tile's alpha and keeps the float tile
