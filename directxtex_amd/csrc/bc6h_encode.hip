@@ -370,7 +370,11 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
         for (int i = 0; i < 12; ++i) { const float4 v = gp[i]; regs[4 * i] = v.x; regs[4 * i + 1] = v.y; regs[4 * i + 2] = v.z; regs[4 * i + 3] = v.w; }
     }
     Org6 o;
-    org_candidate<REGIONS2>(a, nb, r, planes, slot, o);
+    const uint64_t t = REGIONS2 ? uint64_t(nb) * L::TPB + r : uint64_t(a.taskBase) + nb;
+    // Refine's unoptimised half - quantised seeds, AssignIndices, SwapIndices - depends on the endpoint PRECISION, not on the mode's delta
+    // bits: the second and third mode of an 8-bit / 11-bit trio read what the first left in orgs[] instead of assigning indices again
+    const bool reuseOrg = REGIONS2 && a.samePrec != 0;
+    org_candidate<REGIONS2>(a, nb, r, planes, slot, o, reuseOrg ? a.orgs + t : nullptr);
 #if defined(DXTEX_BC6H_TRACE)
     if (nb == 0 && a.mode.index == 0) printf("pre r %u shape %u fit %d A %d %d %d B %d %d %d | T A %d %d %d B %d %d %d err %.9g np %d tr %d delta %d %d %d\n", r, o.shape, int(o.fit), o.ep.A[0], o.ep.A[1], o.ep.A[2], o.ep.B[0], o.ep.B[1], o.ep.B[2], o.epT.A[0], o.epT.A[1], o.epT.A[2], o.epT.B[0], o.epT.B[1], o.epT.B[2], o.err, o.np, a.mode.transformed, a.mode.delta[0], a.mode.delta[1], a.mode.delta[2]);
 #endif
@@ -399,7 +403,7 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
         prune = lb > table;
     }
     if (!inRange) return;
-    const uint64_t t = REGIONS2 ? uint64_t(nb) * L::TPB + r : uint64_t(a.taskBase) + nb;
+    if (!reuseOrg)
     {
         OrgSave sv;
 #pragma unroll
