@@ -123,12 +123,14 @@ __global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
 {
     __shared__ float sF[4][64];
     __shared__ float sP[4][48];
+    __shared__ int sSeedA[4][64][3], sSeedB[4][64][3];     // the fits of the 32 shapes x 2 regions (code = shape * 2 + region)
+    __shared__ float sPart[4][64];                         // their rough errors; < 0: a region of one or two texels (adds nothing)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nb = blockIdx.x * 4 + wave;
-    if (nb >= a.nblocks) return;
+    const bool inRange = nb < a.nblocks;
     const bool sg = a.isSigned != 0;
 
-    if (lane < 16)
+    if (inRange && lane < 16)
     {
         // one texel of the block, with the reference's partial-block replication (DirectXTexCompress.cpp:315-341)
         const BcSeg& im = seg_of(a.seg, nb);
@@ -144,69 +146,84 @@ __global__ void __launch_bounds__(256) bc6h_rough_kernel(Bc6hArgs a)
         float* gp = a.fpix + uint64_t(nb) * 48;
         gp[lane] = ir; gp[16 + lane] = ig; gp[32 + lane] = ib;
     }
-    if (lane == 0) { Best6 b; b.err = 3.402823466e+38f; b.mode = 0xFFFFFFFFu; b.lo = 0; b.hi = 0; a.best[nb] = b; }
-    wave_lds_sync();
-    const float* fpx = sF[wave];
-    const float* planes = sP[wave];         // the subsets are read in place (no per-lane columns: 50 KiB of LDS held the kernel at 3 waves per SIMD)
+    if (inRange && lane == 0) { Best6 b; b.err = 3.402823466e+38f; b.mode = 0xFFFFFFFFu; b.lo = 0; b.hi = 0; a.best[nb] = b; }
+    __syncthreads();
 
-    // lane = shape + 32 * region: every lane fits ONE subset of a two-region shape (the one-region fit has a kernel of its own,
-    // bc6h_block_seed_kernel, so that it does not cost this wavefront a second full pass with one lane active)
-    const uint32_t shape = uint32_t(lane) & 31u, region = uint32_t(lane) >> 5;
-    const uint32_t m1 = uint32_t(kPart2Mask[shape]);
-    const uint32_t mask = region ? m1 : ((~m1) & 0xFFFFu);
-    EndPts seed;
-    float part = 0.0f;
-    bool ranked = false;
+    // Every fit is ONE subset of a two-region shape (the one-region fit has a kernel of its own, bc6h_block_seed_kernel). The 4 x 64
+    // fits of the workgroup's four blocks are dealt to the wavefronts BY SUBSET SIZE (kFit2Order32: largest first, four groups of
+    // sixteen; wavefront w takes group w of all four blocks, lane = block * 16 + entry), so the texel loops of a wavefront run
+    // 13 / 10 / 8 / 4 trips instead of 13 in every wavefront with a lane per (shape, region). The subsets are read in place from the
+    // block's planes (no per-lane columns: 50 KiB of LDS held the kernel at 3 waves per SIMD).
     {
-        uint64_t pos;
-        const int np = region_positions(mask, pos);
-        const uint32_t p0 = uint32_t(pos) & 15u, p1 = uint32_t(pos >> 4) & 15u;
-        if (np == 1)
+        const uint32_t blk = uint32_t(lane) >> 4, ent = uint32_t(lane) & 15u;
+        if (blockIdx.x * 4 + blk < a.nblocks)
         {
-            seed.A[0] = seed.B[0] = int(planes[p0]); seed.A[1] = seed.B[1] = int(planes[16 + p0]); seed.A[2] = seed.B[2] = int(planes[32 + p0]);
-        }
-        else if (np == 2)
-        {
-            seed.A[0] = int(planes[p0]); seed.A[1] = int(planes[16 + p0]); seed.A[2] = int(planes[32 + p0]);
-            seed.B[0] = int(planes[p1]); seed.B[1] = int(planes[16 + p1]); seed.B[2] = int(planes[32 + p1]);
-        }
-        else
-        {
-            float X[4], Y[4];
-            bc7::seed_fit<false>(fpx, mask, X, Y);
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
+            const uint32_t code = kFit2Order32[wave * 16 + ent];
+            const uint32_t m1 = uint32_t(kPart2Mask[code >> 1]);
+            const uint32_t mask = (code & 1u) ? m1 : ((~m1) & 0xFFFFu);
+            const float* fpx = sF[blk];
+            const float* planes = sP[blk];
+            EndPts seed;
+            float part = -1.0f;
+            uint64_t pos;
+            const int np = region_positions(mask, pos);
+            const uint32_t p0 = uint32_t(pos) & 15u, p1 = uint32_t(pos >> 4) & 15u;
+            if (np == 1)
             {
-                seed.A[c] = clamp_seed(float_to_int16f(X[c], sg), sg);
-                seed.B[c] = clamp_seed(float_to_int16f(Y[c], sg), sg);
+                seed.A[0] = seed.B[0] = int(planes[p0]); seed.A[1] = seed.B[1] = int(planes[16 + p0]); seed.A[2] = seed.B[2] = int(planes[32 + p0]);
             }
-            const TileTexels tx = { planes, np };
-            part = rough_error6<8>(tx, seed, pos);
-            ranked = true;
+            else if (np == 2)
+            {
+                seed.A[0] = int(planes[p0]); seed.A[1] = int(planes[16 + p0]); seed.A[2] = int(planes[32 + p0]);
+                seed.B[0] = int(planes[p1]); seed.B[1] = int(planes[16 + p1]); seed.B[2] = int(planes[32 + p1]);
+            }
+            else
+            {
+                float X[4], Y[4];
+                bc7::seed_fit<false>(fpx, mask, X, Y);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                {
+                    seed.A[c] = clamp_seed(float_to_int16f(X[c], sg), sg);
+                    seed.B[c] = clamp_seed(float_to_int16f(Y[c], sg), sg);
+                }
+                const TileTexels tx = { planes, np };
+                part = rough_error6<8>(tx, seed, pos);       // >= 0
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { sSeedA[blk][code][c] = seed.A[c]; sSeedB[blk][code][c] = seed.B[c]; }
+            sPart[blk][code] = part;
         }
     }
-    // RoughMSE's total (:2523-2556): fError += error of region 0, then of region 1; regions of one or two texels add nothing
-    const float p1 = __shfl(part, int(shape + 32u));
-    const int r1 = __shfl(int(ranked), int(shape + 32u));
-    float rough = 0.0f;
-    if (ranked) rough += part;
-    if (r1) rough += p1;
+    __syncthreads();
+    if (!inRange) return;
 
+    // RoughMSE's total (:2523-2556): fError += error of region 0, then of region 1; regions of one or two texels add nothing
+    float rough = 0.0f;
+    if (lane < 32)
+    {
+        const float q0 = sPart[wave][lane * 2], q1 = sPart[wave][lane * 2 + 1];
+        if (q0 >= 0.0f) rough += q0;
+        if (q1 >= 0.0f) rough += q1;
+    }
     int key = (lane < 32) ? __float_as_int(rough) : 0x7FFFFFFF;
     uint32_t shp = uint32_t(lane);
     for (int i = 0; i < 8; ++i) selection_pass(key, shp, lane, i);
-    int* sd = a.seeds + uint64_t(nb) * SEED_INTS;
-    // lane i < 8 now knows the i-th best shape; its seeds still sit in lanes `shp` (region 0) and `shp + 32` (region 1)
+    // lane i < 8 now knows the i-th best shape
+    if (lane < 8)
+    {
+        int* sd = a.seeds + uint64_t(nb) * SEED_INTS;
+        const uint32_t sh = shp & 31u;
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-        {
-            const int from = int((shp & 31u) + 32u * uint32_t(r));
-            const int va = __shfl(seed.A[c], from), vb = __shfl(seed.B[c], from);
-            if (lane < 8) { sd[(lane * 2 + r) * 6 + c] = va; sd[(lane * 2 + r) * 6 + 3 + c] = vb; }
-        }
-    if (lane < 8) a.lists[uint64_t(nb) * 8 + lane] = uint8_t(shp);
+            for (int c = 0; c < 3; ++c)
+            {
+                sd[(lane * 2 + r) * 6 + c] = sSeedA[wave][sh * 2 + r][c];
+                sd[(lane * 2 + r) * 6 + 3 + c] = sSeedB[wave][sh * 2 + r][c];
+            }
+        a.lists[uint64_t(nb) * 8 + lane] = uint8_t(shp);
+    }
 }
 
 // The one-region seed (:2513-2521 with uPartitions == 0): the whole block fitted once, one lane per block, texels in registers.
