@@ -439,16 +439,6 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
         const uint32_t prev = a.tinfo[t];
         if ((prev >> 24) != 0u || (prev & kDoneBit6) != 0u) done = kDoneBit6;
     }
-    if (done)
-        a.recs[t].valid = o.fit ? 1u : 0u;
-    else
-    {
-        Rec6 rec;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { rec.A[c] = o.ep.A[c]; rec.B[c] = o.ep.B[c]; }
-        rec.err = o.err; rec.valid = o.fit ? 1u : 0u;
-        a.recs[t] = rec;
-    }
     // OptimizeEndPoints' quirk (:2215): region 0 is optimised against all sixteen texels. Nothing to search when the
     // candidate does not fit or its error is already 0 (PerturbOne only accepts strictly smaller errors).
     const bool region0 = !REGIONS2 || (r & 1u) == 0;
@@ -458,6 +448,16 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
     // one-region tasks are sorted by mode slot instead (13 + slot: the 16-bit mode, the longest search, goes first); all have 16 texels
     if (!REGIONS2 && snp) snp = 13u + a.taskBase / a.nblocks;
     if (done) snp = 0;
+    // The search record is the start of a search: only a task that will be searched gets one (a `done` task keeps the earlier mode's;
+    // post takes the unoptimised endpoints of everything else from orgs[]) - most tasks of the later modes write nothing here.
+    if (snp)
+    {
+        Rec6 rec;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { rec.A[c] = o.ep.A[c]; rec.B[c] = o.ep.B[c]; }
+        rec.err = o.err; rec.valid = 1u;
+        a.recs[t] = rec;
+    }
     a.tinfo[t] = smask | done | (snp << 24);
 }
 
@@ -492,16 +492,22 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     const uint64_t t = REGIONS2 ? uint64_t(nb) * L::TPB + r : uint64_t(a.taskBase) + nb;
     org_candidate<REGIONS2>(a, nb, r, planes, slot, o, a.orgs + t);
 
-    // the optimised endpoints (== the org ones where no search ran)
-    const Rec6 rec = a.recs[t];
-    EndPts opt;
+    // the optimised endpoints: in recs[] where a search ran for this task (this mode's, or an earlier one's of the same precision), the
+    // unoptimised ones everywhere else
+    const uint32_t ti = a.tinfo[t];
+    const bool ownSearched = (ti >> 24) != 0u || (ti & kDoneBit6) != 0u;
+    EndPts opt = o.ep;
+    if (ownSearched)
+    {
+        const Rec6 rec = a.recs[t];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { opt.A[c] = rec.A[c]; opt.B[c] = rec.B[c]; }
+        for (int c = 0; c < 3; ++c) { opt.A[c] = rec.A[c]; opt.B[c] = rec.B[c]; }
+    }
     // A candidate the search never ran for either region (pruned, does not fit, error already 0: subset size 0 in the task list)
     // still has its unoptimised endpoints: it either cannot win (its lower bound exceeds an error on the table, or it is not
     // encodable) or wins with its unoptimised half (error 0, which nothing beats), so it stands with those numbers. A wavefront
     // whose candidates are all of that kind - most wavefronts of the later modes - skips the second AssignIndices.
-    bool searched = (a.tinfo[t] >> 24) != 0u || (a.tinfo[t] & kDoneBit6) != 0u;      // by this mode, or by an earlier one of the same precision
+    bool searched = ownSearched;
     if (REGIONS2) searched = searched || (__shfl_xor(int(searched), 1) != 0);      // the candidate's other region: Refine scores both (:2401-2410)
     uint64_t optIdx = o.idx;
     float optErr = o.err;
