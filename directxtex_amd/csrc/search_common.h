@@ -132,17 +132,25 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // Reproduces "bubble up the first uItems items" (:2855-2865): position i ends up with the first minimum
 // of positions i.., and every strict prefix-minimum record along the way shifts to the next record's place.
+// Inclusive minimum over lanes 0 ... l of a wavefront, on the data-parallel-primitive path of gfx9 (row_shr within the rows of sixteen
+// lanes, then row_bcast:15 / row_bcast:31 across them): six v_min_i32 with a DPP operand instead of six ds_bpermute + compare + select -
+// the rough passes run 8 - 48 selection passes per block and were waiting on the LDS crossbar. A lane without a source keeps its value.
+__device__ __forceinline__ int wave_prefix_min(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xF, 0xF, false));      // row_shr:1
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xF, 0xF, false));      // row_shr:2
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xF, 0xF, false));      // row_shr:4
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xF, 0xF, false));      // row_shr:8
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));      // row_bcast:15 into rows 1 and 3
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __device__ __forceinline__ void selection_pass(int& e, uint32_t& s, int lane, int i)
 {
     const int v = (lane >= i) ? e : 0x7FFFFFFF;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl = min(incl, o);
-    }
-    int excl = __shfl_up(incl, 1);
+    const int incl = wave_prefix_min(v);
+    int excl = __builtin_amdgcn_update_dpp(0x7FFFFFFF, incl, 0x138, 0xF, 0xF, false);      // wave_shr:1; lane 0 keeps +inf
     if (lane <= i) excl = 0x7FFFFFFF;
     const bool isrec = (lane > i) && (e < excl);
     const unsigned long long mask = __ballot(isrec);
