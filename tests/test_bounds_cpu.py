@@ -60,3 +60,29 @@ def test_triangle_filter_tables_match_the_reference():
         assert int(p[0]) == len(ref) and ours == ref, (source, dest, wrap)
         entries += len(ref)
     assert entries > 100000
+
+
+def test_fit_order_tables_are_size_sorted_permutations():
+    """bc67_tables.h: kFit2Order / kFit2Order32 deal the rough passes' fits to wavefronts by subset size (bc7_rough_kernel,
+    bc6h_rough_kernel). They must list every subset (shape * 2 + subset) of the two-subset partitions exactly once, largest first -
+    a missing or repeated code would leave a fit uncomputed (stale LDS) rather than fail loudly."""
+    import re
+    text = open(os.path.join(ROOT, "directxtex_amd", "csrc", "bc67_tables.h")).read()
+
+    def table(name):
+        body = re.search(name + r"\[\d+\]\s*=\s*\{([^}]*)\}", text).group(1)
+        return [int(x, 0) for x in re.findall(r"0x[0-9a-fA-F]+|\d+", body)]
+
+    masks = table("kPart2Mask")
+    assert len(masks) == 64
+
+    def size(code):
+        ones = bin(masks[code >> 1]).count("1")
+        return ones if code & 1 else 16 - ones
+
+    for name, n in (("kFit2Order", 128), ("kFit2Order32", 64)):
+        order = table(name)
+        assert sorted(order) == list(range(n)), name
+        sizes = [size(c) for c in order]
+        assert sizes == sorted(sizes, reverse=True), name
+        assert min(sizes) >= 3          # no subset of one or two texels among the two-subset shapes: every fit runs OptimizeRGB(A)
