@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 WIDTH = HEIGHT = 4096
 ALGO_BYTES_PER_TEXEL = 5.0          # 4 B read + 1 B written per texel for RGBA8 -> BC7
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s
+PCIE_PEAK_GBS = 63.0                # PCIe 5.0 x16, one direction (MI355X_MICROARCH.md)
 BAND_ROWS = 16                      # block rows per digest band (tests/golden/make_golden_fullsize.py)
 TEX_COMPRESS_PARALLEL = 0x10000000
 
@@ -49,10 +50,11 @@ def make_image(rank):
     return synth.survey_rgba8(WIDTH, HEIGHT, 2 + rank, "opaque")
 
 
-def hbm_roofline(algo_bytes, ms, kernel=None, traffic=None):
+def hbm_roofline(algo_bytes, ms, kernel=None, traffic=None, time_key="kernel_ms"):
+    """time_key names what `ms` is: "kernel_ms" for device time of resident work, "wall_ms" where host copies and PCIe are inside."""
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     r = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-         "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes), "kernel_ms": round(ms, 4)}
+         "traffic": traffic, "algorithmic_bytes_per_launch": int(algo_bytes), time_key: round(ms, 4)}
     if kernel:
         r["kernel"] = kernel
     return r
@@ -115,6 +117,44 @@ def gpu_psnr(ctx, dev, src, dst, fmt_src, fmt_bc, width, height):
     return float(10.0 * np.log10(3.0 / max(1e-30, float(mse[0] + mse[1] + mse[2]))))
 
 
+def resident_end_to_end(ctx, dev, run, src_np, out_bytes, check=None, reps=3):
+    """SURVEY 8d's second number: host buffer -> H2D -> kernels -> D2H -> host buffer, as ONE stream-ordered submission on the context
+    (dxtex_memcpy_h2d_async, the *_device steps, dxtex_memcpy_d2h_async, one synchronize): the source crosses PCIe once, the final
+    payload once, intermediates stay in HBM. `run(src_ptr, dst_ptr)` queues the steps. Measured from pageable numpy memory and from
+    page-locked memory (dxtex_host_alloc); bytes moved come from the context's own transfer counters."""
+    import torch
+    src_np = np.ascontiguousarray(src_np).reshape(-1).view(np.uint8)
+    d_src = torch.empty(src_np.nbytes, dtype=torch.uint8, device=dev)
+    d_dst = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
+    pin_src = ctx.host_alloc(src_np.nbytes); pin_src[:] = src_np
+    pin_dst = ctx.host_alloc(out_bytes)
+    out = {}
+    try:
+        for name, hs, hd in (("pageable", src_np, np.zeros(out_bytes, np.uint8)), ("pinned", pin_src, pin_dst)):
+            best = None
+            for k in range(reps + 1):                        # the first pass warms allocations inside the steps
+                hd[:] = 0
+                ctx.transfer_bytes(reset=True)
+                t0 = time.perf_counter()
+                ctx.upload(d_src.data_ptr(), hs)
+                run(d_src.data_ptr(), d_dst.data_ptr())
+                ctx.download(hd, d_dst.data_ptr())
+                ctx.synchronize()
+                dt = time.perf_counter() - t0
+                if k > 0:
+                    best = dt if best is None else min(best, dt)
+            up, down = ctx.transfer_bytes()
+            e = {"ms": round(best * 1e3, 3), "h2d_bytes": up, "d2h_bytes": down,
+                 "pcie_GBs": round((up + down) / best / 1e9, 2), "pcie_frac_of_63GBs": round((up + down) / best / 1e9 / PCIE_PEAK_GBS, 3)}
+            if check is not None:
+                e["identical_to_reference_golden"] = bool(check(hd))
+            out[name] = e
+        out["transfer_bytes_over_source_plus_payload"] = round((up + down) / float(src_np.nbytes + out_bytes), 4)
+    finally:
+        ctx.host_free(pin_src.ctypes.data); ctx.host_free(pin_dst.ctypes.data)
+    return out
+
+
 def other_workloads(ctx, dev, img, rank, world):
     """The other configurations of BASELINE.json, measured AFTER the timed region (reported, not the metric): device-resident
     inputs, per-call wall time with a stream sync, algorithmic bytes per SURVEY.md section 8d against the 8 TB/s HBM roofline."""
@@ -150,7 +190,19 @@ def other_workloads(ctx, dev, img, rank, world):
     for name, fmt, bpt, n in (("bc1", dx.DXGI_FORMAT_BC1_UNORM, 4.5, 20), ("bc3", dx.DXGI_FORMAT_BC3_UNORM, 5.0, 20), ("bc5", dx.DXGI_FORMAT_BC5_UNORM, 5.0, 20)):
         dst = torch.empty(dx.compute_pitch(fmt, WIDTH, HEIGHT)[1], dtype=torch.uint8, device=dev)
         dt = timed(lambda: ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), fmt, 0, 0.5), n)
-        out[f"{name}_4096"] = entry(dt, tex, tex * bpt, "profiles/r03_kernels.md")
+        out[f"{name}_4096"] = entry(dt, tex, tex * bpt, "profiles/r04_kernels.md")
+        if name != "bc5":
+            nb = dst.numel()
+            out[f"{name}_4096"]["end_to_end"] = resident_end_to_end(
+                ctx, dev, lambda s, d, fmt=fmt: ctx.compress_device(s, WIDTH, HEIGHT, RGBA8, d, fmt, 0, 0.5), img, nb)
+    # cfg1: one 256 x 256 RGBA8 image -> BC1 (BASELINE.json configs[0]; SURVEY 8d seed-1 recipe), kernel-only and end to end
+    c1 = synth.rgba8(256, 256, seed=1, alpha="opaque")
+    c1d = torch.from_numpy(c1).to(dev)
+    c1o = torch.empty(dx.compute_pitch(dx.DXGI_FORMAT_BC1_UNORM, 256, 256)[1], dtype=torch.uint8, device=dev)
+    dt = timed(lambda: ctx.compress_device(c1d.data_ptr(), 256, 256, RGBA8, c1o.data_ptr(), dx.DXGI_FORMAT_BC1_UNORM, 0, 0.5), 50)
+    e = entry(dt, 256 * 256, 256 * 256 * 4.5)
+    e["end_to_end"] = resident_end_to_end(ctx, dev, lambda s, d: ctx.compress_device(s, 256, 256, RGBA8, d, dx.DXGI_FORMAT_BC1_UNORM, 0, 0.5), c1, c1o.numel(), reps=10)
+    out["cfg1_bc1_256"] = e
     # the reference's faster / slower BC7 settings on the same image (TEX_COMPRESS_BC7_QUICK: mode 6 only; BC7_USE_3SUBSETS: + modes 0, 2)
     dst = torch.empty(dx.compute_pitch(dx.DXGI_FORMAT_BC7_UNORM, WIDTH, HEIGHT)[1], dtype=torch.uint8, device=dev)
     for name, fl, n in (("bc7_quick_4096", dx.TEX_COMPRESS_BC7_QUICK, 5), ("bc7_3subsets_4096", 0x80000, 1)):
@@ -172,10 +224,13 @@ def other_workloads(ctx, dev, img, rank, world):
     hdr = torch.from_numpy(hdr_np).to(dev)
     dst6 = torch.empty(dx.compute_pitch(dx.DXGI_FORMAT_BC6H_UF16, WIDTH, HEIGHT)[1], dtype=torch.uint8, device=dev)
     dt = timed(lambda: ctx.compress_device(hdr.data_ptr(), WIDTH, HEIGHT, RGBA16F, dst6.data_ptr(), dx.DXGI_FORMAT_BC6H_UF16, 0, 0.5), 2)
-    e = entry(dt, tex, tex * 9.0, "profiles/r03_kernels.md")
+    e = entry(dt, tex, tex * 9.0, "profiles/r04_kernels.md")
     gold = golden_case("cfg3_bc6h_uf16_4096")
     if gold:
         e["identical_to_reference_golden"] = band_sha(dst6.cpu().numpy(), WIDTH, HEIGHT) == gold["bands"]
+    e["end_to_end"] = resident_end_to_end(
+        ctx, dev, lambda s, d: ctx.compress_device(s, WIDTH, HEIGHT, RGBA16F, d, dx.DXGI_FORMAT_BC6H_UF16, 0, 0.5), hdr_np, dst6.numel(),
+        check=(lambda p: band_sha(p, WIDTH, HEIGHT) == gold["bands"]) if gold else None, reps=2)
     out["cfg3_bc6h_uf16_4096"] = e
     del hdr, hdr_np
     # decoders, 4096^2 to their default targets (block bytes read + target bytes written per texel): BC7 of the headline's own payload
@@ -183,16 +238,17 @@ def other_workloads(ctx, dev, img, rank, world):
     back = torch.empty(tex * 8, dtype=torch.uint8, device=dev)
     ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, 0, 0.5)
     dt = timed(lambda: ctx.decompress_device(dst.data_ptr(), WIDTH, HEIGHT, dx.DXGI_FORMAT_BC7_UNORM, back.data_ptr(), RGBA8), 20)
-    out["bc7_decode_4096"] = entry(dt, tex, tex * 5.0, "profiles/r03_kernels.md")
+    out["bc7_decode_4096"] = entry(dt, tex, tex * 5.0, "profiles/r04_kernels.md")
     for name, fmt, bpt in (("bc1", dx.DXGI_FORMAT_BC1_UNORM, 4.5), ("bc3", dx.DXGI_FORMAT_BC3_UNORM, 5.0)):
         ctx.compress_device(src.data_ptr(), WIDTH, HEIGHT, RGBA8, dst.data_ptr(), fmt, 0, 0.5)
         dt = timed(lambda: ctx.decompress_device(dst.data_ptr(), WIDTH, HEIGHT, fmt, back.data_ptr(), RGBA8), 20)
-        out[f"{name}_decode_4096"] = entry(dt, tex, tex * bpt, "profiles/r03_kernels.md")
+        out[f"{name}_decode_4096"] = entry(dt, tex, tex * bpt, "profiles/r04_kernels.md")
     dt = timed(lambda: ctx.decompress_device(dst6.data_ptr(), WIDTH, HEIGHT, dx.DXGI_FORMAT_BC6H_UF16, back.data_ptr(), RGBA16F), 20)
-    out["bc6h_decode_4096"] = entry(dt, tex, tex * 9.0, "profiles/r03_kernels.md")
+    out["bc6h_decode_4096"] = entry(dt, tex, tex * 9.0, "profiles/r04_kernels.md")
     del back, dst6
     # cfg4: 8192^2 RGBA8 (seed 4, random alpha) full mip chain (box, cubic), then BC3 of all 14 levels
-    big = torch.from_numpy(synth.survey_rgba8(8192, 8192, 4, "random")).to(dev)
+    big_np = synth.survey_rgba8(8192, 8192, 4, "random")
+    big = torch.from_numpy(big_np).to(dev)
     w = h = 8192
     sizes = []
     while True:
@@ -206,7 +262,7 @@ def other_workloads(ctx, dev, img, rank, world):
     chain_tex = sum(a * b for a, b in sizes[1:])
     for name, flt in (("box", dx.TEX_FILTER_BOX), ("cubic", dx.TEX_FILTER_CUBIC)):
         dt = timed(lambda: ctx.generate_mips_device(levels, flt), 5)
-        e = entry(dt, chain_tex, chain_bytes, "profiles/r03_kernels.md")
+        e = entry(dt, chain_tex, chain_bytes, "profiles/r04_kernels.md")
         gold = golden_case(f"cfg4_{name}")
         if gold:
             e["identical_to_reference_golden"] = [hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() for t in bufs] == gold["levels"]
@@ -216,12 +272,31 @@ def other_workloads(ctx, dev, img, rank, world):
     dsts = [dx.capi.device_image(t.data_ptr(), a, b, dx.DXGI_FORMAT_BC3_UNORM) for t, (a, b) in zip(bc3, sizes)]
     dt = timed(lambda: ctx.compress_many_device(levels, dsts, 0, 0.5), 5)
     tex4 = sum(a * b for a, b in sizes)
-    e = entry(dt, tex4, 447392452, "profiles/r03_kernels.md")
+    e = entry(dt, tex4, 447392452, "profiles/r04_kernels.md")
     gold = golden_case("cfg4_box")
     if gold:
         e["identical_to_reference_golden"] = [hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() for t in bc3] == gold["bc3_levels"]
     out["cfg4_mipchain_bc3_8192"] = e
-    del big, bufs, bc3
+    # cfg4 end to end, resident: the 8192^2 source up once (256 MiB), GenerateMipMaps (box) and Compress -> BC3 of all 14 levels on the device,
+    # the BC3 chain down once (85 MiB): texconv's mipmaps -> compress steps (texconv.cpp:3434, 3711) without the round trips between them
+    offs = np.concatenate([[0], np.cumsum([t.numel() for t in bc3])]).astype(np.int64)
+    lv_off = np.concatenate([[0], np.cumsum([a * b * 4 for a, b in sizes[1:]])]).astype(np.int64)
+    mips_d = torch.empty(int(lv_off[-1]), dtype=torch.uint8, device=dev)
+
+    def cfg4_run(s_ptr, d_ptr):
+        lv = [dx.capi.device_image(s_ptr, 8192, 8192, RGBA8)] + [dx.capi.device_image(mips_d.data_ptr() + int(lv_off[i]), a, b, RGBA8) for i, (a, b) in enumerate(sizes[1:])]
+        ds = [dx.capi.device_image(d_ptr + int(offs[i]), a, b, dx.DXGI_FORMAT_BC3_UNORM) for i, (a, b) in enumerate(sizes)]
+        ctx.generate_mips_device(lv, dx.TEX_FILTER_BOX)
+        ctx.compress_many_device(lv, ds, 0, 0.5)
+
+    def cfg4_check(p):
+        return [hashlib.sha256(p[int(offs[i]):int(offs[i + 1])].tobytes()).hexdigest() for i in range(len(sizes))] == gold["bc3_levels"]
+
+    out["cfg4_end_to_end"] = resident_end_to_end(ctx, dev, cfg4_run, big_np, int(offs[-1]), check=cfg4_check if gold else None, reps=2)
+    out["cfg4_end_to_end"]["workload"] = ("cfg4: 8192^2 RGBA8 host image -> H2D -> GenerateMipMaps(box, 14 levels) -> Compress(BC3, all levels) -> D2H of the BC3 chain, "
+                                          "one stream-ordered submission")
+    out["cfg4_end_to_end"]["kernels_only_ms"] = round(out["cfg4_mips_box_8192"]["ms"] + out["cfg4_mipchain_bc3_8192"]["ms"], 3)
+    del big, bufs, bc3, mips_d, big_np
     return out
 
 
@@ -258,7 +333,7 @@ def cfg5_shard(ctx, dev, rank, world, per_rank):
     for i in mine:
         load(i)                                           # image synthesis is not part of the measurement
     many = lambda imgs: ctx.compress_many(imgs, side, side, dx.DXGI_FORMAT_R8G8B8A8_UNORM, dx.DXGI_FORMAT_BC7_UNORM, 0, 0.5)
-    sharding.run_shard(1024, world, rank, load, many, batch=128, limit=per_rank)       # untimed: allocates the pinned / device staging and the copy streams
+    sharding.run_shard(1024, world, rank, load, many, batch=128, limit=min(per_rank, 16))       # untimed, two chunks: allocates both lanes' pinned / device staging and the copy streams
     t0 = time.perf_counter()
     res = sharding.run_shard(1024, world, rank, load, many, batch=128, limit=per_rank)
     dt = time.perf_counter() - t0
@@ -348,8 +423,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="run the reference on the whole 4096^2 image (about 3.5 min on 128 threads)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (cfg3 / cfg4 / cfg5 shard / BC1-5 / decode) reported next to the headline")
-    ap.add_argument("--cfg5-images", type=int, default=40, help="images of the cfg5 shard every rank compresses after the timed region (0 = skip); "
-                    "40 = five chunks of dxtex_compress_many's double-buffered pipeline")
+    ap.add_argument("--cfg5-images", type=int, default=128, help="images of the cfg5 shard every rank compresses after the timed region (0 = skip); "
+                    "128 = a rank's whole share of the 1024 images at 8 GPUs, sixteen chunks of dxtex_compress_many's double-buffered pipeline")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several "
                     "ranks share one GPU in the tests)")
     args = ap.parse_args()
@@ -425,7 +500,7 @@ def main():
                     "golden": "tests/golden/cfg5.json: SHA-256 of the reference's payload for each of the 16 distinct images",
                     "workload": f"cfg5 shard: images i = rank (mod {world}) of 1024 x 2048^2 RGBA8 -> BC7, the first {args.cfg5_images} per GPU, host buffers in and "
                                 "out through dxtex_compress_many (PCIe-inclusive), chunks of eight images",
-                    "roofline": hbm_roofline(tex5 * 5.0, dt5 * 1e3)}
+                    "roofline": hbm_roofline(tex5 * 5.0, dt5 * 1e3, time_key="wall_ms")}
             if info5[0].get("ref_seconds_per_image_golden"):
                 cfg5["reference_seconds_per_image_8_threads"] = info5[0]["ref_seconds_per_image_golden"]
         except Exception as e:

@@ -10,15 +10,18 @@ from . import formats as F
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def library_path():
-    """The product library. DXTEX_AMD_LIBRARY=dev (set by the tests and tools that need development knobs, never by bench.py)
-    selects libdxtex_amd_dev.so: the same sources with -DDXTEX_DEV, the only build that reads DXTEX_* environment variables."""
-    name = "libdxtex_amd_dev.so" if os.environ.get("DXTEX_AMD_LIBRARY") == "dev" else "libdxtex_amd.so"
-    return os.path.join(_HERE, "lib", name)
+_loaded = {"path": None, "dev": False}
 
 
-def _load():
-    path = library_path()
+def library_path(dev=None):
+    """Path of the loaded library (dev=None), of the product library (dev=False) or of the development build (dev=True)."""
+    if dev is None:
+        return _loaded["path"]
+    return os.path.join(_HERE, "lib", "libdxtex_amd_dev.so" if dev else "libdxtex_amd.so")
+
+
+def _open(dev):
+    path = library_path(dev)
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -29,7 +32,7 @@ def _load():
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for the C ABI itself
         pass
-    return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL), path
 
 
 class Volume(ctypes.Structure):
@@ -44,7 +47,7 @@ class Image(ctypes.Structure):
                 ("rowPitch", ctypes.c_size_t), ("slicePitch", ctypes.c_size_t), ("pixels", ctypes.c_void_p)]
 
 
-_lib = _load()
+_lib = None
 _P = ctypes.POINTER
 _ctx_p = ctypes.c_void_p
 
@@ -87,11 +90,33 @@ _SIGS = {
     "dxtex_device_free": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p]),
     "dxtex_memcpy_h2d": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "dxtex_memcpy_d2h": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "dxtex_device_memset": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]),
+    "dxtex_copy_rows_device": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t]),
+    "dxtex_memcpy_h2d_async": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "dxtex_memcpy_d2h_async": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "dxtex_host_alloc": (ctypes.c_int32, [_ctx_p, ctypes.c_size_t, _P(ctypes.c_void_p)]),
+    "dxtex_host_free": (ctypes.c_int32, [_ctx_p, ctypes.c_void_p]),
+    "dxtex_alpha_all_opaque_device": (ctypes.c_int32, [_ctx_p, _P(Image), ctypes.c_size_t, _P(ctypes.c_int)]),
+    "dxtex_ctx_transfer_bytes": (ctypes.c_int32, [_ctx_p, _P(ctypes.c_uint64), _P(ctypes.c_uint64), ctypes.c_int]),
 }
-for _name, (_res, _args) in _SIGS.items():
-    _fn = getattr(_lib, _name)     # AttributeError here == the .so does not export what the header declares
-    _fn.restype = _res
-    _fn.argtypes = _args
+def load(dev=False):
+    """Binds this module to the product library (the default, done at import) or - dev=True - to libdxtex_amd_dev.so: the same sources
+    compiled with -DDXTEX_DEV, the only build that reads DXTEX_* development knobs from the environment. The choice is this explicit
+    call, made by the tests and tools that need knobs before they create a Context; no environment variable selects a library, so
+    nothing in a user's shell changes what `import directxtex_amd` runs. Contexts created earlier keep working on the library that
+    created them only as long as they are not used again: call this first."""
+    global _lib
+    lib, path = _open(dev)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)     # AttributeError here == the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    _loaded["path"], _loaded["dev"] = path, bool(dev)
+    return path
+
+
+load(False)
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -188,6 +213,52 @@ class Context:
         self._check(_lib.dxtex_ctx_profile_end(self._h, names, 16384, ms, n, cap, ctypes.byref(cnt)), "profile_end")
         keys = names.value.decode().split("\n")[:cnt.value]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(keys)}
+
+    # -- device-resident pipeline helpers -----------------------------------------------------------
+    def device_alloc(self, nbytes, zero=False):
+        p = ctypes.c_void_p()
+        self._check(_lib.dxtex_device_alloc(self._h, nbytes, ctypes.byref(p)), "device_alloc")
+        if zero:
+            self._check(_lib.dxtex_device_memset(self._h, p, 0, nbytes), "device_memset")
+        return p.value
+
+    def device_free(self, ptr):
+        self._check(_lib.dxtex_device_free(self._h, ptr), "device_free")
+
+    def host_alloc(self, nbytes):
+        """Page-locked host memory as a numpy uint8 array (free with host_free(arr.ctypes.data) after the last use)."""
+        p = ctypes.c_void_p()
+        self._check(_lib.dxtex_host_alloc(self._h, nbytes, ctypes.byref(p)), "host_alloc")
+        return np.ctypeslib.as_array(ctypes.cast(p, _P(ctypes.c_uint8)), shape=(nbytes,))
+
+    def host_free(self, ptr):
+        self._check(_lib.dxtex_host_free(self._h, ptr), "host_free")
+
+    def upload(self, dst_ptr, arr, nbytes=None, sync=False):
+        """Stream-ordered host -> device copy of a C-contiguous numpy buffer (keep it alive until synchronize())."""
+        n = arr.nbytes if nbytes is None else nbytes
+        fn = _lib.dxtex_memcpy_h2d if sync else _lib.dxtex_memcpy_h2d_async
+        self._check(fn(self._h, dst_ptr, arr.ctypes.data, n), "upload")
+
+    def download(self, arr, src_ptr, nbytes=None, sync=False):
+        n = arr.nbytes if nbytes is None else nbytes
+        fn = _lib.dxtex_memcpy_d2h if sync else _lib.dxtex_memcpy_d2h_async
+        self._check(fn(self._h, arr.ctypes.data, src_ptr, n), "download")
+
+    def copy_rows_device(self, dst_ptr, dst_pitch, src_ptr, src_pitch, row_bytes, rows):
+        self._check(_lib.dxtex_copy_rows_device(self._h, dst_ptr, dst_pitch, src_ptr, src_pitch, row_bytes, rows), "copy_rows_device")
+
+    def alpha_all_opaque_device(self, images):
+        arr = (Image * len(images))(*images)
+        out = ctypes.c_int(0)
+        self._check(_lib.dxtex_alpha_all_opaque_device(self._h, arr, len(images), ctypes.byref(out)), "alpha_all_opaque_device")
+        return bool(out.value)
+
+    def transfer_bytes(self, reset=False):
+        """(host -> device bytes, device -> host bytes) this context has moved since creation / the last reset."""
+        up, down = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(_lib.dxtex_ctx_transfer_bytes(self._h, ctypes.byref(up), ctypes.byref(down), 1 if reset else 0), "transfer_bytes")
+        return int(up.value), int(down.value)
 
     # -- Compress -----------------------------------------------------------------------------------
     def prepare(self, width, height, src_format, dst_format, flags=0, count=1):

@@ -707,278 +707,6 @@ struct EncodeArgs
     float threshold;
 };
 
-// ---- BC1 / BC2 / BC3 from RGBA8 without dithering: the colour fit with its Newton iterations POOLED per workgroup -----------------
-// OptimizeRGB's Newton loop (BC.cpp:208-310) runs 0 ... 8 iterations per block - the reference's convergence test, which cannot
-// change - so with a block per lane a wavefront pays 8 iterations for an average of about 3.5 (35 of 64 lanes active over the
-// kernel, profiles/r02_kernels.md), and the 48 quantised floats it keeps live across the loop cost 120 B of scratch per lane.
-// Here the fit is cut in three: (A) a lane per block quantises its texels to the 5:6:5 grid (one packed dword per texel, to
-// LDS), finds the box and the diagonal, and decides whether the block needs the Newton loop at all; (B) per iteration the
-// workgroup builds the list of blocks that are still iterating and lanes 0 ... n-1 take one block each - whole wavefronts drop out
-// as blocks converge; a block's state is 16 dwords of codes + 6 floats in LDS; (C) a lane per block finishes Encode565, the
-// endpoint order and the indices from its texels, still in registers. Same arithmetic, operation for operation.
-constexpr float kLumR = 0.2125f / 0.7154f, kLumB = 0.0721f / 0.7154f;
-
-__device__ __forceinline__ void grid_rgb(uint32_t q, bool uniform, float& r, float& g, float& b)
-{
-    // cr = float(int32(r * 31 + 0.5)) * (1 / 31), then * LumR unless BC_FLAGS_UNIFORM (BC.cpp:418-490)
-    // (the second factor is 1.0f - exact - with BC_FLAGS_UNIFORM: one multiplication instead of a multiply and a select)
-    const float lr = uniform ? 1.0f : kLumR, lb = uniform ? 1.0f : kLumB;
-    r = float(q & 0xFFu) * (1.0f / 31.0f) * lr; g = float((q >> 8) & 0xFFu) * (1.0f / 63.0f); b = float((q >> 16) & 0xFFu) * (1.0f / 31.0f) * lb;
-}
-
-// OptimizeRGB up to the Newton loop (BC.cpp:85-206). Returns true when the loop has to run.
-template<class Q>
-__device__ __forceinline__ bool rgb_fit_begin(const Q& q, bool uniform, float& Xr, float& Xg, float& Xb, float& Yr, float& Yg, float& Yb)
-{
-    Xr = uniform ? 1.0f : kLumR; Xg = 1.0f; Xb = uniform ? 1.0f : kLumB;
-    Yr = 0.0f; Yg = 0.0f; Yb = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-    {
-        float r, g, b; grid_rgb(q(i), uniform, r, g, b);
-        if (r < Xr) Xr = r;
-        if (g < Xg) Xg = g;
-        if (b < Xb) Xb = b;
-        if (r > Yr) Yr = r;
-        if (g > Yg) Yg = g;
-        if (b > Yb) Yb = b;
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    const float ABr = Yr - Xr, ABg = Yg - Xg, ABb = Yb - Xb;
-    const float fAB = ABr * ABr + ABg * ABg + ABb * ABb;
-    if (fAB < 1.175494351e-38f) return false;            // single colour
-    const float fABInv = 1.0f / fAB;
-    const float Dr = ABr * fABInv, Dg = ABg * fABInv, Db = ABb * fABInv;
-    const float Mr = (Xr + Yr) * 0.5f, Mg = (Xg + Yg) * 0.5f, Mb = (Xb + Yb) * 0.5f;
-    float fDir0 = 0.0f, fDir1 = 0.0f, fDir2 = 0.0f, fDir3 = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-    {
-        float r, g, b; grid_rgb(q(i), uniform, r, g, b);
-        const float Pr = (r - Mr) * Dr;
-        const float Pg = (g - Mg) * Dg;
-        const float Pb = (b - Mb) * Db;
-        float f;
-        f = Pr + Pg + Pb; fDir0 += f * f;
-        f = Pr + Pg - Pb; fDir1 += f * f;
-        f = Pr - Pg + Pb; fDir2 += f * f;
-        f = Pr - Pg - Pb; fDir3 += f * f;
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    float fDirMax = fDir0; uint32_t iDirMax = 0;
-    if (fDir1 > fDirMax) { fDirMax = fDir1; iDirMax = 1; }
-    if (fDir2 > fDirMax) { fDirMax = fDir2; iDirMax = 2; }
-    if (fDir3 > fDirMax) { fDirMax = fDir3; iDirMax = 3; }
-    if (iDirMax & 2) { const float f = Xg; Xg = Yg; Yg = f; }
-    if (iDirMax & 1) { const float f = Xb; Xb = Yb; Yb = f; }
-    return !(fAB < 1.0f / 4096.0f);                       // two-colour block: no loop
-}
-
-// One trip of the Newton loop (BC.cpp:208-310): false = the loop goes on, true = it ends here (either of its two breaks).
-template<class Q>
-__device__ __forceinline__ bool rgb_fit_step(const Q& q, uint32_t cSteps, bool uniform, float& Xr, float& Xg, float& Xb, float& Yr, float& Yg, float& Yb)
-{
-    constexpr float fEpsilon = (0.25f / 64.0f) * (0.25f / 64.0f);
-    const float fSteps = float(cSteps - 1);
-    const StepCoef coef(cSteps);
-    float Dr = Yr - Xr, Dg = Yg - Xg, Db = Yb - Xb;
-    const float fLen = Dr * Dr + Dg * Dg + Db * Db;
-    if (fLen < (1.0f / 4096.0f)) return true;
-    const float fScale = fSteps / fLen;
-    Dr *= fScale; Dg *= fScale; Db *= fScale;
-    float d2X = 0.0f, d2Y = 0.0f;
-    float dXr = 0.0f, dXg = 0.0f, dXb = 0.0f, dYr = 0.0f, dYg = 0.0f, dYb = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-    {
-        float pr, pg, pb; grid_rgb(q(i), uniform, pr, pg, pb);
-        const float fDot = (pr - Xr) * Dr + (pg - Xg) * Dg + (pb - Xb) * Db;
-        const float kStep = float(uint32_t(fminf(fmaxf(fDot, 0.0f), fSteps) + 0.5f));       // see optimize_rgb16
-        const float c = coef.c(kStep), d = coef.d(kStep);
-        const float diffR = (Xr * c + Yr * d) - pr;
-        const float diffG = (Xg * c + Yg * d) - pg;
-        const float diffB = (Xb * c + Yb * d) - pb;
-        const float fC = c * (1.0f / 8.0f);
-        const float fD = d * (1.0f / 8.0f);
-        d2X += fC * c;
-        dXr += fC * diffR; dXg += fC * diffG; dXb += fC * diffB;
-        d2Y += fD * d;
-        dYr += fD * diffR; dYg += fD * diffG; dYb += fD * diffB;
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four texels at a time: bounds the live temporaries
-    }
-    if (d2X > 0.0f)
-    {
-        const float f = -1.0f / d2X;
-        Xr += dXr * f; Xg += dXg * f; Xb += dXb * f;
-    }
-    if (d2Y > 0.0f)
-    {
-        const float f = -1.0f / d2Y;
-        Yr += dYr * f; Yg += dYg * f; Yb += dYb * f;
-    }
-    return (dXr * dXr < fEpsilon) && (dXg * dXg < fEpsilon) && (dXb * dXb < fEpsilon) &&
-           (dYr * dYr < fEpsilon) && (dYg * dYg < fEpsilon) && (dYb * dYb < fEpsilon);
-}
-
-// EncodeBC1 after OptimizeRGB (BC.cpp:492-685), no dithering: Encode565, endpoint order, indices from the unquantised texels.
-template<class TS>
-__device__ __forceinline__ uint2 bc1_color_finish(const TS& s, uint32_t uSteps, bool uniform, float threshold,
-                                                  float Ar, float Ag, float Ab, float Br, float Bg, float Bb)
-{
-    constexpr float LumR = kLumR, LumB = kLumB;
-    constexpr float LumInvR = 0.7154f / 0.2125f, LumInvB = 0.7154f / 0.0721f;
-    float Cr, Cg, Cb, Dr, Dg, Db;
-    if (uniform) { Cr = Ar; Cg = Ag; Cb = Ab; Dr = Br; Dg = Bg; Db = Bb; }
-    else
-    {
-        Cr = Ar * LumInvR; Cg = Ag * 1.0f; Cb = Ab * LumInvB;
-        Dr = Br * LumInvR; Dg = Bg * 1.0f; Db = Bb * LumInvB;
-    }
-    const uint32_t wA = encode565(Cr, Cg, Cb);
-    const uint32_t wB = encode565(Dr, Dg, Db);
-    if ((uSteps == 4) && (wA == wB))
-        return make_uint2(wA | (wB << 16), 0u);
-    decode565(wA, Cr, Cg, Cb);
-    decode565(wB, Dr, Dg, Db);
-    if (uniform) { Ar = Cr; Ag = Cg; Ab = Cb; Br = Dr; Bg = Dg; Bb = Db; }
-    else
-    {
-        Ar = Cr * LumR; Ag = Cg * 1.0f; Ab = Cb * LumB;
-        Br = Dr * LumR; Bg = Dg * 1.0f; Bb = Db * LumB;
-    }
-    float S0r, S0g, S0b, S1r, S1g, S1b;
-    uint32_t rgb0, rgb1;
-    if ((3 == uSteps) == (wA <= wB))
-    {
-        rgb0 = wA; rgb1 = wB;
-        S0r = Ar; S0g = Ag; S0b = Ab; S1r = Br; S1g = Bg; S1b = Bb;
-    }
-    else
-    {
-        rgb0 = wB; rgb1 = wA;
-        S0r = Br; S0g = Bg; S0b = Bb; S1r = Ar; S1g = Ag; S1b = Ab;
-    }
-    float dirR = S1r - S0r, dirG = S1g - S0g, dirB = S1b - S0b;
-    const float fSteps = float(uSteps - 1);
-    const float fScale = (wA != wB) ? (fSteps / (dirR * dirR + dirG * dirG + dirB * dirB)) : 0.0f;
-    dirR *= fScale; dirG *= fScale; dirB *= fScale;
-    uint32_t dw = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-    {
-        if ((3 == uSteps) && (s.a(i) < threshold))
-            dw = (3u << 30) | (dw >> 2);
-        else
-        {
-            float r, g, b;
-            if (uniform) { r = s.r(i); g = s.g(i); b = s.b(i); }
-            else { r = s.r(i) * LumR; g = s.g(i) * 1.0f; b = s.b(i) * LumB; }
-            const float fDot = (r - S0r) * dirR + (g - S0g) * dirG + (b - S0b) * dirB;
-            const uint32_t k = uint32_t(fminf(fmaxf(fDot, 0.0f), fSteps) + 0.5f);          // see encode_bc1_color
-            const uint32_t iStep = (k == 0) ? 0u : (k == uSteps - 1) ? 1u : (k + 1);
-            dw = (iStep << 30) | (dw >> 2);
-        }
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    return make_uint2(rgb0 | (rgb1 << 16), dw);
-}
-
-constexpr int kPoolLanes = 256;
-
-template<int KIND>
-__global__ void __launch_bounds__(kPoolLanes) bc13_pooled_kernel(EncodeArgs a)
-{
-    __shared__ uint32_t sQ[16][kPoolLanes];        // 5:6:5 grid codes of every block's texels
-    __shared__ float sXY[6][kPoolLanes];           // the fit's end points X, Y
-    __shared__ uint32_t sList[kPoolLanes];         // blocks (lane numbers) still in the Newton loop
-    __shared__ uint32_t sDone[kPoolLanes];
-    __shared__ uint32_t sCount[kPoolLanes / 64];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6;
-    const uint32_t nb = blockIdx.x * uint32_t(kPoolLanes) + tid;
-    const bool valid = nb < a.nbw * a.nbh;
-    const uint32_t by = valid ? nb / a.nbw : 0u, bx = valid ? nb - by * a.nbw : 0u;
-    const bool uniform = (a.flags & BCF_UNIFORM) != 0;
-
-    // ---- (A) a lane per block
-    PackedTile t;
-#pragma unroll
-    for (uint32_t y = 0; y < 4; ++y)
-    {
-        const uint4 v = *reinterpret_cast<const uint4*>(a.src.pixels + uint64_t(by * 4 + y) * a.src.rowPitch + uint64_t(bx) * 16);
-        t.px[y * 4 + 0] = v.x; t.px[y * 4 + 1] = v.y; t.px[y * 4 + 2] = v.z; t.px[y * 4 + 3] = v.w;
-    }
-    uint2 al = make_uint2(0u, 0u);
-    if constexpr (KIND == 2 || KIND == 3)
-    {
-        float pa[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) pa[i] = t.a(i);
-        al = (KIND == 2) ? encode_bc2_alpha(pa, a.flags) : encode_bc3_alpha(pa, a.flags);
-    }
-    uint32_t uSteps = 4;
-    bool allKeyed = false;
-    if constexpr (KIND == 1)
-    {
-        uint32_t uColorKey = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (t.a(i) < a.threshold) uColorKey++;
-        allKeyed = (uColorKey == 16);
-        uSteps = (uColorKey > 0) ? 3u : 4u;
-    }
-    uint32_t q[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-    {
-        const uint32_t qr = uint32_t(int32_t(t.r(i) * 31.0f + 0.5f)), qg = uint32_t(int32_t(t.g(i) * 63.0f + 0.5f)), qb = uint32_t(int32_t(t.b(i) * 31.0f + 0.5f));
-        q[i] = qr | (qg << 8) | (qb << 16);
-        sQ[i][tid] = q[i];
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    float Xr, Xg, Xb, Yr, Yg, Yb;
-    // (the asm keeps the two passes of rgb_fit_begin from sharing 48 decoded floats: decoding twice is cheaper than the registers)
-    bool iterating = rgb_fit_begin([&](int i) { uint32_t v = q[i]; asm volatile("" : "+v"(v)); return v; }, uniform, Xr, Xg, Xb, Yr, Yg, Yb) && valid && !allKeyed;
-    sXY[0][tid] = Xr; sXY[1][tid] = Xg; sXY[2][tid] = Xb; sXY[3][tid] = Yr; sXY[4][tid] = Yg; sXY[5][tid] = Yb;
-    sDone[tid] = iterating ? uSteps : 0u;           // non-zero while the block iterates (the step count, for the lane that takes it); 0 = done
-    t.launder();
-
-    // ---- (B) the Newton loop, pooled: per trip the blocks still iterating are listed and dealt to lanes 0 ... n-1
-#pragma unroll 1
-    for (int iter = 0; iter < 8; ++iter)
-    {
-        const unsigned long long m = __ballot(iterating);
-        if ((tid & 63u) == 0) sCount[wave] = uint32_t(__popcll(m));
-        __syncthreads();
-        uint32_t first = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < uint32_t(kPoolLanes / 64); ++w) { const uint32_t c = sCount[w]; first += (w < wave) ? c : 0u; total += c; }
-        if (total == 0) break;
-        if (iterating) sList[first + uint32_t(__popcll(m & ((1ull << (tid & 63u)) - 1ull)))] = tid;
-        __syncthreads();
-        if (tid < total)
-        {
-            const uint32_t blk = sList[tid];
-            float xr = sXY[0][blk], xg = sXY[1][blk], xb = sXY[2][blk], yr = sXY[3][blk], yg = sXY[4][blk], yb = sXY[5][blk];
-            // the owner's colour-key count decides the step count (BC1 only): 3 steps iff some texel is keyed; the owner published it in sDone
-            const uint32_t steps = (KIND == 1) ? sDone[blk] : 4u;
-            const bool done = rgb_fit_step([&](int i) { return sQ[i][blk]; }, steps, uniform, xr, xg, xb, yr, yg, yb);
-            sXY[0][blk] = xr; sXY[1][blk] = xg; sXY[2][blk] = xb; sXY[3][blk] = yr; sXY[4][blk] = yg; sXY[5][blk] = yb;
-            if (done) sDone[blk] = 0u;
-        }
-        __syncthreads();
-        if (iterating && sDone[tid] == 0u) iterating = false;
-    }
-    __syncthreads();
-
-    // ---- (C) a lane per block again
-    if (!valid) return;
-    uint8_t* out = a.dst + uint64_t(by) * a.dstRowPitch;
-    uint2 c;
-    if (allKeyed) c = make_uint2(0xffff0000u, 0xffffffffu);
-    else c = bc1_color_finish(t, uSteps, uniform, a.threshold, sXY[0][tid], sXY[1][tid], sXY[2][tid], sXY[3][tid], sXY[4][tid], sXY[5][tid]);
-    if constexpr (KIND == 1) reinterpret_cast<uint2*>(out)[bx] = c;
-    else reinterpret_cast<uint4*>(out)[bx] = make_uint4(al.x, al.y, c.x, c.y);
-}
 
 
 // KIND: 1..3 = BC1..BC3, 4/5 = BC4/BC5 unsigned, 6/7 = BC4/BC5 signed. One instantiation per format keeps
@@ -1142,22 +870,6 @@ hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowP
 #define DXTEX_LAUNCH(KIND, PACKOK) do { const bool pk_ = packed && (PACKOK); \
                                          if (dither) { if (pk_) DXTEX_LAUNCH2(KIND, true, true); else DXTEX_LAUNCH2(KIND, true, false); } \
                                          else { if (pk_) DXTEX_LAUNCH2(KIND, false, true); else DXTEX_LAUNCH2(KIND, false, false); } } while (0)
-    // RGBA8 -> BC1 / BC2 / BC3 without dithering through the kernel with the pooled Newton loop: measured on MI355X it is no faster
-    // than the block-per-lane kernel (4096^2: BC1 145 vs 150 us, BC3 152 vs 150, BC2 175 vs 146 - the loop runs close to its eight
-    // trips on most blocks of the benchmark image, so pooling saves little and pays LDS traffic, barriers and the per-use decoding
-    // of the 5:6:5 codes). Kept for A/B runs in the development build (DXTEX_BC13_POOLED=1); the bytes are the same.
-    static const bool pooledOn = dev_env("DXTEX_BC13_POOLED") && dev_env("DXTEX_BC13_POOLED")[0] == '1';
-    if (packed && pooledOn && !(flags & (BCF_DITHER_RGB | BCF_DITHER_A)))
-    {
-        const dim3 pgrid(uint32_t((nblocks + kPoolLanes - 1) / kPoolLanes)), pblock(kPoolLanes);
-        switch (dstFormat)
-        {
-        case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: hipLaunchKernelGGL(bc13_pooled_kernel<1>, pgrid, pblock, 0, stream, a); return hipGetLastError();
-        case FMT_BC2_UNORM: case FMT_BC2_UNORM_SRGB: hipLaunchKernelGGL(bc13_pooled_kernel<2>, pgrid, pblock, 0, stream, a); return hipGetLastError();
-        case FMT_BC3_UNORM: case FMT_BC3_UNORM_SRGB: hipLaunchKernelGGL(bc13_pooled_kernel<3>, pgrid, pblock, 0, stream, a); return hipGetLastError();
-        default: break;
-        }
-    }
     switch (dstFormat)
     {
     case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: DXTEX_LAUNCH(1, (flags & BCF_DITHER_A) == 0); break;

@@ -59,6 +59,8 @@ struct Bc7Args
     uint32_t early6Min;      // an early phase (mode 6; modes 4 / 5) only exists when at least this many blocks would be in it
     int early6Pct;           // rough kernel: mode 6 goes first where 100 * lower bound <= early6Pct * best 3-bit rough error
     int phase;               // which blocks this launch of a mode owns: PHASE_ALL, or the early / late half of a split mode
+    const uint32_t* gate;    // a mode (or the early phase of a split mode) that owns no block of the pass - mode 7 on an opaque image, the early phases
+    uint32_t gateMin;        // when too few blocks are flagged - is skipped on the device: its kernels return at once when *gate < gateMin (nullptr: always run)
     uint32_t perturbWaveMax; // whole-block modes: lists of at most this many live tasks are searched by bc7_perturb_wave_kernel (0 = never)
     uint32_t exhWaveMax;     // ... and by bc7_exhaustive_wave_kernel
 };
@@ -387,6 +389,7 @@ __global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nbFirst = (blockIdx.x * 4 + wave) * BPW;
     if (nbFirst >= a.nblocks) return;
+    if (a.gate && *a.gate < a.gateMin) return;          // this launch owns no block: no task list at all (the bin kernels stand down with it)
     const uint32_t blk = uint32_t(lane) / TM::TPB, r = uint32_t(lane) % TM::TPB;
     const uint32_t nb = nbFirst + blk;
     uint32_t shape, mask, anchor, rot;
@@ -1106,6 +1109,9 @@ __global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t nbFirst = (blockIdx.x * 4 + wave) * BPW;
     if (nbFirst >= a.nblocks) return;
+    // a gated launch that owns no block: an early phase leaves every candidate slot to its late phase; mode 7 leaves its slots unwritten
+    // and bc7_pick_kernel skips them on the same condition
+    if (a.gate && *a.gate < a.gateMin) return;
     const uint32_t blk = uint32_t(lane) / TM::TPB, r = uint32_t(lane) % TM::TPB;
     const uint32_t nb = nbFirst + blk;
     const uint32_t rank = r / TM::G, region = r % TM::G;
@@ -1243,6 +1249,7 @@ __global__ void __launch_bounds__(256) bc7_pick_kernel(Bc7Args a, uint32_t slotM
     for (int s = 0; s < NUM_SLOTS; ++s)
     {
         if (!((slotMask >> s) & 1u)) continue;
+        if (s == SLOT_M7 && a.flagged[1] == 0) continue;       // no block has alpha: mode 7's (gated) launch wrote nothing
         const Cand v = c[s];
         if (v.err == 0xFFFFFFFFu) continue;
         const uint64_t key = (uint64_t(v.err) << 32) | v.ord;
@@ -1311,6 +1318,14 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
     const bool maybeShortE = kWhole && !noGroup && (MODE == 6 || ntasks <= 4u * kExhMax);
     const uint32_t wavesP = std::min<uint32_t>(kSearchWaves, (ntasks + 1) / 2), wavesE = std::min<uint32_t>(kSearchWaves, ntasks);
     Bc7Args a = a0;
+    // device-side skip of launches that own no block (flagged[] is written by bc7_flag_count_kernel; BC7_QUICK has neither flags nor phases)
+    a.gate = nullptr; a.gateMin = 0;
+    if (a0.flagged && !(a0.flags & BCF_BC7_QUICK))
+    {
+        if (MODE == 7) { a.gate = a0.flagged + 1; a.gateMin = 1; }                                               // blocks with alpha (phase_owns / task_geometry: lst[32])
+        else if (a0.phase == PHASE_EARLY && (MODE == 4 || MODE == 5)) { a.gate = a0.flagged + 1; a.gateMin = std::max<uint32_t>(1u, a0.early6Min); }
+        else if (a0.phase == PHASE_EARLY && MODE == 6) { a.gate = a0.flagged; a.gateMin = std::max<uint32_t>(1u, a0.early6Min); }
+    }
     a.perturbWaveMax = maybeShortP ? kPerturbWaveMax : 0u;
     a.exhWaveMax = maybeShortE ? kExhMax : 0u;
     if (marks) marks->mark(names[0]);
@@ -1318,9 +1333,9 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
     if (marks) marks->mark(names[1]);
     (void)hipMemsetAsync(a.counters, 0, 64 * sizeof(uint32_t), stream);
     const uint32_t binGroups = std::min<uint32_t>(kBinGroups, (ntasks + 255) / 256);
-    hipLaunchKernelGGL(bc7_bin_count_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters);
+    hipLaunchKernelGGL(bc7_bin_count_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.gate, a.gateMin);
     hipLaunchKernelGGL(bc7_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a.counters);
-    hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order);
+    hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order, a.gate, a.gateMin);
     if (marks) marks->mark(names[2]);
     const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
     static const int tailBelow = dev_env("DXTEX_BC7_TAIL_BELOW") ? atoi(dev_env("DXTEX_BC7_TAIL_BELOW")) : 48;
@@ -1413,6 +1428,7 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         a.nblocks = pass.nblocks;
         a.flags = flags;
         a.perturbWaveMax = 0; a.exhWaveMax = 0;       // set per mode by launch_mode
+        a.gate = nullptr; a.gateMin = 0;
         a.lists = base + L.lists;
         a.cands = reinterpret_cast<Cand*>(base + L.cands);
         a.px = reinterpret_cast<uint32_t*>(base + L.px);

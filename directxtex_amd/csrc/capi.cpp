@@ -68,6 +68,8 @@ struct dxtex_ctx
     std::string lastError;
     bool profiling = false;
     Marks marks;
+    // host <-> device bytes moved for this context (dxtex_ctx_transfer_bytes)
+    uint64_t h2dBytes = 0, d2hBytes = 0;
 };
 
 void Marks::mark(const char* kernelName)
@@ -92,6 +94,14 @@ dxtex_hresult fail(dxtex_ctx* ctx, dxtex_hresult hr, const char* what, hipError_
         if (e != hipSuccess) { ctx->lastError += ": "; ctx->lastError += hipGetErrorString(e); }
     }
     return hr;
+}
+
+// every host <-> device copy of the library goes through here so that dxtex_ctx_transfer_bytes can account for it
+inline hipError_t counted_copy(dxtex_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t stream)
+{
+    if (kind == hipMemcpyHostToDevice) ctx->h2dBytes += bytes;
+    else if (kind == hipMemcpyDeviceToHost) ctx->d2hBytes += bytes;
+    return hipMemcpyAsync(dst, src, bytes, kind, stream);
 }
 
 #define HIP_TRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(ctx, (e_ == hipErrorOutOfMemory) ? DXTEX_E_OUTOFMEMORY : DXTEX_E_FAIL, #expr, e_); } while (0)
@@ -325,11 +335,18 @@ dxtex_hresult dxtex_ctx_set_stream(dxtex_ctx* ctx, void* hip_stream)
     if (next != ctx->stream)
     {
         // the context's scratch, staging and filter tables are ordered by ONE stream: work queued on the old one must be done
-        // before kernels on the new one may reuse them. The previous stream must stay alive until this call returns; if the caller
-        // has destroyed it already (invalid handle) there is nothing left to wait for - the context switches either way.
+        // before kernels on the new one may reuse them. The previous stream must stay alive until this call returns. A handle the
+        // runtime no longer knows (the caller destroyed the stream: nothing left to wait for) is tolerated and the context switches;
+        // any other error is an asynchronous failure of work that was queued on the old stream - a faulted kernel, an ECC error -
+        // whose output the caller must not trust: it is reported and the context keeps its stream.
         ScopedDevice sd(ctx->device);
         const hipError_t drained = hipStreamSynchronize(ctx->stream);
-        if (drained != hipSuccess) (void)hipGetLastError();
+        if (drained != hipSuccess)
+        {
+            (void)hipGetLastError();
+            if (drained != hipErrorInvalidHandle && drained != hipErrorInvalidResourceHandle && drained != hipErrorContextIsDestroyed)
+                return fail(ctx, DXTEX_E_FAIL, "work queued on the previous stream failed", drained);
+        }
         ctx->stream = next;
     }
     return DXTEX_S_OK;
@@ -685,14 +702,14 @@ dxtex_hresult compress_many_pipelined(dxtex_ctx* ctx, const dxtex_image* srcs, c
             atIn += (inBytes[i] + 255) & ~size_t(255);
             atOut += (outBytes[i] + 255) & ~size_t(255);
         }
-        HIP_TRY(ctx, hipMemcpyAsync(l.devIn, l.pinIn, atIn, hipMemcpyHostToDevice, ctx->h2d));
+        HIP_TRY(ctx, counted_copy(ctx, l.devIn, l.pinIn, atIn, hipMemcpyHostToDevice, ctx->h2d));
         HIP_TRY(ctx, hipEventRecord(l.uploaded, ctx->h2d));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, l.uploaded, 0));
         hr = dxtex_compress_many_device(ctx, ds.data(), dd.data(), ch.count, flags, threshold);
         if (hr != DXTEX_S_OK) return hr;
         HIP_TRY(ctx, hipEventRecord(l.computed, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->d2h, l.computed, 0));
-        HIP_TRY(ctx, hipMemcpyAsync(l.pinOut, l.devOut, atOut, hipMemcpyDeviceToHost, ctx->d2h));
+        HIP_TRY(ctx, counted_copy(ctx, l.pinOut, l.devOut, atOut, hipMemcpyDeviceToHost, ctx->d2h));
         HIP_TRY(ctx, hipEventRecord(l.downloaded, ctx->d2h));
         // (no wait of h2d on `computed`: the next upload into this lane's devIn belongs to chunk c + 2, and iteration c + 2 begins with
         // scatter(c), a host wait for downloaded(c), which is stream-ordered after computed(c). The upload of chunk c + 1 - the other
@@ -718,13 +735,13 @@ dxtex_hresult dxtex_compress(dxtex_ctx* ctx, const dxtex_image* src, const dxtex
     hr = check_host_pitches(ctx, src, dst, &srcBytes, &dstBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
     time_begin(ctx);
     hr = submit_compress(ctx, static_cast<const uint8_t*>(ctx->stageIn), src->width, src->height, src->format, src->rowPitch,
                          static_cast<uint8_t*>(ctx->stageOut), dst->format, dst->rowPitch, flags, threshold);
     time_end(ctx);
     if (hr != DXTEX_S_OK) return hr;
-    HIP_TRY(ctx, hipMemcpyAsync(dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -742,7 +759,7 @@ dxtex_hresult dxtex_encode_blocks(dxtex_ctx* ctx, int32_t bc_format, uint32_t bc
     const size_t srcBytes = nblocks * 256, dstBytes = nblocks * bb;
     dxtex_hresult hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, rgba, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, ctx->stageIn, rgba, srcBytes, hipMemcpyHostToDevice, ctx->stream));
 
     SrcView v;
     v.pixels = static_cast<const uint8_t*>(ctx->stageIn); v.width = 4; v.height = uint32_t(nblocks * 4);
@@ -773,7 +790,7 @@ dxtex_hresult dxtex_encode_blocks(dxtex_ctx* ctx, int32_t bc_format, uint32_t bc
     }
     time_end(ctx);
     if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
-    HIP_TRY(ctx, hipMemcpyAsync(bc, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, bc, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -815,13 +832,13 @@ dxtex_hresult dxtex_decompress(dxtex_ctx* ctx, const dxtex_image* src, const dxt
     else { srcBytes = src->rowPitch * std::max<size_t>(1, (src->height + 3) / 4); dstBytes = dst->rowPitch * dst->height; }      // submit_decompress rejects the formats below
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
     time_begin(ctx);
     hr = submit_decompress(ctx, static_cast<const uint8_t*>(ctx->stageIn), src->format, src->rowPitch,
                            static_cast<uint8_t*>(ctx->stageOut), dst->format, dst->rowPitch, src->width, src->height);
     time_end(ctx);
     if (hr != DXTEX_S_OK) return hr;
-    HIP_TRY(ctx, hipMemcpyAsync(dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -838,14 +855,14 @@ dxtex_hresult dxtex_decode_blocks(dxtex_ctx* ctx, int32_t bc_format, const uint8
     const size_t srcBytes = nblocks * bb, dstBytes = nblocks * 256;
     dxtex_hresult hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, bc, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, ctx->stageIn, bc, srcBytes, hipMemcpyHostToDevice, ctx->stream));
     ConvertPlan plan; plan.srgbIn = 0; plan.tcv = TCV_NONE; plan.tsw = TSW_NONE; plan.srgbOut = 0; plan.depth = 0;
     time_begin(ctx);
     hipError_t e = launch_bc_decode(static_cast<const uint8_t*>(ctx->stageIn), bb, bc_format, static_cast<uint8_t*>(ctx->stageOut), 64,
                                     FMT_R32G32B32A32_FLOAT, 4, uint32_t(nblocks * 4), plan, ctx->stream);
     time_end(ctx);
     if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
-    HIP_TRY(ctx, hipMemcpyAsync(rgba, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, rgba, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -873,7 +890,7 @@ dxtex_hresult upload_tables(dxtex_ctx* ctx, const std::vector<uint8_t>& host)
     }
     if (!ctx->triConsumed) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->triConsumed, hipEventDisableTiming));
     std::memcpy(ctx->triPinned, host.data(), host.size());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->triBuf, ctx->triPinned, host.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, ctx->triBuf, ctx->triPinned, host.size(), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->triConsumed, ctx->stream));
     ctx->triPending = true;
     return DXTEX_S_OK;
@@ -1019,7 +1036,7 @@ dxtex_hresult dxtex_generate_mips(dxtex_ctx* ctx, const dxtex_image* levels, siz
     for (size_t i = 0; i < nlevels; ++i) { at[i] = total; total += (levels[i].rowPitch * levels[i].height + 255) & ~size_t(255); }
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, total); if (hr != DXTEX_S_OK) return hr;
     uint8_t* d = static_cast<uint8_t*>(ctx->stageIn);
-    HIP_TRY(ctx, hipMemcpyAsync(d, levels[0].pixels, levels[0].rowPitch * levels[0].height, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, d, levels[0].pixels, levels[0].rowPitch * levels[0].height, hipMemcpyHostToDevice, ctx->stream));
     std::vector<LevelPair> pairs;
     for (size_t i = 1; i < nlevels; ++i)
         pairs.push_back({ d + at[i - 1], levels[i - 1].rowPitch, levels[i - 1].width, levels[i - 1].height,
@@ -1029,7 +1046,7 @@ dxtex_hresult dxtex_generate_mips(dxtex_ctx* ctx, const dxtex_image* levels, siz
     time_end(ctx);
     if (hr != DXTEX_S_OK) return hr;
     for (size_t i = 1; i < nlevels; ++i)
-        HIP_TRY(ctx, hipMemcpyAsync(levels[i].pixels, d + at[i], levels[i].rowPitch * levels[i].height, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, counted_copy(ctx, levels[i].pixels, d + at[i], levels[i].rowPitch * levels[i].height, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -1154,7 +1171,7 @@ dxtex_hresult dxtex_generate_mips3d(dxtex_ctx* ctx, const dxtex_volume* levels, 
     for (size_t i = 0; i < nlevels; ++i) { at[i] = total; total += (levels[i].slicePitch * levels[i].depth + 255) & ~size_t(255); }
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, total); if (hr != DXTEX_S_OK) return hr;
     uint8_t* d = static_cast<uint8_t*>(ctx->stageIn);
-    HIP_TRY(ctx, hipMemcpyAsync(d, levels[0].pixels, levels[0].slicePitch * levels[0].depth, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, d, levels[0].pixels, levels[0].slicePitch * levels[0].depth, hipMemcpyHostToDevice, ctx->stream));
     std::vector<VolumeView> lv(nlevels);
     for (size_t i = 0; i < nlevels; ++i) lv[i] = view_of(levels[i], d + at[i]);
     time_begin(ctx);
@@ -1162,7 +1179,7 @@ dxtex_hresult dxtex_generate_mips3d(dxtex_ctx* ctx, const dxtex_volume* levels, 
     time_end(ctx);
     if (hr != DXTEX_S_OK) return hr;
     for (size_t i = 1; i < nlevels; ++i)
-        HIP_TRY(ctx, hipMemcpyAsync(levels[i].pixels, d + at[i], levels[i].slicePitch * levels[i].depth, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, counted_copy(ctx, levels[i].pixels, d + at[i], levels[i].slicePitch * levels[i].depth, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -1216,14 +1233,14 @@ dxtex_hresult dxtex_resize(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_i
     hr = check_host_pitches(ctx, src, dst, &srcBytes, &dstBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
     std::vector<LevelPair> pairs{ { static_cast<const uint8_t*>(ctx->stageIn), src->rowPitch, src->width, src->height,
                                     static_cast<uint8_t*>(ctx->stageOut), dst->rowPitch, dst->width, dst->height } };
     time_begin(ctx);
     hr = submit_resizes(ctx, pairs, src->format, mode, filter, false);
     time_end(ctx);
     if (hr != DXTEX_S_OK) return hr;
-    HIP_TRY(ctx, hipMemcpyAsync(dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -1287,13 +1304,13 @@ dxtex_hresult dxtex_convert(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_
     hr = check_host_pitches(ctx, src, dst, &srcBytes, &dstBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
     time_begin(ctx);
     hr = submit_convert(ctx, static_cast<const uint8_t*>(ctx->stageIn), src->rowPitch, src->format, static_cast<uint8_t*>(ctx->stageOut),
                         dst->rowPitch, dst->format, src->width, src->height, plan, threshold);
     time_end(ctx);
     if (hr != DXTEX_S_OK) return hr;
-    HIP_TRY(ctx, hipMemcpyAsync(dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -1321,7 +1338,7 @@ dxtex_hresult alpha_coverage(dxtex_ctx* ctx, const uint8_t* d, const dxtex_image
                                          static_cast<unsigned long long*>(ctx->mseBuf), ctx->stream);
     if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
     unsigned long long n = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n, ctx->mseBuf, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, &n, ctx->mseBuf, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const float cscale = static_cast<float>((im.width - 1) * (im.height - 1) * 8 * 8);      // :299-303
     *coverage = (cscale > 0.f) ? static_cast<float>(size_t(n)) / cscale : 0.0f;
@@ -1397,13 +1414,13 @@ dxtex_hresult dxtex_premultiply_alpha(dxtex_ctx* ctx, const dxtex_image* src, co
     hr = check_host_pitches(ctx, src, dst, &srcBytes, &dstBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, srcBytes); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, dstBytes); if (hr != DXTEX_S_OK) return hr;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, ctx->stageIn, src->pixels, srcBytes, hipMemcpyHostToDevice, ctx->stream));
     time_begin(ctx);
     hipError_t e = launch_pmalpha(static_cast<const uint8_t*>(ctx->stageIn), src->rowPitch, static_cast<uint8_t*>(ctx->stageOut), dst->rowPitch, src->format,
                                   uint32_t(src->width), uint32_t(src->height), flags, ctx->stream);
     time_end(ctx);
     if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
-    HIP_TRY(ctx, hipMemcpyAsync(dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, dst->pixels, ctx->stageOut, dstBytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -1436,13 +1453,13 @@ dxtex_hresult dxtex_scale_mips_alpha_for_coverage(dxtex_ctx* ctx, const dxtex_im
     for (size_t i = 0; i < nlevels; ++i)
     {
         s[i] = static_cast<const uint8_t*>(ctx->stageIn) + atS[i]; d[i] = static_cast<uint8_t*>(ctx->stageOut) + atD[i];
-        HIP_TRY(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->stageIn) + atS[i], src[i].pixels, src[i].rowPitch * src[i].height, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, counted_copy(ctx, static_cast<uint8_t*>(ctx->stageIn) + atS[i], src[i].pixels, src[i].rowPitch * src[i].height, hipMemcpyHostToDevice, ctx->stream));
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->stageOut, 0, totalD, ctx->stream));
     hr = submit_coverage_chain(ctx, s, d, src, dst, nlevels, alphaReference);
     if (hr != DXTEX_S_OK) return hr;
     for (size_t i = 0; i < nlevels; ++i)
-        HIP_TRY(ctx, hipMemcpyAsync(dst[i].pixels, d[i], dst[i].rowPitch * dst[i].height, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, counted_copy(ctx, dst[i].pixels, d[i], dst[i].rowPitch * dst[i].height, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -1461,7 +1478,7 @@ dxtex_hresult dxtex_compute_mse_device(dxtex_ctx* ctx, const dxtex_image* a, con
                               static_cast<double*>(ctx->mseBuf), ctx->stream);
     if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
     double sum[4];
-    HIP_TRY(ctx, hipMemcpyAsync(sum, ctx->mseBuf, sizeof(sum), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, sum, ctx->mseBuf, sizeof(sum), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const double n = double(a->width) * double(a->height);
     for (int c = 0; c < 4; ++c) mse[c] = sum[c] / n;
@@ -1486,7 +1503,7 @@ dxtex_hresult dxtex_memcpy_h2d(dxtex_ctx* ctx, void* dst, const void* src, size_
 {
     if (!ctx) return DXTEX_E_POINTER;
     ScopedDevice sd(ctx->device);
-    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return DXTEX_S_OK;
 }
@@ -1494,8 +1511,108 @@ dxtex_hresult dxtex_memcpy_d2h(dxtex_ctx* ctx, void* dst, const void* src, size_
 {
     if (!ctx) return DXTEX_E_POINTER;
     ScopedDevice sd(ctx->device);
-    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, counted_copy(ctx, dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return DXTEX_S_OK;
+}
+
+// ---- the device-resident pipeline's helpers -------------------------------------------------------------------------------------------
+dxtex_hresult dxtex_device_memset(dxtex_ctx* ctx, void* p, int value, size_t bytes)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!p) return fail(ctx, DXTEX_E_POINTER, "null buffer");
+    ScopedDevice sd(ctx->device);
+    if (bytes) HIP_TRY(ctx, hipMemsetAsync(p, value, bytes, ctx->stream));
+    return DXTEX_S_OK;
+}
+dxtex_hresult dxtex_copy_rows_device(dxtex_ctx* ctx, void* dst, size_t dstPitch, const void* src, size_t srcPitch, size_t rowBytes, size_t rows)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!dst || !src) return fail(ctx, DXTEX_E_POINTER, "null buffer");
+    if (rowBytes > dstPitch || rowBytes > srcPitch) return fail(ctx, DXTEX_E_INVALIDARG, "row is wider than a pitch");
+    ScopedDevice sd(ctx->device);
+    if (rowBytes && rows) HIP_TRY(ctx, hipMemcpy2DAsync(dst, dstPitch, src, srcPitch, rowBytes, rows, hipMemcpyDeviceToDevice, ctx->stream));
+    return DXTEX_S_OK;
+}
+dxtex_hresult dxtex_memcpy_h2d_async(dxtex_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    ScopedDevice sd(ctx->device);
+    HIP_TRY(ctx, counted_copy(ctx, dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return DXTEX_S_OK;
+}
+dxtex_hresult dxtex_memcpy_d2h_async(dxtex_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    ScopedDevice sd(ctx->device);
+    HIP_TRY(ctx, counted_copy(ctx, dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return DXTEX_S_OK;
+}
+dxtex_hresult dxtex_host_alloc(dxtex_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx || !out) return DXTEX_E_POINTER;
+    ScopedDevice sd(ctx->device);
+    HIP_TRY(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return DXTEX_S_OK;
+}
+dxtex_hresult dxtex_host_free(dxtex_ctx* ctx, void* p)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    ScopedDevice sd(ctx->device);
+    HIP_TRY(ctx, hipHostFree(p));
+    return DXTEX_S_OK;
+}
+
+dxtex_hresult dxtex_alpha_all_opaque_device(dxtex_ctx* ctx, const dxtex_image* images, size_t count, int* opaque)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (!opaque) return fail(ctx, DXTEX_E_POINTER, "null result");
+    *opaque = 0;
+    if (!images || !count) return fail(ctx, DXTEX_E_INVALIDARG, "no images");
+    const FmtInfo* f = format_info(images[0].format);
+    if (!f || (f->cls & FC_GROUP)) return fail(ctx, DXTEX_E_NOT_SUPPORTED, "format is not supported by the MI355X path");
+    // HasAlpha (DirectXTexUtil.cpp:340-372): of the BC formats BC1 / BC2 / BC3 / BC7 carry alpha; a format without alpha is opaque (:805-806)
+    const bool bc = (f->cls & FC_BC) != 0;
+    const bool bcAlpha = bc && bc_block_bytes(f->format) && f->format != FMT_BC4_UNORM && f->format != FMT_BC4_SNORM && f->format != FMT_BC5_UNORM &&
+                         f->format != FMT_BC5_SNORM && f->format != FMT_BC6H_UF16 && f->format != FMT_BC6H_SF16;
+    if ((bc && !bcAlpha) || (!bc && !(f->cls & FC_A))) { *opaque = 1; return DXTEX_S_OK; }
+    ScopedDevice sd(ctx->device);
+    dxtex_hresult hr = ensure(ctx, &ctx->mseBuf, &ctx->mseBytes, 4 * sizeof(double)); if (hr != DXTEX_S_OK) return hr;
+    unsigned long long* counter = static_cast<unsigned long long*>(ctx->mseBuf);
+    HIP_TRY(ctx, hipMemsetAsync(counter, 0, sizeof(unsigned long long), ctx->stream));
+    for (size_t i = 0; i < count; ++i)
+    {
+        const dxtex_image& im = images[i];
+        if (!im.pixels) return fail(ctx, DXTEX_E_POINTER, "null pixels");
+        if (im.format != images[0].format) return fail(ctx, DXTEX_E_FAIL, "format mismatch");
+        if (!im.width || !im.height || im.width > 0xFFFFFFFFull || im.height > 0xFFFFFFFFull) return fail(ctx, DXTEX_E_INVALIDARG, "image size");
+        hipError_t e;
+        if (bc)
+        {
+            // IsAlphaAllOpaqueBC decodes every block to floats and tests the texels inside the image against 0.99
+            const size_t pitch = im.width * 16;
+            hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, pitch * im.height); if (hr != DXTEX_S_OK) return hr;
+            hr = submit_decompress(ctx, im.pixels, im.format, im.rowPitch, static_cast<uint8_t*>(ctx->stageOut), FMT_R32G32B32A32_FLOAT, pitch, im.width, im.height);
+            if (hr != DXTEX_S_OK) return hr;
+            e = launch_alpha_below(static_cast<const uint8_t*>(ctx->stageOut), pitch, FMT_R32G32B32A32_FLOAT, uint32_t(im.width), uint32_t(im.height), 0.99f, counter, ctx->stream);
+        }
+        else
+            e = launch_alpha_below(im.pixels, im.rowPitch, im.format, uint32_t(im.width), uint32_t(im.height), 0.997f, counter, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
+    }
+    unsigned long long n = 0;
+    HIP_TRY(ctx, counted_copy(ctx, &n, counter, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *opaque = n ? 0 : 1;
+    return DXTEX_S_OK;
+}
+
+dxtex_hresult dxtex_ctx_transfer_bytes(dxtex_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes, int reset)
+{
+    if (!ctx) return DXTEX_E_POINTER;
+    if (h2d_bytes) *h2d_bytes = ctx->h2dBytes;
+    if (d2h_bytes) *d2h_bytes = ctx->d2hBytes;
+    if (reset) ctx->h2dBytes = ctx->d2hBytes = 0;
     return DXTEX_S_OK;
 }
 } // extern "C"

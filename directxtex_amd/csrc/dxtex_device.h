@@ -352,11 +352,14 @@ __device__ __forceinline__ Texel load_texel(const uint8_t* row, uint32_t x, int 
         t.r = float(v & 0x3FFu); t.g = float((v >> 10) & 0x3FFu); t.b = float((v >> 20) & 0x3FFu); t.a = float(v >> 30);
         break;
     }
-    case FMT_R10G10B10_XR_BIAS_A2_UNORM:    // XMLoadUDecN4_XR, :900-901: (field - 0x180) / 510, alpha / 3 (true divisions)
+    case FMT_R10G10B10_XR_BIAS_A2_UNORM:    // XMLoadUDecN4_XR, :900-901
     {
+        // the SSE2 path (the one an x64 build runs, like XMLoadUDecN4 above) subtracts the bias in place and multiplies by 1/510,
+        // 1/(510*2^10), 1/(510*2^20), 1/(3*2^30): float(field - 0x180) * float(1/510) per channel - NOT the scalar path's division,
+        // which differs in the last place for some fields (alpha * float(1/3) equals alpha / 3 for all four values)
         const uint32_t v = reinterpret_cast<const uint32_t*>(row)[x];
-        t.r = float(int32_t(v & 0x3FFu) - 0x180) / 510.0f; t.g = float(int32_t((v >> 10) & 0x3FFu) - 0x180) / 510.0f;
-        t.b = float(int32_t((v >> 20) & 0x3FFu) - 0x180) / 510.0f; t.a = float(v >> 30) / 3.0f;
+        t.r = float(int32_t(v & 0x3FFu) - 0x180) * (1.0f / 510.0f); t.g = float(int32_t((v >> 10) & 0x3FFu) - 0x180) * (1.0f / 510.0f);
+        t.b = float(int32_t((v >> 20) & 0x3FFu) - 0x180) * (1.0f / 510.0f); t.a = float(v >> 30) * (1.0f / 3.0f);
         break;
     }
     case FMT_R8G8B8A8_UINT:         // XMLoadUByte4, :913-914

@@ -89,4 +89,7 @@ hipError_t launch_scale_alpha(const uint8_t* src, uint64_t srcPitch, uint8_t* ds
                               float scale, hipStream_t stream);
 hipError_t launch_alpha_coverage(const uint8_t* src, uint64_t srcPitch, int format, uint32_t width, uint32_t height, float scale, float alphaReference,
                                  unsigned long long* count, hipStream_t stream);
+// IsAlphaAllOpaque's scan: *count (device, NOT cleared here) is incremented by the number of texels with alpha < threshold
+hipError_t launch_alpha_below(const uint8_t* src, uint64_t srcPitch, int format, uint32_t width, uint32_t height, float threshold,
+                              unsigned long long* count, hipStream_t stream);
 } // namespace dxtex

@@ -256,6 +256,19 @@ __global__ void __launch_bounds__(256) alpha_coverage_kernel(ImgView src, float 
     for (uint32_t y = blockIdx.y; y < src.height - 1u; y += gridDim.y) alpha_coverage_kernel_row(src, scale, alphaReference, count, x, y);        // grid_rows(): HIP caps grid.y at 65535
 }
 
+// ScratchImage::IsAlphaAllOpaque (DirectXTexImage.cpp:800-852): counts the texels whose alpha is below the threshold
+// (XMVector4Less on the splatted alpha: a NaN alpha is not "less" and counts as opaque, as there).
+__global__ void __launch_bounds__(256) alpha_below_kernel(ImgView src, float threshold, unsigned long long* count)
+{
+    uint32_t n = 0;
+    for (uint32_t y = blockIdx.y; y < src.height; y += gridDim.y)
+        for (uint32_t x = blockIdx.x * 256u + threadIdx.x; x < src.width; x += gridDim.x * 256u)
+            n += (load_texel(src.pixels + uint64_t(y) * src.rowPitch, x, src.format).a < threshold) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63u) == 0 && n) atomicAdd(count, static_cast<unsigned long long>(n));
+}
+
 // ---- point (:255-309 / :907-987): 16.16 fixed-point stepping -----------------------------------------------------------------
 __device__ __forceinline__ void resize_point_kernel_row(ResizeArgs a, const uint32_t x, const uint32_t y)
 {
@@ -466,9 +479,7 @@ __global__ void __launch_bounds__(256) resize_cubic_kernel(ResizeArgs a)
 __global__ void __launch_bounds__(256) resize_cubic_half_rgba8_kernel(ResizeArgs a, uint32_t stripRows)
 {
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t y0 = blockIdx.y * stripRows;
-    if (x >= a.dst.width || y0 >= a.dst.height) return;
-    const uint32_t y1 = min(y0 + stripRows, a.dst.height);
+    if (x >= a.dst.width) return;
     const int64_t srcW = a.src.width, srcH = a.src.height;
     const int64_t u0 = int64_t(2) * x - 1;
     const bool inside = u0 >= 0 && u0 + 3 < srcW;
@@ -491,6 +502,10 @@ __global__ void __launch_bounds__(256) resize_cubic_half_rgba8_kernel(ResizeArgs
 #undef DXTEX_CH
         return c;
     };
+    // the grid's y dimension is capped at 65535 strips (HIP's limit): a taller level is covered by striding over the strips
+    for (uint64_t s0 = uint64_t(blockIdx.y) * stripRows; s0 < a.dst.height; s0 += uint64_t(gridDim.y) * stripRows)
+    {
+    const uint32_t y0 = uint32_t(s0), y1 = uint32_t(min(s0 + stripRows, uint64_t(a.dst.height)));
     // destination row y takes source rows 2y - 1 .. 2y + 2
     float4 c0 = xpass(int64_t(2) * y0 - 1), c1 = xpass(int64_t(2) * y0), c2 = xpass(int64_t(2) * y0 + 1);
 #pragma unroll 2
@@ -503,6 +518,7 @@ __global__ void __launch_bounds__(256) resize_cubic_half_rgba8_kernel(ResizeArgs
         o.b = cubic1(0.5f, c0.z, c1.z, c2.z, c3.z); o.a = cubic1(0.5f, c0.w, c1.w, c2.w, c3.w);
         reinterpret_cast<uint32_t*>(a.dst.pixels + uint64_t(y) * a.dst.rowPitch)[x] = pack_texel32(FMT_R8G8B8A8_UNORM, o);
         c0 = c2; c1 = c3; c2 = n2;
+    }
     }
 }
 
@@ -900,7 +916,7 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
             // (at least ~4096 wavefronts while that leaves 4 rows or more per strip)
             uint32_t strip = 32;
             while (strip > 4 && uint64_t((dstW + 63) / 64) * ((dstH + strip - 1) / strip) < 4096) strip >>= 1;
-            hipLaunchKernelGGL(resize_cubic_half_rgba8_kernel, dim3((dstW + 255) / 256, (dstH + strip - 1) / strip), block, 0, stream, a, strip);
+            hipLaunchKernelGGL(resize_cubic_half_rgba8_kernel, dim3((dstW + 255) / 256, grid_rows((dstH + strip - 1) / strip)), block, 0, stream, a, strip);
         }
         else
             hipLaunchKernelGGL(resize_cubic_kernel, grid, block, 0, stream, a);
@@ -986,6 +1002,15 @@ hipError_t launch_alpha_coverage(const uint8_t* src, uint64_t srcPitch, int form
     if (width < 2 || height < 2) return hipSuccess;
     hipLaunchKernelGGL(alpha_coverage_kernel, dim3((width - 1 + 255) / 256, grid_rows(height - 1)), dim3(256), 0, stream,
                        make_view(src, srcPitch, width, height, format), scale, alphaReference, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_alpha_below(const uint8_t* src, uint64_t srcPitch, int format, uint32_t width, uint32_t height, float threshold,
+                              unsigned long long* count, hipStream_t stream)
+{
+    if (!width || !height) return hipSuccess;
+    const uint32_t gx = std::min<uint32_t>((width + 255) / 256, 64), gy = std::min<uint32_t>(height, 2048);
+    hipLaunchKernelGGL(alpha_below_kernel, dim3(gx, gy), dim3(256), 0, stream, make_view(src, srcPitch, width, height, format), threshold, count);
     return hipGetLastError();
 }
 

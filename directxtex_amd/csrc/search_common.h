@@ -171,8 +171,11 @@ __device__ __forceinline__ void selection_pass(int& e, uint32_t& s, int lane, in
 // the 16 global counters once per workgroup.
 constexpr int kBinGroups = 2048;
 
-__global__ void __launch_bounds__(256) bc7_bin_count_kernel(const uint32_t* tinfo, uint32_t ntasks, uint32_t* counters)
+// gate / gateMin: a launch whose mode (or phase of a mode) owns no block of the pass - known on the device only - is skipped when
+// *gate < gateMin (the task list was not written then; the zeroed counters leave counters[34] = 0 live tasks). nullptr = always run.
+__global__ void __launch_bounds__(256) bc7_bin_count_kernel(const uint32_t* tinfo, uint32_t ntasks, uint32_t* counters, const uint32_t* gate = nullptr, uint32_t gateMin = 0)
 {
+    if (gate && *gate < gateMin) return;
     __shared__ uint32_t hist[17];
     if (threadIdx.x < 17) hist[threadIdx.x] = 0;
     __syncthreads();
@@ -195,8 +198,9 @@ __global__ void bc7_bin_scan_kernel(uint32_t* counters)
     counters[34] = run;
 }
 
-__global__ void __launch_bounds__(256) bc7_bin_scatter_kernel(const uint32_t* tinfo, uint32_t ntasks, uint32_t* counters, uint2* order)
+__global__ void __launch_bounds__(256) bc7_bin_scatter_kernel(const uint32_t* tinfo, uint32_t ntasks, uint32_t* counters, uint2* order, const uint32_t* gate = nullptr, uint32_t gateMin = 0)
 {
+    if (gate && *gate < gateMin) return;
     __shared__ uint32_t hist[17], cursor[17];
     if (threadIdx.x < 17) hist[threadIdx.x] = 0;
     __syncthreads();

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 namespace DirectXTexAMD
@@ -405,8 +406,14 @@ void ScratchImage::Release() noexcept
     m_metadata = TexMetadata();
 }
 
-HRESULT ScratchImage::Initialize(const TexMetadata& mdata, CP_FLAGS flags) noexcept
+// DetermineImageArray / SetupImageArray (DirectXTexImage.cpp:34-268, argument checks :310-340): item-major then mip; a volume goes level by
+// level with the level's slices consecutive. `pixels` of every entry is its byte OFFSET in the blob; the caller adds its base pointer.
+namespace
 {
+HRESULT LayoutImages(const TexMetadata& mdata, CP_FLAGS flags, std::unique_ptr<Image[]>& images, size_t& nimagesOut, uint64_t& totalOut, size_t& mipLevelsOut,
+                     bool& argumentsAccepted) noexcept
+{
+    argumentsAccepted = false;
     if (!IsValid(mdata.format)) return E_INVALIDARG;
     if (IsPalettized(mdata.format)) return HRESULT_E_NOT_SUPPORTED;
     size_t mipLevels = mdata.mipLevels;
@@ -428,14 +435,8 @@ HRESULT ScratchImage::Initialize(const TexMetadata& mdata, CP_FLAGS flags) noexc
     default:
         return HRESULT_E_NOT_SUPPORTED;
     }
+    argumentsAccepted = true;
     const bool volume = mdata.dimension == TEX_DIMENSION_TEXTURE3D;
-
-    Release();
-    m_metadata = mdata;
-    m_metadata.mipLevels = mipLevels;
-
-    // DetermineImageArray / SetupImageArray (DirectXTexImage.cpp:34-268): item-major then mip; a volume goes level by level with
-    // the level's slices consecutive
     size_t nimages = 0;
     uint64_t total = 0;
     const size_t items = volume ? 1 : mdata.arraySize;
@@ -446,8 +447,8 @@ HRESULT ScratchImage::Initialize(const TexMetadata& mdata, CP_FLAGS flags) noexc
         {
             size_t rp, sp;
             const HRESULT hr = ComputePitch(mdata.format, w, h, rp, sp, flags);
-            if (FAILED(hr)) { Release(); return hr; }
-            if (d && sp > (UINT64_MAX - total) / d) { Release(); return E_OUTOFMEMORY; }          // more than an address space: no wrap-around
+            if (FAILED(hr)) return hr;
+            if (d && sp > (UINT64_MAX - total) / d) return E_OUTOFMEMORY;          // more than an address space: no wrap-around
             total += uint64_t(sp) * d;
             nimages += d;
             if (h > 1) h >>= 1;
@@ -455,17 +456,9 @@ HRESULT ScratchImage::Initialize(const TexMetadata& mdata, CP_FLAGS flags) noexc
             if (d > 1) d >>= 1;
         }
     }
-    m_images.reset(new (std::nothrow) Image[nimages]);
-    if (!m_images) { Release(); return E_OUTOFMEMORY; }
-    const size_t bytes = (size_t(total) + 15) & ~size_t(15);
-    m_memory = static_cast<uint8_t*>(std::aligned_alloc(16, std::max<size_t>(bytes, 16)));
-    if (!m_memory) { Release(); return E_OUTOFMEMORY; }
-    std::memset(m_memory, 0, std::max<size_t>(bytes, 16));        // zero-filled like the reference (DirectXTexImage.cpp:376)
-    m_size = size_t(total);
-    m_nimages = nimages;
-
-    uint8_t* p = m_memory;
-    size_t index = 0;
+    images.reset(new (std::nothrow) Image[nimages]);
+    if (!images) return E_OUTOFMEMORY;
+    size_t at = 0, index = 0;
     for (size_t item = 0; item < items; ++item)
     {
         size_t w = mdata.width, h = mdata.height, d = volume ? mdata.depth : 1;
@@ -473,17 +466,41 @@ HRESULT ScratchImage::Initialize(const TexMetadata& mdata, CP_FLAGS flags) noexc
         {
             for (size_t slice = 0; slice < d; ++slice, ++index)
             {
-                Image& im = m_images[index];
+                Image& im = images[index];
                 im.width = w; im.height = h; im.format = mdata.format;
                 ComputePitch(mdata.format, w, h, im.rowPitch, im.slicePitch, flags);
-                im.pixels = p;
-                p += im.slicePitch;
+                im.pixels = reinterpret_cast<uint8_t*>(at);
+                at += im.slicePitch;
             }
             if (h > 1) h >>= 1;
             if (w > 1) w >>= 1;
             if (d > 1) d >>= 1;
         }
     }
+    nimagesOut = nimages; totalOut = total; mipLevelsOut = mipLevels;
+    return S_OK;
+}
+}
+
+HRESULT ScratchImage::Initialize(const TexMetadata& mdata, CP_FLAGS flags) noexcept
+{
+    std::unique_ptr<Image[]> images;
+    size_t nimages = 0, mipLevels = 0;
+    uint64_t total = 0;
+    bool accepted = false;
+    const HRESULT hr = LayoutImages(mdata, flags, images, nimages, total, mipLevels, accepted);
+    if (FAILED(hr)) { if (accepted) Release(); return hr; }      // the argument checks come before the Release (:310-342)
+    Release();
+    m_metadata = mdata;
+    m_metadata.mipLevels = mipLevels;
+    const size_t bytes = (size_t(total) + 15) & ~size_t(15);
+    m_memory = static_cast<uint8_t*>(std::aligned_alloc(16, std::max<size_t>(bytes, 16)));
+    if (!m_memory) { Release(); return E_OUTOFMEMORY; }
+    std::memset(m_memory, 0, std::max<size_t>(bytes, 16));        // zero-filled like the reference (DirectXTexImage.cpp:376)
+    m_size = size_t(total);
+    m_nimages = nimages;
+    m_images = std::move(images);
+    for (size_t i = 0; i < nimages; ++i) m_images[i].pixels = m_memory + reinterpret_cast<size_t>(m_images[i].pixels);
     return S_OK;
 }
 
@@ -612,6 +629,49 @@ HRESULT Device::Prepare(size_t width, size_t height, DXGI_FORMAT srcFormat, DXGI
 }
 const char* Device::LastError() const noexcept { return m_ctx ? dxtex_ctx_last_error(m_ctx) : "no device"; }
 
+// ---- the two memory spaces of the array entry points ---------------------------------------------------------------------------
+// Host images (ScratchImage out; the C ABI's host-pointer functions stage through the device) and device-resident images
+// (DeviceScratchImage out; the *_device functions, stream-ordered). Each array entry point below is ONE template over the space, so the
+// validation, its order and the error codes are the same code in both.
+namespace
+{
+struct HostSpace
+{
+    using Out = ScratchImage;
+    static HRESULT Init(Device&, Out& out, const TexMetadata& m) noexcept { return out.Initialize(m); }
+    static HRESULT CompressMany(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d, size_t n, uint32_t f, float t) noexcept { return dxtex_compress_many(c, s, d, n, f, t); }
+    static HRESULT Decompress(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d) noexcept { return dxtex_decompress(c, s, d); }
+    static HRESULT Mips(dxtex_ctx* c, const dxtex_image* l, size_t n, uint32_t f) noexcept { return dxtex_generate_mips(c, l, n, f); }
+    static HRESULT Mips3D(dxtex_ctx* c, const dxtex_volume* l, size_t n, uint32_t f) noexcept { return dxtex_generate_mips3d(c, l, n, f); }
+    static HRESULT Resize(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d, uint32_t f) noexcept { return dxtex_resize(c, s, d, f); }
+    static HRESULT Convert(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d, uint32_t f, float t) noexcept { return dxtex_convert(c, s, d, f, t); }
+    static HRESULT PMAlpha(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d, uint32_t f) noexcept { return dxtex_premultiply_alpha(c, s, d, f); }
+    static HRESULT Coverage(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d, size_t n, float r) noexcept { return dxtex_scale_mips_alpha_for_coverage(c, s, d, n, r); }
+    static HRESULT CopyRows(dxtex_ctx*, uint8_t* dst, size_t dstPitch, const uint8_t* src, size_t srcPitch, size_t rowBytes, size_t rows) noexcept
+    {
+        for (size_t y = 0; y < rows; ++y) std::memcpy(dst + y * dstPitch, src + y * srcPitch, rowBytes);
+        return S_OK;
+    }
+};
+struct DeviceSpace
+{
+    using Out = DeviceScratchImage;
+    static HRESULT Init(Device& dev, Out& out, const TexMetadata& m) noexcept { return out.Initialize(dev, m); }
+    static HRESULT CompressMany(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d, size_t n, uint32_t f, float t) noexcept { return dxtex_compress_many_device(c, s, d, n, f, t); }
+    static HRESULT Decompress(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d) noexcept { return dxtex_decompress_device(c, s, d); }
+    static HRESULT Mips(dxtex_ctx* c, const dxtex_image* l, size_t n, uint32_t f) noexcept { return dxtex_generate_mips_device(c, l, n, f); }
+    static HRESULT Mips3D(dxtex_ctx* c, const dxtex_volume* l, size_t n, uint32_t f) noexcept { return dxtex_generate_mips3d_device(c, l, n, f); }
+    static HRESULT Resize(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d, uint32_t f) noexcept { return dxtex_resize_device(c, s, d, f); }
+    static HRESULT Convert(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d, uint32_t f, float t) noexcept { return dxtex_convert_device(c, s, d, f, t); }
+    static HRESULT PMAlpha(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d, uint32_t f) noexcept { return dxtex_premultiply_alpha_device(c, s, d, f); }
+    static HRESULT Coverage(dxtex_ctx* c, const dxtex_image* s, const dxtex_image* d, size_t n, float r) noexcept { return dxtex_scale_mips_alpha_for_coverage_device(c, s, d, n, r); }
+    static HRESULT CopyRows(dxtex_ctx* c, uint8_t* dst, size_t dstPitch, const uint8_t* src, size_t srcPitch, size_t rowBytes, size_t rows) noexcept
+    {
+        return dxtex_copy_rows_device(c, dst, dstPitch, src, srcPitch, rowBytes, rows);
+    }
+};
+}
+
 // ---- Compress (CompressEx, DirectXTexCompress.cpp:664-850) --------------------------------------------------------------------
 namespace
 {
@@ -666,19 +726,25 @@ HRESULT CompressEx(Device& device, const Image& srcImage, DXGI_FORMAT format, co
     return hr;
 }
 
-HRESULT CompressEx(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
-                   const CompressOptions& options, ScratchImage& cImages, StatusCallback statusCallback)
+namespace
+{
+template <class Space>
+HRESULT CompressArrayT(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                       const CompressOptions& options, typename Space::Out& cImages, const StatusCallback& statusCallback)
 {
     if (!device) return E_POINTER;
     if (!srcImages || !nimages) return E_INVALIDARG;
     if (IsCompressed(metadata.format) || !IsCompressed(format)) return E_INVALIDARG;
     if (!IsKnown(metadata.format) || !IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
     cImages.Release();
-    if (statusCallback && nimages == 1 && !metadata.IsVolumemap() && metadata.mipLevels == 1 && metadata.arraySize == 1)
-        return CompressEx(device, srcImages[0], format, options, cImages, statusCallback);         // progress inside the image, :753-764
+    if constexpr (std::is_same_v<Space, HostSpace>)
+    {
+        if (statusCallback && nimages == 1 && !metadata.IsVolumemap() && metadata.mipLevels == 1 && metadata.arraySize == 1)
+            return CompressEx(device, srcImages[0], format, options, cImages, statusCallback);         // progress inside the image, :753-764
+    }
     TexMetadata m2 = metadata;
     m2.format = format;
-    HRESULT hr = cImages.Initialize(m2);
+    HRESULT hr = Space::Init(device, cImages, m2);
     if (FAILED(hr)) return hr;
     if (nimages != cImages.GetImageCount()) { cImages.Release(); return E_FAIL; }
     const Image* dest = cImages.GetImages();
@@ -691,7 +757,7 @@ HRESULT CompressEx(Device& device, const Image* srcImages, size_t nimages, const
     }
     if (!statusCallback)
     {
-        hr = dxtex_compress_many(device.Get(), s.data(), d.data(), nimages, uint32_t(options.flags), options.threshold);   // the whole array in one submission
+        hr = Space::CompressMany(device.Get(), s.data(), d.data(), nimages, uint32_t(options.flags), options.threshold);   // the whole array in one submission
         if (FAILED(hr)) cImages.Release();
         return hr;
     }
@@ -705,6 +771,13 @@ HRESULT CompressEx(Device& device, const Image* srcImages, size_t nimages, const
     }
     if (!statusCallback(nimages, nimages)) { cImages.Release(); return E_ABORT; }
     return S_OK;
+}
+}
+
+HRESULT CompressEx(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                   const CompressOptions& options, ScratchImage& cImages, StatusCallback statusCallback)
+{
+    return CompressArrayT<HostSpace>(device, srcImages, nimages, metadata, format, options, cImages, statusCallback);
 }
 
 // Compress = CompressEx without a callback (DirectXTexCompress.cpp:632-661). The exception barrier is for the noexcept
@@ -748,7 +821,10 @@ HRESULT Decompress(Device& device, const Image& cImage, DXGI_FORMAT format, Scra
     return hr;
 }
 
-HRESULT Decompress(Device& device, const Image* cImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format, ScratchImage& images) noexcept
+namespace
+{
+template <class Space>
+HRESULT DecompressArrayT(Device& device, const Image* cImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format, typename Space::Out& images) noexcept
 {
     if (!device) return E_POINTER;
     if (!cImages || !nimages) return E_INVALIDARG;
@@ -763,7 +839,7 @@ HRESULT Decompress(Device& device, const Image* cImages, size_t nimages, const T
     images.Release();
     TexMetadata m2 = metadata;
     m2.format = format;
-    HRESULT hr = images.Initialize(m2);
+    HRESULT hr = Space::Init(device, images, m2);
     if (FAILED(hr)) return hr;
     if (nimages != images.GetImageCount()) { images.Release(); return E_FAIL; }
     const Image* dest = images.GetImages();
@@ -771,10 +847,16 @@ HRESULT Decompress(Device& device, const Image* cImages, size_t nimages, const T
     {
         if (cImages[i].format != metadata.format) { images.Release(); return E_FAIL; }
         const dxtex_image s = View(cImages[i]), d = View(dest[i]);
-        hr = dxtex_decompress(device.Get(), &s, &d);
+        hr = Space::Decompress(device.Get(), &s, &d);
         if (FAILED(hr)) { images.Release(); return hr; }
     }
     return S_OK;
+}
+}
+
+HRESULT Decompress(Device& device, const Image* cImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format, ScratchImage& images) noexcept
+{
+    return DecompressArrayT<HostSpace>(device, cImages, nimages, metadata, format, images);
 }
 
 // ---- GenerateMipMaps (DirectXTexMipmaps.cpp:2828-3247) ---------------------------------------------------------------------------
@@ -800,8 +882,11 @@ HRESULT GenerateMipMaps(Device& device, const Image& baseImage, TEX_FILTER_FLAGS
     return hr;
 }
 
-HRESULT GenerateMipMaps(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_FILTER_FLAGS filter,
-                        size_t levels, ScratchImage& mipChain) noexcept
+namespace
+{
+template <class Space>
+HRESULT GenerateMipMapsArrayT(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_FILTER_FLAGS filter,
+                              size_t levels, typename Space::Out& mipChain) noexcept
 {
     if (!device) return E_POINTER;
     if (!srcImages || !nimages || metadata.format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
@@ -821,23 +906,33 @@ HRESULT GenerateMipMaps(Device& device, const Image* srcImages, size_t nimages, 
     }
     TexMetadata m2 = metadata;
     m2.mipLevels = levels;
-    HRESULT hr = mipChain.Initialize(m2);
+    HRESULT hr = Space::Init(device, mipChain, m2);
     if (FAILED(hr)) return hr;
     for (size_t item = 0; item < metadata.arraySize; ++item)
     {
         const Image* top = mipChain.GetImage(0, item, 0);
-        for (size_t y = 0; y < top->height; ++y)
-            std::memcpy(top->pixels + y * top->rowPitch, base[item]->pixels + y * base[item]->rowPitch, std::min(top->rowPitch, base[item]->rowPitch));
+        hr = Space::CopyRows(device.Get(), top->pixels, top->rowPitch, base[item]->pixels, base[item]->rowPitch, std::min(top->rowPitch, base[item]->rowPitch), top->height);
+        if (FAILED(hr)) { mipChain.Release(); return hr; }
         std::vector<dxtex_image> views(levels);
         for (size_t l = 0; l < levels; ++l) views[l] = View(*mipChain.GetImage(l, item, 0));
-        hr = dxtex_generate_mips(device.Get(), views.data(), levels, uint32_t(filter));
+        hr = Space::Mips(device.Get(), views.data(), levels, uint32_t(filter));
         if (FAILED(hr)) { mipChain.Release(); return hr; }
     }
     return S_OK;
 }
+}
+
+HRESULT GenerateMipMaps(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_FILTER_FLAGS filter,
+                        size_t levels, ScratchImage& mipChain) noexcept
+{
+    return GenerateMipMapsArrayT<HostSpace>(device, srcImages, nimages, metadata, filter, levels, mipChain);
+}
 
 // ---- GenerateMipMaps3D (DirectXTexMipmaps.cpp:3254-3361) -------------------------------------------------------------------------------
-HRESULT GenerateMipMaps3D(Device& device, const Image* baseImages, size_t depth, TEX_FILTER_FLAGS filter, size_t levels, ScratchImage& mipChain) noexcept
+namespace
+{
+template <class Space>
+HRESULT GenerateMipMaps3DT(Device& device, const Image* baseImages, size_t depth, TEX_FILTER_FLAGS filter, size_t levels, typename Space::Out& mipChain) noexcept
 {
     if (!device) return E_POINTER;
     if (!baseImages || !depth || depth > INT16_MAX) return E_INVALIDARG;
@@ -852,14 +947,17 @@ HRESULT GenerateMipMaps3D(Device& device, const Image* baseImages, size_t depth,
     }
     if (IsCompressed(format) || !IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
     // Setup3DMips (:1608-1664): the base slices go to the top level
-    HRESULT hr = mipChain.Initialize3D(format, width, height, depth, levels);
+    TexMetadata m3;
+    m3.width = width; m3.height = height; m3.depth = depth; m3.arraySize = 1; m3.mipLevels = levels; m3.format = format; m3.dimension = TEX_DIMENSION_TEXTURE3D;
+    HRESULT hr = Space::Init(device, mipChain, m3);               // ScratchImage::Initialize3D (depth <= INT16_MAX was checked above)
     if (FAILED(hr)) return hr;
     for (size_t slice = 0; slice < depth; ++slice)
     {
         const Image* dest = mipChain.GetImage(0, 0, slice);
         if (!dest) { mipChain.Release(); return E_POINTER; }
-        for (size_t y = 0; y < height; ++y)
-            std::memcpy(dest->pixels + y * dest->rowPitch, baseImages[slice].pixels + y * baseImages[slice].rowPitch, std::min(dest->rowPitch, baseImages[slice].rowPitch));
+        hr = Space::CopyRows(device.Get(), dest->pixels, dest->rowPitch, baseImages[slice].pixels, baseImages[slice].rowPitch,
+                             std::min(dest->rowPitch, baseImages[slice].rowPitch), height);
+        if (FAILED(hr)) { mipChain.Release(); return hr; }
     }
     std::vector<dxtex_volume> lv(levels);
     size_t d = depth;
@@ -869,9 +967,15 @@ HRESULT GenerateMipMaps3D(Device& device, const Image* baseImages, size_t depth,
         lv[l] = dxtex_volume{ first->width, first->height, d, int32_t(first->format), first->rowPitch, first->slicePitch, first->pixels };
         if (d > 1) d >>= 1;
     }
-    hr = dxtex_generate_mips3d(device.Get(), lv.data(), lv.size(), uint32_t(filter));
+    hr = Space::Mips3D(device.Get(), lv.data(), lv.size(), uint32_t(filter));
     if (FAILED(hr)) mipChain.Release();
     return hr;
+}
+}
+
+HRESULT GenerateMipMaps3D(Device& device, const Image* baseImages, size_t depth, TEX_FILTER_FLAGS filter, size_t levels, ScratchImage& mipChain) noexcept
+{
+    return GenerateMipMaps3DT<HostSpace>(device, baseImages, depth, filter, levels, mipChain);
 }
 
 HRESULT GenerateMipMaps3D(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_FILTER_FLAGS filter, size_t levels,
@@ -905,8 +1009,11 @@ HRESULT Resize(Device& device, const Image& srcImage, size_t width, size_t heigh
 
 // Resize (complex), DirectXTexResize.cpp:942-1103: only mip 0 of every array item / depth slice is resized, the result has
 // one mip level.
-HRESULT Resize(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, size_t width, size_t height,
-               TEX_FILTER_FLAGS filter, ScratchImage& result) noexcept
+namespace
+{
+template <class Space>
+HRESULT ResizeArrayT(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, size_t width, size_t height,
+                     TEX_FILTER_FLAGS filter, typename Space::Out& result) noexcept
 {
     if (!device) return E_POINTER;
     if (!srcImages || !nimages || width == 0 || height == 0) return E_INVALIDARG;
@@ -916,7 +1023,7 @@ HRESULT Resize(Device& device, const Image* srcImages, size_t nimages, const Tex
     mdata2.width = width;
     mdata2.height = height;
     mdata2.mipLevels = 1;
-    HRESULT hr = result.Initialize(mdata2);
+    HRESULT hr = Space::Init(device, result, mdata2);
     if (FAILED(hr)) return hr;
     const bool volume = metadata.dimension == TEX_DIMENSION_TEXTURE3D;
     const size_t count = volume ? metadata.depth : metadata.arraySize;
@@ -930,10 +1037,17 @@ HRESULT Resize(Device& device, const Image* srcImages, size_t nimages, const Tex
         if (srcimg.format != metadata.format) { result.Release(); return E_FAIL; }
         if (srcimg.width > UINT32_MAX || srcimg.height > UINT32_MAX) { result.Release(); return E_FAIL; }
         const dxtex_image s = View(srcimg), d = View(*destimg);
-        hr = dxtex_resize(device.Get(), &s, &d, uint32_t(filter));
+        hr = Space::Resize(device.Get(), &s, &d, uint32_t(filter));
         if (FAILED(hr)) { result.Release(); return hr; }
     }
     return S_OK;
+}
+}
+
+HRESULT Resize(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, size_t width, size_t height,
+               TEX_FILTER_FLAGS filter, ScratchImage& result) noexcept
+{
+    return ResizeArrayT<HostSpace>(device, srcImages, nimages, metadata, width, height, filter, result);
 }
 
 // ---- Convert (ConvertEx, DirectXTexConvert.cpp:5107-5176) ---------------------------------------------------------------------------
@@ -987,19 +1101,25 @@ HRESULT ConvertEx(Device& device, const Image& srcImage, DXGI_FORMAT format, con
 }
 
 // ConvertEx (complex), DirectXTexConvert.cpp:5198-5405: every image of the set (all items, mips, slices) is converted.
-HRESULT ConvertEx(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
-                  const ConvertOptions& options, ScratchImage& result, StatusCallback statusCallback)
+namespace
+{
+template <class Space>
+HRESULT ConvertArrayT(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                      const ConvertOptions& options, typename Space::Out& result, const StatusCallback& statusCallback)
 {
     if (!device) return E_POINTER;
     if (!srcImages || !nimages || metadata.format == format || format == DXGI_FORMAT_UNKNOWN || metadata.format == DXGI_FORMAT_UNKNOWN)
         return E_INVALIDARG;
     if (IsCompressed(metadata.format) || IsCompressed(format) || !IsKnown(metadata.format) || !IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
     if (metadata.width > UINT32_MAX || metadata.height > UINT32_MAX) return E_INVALIDARG;
-    if (statusCallback && nimages == 1 && !metadata.IsVolumemap() && metadata.mipLevels == 1 && metadata.arraySize == 1)
-        return ConvertEx(device, srcImages[0], format, options, result, statusCallback);              // :5224-5235
+    if constexpr (std::is_same_v<Space, HostSpace>)
+    {
+        if (statusCallback && nimages == 1 && !metadata.IsVolumemap() && metadata.mipLevels == 1 && metadata.arraySize == 1)
+            return ConvertEx(device, srcImages[0], format, options, result, statusCallback);              // :5224-5235
+    }
     TexMetadata mdata2 = metadata;
     mdata2.format = format;
-    HRESULT hr = result.Initialize(mdata2);
+    HRESULT hr = Space::Init(device, result, mdata2);
     if (FAILED(hr)) return hr;
     if (nimages != result.GetImageCount()) { result.Release(); return E_FAIL; }
     const Image* dest = result.GetImages();
@@ -1013,12 +1133,19 @@ HRESULT ConvertEx(Device& device, const Image* srcImages, size_t nimages, const 
         if (src.width != dest[i].width || src.height != dest[i].height) { result.Release(); return E_FAIL; }
         if (!src.pixels) { result.Release(); return E_POINTER; }
         const dxtex_image s = View(src), d = View(dest[i]);
-        hr = dxtex_convert(device.Get(), &s, &d, uint32_t(options.filter), options.threshold);
+        hr = Space::Convert(device.Get(), &s, &d, uint32_t(options.filter), options.threshold);
         if (FAILED(hr)) { result.Release(); return hr; }
         if (statusCallback && !statusCallback(i, nimages)) { result.Release(); return E_ABORT; }
     }
     if (statusCallback && !statusCallback(nimages, nimages)) { result.Release(); return E_ABORT; }
     return S_OK;
+}
+}
+
+HRESULT ConvertEx(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
+                  const ConvertOptions& options, ScratchImage& result, StatusCallback statusCallback)
+{
+    return ConvertArrayT<HostSpace>(device, srcImages, nimages, metadata, format, options, result, statusCallback);
 }
 
 HRESULT Convert(Device& device, const Image& srcImage, DXGI_FORMAT format, TEX_FILTER_FLAGS filter, float threshold, ScratchImage& image) noexcept
@@ -1055,7 +1182,10 @@ HRESULT PremultiplyAlpha(Device& device, const Image& srcImage, TEX_PMALPHA_FLAG
     return hr;
 }
 
-HRESULT PremultiplyAlpha(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_PMALPHA_FLAGS flags, ScratchImage& result) noexcept
+namespace
+{
+template <class Space>
+HRESULT PremultiplyAlphaArrayT(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_PMALPHA_FLAGS flags, typename Space::Out& result) noexcept
 {
     if (!device) return E_POINTER;
     if (!srcImages || !nimages) return E_INVALIDARG;
@@ -1065,7 +1195,7 @@ HRESULT PremultiplyAlpha(Device& device, const Image* srcImages, size_t nimages,
     if (isPM != ((flags & TEX_PMALPHA_REVERSE) != 0)) return E_FAIL;                      // :283-284
     TexMetadata mdata2 = metadata;
     mdata2.SetAlphaMode((flags & TEX_PMALPHA_REVERSE) ? TEX_ALPHA_MODE_STRAIGHT : TEX_ALPHA_MODE_PREMULTIPLIED);
-    HRESULT hr = result.Initialize(mdata2);
+    HRESULT hr = Space::Init(device, result, mdata2);
     if (FAILED(hr)) return hr;
     if (nimages != result.GetImageCount()) { result.Release(); return E_FAIL; }
     const Image* dest = result.GetImages();
@@ -1077,15 +1207,24 @@ HRESULT PremultiplyAlpha(Device& device, const Image* srcImages, size_t nimages,
         if (src.width > UINT32_MAX || src.height > UINT32_MAX) { result.Release(); return E_FAIL; }
         if (src.width != dest[i].width || src.height != dest[i].height) { result.Release(); return E_FAIL; }
         const dxtex_image s = View(src), d = View(dest[i]);
-        hr = dxtex_premultiply_alpha(device.Get(), &s, &d, uint32_t(flags));
+        hr = Space::PMAlpha(device.Get(), &s, &d, uint32_t(flags));
         if (FAILED(hr)) { result.Release(); return hr; }
     }
     return S_OK;
 }
+}
+
+HRESULT PremultiplyAlpha(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, TEX_PMALPHA_FLAGS flags, ScratchImage& result) noexcept
+{
+    return PremultiplyAlphaArrayT<HostSpace>(device, srcImages, nimages, metadata, flags, result);
+}
 
 // ---- ScaleMipMapsAlphaForCoverage (DirectXTexMipmaps.cpp:3483-3556) ------------------------------------------------------------------
-HRESULT ScaleMipMapsAlphaForCoverage(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, size_t item,
-                                     float alphaReference, ScratchImage& mipChain) noexcept
+namespace
+{
+template <class Space>
+HRESULT ScaleMipMapsAlphaForCoverageT(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, size_t item,
+                                      float alphaReference, typename Space::Out& mipChain) noexcept
 {
     if (!device) return E_POINTER;
     if (!srcImages || !nimages || metadata.format == DXGI_FORMAT_UNKNOWN || nimages > metadata.mipLevels || !mipChain.GetImages()) return E_INVALIDARG;
@@ -1099,7 +1238,14 @@ HRESULT ScaleMipMapsAlphaForCoverage(Device& device, const Image* srcImages, siz
         if (!dst || !dst->pixels || !srcImages[level].pixels) return E_POINTER;
         s[level] = View(srcImages[level]); d[level] = View(*dst);
     }
-    return dxtex_scale_mips_alpha_for_coverage(device.Get(), s.data(), d.data(), s.size(), alphaReference);
+    return Space::Coverage(device.Get(), s.data(), d.data(), s.size(), alphaReference);
+}
+}
+
+HRESULT ScaleMipMapsAlphaForCoverage(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, size_t item,
+                                     float alphaReference, ScratchImage& mipChain) noexcept
+{
+    return ScaleMipMapsAlphaForCoverageT<HostSpace>(device, srcImages, nimages, metadata, item, alphaReference, mipChain);
 }
 
 // ---- ComputeMSE (DirectXTexMisc.cpp:181-260): compressed inputs are decompressed first -----------------------------------------------
@@ -1145,5 +1291,239 @@ HRESULT ComputeMSE(Device& device, const Image& image1, const Image& image2, flo
     if (mseV) for (int c = 0; c < 4; ++c) mseV[c] = float(v[c]);
     mse = float(v[0]) + float(v[1]) + float(v[2]) + float(v[3]);
     return S_OK;
+}
+
+// ---- DeviceScratchImage: a ScratchImage whose blob lives in HBM ---------------------------------------------------------------------
+DeviceScratchImage& DeviceScratchImage::operator=(DeviceScratchImage&& o) noexcept
+{
+    if (this != &o)
+    {
+        Release();
+        m_device = o.m_device; m_nimages = o.m_nimages; m_size = o.m_size; m_metadata = o.m_metadata;
+        m_images = std::move(o.m_images); m_memory = o.m_memory;
+        o.m_device = nullptr; o.m_nimages = 0; o.m_size = 0; o.m_memory = nullptr; o.m_metadata = TexMetadata();
+    }
+    return *this;
+}
+
+void DeviceScratchImage::Release() noexcept
+{
+    m_nimages = 0; m_size = 0;
+    m_images.reset();
+    if (m_memory && m_device && *m_device) dxtex_device_free(m_device->Get(), m_memory);      // waits for the work that still uses it
+    m_memory = nullptr; m_device = nullptr;
+    m_metadata = TexMetadata();
+}
+
+HRESULT DeviceScratchImage::Initialize(Device& device, const TexMetadata& mdata, CP_FLAGS flags) noexcept
+{
+    if (!device) return E_POINTER;
+    std::unique_ptr<Image[]> images;
+    size_t nimages = 0, mipLevels = 0;
+    uint64_t total = 0;
+    bool accepted = false;
+    HRESULT hr = LayoutImages(mdata, flags, images, nimages, total, mipLevels, accepted);
+    if (FAILED(hr)) { if (accepted) Release(); return hr; }
+    Release();
+    const size_t bytes = std::max<size_t>((size_t(total) + 15) & ~size_t(15), 16);
+    void* mem = nullptr;
+    hr = dxtex_device_alloc(device.Get(), bytes, &mem);
+    if (FAILED(hr)) return hr;
+    hr = dxtex_device_memset(device.Get(), mem, 0, bytes);                  // zero-filled like ScratchImage (DirectXTexImage.cpp:376)
+    if (FAILED(hr)) { dxtex_device_free(device.Get(), mem); return hr; }
+    m_device = &device;
+    m_memory = static_cast<uint8_t*>(mem);
+    m_metadata = mdata;
+    m_metadata.mipLevels = mipLevels;
+    m_size = size_t(total);
+    m_nimages = nimages;
+    m_images = std::move(images);
+    for (size_t i = 0; i < nimages; ++i) m_images[i].pixels = m_memory + reinterpret_cast<size_t>(m_images[i].pixels);
+    return S_OK;
+}
+
+HRESULT DeviceScratchImage::Upload(Device& device, const ScratchImage& src) noexcept
+{
+    if (!src.GetPixels() || !src.GetImageCount()) return E_INVALIDARG;
+    HRESULT hr = Initialize(device, src.GetMetadata());
+    if (FAILED(hr)) return hr;
+    // A ScratchImage built with CP_FLAGS other than NONE has other pitches: go image by image then.
+    bool sameLayout = src.GetImageCount() == m_nimages && src.GetPixelsSize() == m_size;
+    for (size_t i = 0; sameLayout && i < m_nimages; ++i)
+        sameLayout = src.GetImages()[i].rowPitch == m_images[i].rowPitch && src.GetImages()[i].slicePitch == m_images[i].slicePitch &&
+                     size_t(src.GetImages()[i].pixels - src.GetPixels()) == size_t(m_images[i].pixels - m_memory);
+    if (!sameLayout) return Upload(device, src.GetImages(), src.GetImageCount(), src.GetMetadata());
+    hr = dxtex_memcpy_h2d(device.Get(), m_memory, src.GetPixels(), m_size);
+    if (FAILED(hr)) Release();
+    return hr;
+}
+
+HRESULT DeviceScratchImage::Upload(Device& device, const Image* images, size_t nimages, const TexMetadata& metadata) noexcept
+{
+    if (!images || !nimages) return E_INVALIDARG;
+    HRESULT hr = Initialize(device, metadata);
+    if (FAILED(hr)) return hr;
+    if (nimages != m_nimages) { Release(); return E_FAIL; }
+    for (size_t i = 0; i < nimages; ++i)
+    {
+        const Image& s = images[i];
+        const Image& d = m_images[i];
+        if (!s.pixels) { Release(); return E_POINTER; }
+        if (s.format != d.format || s.width != d.width || s.height != d.height) { Release(); return E_FAIL; }
+        const size_t rows = ComputeScanlines(d.format, d.height);
+        if (s.rowPitch == d.rowPitch) hr = dxtex_memcpy_h2d_async(device.Get(), d.pixels, s.pixels, d.rowPitch * rows);
+        else
+            for (size_t y = 0; y < rows && SUCCEEDED(hr); ++y)
+                hr = dxtex_memcpy_h2d_async(device.Get(), d.pixels + y * d.rowPitch, s.pixels + y * s.rowPitch, std::min(s.rowPitch, d.rowPitch));
+        if (FAILED(hr)) { Release(); return hr; }
+    }
+    hr = dxtex_ctx_synchronize(device.Get());          // the caller's images may go away once this returns
+    if (FAILED(hr)) Release();
+    return hr;
+}
+
+HRESULT DeviceScratchImage::Download(ScratchImage& dst) const noexcept
+{
+    if (!m_memory || !m_device || !*m_device) return E_POINTER;
+    HRESULT hr = dst.Initialize(m_metadata);
+    if (FAILED(hr)) return hr;
+    if (dst.GetPixelsSize() != m_size) { dst.Release(); return E_FAIL; }
+    hr = dxtex_memcpy_d2h(m_device->Get(), dst.GetPixels(), m_memory, m_size);
+    if (FAILED(hr)) dst.Release();
+    return hr;
+}
+
+bool DeviceScratchImage::OverrideFormat(DXGI_FORMAT f) noexcept
+{
+    if (!m_images || !IsValid(f) || IsPlanar(f) || IsPalettized(f)) return false;
+    for (size_t i = 0; i < m_nimages; ++i) m_images[i].format = f;
+    m_metadata.format = f;
+    return true;
+}
+
+const Image* DeviceScratchImage::GetImage(size_t mip, size_t item, size_t slice) const noexcept
+{
+    const size_t i = m_metadata.ComputeIndex(mip, item, slice);
+    return (i < m_nimages) ? &m_images[i] : nullptr;
+}
+
+// ---- the resident steps: the array templates above in DeviceSpace ---------------------------------------------------------------------
+namespace
+{
+inline bool Resident(const Device& device, const DeviceScratchImage& src) noexcept { return src.GetImages() && src.GetDevice() == &device; }
+}
+
+HRESULT Compress(Device& device, const DeviceScratchImage& src, DXGI_FORMAT format, TEX_COMPRESS_FLAGS compress, float threshold, DeviceScratchImage& cImages) noexcept
+{
+    if (!Resident(device, src)) return E_INVALIDARG;
+    CompressOptions options = {};
+    options.flags = compress; options.threshold = threshold;
+    try { return CompressArrayT<DeviceSpace>(device, src.GetImages(), src.GetImageCount(), src.GetMetadata(), format, options, cImages, nullptr); }
+    catch (...) { cImages.Release(); return E_OUTOFMEMORY; }
+}
+
+HRESULT Decompress(Device& device, const DeviceScratchImage& cImages, DXGI_FORMAT format, DeviceScratchImage& images) noexcept
+{
+    if (!Resident(device, cImages)) return E_INVALIDARG;
+    return DecompressArrayT<DeviceSpace>(device, cImages.GetImages(), cImages.GetImageCount(), cImages.GetMetadata(), format, images);
+}
+
+HRESULT GenerateMipMaps(Device& device, const DeviceScratchImage& src, TEX_FILTER_FLAGS filter, size_t levels, DeviceScratchImage& mipChain) noexcept
+{
+    if (!Resident(device, src)) return E_INVALIDARG;
+    return GenerateMipMapsArrayT<DeviceSpace>(device, src.GetImages(), src.GetImageCount(), src.GetMetadata(), filter, levels, mipChain);
+}
+
+HRESULT GenerateMipMaps3D(Device& device, const DeviceScratchImage& src, TEX_FILTER_FLAGS filter, size_t levels, DeviceScratchImage& mipChain) noexcept
+{
+    if (!Resident(device, src)) return E_INVALIDARG;
+    const TexMetadata& metadata = src.GetMetadata();
+    // the complex overload's checks (DirectXTexMipmaps.cpp:3364-3480)
+    if (metadata.dimension != TEX_DIMENSION_TEXTURE3D) return E_INVALIDARG;
+    if (metadata.depth > src.GetImageCount()) return E_FAIL;
+    return GenerateMipMaps3DT<DeviceSpace>(device, src.GetImages(), metadata.depth, filter, levels, mipChain);
+}
+
+HRESULT Resize(Device& device, const DeviceScratchImage& src, size_t width, size_t height, TEX_FILTER_FLAGS filter, DeviceScratchImage& result) noexcept
+{
+    if (!Resident(device, src)) return E_INVALIDARG;
+    return ResizeArrayT<DeviceSpace>(device, src.GetImages(), src.GetImageCount(), src.GetMetadata(), width, height, filter, result);
+}
+
+HRESULT Convert(Device& device, const DeviceScratchImage& src, DXGI_FORMAT format, TEX_FILTER_FLAGS filter, float threshold, DeviceScratchImage& result) noexcept
+{
+    if (!Resident(device, src)) return E_INVALIDARG;
+    ConvertOptions options = {};
+    options.filter = filter; options.threshold = threshold;
+    try { return ConvertArrayT<DeviceSpace>(device, src.GetImages(), src.GetImageCount(), src.GetMetadata(), format, options, result, nullptr); }
+    catch (...) { result.Release(); return E_OUTOFMEMORY; }
+}
+
+HRESULT PremultiplyAlpha(Device& device, const DeviceScratchImage& src, TEX_PMALPHA_FLAGS flags, DeviceScratchImage& result) noexcept
+{
+    if (!Resident(device, src)) return E_INVALIDARG;
+    return PremultiplyAlphaArrayT<DeviceSpace>(device, src.GetImages(), src.GetImageCount(), src.GetMetadata(), flags, result);
+}
+
+HRESULT ScaleMipMapsAlphaForCoverage(Device& device, const DeviceScratchImage& src, float alphaReference, DeviceScratchImage& mipChain) noexcept
+{
+    if (!Resident(device, src)) return E_INVALIDARG;
+    const TexMetadata& info = src.GetMetadata();
+    HRESULT hr = mipChain.Initialize(device, info);
+    if (FAILED(hr)) return hr;
+    for (size_t item = 0; item < info.arraySize; ++item)
+    {
+        const Image* first = src.GetImage(0, item, 0);
+        if (!first) { mipChain.Release(); return E_FAIL; }
+        hr = ScaleMipMapsAlphaForCoverageT<DeviceSpace>(device, first, info.mipLevels, info, item, alphaReference, mipChain);
+        if (FAILED(hr)) { mipChain.Release(); return hr; }
+    }
+    return S_OK;
+}
+
+HRESULT CopyTopLevels(Device& device, const DeviceScratchImage& src, DeviceScratchImage& result) noexcept
+{
+    if (!Resident(device, src)) return E_INVALIDARG;
+    TexMetadata m = src.GetMetadata();
+    m.mipLevels = 1;
+    HRESULT hr = result.Initialize(device, m);
+    if (FAILED(hr)) return hr;
+    const bool volume = m.dimension == TEX_DIMENSION_TEXTURE3D;
+    for (size_t i = 0; i < (volume ? m.depth : m.arraySize); ++i)
+    {
+        const Image* s = volume ? src.GetImage(0, 0, i) : src.GetImage(0, i, 0);
+        const Image* d = volume ? result.GetImage(0, 0, i) : result.GetImage(0, i, 0);
+        if (!s || !d) { result.Release(); return E_FAIL; }
+        const size_t rows = ComputeScanlines(d->format, d->height);
+        hr = dxtex_copy_rows_device(device.Get(), d->pixels, d->rowPitch, s->pixels, s->rowPitch, std::min(s->rowPitch, d->rowPitch), rows);
+        if (FAILED(hr)) { result.Release(); return hr; }
+    }
+    return S_OK;
+}
+
+bool IsAlphaAllOpaque(Device& device, const Image* deviceImages, size_t nimages) noexcept
+{
+    if (!device || !deviceImages || !nimages) return false;
+    if (!HasAlpha(deviceImages[0].format)) return true;                  // DirectXTexImage.cpp:805-806
+    try
+    {
+        std::vector<dxtex_image> v(nimages);
+        for (size_t i = 0; i < nimages; ++i) v[i] = View(deviceImages[i]);
+        int opaque = 0;
+        return SUCCEEDED(dxtex_alpha_all_opaque_device(device.Get(), v.data(), nimages, &opaque)) && opaque != 0;
+    }
+    catch (...) { return false; }
+}
+
+bool IsAlphaAllOpaque(Device& device, const DeviceScratchImage& image) noexcept
+{
+    if (!Resident(device, image)) return false;
+    return IsAlphaAllOpaque(device, image.GetImages(), image.GetImageCount());
+}
+
+void GetTransferBytes(Device& device, uint64_t& hostToDevice, uint64_t& deviceToHost, bool reset) noexcept
+{
+    hostToDevice = deviceToHost = 0;
+    if (device) dxtex_ctx_transfer_bytes(device.Get(), &hostToDevice, &deviceToHost, reset ? 1 : 0);
 }
 } // namespace DirectXTexAMD

@@ -280,6 +280,71 @@ HRESULT ScaleMipMapsAlphaForCoverage(Device& device, const Image* srcImages, siz
                                      float alphaReference, ScratchImage& mipChain) noexcept;
 
 HRESULT ComputeMSE(Device& device, const Image& image1, const Image& image2, float& mse, float* mseV) noexcept;
+
+// ---- the device-resident pipeline ---------------------------------------------------------------------------------------------------
+// texconv runs resize -> convert -> mipmaps -> compress (Texconv/texconv.cpp:2609, 3109, 3434, 3711) as four ScratchImage -> ScratchImage calls;
+// on a GPU that is four uploads and four downloads around a millisecond of kernels. The reference's own GPU path keeps its intermediate on
+// the device (DirectXTexCompressGPU.cpp:34-140 converts on the way in, BCDirectCompute.cpp:373-642 reads the result back once). Here the
+// whole chain can stay there: a DeviceScratchImage is a ScratchImage whose blob lives in HBM - same layout (item-major, then mips), same
+// pitches, zero-filled - and every step below takes one and produces one with the SAME validation, error codes and kernels as the
+// host-memory overload of the same name. Upload() is the chain's one host -> device copy, Download() its one device -> host copy.
+class DeviceScratchImage
+{
+public:
+    DeviceScratchImage() noexcept = default;
+    DeviceScratchImage(DeviceScratchImage&& o) noexcept { *this = static_cast<DeviceScratchImage&&>(o); }
+    DeviceScratchImage& operator=(DeviceScratchImage&& o) noexcept;
+    DeviceScratchImage(const DeviceScratchImage&) = delete;
+    DeviceScratchImage& operator=(const DeviceScratchImage&) = delete;
+    ~DeviceScratchImage() { Release(); }
+
+    // allocates and zero-fills (stream-ordered) device memory laid out like ScratchImage::Initialize(mdata, flags); the Device must outlive the image
+    HRESULT Initialize(Device& device, const TexMetadata& mdata, CP_FLAGS flags = CP_FLAGS_NONE) noexcept;
+    // Initialize + ONE host -> device copy of the source's blob (same layout on both sides)
+    HRESULT Upload(Device& device, const ScratchImage& src) noexcept;
+    // caller images of any pitch (nimages must match the metadata's image count): one copy per image when the pitches agree, else per row
+    HRESULT Upload(Device& device, const Image* images, size_t nimages, const TexMetadata& metadata) noexcept;
+    // dst.Initialize(metadata) + ONE device -> host copy; returns after the copy
+    HRESULT Download(ScratchImage& dst) const noexcept;
+    bool OverrideFormat(DXGI_FORMAT f) noexcept;
+    void Release() noexcept;
+
+    const TexMetadata& GetMetadata() const noexcept { return m_metadata; }
+    // Image views whose `pixels` are DEVICE pointers: valid arguments for the *_device entry points of the C ABI, not for host code
+    const Image* GetImage(size_t mip, size_t item, size_t slice) const noexcept;
+    const Image* GetImages() const noexcept { return m_images.get(); }
+    size_t GetImageCount() const noexcept { return m_nimages; }
+    uint8_t* GetPixels() const noexcept { return m_memory; }
+    size_t GetPixelsSize() const noexcept { return m_size; }
+    Device* GetDevice() const noexcept { return m_device; }
+
+private:
+    Device* m_device = nullptr;
+    size_t m_nimages = 0, m_size = 0;
+    TexMetadata m_metadata;
+    std::unique_ptr<Image[]> m_images;
+    uint8_t* m_memory = nullptr;
+};
+
+// The steps, resident: same argument meaning and HRESULTs as the (Image*, nimages, metadata) overloads above; all work is queued on the
+// Device's stream and the result may be handed to the next step at once. `src` and the result must belong to `device`.
+HRESULT Compress(Device& device, const DeviceScratchImage& src, DXGI_FORMAT format, TEX_COMPRESS_FLAGS compress, float threshold, DeviceScratchImage& cImages) noexcept;
+HRESULT Decompress(Device& device, const DeviceScratchImage& cImages, DXGI_FORMAT format, DeviceScratchImage& images) noexcept;
+HRESULT GenerateMipMaps(Device& device, const DeviceScratchImage& src, TEX_FILTER_FLAGS filter, size_t levels, DeviceScratchImage& mipChain) noexcept;
+HRESULT GenerateMipMaps3D(Device& device, const DeviceScratchImage& src, TEX_FILTER_FLAGS filter, size_t levels, DeviceScratchImage& mipChain) noexcept;
+HRESULT Resize(Device& device, const DeviceScratchImage& src, size_t width, size_t height, TEX_FILTER_FLAGS filter, DeviceScratchImage& result) noexcept;
+HRESULT Convert(Device& device, const DeviceScratchImage& src, DXGI_FORMAT format, TEX_FILTER_FLAGS filter, float threshold, DeviceScratchImage& result) noexcept;
+HRESULT PremultiplyAlpha(Device& device, const DeviceScratchImage& src, TEX_PMALPHA_FLAGS flags, DeviceScratchImage& result) noexcept;
+// every array item of a mip chain (the per-item loop texconv runs, texconv.cpp:3470-3490); the 10-step bisection per level reads 8 bytes back per step
+HRESULT ScaleMipMapsAlphaForCoverage(Device& device, const DeviceScratchImage& src, float alphaReference, DeviceScratchImage& mipChain) noexcept;
+// level 0 of every array item / depth slice as a texture with one mip level (what texconv keeps before it regenerates a chain, texconv.cpp:3324-3380)
+HRESULT CopyTopLevels(Device& device, const DeviceScratchImage& src, DeviceScratchImage& result) noexcept;
+// ScratchImage::IsAlphaAllOpaque (DirectXTexImage.cpp:800-852) as a device reduction; false on any failure, like the reference. The Image form takes
+// device-resident images of one format (e.g. the top levels of a chain).
+bool IsAlphaAllOpaque(Device& device, const DeviceScratchImage& image) noexcept;
+bool IsAlphaAllOpaque(Device& device, const Image* deviceImages, size_t nimages) noexcept;
+// bytes moved between host and device for this Device since the last reset (see dxtex_ctx_transfer_bytes)
+void GetTransferBytes(Device& device, uint64_t& hostToDevice, uint64_t& deviceToHost, bool reset = false) noexcept;
 } // namespace DirectXTexAMD
 
 // ---- DDS container: the on-disk format either side of the path ---------------------------------

@@ -16,6 +16,7 @@
 //     -dword -badtails -permissive -ignoremips -xlum            DDS reader tolerances (DDS_FLAGS)
 //     -dx10 -dx9           force the 'DX10' header (+ alpha mode) / a Direct3D 9 file        -tga20   TGA output with the 2.0 extension area
 //     -px <s> -sx <s> -l   output name prefix / suffix, lower case    -y   overwrite    -info (print what the files hold, no GPU)    -timing -nologo -gpu <n> | -gpus <a,b,...> (files dealt out over the GPUs)
+//     -overlap <n>         workers (contexts) per GPU, default 2: the transfers and file codecs of one file overlap the kernels of another
 #include "../host/DirectXTexAMD.h"
 
 #include <algorithm>
@@ -83,6 +84,7 @@ struct Options
     uint32_t format = 0, filter = 0, filterOpts = 0, srgb = 0, convert = 0, compress = 0, ddsRead = DDS_FLAGS_ALLOW_LARGE_FILES;
     float alphaThreshold = TEX_THRESHOLD_DEFAULT, keepCoverage = 0.f;
     std::vector<int> gpus;              // one worker (own Device, own host thread) per entry; input i goes to worker i mod n
+    size_t overlap = 2;                 // workers per listed GPU: file k + 1 is read, decoded and uploaded while file k's kernels run
     std::string prefix, suffix, out;
     std::vector<std::string> inputs;
 };
@@ -107,55 +109,7 @@ void FitPowerOf2(size_t origx, size_t origy, size_t& targetx, size_t& targety, s
     }
 }
 
-// ScratchImage::IsAlphaAllOpaque (DirectXTexImage.cpp:800-852): every alpha >= 0.997. Block-compressed images are decoded on the GPU.
-bool IsAlphaAllOpaque(Device& dev, const ScratchImage& image)
-{
-    const TexMetadata& info = image.GetMetadata();
-    if (!image.GetImageCount()) return false;
-    if (!HasAlpha(info.format)) return true;
-    ScratchImage decoded;
-    const ScratchImage* src = &image;
-    if (IsCompressed(info.format))
-    {
-        // to floats, so that the decoder's own alpha values meet the threshold (IsAlphaAllOpaqueBC, DirectXTexCompress.cpp:537-610)
-        if (FAILED(Decompress(dev, image.GetImages(), image.GetImageCount(), info, DXGI_FORMAT_R32G32B32A32_FLOAT, decoded))) return false;
-        src = &decoded;
-    }
-    const DXGI_FORMAT f = src->GetMetadata().format;
-    auto half = [](uint16_t h) -> float
-    {
-        const uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ff;
-        const float v = (e == 0) ? std::ldexp(float(m), -24) : (e == 31) ? (m ? NAN : INFINITY) : std::ldexp(float(m | 0x400), int(e) - 25);
-        return (h & 0x8000) ? -v : v;
-    };
-    for (size_t i = 0; i < src->GetImageCount(); ++i)
-    {
-        const Image& im = src->GetImages()[i];
-        for (size_t y = 0; y < im.height; ++y)
-        {
-            const uint8_t* row = im.pixels + y * im.rowPitch;
-            for (size_t x = 0; x < im.width; ++x)
-            {
-                float a;
-                switch (f)
-                {
-                case DXGI_FORMAT_R8G8B8A8_UNORM: case DXGI_FORMAT_R8G8B8A8_UNORM_SRGB: case DXGI_FORMAT_B8G8R8A8_UNORM: case DXGI_FORMAT_B8G8R8A8_UNORM_SRGB:
-                    a = float(row[x * 4 + 3]) * (1.0f / 255.0f); break;
-                case DXGI_FORMAT_R8G8B8A8_SNORM: a = std::max(float(int8_t(row[x * 4 + 3])) * (1.0f / 127.0f), -1.0f); break;
-                case DXGI_FORMAT_A8_UNORM: a = float(row[x]) / 255.0f; break;
-                case DXGI_FORMAT_R16G16B16A16_UNORM: { uint16_t v; std::memcpy(&v, row + x * 8 + 6, 2); a = float(v) * (1.0f / 65535.0f); break; }
-                case DXGI_FORMAT_R16G16B16A16_FLOAT: { uint16_t v; std::memcpy(&v, row + x * 8 + 6, 2); a = half(v); break; }
-                case DXGI_FORMAT_R32G32B32A32_FLOAT: std::memcpy(&a, row + x * 16 + 12, 4); break;
-                default: return false;
-                }
-                if (a < 0.997f) return false;
-            }
-        }
-    }
-    return true;
-}
-
-// mip level 0 of every array item / depth slice as a texture with one level (texconv.cpp:3324-3380)
+// mip level 0 of every array item / depth slice as a texture with one level (texconv.cpp:3324-3380), host images
 HRESULT TopLevels(const ScratchImage& in, ScratchImage& out)
 {
     TexMetadata m = in.GetMetadata();
@@ -177,7 +131,7 @@ int usage()
 {
     std::fprintf(stderr, "usage: dxtexconv [-w W] [-h H] [-pow2] [-fl LEVEL] [-m N] [-f FORMAT] [-if FILTER] [-wrap] [-mirror] [-srgb|-srgbi|-srgbo]\n"
                          "                 [-pmalpha|-alpha] [-keepcoverage REF] [-at T] [-bc qxdu] [-x2bias] [-sepalpha] [-dword] [-badtails] [-permissive]\n"
-                         "                 [-ignoremips] [-xlum] [-dx10|-dx9] [-px S] [-sx S] [-l] [-y] [-timing] [-nologo] [-gpu N | -gpus A,B,...] -o <out.dds | dir> in.dds...\n");
+                         "                 [-ignoremips] [-xlum] [-dx10|-dx9] [-px S] [-sx S] [-l] [-y] [-timing] [-nologo] [-gpu N | -gpus A,B,...] [-overlap N] -o <out.dds | dir> in.dds...\n");
     return 1;
 }
 
@@ -251,6 +205,7 @@ bool Parse(int argc, char** argv, Options& o)
             }
             if (o.gpus.empty()) { std::fprintf(stderr, "-gpus wants a comma-separated list of device ordinals\n"); return false; }
         }
+        else if (a == "-overlap") { o.overlap = std::strtoull(next(), nullptr, 10); if (o.overlap < 1 || o.overlap > 8) { std::fprintf(stderr, "-overlap wants 1 .. 8 workers per GPU\n"); return false; } }
         else if (a == "-o") o.out = next();
         else if (a == "-ft")
         {
@@ -285,39 +240,59 @@ std::string OutputName(const Options& o, const std::string& input)
 
 struct StepFailed { const char* what; HRESULT hr; };
 
-// one file through the pipeline; throws StepFailed
+// PremultiplyAlpha checks the texture's alpha mode (DirectXTexPMAlpha.cpp:283-284); the tool tracks it in `info`, which must be what the
+// resident image carries
+HRESULT PremultiplyAlphaWithMode(Device& dev, const DeviceScratchImage& image, const TexMetadata& info, TEX_PMALPHA_FLAGS flags, DeviceScratchImage& result)
+{
+    if (image.GetMetadata().miscFlags2 != info.miscFlags2) return E_FAIL;
+    return PremultiplyAlpha(dev, image, flags, result);
+}
+
+// One file through the pipeline; throws StepFailed. The texture is uploaded ONCE after the file has been decoded, every step runs on the
+// device-resident copy (DeviceScratchImage in, DeviceScratchImage out: the steps queue their kernels on the Device's stream back to back),
+// and the final images come back ONCE for the file writer: two PCIe transfers per file whatever the number of steps, where the
+// ScratchImage -> ScratchImage calls of the reference tool's sequence would be one round trip per step.
 void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const std::string& outFile)
 {
     auto check = [](const char* what, HRESULT hr) { if (FAILED(hr)) throw StepFailed{ what, hr }; };
     const TEX_FILTER_FLAGS filter = TEX_FILTER_FLAGS(o.filter | o.filterOpts);
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t up0 = 0, down0 = 0;
+    GetTransferBytes(dev, up0, down0);
 
-    ScratchImage image; TexMetadata info;
+    ScratchImage loaded; TexMetadata info;
     auto hasExt = [](const std::string& f, const char* ext) { const size_t n = std::strlen(ext); return f.size() > n && !strcasecmp(f.c_str() + f.size() - n, ext); };
-    if (hasExt(inFile, ".hdr")) check("load", LoadFromHDRFile(inFile.c_str(), &info, image));               // Radiance RGBE -> RGBA32F
-    else if (hasExt(inFile, ".tga")) check("load", LoadFromTGAFile(inFile.c_str(), TGA_FLAGS_NONE, &info, image));
-    else check("load", LoadFromDDSFile(inFile.c_str(), DDS_FLAGS(o.ddsRead), &info, image));
+    if (hasExt(inFile, ".hdr")) check("load", LoadFromHDRFile(inFile.c_str(), &info, loaded));               // Radiance RGBE -> RGBA32F
+    else if (hasExt(inFile, ".tga")) check("load", LoadFromTGAFile(inFile.c_str(), TGA_FLAGS_NONE, &info, loaded));
+    else check("load", LoadFromDDSFile(inFile.c_str(), DDS_FLAGS(o.ddsRead), &info, loaded));
     std::printf("reading %s (%zux%zu", inFile.c_str(), info.width, info.height);
     if (info.dimension == TEX_DIMENSION_TEXTURE3D) std::printf("x%zu", info.depth);
     std::printf(", %zu mips, %zu items, format %u)\n", info.mipLevels, info.arraySize, unsigned(info.format));
     const DXGI_FORMAT tformat = o.format ? DXGI_FORMAT(o.format) : info.format;
     size_t tMips = (!o.mipLevels && info.mipLevels > 1) ? info.mipLevels : o.mipLevels;           // texconv.cpp:2270
 
-    // --- decompress (texconv.cpp:2325-2480). The compressed original is kept: if no step below changes the texels and the
-    // target is its format, it is written back as it is instead of being encoded again.
-    ScratchImage cimage;
-    bool haveOriginal = false;
-    auto keep = [&](ScratchImage& t)             // a step produced t: it becomes the image, metadata keeps its alpha mode
+    // --- the one upload
+    DeviceScratchImage image;
+    check("upload", image.Upload(dev, loaded));
+    auto keep = [&](DeviceScratchImage& t)         // a step produced t: it becomes the image, metadata keeps its alpha mode
     {
         const uint32_t misc2 = info.miscFlags2;
         image = std::move(t); info = image.GetMetadata(); info.miscFlags2 = misc2;
     };
+
+    // --- decompress (texconv.cpp:2325-2480). The compressed original is kept (on the host, where it already is, and on the device for the
+    // alpha scan): if no step below changes the texels and the target is its format, it is written back as it is instead of being encoded again.
+    ScratchImage cimage;
+    DeviceScratchImage dcimage;
+    bool haveOriginal = false;
     if (IsCompressed(info.format))
     {
-        ScratchImage t;
-        check("decompress", Decompress(dev, image.GetImages(), image.GetImageCount(), info, DXGI_FORMAT_UNKNOWN, t));
-        cimage = std::move(image); haveOriginal = true;
+        DeviceScratchImage t;
+        check("decompress", Decompress(dev, image, DXGI_FORMAT_UNKNOWN, t));
+        cimage = std::move(loaded); dcimage = std::move(image); haveOriginal = true;
         keep(t);
     }
+    else loaded.Release();
 
     // --- undo premultiplied alpha
     if (o.demul && HasAlpha(info.format) && info.format != DXGI_FORMAT_A8_UNORM)
@@ -326,8 +301,9 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
         else if (!info.IsPMAlpha()) std::printf("WARNING: image is not using premultiplied alpha\n");
         else
         {
-            ScratchImage t;
-            check("demultiply alpha", PremultiplyAlpha(dev, image.GetImages(), image.GetImageCount(), info, TEX_PMALPHA_FLAGS(TEX_PMALPHA_REVERSE | o.srgb), t));
+            DeviceScratchImage t;
+            // the alpha mode lives in the tool's metadata: the resident image carries the file's, which the step checks (DirectXTexPMAlpha.cpp:283-284)
+            check("demultiply alpha", PremultiplyAlphaWithMode(dev, image, info, TEX_PMALPHA_FLAGS(TEX_PMALPHA_REVERSE | o.srgb), t));
             info.miscFlags2 = t.GetMetadata().miscFlags2;
             image = std::move(t);
             haveOriginal = false;
@@ -341,8 +317,8 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
     if (o.pow2) FitPowerOf2(info.width, info.height, tw, th, o.maxSize);
     if (tw != info.width || th != info.height)
     {
-        ScratchImage t;
-        check("resize", Resize(dev, image.GetImages(), image.GetImageCount(), info, tw, th, filter, t));
+        DeviceScratchImage t;
+        check("resize", Resize(dev, image, tw, th, filter, t));
         keep(t);
         haveOriginal = false;
         if (tMips > 0)
@@ -356,8 +332,8 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
     // --- convert to the uncompressed target format
     if (!IsCompressed(tformat) && tformat != info.format)
     {
-        ScratchImage t;
-        check("convert", Convert(dev, image.GetImages(), image.GetImageCount(), info, tformat, TEX_FILTER_FLAGS(filter | o.srgb | o.convert), o.alphaThreshold, t));
+        DeviceScratchImage t;
+        check("convert", Convert(dev, image, tformat, TEX_FILTER_FLAGS(filter | o.srgb | o.convert), o.alphaThreshold, t));
         keep(t);
         haveOriginal = false;
     }
@@ -373,8 +349,8 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
     if ((!tMips || info.mipLevels != tMips || keepCoverage) && info.mipLevels != 1)
     {
         // generation starts from a single level: strip the existing chain
-        ScratchImage t;
-        check("copy to single level", TopLevels(image, t));
+        DeviceScratchImage t;
+        check("copy to single level", CopyTopLevels(dev, image, t));
         keep(t);
         if (haveOriginal && tMips == 1)
         {
@@ -382,14 +358,17 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
             ScratchImage c;
             check("copy compressed to single level", TopLevels(cimage, c));
             cimage = std::move(c);
+            DeviceScratchImage dc;
+            check("copy compressed to single level", CopyTopLevels(dev, dcimage, dc));
+            dcimage = std::move(dc);
         }
         else haveOriginal = false;
     }
     if ((!tMips || info.mipLevels != tMips) && (info.width > 1 || info.height > 1 || info.depth > 1))
     {
-        ScratchImage t;
-        if (info.dimension == TEX_DIMENSION_TEXTURE3D) check("mipmaps", GenerateMipMaps3D(dev, image.GetImages(), image.GetImageCount(), info, filter3D, tMips, t));
-        else check("mipmaps", GenerateMipMaps(dev, image.GetImages(), image.GetImageCount(), info, filter, tMips, t));
+        DeviceScratchImage t;
+        if (info.dimension == TEX_DIMENSION_TEXTURE3D) check("mipmaps", GenerateMipMaps3D(dev, image, filter3D, tMips, t));
+        else check("mipmaps", GenerateMipMaps(dev, image, filter, tMips, t));
         keep(t);
         haveOriginal = false;
     }
@@ -397,10 +376,8 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
     // --- keep the alpha-test coverage of level 0 in the smaller levels
     if (keepCoverage && info.mipLevels != 1)
     {
-        ScratchImage t;
-        check("keepcoverage", t.Initialize(info));
-        for (size_t item = 0; item < info.arraySize; ++item)
-            check("keepcoverage", ScaleMipMapsAlphaForCoverage(dev, image.GetImage(0, item, 0), info.mipLevels, info, item, o.keepCoverage, t));
+        DeviceScratchImage t;
+        check("keepcoverage", ScaleMipMapsAlphaForCoverage(dev, image, o.keepCoverage, t));
         image = std::move(t);
         haveOriginal = false;
     }
@@ -411,8 +388,8 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
         if (info.IsPMAlpha()) std::printf("WARNING: image is already using premultiplied alpha\n");
         else
         {
-            ScratchImage t;
-            check("premultiply alpha", PremultiplyAlpha(dev, image.GetImages(), image.GetImageCount(), info, TEX_PMALPHA_FLAGS(TEX_PMALPHA_DEFAULT | o.srgb), t));
+            DeviceScratchImage t;
+            check("premultiply alpha", PremultiplyAlphaWithMode(dev, image, info, TEX_PMALPHA_FLAGS(TEX_PMALPHA_DEFAULT | o.srgb), t));
             info.miscFlags2 = t.GetMetadata().miscFlags2;
             image = std::move(t);
             haveOriginal = false;
@@ -420,23 +397,27 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
     }
 
     // --- compress
+    bool handThrough = false;
     if (IsCompressed(tformat))
     {
         if (haveOriginal && cimage.GetMetadata().format == tformat)
         {
             // nothing touched the texels and the input already has the target format: hand its blocks through (:3566-3574)
-            keep(cimage);
+            handThrough = true;
+            const uint32_t misc2 = info.miscFlags2;
+            info = cimage.GetMetadata(); info.miscFlags2 = misc2;
+            image = std::move(dcimage);
         }
         else
         {
             if ((info.width % 4) || (info.height % 4)) std::printf("WARNING: block-compressed texture whose size is not a multiple of 4\n");
-            ScratchImage t;
-            check("compress", Compress(dev, image.GetImages(), image.GetImageCount(), info, tformat, TEX_COMPRESS_FLAGS(o.compress | o.srgb), o.alphaThreshold, t));
+            DeviceScratchImage t;
+            check("compress", Compress(dev, image, tformat, TEX_COMPRESS_FLAGS(o.compress | o.srgb), o.alphaThreshold, t));
             keep(t);
         }
     }
 
-    // --- alpha mode (texconv.cpp:3738-3766)
+    // --- alpha mode (texconv.cpp:3738-3766): a reduction on the device, compressed results decoded there
     if (HasAlpha(info.format) && info.format != DXGI_FORMAT_A8_UNORM)
     {
         if (IsAlphaAllOpaque(dev, image)) info.SetAlphaMode(TEX_ALPHA_MODE_OPAQUE);
@@ -452,15 +433,27 @@ void ConvertOne(Device& dev, const Options& o, const std::string& inFile, const 
         struct stat st;
         if (::stat(outFile.c_str(), &st) == 0) { std::printf("skipping %s: it exists (use -y to overwrite)\n", outFile.c_str()); return; }
     }
+    // --- the one download (blocks handed through are still on the host)
+    ScratchImage result;
+    if (handThrough) result = std::move(cimage);
+    else check("download", image.Download(result));
+    image.Release();
     uint32_t ddsFlags = DDS_FLAGS_NONE;
     if (o.dx10) ddsFlags |= DDS_FLAGS_FORCE_DX10_EXT | DDS_FLAGS_FORCE_DX10_EXT_MISC2;
     else if (o.dx9) ddsFlags |= DDS_FLAGS_FORCE_DX9_LEGACY;
-    if (o.hdrOut) check("save", SaveToHDRFile(image.GetImages()[0], outFile.c_str()));                     // level 0 of the first item, like texconv's non-DDS codecs
-    else if (o.tgaOut) check("save", SaveToTGAFile(image.GetImages()[0], TGA_FLAGS_NONE, outFile.c_str(), o.tga20 ? &info : nullptr));      // -tga20: with the TGA 2.0 extension area
-    else check("save", SaveToDDSFile(image.GetImages(), image.GetImageCount(), info, DDS_FLAGS(ddsFlags), outFile.c_str()));
+    if (o.hdrOut) check("save", SaveToHDRFile(result.GetImages()[0], outFile.c_str()));                     // level 0 of the first item, like texconv's non-DDS codecs
+    else if (o.tgaOut) check("save", SaveToTGAFile(result.GetImages()[0], TGA_FLAGS_NONE, outFile.c_str(), o.tga20 ? &info : nullptr));      // -tga20: with the TGA 2.0 extension area
+    else check("save", SaveToDDSFile(result.GetImages(), result.GetImageCount(), info, DDS_FLAGS(ddsFlags), outFile.c_str()));
     std::printf("writing %s (%zux%zu", outFile.c_str(), info.width, info.height);
     if (info.dimension == TEX_DIMENSION_TEXTURE3D) std::printf("x%zu", info.depth);
     std::printf(", %zu mips, %zu items, format %u)\n", info.mipLevels, info.arraySize, unsigned(info.format));
+    if (o.timing)
+    {
+        uint64_t up = 0, down = 0;
+        GetTransferBytes(dev, up, down);
+        std::printf("  %s: %.3f ms, host -> device %llu bytes, device -> host %llu bytes\n", inFile.c_str(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), (unsigned long long)(up - up0), (unsigned long long)(down - down0));
+    }
 }
 }
 
@@ -522,6 +515,14 @@ int main(int argc, char** argv)
             }
         }
     };
+    // Two (-overlap n) workers per GPU, each with its own Device: while one worker's kernels run, the other reads, decodes and uploads its next
+    // file (or downloads and writes its last one), so the PCIe transfers and the file codecs of file k + 1 overlap the kernels of file k.
+    if (o.overlap > 1 && o.inputs.size() > o.gpus.size())
+    {
+        std::vector<int> expanded;
+        for (size_t r = 0; r < o.overlap; ++r) expanded.insert(expanded.end(), o.gpus.begin(), o.gpus.end());
+        o.gpus = expanded;
+    }
     const auto t0 = std::chrono::steady_clock::now();
     const size_t workers = std::min(o.gpus.size(), o.inputs.size());
     if (workers <= 1) work(0, 1);

@@ -92,7 +92,8 @@ typedef struct dxtex_ctx dxtex_ctx;
 dxtex_hresult dxtex_ctx_create(int device, dxtex_ctx** out);
 void          dxtex_ctx_destroy(dxtex_ctx* ctx);
 /* Run subsequent work on a caller-owned hipStream_t (e.g. the current PyTorch stream); NULL restores
- * the context's own stream. */
+ * the context's own stream. Waits for the work queued on the previous stream, which must outlive this call (a handle
+ * the runtime no longer knows is tolerated); DXTEX_E_FAIL, stream unchanged, if that work failed asynchronously. */
 dxtex_hresult dxtex_ctx_set_stream(dxtex_ctx* ctx, void* hip_stream);
 void*         dxtex_ctx_get_stream(dxtex_ctx* ctx);
 dxtex_hresult dxtex_ctx_synchronize(dxtex_ctx* ctx);
@@ -215,6 +216,33 @@ dxtex_hresult dxtex_device_alloc(dxtex_ctx* ctx, size_t bytes, void** out);
 dxtex_hresult dxtex_device_free(dxtex_ctx* ctx, void* p);
 dxtex_hresult dxtex_memcpy_h2d(dxtex_ctx* ctx, void* dst, const void* src, size_t bytes);
 dxtex_hresult dxtex_memcpy_d2h(dxtex_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* ---- the device-resident pipeline (texconv's resize -> convert -> mipmaps -> compress chain, Texconv/texconv.cpp:2609, 3109, 3434,
+ * 3711, with ONE upload of the source and ONE download of the final payload; the reference's own GPU path keeps its intermediate
+ * in device memory the same way, DirectXTexCompressGPU.cpp:34-140) -------------------------------------------------------------
+ * The *_device entry points above are the steps; these are what a host needs around them. All are stream-ordered on the context's
+ * stream unless stated. */
+/* hipMemsetAsync on the context's stream: a device image starts zero-filled like ScratchImage's memory (DirectXTexImage.cpp:376). */
+dxtex_hresult dxtex_device_memset(dxtex_ctx* ctx, void* p, int value, size_t bytes);
+/* Device-to-device copy of `rows` rows of `rowBytes` bytes between two pitched images (Setup2DMips' copy of the base image into
+ * the top of the chain, DirectXTexMipmaps.cpp:851-904). */
+dxtex_hresult dxtex_copy_rows_device(dxtex_ctx* ctx, void* dst, size_t dstPitch, const void* src, size_t srcPitch, size_t rowBytes, size_t rows);
+/* Asynchronous transfers on the context's stream (host memory from dxtex_host_alloc is page-locked, so these overlap with the
+ * kernels of other contexts of the same GPU and return at once; with pageable memory they are staged by the runtime). The host
+ * buffer must stay valid until dxtex_ctx_synchronize. */
+dxtex_hresult dxtex_memcpy_h2d_async(dxtex_ctx* ctx, void* dst, const void* src, size_t bytes);
+dxtex_hresult dxtex_memcpy_d2h_async(dxtex_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* Page-locked host memory for the two ends of the pipeline. */
+dxtex_hresult dxtex_host_alloc(dxtex_ctx* ctx, size_t bytes, void** out);
+dxtex_hresult dxtex_host_free(dxtex_ctx* ctx, void* p);
+/* ScratchImage::IsAlphaAllOpaque (DirectXTexImage.cpp:800-852) over `count` device images of one format: *opaque = 1 when every
+ * texel's alpha is >= 0.997 (uncompressed; LoadScanline's alpha) or >= 0.99 (BC1 / BC2 / BC3 / BC7, decoded as IsAlphaAllOpaqueBC
+ * does, DirectXTexCompress.cpp:537-625), or when the format has no alpha. Synchronises the stream (4 bytes come back). */
+dxtex_hresult dxtex_alpha_all_opaque_device(dxtex_ctx* ctx, const dxtex_image* images, size_t count, int* opaque);
+/* Bytes this context has moved over PCIe since its creation or the last reset (every host <-> device copy the library issues for
+ * it, staging and tables included): what tests/ and bench.py use to show that a resident pipeline uploads the source once and
+ * downloads the payload once. */
+dxtex_hresult dxtex_ctx_transfer_bytes(dxtex_ctx* ctx, uint64_t* h2d_bytes, uint64_t* d2h_bytes, int reset);
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,7 @@
 // produced by the C ABI, and every failure releases the result as the reference does.
 #include "DirectXTexP.h"
 #include <dxtex_amd.h>
+#include "MI355XContext.h"
 #include <vector>
 
 namespace DirectX
@@ -28,12 +29,6 @@ namespace
         return dxtex_image{ i.width, i.height, int32_t(i.format), i.rowPitch, i.slicePitch, i.pixels };
     }
 
-    struct Ctx
-    {
-        dxtex_ctx* h = nullptr;
-        explicit Ctx(int device) noexcept { if (dxtex_ctx_create(device, &h) != DXTEX_S_OK) h = nullptr; }
-        ~Ctx() { dxtex_ctx_destroy(h); }
-    };
 }
 
 // DirectXTexCompressGPU.cpp:320-470: one Prepare per mip size (GPUCompressBC::Prepare, :392), then the images of that size.
@@ -47,8 +42,8 @@ HRESULT DirectX::CompressMI355X(int hipDevice, const Image* srcImages, size_t ni
     if (IsTypeless(format) || IsTypeless(metadata.format) || IsPlanar(metadata.format) || IsPalettized(metadata.format))
         return HRESULT_E_NOT_SUPPORTED;                                                               // :338-340
     cImages.Release();
-    Ctx ctx(hipDevice);
-    if (!ctx.h) return E_FAIL;
+    dxtex_ctx* const ctx = MI355X::ContextFor(hipDevice);          // one per (thread, device), kept: MI355XContext.h
+    if (!ctx) return E_FAIL;
     TexMetadata mdata2 = metadata;
     mdata2.format = format;
     HRESULT hr = cImages.Initialize(mdata2);                                                          // :353-358
@@ -63,7 +58,7 @@ HRESULT DirectX::CompressMI355X(int hipDevice, const Image* srcImages, size_t ni
     for (size_t level = 0; level < metadata.mipLevels; ++level)
     {
         size_t held = 0;
-        hr = HRESULT(dxtex_ctx_prepare(ctx.h, w, h, int32_t(metadata.format), int32_t(format), uint32_t(compress), metadata.arraySize, &held));      // Prepare, :392
+        hr = HRESULT(dxtex_ctx_prepare(ctx, w, h, int32_t(metadata.format), int32_t(format), uint32_t(compress), metadata.arraySize, &held));      // Prepare, :392
         if (FAILED(hr)) { cImages.Release(); return hr; }
         for (size_t item = 0; item < metadata.arraySize; ++item)
         {
@@ -76,7 +71,7 @@ HRESULT DirectX::CompressMI355X(int hipDevice, const Image* srcImages, size_t ni
         if (h > 1) h >>= 1;
         if (w > 1) w >>= 1;
     }
-    hr = HRESULT(dxtex_compress_many(ctx.h, srcs.data(), dsts.data(), srcs.size(), uint32_t(compress), threshold));
+    hr = HRESULT(dxtex_compress_many(ctx, srcs.data(), dsts.data(), srcs.size(), uint32_t(compress), threshold));
     if (FAILED(hr)) cImages.Release();
     return hr;
 }
@@ -98,10 +93,10 @@ HRESULT DirectX::DecompressMI355X(int hipDevice, const Image& cImage, DXGI_FORMA
     if (FAILED(hr)) return hr;
     const Image* img = image.GetImage(0, 0, 0);
     if (!img) { image.Release(); return E_POINTER; }
-    Ctx ctx(hipDevice);
-    if (!ctx.h) { image.Release(); return E_FAIL; }
+    dxtex_ctx* const ctx = MI355X::ContextFor(hipDevice);          // one per (thread, device), kept: MI355XContext.h
+    if (!ctx) { image.Release(); return E_FAIL; }
     const dxtex_image src = View(cImage), dst = View(*img);
-    hr = HRESULT(dxtex_decompress(ctx.h, &src, &dst));
+    hr = HRESULT(dxtex_decompress(ctx, &src, &dst));
     if (FAILED(hr)) image.Release();                                                                   // :890-894
     return hr;
 }
@@ -128,11 +123,11 @@ HRESULT DirectX::GenerateMipMapsMI355X(int hipDevice, const Image& baseImage, TE
         const size_t size = std::min<size_t>(baseImage.rowPitch, dest->rowPitch);
         for (size_t y = 0; y < baseImage.height; ++y) { memcpy(pDest, pSrc, size); pSrc += baseImage.rowPitch; pDest += dest->rowPitch; }
     }
-    Ctx ctx(hipDevice);
-    if (!ctx.h) { mipChain.Release(); return E_FAIL; }
+    dxtex_ctx* const ctx = MI355X::ContextFor(hipDevice);          // one per (thread, device), kept: MI355XContext.h
+    if (!ctx) { mipChain.Release(); return E_FAIL; }
     std::vector<dxtex_image> chain;
     for (size_t level = 0; level < levels; ++level) chain.push_back(View(*mipChain.GetImage(level, 0, 0)));
-    hr = HRESULT(dxtex_generate_mips(ctx.h, chain.data(), chain.size(), uint32_t(filter)));
+    hr = HRESULT(dxtex_generate_mips(ctx, chain.data(), chain.size(), uint32_t(filter)));
     if (FAILED(hr)) mipChain.Release();
     return hr;
 }
@@ -150,10 +145,10 @@ HRESULT DirectX::ResizeMI355X(int hipDevice, const Image& srcImage, size_t width
     if (FAILED(hr)) return hr;
     const Image* rimage = image.GetImage(0, 0, 0);
     if (!rimage) { image.Release(); return E_POINTER; }
-    Ctx ctx(hipDevice);
-    if (!ctx.h) { image.Release(); return E_FAIL; }
+    dxtex_ctx* const ctx = MI355X::ContextFor(hipDevice);          // one per (thread, device), kept: MI355XContext.h
+    if (!ctx) { image.Release(); return E_FAIL; }
     const dxtex_image src = View(srcImage), dst = View(*rimage);
-    hr = HRESULT(dxtex_resize(ctx.h, &src, &dst, uint32_t(filter)));
+    hr = HRESULT(dxtex_resize(ctx, &src, &dst, uint32_t(filter)));
     if (FAILED(hr)) image.Release();                                                                    // :922-926
     return hr;
 }
@@ -173,10 +168,10 @@ HRESULT DirectX::ConvertMI355X(int hipDevice, const Image& srcImage, DXGI_FORMAT
     if (FAILED(hr)) return hr;
     const Image* rimage = image.GetImage(0, 0, 0);
     if (!rimage) { image.Release(); return E_POINTER; }
-    Ctx ctx(hipDevice);
-    if (!ctx.h) { image.Release(); return E_FAIL; }
+    dxtex_ctx* const ctx = MI355X::ContextFor(hipDevice);          // one per (thread, device), kept: MI355XContext.h
+    if (!ctx) { image.Release(); return E_FAIL; }
     const dxtex_image src = View(srcImage), dst = View(*rimage);
-    hr = HRESULT(dxtex_convert(ctx.h, &src, &dst, uint32_t(filter), threshold));
+    hr = HRESULT(dxtex_convert(ctx, &src, &dst, uint32_t(filter), threshold));
     if (FAILED(hr)) image.Release();                                                                    // :5168-5172
     return hr;
 }

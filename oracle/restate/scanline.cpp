@@ -260,8 +260,10 @@ bool DirectX::Internal::LoadScanline(XMVECTOR* pDestination, size_t count, const
         for (size_t i = 0, n = texels(4); i < n; ++i)
         {
             uint32_t u; memcpy(&u, s + i * 4, 4);
-            pDestination[i] = XMVectorSet(float(int32_t(u & 0x3FF) - 0x180) / 510.0f, float(int32_t((u >> 10) & 0x3FF) - 0x180) / 510.0f,
-                                          float(int32_t((u >> 20) & 0x3FF) - 0x180) / 510.0f, float(u >> 30) / 3.0f);
+            // the SSE2 path multiplies by XRMul = { 1/510, 1/(510*2^10), 1/(510*2^20), 1/(3*2^30) } after subtracting the bias in place
+            const float m = 1.0f / 510.0f;
+            pDestination[i] = XMVectorSet(float(int32_t(u & 0x3FF) - 0x180) * m, float(int32_t((u >> 10) & 0x3FF) - 0x180) * m,
+                                          float(int32_t((u >> 20) & 0x3FF) - 0x180) * m, float(u >> 30) * (1.0f / 3.0f));
         }
         return true;
     case DXGI_FORMAT_AYUV:                      // :1291-1326

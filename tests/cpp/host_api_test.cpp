@@ -285,6 +285,81 @@ static int gpu_run(const std::string& outdir)
         CHECK(CompressEx(dev, src, DXGI_FORMAT_BC1_UNORM, co, ex, record) == S_OK && calls.size() == 2);
     }
 
+    // ---- the device-resident pipeline: the same steps on DeviceScratchImages, one upload, one download, identical bytes ----------------
+    {
+        auto same = [](const ScratchImage& a, const ScratchImage& b) { return a.GetPixelsSize() == b.GetPixelsSize() && a.GetImageCount() == b.GetImageCount() &&
+                                                                          std::memcmp(a.GetPixels(), b.GetPixels(), a.GetPixelsSize()) == 0; };
+        ScratchImage srcS, got;
+        CHECK(srcS.InitializeFromImage(src) == S_OK);
+        uint64_t up = 0, down = 0;
+        GetTransferBytes(dev, up, down, true);
+        DeviceScratchImage dsrc, dmips, dbc3, dbc7, dback, dresized, dconv, dconvAll, dresizedAll, dpm, dcov, dtop;
+        CHECK(dsrc.Upload(dev, srcS) == S_OK);
+        CHECK(dsrc.GetImageCount() == 1 && dsrc.GetMetadata().width == W && dsrc.GetImage(0, 0, 0)->rowPitch == W * 4 && dsrc.GetDevice() == &dev);
+        // resize -> convert -> mipmaps -> compress, texconv's order, without leaving the device
+        CHECK(GenerateMipMaps(dev, dsrc, TEX_FILTER_CUBIC, 0, dmips) == S_OK && dmips.GetMetadata().mipLevels == 7 && dmips.GetImageCount() == 7);
+        CHECK(Compress(dev, dmips, DXGI_FORMAT_BC3_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, dbc3) == S_OK);
+        GetTransferBytes(dev, up, down);
+        CHECK(up == srcS.GetPixelsSize() && down == 0);                       // nothing but the source has crossed PCIe so far
+        CHECK(dbc3.Download(got) == S_OK && same(got, bc3));
+        GetTransferBytes(dev, up, down);
+        CHECK(up == srcS.GetPixelsSize() && down == bc3.GetPixelsSize());     // one upload, one download
+        CHECK(dmips.Download(got) == S_OK && same(got, mips));
+        CHECK(Compress(dev, dmips, DXGI_FORMAT_BC7_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, dbc7) == S_OK && dbc7.Download(got) == S_OK && same(got, bc7chain));
+        CHECK(Compress(dev, dsrc, DXGI_FORMAT_BC7_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, dbc7) == S_OK && dbc7.Download(got) == S_OK && same(got, bc7));
+        CHECK(Decompress(dev, dbc7, DXGI_FORMAT_UNKNOWN, dback) == S_OK && dback.GetMetadata().format == DXGI_FORMAT_R8G8B8A8_UNORM && dback.Download(got) == S_OK && same(got, back));
+        CHECK(Resize(dev, dsrc, 50, 70, TEX_FILTER_TRIANGLE, dresized) == S_OK && dresized.Download(got) == S_OK && same(got, resized));
+        CHECK(Convert(dev, dsrc, DXGI_FORMAT_R16G16B16A16_FLOAT, TEX_FILTER_DEFAULT, 0.5f, dconv) == S_OK && dconv.Download(got) == S_OK && same(got, conv));
+        CHECK(Convert(dev, dmips, DXGI_FORMAT_B8G8R8A8_UNORM, TEX_FILTER_DEFAULT, 0.5f, dconvAll) == S_OK && dconvAll.Download(got) == S_OK && same(got, convAll));
+        CHECK(Resize(dev, dmips, 40, 24, TEX_FILTER_LINEAR, dresizedAll) == S_OK && dresizedAll.GetMetadata().mipLevels == 1 && dresizedAll.Download(got) == S_OK && same(got, resizedAll));
+        CHECK(PremultiplyAlpha(dev, dsrc, TEX_PMALPHA_DEFAULT, dpm) == S_OK && dpm.GetMetadata().IsPMAlpha() && dpm.Download(got) == S_OK && same(got, pm));
+        CHECK(ScaleMipMapsAlphaForCoverage(dev, dmips, 0.6f, dcov) == S_OK && dcov.Download(got) == S_OK && same(got, cov));
+        CHECK(CopyTopLevels(dev, dmips, dtop) == S_OK && dtop.GetMetadata().mipLevels == 1 && dtop.Download(got) == S_OK && same(got, srcS));
+        // alpha scan: this image has alpha 192 .. 255; an opaque copy; the BC forms (decoded on the device, threshold 0.99)
+        CHECK(!IsAlphaAllOpaque(dev, dsrc) && !IsAlphaAllOpaque(dev, dbc3));
+        {
+            std::vector<uint8_t> opq(px);
+            for (size_t i = 3; i < opq.size(); i += 4) opq[i] = (i % 8 == 3) ? 255 : 254;           // 254 / 255 = 0.9961 < 0.997: not opaque as RGBA8 ...
+            Image o = src; o.pixels = opq.data();
+            ScratchImage oS; DeviceScratchImage dO, dOB;
+            CHECK(oS.InitializeFromImage(o) == S_OK && dO.Upload(dev, oS) == S_OK && !IsAlphaAllOpaque(dev, dO));
+            CHECK(Compress(dev, dO, DXGI_FORMAT_BC3_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, dOB) == S_OK && IsAlphaAllOpaque(dev, dOB));    // ... but >= 0.99 once block-compressed
+            for (size_t i = 3; i < opq.size(); i += 4) opq[i] = 255;
+            CHECK(dO.Upload(dev, &o, 1, oS.GetMetadata()) == S_OK && IsAlphaAllOpaque(dev, dO));
+            CHECK(Compress(dev, dO, DXGI_FORMAT_BC1_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, dOB) == S_OK && IsAlphaAllOpaque(dev, dOB));
+            CHECK(Compress(dev, dO, DXGI_FORMAT_BC5_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, dOB) == S_OK && IsAlphaAllOpaque(dev, dOB));    // no alpha channel: opaque
+        }
+        // a padded source uploaded image by image
+        {
+            std::vector<uint8_t> wide(H * (W * 4 + 32), 0xEE);
+            for (size_t y = 0; y < H; ++y) std::memcpy(&wide[y * (W * 4 + 32)], &px[y * W * 4], W * 4);
+            Image wsrc = src; wsrc.rowPitch = W * 4 + 32; wsrc.slicePitch = wide.size(); wsrc.pixels = wide.data();
+            DeviceScratchImage dw;
+            CHECK(dw.Upload(dev, &wsrc, 1, srcS.GetMetadata()) == S_OK && dw.Download(got) == S_OK && same(got, srcS));
+        }
+        // a volume
+        {
+            const size_t VW = 32, VH = 16, VD = 8;
+            std::vector<Image> slices(VD);
+            for (size_t z = 0; z < VD; ++z) { slices[z] = src; slices[z].width = VW; slices[z].height = VH; slices[z].pixels = px.data() + (z * 4) * src.rowPitch + (z * 8) * 4; }
+            ScratchImage vbase, vol;
+            CHECK(vbase.Initialize3DFromImages(slices.data(), VD) == S_OK && GenerateMipMaps3D(dev, slices.data(), VD, TEX_FILTER_CUBIC, 0, vol) == S_OK);
+            DeviceScratchImage dv, dvm;
+            CHECK(dv.Upload(dev, vbase) == S_OK && GenerateMipMaps3D(dev, dv, TEX_FILTER_CUBIC, 0, dvm) == S_OK && dvm.Download(got) == S_OK && same(got, vol));
+        }
+        // error behaviour matches the host overloads; a failed step leaves its output released
+        DeviceScratchImage dbad, dnone;
+        CHECK(Compress(dev, dbc7, DXGI_FORMAT_BC1_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, dbad) == E_INVALIDARG);
+        CHECK(Compress(dev, dsrc, DXGI_FORMAT_R8G8B8A8_UNORM, TEX_COMPRESS_DEFAULT, 0.5f, dbad) == E_INVALIDARG);
+        CHECK(Convert(dev, dsrc, DXGI_FORMAT_R8G8B8A8_UNORM, TEX_FILTER_DEFAULT, 0.5f, dbad) == E_INVALIDARG);
+        CHECK(GenerateMipMaps(dev, dsrc, TEX_FILTER_BOX, 0, dbad) == E_FAIL && dbad.GetPixels() == nullptr);      // 96 is not a power of two
+        CHECK(Resize(dev, dnone, 8, 8, TEX_FILTER_LINEAR, dbad) == E_INVALIDARG);                                   // nothing uploaded
+        CHECK(dnone.Download(got) == E_POINTER);
+        Device other;                                                                                               // an image belongs to its Device
+        CHECK(Resize(other, dsrc, 8, 8, TEX_FILTER_LINEAR, dbad) == E_INVALIDARG);
+        std::puts("resident pipeline OK");
+    }
+
     float mse = 0, v[4];
     CHECK(ComputeMSE(dev, src, *bc7.GetImage(0, 0, 0), mse, v) == S_OK);
     std::printf("mse %.9g %.9g %.9g %.9g %.9g\n", mse, v[0], v[1], v[2], v[3]);

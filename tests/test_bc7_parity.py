@@ -96,6 +96,7 @@ def test_multi_pass_images(oracle):
         import sys; sys.path.insert(0, %r)
         import numpy as np, directxtex_amd as dx, oracle
         from directxtex_amd import synth
+        dx.capi.load(dev=True)             # only the -DDXTEX_DEV build reads knobs
         c = dx.Context(0)
         w, h = 52, 36                      # 13 x 9 = 117 blocks, 7 passes of 17 blocks
         img = synth.rgba8(w, h, seed=8, alpha="smooth")
@@ -104,7 +105,7 @@ def test_multi_pass_images(oracle):
         assert np.array_equal(c.compress(hdr, w, h, 10, 95, 0, 0.5), oracle.ref_compress_image(hdr, w, h, 10, 95, 0, 0.5))
         print("multi-pass OK")
     """ % root)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DXTEX_AMD_LIBRARY="dev", DXTEX_MAX_BLOCKS_PER_PASS="17"), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DXTEX_MAX_BLOCKS_PER_PASS="17"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "multi-pass OK" in r.stdout, r.stdout + r.stderr
 
 
@@ -119,6 +120,7 @@ def test_array_goes_through_one_block_list(oracle, pass_blocks):
         import sys; sys.path.insert(0, %r)
         import numpy as np, torch, directxtex_amd as dx, oracle
         from directxtex_amd import synth
+        if "--dev" in sys.argv: dx.capi.load(dev=True)          # only the -DDXTEX_DEV build reads knobs
         c = dx.Context(0); dev = torch.device("cuda", 0)
         base = synth.rgba8(40, 24, seed=3, alpha="smooth")
         imgs = [(m, w, h, 28) for m, (w, h) in zip(oracle.ref_generate_mips(base, 40, 24, 28, 0x200000, 6), oracle.mip_sizes(40, 24, 6))]
@@ -145,9 +147,8 @@ def test_array_goes_through_one_block_list(oracle, pass_blocks):
     """ % root)
     env = dict(os.environ)
     if pass_blocks:
-        env["DXTEX_AMD_LIBRARY"] = "dev"                     # only the -DDXTEX_DEV build reads knobs
         env["DXTEX_MAX_BLOCKS_PER_PASS"] = pass_blocks
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code] + (["--dev"] if pass_blocks else []), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "array OK" in r.stdout, r.stdout + r.stderr
 
 
@@ -158,13 +159,15 @@ def test_pruning_changes_nothing():
     short) are the same search, as is mode 1's PerturbOne with (default) and without (DXTEX_BC7_PERTURB_PLAIN) the bound filter, and BC6H's
     modes of equal endpoint precision sharing one search (default) or searching each from scratch (DXTEX_BC6H_NO_REUSE), and BC7's
     two-region modes in the encoder's order (DXTEX_BC6H_ORDER) instead of the default running order, and BC7's
-    whole-block tasks (modes 4 / 5 / 6) searched by groups of lanes (default on lists this short) or a lane each (DXTEX_BC7_NO_GROUP)."""
+    whole-block tasks (modes 4 / 5 / 6) searched by groups of lanes (default on lists this short) or a lane each (DXTEX_BC7_NO_GROUP), and the
+    late modes 4 / 5 on the context's side streams (default) or one after the other on its stream (DXTEX_BC7_SERIAL)."""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
         import sys, hashlib; sys.path.insert(0, %r)
         import numpy as np, directxtex_amd as dx
         from directxtex_amd import synth
+        if "--dev" in sys.argv: dx.capi.load(dev=True)          # only the -DDXTEX_DEV build reads knobs; the first run is the product library
         c = dx.Context(0)
         yy, xx = np.mgrid[0:256, 0:256]
         smooth = np.stack([xx, yy, (xx + yy) // 2, 255 - xx // 2], -1).astype(np.uint8)
@@ -179,11 +182,9 @@ def test_pruning_changes_nothing():
                 print(hashlib.sha256(c.compress(hdr, w, h, 10, fmt, 0, 0.5).tobytes()).hexdigest())
     """ % root)
     outs = []
-    for env in ({}, {"DXTEX_BC7_NO_PRUNE": "1", "DXTEX_BC6H_NO_PRUNE": "1"}, {"DXTEX_BC7_ORDER": "7,6,5,8,4,3,2,1,0", "DXTEX_BC7_PERTURB_PLAIN": "1", "DXTEX_BC7_NO_GROUP": "1"},
+    for env in ({}, {"DXTEX_BC7_NO_PRUNE": "1", "DXTEX_BC6H_NO_PRUNE": "1"}, {"DXTEX_BC7_ORDER": "7,6,5,8,4,3,2,1,0", "DXTEX_BC7_PERTURB_PLAIN": "1", "DXTEX_BC7_NO_GROUP": "1", "DXTEX_BC7_SERIAL": "1"},
                 {"DXTEX_BC7_ORDER": "26,25,3,1,16,7,15,14,18,24,28,0,2", "DXTEX_BC6H_WAVE_MAX": "0", "DXTEX_BC6H_NO_REUSE": "1", "DXTEX_BC6H_ORDER": "0,1,2,3,4,5,6,7,8,9"}):
-        if env:
-            env = dict(env, DXTEX_AMD_LIBRARY="dev")         # only the -DDXTEX_DEV build reads knobs; the first run is the product library
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, "-c", code] + (["--dev"] if env else []), env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.split())
     assert len(outs[0]) == 20

@@ -201,3 +201,43 @@ def test_files_dealt_out_over_worker_contexts(tmp_path, oracle):
     for i, (p, img) in enumerate(srcs):
         want = oracle.ref_save_dds(oracle.ref_compress_image(img, w, h, RGBA8, 98, 0, 0.5), w, h, 98)
         assert np.array_equal(np.fromfile(outdir / f"t{i}.dds", np.uint8), want), i
+
+
+def test_the_chain_stays_on_the_device(tmp_path, oracle):
+    """resize -> mipmaps -> keepcoverage -> BC3 on ONE uploaded copy (DeviceScratchImage): the bytes are those of the
+    reference's step-by-step pipeline, and what crosses PCIe is the decoded source once and the final payload once (+ 8-byte
+    reduction results: the alpha scans and the coverage bisection) - `-timing` prints the context's transfer counters."""
+    import re
+    w, h = 200, 120
+    img = synth.rgba8(w, h, seed=131, alpha="smooth")
+    src = tmp_path / "in.dds"; out = tmp_path / "out.dds"
+    oracle.ref_save_dds(img, w, h, RGBA8).tofile(src)
+    txt = _run(["-w", "128", "-h", "64", "-m", "0", "-if", "CUBIC", "-keepcoverage", "0.4", "-f", "BC3_UNORM", "-timing", "-overlap", "1", "-o", str(out), str(src)])
+    small = oracle.ref_resize(img, w, h, RGBA8, 128, 64, 0x300000)
+    sizes = oracle.mip_sizes(128, 64, 8)
+    mips = oracle.ref_generate_mips(small, 128, 64, RGBA8, 0x300000, 8)
+    cov = oracle.ref_scale_mips_alpha_for_coverage(mips, 128, 64, RGBA8, 0.4)
+    payload = np.concatenate([oracle.ref_compress_image(m, a, b, RGBA8, 77, 0, 0.5) for m, (a, b) in zip(cov, sizes)])
+    assert np.array_equal(np.fromfile(out, np.uint8), oracle.ref_save_dds(payload, 128, 64, 77, 1, 8))
+    m = re.search(r"host -> device (\d+) bytes, device -> host (\d+) bytes", txt)
+    assert m, txt
+    up, down = int(m.group(1)), int(m.group(2))
+    assert up == w * h * 4, (up, w * h * 4)
+    assert payload.size <= down <= payload.size + 8 * (2 + 1 + 10 * 7), (down, payload.size)
+
+
+def test_two_workers_per_gpu_by_default(tmp_path, oracle):
+    """more files than GPUs: two contexts per GPU take turns, so one file's codec work and transfers overlap another's kernels; the
+    outputs are those of one worker."""
+    w = h = 48
+    outdir = tmp_path / "out"; outdir.mkdir()
+    srcs = []
+    for i in range(4):
+        img = synth.rgba8(w, h, seed=140 + i, alpha="opaque")
+        p = tmp_path / f"u{i}.dds"
+        oracle.ref_save_dds(img, w, h, RGBA8).tofile(p)
+        srcs.append((p, img))
+    _run(["-f", "BC1_UNORM", "-m", "1", "-nologo", "-o", str(outdir)] + [str(p) for p, _ in srcs])
+    for i, (p, img) in enumerate(srcs):
+        want = oracle.ref_save_dds(oracle.ref_compress_image(img, w, h, RGBA8, 71, 0, 0.5), w, h, 71)
+        assert np.array_equal(np.fromfile(outdir / f"u{i}.dds", np.uint8), want), i

@@ -36,8 +36,8 @@ def np_load(raw, fmt, n):
         return np.stack([(u & 1023).astype(F), ((u >> 10) & 1023).astype(F), ((u >> 20) & 1023).astype(F), (u >> 30).astype(F)], 1)
     if fmt == XR_BIAS:
         u = w[:, 0]
-        c = lambda s: (((u >> s) & 1023).astype(np.int32) - 0x180).astype(F) / F(510.0)
-        return np.stack([c(0), c(10), c(20), (u >> 30).astype(F) / F(3.0)], 1)
+        c = lambda s: (((u >> s) & 1023).astype(np.int32) - 0x180).astype(F) * (F(1.0) / F(510.0))       # the SSE2 path: a multiplication by float(1/510)
+        return np.stack([c(0), c(10), c(20), (u >> 30).astype(F) * (F(1.0) / F(3.0))], 1)
     if fmt == AYUV:
         b = raw.reshape(n, 4).astype(np.int64)
         v, u, y, a = b[:, 0] - 128, b[:, 1] - 128, b[:, 2] - 16, b[:, 3]

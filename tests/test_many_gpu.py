@@ -44,6 +44,7 @@ CODE = textwrap.dedent("""
     import numpy as np, directxtex_amd as dx, oracle
     from directxtex_amd import synth
     from directxtex_amd.capi import DxtexError
+    if "--dev" in sys.argv: dx.capi.load(dev=True)          # only the -DDXTEX_DEV build reads knobs
     shapes = %(shapes)r
     PARALLEL = 0x10000000              # TEX_COMPRESS_PARALLEL for the reference side only: CompressBC_Parallel, the same bytes on all host cores
     items, tight = [], []
@@ -95,6 +96,6 @@ def test_compress_many_steady_state(oracle, chunk_texels):
     library's default (one chunk): BC7 and BC1 payloads of 16 uneven images in two source formats, byte-identical to the reference."""
     env = dict(os.environ)
     if chunk_texels:
-        env.update(DXTEX_AMD_LIBRARY="dev", DXTEX_MANY_CHUNK_TEXELS=chunk_texels)
-    r = subprocess.run([sys.executable, "-c", CODE % {"root": ROOT, "shapes": SHAPES}], env=env, capture_output=True, text=True, timeout=900)
+        env.update(DXTEX_MANY_CHUNK_TEXELS=chunk_texels)
+    r = subprocess.run([sys.executable, "-c", CODE % {"root": ROOT, "shapes": SHAPES}] + (["--dev"] if chunk_texels else []), env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "many OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -2,8 +2,8 @@
 # DEVELOPMENT TOOL: builds variants of the library that differ in compile-time definitions of ONE translation unit, for A/B runs on
 # the GPU box in one gpurun call.
 #   build (here):   tools/ab_variants.sh build bc7_encode.hip  v6="-DDXTEX_ROUGH_WGS=6" v7="-DDXTEX_ROUGH_WGS=7" ...
-#   run (GPU box):  tools/ab_variants.sh run "python tools/r03_quick.py bc7"       -> runs the command once per variant in build/variants/
-# A variant replaces lib/libdxtex_amd_dev.so for its run (DXTEX_AMD_LIBRARY=dev); the product library is not touched.
+#   run (GPU box):  tools/ab_variants.sh run "python tools/r03_quick.py --dev bc7" -> runs the command once per variant in build/variants/
+# A variant replaces lib/libdxtex_amd_dev.so for its run (the command selects the development build itself: --dev); the product library is not touched.
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$HERE/..
 CS=$ROOT/directxtex_amd/csrc; OBJ=$ROOT/build/obj; VAR=$ROOT/build/variants
@@ -32,7 +32,7 @@ else
   for v in $VAR/*.so; do
     echo "=== variant $(basename $v .so)"
     cp $v $ROOT/directxtex_amd/lib/libdxtex_amd_dev.so
-    DXTEX_AMD_LIBRARY=dev bash -c "$*" 2>&1 | grep -v amdgpu.ids
+    bash -c "$*" 2>&1 | grep -v amdgpu.ids
   done
   cp /tmp/dev_keep.so $ROOT/directxtex_amd/lib/libdxtex_amd_dev.so
 fi

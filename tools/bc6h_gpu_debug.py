@@ -22,9 +22,9 @@ for t in range(len(sel)):
 ctx.close()
 for mode in range(14):
     for ns in (0, 1):
-        env = dict(os.environ, DXTEX_AMD_LIBRARY="dev", DXTEX_BC6H_ONLY_MODE=str(mode))
+        env = dict(os.environ, DXTEX_BC6H_ONLY_MODE=str(mode))
         if ns: env["DXTEX_BC6H_NO_SEARCH"] = "1"
-        code = ("import sys; sys.path.insert(0, %r); import numpy as np, directxtex_amd as dx; c = dx.Context(0); "
+        code = ("import sys; sys.path.insert(0, %r); import numpy as np, directxtex_amd as dx; dx.capi.load(dev=True); c = dx.Context(0); "
                 "t = np.fromfile(%r, np.float32).reshape(-1,16,4); o = c.encode_blocks(%d, t, 0); "
                 "print(' '.join(b.tobytes()[::-1].hex() for b in o))") % (ROOT, os.path.join(ROOT, "gpurun_out", "bc6h_bad_tiles.bin"), fmt)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)

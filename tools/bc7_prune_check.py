@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 def emit():
     import numpy as np, torch
     import directxtex_amd as dx
+    if "--dev" in sys.argv: dx.capi.load(dev=True)
     from directxtex_amd import synth
     import bench
     ctx = dx.Context(0); dev = torch.device("cuda", 0)
@@ -49,7 +50,7 @@ else:
     extra = ["--bc6h"] if "--bc6h" in sys.argv else []
     envs = [("unpruned", {"DXTEX_BC7_NO_PRUNE": "1", "DXTEX_BC6H_NO_PRUNE": "1"}), ("default", {})] + [("order " + o, {"DXTEX_BC7_ORDER": o}) for o in sys.argv[1:] if o[0].isdigit()]
     for tag, env in envs:
-        r = subprocess.run([sys.executable, __file__, "--emit"] + extra, env=dict(os.environ, DXTEX_AMD_LIBRARY="dev", **env), capture_output=True, text=True)
+        r = subprocess.run([sys.executable, __file__, "--emit", "--dev"] + extra, env=dict(os.environ, **env), capture_output=True, text=True)
         runs.append([l.split("|") for l in r.stdout.splitlines() if l.count("|") == 2])
         if r.returncode != 0: print(r.stderr[-2000:])
     ok = all(len(r) == len(runs[0]) for r in runs) and bool(runs[0])

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """DEVELOPMENT TOOL: per-kernel times of one 4096^2 BC7 encode (the context's hipEvent marks) and wall time of the small kernels, for
-A/B runs of development knobs: `DXTEX_AMD_LIBRARY=dev DXTEX_...=... python tools/r03_probe.py [bc7] [convert] [bc15] [decode]`."""
+A/B runs of development knobs: `DXTEX_...=... python tools/r03_probe.py --dev [bc7] [convert] [bc15] [decode]`."""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import directxtex_amd as dx
+if "--dev" in sys.argv:
+    sys.argv.remove("--dev"); dx.capi.load(dev=True)      # the -DDXTEX_DEV build: the only one that reads DXTEX_* knobs
 from directxtex_amd import synth
 
 what = set(sys.argv[1:]) or {"bc7"}

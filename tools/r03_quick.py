@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """DEVELOPMENT TOOL: torch-free A/B probe (device buffers through libamdhip64 directly, so a fresh GPU box does not pay for importing
 torch): wall time per image, the context's per-kernel times and the golden check of the full-size BC7 (cfg2) / BC6H (cfg3) encodes.
-usage: [DXTEX_AMD_LIBRARY=dev DXTEX_...=...] python tools/r03_quick.py [bc7] [bc6h] [bc1] [small]"""
+usage: [DXTEX_...=...] python tools/r03_quick.py [--dev] [bc7] [bc6h] [bc1] [small]"""
 import ctypes, hashlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 import directxtex_amd as dx
+if "--dev" in sys.argv:
+    sys.argv.remove("--dev"); dx.capi.load(dev=True)      # the -DDXTEX_DEV build: the only one that reads DXTEX_* knobs
 from directxtex_amd import synth
 
 hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so", mode=os.RTLD_LAZY)      # lazy: the image's HSA runtime lacks a symbol RTLD_NOW insists on
