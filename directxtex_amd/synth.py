@@ -131,3 +131,23 @@ def survey_rgba16f(width, height, seed=3):
         out[..., c] = np.exp2(e) * g * (0.75 + 0.5 * n)
     out[..., 3] = 1.0
     return np.minimum(out, 60000.0).astype(np.float16)
+
+
+def huge_rgba8(width, height, seed, noisy_block_rows, alpha="opaque"):
+    """An image of the sizes DirectXTexImage.cpp:127-131 allows (up to 16384^2) that the reference still encodes in minutes: every
+    4 x 4 block is one flat colour (a hash of its position: the encoders' early-outs), except the block rows listed in
+    `noisy_block_rows` (iterable of block-row indices), which carry the SURVEY 8d recipe (survey_rgba8 of that strip, seed + block row).
+    Put the noisy rows where the path has a seam: the first and last rows, around a multiple of 65536 texel rows' worth of bytes,
+    around block 2^22 (the BC6H / BC7 pass boundary). (H, W, 4) uint8."""
+    nbw, nbh = (width + 3) // 4, (height + 3) // 4
+    by, bx = np.meshgrid(np.arange(nbh, dtype=np.uint64), np.arange(nbw, dtype=np.uint64), indexing="ij")
+    h = _hash32(bx * 2654435761 + by * 40503 + seed * 97 + 1)
+    flat = np.empty((nbh, nbw, 4), np.uint8)
+    flat[..., 0] = h & 0xFF; flat[..., 1] = (h >> 8) & 0xFF; flat[..., 2] = (h >> 16) & 0xFF
+    flat[..., 3] = 255 if alpha == "opaque" else (h >> 24) & 0xFF
+    out = np.repeat(np.repeat(flat, 4, axis=0), 4, axis=1)[:height, :width].copy()
+    for r in sorted(set(int(v) for v in noisy_block_rows)):
+        if 0 <= r < nbh:
+            y0, y1 = r * 4, min(height, r * 4 + 4)
+            out[y0:y1] = survey_rgba8(width, 4, seed + r, alpha)[:y1 - y0]
+    return out
