@@ -32,7 +32,11 @@ def _open(dev):
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for the C ABI itself
         pass
-    return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL), path
+    # RTLD_LOCAL: the product and the development build export the same C++ symbols (dxtex::launch_*); with both in the global scope the
+    # second one's internal calls would bind to the first one's definitions and a development knob would silently do nothing. (The libraries
+    # are also linked with -Bsymbolic-functions, so each binds its own calls whatever the loader is told.) libamdhip64 is shared with
+    # PyTorch by its SONAME, not through this handle's visibility.
+    return ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL), path
 
 
 class Volume(ctypes.Structure):

@@ -52,6 +52,7 @@ struct dxtex_ctx
     std::vector<uint8_t> triHost;
     void* triPinned = nullptr; size_t triPinnedBytes = 0; hipEvent_t triConsumed = nullptr; bool triPending = false;
     void* mseBuf = nullptr; size_t mseBytes = 0;
+    void* bcQueues = nullptr; size_t bcQueuesBytes = 0;       // work queues of the streaming BC1 - BC5 kernel (launch_bc15_encode)
     // R32G32B32A32_FLOAT rows on their way into a format whose element holds several texels (launch_pack_group)
     void* groupRows = nullptr; size_t groupRowsBytes = 0;
     // dxtex_compress_many (host pointers): double-buffered pinned + device staging, copy streams on either side of ctx->stream
@@ -223,7 +224,9 @@ dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width,
     case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: case FMT_BC2_UNORM: case FMT_BC2_UNORM_SRGB:
     case FMT_BC3_UNORM: case FMT_BC3_UNORM_SRGB: case FMT_BC4_UNORM: case FMT_BC4_SNORM:
     case FMT_BC5_UNORM: case FMT_BC5_SNORM:
-        e = launch_bc15_encode(v, dDst, dstRowPitch, dstFormat, flags, threshold, ctx->stream);
+        hr = ensure(ctx, &ctx->bcQueues, &ctx->bcQueuesBytes, bc15_queue_bytes());
+        if (hr != DXTEX_S_OK) return hr;
+        e = launch_bc15_encode(v, dDst, dstRowPitch, dstFormat, flags, threshold, ctx->stream, static_cast<uint32_t*>(ctx->bcQueues));
         break;
     case FMT_BC7_UNORM: case FMT_BC7_UNORM_SRGB:
     {
@@ -303,6 +306,7 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
     if (ctx->triPinned) (void)hipHostFree(ctx->triPinned);
     if (ctx->triConsumed) (void)hipEventDestroy(ctx->triConsumed);
     if (ctx->mseBuf) (void)hipFree(ctx->mseBuf);
+    if (ctx->bcQueues) (void)hipFree(ctx->bcQueues);
     if (ctx->h2d) { (void)hipStreamSynchronize(ctx->h2d); (void)hipStreamDestroy(ctx->h2d); }
     if (ctx->d2h) { (void)hipStreamSynchronize(ctx->d2h); (void)hipStreamDestroy(ctx->d2h); }
     for (dxtex_ctx::Lane& l : ctx->lane)
@@ -955,15 +959,20 @@ dxtex_hresult submit_resizes(dxtex_ctx* ctx, const std::vector<LevelPair>& pairs
     {
         const LevelPair& p = pairs[i];
         // a mip chain's last levels (source at most 64 x 64, each level the next one's source) run in one workgroup
-        if (mipAlias && !grouped && pairs.size() - i >= 2 && resize_tail_applies(uint32_t(p.sw), uint32_t(p.sh), mode))
+        const bool cubicTail = mode == DXTEX_FILTER_CUBIC && p.sw <= 64 && p.sh <= 64;
+        if (mipAlias && !grouped && pairs.size() - i >= 2 && (cubicTail || resize_tail_applies(uint32_t(p.sw), uint32_t(p.sh), mode)))
         {
             bool chain = true;
             for (size_t k = i + 1; k < pairs.size(); ++k) chain = chain && pairs[k].src == pairs[k - 1].dst && pairs[k].srcPitch == pairs[k - 1].dstPitch;
+            std::vector<MipLevel> lv;
             if (chain)
             {
-                std::vector<MipLevel> lv;
                 lv.push_back({ const_cast<uint8_t*>(p.src), p.srcPitch, uint32_t(p.sw), uint32_t(p.sh) });
                 for (size_t k = i; k < pairs.size(); ++k) lv.push_back({ pairs[k].dst, pairs[k].dstPitch, uint32_t(pairs[k].dw), uint32_t(pairs[k].dh) });
+                if (cubicTail) chain = resize_cubic_tail_applies(lv.data(), int(lv.size()), format, flags);
+            }
+            if (chain)
+            {
                 MipLevel th = { nullptr, 0, 0, 0 };
                 if (twoHigh) th = { const_cast<uint8_t*>(twoHigh->src), twoHigh->srcPitch, uint32_t(twoHigh->sw), uint32_t(twoHigh->sh) };
                 const hipError_t e = launch_resize_tail(lv.data(), int(lv.size()), format, mode, flags, twoHigh ? &th : nullptr, ctx->stream);

@@ -15,8 +15,11 @@ protected:
     ~KernelMarks() = default;
 };
 
+// `queues`: bc15_queue_bytes() bytes of device memory owned by the caller's context (the work queues of the streaming kernel that large
+// RGBA8 images take; cleared stream-ordered by the launcher), or nullptr: every image through the one-unit-per-wavefront kernel.
+size_t bc15_queue_bytes();
 hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, int dstFormat,
-                              uint32_t flags, float threshold, hipStream_t stream);
+                              uint32_t flags, float threshold, hipStream_t stream, uint32_t* queues = nullptr);
 
 // BC7: `scratch` must hold bc7_scratch_bytes(total number of 4x4 blocks, flags, number of images) bytes of device memory.
 // The _many form runs an array of images (a mip chain, a texture array) through the per-mode pipeline as one block list.
@@ -69,6 +72,9 @@ hipError_t launch_pack_group(const uint8_t* rows, uint64_t rowsPitch, uint8_t* d
 // levels[0] that was at least 2 texels high (the box filter's stale tap, see resize_box_kernel), or nullptr.
 struct MipLevel { uint8_t* pixels; uint64_t pitch; uint32_t width, height; };
 bool resize_tail_applies(uint32_t srcW, uint32_t srcH, uint32_t filterMode);
+// cubic: only the tail of a power-of-two RGBA8 chain with clamp addressing (every level an exact halving) has a one-workgroup form;
+// levels[] as for launch_resize_tail
+bool resize_cubic_tail_applies(const MipLevel* levels, int nlevels, int format, uint32_t filterFlags);
 hipError_t launch_resize_tail(const MipLevel* levels, int nlevels, int format, uint32_t filterMode, uint32_t filterFlags,
                               const MipLevel* twoHigh, hipStream_t stream);
 

@@ -15,6 +15,7 @@
 #include "dxtex_kernels.h"
 #include "dxtex_store.h"
 #include "dxtex_formats.h"
+#include "cubic_filter.h"
 #include <algorithm>
 
 namespace dxtex
@@ -412,21 +413,6 @@ __device__ __forceinline__ Cub cubic_entry(uint32_t source, uint32_t dest, bool 
     return e;
 }
 
-// CUBIC_INTERPOLATE for one channel, operation for operation
-__device__ __forceinline__ float cubic1(float dx, float p0, float p1, float p2, float p3)
-{
-    const float a0 = p1;
-    const float d0 = p0 - a0, d2 = p2 - a0, d3 = p3 - a0;
-    float a1 = d2 - (1.0f / 3.0f) * d0;
-    a1 = a1 - (1.0f / 6.0f) * d3;
-    const float a2 = (1.0f / 2.0f) * d0 + (1.0f / 2.0f) * d2;
-    float a3 = (1.0f / 6.0f) * d3 - (1.0f / 6.0f) * d0;
-    a3 = a3 - (1.0f / 2.0f) * d2;
-    const float dx2 = dx * dx;
-    const float dx3 = dx2 * dx;
-    return ((a0 + a1 * dx) + a2 * dx2) + a3 * dx3;
-}
-
 __device__ __forceinline__ void resize_cubic_kernel_row(ResizeArgs a, const uint32_t x, const uint32_t y)
 {
     if (x >= a.dst.width) return;
@@ -495,10 +481,10 @@ __global__ void __launch_bounds__(256) resize_cubic_half_rgba8_kernel(ResizeArgs
         else { w0 = q[i0]; w1 = q[i1]; w2 = q[i2]; w3 = q[i3]; }
 #define DXTEX_CH(W, S) (float(((W) >> (S)) & 0xFFu) * (1.0f / 255.0f))
         float4 c;
-        c.x = cubic1(0.5f, DXTEX_CH(w0, 0), DXTEX_CH(w1, 0), DXTEX_CH(w2, 0), DXTEX_CH(w3, 0));
-        c.y = cubic1(0.5f, DXTEX_CH(w0, 8), DXTEX_CH(w1, 8), DXTEX_CH(w2, 8), DXTEX_CH(w3, 8));
-        c.z = cubic1(0.5f, DXTEX_CH(w0, 16), DXTEX_CH(w1, 16), DXTEX_CH(w2, 16), DXTEX_CH(w3, 16));
-        c.w = cubic1(0.5f, DXTEX_CH(w0, 24), DXTEX_CH(w1, 24), DXTEX_CH(w2, 24), DXTEX_CH(w3, 24));
+        c.x = cubic_half1(DXTEX_CH(w0, 0), DXTEX_CH(w1, 0), DXTEX_CH(w2, 0), DXTEX_CH(w3, 0));
+        c.y = cubic_half1(DXTEX_CH(w0, 8), DXTEX_CH(w1, 8), DXTEX_CH(w2, 8), DXTEX_CH(w3, 8));
+        c.z = cubic_half1(DXTEX_CH(w0, 16), DXTEX_CH(w1, 16), DXTEX_CH(w2, 16), DXTEX_CH(w3, 16));
+        c.w = cubic_half1(DXTEX_CH(w0, 24), DXTEX_CH(w1, 24), DXTEX_CH(w2, 24), DXTEX_CH(w3, 24));
 #undef DXTEX_CH
         return c;
     };
@@ -514,11 +500,58 @@ __global__ void __launch_bounds__(256) resize_cubic_half_rgba8_kernel(ResizeArgs
         const float4 c3 = xpass(int64_t(2) * y + 2);
         const float4 n2 = xpass(int64_t(2) * y + 3);             // row 2(y+1) + 1 of the next trip, loaded before this trip's store
         Texel o;
-        o.r = cubic1(0.5f, c0.x, c1.x, c2.x, c3.x); o.g = cubic1(0.5f, c0.y, c1.y, c2.y, c3.y);
-        o.b = cubic1(0.5f, c0.z, c1.z, c2.z, c3.z); o.a = cubic1(0.5f, c0.w, c1.w, c2.w, c3.w);
+        o.r = cubic_half1(c0.x, c1.x, c2.x, c3.x); o.g = cubic_half1(c0.y, c1.y, c2.y, c3.y);
+        o.b = cubic_half1(c0.z, c1.z, c2.z, c3.z); o.a = cubic_half1(c0.w, c1.w, c2.w, c3.w);
         reinterpret_cast<uint32_t*>(a.dst.pixels + uint64_t(y) * a.dst.rowPitch)[x] = pack_texel32(FMT_R8G8B8A8_UNORM, o);
         c0 = c2; c1 = c3; c2 = n2;
     }
+    }
+}
+
+// The same filter with TWO adjacent destination texels per lane (destination width even, rows 16-byte aligned): the six source texels a
+// pair needs are one 16-byte load and two neighbouring dwords, every source texel is unpacked once per pair instead of once per destination
+// texel, and a wavefront reads 1 KiB runs. Same expressions in the same order as resize_cubic_half_rgba8_kernel, hence the same bits.
+__global__ void __launch_bounds__(256) resize_cubic_half_rgba8_x2_kernel(ResizeArgs a, uint32_t stripRows)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;            // pair index: destination texels 2k, 2k + 1
+    if (2u * k >= a.dst.width) return;
+    const int64_t srcW = a.src.width, srcH = a.src.height;
+    const uint32_t iL = (k == 0) ? 0u : 4u * k - 1u;               // clamp addressing: texel 4k - 1 / 4k + 4
+    const uint32_t iR = uint32_t(int64_t(4) * k + 4 > srcW - 1 ? srcW - 1 : int64_t(4) * k + 4);
+    struct Pair { float4 l, r; };
+    auto xpass = [&](int64_t sy) -> Pair
+    {
+        sy = sy < 0 ? 0 : (sy > srcH - 1 ? srcH - 1 : sy);
+        const uint8_t* row = a.src.pixels + uint64_t(sy) * a.src.rowPitch;
+        const uint4 m = reinterpret_cast<const uint4*>(row)[k];
+        const uint32_t wl = reinterpret_cast<const uint32_t*>(row)[iL], wr = reinterpret_cast<const uint32_t*>(row)[iR];
+#define DXTEX_CH(W, S) (float(((W) >> (S)) & 0xFFu) * (1.0f / 255.0f))
+        Pair o;
+#define DXTEX_ONE(S, FL, FR) { const float t0 = DXTEX_CH(wl, S), t1 = DXTEX_CH(m.x, S), t2 = DXTEX_CH(m.y, S), t3 = DXTEX_CH(m.z, S), t4 = DXTEX_CH(m.w, S), t5 = DXTEX_CH(wr, S); \
+                               FL = cubic_half1(t0, t1, t2, t3); FR = cubic_half1(t2, t3, t4, t5); }
+        DXTEX_ONE(0, o.l.x, o.r.x) DXTEX_ONE(8, o.l.y, o.r.y) DXTEX_ONE(16, o.l.z, o.r.z) DXTEX_ONE(24, o.l.w, o.r.w)
+#undef DXTEX_ONE
+#undef DXTEX_CH
+        return o;
+    };
+    for (uint64_t s0 = uint64_t(blockIdx.y) * stripRows; s0 < a.dst.height; s0 += uint64_t(gridDim.y) * stripRows)
+    {
+        const uint32_t y0 = uint32_t(s0), y1 = uint32_t(min(s0 + stripRows, uint64_t(a.dst.height)));
+        Pair c0 = xpass(int64_t(2) * y0 - 1), c1 = xpass(int64_t(2) * y0), c2 = xpass(int64_t(2) * y0 + 1);
+#pragma unroll 2
+        for (uint32_t y = y0; y < y1; ++y)
+        {
+            const Pair c3 = xpass(int64_t(2) * y + 2);
+            const Pair n2 = xpass(int64_t(2) * y + 3);
+            Texel ol, orr;
+            ol.r = cubic_half1(c0.l.x, c1.l.x, c2.l.x, c3.l.x); ol.g = cubic_half1(c0.l.y, c1.l.y, c2.l.y, c3.l.y);
+            ol.b = cubic_half1(c0.l.z, c1.l.z, c2.l.z, c3.l.z); ol.a = cubic_half1(c0.l.w, c1.l.w, c2.l.w, c3.l.w);
+            orr.r = cubic_half1(c0.r.x, c1.r.x, c2.r.x, c3.r.x); orr.g = cubic_half1(c0.r.y, c1.r.y, c2.r.y, c3.r.y);
+            orr.b = cubic_half1(c0.r.z, c1.r.z, c2.r.z, c3.r.z); orr.a = cubic_half1(c0.r.w, c1.r.w, c2.r.w, c3.r.w);
+            reinterpret_cast<uint2*>(a.dst.pixels + uint64_t(y) * a.dst.rowPitch)[k] =
+                make_uint2(pack_texel32(FMT_R8G8B8A8_UNORM, ol), pack_texel32(FMT_R8G8B8A8_UNORM, orr));
+            c0 = c2; c1 = c3; c2 = n2;
+        }
     }
 }
 
@@ -628,6 +661,65 @@ __global__ void __launch_bounds__(1024) resize_tail_kernel(TailArgs t)
         }
         __syncthreads();                                                     // level l is complete and visible to the whole workgroup
         a.src = a.dst;
+    }
+}
+
+// The tail of a power-of-two RGBA8 cubic chain in LDS: from a source of at most 64 x 64 texels down to 1 x 1, every level an exact halving in
+// both directions (clamp addressing, no sRGB). The generic tail above reads each level back from global memory - sixteen dependent taps per
+// texel with nothing to hide their latency, 84 us for the six levels - and a launch per level costs ~6.6 us each. Here the source level is
+// staged once, every level is produced from the previous one's packed texels in LDS (and written out), a barrier per level: the arithmetic of
+// resize_cubic_half_rgba8_kernel (x-pass over four clamped taps of each of four clamped rows, then y), the same bits.
+struct CubicTailArgs
+{
+    const uint8_t* src; uint64_t srcPitch; uint32_t srcW, srcH; int nlevels;
+    uint8_t* dst[kTailMaxLevels]; uint64_t dstPitch[kTailMaxLevels];
+};
+__global__ void __launch_bounds__(1024) resize_cubic_tail_rgba8_kernel(CubicTailArgs t)
+{
+    __shared__ uint32_t bufA[kTailSide * kTailSide], bufB[(kTailSide / 2) * (kTailSide / 2)];
+    uint32_t w = t.srcW, h = t.srcH;
+    for (uint32_t i = threadIdx.x; i < w * h; i += 1024u)
+    {
+        const uint32_t y = i / w, x = i - y * w;
+        bufA[i] = reinterpret_cast<const uint32_t*>(t.src + uint64_t(y) * t.srcPitch)[x];
+    }
+    __syncthreads();
+    uint32_t* s = bufA;
+    uint32_t* d = bufB;
+    for (int l = 0; l < t.nlevels; ++l)
+    {
+        const uint32_t dw = w >> 1, dh = h >> 1;
+        for (uint32_t i = threadIdx.x; i < dw * dh; i += 1024u)
+        {
+            const uint32_t y = i / dw, x = i - y * dw;
+            const int32_t u0 = int32_t(2u * x) - 1, v0 = int32_t(2u * y) - 1;
+            uint32_t xi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int32_t u = u0 + k; xi[k] = uint32_t(u < 0 ? 0 : (u > int32_t(w) - 1 ? int32_t(w) - 1 : u)); }
+            float4 c[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const int32_t v = v0 + r;
+                const uint32_t* row = s + uint32_t(v < 0 ? 0 : (v > int32_t(h) - 1 ? int32_t(h) - 1 : v)) * w;
+                const uint32_t w0 = row[xi[0]], w1 = row[xi[1]], w2 = row[xi[2]], w3 = row[xi[3]];
+#define DXTEX_CH(W, S) (float(((W) >> (S)) & 0xFFu) * (1.0f / 255.0f))
+                c[r].x = cubic_half1(DXTEX_CH(w0, 0), DXTEX_CH(w1, 0), DXTEX_CH(w2, 0), DXTEX_CH(w3, 0));
+                c[r].y = cubic_half1(DXTEX_CH(w0, 8), DXTEX_CH(w1, 8), DXTEX_CH(w2, 8), DXTEX_CH(w3, 8));
+                c[r].z = cubic_half1(DXTEX_CH(w0, 16), DXTEX_CH(w1, 16), DXTEX_CH(w2, 16), DXTEX_CH(w3, 16));
+                c[r].w = cubic_half1(DXTEX_CH(w0, 24), DXTEX_CH(w1, 24), DXTEX_CH(w2, 24), DXTEX_CH(w3, 24));
+#undef DXTEX_CH
+            }
+            Texel o;
+            o.r = cubic_half1(c[0].x, c[1].x, c[2].x, c[3].x); o.g = cubic_half1(c[0].y, c[1].y, c[2].y, c[3].y);
+            o.b = cubic_half1(c[0].z, c[1].z, c[2].z, c[3].z); o.a = cubic_half1(c[0].w, c[1].w, c[2].w, c[3].w);
+            const uint32_t packed = pack_texel32(FMT_R8G8B8A8_UNORM, o);
+            d[i] = packed;
+            reinterpret_cast<uint32_t*>(t.dst[l] + uint64_t(y) * t.dstPitch[l])[x] = packed;
+        }
+        __syncthreads();
+        uint32_t* const tmp = s; s = d; d = tmp;          // the next level (a quarter of this one) fits where this level's source was
+        w = dw; h = dh;
     }
 }
 
@@ -915,8 +1007,16 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
             // rows per lane: long strips amortise the two extra row passes at their top; short ones keep a small level spread over the chip
             // (at least ~4096 wavefronts while that leaves 4 rows or more per strip)
             uint32_t strip = 32;
-            while (strip > 4 && uint64_t((dstW + 63) / 64) * ((dstH + strip - 1) / strip) < 4096) strip >>= 1;
-            hipLaunchKernelGGL(resize_cubic_half_rgba8_kernel, dim3((dstW + 255) / 256, grid_rows((dstH + strip - 1) / strip)), block, 0, stream, a, strip);
+            // two destination texels per lane where the rows allow 16-byte loads and 8-byte stores (every level of a power-of-two chain down to 2 texels)
+#if !defined(DXTEX_CUBIC_X2)
+#define DXTEX_CUBIC_X2 1               // 0: every level through the one-texel-per-lane kernel (A/B builds)
+#endif
+            const bool pairs = DXTEX_CUBIC_X2 && (dstW % 2) == 0 && (srcPitch % 16) == 0 && (dstPitch % 8) == 0 && (reinterpret_cast<uintptr_t>(src) % 16) == 0 &&
+                               (reinterpret_cast<uintptr_t>(dst) % 8) == 0;
+            const uint32_t lanesX = pairs ? dstW / 2 : dstW;
+            while (strip > 4 && uint64_t((lanesX + 63) / 64) * ((dstH + strip - 1) / strip) < 4096) strip >>= 1;
+            if (pairs) hipLaunchKernelGGL(resize_cubic_half_rgba8_x2_kernel, dim3((lanesX + 255) / 256, grid_rows((dstH + strip - 1) / strip)), block, 0, stream, a, strip);
+            else hipLaunchKernelGGL(resize_cubic_half_rgba8_kernel, dim3((dstW + 255) / 256, grid_rows((dstH + strip - 1) / strip)), block, 0, stream, a, strip);
         }
         else
             hipLaunchKernelGGL(resize_cubic_kernel, grid, block, 0, stream, a);
@@ -938,6 +1038,22 @@ hipError_t launch_resize_tail(const MipLevel* levels, int nlevels, int format, u
                               const MipLevel* twoHigh, hipStream_t stream)
 {
     if (nlevels < 2) return hipSuccess;
+    if (filterMode == 0x300000u)
+    {
+        // resize_tail_applies admitted the chain: RGBA8, clamp, no sRGB, every level an exact halving (checked again here)
+        CubicTailArgs c;
+        c.src = levels[0].pixels; c.srcPitch = levels[0].pitch; c.srcW = levels[0].width; c.srcH = levels[0].height; c.nlevels = nlevels - 1;
+        if (format != FMT_R8G8B8A8_UNORM || (filterFlags & 0x3000077u) || c.nlevels > kTailMaxLevels || c.srcW > kTailSide || c.srcH > kTailSide) return hipErrorInvalidValue;
+        for (int k = 1; k < nlevels; ++k)
+        {
+            if (levels[k].width * 2u != levels[k - 1].width || levels[k].height * 2u != levels[k - 1].height || (levels[k].pitch % 4) != 0 ||
+                (reinterpret_cast<uintptr_t>(levels[k].pixels) % 4) != 0) return hipErrorInvalidValue;
+            c.dst[k - 1] = levels[k].pixels; c.dstPitch[k - 1] = levels[k].pitch;
+        }
+        for (int k = nlevels - 1; k < kTailMaxLevels; ++k) { c.dst[k] = c.dst[0]; c.dstPitch[k] = c.dstPitch[0]; }
+        hipLaunchKernelGGL(resize_cubic_tail_rgba8_kernel, dim3(1), dim3(1024), 0, stream, c);
+        return hipGetLastError();
+    }
     TailArgs t;
     ResizeArgs& a = t.a;
     a.stale = make_view(nullptr, 0, 0, 2, format);
@@ -963,6 +1079,17 @@ hipError_t launch_resize_tail(const MipLevel* levels, int nlevels, int format, u
         at += t.nlevels;
     }
     return hipGetLastError();
+}
+
+bool resize_cubic_tail_applies(const MipLevel* levels, int nlevels, int format, uint32_t filterFlags)
+{
+    // the LDS tail of a power-of-two RGBA8 chain (resize_cubic_tail_rgba8_kernel): every remaining level halves both sides exactly
+    if (nlevels < 2 || nlevels - 1 > kTailMaxLevels || format != FMT_R8G8B8A8_UNORM || (filterFlags & 0x3000077u)) return false;       // sRGB, wrap, mirror bits
+    if (levels[0].width > kTailSide || levels[0].height > kTailSide || (levels[0].pitch % 4) != 0 || (reinterpret_cast<uintptr_t>(levels[0].pixels) % 4) != 0) return false;
+    for (int k = 1; k < nlevels; ++k)
+        if (levels[k].width * 2u != levels[k - 1].width || levels[k].height * 2u != levels[k - 1].height || (levels[k].pitch % 4) != 0 ||
+            (reinterpret_cast<uintptr_t>(levels[k].pixels) % 4) != 0) return false;
+    return true;
 }
 
 bool resize_tail_applies(uint32_t srcW, uint32_t srcH, uint32_t filterMode)

@@ -22,7 +22,7 @@ if [ "$1" = build ]; then
     # capi.cpp / the other knob-reading units come from the dev objects where they exist
     LINK=""
     for o in $OTHERS; do b=$(basename $o); if [ -f $OBJ/dev_${b%.o}.o ] ; then LINK="$LINK $OBJ/dev_${b%.o}.o"; else LINK="$LINK $o"; fi; done
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $VAR/$name.so $LINK $VAR/$name.o -Wl,-soname,libdxtex_amd_dev.so -Wl,-rpath,/opt/rocm/lib
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $VAR/$name.so $LINK $VAR/$name.o -Wl,-soname,libdxtex_amd_dev.so -Wl,-Bsymbolic-functions -Wl,-rpath,/opt/rocm/lib
     rm $VAR/$name.o
   done
   ls -la $VAR
