@@ -798,90 +798,14 @@ __device__ __forceinline__ void encode_packed(PackedTile& t, uint8_t* out, uint3
     }
 }
 
-// Streaming form of the packed-tile path for large images: a wavefront walks over units of 64 blocks (8 x 8 tiles for the colour codecs,
-// runs of a block row for BC4 / BC5) with a stride of the whole grid and loads the NEXT unit's texels - four 16-byte loads per lane -
-// before it encodes the current one. With a unit per wavefront the loads sit at the head of ~10 000 cycles of dependent arithmetic, and at
-// the two or three waves per SIMD the fits' registers allow nothing covers them: the counters showed the waves parked on s_waitcnt for a
-// quarter of their life (profiles/r04_kernels.md). Same per-block code, same bytes.
-#if !defined(DXTEX_BC15_STREAM_WGS)
-#define DXTEX_BC15_STREAM_WGS 2
-#endif
-#if !defined(DXTEX_BC15_STREAM)
-#define DXTEX_BC15_STREAM 1            // 0: every image through the one-unit-per-wavefront kernel (A/B builds)
-#endif
-#if !defined(DXTEX_BC15_STREAM_OVERSUB)
-#define DXTEX_BC15_STREAM_OVERSUB 1    // wavefronts launched per resident slot
-#endif
-#if !defined(DXTEX_BC15_STREAM_BC45)
-#define DXTEX_BC15_STREAM_BC45 0       // BC4 / BC5 have no content-dependent paths and run at 3 - 8 waves per SIMD: measured slower through the queues (94.8 vs 84.8 us, 50.4 vs 38.7 us)
-#endif
-// workgroups per CU a streaming instantiation is compiled for (and launched with): the colour fits need ~210 - 240 registers, BC4 / BC5 fewer
-constexpr int stream_wgs(int kind) { return kind <= 3 ? DXTEX_BC15_STREAM_WGS : kind == 4 ? 4 : 3; }
-// Work distribution: the cost of a unit depends on its content (flat blocks leave the fit at once, noisy ones run its eight trips: 2 - 12 us
-// per unit on the benchmark image) and content is spatially correlated, so a fixed assignment of units to wavefronts left the slowest
-// wavefront at 1.7 x the mean (measured: 145 us kernel, 84 us mean wavefront). Units are therefore taken from queues: kStreamQueues
-// counters (same-address atomics serialise at ~11 ns each machine-wide, tools/atomic_ubench.hip, so one counter for 16 384 units would cost
-// more than the kernel; 32 counters cost ~0.5 ns per take), queue q owning the units q, q + 32, q + 64, ... - each queue's units are
-// spread over the whole image - and serving the wavefronts w with w mod 32 = q. A wavefront holds its next ticket one trip ahead, so
-// neither the atomic's round trip nor the next unit's loads are waited for before the current unit is encoded.
-constexpr uint32_t kStreamQueues = 32, kStreamQueueStride = 64;      // counters 256 bytes apart
-template<int KIND, bool DITHER>
-__global__ void __launch_bounds__(256, stream_wgs(KIND)) bc15_stream_kernel(EncodeArgs a, uint32_t units, uint32_t tiled, uint32_t* queues)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t tilesX = (a.nbw + 7u) >> 3;
-    const uint32_t nblocks = a.nbw * a.nbh;
-    // block of this lane in unit u; false if the unit's slot is outside the image (edge tiles, the last run)
-    auto locate = [&](uint32_t u, uint32_t& bx, uint32_t& by) -> bool
-    {
-        if (tiled)
-        {
-            const uint32_t ty = u / tilesX, tx = u - ty * tilesX;
-            bx = tx * 8u + (lane & 7u); by = ty * 8u + (lane >> 3);
-            return bx < a.nbw && by < a.nbh;
-        }
-        const uint32_t nb = u * 64u + lane;
-        by = nb / a.nbw; bx = nb - by * a.nbw;
-        return nb < nblocks;
-    };
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t q = wave % kStreamQueues;
-    uint32_t* head = queues + q * kStreamQueueStride;
-    auto take = [&]() -> uint32_t              // next unit of this wavefront's queue (>= units: the queue is empty)
-    {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(head, 1u);
-        t = uint32_t(__builtin_amdgcn_readfirstlane(int(t)));
-        return (t < 0x04000000u) ? q + t * kStreamQueues : 0xFFFFFFFFu;
-    };
-    uint32_t u = take();
-    if (u >= units) return;
-    uint32_t un = take();
-    PackedTile cur, nxt;
-    uint32_t bx, by;
-    bool ok = locate(u, bx, by);
-    if (ok) load_packed_tile(a, bx, by, cur);
-    for (;;)
-    {
-        uint32_t nbx = 0, nby = 0;
-        const bool more = un < units;
-        const bool nok = more && locate(un, nbx, nby);
-        if (nok) load_packed_tile(a, nbx, nby, nxt);              // in flight while this unit is encoded
-        const uint32_t unn = more ? take() : 0xFFFFFFFFu;          // ... and so is the ticket after it
-        if (ok) encode_packed<KIND, DITHER>(cur, a.dst + uint64_t(by) * a.dstRowPitch, bx, a);
-        if (!more) break;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) cur.px[i] = nxt.px[i];
-        u = un; un = unn; bx = nbx; by = nby; ok = nok;
-    }
-}
-
 #if !defined(DXTEX_BC15_PACKED_WGS)
-#define DXTEX_BC15_PACKED_WGS 3        // workgroups per CU the packed-tile instantiation is compiled for (BC1: 2 - no spill; with 8 x 8 tiles
-                                       // per wavefront 0.130 against 0.145 ms per 4096^2 image; BC3 does not care: 0.127 / 0.125)
+#define DXTEX_BC15_PACKED_WGS 3        // workgroups per CU the packed-tile instantiations of BC3 - BC5 are compiled for
 #endif
+// Occupancy per codec, measured (round 4, 4096^2 cfg2 image / BC3 of the 8192^2 cfg4 chain with random alpha): BC1 and BC2 at 2 workgroups per
+// CU (no spill; BC2 0.123 ms against 0.144 at 3), BC3 at 3 (128 bytes of scratch per lane, and still the faster one where alpha is busy: the
+// cfg4 chain 0.956 ms against 1.065 at 2; no difference on opaque images).
 template<int KIND, bool DITHER, bool PACKED8>
-__global__ void __launch_bounds__(256, PACKED8 ? (KIND == 1 ? 2 : DXTEX_BC15_PACKED_WGS) : 1) bc15_encode_kernel(EncodeArgs a)
+__global__ void __launch_bounds__(256, PACKED8 ? (KIND <= 2 ? 2 : DXTEX_BC15_PACKED_WGS) : 1) bc15_encode_kernel(EncodeArgs a)
 {
     // A wavefront takes an 8 x 8 tile of blocks (32 x 32 texels), not 64 blocks of one block row: what the lanes of a wavefront do
     // differs by content - flat blocks leave the fit at once, noisy ones run its eight Newton trips - and content is coherent in two
@@ -938,10 +862,8 @@ __global__ void __launch_bounds__(256) bc15_encode_multi_kernel(MultiArgs m)
 }
 } // namespace
 
-size_t bc15_queue_bytes() { return size_t(kStreamQueues) * kStreamQueueStride * sizeof(uint32_t); }
-
 hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, int dstFormat,
-                              uint32_t flags, float threshold, hipStream_t stream, uint32_t* queues)
+                              uint32_t flags, float threshold, hipStream_t stream)
 {
     EncodeArgs a;
     a.src = src; a.dst = dst; a.dstRowPitch = dstRowPitch;
@@ -963,35 +885,6 @@ hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowP
 #define DXTEX_LAUNCH(KIND, PACKOK) do { const bool pk_ = packed && (PACKOK); \
                                          if (dither) { if (pk_) DXTEX_LAUNCH2(KIND, true, true); else DXTEX_LAUNCH2(KIND, true, false); } \
                                          else { if (pk_) DXTEX_LAUNCH2(KIND, false, true); else DXTEX_LAUNCH2(KIND, false, false); } } while (0)
-    // large packed images: the streaming kernel (persistent wavefronts, next unit's loads in flight while the current one is encoded)
-    {
-        static const uint32_t cus = [] { int dev = 0; hipDeviceProp_t p; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? uint32_t(p.multiProcessorCount) : 256u; }();
-        const bool tiled = colourFit && a.nbw >= 8 && a.nbh >= 8;
-        const uint64_t units64 = tiled ? tiles : (nblocks + 63) / 64;
-        const int kind = colourFit ? 1 : (dstFormat == FMT_BC4_UNORM ? 4 : 5);
-        const uint32_t resident = cus * uint32_t(stream_wgs(kind)) * 4u * uint32_t(DXTEX_BC15_STREAM_OVERSUB);
-        const bool packOk = packed && !(dstFormat == FMT_BC4_SNORM || dstFormat == FMT_BC5_SNORM) && (colourFit || DXTEX_BC15_STREAM_BC45) &&
-                            !((dstFormat == FMT_BC1_UNORM || dstFormat == FMT_BC1_UNORM_SRGB) && (flags & BCF_DITHER_A));
-        if (DXTEX_BC15_STREAM && queues && packOk && units64 >= 2ull * resident && units64 < 0x7FFFFFFFull && nblocks < 0xFFFFFFFFull)
-        {
-            const uint32_t units = uint32_t(units64);
-            const dim3 sgrid((resident + 3) / 4);
-            const hipError_t ze = hipMemsetAsync(queues, 0, bc15_queue_bytes(), stream);
-            if (ze != hipSuccess) return ze;
-#define DXTEX_STREAM(KIND) do { if (dither) hipLaunchKernelGGL((bc15_stream_kernel<KIND, true>), sgrid, block, 0, stream, a, units, tiled ? 1u : 0u, queues); \
-                                else hipLaunchKernelGGL((bc15_stream_kernel<KIND, false>), sgrid, block, 0, stream, a, units, tiled ? 1u : 0u, queues); } while (0)
-            switch (dstFormat)
-            {
-            case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: DXTEX_STREAM(1); return hipGetLastError();
-            case FMT_BC2_UNORM: case FMT_BC2_UNORM_SRGB: DXTEX_STREAM(2); return hipGetLastError();
-            case FMT_BC3_UNORM: case FMT_BC3_UNORM_SRGB: DXTEX_STREAM(3); return hipGetLastError();
-            case FMT_BC4_UNORM: hipLaunchKernelGGL((bc15_stream_kernel<4, false>), sgrid, block, 0, stream, a, units, 0u, queues); return hipGetLastError();
-            case FMT_BC5_UNORM: hipLaunchKernelGGL((bc15_stream_kernel<5, false>), sgrid, block, 0, stream, a, units, 0u, queues); return hipGetLastError();
-            default: break;
-            }
-#undef DXTEX_STREAM
-        }
-    }
     switch (dstFormat)
     {
     case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: DXTEX_LAUNCH(1, (flags & BCF_DITHER_A) == 0); break;

@@ -32,9 +32,27 @@ namespace
 {
 using namespace bc6h;
 
-struct Rec6 { int A[3], B[3]; float err; uint32_t valid; };        // 32 bytes per task
+// A task's quantised endpoints as six 16-bit fields: every mode's endpoint precision is at most 16 bits (ms_aInfo, :1051-1067), unsigned
+// formats hold 0 ... 2^prec - 1 and signed ones -(2^(prec-1)) ... 2^(prec-1) - 1, so the extension on the way back is the format's.
+// (Round 3 kept them as six ints: 72 bytes of records per task, 1.2 GB written by every mode's pre and read by its post.)
+struct Ep16 { uint32_t a01, a2b0, b12; };
+__device__ __forceinline__ Ep16 pack_ep16(const int (&A)[3], const int (&B)[3])
+{
+    Ep16 e;
+    e.a01 = (uint32_t(A[0]) & 0xFFFFu) | (uint32_t(A[1]) << 16);
+    e.a2b0 = (uint32_t(A[2]) & 0xFFFFu) | (uint32_t(B[0]) << 16);
+    e.b12 = (uint32_t(B[1]) & 0xFFFFu) | (uint32_t(B[2]) << 16);
+    return e;
+}
+__device__ __forceinline__ void unpack_ep16(const Ep16& e, bool sg, int (&A)[3], int (&B)[3])
+{
+    const auto lo = [sg](uint32_t w) { return sg ? int(int16_t(w & 0xFFFFu)) : int(w & 0xFFFFu); };
+    const auto hi = [sg](uint32_t w) { return sg ? (int(w) >> 16) : int(w >> 16); };
+    A[0] = lo(e.a01); A[1] = hi(e.a01); A[2] = lo(e.a2b0); B[0] = hi(e.a2b0); B[1] = lo(e.b12); B[2] = hi(e.b12);
+}
+struct Rec6 { Ep16 ep; float err; };                               // 16 bytes per task: the search's start, then its result
 struct Best6 { float err; uint32_t mode; uint64_t lo, hi; };       // 24 bytes per block; mode = position of the winner's mode in the encoder's order
-struct OrgSave { int A[3], B[3]; float err; uint32_t pad; uint64_t idx; };      // 40 bytes per task: Refine's unoptimised half, pre -> post
+struct OrgSave { Ep16 ep; float err; uint64_t idx; };              // 24 bytes per task: Refine's unoptimised half, pre -> post
 
 enum : int { SEED_INTS = 17 * 6 + 2 };      // 8 shapes x 2 regions + the one-region seed, 6 ints each (+ pad)
 
@@ -333,8 +351,7 @@ __device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, ui
     {
         // post: the pre kernel of this mode already quantised the seeds and assigned the indices
         const OrgSave sv = *saved;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { o.ep.A[c] = sv.A[c]; o.ep.B[c] = sv.B[c]; }
+        unpack_ep16(sv.ep, sg, o.ep.A, o.ep.B);
         o.err = sv.err; o.idx = sv.idx;
     }
     else
@@ -423,9 +440,8 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
     if (!reuseOrg)
     {
         OrgSave sv;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { sv.A[c] = o.ep.A[c]; sv.B[c] = o.ep.B[c]; }
-        sv.err = o.err; sv.pad = 0; sv.idx = o.idx;
+        sv.ep = pack_ep16(o.ep.A, o.ep.B);
+        sv.err = o.err; sv.idx = o.idx;
         a.orgs[t] = sv;
     }
     // OptimizeOne's search (:2145-2194) depends on the block, the shape, the region and the endpoint PRECISION - not on the mode's delta
@@ -453,9 +469,8 @@ __global__ void __launch_bounds__(256) bc6h_pre_kernel(Bc6hArgs a)
     if (snp)
     {
         Rec6 rec;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { rec.A[c] = o.ep.A[c]; rec.B[c] = o.ep.B[c]; }
-        rec.err = o.err; rec.valid = 1u;
+        rec.ep = pack_ep16(o.ep.A, o.ep.B);
+        rec.err = o.err;
         a.recs[t] = rec;
     }
     a.tinfo[t] = smask | done | (snp << 24);
@@ -500,8 +515,7 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     if (ownSearched)
     {
         const Rec6 rec = a.recs[t];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { opt.A[c] = rec.A[c]; opt.B[c] = rec.B[c]; }
+        unpack_ep16(rec.ep, sg, opt.A, opt.B);
     }
     // A candidate the search never ran for either region (pruned, does not fit, error already 0: subset size 0 in the task list)
     // still has its unoptimised endpoints: it either cannot win (its lower bound exceeds an error on the table, or it is not
@@ -619,8 +633,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a, uint32_t w
                 uint64_t pos;
                 tx.np = gather_texels(planes, task.y & 0xFFFFu, slot, pos);
                 EndPts e;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { e.A[c] = rec.A[c]; e.B[c] = rec.B[c]; }
+                unpack_ep16(rec.ep, sg, e.A, e.B);
                 st = perturb6_begin(e, rec.err);
             }
         }
@@ -636,9 +649,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a, uint32_t w
             st = perturb6_transition(st, e, v);
             if (st.ch >= 3)
             {
-                Rec6* r = a.recs + myTask;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { r->A[c] = st.ep.A[c]; r->B[c] = st.ep.B[c]; }
+                a.recs[myTask].ep = pack_ep16(st.ep.A, st.ep.B);
                 myTask = 0xFFFFFFFFu;
             }
         }
@@ -708,8 +719,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_wave_kernel(Bc6hArgs a, uint3
         const float* gp = a.fpix + uint64_t(nb) * 48 + (lane & 15);
         const float tr = gp[0], tg = gp[16], tb = gp[32];
         EndPts e;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { e.A[c] = rec.A[c]; e.B[c] = rec.B[c]; }
+        unpack_ep16(rec.ep, sg, e.A, e.B);
         Perturb6 st = perturb6_begin(e, rec.err);
         while (st.ch < 3)
         {
@@ -719,9 +729,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_wave_kernel(Bc6hArgs a, uint3
         }
         if (lane == 0)
         {
-            Rec6* r = a.recs + myTask;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { r->A[c] = st.ep.A[c]; r->B[c] = st.ep.B[c]; }
+            a.recs[myTask].ep = pack_ep16(st.ep.A, st.ep.B);
         }
     }
 }

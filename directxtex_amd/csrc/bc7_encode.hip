@@ -1269,13 +1269,21 @@ namespace
 // bounds the scratch (about 1.1 KiB per block); DXTEX_MAX_BLOCKS_PER_PASS shrinks it so tests can exercise the pass loop
 const uint64_t kMaxBlocksPerPass = dev_env("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(dev_env("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 22);
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
+// A submission of at most this many blocks (a lone 1024^2 image, a small mip chain) is a LATENCY problem: every kernel of the per-mode
+// pipelines has fewer tasks than the machine has lanes and lasts as long as its longest serial chain, so the modes - independent until
+// `pick`, see launch_bc7_encode_many - run side by side on the context's side streams, each pipeline with task arrays of its own.
+const uint64_t kSmallPassBlocks = dev_env("DXTEX_BC7_SMALL_BLOCKS") ? strtoull(dev_env("DXTEX_BC7_SMALL_BLOCKS"), nullptr, 10) : 65536;
 struct ScratchLayout
 {
     size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, seeds, seeds1, seeds3, flagcnt, auxRecs, auxOrder, auxTinfo, auxCounters, total;
+    size_t auxTpb, auxSlices;     // the extra pipelines' task arrays: slices of nb * auxTpb tasks
     explicit ScratchLayout(uint64_t nb, bool threeSubsets)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
         const size_t tpb = threeSubsets ? kMaxTasksPerBlock : 32;
+        // large passes: modes 4 (both index modes) and 5 side by side, 4 tasks per block each; small submissions: any mode on any side stream
+        const bool small = nb <= kSmallPassBlocks;
+        auxTpb = small ? tpb : 4; auxSlices = small ? size_t(kSideStreams) : 2;
         size_t o = 0;
         lists = o; o = up(o + nb * LIST_BYTES);
         cands = o; o = up(o + nb * NUM_SLOTS * sizeof(Cand));
@@ -1290,11 +1298,10 @@ struct ScratchLayout
         seeds1 = o; o = up(o + nb * 2 * sizeof(uint2));
         seeds3 = o; o = up(o + (threeSubsets ? nb * 192 * sizeof(uint2) : 0));
         flagcnt = o; o = up(o + 256);
-        // task arrays of the two extra pipelines when modes 4 (both index modes) and 5 run side by side: 4 tasks per block each
-        auxRecs = o; o = up(o + 2 * nb * 4 * sizeof(TaskRec));
-        auxOrder = o; o = up(o + 2 * nb * 4 * sizeof(uint2));
-        auxTinfo = o; o = up(o + 2 * nb * 4 * sizeof(uint32_t));
-        auxCounters = o; o = up(o + 2 * 64 * sizeof(uint32_t));
+        auxRecs = o; o = up(o + auxSlices * nb * auxTpb * sizeof(TaskRec));
+        auxOrder = o; o = up(o + auxSlices * nb * auxTpb * sizeof(uint2));
+        auxTinfo = o; o = up(o + auxSlices * nb * auxTpb * sizeof(uint32_t));
+        auxCounters = o; o = up(o + size_t(kSideStreams) * 64 * sizeof(uint32_t));
         total = o;
     }
 };
@@ -1518,6 +1525,66 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         auto family45 = [](int step) { const int m = step % 10; return m == 4 || m == 8 || m == 5; };
         static const bool serial45 = dev_env("DXTEX_BC7_SERIAL") != nullptr;
         const SideStreams* fork = (marks || serial45 || quick) ? nullptr : side;
+        // the task arrays of side pipeline k (0-based)
+        auto side_args = [&](const Bc7Args& a0, size_t k)
+        {
+            Bc7Args b = a0;
+            b.recs = reinterpret_cast<TaskRec*>(base + L.auxRecs) + k * size_t(a0.nblocks) * L.auxTpb;
+            b.order = reinterpret_cast<uint2*>(base + L.auxOrder) + k * size_t(a0.nblocks) * L.auxTpb;
+            b.tinfo = reinterpret_cast<uint32_t*>(base + L.auxTinfo) + k * size_t(a0.nblocks) * L.auxTpb;
+            b.counters = reinterpret_cast<uint32_t*>(base + L.auxCounters) + k * 64;
+            return b;
+        };
+        // Small submissions: the whole schedule as four concurrent pipelines (the context's stream + three side streams), joined before
+        // `pick`. What an earlier mode leaves on the table for a later one's pruning is given up where the two now run at the same time -
+        // never the result: every bound is exact, `pick` restores Encode's order, bestErr / zeroOrd are folded with atomicMin - and the
+        // search work that adds is free on a machine that a small submission cannot fill. Mode 6's late phase, which lives off the
+        // table (97 % pruned), still runs last on the main stream; mode 3 gets a stream to itself next to mode 1.
+        // The plan: stages separated by '|' (joined on the main stream), pipelines of a stage by '/', steps by ','. Measured on MI355X (rocprofv3
+        // timeline of a lone 512^2 image): modes 1 and 3 next to each other take 2.0 ms instead of 1.6 + 1.1 one after the other; a FOURTH
+        // hardware queue does not start before the first three drain, so a stage has at most three pipelines; the late single-subset modes
+        // keep a three-way stage of their own after modes 1 / 3 (next to them their kernels starved behind the persistent search waves:
+        // 1.8 ms instead of 0.8). Of the dozen plans tried this one was the best at all three sizes - lone 256^2 / 512^2 / 1024^2 images:
+        // 2.48 / 4.82 / 12.46 ms serial -> 1.73 / 3.78 / 11.39 ms (mode 6's early phase beside modes 1 / 3 instead of before them, its late
+        // phase right after mode 1 on the main stream).
+        static const std::vector<std::vector<std::vector<int>>> smallPlan = []
+        {
+            const char* e = dev_env("DXTEX_BC7_SMALL_PLAN");
+            const char* p = e ? e : "1,26/3,2/16,14,15,18,7,0|24/28/25";
+            std::vector<std::vector<std::vector<int>>> stages(1, std::vector<std::vector<int>>(1));
+            while (*p)
+            {
+                if (*p >= '0' && *p <= '9') stages.back().back().push_back(int(strtol(p, const_cast<char**>(&p), 10)));
+                else
+                {
+                    if (*p == '|') stages.emplace_back(1);
+                    else if (*p == '/' && stages.back().size() < size_t(kSideStreams) + 1) stages.back().emplace_back();
+                    ++p;
+                }
+            }
+            return stages;
+        }();
+        static const bool noSmall = dev_env("DXTEX_BC7_NO_SMALL_PLAN") != nullptr;
+        if (fork && !noSmall && L.auxTpb >= 32 && perPass <= kSmallPassBlocks && dev_env("DXTEX_BC7_ORDER") == nullptr)
+        {
+            for (const std::vector<std::vector<int>>& stage : smallPlan)
+            {
+                if (stage.size() > 1) (void)hipEventRecord(fork->forked, stream);
+                for (size_t l = 1; l < stage.size(); ++l)
+                {
+                    hipStream_t s = fork->side[l - 1];
+                    (void)hipStreamWaitEvent(s, fork->forked, 0);
+                    const Bc7Args al = side_args(a, l - 1);
+                    for (int step : stage[l])
+                        if (three || (step != 0 && step != 2)) run_step(step, al, s, nullptr);
+                    (void)hipEventRecord(fork->joined[l - 1], s);
+                }
+                for (int step : stage[0])
+                    if (three || (step != 0 && step != 2)) run_step(step, a, stream, nullptr);
+                for (size_t l = 1; l < stage.size(); ++l) (void)hipStreamWaitEvent(stream, fork->joined[l - 1], 0);
+            }
+        }
+        else
         for (size_t at = 0; at < order.size() && !quick; )
         {
             const int step = order[at];
@@ -1529,11 +1596,7 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
             (void)hipEventRecord(fork->forked, stream);
             for (size_t k = 1; k < run; ++k)
             {
-                Bc7Args b = a;
-                b.recs = reinterpret_cast<TaskRec*>(base + L.auxRecs) + (k - 1) * size_t(a.nblocks) * 4;
-                b.order = reinterpret_cast<uint2*>(base + L.auxOrder) + (k - 1) * size_t(a.nblocks) * 4;
-                b.tinfo = reinterpret_cast<uint32_t*>(base + L.auxTinfo) + (k - 1) * size_t(a.nblocks) * 4;
-                b.counters = reinterpret_cast<uint32_t*>(base + L.auxCounters) + (k - 1) * 64;
+                const Bc7Args b = side_args(a, k - 1);
                 (void)hipStreamWaitEvent(fork->side[k - 1], fork->forked, 0);
                 run_step(order[at + k], b, fork->side[k - 1], nullptr);
                 (void)hipEventRecord(fork->joined[k - 1], fork->side[k - 1]);

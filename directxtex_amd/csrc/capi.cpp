@@ -52,7 +52,6 @@ struct dxtex_ctx
     std::vector<uint8_t> triHost;
     void* triPinned = nullptr; size_t triPinnedBytes = 0; hipEvent_t triConsumed = nullptr; bool triPending = false;
     void* mseBuf = nullptr; size_t mseBytes = 0;
-    void* bcQueues = nullptr; size_t bcQueuesBytes = 0;       // work queues of the streaming BC1 - BC5 kernel (launch_bc15_encode)
     // R32G32B32A32_FLOAT rows on their way into a format whose element holds several texels (launch_pack_group)
     void* groupRows = nullptr; size_t groupRowsBytes = 0;
     // dxtex_compress_many (host pointers): double-buffered pinned + device staging, copy streams on either side of ctx->stream
@@ -64,7 +63,7 @@ struct dxtex_ctx
     } lane[2];
     hipStream_t h2d = nullptr, d2h = nullptr;
     // side streams of the BC7 pipeline (modes 4 / 5 run next to each other): created on first use, destroyed with the context
-    SideStreams side = { { nullptr, nullptr }, nullptr, { nullptr, nullptr } };
+    SideStreams side = {};
     bool sideTried = false, sideOk = false;
     std::string lastError;
     bool profiling = false;
@@ -131,7 +130,7 @@ const SideStreams* side_streams(dxtex_ctx* ctx)
     {
         ctx->sideTried = true;
         bool ok = hipEventCreateWithFlags(&ctx->side.forked, hipEventDisableTiming) == hipSuccess;
-        for (int k = 0; k < 2 && ok; ++k)
+        for (int k = 0; k < kSideStreams && ok; ++k)
             ok = hipStreamCreateWithFlags(&ctx->side.side[k], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&ctx->side.joined[k], hipEventDisableTiming) == hipSuccess;
         ctx->sideOk = ok;
@@ -224,9 +223,7 @@ dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width,
     case FMT_BC1_UNORM: case FMT_BC1_UNORM_SRGB: case FMT_BC2_UNORM: case FMT_BC2_UNORM_SRGB:
     case FMT_BC3_UNORM: case FMT_BC3_UNORM_SRGB: case FMT_BC4_UNORM: case FMT_BC4_SNORM:
     case FMT_BC5_UNORM: case FMT_BC5_SNORM:
-        hr = ensure(ctx, &ctx->bcQueues, &ctx->bcQueuesBytes, bc15_queue_bytes());
-        if (hr != DXTEX_S_OK) return hr;
-        e = launch_bc15_encode(v, dDst, dstRowPitch, dstFormat, flags, threshold, ctx->stream, static_cast<uint32_t*>(ctx->bcQueues));
+        e = launch_bc15_encode(v, dDst, dstRowPitch, dstFormat, flags, threshold, ctx->stream);
         break;
     case FMT_BC7_UNORM: case FMT_BC7_UNORM_SRGB:
     {
@@ -306,7 +303,6 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
     if (ctx->triPinned) (void)hipHostFree(ctx->triPinned);
     if (ctx->triConsumed) (void)hipEventDestroy(ctx->triConsumed);
     if (ctx->mseBuf) (void)hipFree(ctx->mseBuf);
-    if (ctx->bcQueues) (void)hipFree(ctx->bcQueues);
     if (ctx->h2d) { (void)hipStreamSynchronize(ctx->h2d); (void)hipStreamDestroy(ctx->h2d); }
     if (ctx->d2h) { (void)hipStreamSynchronize(ctx->d2h); (void)hipStreamDestroy(ctx->d2h); }
     for (dxtex_ctx::Lane& l : ctx->lane)
@@ -319,7 +315,7 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
         if (l.computed) (void)hipEventDestroy(l.computed);
         if (l.downloaded) (void)hipEventDestroy(l.downloaded);
     }
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < kSideStreams; ++k)
     {
         if (ctx->side.side[k]) { (void)hipStreamSynchronize(ctx->side.side[k]); (void)hipStreamDestroy(ctx->side.side[k]); }
         if (ctx->side.joined[k]) (void)hipEventDestroy(ctx->side.joined[k]);

@@ -15,11 +15,8 @@ protected:
     ~KernelMarks() = default;
 };
 
-// `queues`: bc15_queue_bytes() bytes of device memory owned by the caller's context (the work queues of the streaming kernel that large
-// RGBA8 images take; cleared stream-ordered by the launcher), or nullptr: every image through the one-unit-per-wavefront kernel.
-size_t bc15_queue_bytes();
 hipError_t launch_bc15_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, int dstFormat,
-                              uint32_t flags, float threshold, hipStream_t stream, uint32_t* queues = nullptr);
+                              uint32_t flags, float threshold, hipStream_t stream);
 
 // BC7: `scratch` must hold bc7_scratch_bytes(total number of 4x4 blocks, flags, number of images) bytes of device memory.
 // The _many form runs an array of images (a mip chain, a texture array) through the per-mode pipeline as one block list.
@@ -31,7 +28,8 @@ int bc15_small_batch_max();
 hipError_t launch_bc15_encode_small(const BcImage* images, int count, int dstFormat, uint32_t flags, float threshold, hipStream_t stream);
 // Two extra streams (and the events that fork / join them) for pipelines that are independent of each other until the last kernel:
 // owned by the context (one set per context and device, destroyed with it); nullptr = everything on `stream`.
-struct SideStreams { hipStream_t side[2]; hipEvent_t forked; hipEvent_t joined[2]; };
+constexpr int kSideStreams = 3;
+struct SideStreams { hipStream_t side[kSideStreams]; hipEvent_t forked; hipEvent_t joined[kSideStreams]; };
 size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags, size_t nimages = 1);
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
                              void* scratch, hipStream_t stream, KernelMarks* marks, const SideStreams* side = nullptr);

@@ -163,7 +163,8 @@ def test_pruning_changes_nothing():
     modes of equal endpoint precision sharing one search (default) or searching each from scratch (DXTEX_BC6H_NO_REUSE), and BC7's
     two-region modes in the encoder's order (DXTEX_BC6H_ORDER) instead of the default running order, and BC7's
     whole-block tasks (modes 4 / 5 / 6) searched by groups of lanes (default on lists this short) or a lane each (DXTEX_BC7_NO_GROUP), and the
-    late modes 4 / 5 on the context's side streams (default) or one after the other on its stream (DXTEX_BC7_SERIAL)."""
+    late modes 4 / 5 on the context's side streams (default) or one after the other on its stream (DXTEX_BC7_SERIAL), and a small submission's
+    modes side by side as the default plan has them, in the large-pass order (DXTEX_BC7_NO_SMALL_PLAN) or in another plan (DXTEX_BC7_SMALL_PLAN)."""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
@@ -186,6 +187,7 @@ def test_pruning_changes_nothing():
     """ % root)
     outs = []
     for env in ({}, {"DXTEX_BC7_NO_PRUNE": "1", "DXTEX_BC6H_NO_PRUNE": "1"}, {"DXTEX_BC7_ORDER": "7,6,5,8,4,3,2,1,0", "DXTEX_BC7_PERTURB_PLAIN": "1", "DXTEX_BC7_NO_GROUP": "1", "DXTEX_BC7_SERIAL": "1"},
+                {"DXTEX_BC7_NO_SMALL_PLAN": "1"}, {"DXTEX_BC7_SMALL_PLAN": "16/1/3,2|7,14,15,18|24,26/28/25,0"},
                 {"DXTEX_BC7_ORDER": "26,25,3,1,16,7,15,14,18,24,28,0,2", "DXTEX_BC6H_WAVE_MAX": "0", "DXTEX_BC6H_NO_REUSE": "1", "DXTEX_BC6H_ORDER": "0,1,2,3,4,5,6,7,8,9"}):
         r = subprocess.run([sys.executable, "-c", code] + (["--dev"] if env else []), env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
