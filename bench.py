@@ -404,6 +404,56 @@ def end_to_end(ctx, img, gold_sha):
     return out
 
 
+# kernel name the context's profiler reports -> name rocprofv3 reports
+ROCPROF_NAME = {"bc7_exhaustive_mode1": "bc7_exhaustive_kernel<1, 0, 0>", "bc7_exhaustive_mode3": "bc7_exhaustive_kernel<3, 0, 0>",
+                "bc7_perturb_mode1": "bc7_perturb_filter_kernel<1, 0, 0>", "bc7_perturb_mode3": "bc7_perturb_kernel<3, 0, 0>", "bc7_rough": "bc7_rough_kernel"}
+
+
+def live_pmc(dom, budget_s=150.0):
+    """PMC counters of the dominant kernel, collected NOW, in this run: bench.py cannot read counters in its own process, so it runs the
+    same workload (tools/prof_workloads.py bc7: the same image, the same call, one repetition) under `rocprofv3 --kernel-trace --pmc ...`
+    in child processes - separate passes for TCC FETCH_SIZE, TCC WRITE_SIZE (they do not fit one pass) and the SQ VALU counters, as
+    MI355X_MICROARCH.md's rocprofv3 section prescribes - and parses the CSVs. Returns None when rocprofv3 is missing or a pass fails
+    (the committed profiles/pmc_traffic.json is used then, and says so)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    name = ROCPROF_NAME.get(dom)
+    if not name or not os.path.exists(exe):
+        return None
+    t_start = time.perf_counter()
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="dxtex_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    passes = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]))
+    try:
+        for tag, counters in passes:
+            if time.perf_counter() - t_start > budget_s:
+                return None
+            cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["-d", tmp, "-o", tag, "--output-format", "csv", "--",
+                                                                  sys.executable, os.path.join(ROOT, "tools", "prof_workloads.py"), "bc7", "1"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
+            files = glob.glob(os.path.join(tmp, "**", tag + "_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            acc = {}; n = {}; dur = []
+            for row in csv.DictReader(open(files[0])):
+                if name in row["Kernel_Name"]:
+                    c = row["Counter_Name"]
+                    acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"]); n[c] = n.get(c, 0) + 1
+                    dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+            if not acc:
+                return None
+            for c in acc:
+                out[c] = acc[c] / n[c]
+            out.setdefault("ms_under_counters", {})[tag] = round(sum(dur) / len(dur), 3)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["seconds"] = round(time.perf_counter() - t_start, 1)
+    return out
+
+
 _GOLD = None
 
 
@@ -422,6 +472,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="run the reference on the whole 4096^2 image (about 3.5 min on 128 threads)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes for roofline.traffic / roofline.valu (the committed "
+                    "profiles/pmc_traffic.json is used instead, if it matches the kernel sources)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (cfg3 / cfg4 / cfg5 shard / BC1-5 / decode) reported next to the headline")
     ap.add_argument("--cfg5-images", type=int, default=128, help="images of the cfg5 shard every rank compresses after the timed region (0 = skip); "
                     "128 = a rank's whole share of the 1024 images at 8 GPUs, sixteen chunks of dxtex_compress_many's double-buffered pipeline")
@@ -521,10 +573,44 @@ def main():
             roof["all_kernels_ms"] = {k: round(v, 4) for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])}
             roof["step_kernel_ms"] = round(sum(ms for ms, n in kernels.values()) / nprof, 4)
             roof["step_hbm_frac"] = round(algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6)
-        # PMC counters cannot be collected inside this process: they come from the committed rocprofv3 --pmc passes, and ONLY if that
-        # file was measured on these kernel sources (stamp) and names this run's dominant kernel; otherwise traffic stays null.
+        # PMC counters: measured in THIS run by child rocprofv3 passes over the same workload (live_pmc); the committed file only supplies the
+        # static issue cost per instruction of the kernel's opcode mix (a property of the code: it needs a disassembly) and is the fallback
+        # for everything when rocprofv3 is not available - and then ONLY if it was measured on these kernel sources (stamp) and names this
+        # run's dominant kernel; otherwise traffic stays null.
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if roof and os.path.exists(pmc):
+        committed = None
+        if os.path.exists(pmc):
+            try:
+                committed = json.load(open(pmc))
+            except Exception:
+                committed = None
+        live = None
+        if roof and n_gpus == 1 and not args.no_pmc and not args.no_extra:
+            live = live_pmc(dom)
+        if roof and live and "FETCH_SIZE" in live and "WRITE_SIZE" in live:
+            # rocprofv3 reports the TCC sizes in KiB; the search kernels read task records and 4-byte texels, not 16-byte-per-lane image streams,
+            # so FETCH_SIZE needs no x2 correction here (MI355X_MICROARCH.md, HBM section)
+            roof["traffic"] = int((live["FETCH_SIZE"] + live["WRITE_SIZE"]) * 1024)
+            roof["traffic_source"] = "this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate child passes over tools/prof_workloads.py bc7 (same image, same call)"
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / algo_bytes, 2)
+            if live.get("SQ_INSTS_VALU"):
+                same_src = bool(committed) and committed.get("sources_sha256") == kernel_sources_sha256() and committed.get("kernel") == dom
+                cyc = committed["valu"]["mean_issue_cycles_per_inst"] if same_src and committed.get("valu") else None
+                v = {"valu_insts_per_launch": int(live["SQ_INSTS_VALU"]), "waves": int(live.get("SQ_WAVES", 0)),
+                     "active_lanes_per_valu_inst": round(live["SQ_THREAD_CYCLES_VALU"] / max(1.0, live["SQ_ACTIVE_INST_VALU"]), 1),
+                     "kernel_ms_live": round(per_launch[dom], 3), "kernel_ms_under_counters": live.get("ms_under_counters"),
+                     "method": "SQ_INSTS_VALU (this run) per SIMD x loop-weighted static issue cost of the kernel's opcode mix (profiles/r02_valu_rates.md) / (live duration x 2.4 GHz)"}
+                if cyc:
+                    v["mean_issue_cycles_per_inst"] = cyc
+                    v["issue_utilisation"] = round(min(1.0, live["SQ_INSTS_VALU"] / 1024.0 * cyc / (per_launch[dom] * 1e-3 * 2.4e9)), 3)
+                else:
+                    v["issue_utilisation_if_2_or_4_cycles"] = [round(live["SQ_INSTS_VALU"] / 1024.0 * c / (per_launch[dom] * 1e-3 * 2.4e9), 3) for c in (2.15, 4.15)]
+                tot = live.get("SQ_WAIT_ANY", 0) + live.get("SQ_WAIT_INST_ANY", 0) + live.get("SQ_ACTIVE_INST_ANY", 0)
+                if tot:
+                    v["wave_cycles_parked_stalled_issuing"] = [round(live.get(k, 0) / tot, 2) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")]
+                roof["valu"] = v
+            roof["pmc_seconds"] = live.get("seconds")
+        elif roof and os.path.exists(pmc):
             try:
                 t = json.load(open(pmc))
                 if t.get("kernel") != dom:

@@ -1269,10 +1269,10 @@ namespace
 // bounds the scratch (about 1.1 KiB per block); DXTEX_MAX_BLOCKS_PER_PASS shrinks it so tests can exercise the pass loop
 const uint64_t kMaxBlocksPerPass = dev_env("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(dev_env("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 22);
 constexpr int kMaxTasksPerBlock = 64;                 // mode 2: 16 candidates x 4 lanes
-// A submission of at most this many blocks (a lone 1024^2 image, a small mip chain) is a LATENCY problem: every kernel of the per-mode
+// A submission of at most this many blocks (a lone image up to 2048^2, a mip chain) is a LATENCY problem: every kernel of the per-mode
 // pipelines has fewer tasks than the machine has lanes and lasts as long as its longest serial chain, so the modes - independent until
 // `pick`, see launch_bc7_encode_many - run side by side on the context's side streams, each pipeline with task arrays of its own.
-const uint64_t kSmallPassBlocks = dev_env("DXTEX_BC7_SMALL_BLOCKS") ? strtoull(dev_env("DXTEX_BC7_SMALL_BLOCKS"), nullptr, 10) : 65536;
+const uint64_t kSmallPassBlocks = dev_env("DXTEX_BC7_SMALL_BLOCKS") ? strtoull(dev_env("DXTEX_BC7_SMALL_BLOCKS"), nullptr, 10) : 262144;     // up to a lone 2048^2 image (1448^2: 22.1 -> 20.4 ms, 2048^2: 39.2 -> 38.7; at 4096^2 the plan loses: 139.5 -> 143.7)
 struct ScratchLayout
 {
     size_t lists, cands, px, recs, order, tinfo, counters, zeroOrd, bestErr, seeds, seeds1, seeds3, flagcnt, auxRecs, auxOrder, auxTinfo, auxCounters, total;

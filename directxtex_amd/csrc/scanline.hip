@@ -674,7 +674,8 @@ struct CubicTailArgs
     const uint8_t* src; uint64_t srcPitch; uint32_t srcW, srcH; int nlevels;
     uint8_t* dst[kTailMaxLevels]; uint64_t dstPitch[kTailMaxLevels];
 };
-__global__ void __launch_bounds__(1024) resize_cubic_tail_rgba8_kernel(CubicTailArgs t)
+template<bool CUBIC>
+__global__ void __launch_bounds__(1024) resize_half_tail_rgba8_kernel(CubicTailArgs t)
 {
     __shared__ uint32_t bufA[kTailSide * kTailSide], bufB[(kTailSide / 2) * (kTailSide / 2)];
     uint32_t w = t.srcW, h = t.srcH;
@@ -692,6 +693,22 @@ __global__ void __launch_bounds__(1024) resize_cubic_tail_rgba8_kernel(CubicTail
         for (uint32_t i = threadIdx.x; i < dw * dh; i += 1024u)
         {
             const uint32_t y = i / dw, x = i - y * dw;
+            if constexpr (!CUBIC)
+            {
+                // the box filter of resize_box_half_rgba8_kernel: (((p0 + p1) + p2) + p3) * 0.25 over (2x, 2y), (2x, 2y + 1), (2x + 1, 2y), (2x + 1, 2y + 1)
+                const uint32_t t0 = s[(2u * y) * w + 2u * x], t1 = s[(2u * y) * w + 2u * x + 1u], b0 = s[(2u * y + 1u) * w + 2u * x], b1 = s[(2u * y + 1u) * w + 2u * x + 1u];
+                uint32_t packed = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                {
+                    const float p0 = float((t0 >> (8 * c)) & 0xFFu) * (1.0f / 255.0f), p1 = float((b0 >> (8 * c)) & 0xFFu) * (1.0f / 255.0f);
+                    const float p2 = float((t1 >> (8 * c)) & 0xFFu) * (1.0f / 255.0f), p3 = float((b1 >> (8 * c)) & 0xFFu) * (1.0f / 255.0f);
+                    packed |= store_ubn_biased((((p0 + p1) + p2) + p3) * 0.25f) << (8 * c);
+                }
+                d[i] = packed;
+                reinterpret_cast<uint32_t*>(t.dst[l] + uint64_t(y) * t.dstPitch[l])[x] = packed;
+                continue;
+            }
             const int32_t u0 = int32_t(2u * x) - 1, v0 = int32_t(2u * y) - 1;
             uint32_t xi[4];
 #pragma unroll
@@ -1034,13 +1051,14 @@ hipError_t launch_resize(const uint8_t* src, uint64_t srcPitch, uint32_t srcW, u
     return hipGetLastError();
 }
 
+bool resize_half_tail_applies(const MipLevel* levels, int nlevels, int format, uint32_t filterFlags);
 hipError_t launch_resize_tail(const MipLevel* levels, int nlevels, int format, uint32_t filterMode, uint32_t filterFlags,
                               const MipLevel* twoHigh, hipStream_t stream)
 {
     if (nlevels < 2) return hipSuccess;
-    if (filterMode == 0x300000u)
+    if (filterMode == 0x300000u || (filterMode == 0x400000u && resize_half_tail_applies(levels, nlevels, format, filterFlags)))
     {
-        // resize_tail_applies admitted the chain: RGBA8, clamp, no sRGB, every level an exact halving (checked again here)
+        // the LDS tail: RGBA8, no sRGB, every level an exact halving (cubic: clamp addressing; admitted by the caller, checked again here)
         CubicTailArgs c;
         c.src = levels[0].pixels; c.srcPitch = levels[0].pitch; c.srcW = levels[0].width; c.srcH = levels[0].height; c.nlevels = nlevels - 1;
         if (format != FMT_R8G8B8A8_UNORM || (filterFlags & 0x3000077u) || c.nlevels > kTailMaxLevels || c.srcW > kTailSide || c.srcH > kTailSide) return hipErrorInvalidValue;
@@ -1051,7 +1069,8 @@ hipError_t launch_resize_tail(const MipLevel* levels, int nlevels, int format, u
             c.dst[k - 1] = levels[k].pixels; c.dstPitch[k - 1] = levels[k].pitch;
         }
         for (int k = nlevels - 1; k < kTailMaxLevels; ++k) { c.dst[k] = c.dst[0]; c.dstPitch[k] = c.dstPitch[0]; }
-        hipLaunchKernelGGL(resize_cubic_tail_rgba8_kernel, dim3(1), dim3(1024), 0, stream, c);
+        if (filterMode == 0x300000u) hipLaunchKernelGGL(resize_half_tail_rgba8_kernel<true>, dim3(1), dim3(1024), 0, stream, c);
+        else hipLaunchKernelGGL(resize_half_tail_rgba8_kernel<false>, dim3(1), dim3(1024), 0, stream, c);
         return hipGetLastError();
     }
     TailArgs t;
@@ -1081,7 +1100,7 @@ hipError_t launch_resize_tail(const MipLevel* levels, int nlevels, int format, u
     return hipGetLastError();
 }
 
-bool resize_cubic_tail_applies(const MipLevel* levels, int nlevels, int format, uint32_t filterFlags)
+bool resize_half_tail_applies(const MipLevel* levels, int nlevels, int format, uint32_t filterFlags)
 {
     // the LDS tail of a power-of-two RGBA8 chain (resize_cubic_tail_rgba8_kernel): every remaining level halves both sides exactly
     if (nlevels < 2 || nlevels - 1 > kTailMaxLevels || format != FMT_R8G8B8A8_UNORM || (filterFlags & 0x3000077u)) return false;       // sRGB, wrap, mirror bits
@@ -1090,6 +1109,11 @@ bool resize_cubic_tail_applies(const MipLevel* levels, int nlevels, int format, 
         if (levels[k].width * 2u != levels[k - 1].width || levels[k].height * 2u != levels[k - 1].height || (levels[k].pitch % 4) != 0 ||
             (reinterpret_cast<uintptr_t>(levels[k].pixels) % 4) != 0) return false;
     return true;
+}
+
+bool resize_cubic_tail_applies(const MipLevel* levels, int nlevels, int format, uint32_t filterFlags)
+{
+    return resize_half_tail_applies(levels, nlevels, format, filterFlags);
 }
 
 bool resize_tail_applies(uint32_t srcW, uint32_t srcH, uint32_t filterMode)

@@ -76,7 +76,7 @@ if "bc1" in what:
     for fmt, nm in ((71, "bc1"), (74, "bc2"), (77, "bc3"), (80, "bc4"), (83, "bc5")):
         run(nm + " 4096^2", img, 28, fmt, 4096, 4096, None, reps=20)
 if "small" in what:
-    for S in (256, 512, 1024):
+    for S in [int(x) for x in os.environ.get("PROBE_SIZES", "256,512,1024").split(",")]:
         run("bc7 %d^2" % S, synth.survey_rgba8(S, S, 2, "opaque"), 28, 98, S, S, None, reps=5)
 if "cfg4" in what:
     W = H = 8192
