@@ -15,6 +15,10 @@
 #include "dxtex_dev.h"
 #include "dxtex_kernels.h"
 
+#if !defined(DXTEX_BC15_CODES)
+#define DXTEX_BC15_CODES 1             // 0: the colour fit on 48 floats per lane as in rounds 2 - 3 (A/B builds)
+#endif
+
 namespace dxtex
 {
 namespace
@@ -68,9 +72,60 @@ struct StepCoef
     __device__ __forceinline__ float d(float k) const { return k * r; }
 };
 
+// What the colour fit reads: the sixteen quantised (5:6:5 grid), luminance-weighted colours of the block (BC.cpp:418-490).
+// ArrayColors: as 48 floats (any tile, the dithered path). CodeColors: as one dword of 5:6:5 codes per texel, decoded where a component is
+// read - float(code) * (1/31 | 1/63), then the luminance weight: the operations that produced the array's floats, so the same floats - which
+// keeps 16 registers live across the Newton loop instead of 48. The fit needs ~200 registers with the array (two waves per SIMD, where a
+// SIMD that loses one wave to a stall issues at a single wave's rate - 4 cycles per instruction even for the 2-cycle opcodes,
+// profiles/r02_valu_rates.md, W = 1 column); with the codes it fits four.
+struct ArrayColors
+{
+    const float (&pr)[16]; const float (&pg)[16]; const float (&pb)[16];
+    __device__ __forceinline__ float r(int i) const { return pr[i]; }
+    __device__ __forceinline__ float g(int i) const { return pg[i]; }
+    __device__ __forceinline__ float b(int i) const { return pb[i]; }
+    __device__ __forceinline__ void launder() const {}
+    template<class F>
+    __device__ __forceinline__ void for_texels(F&& f)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) f(i);
+    }
+};
+struct CodeColors
+{
+    uint32_t q[16];          // r5 | g6 << 8 | b5 << 16
+    float wr, wb;            // luminance weights of red and blue (1.0f with BC_FLAGS_UNIFORM: x * 1.0f is x; green's weight is 1)
+    __device__ __forceinline__ float r(int i) const { return float(q[i] & 0xFFu) * (1.0f / 31.0f) * wr; }
+    __device__ __forceinline__ float g(int i) const { return float((q[i] >> 8) & 0xFFu) * (1.0f / 63.0f); }
+    __device__ __forceinline__ float b(int i) const { return float((q[i] >> 16) & 0xFFu) * (1.0f / 31.0f) * wb; }
+    // keeps the optimiser from hoisting the 48 decoded floats out of a loop (they are loop invariants): no instruction is emitted
+    __device__ __forceinline__ void launder()
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(q[i]));
+    }
+    // f(k) for the texels in order, four per trip of a ROLLED loop: the trip works on q[0..3] and then rotates the sixteen registers by
+    // four (sixteen moves), so the body exists once - four texels of temporaries - instead of sixteen times interleaved by the scheduler,
+    // which is what held the fit at ~200 registers whatever the texels were kept as. After four trips the order is the original one.
+    template<class F>
+    __device__ __forceinline__ void for_texels(F&& f)
+    {
+#pragma unroll 1
+        for (int grp = 0; grp < 4; ++grp)
+        {
+            f(0); f(1); f(2); f(3);
+            const uint32_t t0 = q[0], t1 = q[1], t2 = q[2], t3 = q[3];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) q[k] = q[k + 4];
+            q[12] = t0; q[13] = t1; q[14] = t2; q[15] = t3;
+        }
+    }
+};
+
 // 6-D Newton endpoint fit over 16 points (BC.cpp:65-314).
-__device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const float (&pg)[16], const float (&pb)[16],
-                               uint32_t cSteps, bool uniform,
+template<class CS>
+__device__ __forceinline__ void optimize_rgb16(CS& cs, uint32_t cSteps, bool uniform,
                                float& oXr, float& oXg, float& oXb, float& oYr, float& oYg, float& oYb)
 {
     constexpr float fEpsilon = (0.25f / 64.0f) * (0.25f / 64.0f);
@@ -80,16 +135,16 @@ __device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const floa
     float Xb = uniform ? 1.0f : (0.0721f / 0.7154f);
     float Yr = 0.0f, Yg = 0.0f, Yb = 0.0f;
 
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
+    cs.for_texels([&](int i)
     {
-        if (pr[i] < Xr) Xr = pr[i];
-        if (pg[i] < Xg) Xg = pg[i];
-        if (pb[i] < Xb) Xb = pb[i];
-        if (pr[i] > Yr) Yr = pr[i];
-        if (pg[i] > Yg) Yg = pg[i];
-        if (pb[i] > Yb) Yb = pb[i];
-    }
+        const float vr = cs.r(i), vg = cs.g(i), vb = cs.b(i);
+        if (vr < Xr) Xr = vr;
+        if (vg < Xg) Xg = vg;
+        if (vb < Xb) Xb = vb;
+        if (vr > Yr) Yr = vr;
+        if (vg > Yg) Yg = vg;
+        if (vb > Yb) Yb = vb;
+    });
 
     const float ABr = Yr - Xr, ABg = Yg - Xg, ABb = Yb - Xb;
     const float fAB = ABr * ABr + ABg * ABg + ABb * ABb;
@@ -105,18 +160,17 @@ __device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const floa
     const float Mr = (Xr + Yr) * 0.5f, Mg = (Xg + Yg) * 0.5f, Mb = (Xb + Yb) * 0.5f;
 
     float fDir0 = 0.0f, fDir1 = 0.0f, fDir2 = 0.0f, fDir3 = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
+    cs.for_texels([&](int i)
     {
-        const float Pr = (pr[i] - Mr) * Dr;
-        const float Pg = (pg[i] - Mg) * Dg;
-        const float Pb = (pb[i] - Mb) * Db;
+        const float Pr = (cs.r(i) - Mr) * Dr;
+        const float Pg = (cs.g(i) - Mg) * Dg;
+        const float Pb = (cs.b(i) - Mb) * Db;
         float f;
         f = Pr + Pg + Pb; fDir0 += f * f;
         f = Pr + Pg - Pb; fDir1 += f * f;
         f = Pr - Pg + Pb; fDir2 += f * f;
         f = Pr - Pg - Pb; fDir3 += f * f;
-    }
+    });
 
     float fDirMax = fDir0; uint32_t iDirMax = 0;
     if (fDir1 > fDirMax) { fDirMax = fDir1; iDirMax = 1; }
@@ -149,10 +203,10 @@ __device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const floa
         float d2X = 0.0f, d2Y = 0.0f;
         float dXr = 0.0f, dXg = 0.0f, dXb = 0.0f, dYr = 0.0f, dYg = 0.0f, dYb = 0.0f;
 
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
+        cs.for_texels([&](int i)
         {
-            const float fDot = (pr[i] - Xr) * Dr + (pg[i] - Xg) * Dg + (pb[i] - Xb) * Db;
+            const float vr = cs.r(i), vg = cs.g(i), vb = cs.b(i);
+            const float fDot = (vr - Xr) * Dr + (vg - Xg) * Dg + (vb - Xb) * Db;
 
             // fDot <= 0 -> 0, fDot >= fSteps -> cSteps - 1, else uint32(fDot + 0.5f) (BC.cpp:225-231): the clamp maps the two outer
             // cases onto the same conversion, so the three-way branch becomes straight-line code (inputs are finite)
@@ -160,9 +214,9 @@ __device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const floa
 
             const float c = coef.c(kStep), d = coef.d(kStep);
             // pSteps[iStep] = X * pC[iStep] + Y * pD[iStep], evaluated where it is used
-            const float diffR = (Xr * c + Yr * d) - pr[i];
-            const float diffG = (Xg * c + Yg * d) - pg[i];
-            const float diffB = (Xb * c + Yb * d) - pb[i];
+            const float diffR = (Xr * c + Yr * d) - vr;
+            const float diffG = (Xg * c + Yg * d) - vg;
+            const float diffB = (Xb * c + Yb * d) - vb;
 
             const float fC = c * (1.0f / 8.0f);
             const float fD = d * (1.0f / 8.0f);
@@ -172,7 +226,7 @@ __device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const floa
             d2Y += fD * d;
             dYr += fD * diffR; dYg += fD * diffG; dYb += fD * diffB;
             if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four texels at a time: keeps the temporaries of an iteration within the register budget
-        }
+        });
 
         if (d2X > 0.0f)
         {
@@ -198,6 +252,7 @@ __device__ __forceinline__ void optimize_rgb16(const float (&pr)[16], const floa
 // load_tile uses) applied wherever a component is read; with it the BC1-BC5 kernels fit twice as many waves per SIMD.
 struct TileView
 {
+    static constexpr bool kPacked = false;
     const Tile& t; const float (&al)[16];
     __device__ __forceinline__ void launder() const {}
     __device__ __forceinline__ float r(int i) const { return t.r[i]; }
@@ -207,6 +262,7 @@ struct TileView
 };
 struct PackedTile
 {
+    static constexpr bool kPacked = true;
     uint32_t px[16];
     __device__ __forceinline__ float r(int i) const { return float(px[i] & 0xFFu) * (1.0f / 255.0f); }
     __device__ __forceinline__ float g(int i) const { return float((px[i] >> 8) & 0xFFu) * (1.0f / 255.0f); }
@@ -222,7 +278,7 @@ struct PackedTile
 };
 
 // BC1 colour block (BC.cpp:370-685). Alpha is only read when bColorKey is set.
-template<bool DITHER, class TS>
+template<bool DITHER, class TS, bool CODES = false>
 __device__ __forceinline__ uint2 encode_bc1_color(TS& s, bool bColorKey, float threshold, uint32_t flags)
 {
     const bool uniform = (flags & BCF_UNIFORM) != 0;
@@ -243,9 +299,22 @@ __device__ __forceinline__ uint2 encode_bc1_color(TS& s, bool bColorKey, float t
         uSteps = (uColorKey > 0) ? 3u : 4u;
     }
 
+    float er[DITHER ? 16 : 1], eg[DITHER ? 16 : 1], eb[DITHER ? 16 : 1];
+    float Ar, Ag, Ab, Br, Bg, Bb;
+    if constexpr (!DITHER && TS::kPacked && CODES && DXTEX_BC15_CODES)
+    {
+        // Quantise to the 5:6:5 grid; the codes stay packed and the fit decodes them where it reads them (CodeColors)
+        CodeColors cc;
+        cc.wr = uniform ? 1.0f : LumR; cc.wb = uniform ? 1.0f : LumB;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            cc.q[i] = uint32_t(int32_t(s.r(i) * 31.0f + 0.5f)) | (uint32_t(int32_t(s.g(i) * 63.0f + 0.5f)) << 8) | (uint32_t(int32_t(s.b(i) * 31.0f + 0.5f)) << 16);
+        optimize_rgb16(cc, uSteps, uniform, Ar, Ag, Ab, Br, Bg, Bb);
+    }
+    else
+    {
     // Quantise to the 565 grid (optionally error-diffused), then weight by luminance.
     float cr[16], cg[16], cb[16];
-    float er[DITHER ? 16 : 1], eg[DITHER ? 16 : 1], eb[DITHER ? 16 : 1];
     if constexpr (DITHER)
     {
 #pragma unroll
@@ -273,8 +342,9 @@ __device__ __forceinline__ uint2 encode_bc1_color(TS& s, bool bColorKey, float t
         if (!uniform) { cr[i] *= LumR; cg[i] *= 1.0f; cb[i] *= LumB; }
     }
 
-    float Ar, Ag, Ab, Br, Bg, Bb;
-    optimize_rgb16(cr, cg, cb, uSteps, uniform, Ar, Ag, Ab, Br, Bg, Bb);
+    ArrayColors ac{ cr, cg, cb };
+    optimize_rgb16(ac, uSteps, uniform, Ar, Ag, Ab, Br, Bg, Bb);
+    }
     s.launder();
 
     float Cr, Cg, Cb, Dr, Dg, Db;
@@ -778,7 +848,8 @@ __device__ __forceinline__ void encode_packed(PackedTile& t, uint8_t* out, uint3
             for (int i = 0; i < 16; ++i) pa[i] = t.a(i);
             al = (KIND == 2) ? encode_bc2_alpha(pa, a.flags) : encode_bc3_alpha(pa, a.flags);
         }
-        const uint2 c = encode_bc1_color<DITHER>(t, false, 0.0f, a.flags);
+        // BC3: the fit on packed codes (four waves per SIMD, no spill); BC2 keeps the float array at two (measured, see bc15_encode_kernel)
+        const uint2 c = encode_bc1_color<DITHER, PackedTile, KIND == 3>(t, false, 0.0f, a.flags);
         reinterpret_cast<uint4*>(out)[bx] = make_uint4(al.x, al.y, c.x, c.y);
     }
     else
@@ -798,14 +869,19 @@ __device__ __forceinline__ void encode_packed(PackedTile& t, uint8_t* out, uint3
     }
 }
 
+#if !defined(DXTEX_BC15_COLOR_WGS)
+#define DXTEX_BC15_COLOR_WGS 4         // workgroups per CU of the BC1 - BC3 instantiations whose fit reads packed 5:6:5 codes (CodeColors)
+#endif
 #if !defined(DXTEX_BC15_PACKED_WGS)
 #define DXTEX_BC15_PACKED_WGS 3        // workgroups per CU the packed-tile instantiations of BC3 - BC5 are compiled for
 #endif
-// Occupancy per codec, measured (round 4, 4096^2 cfg2 image / BC3 of the 8192^2 cfg4 chain with random alpha): BC1 and BC2 at 2 workgroups per
-// CU (no spill; BC2 0.123 ms against 0.144 at 3), BC3 at 3 (128 bytes of scratch per lane, and still the faster one where alpha is busy: the
-// cfg4 chain 0.956 ms against 1.065 at 2; no difference on opaque images).
+// Occupancy per codec, measured (round 4, 4096^2 cfg2 image / BC3 of the 8192^2 cfg4 chain with random alpha, same box): BC1 and BC2 with the
+// fit on 48 floats at 2 workgroups per CU (no spill; BC2 0.128 ms against 0.144 at 3) - on packed codes at 3 - 4 workgroups they are slower
+// (0.146 against 0.135 / 0.128: decoding costs 8 operations per texel and trip, a quarter more VALU work, and these kernels are VALU-bound at
+// any occupancy). BC3, whose alpha fit shares the registers, spilled 128 bytes per lane at 3 workgroups and was slower still at 2; on codes
+// at 4 workgroups it has no scratch: 0.163 -> 0.147 ms per 4096^2 image, the cfg4 chain 1.16 -> 0.93 ms.
 template<int KIND, bool DITHER, bool PACKED8>
-__global__ void __launch_bounds__(256, PACKED8 ? (KIND <= 2 ? 2 : DXTEX_BC15_PACKED_WGS) : 1) bc15_encode_kernel(EncodeArgs a)
+__global__ void __launch_bounds__(256, PACKED8 ? ((KIND == 3 && !DITHER && DXTEX_BC15_CODES) ? DXTEX_BC15_COLOR_WGS : (KIND <= 2 ? 2 : DXTEX_BC15_PACKED_WGS)) : 1) bc15_encode_kernel(EncodeArgs a)
 {
     // A wavefront takes an 8 x 8 tile of blocks (32 x 32 texels), not 64 blocks of one block row: what the lanes of a wavefront do
     // differs by content - flat blocks leave the fit at once, noisy ones run its eight Newton trips - and content is coherent in two
