@@ -560,6 +560,46 @@ def main():
             if distributed:
                 raise
 
+    # One image split over the GPUs (strong scaling): every rank encodes a stripe of block rows of THE SAME 4096^2 image (rank 0's),
+    # the stripes are gathered on every rank - the package's only data-path collective, one all_gather of 16 MiB / N per rank. Reported next
+    # to the headline for N > 1; the headline itself stays image-per-GPU.
+    split = None
+    if distributed and not args.no_extra:
+        try:
+            img0 = make_image(0)
+            nbh = HEIGHT // 4
+            r0, r1 = sharding.stripe_rows(nbh, world, rank)
+            s_src = torch.from_numpy(np.ascontiguousarray(img0[r0 * 4:r1 * 4])).to(dev)
+            s_dst = torch.empty((r1 - r0) * rp, dtype=torch.uint8, device=dev)
+
+            def split_step():
+                if r1 > r0:
+                    ctx.compress_device(s_src.data_ptr(), WIDTH, (r1 - r0) * 4, dx.DXGI_FORMAT_R8G8B8A8_UNORM, s_dst.data_ptr(), dx.DXGI_FORMAT_BC7_UNORM, 0, 0.5)
+                torch.cuda.synchronize(dev)
+                return sharding.gather_stripes(s_dst, nbh, rp, world, rank)
+
+            split_step()                                      # warm-up: scratch for the stripe's size, the collective's buffers
+            barrier(); torch.cuda.synchronize(dev)
+            ts = time.perf_counter()
+            nsplit = max(1, min(3, args.steps))
+            for _ in range(nsplit):
+                whole = split_step()
+            torch.cuda.synchronize(dev); barrier()
+            dts, _ = sharding.aggregate((time.perf_counter() - ts) / nsplit, 0.0, world, dev)
+            if rank == 0:
+                gold = golden_case("cfg2_bc7_4096")
+                ok = None
+                if gold and hashlib.sha256(img0.tobytes()).hexdigest() == gold["input_sha256"]:
+                    ok = band_sha(whole.cpu().numpy(), WIDTH, HEIGHT) == gold["bands"]
+                split = {"ms": round(dts * 1e3, 3), "Mtexels_s": round(WIDTH * HEIGHT / dts / 1e6, 2), "n_gpus": world, "scaling": "strong",
+                         "identical_to_reference_golden": ok,
+                         "workload": f"ONE 4096^2 RGBA8 image -> BC7: rank r encodes block rows [r, r+1) * {nbh} / {world}, the stripes are all_gathered ({args.backend}); "
+                                     "time = slowest rank, payload on every GPU when it stops"}
+            del s_src, s_dst, whole
+        except Exception as e:
+            if rank == 0:
+                split = {"error": repr(e)}
+
     if rank == 0:
         # ---- roofline of the dominant kernel -----------------------------------------------------------
         per_launch = {k: (ms / max(1, n)) for k, (ms, n) in kernels.items()}
@@ -664,6 +704,8 @@ def main():
                 extra["other_workloads"] = other_workloads(ctx, dev, img, rank, world)
             except Exception as e:
                 extra["other_workloads_error"] = repr(e)
+        if split:
+            extra.setdefault("other_workloads", {})["bc7_4096_split"] = split
         if cfg5:
             if n_gpus == 1 and not args.no_cpu_baseline and "error" not in cfg5:
                 try:

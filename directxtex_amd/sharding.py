@@ -2,7 +2,11 @@
 round-robin; units are independent, so there is NO data-path collective. The only communication is the timing protocol
 of the benchmark: a barrier on both sides of the timed region and a MAX over the ranks' elapsed times (plus a SUM of
 the texels each rank processed). Works with any torch.distributed backend: "nccl" (= RCCL over xGMI) on the GPUs,
-"gloo" in the CPU tests."""
+"gloo" in the CPU tests.
+
+The one place with a real exchange step is a SINGLE image split over the GPUs ("a single huge image may be split by
+block-rows", no halo for a block codec): every rank encodes a stripe of block rows and the stripes are gathered where the caller
+wants the payload (stripe_rows, gather_stripes: one all_gather of the BC stripes - RCCL over xGMI on the GPUs)."""
 import os
 
 
@@ -25,6 +29,37 @@ def run_shard(n_images, world, rank, load, compress_many, batch=128, limit=None)
         for i, payload in zip(idx, compress_many([load(i) for i in idx])):
             out[i] = payload
     return out
+
+
+def stripe_rows(block_rows, world, rank):
+    """Block rows [r0, r1) of a single image that rank `rank` of `world` encodes: contiguous, the first block_rows % world ranks take one
+    more (a block codec needs no halo: blocks are independent, DirectXTexCompress.cpp:257-281)."""
+    base, rem = divmod(int(block_rows), int(world))
+    r0 = rank * base + min(rank, rem)
+    return r0, r0 + base + (1 if rank < rem else 0)
+
+
+def gather_stripes(stripe, block_rows, row_bytes, world, rank):
+    """The one data-path collective of the package: every rank's stripe of BC block rows (a uint8 tensor of (r1 - r0) * row_bytes bytes, on
+    the GPU with "nccl", anywhere with "gloo") -> the whole payload, on every rank (all_gather; stripes are padded to the longest one, which
+    differs by at most one block row). Returns a uint8 tensor of block_rows * row_bytes bytes on the stripe's device."""
+    import torch
+    if world <= 1:
+        return stripe
+    import torch.distributed as dist
+    longest = stripe_rows(block_rows, world, 0)[1] * row_bytes
+    dev = stripe.device
+    send = torch.zeros(longest, dtype=torch.uint8, device=dev)
+    send[:stripe.numel()] = stripe
+    if dist.get_backend() == "gloo":
+        send = send.cpu()                                  # gloo gathers host tensors
+    got = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(got, send)
+    parts = []
+    for r in range(world):
+        r0, r1 = stripe_rows(block_rows, world, r)
+        parts.append(got[r][:(r1 - r0) * row_bytes])
+    return torch.cat(parts).to(dev)
 
 
 def gather_index(results, world):

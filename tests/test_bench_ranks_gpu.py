@@ -33,6 +33,12 @@ def test_two_ranks_one_gpu():
     # whole-job value = texels of both ranks / the slower rank's time
     texels = 2 * 4096 * 4096 * line["steps"]
     assert abs(line["value"] - texels / (line["ms_per_step"] * 1e-3 * line["steps"]) / 1e6) <= 0.01 * line["value"]
+    # the single-image split (strong scaling): both ranks encode half of rank 0's image, the stripes are all_gathered, the payload is the reference's
+    sp = line["other_workloads"]["bc7_4096_split"]
+    assert "error" not in sp, sp
+    assert sp["n_gpus"] == 2 and sp["scaling"] == "strong" and sp["ms"] > 0
+    if os.path.exists(os.path.join(ROOT, "tests", "golden", "fullsize.json")):
+        assert sp["identical_to_reference_golden"] is True, sp
     c5 = line["other_workloads"]["cfg5_shard"]
     assert "error" not in c5, c5
     assert c5["images"] == 20 and c5["indices_disjoint"] is True

@@ -114,3 +114,47 @@ def test_single_rank_is_identity():
     from directxtex_amd import sharding
     assert sharding.images_for_rank(5, 1, 0) == [0, 1, 2, 3, 4]
     assert sharding.aggregate(0.5, 100, 1) == (0.5, 100.0)
+
+
+STRIPE_WORKER = r'''
+import os, sys, json, hashlib
+import numpy as np, torch
+sys.path.insert(0, %r)
+from directxtex_amd import sharding
+rank, world = sharding.init_from_env("gloo")
+rows, row_bytes = 11, 48                              # 11 block rows over 3 ranks: 4 + 4 + 3
+whole = (np.arange(rows * row_bytes, dtype=np.uint32) * 2654435761 >> 13).astype(np.uint8)
+r0, r1 = sharding.stripe_rows(rows, world, rank)
+mine = torch.from_numpy(whole[r0 * row_bytes:r1 * row_bytes].copy())
+got = sharding.gather_stripes(mine, rows, row_bytes, world, rank)
+print(json.dumps({"rank": rank, "r": [r0, r1], "same": bool(np.array_equal(got.numpy(), whole)), "n": int(got.numel())}), flush=True)
+import torch.distributed as dist
+dist.destroy_process_group()
+'''
+
+
+def test_one_image_split_by_block_rows():
+    """The single-image split (SURVEY 8e): stripes of block rows are contiguous, cover the image exactly once whatever the rank count, and
+    the all_gather of the (padded) stripes reassembles the payload on every rank - three gloo ranks, eleven block rows."""
+    import json
+    from directxtex_amd import sharding
+    for rows in (1, 7, 8, 1024, 1026):
+        for world in (1, 2, 3, 8):
+            cover = [sharding.stripe_rows(rows, world, r) for r in range(world)]
+            assert cover[0][0] == 0 and cover[-1][1] == rows
+            assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+            sizes = [b - a for a, b in cover]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    port = _free_port()
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", STRIPE_WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("{")][-1]))
+    outs.sort(key=lambda d: d["rank"])
+    assert [o["r"] for o in outs] == [[0, 4], [4, 8], [8, 11]]
+    assert all(o["same"] and o["n"] == 11 * 48 for o in outs)
