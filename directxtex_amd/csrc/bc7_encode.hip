@@ -380,8 +380,11 @@ __device__ __forceinline__ void stage_packed(const Bc7Args& a, uint32_t nbFirst,
     wave_lds_sync();
 }
 
+#if !defined(DXTEX_PP45_WGS)
+#define DXTEX_PP45_WGS 1               // workgroups per CU the pre / post kernels of modes 4 / 5 are compiled for (1 = unconstrained: 200 - 256 registers, two waves per SIMD)
+#endif
 template<int MODE, int IM>
-__global__ void __launch_bounds__(256) bc7_pre_kernel(Bc7Args a)
+__global__ void __launch_bounds__(256, (MODE == 4 || MODE == 5) ? DXTEX_PP45_WGS : 1) bc7_pre_kernel(Bc7Args a)
 {
     typedef TaskMap<MODE, IM> TM;
     constexpr int BPW = (TM::TPB >= 64) ? 1 : 64 / TM::TPB;       // blocks per wavefront
@@ -1101,7 +1104,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_wave_kernel(Bc7Args a)
 }
 
 template<int MODE, int IM>
-__global__ void __launch_bounds__(256) bc7_post_kernel(Bc7Args a)
+__global__ void __launch_bounds__(256, (MODE == 4 || MODE == 5) ? DXTEX_PP45_WGS : 1) bc7_post_kernel(Bc7Args a)
 {
     typedef TaskMap<MODE, IM> TM;
     constexpr int BPW = (TM::TPB >= 64) ? 1 : 64 / TM::TPB;
