@@ -341,6 +341,90 @@ DXTEX_HD6 float perturb6_candidate(const Texels& tx, const Perturb6& s, const fl
     return map_colors_q<N>(tx, pr, pg, pb);
 }
 
+// ---- a LOWER BOUND on perturb6_candidate's result (bc6h_perturb_filter_kernel) ------------------------------------------------
+// PerturbOne accepts a candidate only if its error is BELOW the best so far (:2124), so a candidate whose error provably is not
+// needs no exact evaluation. The reference's error is Σ_k fl(first local minimum over the entries of fl(|p_k - q_i|^2)), every
+// operation rounded to fp32: with u = 2^-24 it is at least (1 - 18 u) E*, E* = Σ_k min_i |p_k - q_i|^2 in real arithmetic (all
+// terms are non-negative, a region has at most 16 texels; the first local minimum is never below the minimum). E* is evaluated
+// through scores, |p - q|^2 = |p|^2 - (2 p.q - |q|^2): three FMAs per (texel, entry) and a running maximum instead of eight ordered
+// operations and a compare / select pair, with the coordinates moved to the region's first texel o (an exact integer translation)
+// so that the cancellation in |p|^2 - score is of the order of the region's spread, not of its brightness. Rounding: every
+// intermediate of a score is at most G = |p'|^2 + 2 |q'|^2 in magnitude and passes six roundings (|q'|^2: three, the FMAs: three);
+// the sum of the maxima adds np - 1 roundings of partial sums below H = Σ|p'_k|^2 + 2 np max_i |q'_i|^2, the sum of |p'_k|^2 np + 2,
+// the subtraction one: |computed - E*| <= 42 u H, and 18 u E* <= 36 u H (E* <= 2 H). The bound subtracts 2^-17 H = 128 u H.
+// tools/bc6h_debug.cpp (-DDXTEX_COUNT_EVALS6) checks bound <= exact on every candidate of the host search and counts what passes.
+#if defined(DXTEX_COUNT_EVALS6)
+void count_bound6(int n, int np, int step, float bound, float exact, float best);     // tools/bc6h_debug.cpp
+#endif
+struct Bound6 { float o[3]; float pp; };                 // per task: the centre and fl(Σ |p_k - o|^2)
+
+DXTEX_HD6 Bound6 bound6_begin(const Texels& tx)
+{
+    Bound6 b; b.o[0] = tx.r[0]; b.o[1] = tx.g[0]; b.o[2] = tx.b[0];
+    float pp = 0.0f;
+    for (int k = 0; k < tx.np; ++k)
+    {
+        const float x = tx.r[k * tx.stride] - b.o[0], y = tx.g[k * tx.stride] - b.o[1], z = tx.b[k * tx.stride] - b.o[2];
+        pp += __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+    }
+    b.pp = pp;
+    return b;
+}
+
+// per PerturbOne call: the walked channel first (the order of a dot product's terms is free in a bound), the other two channels'
+// centred palettes and minus their squares
+template<int N>
+struct MacroBound6
+{
+    const float* pv; const float* p1; const float* p2;      // texel planes: walked channel, the two fixed ones
+    float ov, n2ov, n2o1, n2o2;
+    float f1[N], f2[N], baseN[N];
+};
+
+template<int N>
+DXTEX_HD6 MacroBound6<N> bound6_macro(const Texels& tx, const Bound6& bd, int ch, const float (&base)[3][N])
+{
+    MacroBound6<N> m;
+    m.pv = (ch == 0) ? tx.r : (ch == 1) ? tx.g : tx.b;
+    m.p1 = (ch == 0) ? tx.g : (ch == 1) ? tx.b : tx.r;
+    m.p2 = (ch == 0) ? tx.b : (ch == 1) ? tx.r : tx.g;
+    const float o0 = bd.o[0], o1 = bd.o[1], o2 = bd.o[2];
+    m.ov = (ch == 0) ? o0 : (ch == 1) ? o1 : o2;
+    const float oa = (ch == 0) ? o1 : (ch == 1) ? o2 : o0, ob = (ch == 0) ? o2 : (ch == 1) ? o0 : o1;
+    m.n2ov = -2.0f * m.ov; m.n2o1 = -2.0f * oa; m.n2o2 = -2.0f * ob;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+        const float a = ((ch == 0) ? base[1][i] : (ch == 1) ? base[2][i] : base[0][i]) - oa;
+        const float b = ((ch == 0) ? base[2][i] : (ch == 1) ? base[0][i] : base[1][i]) - ob;
+        m.f1[i] = a; m.f2[i] = b;
+        m.baseN[i] = -__builtin_fmaf(b, b, a * a);
+    }
+    return m;
+}
+
+template<int N>
+DXTEX_HD6 float perturb6_bound(const Texels& tx, const Bound6& bd, const MacroBound6<N>& m, const float (&var)[N])
+{
+    float vq[N], qn[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { vq[i] = var[i] - m.ov; qn[i] = __builtin_fmaf(-vq[i], vq[i], m.baseN[i]); }
+    float qmin = qn[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) qmin = __builtin_fminf(qmin, qn[i]);
+    float S = 0.0f;
+    for (int k = 0; k < tx.np; ++k)
+    {
+        const float a = __builtin_fmaf(m.pv[k * tx.stride], 2.0f, m.n2ov), b = __builtin_fmaf(m.p1[k * tx.stride], 2.0f, m.n2o1), c = __builtin_fmaf(m.p2[k * tx.stride], 2.0f, m.n2o2);
+        float mx = __builtin_fmaf(a, vq[0], __builtin_fmaf(b, m.f1[0], __builtin_fmaf(c, m.f2[0], qn[0])));
+#pragma unroll
+        for (int i = 1; i < N; ++i) mx = __builtin_fmaxf(mx, __builtin_fmaf(a, vq[i], __builtin_fmaf(b, m.f1[i], __builtin_fmaf(c, m.f2[i], qn[i]))));
+        S = (k == 0) ? mx : S + mx;
+    }
+    const float H = __builtin_fmaf(float(2 * tx.np), -qmin, bd.pp);
+    return __builtin_fmaf(-0x1p-17f, H, bd.pp - S);
+}
+
 // One PerturbOne call (:2081-2141): 2 * prec - 1 candidate evaluations, straight-line.
 template<int N>
 DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, bool isSigned, float& outErr, int& outVal)
@@ -352,6 +436,14 @@ DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, boo
     const int fixedQ = (s.ch == 0) ? (s.do_b ? s.ep.A[0] : s.ep.B[0]) : (s.ch == 1) ? (s.do_b ? s.ep.A[1] : s.ep.B[1]) : (s.do_b ? s.ep.A[2] : s.ep.B[2]);
     int cur = (s.ch == 0) ? (s.do_b ? s.ep.B[0] : s.ep.A[0]) : (s.ch == 1) ? (s.do_b ? s.ep.B[1] : s.ep.A[1]) : (s.do_b ? s.ep.B[2] : s.ep.A[2]);
     float minErr = s.err;
+#if defined(DXTEX_COUNT_EVALS6)
+    const Bound6 cbd = bound6_begin(tx);
+    const MacroBound6<N> cmb = bound6_macro<N>(tx, cbd, s.ch, base);
+#define DXTEX_COUNT6(tmp_, e_, step_) do { if (valid) { float var_[N]; palette_channel<N>(s.do_b ? fixedQ : (tmp_), s.do_b ? (tmp_) : fixedQ, prec, isSigned, var_); \
+        count_bound6(N, tx.np, step_, perturb6_bound<N>(tx, cbd, cmb, var_), e_, minErr); } } while (0)
+#else
+#define DXTEX_COUNT6(tmp_, e_, step_) do { } while (0)
+#endif
     // The first step is half the range: cur - step is legal only for cur >= step, cur + step only for cur < step - never both, and the
     // reference skips the other one (:2112). One evaluation instead of two.
     {
@@ -359,6 +451,7 @@ DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, boo
         const int tmp = (cur >= half) ? cur - half : cur + half;
         const bool valid = (tmp >= 0) && (tmp < (1 << prec));
         const float e = perturb6_candidate<N>(tx, s, base, fixedQ, tmp, prec, isSigned);
+        DXTEX_COUNT6(tmp, e, 0);
         if (valid && e < minErr) { minErr = e; cur = tmp; }
     }
 #pragma unroll 1
@@ -371,6 +464,7 @@ DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, boo
             const int tmp = cur + sign * step;
             const bool valid = (tmp >= 0) && (tmp < (1 << prec));
             const float e = perturb6_candidate<N>(tx, s, base, fixedQ, tmp, prec, isSigned);
+            DXTEX_COUNT6(tmp, e, step);
             if (valid && e < minErr) { minErr = e; beststep = sign * step; }
         }
         cur += beststep;

@@ -21,6 +21,39 @@ static inline uint32_t dxtex_host_float_to_half(float v) { return DirectX::Packe
 using namespace dxtex;
 using namespace dxtex::bc6h;
 
+#if defined(DXTEX_COUNT_EVALS6)
+// statistics of the PerturbOne bound (bc6h_core.h: perturb6_bound): [entries 8 / 16][step class: first, large, 4, 2, 1]
+static unsigned long long g_cand[2][5], g_pass[2][5], g_texels[2][5], g_passTexels[2][5], g_unsound;
+static double g_worst = 0.0;
+namespace dxtex { namespace bc6h {
+void count_bound6(int n, int np, int step, float bound, float exact, float best)
+{
+    const int a = n == 16, c = step == 0 ? 0 : step > 4 ? 1 : step == 4 ? 2 : step == 2 ? 3 : 4;
+    ++g_cand[a][c]; g_texels[a][c] += np;
+    if (bound < best) { ++g_pass[a][c]; g_passTexels[a][c] += np; }
+    if (bound > exact) { ++g_unsound; if (g_unsound <= 5) printf("UNSOUND bound %.9g > exact %.9g (np %d step %d)\n", bound, exact, np, step); }
+    if (exact > 0 && bound / exact > g_worst && bound <= exact) g_worst = bound / exact;
+}
+} }
+static void print_bound_stats()
+{
+    const char* cls[5] = { "first", ">4", "4", "2", "1" };
+    for (int a = 0; a < 2; ++a)
+    {
+        unsigned long long tc = 0, tp = 0, tt = 0, tpt = 0;
+        for (int c = 0; c < 5; ++c)
+        {
+            if (!g_cand[a][c]) continue;
+            printf("entries %2d step %-5s: %10llu candidates, %5.1f %% pass the bound (texel-weighted %5.1f %%)\n", a ? 16 : 8, cls[c], g_cand[a][c],
+                   100.0 * g_pass[a][c] / g_cand[a][c], 100.0 * g_passTexels[a][c] / g_texels[a][c]);
+            tc += g_cand[a][c]; tp += g_pass[a][c]; tt += g_texels[a][c]; tpt += g_passTexels[a][c];
+        }
+        if (tc) printf("entries %2d all steps : %10llu candidates, %5.1f %% pass (texel-weighted %5.1f %%), mean texels %.1f\n", a ? 16 : 8, tc, 100.0 * tp / tc, 100.0 * tpt / tt, double(tt) / tc);
+    }
+    printf("bound above the exact error: %llu candidates; tightest bound / exact = %.6f\n", g_unsound, g_worst);
+}
+#endif
+
 static uint32_t g_rng = 1;
 static uint32_t rnd() { g_rng = g_rng * 1664525u + 1013904223u; return g_rng >> 8; }
 static float frand() { return float(rnd() & 0xFFFF) / 65535.0f; }
@@ -139,7 +172,10 @@ int main(int argc, char** argv)
         if (argc > 4) g_onlyMode = atoi(argv[4]);
         if (argc > 5) g_noSearch = atoi(argv[5]) != 0;
         alignas(16) float px[64]; int t = 0;
-        while (fread(px, sizeof(px), 1, f) == 1) { uint64_t lo, hi; encode_host(px, sg, lo, hi); printf("%d %016llx %016llx\n", t++, (unsigned long long)lo, (unsigned long long)hi); }
+        while (fread(px, sizeof(px), 1, f) == 1) { uint64_t lo, hi; encode_host(px, sg, lo, hi); if (!getenv("DXTEX_BC6H_QUIET")) printf("%d %016llx %016llx\n", t, (unsigned long long)lo, (unsigned long long)hi); ++t; }
+#if defined(DXTEX_COUNT_EVALS6)
+        print_bound_stats();
+#endif
         return 0;
     }
     const int ntiles = argc > 1 ? atoi(argv[1]) : 100;
@@ -178,6 +214,9 @@ int main(int argc, char** argv)
                                   (unsigned long long)rhi, (unsigned long long)rlo, (unsigned long long)hi, (unsigned long long)lo, unsigned(rlo & 31), unsigned(lo & 31));
         }
     }
+#if defined(DXTEX_COUNT_EVALS6)
+    print_bound_stats();
+#endif
     printf("%d of %d encodes differ\n", nbad, ntiles * 2);
     return nbad ? 1 : 0;
 }
