@@ -191,10 +191,22 @@ DXTEX_HD6 float scan_min_idx(const float (&e)[N], uint32_t& idx)
 // A region's texels: texel k of the region is at block position pos(k); values as floats holding exact ints.
 struct Texels
 {
+    typedef float T;
     const float* r; const float* g; const float* b;     // r[k * stride] etc.
     int stride;
     int np;
     DXTEX_HD6 void fetch(int k, uint32_t /*blockPos*/, float& pr, float& pg, float& pb) const { pr = r[k * stride]; pg = g[k * stride]; pb = b[k * stride]; }
+};
+
+// The same columns as 16-bit integers (texel components are half-float bit patterns, |v| <= 32767): half the LDS of a search kernel's
+// columns, one conversion per fetch. What bc6h_perturb_filter_kernel keeps.
+struct Texels16
+{
+    typedef int16_t T;
+    const int16_t* r; const int16_t* g; const int16_t* b;
+    int stride;
+    int np;
+    DXTEX_HD6 void fetch(int k, uint32_t /*blockPos*/, float& pr, float& pg, float& pb) const { pr = float(r[k * stride]); pg = float(g[k * stride]); pb = float(b[k * stride]); }
 };
 
 // The same texels read in place from the block's planes (r[16], g[16], b[16], one copy per block shared by the lanes that work on
@@ -208,9 +220,8 @@ struct TileTexels
 
 // Palette of quantised endpoints (GeneratePaletteQuantized, :1990-2040) for one channel
 template<int N>
-DXTEX_HD6 void palette_channel(int qa, int qb, int prec, bool isSigned, float (&out)[N])
+DXTEX_HD6 void palette_channel_unq(int ua, int ub, bool isSigned, float (&out)[N])      // from unquantised endpoints
 {
-    const int ua = unquantize(qa, prec, isSigned), ub = unquantize(qb, prec, isSigned);
     // (ua (64 - w) + ub w + 32) >> 6 as (64 ua + 32 + w (ub - ua)) >> 6: one 24-bit multiply-add per entry (|ub - ua| < 2^17)
     const int b64 = ua * 64 + 32, d = ub - ua;
 #pragma unroll
@@ -219,6 +230,11 @@ DXTEX_HD6 void palette_channel(int qa, int qb, int prec, bool isSigned, float (&
         const int w = weight_of<N>(i);
         out[i] = float(finish_unquantize((mul24i(d, w) + b64) >> 6, isSigned));
     }
+}
+template<int N>
+DXTEX_HD6 void palette_channel(int qa, int qb, int prec, bool isSigned, float (&out)[N])
+{
+    palette_channel_unq<N>(unquantize(qa, prec, isSigned), unquantize(qb, prec, isSigned), isSigned, out);
 }
 
 struct EndPts { int A[3], B[3]; };
@@ -358,13 +374,14 @@ void count_bound6(int n, int np, int step, float bound, float exact, float best)
 #endif
 struct Bound6 { float o[3]; float pp; };                 // per task: the centre and fl(Σ |p_k - o|^2)
 
-DXTEX_HD6 Bound6 bound6_begin(const Texels& tx)
+template<class TX>
+DXTEX_HD6 Bound6 bound6_begin(const TX& tx)
 {
-    Bound6 b; b.o[0] = tx.r[0]; b.o[1] = tx.g[0]; b.o[2] = tx.b[0];
+    Bound6 b; b.o[0] = float(tx.r[0]); b.o[1] = float(tx.g[0]); b.o[2] = float(tx.b[0]);
     float pp = 0.0f;
     for (int k = 0; k < tx.np; ++k)
     {
-        const float x = tx.r[k * tx.stride] - b.o[0], y = tx.g[k * tx.stride] - b.o[1], z = tx.b[k * tx.stride] - b.o[2];
+        const float x = float(tx.r[k * tx.stride]) - b.o[0], y = float(tx.g[k * tx.stride]) - b.o[1], z = float(tx.b[k * tx.stride]) - b.o[2];
         pp += __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
     }
     b.pp = pp;
@@ -373,21 +390,22 @@ DXTEX_HD6 Bound6 bound6_begin(const Texels& tx)
 
 // per PerturbOne call: the walked channel first (the order of a dot product's terms is free in a bound), the other two channels'
 // centred palettes and minus their squares
-template<int N>
+template<int N, class T = float>
 struct MacroBound6
 {
-    const float* pv; const float* p1; const float* p2;      // texel planes: walked channel, the two fixed ones
+    const T* pv; const T* p1; const T* p2;                  // texel planes: walked channel, the two fixed ones
     float ov, n2ov, n2o1, n2o2;
     float f1[N], f2[N], baseN[N];
 };
 
-template<int N>
-DXTEX_HD6 MacroBound6<N> bound6_macro(const Texels& tx, const Bound6& bd, int ch, const float (&base)[3][N])
+template<int N, class TX>
+DXTEX_HD6 MacroBound6<N, typename TX::T> bound6_macro(const TX& tx, const Bound6& bd, int ch, const float (&base)[3][N])
 {
-    MacroBound6<N> m;
-    m.pv = (ch == 0) ? tx.r : (ch == 1) ? tx.g : tx.b;
-    m.p1 = (ch == 0) ? tx.g : (ch == 1) ? tx.b : tx.r;
-    m.p2 = (ch == 0) ? tx.b : (ch == 1) ? tx.r : tx.g;
+    MacroBound6<N, typename TX::T> m;
+    const int og = int(tx.g - tx.r), ob2 = int(tx.b - tx.r);              // plane offsets (one array on the device: the pointers stay LDS pointers)
+    m.pv = tx.r + ((ch == 0) ? 0 : (ch == 1) ? og : ob2);
+    m.p1 = tx.r + ((ch == 0) ? og : (ch == 1) ? ob2 : 0);
+    m.p2 = tx.r + ((ch == 0) ? ob2 : (ch == 1) ? 0 : og);
     const float o0 = bd.o[0], o1 = bd.o[1], o2 = bd.o[2];
     m.ov = (ch == 0) ? o0 : (ch == 1) ? o1 : o2;
     const float oa = (ch == 0) ? o1 : (ch == 1) ? o2 : o0, ob = (ch == 0) ? o2 : (ch == 1) ? o0 : o1;
@@ -403,8 +421,8 @@ DXTEX_HD6 MacroBound6<N> bound6_macro(const Texels& tx, const Bound6& bd, int ch
     return m;
 }
 
-template<int N>
-DXTEX_HD6 float perturb6_bound(const Texels& tx, const Bound6& bd, const MacroBound6<N>& m, const float (&var)[N])
+template<int N, class TX>
+DXTEX_HD6 float perturb6_bound(const TX& tx, const Bound6& bd, const MacroBound6<N, typename TX::T>& m, const float (&var)[N])
 {
     float vq[N], qn[N];
 #pragma unroll
@@ -415,7 +433,7 @@ DXTEX_HD6 float perturb6_bound(const Texels& tx, const Bound6& bd, const MacroBo
     float S = 0.0f;
     for (int k = 0; k < tx.np; ++k)
     {
-        const float a = __builtin_fmaf(m.pv[k * tx.stride], 2.0f, m.n2ov), b = __builtin_fmaf(m.p1[k * tx.stride], 2.0f, m.n2o1), c = __builtin_fmaf(m.p2[k * tx.stride], 2.0f, m.n2o2);
+        const float a = __builtin_fmaf(float(m.pv[k * tx.stride]), 2.0f, m.n2ov), b = __builtin_fmaf(float(m.p1[k * tx.stride]), 2.0f, m.n2o1), c = __builtin_fmaf(float(m.p2[k * tx.stride]), 2.0f, m.n2o2);
         float mx = __builtin_fmaf(a, vq[0], __builtin_fmaf(b, m.f1[0], __builtin_fmaf(c, m.f2[0], qn[0])));
 #pragma unroll
         for (int i = 1; i < N; ++i) mx = __builtin_fmaxf(mx, __builtin_fmaf(a, vq[i], __builtin_fmaf(b, m.f1[i], __builtin_fmaf(c, m.f2[i], qn[i]))));
@@ -423,6 +441,41 @@ DXTEX_HD6 float perturb6_bound(const Texels& tx, const Bound6& bd, const MacroBo
     }
     const float H = __builtin_fmaf(float(2 * tx.np), -qmin, bd.pp);
     return __builtin_fmaf(-0x1p-17f, H, bd.pp - S);
+}
+
+// The two candidates of a PerturbOne step (cur - step, cur + step) in one pass over the texels: same operations per candidate as
+// perturb6_bound, the texel fetches and the doubled centred coordinates shared.
+template<int N, class TX>
+DXTEX_HD6 void perturb6_bound_pair(const TX& tx, const Bound6& bd, const MacroBound6<N, typename TX::T>& m, const float (&varM)[N], const float (&varP)[N], float& lbM, float& lbP)
+{
+    float vqM[N], qnM[N], vqP[N], qnP[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+    {
+        vqM[i] = varM[i] - m.ov; qnM[i] = __builtin_fmaf(-vqM[i], vqM[i], m.baseN[i]);
+        vqP[i] = varP[i] - m.ov; qnP[i] = __builtin_fmaf(-vqP[i], vqP[i], m.baseN[i]);
+    }
+    float qminM = qnM[0], qminP = qnP[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) { qminM = __builtin_fminf(qminM, qnM[i]); qminP = __builtin_fminf(qminP, qnP[i]); }
+    float SM = 0.0f, SP = 0.0f;
+    for (int k = 0; k < tx.np; ++k)
+    {
+        const float a = __builtin_fmaf(float(m.pv[k * tx.stride]), 2.0f, m.n2ov), b = __builtin_fmaf(float(m.p1[k * tx.stride]), 2.0f, m.n2o1), c = __builtin_fmaf(float(m.p2[k * tx.stride]), 2.0f, m.n2o2);
+        float mM = __builtin_fmaf(a, vqM[0], __builtin_fmaf(b, m.f1[0], __builtin_fmaf(c, m.f2[0], qnM[0])));
+        float mP = __builtin_fmaf(a, vqP[0], __builtin_fmaf(b, m.f1[0], __builtin_fmaf(c, m.f2[0], qnP[0])));
+#pragma unroll
+        for (int i = 1; i < N; ++i)
+        {
+            mM = __builtin_fmaxf(mM, __builtin_fmaf(a, vqM[i], __builtin_fmaf(b, m.f1[i], __builtin_fmaf(c, m.f2[i], qnM[i]))));
+            mP = __builtin_fmaxf(mP, __builtin_fmaf(a, vqP[i], __builtin_fmaf(b, m.f1[i], __builtin_fmaf(c, m.f2[i], qnP[i]))));
+        }
+        SM = (k == 0) ? mM : SM + mM;
+        SP = (k == 0) ? mP : SP + mP;
+    }
+    const float n2 = float(2 * tx.np);
+    lbM = __builtin_fmaf(-0x1p-17f, __builtin_fmaf(n2, -qminM, bd.pp), bd.pp - SM);
+    lbP = __builtin_fmaf(-0x1p-17f, __builtin_fmaf(n2, -qminP, bd.pp), bd.pp - SP);
 }
 
 // One PerturbOne call (:2081-2141): 2 * prec - 1 candidate evaluations, straight-line.
@@ -438,7 +491,7 @@ DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, boo
     float minErr = s.err;
 #if defined(DXTEX_COUNT_EVALS6)
     const Bound6 cbd = bound6_begin(tx);
-    const MacroBound6<N> cmb = bound6_macro<N>(tx, cbd, s.ch, base);
+    const MacroBound6<N, float> cmb = bound6_macro<N>(tx, cbd, s.ch, base);
 #define DXTEX_COUNT6(tmp_, e_, step_) do { if (valid) { float var_[N]; palette_channel<N>(s.do_b ? fixedQ : (tmp_), s.do_b ? (tmp_) : fixedQ, prec, isSigned, var_); \
         count_bound6(N, tx.np, step_, perturb6_bound<N>(tx, cbd, cmb, var_), e_, minErr); } } while (0)
 #else

@@ -73,6 +73,7 @@ struct Bc6hArgs
     Best6* best;
     float* bounds;          // nblocks x 17: region_lower_bound6 of the 8 ranked shapes x 2 regions and of the whole block (the same for every mode)
     int boundsReady;        // 0: this launch computes and stores them, 1: it reads them
+    int filterStats;        // development build: bc6h_perturb_filter_kernel counts its steps and exact rounds in counters[48..]
     int samePrec;           // two-region modes: the previous mode had the same endpoint precision and its task arrays are still in place
     ModeRt mode;
 };
@@ -656,6 +657,234 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a, uint32_t w
     }
 }
 
+// ---- perturb of the two-region modes through a bound filter (round 4) ------------------------------------------------------------
+// PerturbOne (:2081-2141) accepts a candidate only when its error is BELOW the best so far. perturb6_bound_pair (bc6h_core.h) bounds the
+// two candidates of a step from below at well under half the cost of evaluating them (three FMAs and a maximum per (texel, entry)
+// instead of eight ordered fp32 operations and a compare / select pair; the rounding of the reference's fp32 sums and of the bound's own
+// arithmetic is covered by an explicit margin). On the cfg3 image 1.6 % of the candidates pass it (none at the large steps, 8 % at step
+// 1; tools/bc6h_debug.cpp -DDXTEX_COUNT_EVALS6). Those are evaluated exactly - operation for operation as MapColorsQuantized does - by
+// the WHOLE wavefront: the owners put the candidates' palettes on a list in LDS, sixteen lanes take one list entry, lane k scores texel k
+// (norm3 + scan_min, the functions of the plain kernel), and the per-texel errors are summed in texel order by the group's first lane.
+constexpr int kFilterSlots = 32;          // list entries per round (a step with more passing candidates takes several rounds)
+struct FilterLds
+{
+    float4 pal[kFilterSlots][6];          // r[8], g[8], b[8] of a passing candidate
+    float tot[kFilterSlots];
+    uint32_t meta[kFilterSlots];          // owner lane | np << 8
+};
+
+// lane k of a row of sixteen gets lane k - 1's value (v_mov_b32_dpp row_shr:1; lane 0 of the row gets 0)
+__device__ __forceinline__ float row_shr1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
+}
+
+template<class WRITE>
+__device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L, int lane, int np, bool pass0, bool pass1, WRITE writePal, float& e0, float& e1, uint32_t* stats)
+{
+    const unsigned long long b0 = __ballot(pass0), b1 = __ballot(pass1);
+    if ((b0 | b1) == 0ull) return;                                            // wave-uniform: most steps end here
+#if defined(DXTEX_DEV)
+    if (stats && lane == 0) { atomicAdd(stats + 1, 1u); atomicAdd(stats + 2, uint32_t(__popcll(b0) + __popcll(b1))); }
+#endif
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t n0 = uint32_t(__popcll(b0)), total = n0 + uint32_t(__popcll(b1));
+    const uint32_t s0 = uint32_t(__popcll(b0 & below)), s1 = n0 + uint32_t(__popcll(b1 & below));
+    const int grp = lane >> 4, k = lane & 15;
+    for (uint32_t first = 0; first < total; first += kFilterSlots)
+    {
+        const uint32_t cnt = min(total - first, uint32_t(kFilterSlots));
+        const bool in0 = pass0 && (s0 - first) < cnt, in1 = pass1 && (s1 - first) < cnt;          // unsigned: s < first wraps above cnt
+        if (in0) { writePal(0, reinterpret_cast<float*>(L.pal[s0 - first])); L.meta[s0 - first] = uint32_t(lane) | (uint32_t(np) << 8); }
+        if (in1) { writePal(1, reinterpret_cast<float*>(L.pal[s1 - first])); L.meta[s1 - first] = uint32_t(lane) | (uint32_t(np) << 8); }
+        __syncthreads();                  // one wavefront per workgroup: orders the LDS traffic, costs no barrier
+        for (uint32_t g = 0; g < cnt; g += 4)
+        {
+#if defined(DXTEX_DEV)
+            if (stats && lane == 0) atomicAdd(stats + 3, 1u);
+#endif
+            const uint32_t sl = g + uint32_t(grp);
+            const uint32_t meta = (sl < cnt) ? L.meta[sl] : 0u;
+            const int owner = int(meta & 63u), onp = int(meta >> 8);
+            float err = 0.0f;
+            if (k < onp)
+            {
+                const int16_t* t = cols + owner + k * 64;
+                const float tr = float(t[0]), tg = float(t[16 * 64]), tb = float(t[32 * 64]);
+                const float4 r0 = L.pal[sl][0], r1 = L.pal[sl][1], g0 = L.pal[sl][2], g1 = L.pal[sl][3], c0 = L.pal[sl][4], c1 = L.pal[sl][5];
+                const float pr[8] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w }, pg[8] = { g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w },
+                            pb[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+                float e[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) e[i] = norm3(tr, tg, tb, pr[i], pg[i], pb[i]);
+                err = scan_min(e);
+            }
+            // fTotErr += fBestErr, texel by texel (:2074): lane j of the group takes lane j - 1's partial sum and adds its texel's error -
+            // the reference's order; texels past the region's end add +0.0f, which changes nothing, so lane 15 ends with the total
+            float S = err;
+#pragma unroll
+            for (int j = 1; j < 16; ++j) { const float t = row_shr1(S); S = (k == j) ? t + err : S; }
+            if (k == 15 && sl < cnt) L.tot[sl] = S;
+        }
+        __syncthreads();
+        if (in0) e0 = L.tot[s0 - first];
+        if (in1) e1 = L.tot[s1 - first];
+        __syncthreads();
+    }
+}
+
+// One PerturbOne call for every lane of the wavefront (lanes without a task take part in the exact evaluations only): perturb6_macro with
+// the evaluations replaced by bound + shared exact evaluation. Same decisions: a candidate the bound excludes has an error >= the bound >=
+// the best so far and `<` would refuse it; the +step candidate is bounded against the best error before the -step candidate's result (a
+// superset passes) and accepted against the one after it, as in the reference's loop.
+template<bool SG>
+__device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, FilterLds& L, int lane, bool active, const Texels16& tx, const Bound6& bd, const Perturb6& s,
+                                                      int prec, float& outErr, int& outVal, uint32_t* stats)
+{
+    constexpr int N = 8;
+#if defined(DXTEX_DEV)
+    if (stats) { const unsigned long long act = __ballot(active); if (lane == 0) { atomicAdd(stats + 4, 1u); atomicAdd(stats + 5, uint32_t(__popcll(act))); } }
+#endif
+    float base[3][N];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) palette_channel<N>(s.ep.A[c], s.ep.B[c], prec, SG, base[c]);
+    const int fixedQ = (s.ch == 0) ? (s.do_b ? s.ep.A[0] : s.ep.B[0]) : (s.ch == 1) ? (s.do_b ? s.ep.A[1] : s.ep.B[1]) : (s.do_b ? s.ep.A[2] : s.ep.B[2]);
+    int cur = (s.ch == 0) ? (s.do_b ? s.ep.B[0] : s.ep.A[0]) : (s.ch == 1) ? (s.do_b ? s.ep.B[1] : s.ep.A[1]) : (s.do_b ? s.ep.B[2] : s.ep.A[2]);
+    const int uFixed = unquantize(fixedQ, prec, SG);                 // the other endpoint does not move during this call
+    const MacroBound6<N, int16_t> mb = bound6_macro<N>(tx, bd, s.ch, base);
+    float minErr = s.err;
+    // the walked channel's palette of a candidate (GeneratePaletteQuantized with the candidate's endpoint)
+    auto var_of = [&](int tmp, float (&var)[N])
+    {
+        const int uT = unquantize(tmp, prec, SG);
+        palette_channel_unq<N>(s.do_b ? uFixed : uT, s.do_b ? uT : uFixed, SG, var);
+    };
+    auto write_pal = [&](const float (&var)[N], float* dst)
+    {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+        {
+            dst[i] = (s.ch == 0) ? var[i] : base[0][i];
+            dst[8 + i] = (s.ch == 1) ? var[i] : base[1][i];
+            dst[16 + i] = (s.ch == 2) ? var[i] : base[2][i];
+        }
+    };
+    {
+        const int half = 1 << (prec - 1);
+        const int tmp = (cur >= half) ? cur - half : cur + half;
+        const bool valid = (tmp >= 0) && (tmp < (1 << prec));
+        float var[N];
+        var_of(tmp, var);
+        bool pass = active && valid && perturb6_bound<N>(tx, bd, mb, var) < minErr;
+#if defined(DXTEX_F6_NOPASS)
+        pass = false;
+#endif
+        float e = 0.0f, none = 0.0f;
+        exact_by_wave(cols, L, lane, tx.np, pass, false, [&](int, float* dst) { write_pal(var, dst); }, e, none, stats);
+        if (pass && e < minErr) { minErr = e; cur = tmp; }
+    }
+#pragma unroll 1
+    for (int step = 1 << (prec - 1) >> 1; step; step >>= 1)
+    {
+        const int tM = cur - step, tP = cur + step;
+        float varM[N], varP[N];
+        var_of(tM, varM);
+        var_of(tP, varP);
+        float lbM, lbP;
+        perturb6_bound_pair<N>(tx, bd, mb, varM, varP, lbM, lbP);
+        bool passM = active && (tM >= 0) && (tM < (1 << prec)) && lbM < minErr;
+        bool passP = active && (tP >= 0) && (tP < (1 << prec)) && lbP < minErr;
+#if defined(DXTEX_F6_NOPASS)
+        passM = passP = lbM + lbP == 12345.678f;      // timing experiment: the bounds alone (results are wrong)
+#endif
+        float eM = 0.0f, eP = 0.0f;
+#if defined(DXTEX_DEV)
+        if (stats && lane == 0) atomicAdd(stats + 0, 1u);
+#endif
+        exact_by_wave(cols, L, lane, tx.np, passM, passP, [&](int which, float* dst) { if (which) write_pal(varP, dst); else write_pal(varM, dst); }, eM, eP, stats);
+        int beststep = 0;
+        if (passM && eM < minErr) { minErr = eM; beststep = -step; }
+        if (passP && eP < minErr) { minErr = eP; beststep = step; }
+        cur += beststep;
+    }
+    outErr = minErr; outVal = cur;
+}
+
+#if !defined(DXTEX_F6_WAVES)
+#define DXTEX_F6_WAVES 3
+#endif
+template<bool SG>
+__global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel(Bc6hArgs a)
+{
+    __shared__ int16_t sCols[48 * 64];        // 6 KiB + the list: sixteen wavefronts per CU
+    __shared__ FilterLds sList;
+    const int lane = threadIdx.x;
+    const uint32_t live = a.counters[34];
+    if (live == 0) return;
+    uint32_t* head = a.counters + kQueueBase;
+    int16_t* slot = &sCols[lane];
+    EndPts zero; for (int c = 0; c < 3; ++c) { zero.A[c] = 0; zero.B[c] = 0; }
+    Perturb6 st = perturb6_begin(zero, 0.0f);
+    Texels16 tx; tx.r = slot; tx.g = slot + 16 * 64; tx.b = slot + 32 * 64; tx.stride = 64; tx.np = 0;
+    Bound6 bd; bd.o[0] = bd.o[1] = bd.o[2] = 0.0f; bd.pp = 0.0f;
+    uint32_t myTask = 0xFFFFFFFFu;
+    const int prec = a.mode.prec;
+#if defined(DXTEX_DEV)
+    uint32_t* stats = a.filterStats ? a.counters + 48 : nullptr;      // [0] pair steps, [1] steps with passing candidates, [2] passing candidates, [3] rounds of four, [4] macros, [5] active lanes in them
+#else
+    uint32_t* stats = nullptr;
+#endif
+    WaveQueue q; q.lo = q.hi = 0; q.drained = false;
+    for (;;)
+    {
+        const unsigned long long idle = __ballot(myTask == 0xFFFFFFFFu);
+        if (idle && !(q.drained && q.lo >= q.hi))
+        {
+            const uint32_t idx = queue_take(q, head, live, idle, lane);
+            if (idx != 0xFFFFFFFFu)
+            {
+                const uint2 task = a.order[idx];
+                myTask = task.x;
+                const Rec6 rec = a.recs[myTask];
+                const float* gp = a.fpix + uint64_t(myTask / 16u) * 48;
+                // the region's texels into the lane's columns (floats holding integers of at most 16 bits)
+                uint32_t mask = task.y & 0xFFFFu;
+                int np = 0;
+                while (mask)
+                {
+                    const int i = __ffs(int(mask)) - 1;
+                    mask &= mask - 1u;
+                    slot[np * 64] = int16_t(int(gp[i])); slot[(16 + np) * 64] = int16_t(int(gp[16 + i])); slot[(32 + np) * 64] = int16_t(int(gp[32 + i]));
+                    ++np;
+                }
+                tx.np = np;
+                bd = bound6_begin(tx);
+                EndPts e;
+                unpack_ep16(rec.ep, SG, e.A, e.B);
+                st = perturb6_begin(e, rec.err);
+            }
+        }
+        const bool active = myTask != 0xFFFFFFFFu;
+        if (__ballot(active) == 0ull)
+        {
+            if (q.drained && q.lo >= q.hi) break;
+            continue;
+        }
+        if (!active) tx.np = 0;
+        float e; int v;
+        perturb6_macro_filter<SG>(sCols, sList, lane, active, tx, bd, st, prec, e, v, stats);
+        if (active)
+        {
+            st = perturb6_transition(st, e, v);
+            if (st.ch >= 3)
+            {
+                a.recs[myTask].ep = pack_ep16(st.ep.A, st.ep.B);
+                myTask = 0xFFFFFFFFu;
+            }
+        }
+    }
+}
+
 // The one-region modes have one task per block, and after pruning few of them are left (hundreds to a few thousand in a 4096^2
 // image) - but each is long: a PerturbOne call of the 16-bit mode walks 32 candidates of 16 texels x 16 palette entries, and the
 // alternating loop repeats it as long as it improves. With a lane per task the kernel takes as long as its longest chain
@@ -812,6 +1041,7 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         a.best = reinterpret_cast<Best6*>(base + L.best);
         a.bounds = reinterpret_cast<float*>(base + L.bounds);
         a.boundsReady = 0;
+        a.filterStats = 0;
         a.mode = ModeRt();
 
         DXTEX_MARK("bc6h_rough");
@@ -891,6 +1121,7 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
             sort_tasks(ntasks);
 #if defined(DXTEX_DEV)
             static const bool stats6 = dev_env("DXTEX_BC6H_STATS") != nullptr;       // development statistics: tasks that survive pre, per mode
+            a.filterStats = stats6 ? 1 : 0;
             if (stats6)
             {
                 uint32_t c[40] = {};
@@ -900,7 +1131,24 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
             }
 #endif
             DXTEX_MARK(kPerturb[mi]);
-            if (!noSearch) hipLaunchKernelGGL(bc6h_perturb_kernel<8>, dim3(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64)), dim3(64), 0, stream, a, 0u);
+            static const bool plainPerturb = dev_env("DXTEX_BC6H_PERTURB_PLAIN") != nullptr;      // development A/B: every candidate evaluated exactly, a lane per task
+            if (!noSearch)
+            {
+                const dim3 grid(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64));
+                if (plainPerturb) hipLaunchKernelGGL(bc6h_perturb_kernel<8>, grid, dim3(64), 0, stream, a, 0u);
+                else if (isSigned) hipLaunchKernelGGL(bc6h_perturb_filter_kernel<true>, grid, dim3(64), 0, stream, a);
+                else hipLaunchKernelGGL(bc6h_perturb_filter_kernel<false>, grid, dim3(64), 0, stream, a);
+            }
+#if defined(DXTEX_DEV)
+            if (stats6 && !plainPerturb)
+            {
+                uint32_t c[8] = {};
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(c, a.counters + 48, sizeof(c), hipMemcpyDeviceToHost);
+                std::fprintf(stderr, "bc6h filter mode %d: %u macros (%.1f lanes active), %u pair steps, %u with passing candidates (%.2f per such step), %u rounds of four\n", mi, c[4],
+                             c[4] ? double(c[5]) / c[4] : 0.0, c[0], c[1], c[1] ? double(c[2]) / c[1] : 0.0, c[3]);
+            }
+#endif
             DXTEX_MARK(kPost[mi]);
             hipLaunchKernelGGL(bc6h_post_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
         }

@@ -45,3 +45,17 @@ def test_bc6h_core_on_the_host_matches_the_reference(seed):
         pytest.fail(f"{BC6H_EXE} missing: run __graft_entry__.build() where /root/reference exists")
     r = subprocess.run([BC6H_EXE, "150", str(seed)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "0 of 300 encodes differ" in r.stdout, r.stdout[-3000:]
+
+
+BC6H_BOUND_EXE = os.path.join(ROOT, "oracle", "_ref", "bc6h_bound_check")
+
+
+@pytest.mark.parametrize("seed", [3, 41])
+def test_bc6h_perturb_bound_never_exceeds_the_exact_error(seed):
+    """perturb6_bound (bc6h_core.h) is what lets bc6h_perturb_filter_kernel skip the exact evaluation of a PerturbOne candidate: it must never be
+    above the error MapColorsQuantized's fp32 arithmetic gives, whatever the brightness (tiles from 0.001 to 30000, negatives, flat and noisy,
+    unsigned and signed). The host search evaluates both for every candidate (millions) and counts violations; the encodes still match."""
+    if not os.path.exists(BC6H_BOUND_EXE):
+        pytest.fail(f"{BC6H_BOUND_EXE} missing: run __graft_entry__.build() where /root/reference exists")
+    r = subprocess.run([BC6H_BOUND_EXE, "250", str(seed)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "bound above the exact error: 0 candidates" in r.stdout and "0 of 500 encodes differ" in r.stdout, r.stdout[-3000:]

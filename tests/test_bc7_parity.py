@@ -159,7 +159,8 @@ def test_pruning_changes_nothing():
     """subset_lower_bound / region_lower_bound6 only drop candidates that cannot win: the payloads with pruning (default) and
     without (DXTEX_BC7_NO_PRUNE / DXTEX_BC6H_NO_PRUNE) must be the same bytes, and so must any legal order of the modes - and
     BC6H's one-region modes searched by a lane per task (DXTEX_BC6H_WAVE_MAX=0) or by a wavefront per task (the default for lists this
-    short) are the same search, as is mode 1's PerturbOne with (default) and without (DXTEX_BC7_PERTURB_PLAIN) the bound filter, and BC6H's
+    short) are the same search, as is mode 1's PerturbOne with (default) and without (DXTEX_BC7_PERTURB_PLAIN) the bound filter and the PerturbOne of
+    BC6H's two-region modes with (default) and without (DXTEX_BC6H_PERTURB_PLAIN) its bound filter, and BC6H's
     modes of equal endpoint precision sharing one search (default) or searching each from scratch (DXTEX_BC6H_NO_REUSE), and BC7's
     two-region modes in the encoder's order (DXTEX_BC6H_ORDER) instead of the default running order, and BC7's
     whole-block tasks (modes 4 / 5 / 6) searched by groups of lanes (default on lists this short) or a lane each (DXTEX_BC7_NO_GROUP), and the
@@ -186,7 +187,7 @@ def test_pruning_changes_nothing():
                 print(hashlib.sha256(c.compress(hdr, w, h, 10, fmt, 0, 0.5).tobytes()).hexdigest())
     """ % root)
     outs = []
-    for env in ({}, {"DXTEX_BC7_NO_PRUNE": "1", "DXTEX_BC6H_NO_PRUNE": "1"}, {"DXTEX_BC7_ORDER": "7,6,5,8,4,3,2,1,0", "DXTEX_BC7_PERTURB_PLAIN": "1", "DXTEX_BC7_NO_GROUP": "1", "DXTEX_BC7_SERIAL": "1"},
+    for env in ({}, {"DXTEX_BC7_NO_PRUNE": "1", "DXTEX_BC6H_NO_PRUNE": "1"}, {"DXTEX_BC7_ORDER": "7,6,5,8,4,3,2,1,0", "DXTEX_BC7_PERTURB_PLAIN": "1", "DXTEX_BC7_NO_GROUP": "1", "DXTEX_BC7_SERIAL": "1", "DXTEX_BC6H_PERTURB_PLAIN": "1"},
                 {"DXTEX_BC7_NO_SMALL_PLAN": "1"}, {"DXTEX_BC7_SMALL_PLAN": "16/1/3,2|7,14,15,18|24,26/28/25,0"},
                 {"DXTEX_BC7_ORDER": "26,25,3,1,16,7,15,14,18,24,28,0,2", "DXTEX_BC6H_WAVE_MAX": "0", "DXTEX_BC6H_NO_REUSE": "1", "DXTEX_BC6H_ORDER": "0,1,2,3,4,5,6,7,8,9"}):
         r = subprocess.run([sys.executable, "-c", code] + (["--dev"] if env else []), env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
