@@ -367,22 +367,27 @@ DXTEX_HD6 float perturb6_candidate(const Texels& tx, const Perturb6& s, const fl
 // so that the cancellation in |p|^2 - score is of the order of the region's spread, not of its brightness. Rounding: every
 // intermediate of a score is at most G = |p'|^2 + 2 |q'|^2 in magnitude and passes six roundings (|q'|^2: three, the FMAs: three);
 // the sum of the maxima adds np - 1 roundings of partial sums below H = Σ|p'_k|^2 + 2 np max_i |q'_i|^2, the sum of |p'_k|^2 np + 2,
-// the subtraction one: |computed - E*| <= 42 u H, and 18 u E* <= 36 u H (E* <= 2 H). The bound subtracts 2^-17 H = 128 u H.
+// the subtraction one: |computed - E*| <= 42 u H, and 18 u E* <= 36 u H (E* <= 2 H). The bound subtracts 2^-17 H = 128 u H. The same
+// holds for a PREFIX of the texels (the other texels' errors are >= 0; Bound6::pre holds the prefixes of Σ|p'_k|^2 over 4 / 8 / 12
+// texels), which is what lets the loop stop as soon as a prefix already excludes the candidate(s).
 // tools/bc6h_debug.cpp (-DDXTEX_COUNT_EVALS6) checks bound <= exact on every candidate of the host search and counts what passes.
 #if defined(DXTEX_COUNT_EVALS6)
 void count_bound6(int n, int np, int step, float bound, float exact, float best);     // tools/bc6h_debug.cpp
 #endif
-struct Bound6 { float o[3]; float pp; };                 // per task: the centre and fl(Σ |p_k - o|^2)
+struct Bound6 { float o[3]; float pp; float pre[3]; };   // per task: the centre, fl(Σ |p_k - o|^2), and the sum's prefixes over 4 / 8 / 12 texels
 
 template<class TX>
 DXTEX_HD6 Bound6 bound6_begin(const TX& tx)
 {
-    Bound6 b; b.o[0] = float(tx.r[0]); b.o[1] = float(tx.g[0]); b.o[2] = float(tx.b[0]);
+    Bound6 b; b.o[0] = float(tx.r[0]); b.o[1] = float(tx.g[0]); b.o[2] = float(tx.b[0]); b.pre[0] = b.pre[1] = b.pre[2] = 0.0f;
     float pp = 0.0f;
     for (int k = 0; k < tx.np; ++k)
     {
         const float x = float(tx.r[k * tx.stride]) - b.o[0], y = float(tx.g[k * tx.stride]) - b.o[1], z = float(tx.b[k * tx.stride]) - b.o[2];
         pp += __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+        if (k == 3) b.pre[0] = pp;
+        if (k == 7) b.pre[1] = pp;
+        if (k == 11) b.pre[2] = pp;
     }
     b.pp = pp;
     return b;
@@ -421,32 +426,13 @@ DXTEX_HD6 MacroBound6<N, typename TX::T> bound6_macro(const TX& tx, const Bound6
     return m;
 }
 
+// The two candidates of a PerturbOne step (cur - step, cur + step) in one pass over the texels; the texel fetches and the doubled centred
+// coordinates are shared. `best` is the error a candidate has to beat: every fourth texel a lane whose prefix bounds already exclude both
+// candidates leaves the loop (the large steps of the logarithmic search end after four texels: their candidates are hopeless).
+// Returns lower bounds of the two candidates' errors (of a prefix of the texels when the loop was left early).
 template<int N, class TX>
-DXTEX_HD6 float perturb6_bound(const TX& tx, const Bound6& bd, const MacroBound6<N, typename TX::T>& m, const float (&var)[N])
-{
-    float vq[N], qn[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) { vq[i] = var[i] - m.ov; qn[i] = __builtin_fmaf(-vq[i], vq[i], m.baseN[i]); }
-    float qmin = qn[0];
-#pragma unroll
-    for (int i = 1; i < N; ++i) qmin = __builtin_fminf(qmin, qn[i]);
-    float S = 0.0f;
-    for (int k = 0; k < tx.np; ++k)
-    {
-        const float a = __builtin_fmaf(float(m.pv[k * tx.stride]), 2.0f, m.n2ov), b = __builtin_fmaf(float(m.p1[k * tx.stride]), 2.0f, m.n2o1), c = __builtin_fmaf(float(m.p2[k * tx.stride]), 2.0f, m.n2o2);
-        float mx = __builtin_fmaf(a, vq[0], __builtin_fmaf(b, m.f1[0], __builtin_fmaf(c, m.f2[0], qn[0])));
-#pragma unroll
-        for (int i = 1; i < N; ++i) mx = __builtin_fmaxf(mx, __builtin_fmaf(a, vq[i], __builtin_fmaf(b, m.f1[i], __builtin_fmaf(c, m.f2[i], qn[i]))));
-        S = (k == 0) ? mx : S + mx;
-    }
-    const float H = __builtin_fmaf(float(2 * tx.np), -qmin, bd.pp);
-    return __builtin_fmaf(-0x1p-17f, H, bd.pp - S);
-}
-
-// The two candidates of a PerturbOne step (cur - step, cur + step) in one pass over the texels: same operations per candidate as
-// perturb6_bound, the texel fetches and the doubled centred coordinates shared.
-template<int N, class TX>
-DXTEX_HD6 void perturb6_bound_pair(const TX& tx, const Bound6& bd, const MacroBound6<N, typename TX::T>& m, const float (&varM)[N], const float (&varP)[N], float& lbM, float& lbP)
+DXTEX_HD6 void perturb6_bound_pair(const TX& tx, const Bound6& bd, const MacroBound6<N, typename TX::T>& m, const float (&varM)[N], const float (&varP)[N],
+                                   float best, float& lbM, float& lbP)
 {
     float vqM[N], qnM[N], vqP[N], qnP[N];
 #pragma unroll
@@ -458,7 +444,9 @@ DXTEX_HD6 void perturb6_bound_pair(const TX& tx, const Bound6& bd, const MacroBo
     float qminM = qnM[0], qminP = qnP[0];
 #pragma unroll
     for (int i = 1; i < N; ++i) { qminM = __builtin_fminf(qminM, qnM[i]); qminP = __builtin_fminf(qminP, qnP[i]); }
-    float SM = 0.0f, SP = 0.0f;
+    const float n2 = float(2 * tx.np);
+    const float mgM = 0x1p-17f * __builtin_fmaf(n2, -qminM, bd.pp), mgP = 0x1p-17f * __builtin_fmaf(n2, -qminP, bd.pp);      // 2^-17 H, exact scaling
+    float SM = 0.0f, SP = 0.0f, ppk = bd.pp;
     for (int k = 0; k < tx.np; ++k)
     {
         const float a = __builtin_fmaf(float(m.pv[k * tx.stride]), 2.0f, m.n2ov), b = __builtin_fmaf(float(m.p1[k * tx.stride]), 2.0f, m.n2o1), c = __builtin_fmaf(float(m.p2[k * tx.stride]), 2.0f, m.n2o2);
@@ -472,10 +460,22 @@ DXTEX_HD6 void perturb6_bound_pair(const TX& tx, const Bound6& bd, const MacroBo
         }
         SM = (k == 0) ? mM : SM + mM;
         SP = (k == 0) ? mP : SP + mP;
+        if ((k & 3) == 3 && k < 12)
+        {
+            const float pk = (k == 3) ? bd.pre[0] : (k == 7) ? bd.pre[1] : bd.pre[2];
+            if (!((pk - SM) - mgM < best) && !((pk - SP) - mgP < best)) { ppk = pk; break; }
+        }
     }
-    const float n2 = float(2 * tx.np);
-    lbM = __builtin_fmaf(-0x1p-17f, __builtin_fmaf(n2, -qminM, bd.pp), bd.pp - SM);
-    lbP = __builtin_fmaf(-0x1p-17f, __builtin_fmaf(n2, -qminP, bd.pp), bd.pp - SP);
+    lbM = (ppk - SM) - mgM;
+    lbP = (ppk - SP) - mgP;
+}
+
+template<int N, class TX>
+DXTEX_HD6 float perturb6_bound(const TX& tx, const Bound6& bd, const MacroBound6<N, typename TX::T>& m, const float (&var)[N], float best)
+{
+    float lbM, lbP;
+    perturb6_bound_pair<N>(tx, bd, m, var, var, best, lbM, lbP);
+    return lbM;
 }
 
 // One PerturbOne call (:2081-2141): 2 * prec - 1 candidate evaluations, straight-line.
@@ -493,7 +493,7 @@ DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, boo
     const Bound6 cbd = bound6_begin(tx);
     const MacroBound6<N, float> cmb = bound6_macro<N>(tx, cbd, s.ch, base);
 #define DXTEX_COUNT6(tmp_, e_, step_) do { if (valid) { float var_[N]; palette_channel<N>(s.do_b ? fixedQ : (tmp_), s.do_b ? (tmp_) : fixedQ, prec, isSigned, var_); \
-        count_bound6(N, tx.np, step_, perturb6_bound<N>(tx, cbd, cmb, var_), e_, minErr); } } while (0)
+        count_bound6(N, tx.np, step_, perturb6_bound<N>(tx, cbd, cmb, var_, minErr), e_, minErr); } } while (0)
 #else
 #define DXTEX_COUNT6(tmp_, e_, step_) do { } while (0)
 #endif

@@ -686,6 +686,7 @@ __device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L,
     if ((b0 | b1) == 0ull) return;                                            // wave-uniform: most steps end here
 #if defined(DXTEX_DEV)
     if (stats && lane == 0) { atomicAdd(stats + 1, 1u); atomicAdd(stats + 2, uint32_t(__popcll(b0) + __popcll(b1))); }
+    const long long t0 = stats ? clock64() : 0;
 #endif
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t n0 = uint32_t(__popcll(b0)), total = n0 + uint32_t(__popcll(b1));
@@ -731,6 +732,9 @@ __device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L,
         if (in1) e1 = L.tot[s1 - first];
         __syncthreads();
     }
+#if defined(DXTEX_DEV)
+    if (stats && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(stats + 8), (unsigned long long)(clock64() - t0));
+#endif
 }
 
 // One PerturbOne call for every lane of the wavefront (lanes without a task take part in the exact evaluations only): perturb6_macro with
@@ -759,8 +763,10 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
         const int uT = unquantize(tmp, prec, SG);
         palette_channel_unq<N>(s.do_b ? uFixed : uT, s.do_b ? uT : uFixed, SG, var);
     };
-    auto write_pal = [&](const float (&var)[N], float* dst)
+    auto write_pal = [&](int tmp, float* dst)        // the rare path: the palette is derived again rather than kept across the bound's loop
     {
+        float var[N];
+        var_of(tmp, var);
 #pragma unroll
         for (int i = 0; i < N; ++i)
         {
@@ -775,12 +781,12 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
         const bool valid = (tmp >= 0) && (tmp < (1 << prec));
         float var[N];
         var_of(tmp, var);
-        bool pass = active && valid && perturb6_bound<N>(tx, bd, mb, var) < minErr;
+        bool pass = active && valid && perturb6_bound<N>(tx, bd, mb, var, minErr) < minErr;
 #if defined(DXTEX_F6_NOPASS)
         pass = false;
 #endif
         float e = 0.0f, none = 0.0f;
-        exact_by_wave(cols, L, lane, tx.np, pass, false, [&](int, float* dst) { write_pal(var, dst); }, e, none, stats);
+        exact_by_wave(cols, L, lane, tx.np, pass, false, [&](int, float* dst) { write_pal(tmp, dst); }, e, none, stats);
         if (pass && e < minErr) { minErr = e; cur = tmp; }
     }
 #pragma unroll 1
@@ -791,7 +797,7 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
         var_of(tM, varM);
         var_of(tP, varP);
         float lbM, lbP;
-        perturb6_bound_pair<N>(tx, bd, mb, varM, varP, lbM, lbP);
+        perturb6_bound_pair<N>(tx, bd, mb, varM, varP, minErr, lbM, lbP);
         bool passM = active && (tM >= 0) && (tM < (1 << prec)) && lbM < minErr;
         bool passP = active && (tP >= 0) && (tP < (1 << prec)) && lbP < minErr;
 #if defined(DXTEX_F6_NOPASS)
@@ -801,7 +807,7 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
 #if defined(DXTEX_DEV)
         if (stats && lane == 0) atomicAdd(stats + 0, 1u);
 #endif
-        exact_by_wave(cols, L, lane, tx.np, passM, passP, [&](int which, float* dst) { if (which) write_pal(varP, dst); else write_pal(varM, dst); }, eM, eP, stats);
+        exact_by_wave(cols, L, lane, tx.np, passM, passP, [&](int which, float* dst) { write_pal(which ? tP : tM, dst); }, eM, eP, stats);
         int beststep = 0;
         if (passM && eM < minErr) { minErr = eM; beststep = -step; }
         if (passP && eP < minErr) { minErr = eP; beststep = step; }
@@ -835,6 +841,9 @@ __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel
     uint32_t* stats = nullptr;
 #endif
     WaveQueue q; q.lo = q.hi = 0; q.drained = false;
+#if defined(DXTEX_DEV)
+    const long long tk0 = stats ? clock64() : 0;
+#endif
     for (;;)
     {
         const unsigned long long idle = __ballot(myTask == 0xFFFFFFFFu);
@@ -883,6 +892,9 @@ __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel
             }
         }
     }
+#if defined(DXTEX_DEV)
+    if (stats && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(stats + 10), (unsigned long long)(clock64() - tk0));
+#endif
 }
 
 // The one-region modes have one task per block, and after pruning few of them are left (hundreds to a few thousand in a 4096^2
@@ -1142,11 +1154,13 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
 #if defined(DXTEX_DEV)
             if (stats6 && !plainPerturb)
             {
-                uint32_t c[8] = {};
+                uint32_t c[12] = {};
                 (void)hipStreamSynchronize(stream);
                 (void)hipMemcpy(c, a.counters + 48, sizeof(c), hipMemcpyDeviceToHost);
-                std::fprintf(stderr, "bc6h filter mode %d: %u macros (%.1f lanes active), %u pair steps, %u with passing candidates (%.2f per such step), %u rounds of four\n", mi, c[4],
-                             c[4] ? double(c[5]) / c[4] : 0.0, c[0], c[1], c[1] ? double(c[2]) / c[1] : 0.0, c[3]);
+                unsigned long long tx = 0, tk = 0; memcpy(&tx, c + 8, 8); memcpy(&tk, c + 10, 8);
+                std::fprintf(stderr, "bc6h filter mode %d: %u macros (%.1f lanes active), %u pair steps, %u with passing candidates (%.2f per such step), %u rounds of four; "
+                             "exact evaluation %.1f %% of the waves' time\n", mi, c[4],
+                             c[4] ? double(c[5]) / c[4] : 0.0, c[0], c[1], c[1] ? double(c[2]) / c[1] : 0.0, c[3], tk ? 100.0 * double(tx) / double(tk) : 0.0);
             }
 #endif
             DXTEX_MARK(kPost[mi]);

@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/f6pmc; mkdir -p $OUT
+CMD="python $GRAFT_REPO_ROOT/tools/r04_quick.py bc6h"
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT -o p1 --output-format csv -- $CMD > $OUT/p1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD -d $OUT -o p2 --output-format csv -- $CMD > $OUT/p2.log 2>&1
+ls $OUT
