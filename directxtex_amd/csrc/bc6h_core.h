@@ -373,6 +373,7 @@ DXTEX_HD6 float perturb6_candidate(const Texels& tx, const Perturb6& s, const fl
 // tools/bc6h_debug.cpp (-DDXTEX_COUNT_EVALS6) checks bound <= exact on every candidate of the host search and counts what passes.
 #if defined(DXTEX_COUNT_EVALS6)
 void count_bound6(int n, int np, int step, float bound, float exact, float best);     // tools/bc6h_debug.cpp
+void count_prefix6(const float* r, const float* g, const float* b, int stride, int np, const float* pr, const float* pg, const float* pb, float best, int step);
 #endif
 struct Bound6 { float o[3]; float pp; float pre[3]; };   // per task: the centre, fl(Σ |p_k - o|^2), and the sum's prefixes over 4 / 8 / 12 texels
 
@@ -493,7 +494,9 @@ DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, boo
     const Bound6 cbd = bound6_begin(tx);
     const MacroBound6<N, float> cmb = bound6_macro<N>(tx, cbd, s.ch, base);
 #define DXTEX_COUNT6(tmp_, e_, step_) do { if (valid) { float var_[N]; palette_channel<N>(s.do_b ? fixedQ : (tmp_), s.do_b ? (tmp_) : fixedQ, prec, isSigned, var_); \
-        count_bound6(N, tx.np, step_, perturb6_bound<N>(tx, cbd, cmb, var_, minErr), e_, minErr); } } while (0)
+        count_bound6(N, tx.np, step_, perturb6_bound<N>(tx, cbd, cmb, var_, minErr), e_, minErr); \
+        if (N == 8) { float pr_[N], pg_[N], pb_[N]; for (int i_ = 0; i_ < N; ++i_) { pr_[i_] = (s.ch == 0) ? var_[i_] : base[0][i_]; pg_[i_] = (s.ch == 1) ? var_[i_] : base[1][i_]; pb_[i_] = (s.ch == 2) ? var_[i_] : base[2][i_]; } \
+                      count_prefix6(tx.r, tx.g, tx.b, tx.stride, tx.np, pr_, pg_, pb_, minErr, step_); } } } while (0)
 #else
 #define DXTEX_COUNT6(tmp_, e_, step_) do { } while (0)
 #endif

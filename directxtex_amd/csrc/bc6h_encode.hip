@@ -763,16 +763,16 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
         const int uT = unquantize(tmp, prec, SG);
         palette_channel_unq<N>(s.do_b ? uFixed : uT, s.do_b ? uT : uFixed, SG, var);
     };
-    auto write_pal = [&](int tmp, float* dst)        // the rare path: the palette is derived again rather than kept across the bound's loop
+    auto write_pal = [&](int tmp, float* dst)        // the rare path: all three channels' palettes are derived again rather than kept across the bound's loop
     {
-        float var[N];
-        var_of(tmp, var);
 #pragma unroll
-        for (int i = 0; i < N; ++i)
+        for (int c = 0; c < 3; ++c)
         {
-            dst[i] = (s.ch == 0) ? var[i] : base[0][i];
-            dst[8 + i] = (s.ch == 1) ? var[i] : base[1][i];
-            dst[16 + i] = (s.ch == 2) ? var[i] : base[2][i];
+            const int qa = (c == s.ch && !s.do_b) ? tmp : s.ep.A[c], qb = (c == s.ch && s.do_b) ? tmp : s.ep.B[c];
+            float pal[N];
+            palette_channel<N>(qa, qb, prec, SG, pal);
+#pragma unroll
+            for (int i = 0; i < N; ++i) dst[8 * c + i] = pal[i];
         }
     };
     {
@@ -817,7 +817,7 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
 }
 
 #if !defined(DXTEX_F6_WAVES)
-#define DXTEX_F6_WAVES 3
+#define DXTEX_F6_WAVES 4
 #endif
 template<bool SG>
 __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel(Bc6hArgs a)

@@ -35,8 +35,56 @@ void count_bound6(int n, int np, int step, float bound, float exact, float best)
     if (exact > 0 && bound / exact > g_worst && bound <= exact) g_worst = bound / exact;
 }
 } }
+// experiment: after how many texels does the prefix of the bound exclude a candidate - in the region's order and "outside in" along the
+// channel of largest range. [order][step class][checkpoint 4 / 8 / 12 / never before the end]
+static unsigned long long g_pref[2][5][4];
+namespace dxtex { namespace bc6h {
+void count_prefix6(const float* r, const float* g, const float* b, int stride, int np, const float* pr, const float* pg, const float* pb, float best, int step)
+{
+    const int c = step == 0 ? 0 : step > 4 ? 1 : step == 4 ? 2 : step == 2 ? 3 : 4;
+    double D[16];
+    for (int k = 0; k < np; ++k)
+    {
+        double m = 1e300;
+        for (int i = 0; i < 8; ++i) { const double dr = r[k * stride] - pr[i], dg = g[k * stride] - pg[i], db = b[k * stride] - pb[i]; m = std::min(m, dr * dr + dg * dg + db * db); }
+        D[k] = m;
+    }
+    int order[2][16];
+    for (int k = 0; k < np; ++k) order[0][k] = k;
+    // outside in along the channel of largest range
+    float lo[3] = { 1e30f, 1e30f, 1e30f }, hi[3] = { -1e30f, -1e30f, -1e30f };
+    for (int k = 0; k < np; ++k) { const float v[3] = { r[k * stride], g[k * stride], b[k * stride] }; for (int ch = 0; ch < 3; ++ch) { lo[ch] = std::min(lo[ch], v[ch]); hi[ch] = std::max(hi[ch], v[ch]); } }
+    int cm = 0; for (int ch = 1; ch < 3; ++ch) if (hi[ch] - lo[ch] > hi[cm] - lo[cm]) cm = ch;
+    const float* pl = cm == 0 ? r : cm == 1 ? g : b;
+    for (int k = 0; k < np; ++k)
+    {
+        int rank = 0;
+        for (int j = 0; j < np; ++j) rank += (pl[j * stride] < pl[k * stride]) || (pl[j * stride] == pl[k * stride] && j < k);
+        const int pos = (rank < (np + 1) / 2) ? 2 * rank : 2 * (np - 1 - rank) + 1;
+        order[1][pos] = k;
+    }
+    for (int o = 0; o < 2; ++o)
+    {
+        double sum = 0; int at = 3;
+        for (int k = 0; k < np; ++k)
+        {
+            sum += D[order[o][k]];
+            if ((k & 3) == 3 && k < 12 && sum * 0.9999 >= best) { at = k >> 2; break; }
+        }
+        ++g_pref[o][c][at];
+    }
+}
+} }
 static void print_bound_stats()
 {
+    const char* ord[2] = { "region order", "outside in  " }; const char* cl[5] = { "first", ">4", "4", "2", "1" };
+    for (int o = 0; o < 2; ++o)
+        for (int c = 0; c < 5; ++c)
+        {
+            const double t = double(g_pref[o][c][0] + g_pref[o][c][1] + g_pref[o][c][2] + g_pref[o][c][3]);
+            if (t > 0) printf("%s step %-5s: excluded after 4 texels %6.2f %%, 8: %6.2f %%, 12: %6.2f %%, later or never %6.2f %%\n", ord[o], cl[c],
+                              100 * g_pref[o][c][0] / t, 100 * g_pref[o][c][1] / t, 100 * g_pref[o][c][2] / t, 100 * g_pref[o][c][3] / t);
+        }
     const char* cls[5] = { "first", ">4", "4", "2", "1" };
     for (int a = 0; a < 2; ++a)
     {
