@@ -147,14 +147,19 @@ DXTEX_HD6 int weight4(int i)
 }
 template<int N> DXTEX_HD6 int weight_of(int i) { return N == 8 ? weight3(i) : weight4(i); }
 
-// NBits (:1176-1194)
+// NBits (:1176-1194). The reference counts with shift loops: for n > 0 the position of the highest set bit (+ 1 for a sign bit), for n < 0
+// the shifts until -1 is left = the position of the highest CLEAR bit, + 1; both are 32 - clz (of n resp. ~n; clz(0) = 32 gives 0 for n = -1).
+// As loops they were a third of bc6h_pre_kernel's and half of bc6h_post_kernel's instructions (six per-lane loops of up to 17 trips per
+// EndPointsFit). The host search (tools/bc6h_debug.cpp) runs this function against D3DX_BC6H::Encode; main() there also compares it with the loops.
 DXTEX_HD6 int nbits(int n, bool isSigned)
 {
-    int nb;
-    if (n == 0) return 0;
-    if (n > 0) { for (nb = 0; n; ++nb, n >>= 1) {} return nb + (isSigned ? 1 : 0); }
-    for (nb = 0; n < -1; ++nb, n >>= 1) {}
-    return nb + 1;
+    const uint32_t m = uint32_t(n < 0 ? ~n : n);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int bits = 32 - __clz(int(m));
+#else
+    const int bits = m ? 32 - __builtin_clz(m) : 0;
+#endif
+    return n == 0 ? 0 : bits + ((n < 0 || isSigned) ? 1 : 0);
 }
 
 // Norm (:1167-1173) on floats that hold exact integers

@@ -226,6 +226,11 @@ int main(int argc, char** argv)
 #endif
         return 0;
     }
+    // nbits (bc6h_core.h, count-leading-zeros form) against the reference's NBits loops, every value EndPointsFit can see
+    for (int n = -140000; n <= 140000; ++n)
+        for (int sg = 0; sg < 2; ++sg)
+            if (n >= 0 || sg)
+                if (nbits(n, sg != 0) != NBits(n, sg != 0)) { printf("nbits(%d, %d) = %d, the reference's NBits gives %d\n", n, sg, nbits(n, sg != 0), NBits(n, sg != 0)); return 3; }
     const int ntiles = argc > 1 ? atoi(argv[1]) : 100;
     g_rng = argc > 2 ? uint32_t(atoi(argv[2])) : 1u;
     int nbad = 0;
