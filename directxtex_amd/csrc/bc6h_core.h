@@ -410,7 +410,7 @@ struct MacroBound6
 };
 
 template<int N, class TX>
-DXTEX_HD6 MacroBound6<N, typename TX::T> bound6_macro(const TX& tx, const Bound6& bd, int ch, const float (&base)[3][N])
+DXTEX_HD6 MacroBound6<N, typename TX::T> bound6_macro(const TX& tx, const Bound6& bd, int ch, const float (&fix1)[N], const float (&fix2)[N])      // fix1 / fix2: the palettes of channels (ch + 1) % 3 and (ch + 2) % 3
 {
     MacroBound6<N, typename TX::T> m;
     const int og = int(tx.g - tx.r), ob2 = int(tx.b - tx.r);              // plane offsets (one array on the device: the pointers stay LDS pointers)
@@ -424,8 +424,8 @@ DXTEX_HD6 MacroBound6<N, typename TX::T> bound6_macro(const TX& tx, const Bound6
 #pragma unroll
     for (int i = 0; i < N; ++i)
     {
-        const float a = ((ch == 0) ? base[1][i] : (ch == 1) ? base[2][i] : base[0][i]) - oa;
-        const float b = ((ch == 0) ? base[2][i] : (ch == 1) ? base[0][i] : base[1][i]) - ob;
+        const float a = fix1[i] - oa;
+        const float b = fix2[i] - ob;
         m.f1[i] = a; m.f2[i] = b;
         m.baseN[i] = -__builtin_fmaf(b, b, a * a);
     }
@@ -497,7 +497,7 @@ DXTEX_HD6 void perturb6_macro(const Texels& tx, const Perturb6& s, int prec, boo
     float minErr = s.err;
 #if defined(DXTEX_COUNT_EVALS6)
     const Bound6 cbd = bound6_begin(tx);
-    const MacroBound6<N, float> cmb = bound6_macro<N>(tx, cbd, s.ch, base);
+    const MacroBound6<N, float> cmb = bound6_macro<N>(tx, cbd, s.ch, base[(s.ch + 1) % 3], base[(s.ch + 2) % 3]);
 #define DXTEX_COUNT6(tmp_, e_, step_) do { if (valid) { float var_[N]; palette_channel<N>(s.do_b ? fixedQ : (tmp_), s.do_b ? (tmp_) : fixedQ, prec, isSigned, var_); \
         count_bound6(N, tx.np, step_, perturb6_bound<N>(tx, cbd, cmb, var_, minErr), e_, minErr); \
         if (N == 8) { float pr_[N], pg_[N], pb_[N]; for (int i_ = 0; i_ < N; ++i_) { pr_[i_] = (s.ch == 0) ? var_[i_] : base[0][i_]; pg_[i_] = (s.ch == 1) ? var_[i_] : base[1][i_]; pb_[i_] = (s.ch == 2) ? var_[i_] : base[2][i_]; } \

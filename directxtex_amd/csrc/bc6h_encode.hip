@@ -749,13 +749,15 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
 #if defined(DXTEX_DEV)
     if (stats) { const unsigned long long act = __ballot(active); if (lane == 0) { atomicAdd(stats + 4, 1u); atomicAdd(stats + 5, uint32_t(__popcll(act))); } }
 #endif
-    float base[3][N];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) palette_channel<N>(s.ep.A[c], s.ep.B[c], prec, SG, base[c]);
     const int fixedQ = (s.ch == 0) ? (s.do_b ? s.ep.A[0] : s.ep.B[0]) : (s.ch == 1) ? (s.do_b ? s.ep.A[1] : s.ep.B[1]) : (s.do_b ? s.ep.A[2] : s.ep.B[2]);
     int cur = (s.ch == 0) ? (s.do_b ? s.ep.B[0] : s.ep.A[0]) : (s.ch == 1) ? (s.do_b ? s.ep.B[1] : s.ep.A[1]) : (s.do_b ? s.ep.B[2] : s.ep.A[2]);
     const int uFixed = unquantize(fixedQ, prec, SG);                 // the other endpoint does not move during this call
-    const MacroBound6<N, int16_t> mb = bound6_macro<N>(tx, bd, s.ch, base);
+    // the palettes of the two channels this call does not walk: (ch + 1) % 3 and (ch + 2) % 3 (the endpoints are selected, not the palettes:
+    // three palettes indexed by the channel would live in scratch)
+    float fix1[N], fix2[N];
+    palette_channel<N>((s.ch == 0) ? s.ep.A[1] : (s.ch == 1) ? s.ep.A[2] : s.ep.A[0], (s.ch == 0) ? s.ep.B[1] : (s.ch == 1) ? s.ep.B[2] : s.ep.B[0], prec, SG, fix1);
+    palette_channel<N>((s.ch == 0) ? s.ep.A[2] : (s.ch == 1) ? s.ep.A[0] : s.ep.A[1], (s.ch == 0) ? s.ep.B[2] : (s.ch == 1) ? s.ep.B[0] : s.ep.B[1], prec, SG, fix2);
+    const MacroBound6<N, int16_t> mb = bound6_macro<N>(tx, bd, s.ch, fix1, fix2);
     float minErr = s.err;
     // the walked channel's palette of a candidate (GeneratePaletteQuantized with the candidate's endpoint)
     auto var_of = [&](int tmp, float (&var)[N])
