@@ -79,3 +79,26 @@ def test_bc6h_from_rgba32f_and_rgba8(ctx, oracle):
     assert np.array_equal(ctx.compress(img32, w, h, RGBA32F, UF16, 0, 0.5), oracle.ref_compress_image(img32, w, h, RGBA32F, UF16, 0, 0.5))
     img8 = synth.rgba8(w, h, seed=4, alpha="opaque")
     assert np.array_equal(ctx.compress(img8, w, h, 28, UF16, 0, 0.5), oracle.ref_compress_image(img8, w, h, 28, UF16, 0, 0.5))
+
+
+@pytest.mark.parametrize("fmt", [UF16, SF16])
+def test_bc6h_extreme_ranges_bit_exact(ctx, oracle, fmt):
+    """The bound filter of bc6h_perturb_filter_kernel carries an explicit margin for fp32 rounding that scales with the SQUARE of the texel
+    values: images at the ends of the half range (noise around 60 000, subnormal halves, blocks that mix 0 and 65504, steep ramps; negatives
+    for SF16) against the reference, block for block."""
+    rng = np.random.default_rng(1000 + fmt)
+    w, h = 128, 64
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    imgs = []
+    imgs.append(60000.0 - 8000.0 * rng.random((h, w, 3), dtype=np.float32))                                  # bright noise, just below the half maximum
+    imgs.append(6.0e-5 * rng.random((h, w, 3), dtype=np.float32))                                            # subnormal halves
+    imgs.append(np.where(rng.random((h, w, 3)) < 0.5, 0.0, 65504.0).astype(np.float32))                      # 0 / maximum per component
+    imgs.append(np.stack([np.exp2(x / 8 - 8), np.exp2(y / 4 - 8), np.exp2((x + y) / 12 - 8)], -1).astype(np.float32) * (1 + 0.01 * rng.standard_normal((h, w, 3)).astype(np.float32)))
+    imgs.append((30000.0 + 5.0 * rng.standard_normal((h, w, 3))).astype(np.float32))                         # bright and nearly flat: errors of a few units on values of 3e4
+    for i, v in enumerate(imgs):
+        if fmt == SF16:
+            v = v * np.sign(rng.standard_normal((h, w, 3))).astype(np.float32)
+        img = np.concatenate([np.clip(v, -65504, 65504), np.ones((h, w, 1), np.float32)], -1).astype(np.float16)
+        got = ctx.compress(img, w, h, RGBA16F, fmt, 0, 0.5)
+        ref = oracle.ref_compress_image(img, w, h, RGBA16F, fmt, 0, 0.5)
+        _check(oracle, got, ref, f"{fmt} extreme image {i}")

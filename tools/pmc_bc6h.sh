@@ -1,3 +1,6 @@
+#!/bin/bash
+# DEVELOPMENT TOOL (run on the GPU box through gpurun): two rocprofv3 --pmc passes (SQ instruction counters; SQ wait / LDS counters) over the cfg3
+# BC6H encode of tools/r04_quick.py - what the round-4 work on bc6h_perturb_filter_kernel was steered by. Outputs under gpurun_out/f6pmc.
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/f6pmc; mkdir -p $OUT
 CMD="python $GRAFT_REPO_ROOT/tools/r04_quick.py bc6h"
