@@ -783,10 +783,7 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
         const bool valid = (tmp >= 0) && (tmp < (1 << prec));
         float var[N];
         var_of(tmp, var);
-        bool pass = active && valid && perturb6_bound<N>(tx, bd, mb, var, minErr) < minErr;
-#if defined(DXTEX_F6_NOPASS)
-        pass = false;
-#endif
+        const bool pass = active && valid && perturb6_bound<N>(tx, bd, mb, var, minErr) < minErr;
         float e = 0.0f, none = 0.0f;
         exact_by_wave(cols, L, lane, tx.np, pass, false, [&](int, float* dst) { write_pal(tmp, dst); }, e, none, stats);
         if (pass && e < minErr) { minErr = e; cur = tmp; }
@@ -800,11 +797,8 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
         var_of(tP, varP);
         float lbM, lbP;
         perturb6_bound_pair<N>(tx, bd, mb, varM, varP, minErr, lbM, lbP);
-        bool passM = active && (tM >= 0) && (tM < (1 << prec)) && lbM < minErr;
-        bool passP = active && (tP >= 0) && (tP < (1 << prec)) && lbP < minErr;
-#if defined(DXTEX_F6_NOPASS)
-        passM = passP = lbM + lbP == 12345.678f;      // timing experiment: the bounds alone (results are wrong)
-#endif
+        const bool passM = active && (tM >= 0) && (tM < (1 << prec)) && lbM < minErr;
+        const bool passP = active && (tP >= 0) && (tP < (1 << prec)) && lbP < minErr;
         float eM = 0.0f, eP = 0.0f;
 #if defined(DXTEX_DEV)
         if (stats && lane == 0) atomicAdd(stats + 0, 1u);
