@@ -102,3 +102,14 @@ def test_bc6h_extreme_ranges_bit_exact(ctx, oracle, fmt):
         got = ctx.compress(img, w, h, RGBA16F, fmt, 0, 0.5)
         ref = oracle.ref_compress_image(img, w, h, RGBA16F, fmt, 0, 0.5)
         _check(oracle, got, ref, f"{fmt} extreme image {i}")
+
+
+@pytest.mark.parametrize("fmt", [UF16, SF16])
+def test_bc6h_512_bit_exact(ctx, oracle, fmt):
+    """16 384 blocks per format against the reference (the task lists of a 512^2 image are long enough for the lane-per-task search kernels -
+    bc6h_perturb_filter_kernel for the two-region modes - with every lane of a wavefront busy and the queue refilling them)."""
+    w = h = 512
+    img = _hdr_image(w, h, seed=77 + fmt, signed=(fmt == SF16))
+    got = ctx.compress(img, w, h, RGBA16F, fmt, 0, 0.5)
+    ref = oracle.ref_compress_image(img, w, h, RGBA16F, fmt, 0, 0.5)
+    _check(oracle, got, ref, f"{fmt} 512^2")
