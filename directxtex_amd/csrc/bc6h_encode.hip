@@ -661,10 +661,11 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a, uint32_t w
 // PerturbOne (:2081-2141) accepts a candidate only when its error is BELOW the best so far. perturb6_bound_pair (bc6h_core.h) bounds the
 // two candidates of a step from below at well under half the cost of evaluating them (three FMAs and a maximum per (texel, entry)
 // instead of eight ordered fp32 operations and a compare / select pair; the rounding of the reference's fp32 sums and of the bound's own
-// arithmetic is covered by an explicit margin). On the cfg3 image 1.6 % of the candidates pass it (none at the large steps, 8 % at step
-// 1; tools/bc6h_debug.cpp -DDXTEX_COUNT_EVALS6). Those are evaluated exactly - operation for operation as MapColorsQuantized does - by
-// the WHOLE wavefront: the owners put the candidates' palettes on a list in LDS, sixteen lanes take one list entry, lane k scores texel k
-// (norm3 + scan_min, the functions of the plain kernel), and the per-texel errors are summed in texel order by the group's first lane.
+// arithmetic is covered by an explicit margin). On the cfg3 image 2.6 % of the candidates pass it (none at the large steps, 8 % at step
+// 1; DXTEX_BC6H_STATS in the development build, tools/bc6h_debug.cpp -DDXTEX_COUNT_EVALS6 on the host). Those are evaluated exactly -
+// operation for operation as MapColorsQuantized does - by the WHOLE wavefront: the owners put the candidates' palettes on a list in LDS,
+// sixteen lanes take one list entry, lane k scores texel k (norm3 + scan_min, the functions of the plain kernel), and the per-texel errors
+// are summed in texel order along the sixteen lanes (a DPP row_shr:1 chain: the reference's fTotErr += fBestErr, :2074).
 constexpr int kFilterSlots = 32;          // list entries per round (a step with more passing candidates takes several rounds)
 struct FilterLds
 {
@@ -828,7 +829,7 @@ __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel
     EndPts zero; for (int c = 0; c < 3; ++c) { zero.A[c] = 0; zero.B[c] = 0; }
     Perturb6 st = perturb6_begin(zero, 0.0f);
     Texels16 tx; tx.r = slot; tx.g = slot + 16 * 64; tx.b = slot + 32 * 64; tx.stride = 64; tx.np = 0;
-    Bound6 bd; bd.o[0] = bd.o[1] = bd.o[2] = 0.0f; bd.pp = 0.0f;
+    Bound6 bd; bd.o[0] = bd.o[1] = bd.o[2] = 0.0f; bd.pp = 0.0f; bd.pre[0] = bd.pre[1] = bd.pre[2] = 0.0f;
     uint32_t myTask = 0xFFFFFFFFu;
     const int prec = a.mode.prec;
 #if defined(DXTEX_DEV)
