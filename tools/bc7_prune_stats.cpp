@@ -95,8 +95,10 @@ int main(int argc, char** argv)
             for (int i = 0; i < 16; ++i) (pass ? l2 : l3)[i] = sh[i];
         }
         int prevBest = 0x7FFFFFFF;
-        for (int m = 0; m < 2; ++m)
+        static const bool order31 = getenv("DXTEX_STATS_ORDER31") != nullptr;      // what if mode 3 ran before mode 1?
+        for (int mm = 0; mm < 2; ++mm)
         {
+            const int m = order31 ? 1 - mm : mm;
             CandStat c[16];
             for (int i = 0; i < 16; ++i) c[i] = m ? cand<3>(b, l2[i]) : cand<1>(b, l3[i]);
             int tabNow = prevBest, best = 0x7FFFFFFF, bi = 0;
