@@ -13,6 +13,8 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <array>
+#include <cmath>
 #include "../directxtex_amd/csrc/bc67_tables.h"
 #include "../directxtex_amd/csrc/bc7_core.h"
 using namespace dxtex; using namespace dxtex::bc7;
@@ -43,11 +45,116 @@ static void seeds2(const HB& b, uint32_t shape, int region, Region& rg, uint32_t
     else seed_endpoints<true>(b.f, mask, A, B);
     anchor = region ? kAnchor2[shape] : 0;
 }
-struct CandStat { int lb, org, fin, np[2], orgS[2], finS[2]; double cost, resid; };
+// EXPERIMENT (round 4, host only): a lower bound that also counts the error ALONG the palette's line. For a palette on a line with direction u
+// the texels' squared distances to the real line points split into the distance to the line and the distance, along the line, to the nearest
+// of the N points (Pythagoras): sum >= R(u) + K_N(u), R(u) = tr S - u'Su, K_N(u) = optimum of 1-D N-means of the projections. With u = c u1 +
+// s v (u1 the principal axis): R(u) >= tr S - c^2 l1 - s^2 l2, sqrt K_N(u) >= c sqrt K_N(u1) - s sqrt l2 (the root of a k-means cost is
+// 1-Lipschitz and homogeneous), and (x - y)+^2 >= (1 - e) x^2 - (1/e - 1) y^2 makes the sum linear in c^2: >= min(R1 + (1 - e) K0, tr S - l2 / e)
+// for every e in (0, 1); the best e solves K0 e^2 + (l1 - K0) e - l2 = 0. The rounding of the entries costs 1/2 sqrt(C n) under the root as before.
+static void jacobi3(double A[3][3], double w[3], double V[3][3])
+{
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j;
+    for (int sweep = 0; sweep < 60; ++sweep)
+    {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q)
+        {
+            if (fabs(A[p][q]) < 1e-300) continue;
+            const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0)), c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+            for (int k = 0; k < 3; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+            for (int k = 0; k < 3; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+            for (int k = 0; k < 3; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+        }
+    }
+    for (int i = 0; i < 3; ++i) w[i] = A[i][i];
+}
+static double kmeans1d(std::vector<double> t, int N)
+{
+    std::sort(t.begin(), t.end()); const int n = int(t.size());
+    if (n <= N) return 0.0;
+    std::vector<double> s1(n + 1, 0.0), s2(n + 1, 0.0);
+    for (int i = 0; i < n; ++i) { s1[i + 1] = s1[i] + t[i]; s2[i + 1] = s2[i] + t[i] * t[i]; }
+    auto sse = [&](int i, int j) { const double m = s1[j + 1] - s1[i]; const double c = (s2[j + 1] - s2[i]) - m * m / double(j - i + 1); return c > 0 ? c : 0.0; };
+    std::vector<double> d(n), e(n);
+    for (int j = 0; j < n; ++j) d[j] = sse(0, j);
+    for (int k = 2; k <= N; ++k)
+    {
+        for (int j = 0; j < n; ++j)
+        {
+            double best = (j < k) ? 0.0 : 1e300;
+            if (j >= k) for (int i = k - 1; i <= j; ++i) best = std::min(best, d[i - 1] + sse(i, j));
+            e[j] = best;
+        }
+        d = e;
+    }
+    return d[n - 1];
+}
+// exact optimum of "N equally weighted points alpha + beta w_i / 64 against the sorted values t": every monotone assignment, least squares for (alpha, beta)
+static double kconstr1d(std::vector<double> t, int N)
+{
+    static const double w3[8] = { 0, 9, 18, 27, 37, 46, 55, 64 }, w2[4] = { 0, 21, 43, 64 };
+    const double* w = (N == 8) ? w3 : w2;
+    std::sort(t.begin(), t.end()); const int n = int(t.size());
+    double st = 0, stt = 0; for (double v : t) { st += v; stt += v * v; }
+    double best = 1e300;
+    // depth-first over non-decreasing index sequences
+    struct F { int k, i; double sx, sxx, sxt; };
+    std::vector<F> stack; stack.push_back({ 0, 0, 0, 0, 0 });
+    while (!stack.empty())
+    {
+        F f = stack.back(); stack.pop_back();
+        if (f.k == n)
+        {
+            const double vx = f.sxx - f.sx * f.sx / n, cxt = f.sxt - f.sx * st / n, vt = stt - st * st / n;
+            const double c = (vx > 1e-12) ? vt - cxt * cxt / vx : vt;
+            best = std::min(best, c > 0 ? c : 0.0);
+            continue;
+        }
+        for (int i = f.i; i < N; ++i) { const double x = w[i] / 64.0; stack.push_back({ f.k + 1, i, f.sx + x, f.sxx + x * x, f.sxt + x * t[f.k] }); }
+    }
+    return best;
+}
+static double g_lb2Diag[4];
+static int subset_lower_bound2(const uint32_t* pix, uint32_t mask, int N)
+{
+    double n = 0, m[3] = {0,0,0}; std::vector<std::array<double,3>> P;
+    for (int i = 0; i < 16; ++i) if ((mask >> i) & 1u) { std::array<double,3> v = { double(pix[i] & 0xFF), double((pix[i] >> 8) & 0xFF), double((pix[i] >> 16) & 0xFF) }; P.push_back(v); n += 1; for (int a = 0; a < 3; ++a) m[a] += v[a]; }
+    if (n < 2) return 0;
+    for (int a = 0; a < 3; ++a) m[a] /= n;
+    double S[3][3] = {};
+    for (auto& v : P) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) S[a][b] += (v[a] - m[a]) * (v[b] - m[b]);
+    const double tr = S[0][0] + S[1][1] + S[2][2];
+    if (!(tr > 0)) return 0;
+    double A[3][3]; memcpy(A, S, sizeof(A)); double w[3], V[3][3]; jacobi3(A, w, V);
+    int i1 = 0; for (int i = 1; i < 3; ++i) if (w[i] > w[i1]) i1 = i;
+    double l1 = w[i1], l2 = -1e300; for (int i = 0; i < 3; ++i) if (i != i1) l2 = std::max(l2, w[i]);
+    l1 *= (1.0 + 1e-9); l2 = std::max(0.0, l2) * (1.0 + 1e-9) + 1e-9;
+    std::vector<double> t; for (auto& v : P) t.push_back((v[0] - m[0]) * V[0][i1] + (v[1] - m[1]) * V[1][i1] + (v[2] - m[2]) * V[2][i1]);
+    static const bool constrained = getenv("DXTEX_STATS_CONSTRAINED_K") != nullptr;
+    const double K0 = (constrained ? kconstr1d(t, N) : kmeans1d(t, N)) * (1.0 - 1e-9);
+    const double R1 = std::max(0.0, tr - l1);
+    double G = R1;
+    if (K0 > 0)
+    {
+        const double bq = l1 - K0, e = (-bq + sqrt(bq * bq + 4.0 * K0 * l2)) / (2.0 * K0);
+        if (e > 0 && e < 1) { const double ee = std::min(1.0, e * (1.0 + 1e-9) + 1e-12); G = std::min(R1 + (1.0 - ee) * K0, tr - l2 / ee); G = std::max(G, R1); }
+    }
+    g_lb2Diag[0] = R1; g_lb2Diag[1] = K0; g_lb2Diag[2] = G;
+    // and without any rounding slack: whatever the N palette entries are, the error is at least the optimum of N-means in space, which is at
+    // least the optimum of N-means of the projections on any one direction (K0)
+    const double d = sqrt(G) - 0.5 * sqrt(3.0 * n) - 1e-3;
+    double lb = (d > 0) ? d * d * 0.99999 - 1.0 : 0.0;
+    static const bool noFree = getenv("DXTEX_STATS_NO_FREE_K") != nullptr;
+    if (!noFree) lb = std::max(lb, K0 * 0.99999 - 1.0);
+    return lb > 0 ? int(lb) : 0;
+}
+struct CandStat { int lb, lb2, org, fin, np[2], orgS[2], finS[2], lb2S[2]; double cost, resid; };
 static double line_resid(const uint32_t* pix, uint32_t mask);
 template<int MODE> static CandStat cand(const HB& b, uint32_t shape)
 {
-    CandStat c; c.lb = 0; c.org = 0; c.cost = 0; c.resid = 0; int opt = 0;
+    CandStat c; c.lb = 0; c.lb2 = 0; c.org = 0; c.cost = 0; c.resid = 0; int opt = 0;
     for (int r = 0; r < 2; ++r)
     {
         Region rg; uint32_t A, B, anchor, mask; seeds2(b, shape, r, rg, A, B, anchor, mask);
@@ -56,6 +163,7 @@ template<int MODE> static CandStat cand(const HB& b, uint32_t shape)
         c.cost += (double(g_evalCount[MODE] - e0) + 0.45 * double(g_boundCount[MODE] - b0)) * rg.np;      // texel-evaluations, a bound ~0.45 of an exact one
         c.org += res.orgErr; opt += res.optErr; c.np[r] = rg.np; c.orgS[r] = res.orgErr; c.finS[r] = res.optErr;
         c.lb += subset_lower_bound(b.ldr, mask, 0u, 3); c.resid += line_resid(b.ldr, mask);
+        c.lb2S[r] = subset_lower_bound2(b.ldr, mask, (MODE == 1) ? 8 : 4); c.lb2 += c.lb2S[r];
     }
     c.fin = std::min(c.org, opt);
     return c;
@@ -77,7 +185,7 @@ int main(int argc, char** argv)
     std::vector<uint8_t> tiles(size_t(n) * 64); if (fread(tiles.data(), 1, tiles.size(), f) != tiles.size()) return 2; fclose(f);
     double noslack[2] = {0, 0}, fr[2] = {0, 0}, frN[2] = {0, 0}, tot[2] = {0, 0}, now[2] = {0, 0}, inmode[2] = {0, 0}, oracle[2] = {0, 0}, top4[2] = {0, 0}, flat[2] = {0, 0}; long winRankHist[2][16] = {};
     double ratioSum[2] = {0, 0}; long ratioN[2] = {0, 0};
-    double lbHist[2][12] = {}; double costByBest[2][8] = {};
+    double lbHist[2][12] = {}; double costByBest[2][8] = {}; double now2[2] = {0, 0}, lbSum[2] = {0,0}, lb2Sum[2] = {0,0}, finSum[2] = {0,0}; long viol[2] = {0, 0}, violC[2] = {0, 0};
     for (int t = 0; t < n; ++t)
     {
         HB b; make_block(b, &tiles[size_t(t) * 64]);
@@ -114,6 +222,10 @@ int main(int argc, char** argv)
                 const double w = c[i].cost;
                 tot[m] += w;
                 const bool sNow = !(c[i].lb > tabNow);
+                if (!(std::max(c[i].lb, c[i].lb2) > tabNow)) now2[m] += w;
+                for (int r = 0; r < 2; ++r) if (c[i].lb2S[r] > c[i].finS[r]) { ++viol[m]; if (viol[m] <= 3) printf("VIOLATION mode %d: subset bound %d > final %d (np %d)\n", m ? 3 : 1, c[i].lb2S[r], c[i].finS[r], c[i].np[r]); }
+                if (c[i].lb2 > c[i].fin) ++violC[m];
+                lbSum[m] += c[i].lb; lb2Sum[m] += std::max(c[i].lb, c[i].lb2); finSum[m] += c[i].fin;
                 if (sNow) now[m] += w;
                 if (!(c[i].resid > tabNow)) noslack[m] += w;
                 if (sNow && c[i].resid > 1) { fr[m] += w * double(c[i].fin) / c[i].resid; frN[m] += w; }
@@ -133,6 +245,7 @@ int main(int argc, char** argv)
     {
         printf("mode %d: %.0f cost units (texel-evaluations) unpruned; searched now %.1f %%; with the in-mode final table %.1f %%; two-phase (best 4 by org first) %.1f %%; oracle %.1f %%; mean final/LB of the searched %.2f\n",
                m ? 3 : 1, tot[m], 100.0 * now[m] / tot[m], 100.0 * inmode[m] / tot[m], 100.0 * top4[m] / tot[m], 100.0 * oracle[m] / tot[m], ratioSum[m] / std::max(1L, ratioN[m]));
+        printf("  EXPERIMENT along-the-line bound: searched %.1f %% (bound above a subset's final error: %ld subsets, %ld candidates); mean bound / final: now %.3f, new %.3f\n", 100.0 * now2[m] / tot[m], viol[m], violC[m], lbSum[m] / finSum[m], lb2Sum[m] / finSum[m]);
         printf("  searched if the bound were the plain line residual (no rounding slack; NOT valid, potential only): %.1f %%; cost-weighted final / residual of the searched: %.2f\n", 100.0 * noslack[m] / tot[m], fr[m] / std::max(1.0, frN[m]));
         printf("  cost share by LB / table of the searched (0.0-0.1 ... 1.0+):"); for (int k = 0; k < 12; ++k) printf(" %.1f%%", 100.0 * lbHist[m][k] / now[m]); printf("\n");
         printf("  cost share by the mode's best final error (0, 1-3, 4-15, 16-63, 64-255, 256-1023, 1024-4095, 4096+):"); for (int k = 0; k < 8; ++k) printf(" %.1f%%", 100.0 * costByBest[m][k] / now[m]); printf("\n");
