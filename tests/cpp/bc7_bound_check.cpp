@@ -13,6 +13,7 @@
 #include <cstring>
 #include "../../directxtex_amd/csrc/bc67_tables.h"
 #include "../../directxtex_amd/csrc/bc7_core.h"
+#include "../../directxtex_amd/csrc/bc7_bound2.h"
 
 using namespace dxtex;
 using namespace dxtex::bc7;
@@ -50,7 +51,7 @@ static long palette_error(const uint32_t* px, uint32_t mask, int C, int bits, co
 int main(int argc, char** argv)
 {
     const int trials = argc > 1 ? std::atoi(argv[1]) : 20000;
-    long violations = 0, checked = 0; double tightest = 1e30;
+    long violations = 0, checked = 0, lineChecked = 0, lineOrder = 0, lineGain = 0; double tightest = 1e30;
     for (int t = 0; t < trials; ++t)
     {
         // texels: a mix of noisy, near-linear and few-colour blocks
@@ -77,7 +78,12 @@ int main(int argc, char** argv)
         if (!mask) continue;
         const int C = (rnd() & 1) ? 3 : 4;
         const int bits = 2 + rnd() % 3;
-        const int lb = subset_lower_bound(px, mask, 0, C);
+        const int lbPlain = subset_lower_bound(px, mask, 0, C);
+        // the along-the-line bound of bc7_bound2.h (2-bit indices: free and fixed-weight term; 3-bit: free term) must hold for every palette too,
+        // and is never below the plain one
+        int lb = lbPlain;
+        if (bits == 2) { const int f = subset_lower_bound_line<4, false>(px, mask, 0, C), x = subset_lower_bound_line<4, true>(px, mask, 0, C); lineChecked += 2; if (f < lbPlain - 1 || x < f - 1) ++lineOrder; lineGain += (x > lbPlain); lb = std::max(lb, std::max(f, x)); }
+        if (bits == 3) { const int f = subset_lower_bound_line<8, false>(px, mask, 0, C); ++lineChecked; if (f < lbPlain - 1) ++lineOrder; lineGain += (f > lbPlain); lb = std::max(lb, f); }
         // random endpoints, endpoints drawn from the texels, and a little hill climbing from the best of those
         long bestErr = -1; int be[4] = { 0, 0, 0, 0 }, bf[4] = { 0, 0, 0, 0 };
         for (int k = 0; k < 60; ++k)
@@ -168,6 +174,8 @@ int main(int argc, char** argv)
         }
     }
     std::printf("%ld palettes checked, %ld violations, best found error / bound >= %.3f\n", checked, violations, tightest);
+    std::printf("along-the-line bound (bc7_bound2.h): %ld evaluated, above the plain bound in %ld, below the plain bound or out of order in %ld\n", lineChecked, lineGain, lineOrder);
+    if (lineOrder) violations += lineOrder;
     std::printf("%ld opaque fits, %ld differ between the RGBA fit and its opaque-block variant\n", fits, fitDiff);
     return (violations || fitDiff) ? 1 : 0;
 }

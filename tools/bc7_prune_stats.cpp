@@ -17,6 +17,7 @@
 #include <cmath>
 #include "../directxtex_amd/csrc/bc67_tables.h"
 #include "../directxtex_amd/csrc/bc7_core.h"
+#include "../directxtex_amd/csrc/bc7_bound2.h"
 using namespace dxtex; using namespace dxtex::bc7;
 
 struct HB { float f[64]; uint32_t ldr[16]; };
@@ -163,7 +164,12 @@ template<int MODE> static CandStat cand(const HB& b, uint32_t shape)
         c.cost += (double(g_evalCount[MODE] - e0) + 0.45 * double(g_boundCount[MODE] - b0)) * rg.np;      // texel-evaluations, a bound ~0.45 of an exact one
         c.org += res.orgErr; opt += res.optErr; c.np[r] = rg.np; c.orgS[r] = res.orgErr; c.finS[r] = res.optErr;
         c.lb += subset_lower_bound(b.ldr, mask, 0u, 3); c.resid += line_resid(b.ldr, mask);
-        c.lb2S[r] = subset_lower_bound2(b.ldr, mask, (MODE == 1) ? 8 : 4); c.lb2 += c.lb2S[r];
+        // DXTEX_STATS_DEVICE_FORM: the device-ready function of bc7_bound2.h (approximate axis from the squared matrix) instead of this file's
+        // Jacobi version; DXTEX_STATS_CONSTRAINED_K selects the fixed-weight term in both (2-bit indices only in the device form)
+        static const bool devForm = getenv("DXTEX_STATS_DEVICE_FORM") != nullptr, fixedK = getenv("DXTEX_STATS_CONSTRAINED_K") != nullptr;
+        if (devForm) c.lb2S[r] = (MODE == 1) ? subset_lower_bound_line<8, false>(b.ldr, mask, 0u, 3) : (fixedK ? subset_lower_bound_line<4, true>(b.ldr, mask, 0u, 3) : subset_lower_bound_line<4, false>(b.ldr, mask, 0u, 3));
+        else c.lb2S[r] = subset_lower_bound2(b.ldr, mask, (MODE == 1) ? 8 : 4);
+        c.lb2 += c.lb2S[r];
     }
     c.fin = std::min(c.org, opt);
     return c;
