@@ -118,6 +118,7 @@ static double kconstr1d(std::vector<double> t, int N)
     return best;
 }
 static double g_lb2Diag[4];
+static double g_diagSum[2][5];
 static int subset_lower_bound2(const uint32_t* pix, uint32_t mask, int N)
 {
     double n = 0, m[3] = {0,0,0}; std::vector<std::array<double,3>> P;
@@ -170,6 +171,7 @@ template<int MODE> static CandStat cand(const HB& b, uint32_t shape)
         if (devForm) c.lb2S[r] = (MODE == 1) ? subset_lower_bound_line<8, false>(b.ldr, mask, 0u, 3) : (fixedK ? subset_lower_bound_line<4, true>(b.ldr, mask, 0u, 3) : subset_lower_bound_line<4, false>(b.ldr, mask, 0u, 3));
         else c.lb2S[r] = subset_lower_bound2(b.ldr, mask, (MODE == 1) ? 8 : 4);
         c.lb2 += c.lb2S[r];
+        if (!devForm) { g_diagSum[MODE == 1 ? 0 : 1][0] += g_lb2Diag[0]; g_diagSum[MODE == 1 ? 0 : 1][1] += g_lb2Diag[1]; g_diagSum[MODE == 1 ? 0 : 1][2] += g_lb2Diag[2]; g_diagSum[MODE == 1 ? 0 : 1][3] += res.optErr < res.orgErr ? res.optErr : res.orgErr; g_diagSum[MODE == 1 ? 0 : 1][4] += c.lb2S[r]; }
     }
     c.fin = std::min(c.org, opt);
     return c;
@@ -191,6 +193,7 @@ int main(int argc, char** argv)
     std::vector<uint8_t> tiles(size_t(n) * 64); if (fread(tiles.data(), 1, tiles.size(), f) != tiles.size()) return 2; fclose(f);
     double noslack[2] = {0, 0}, fr[2] = {0, 0}, frN[2] = {0, 0}, tot[2] = {0, 0}, now[2] = {0, 0}, inmode[2] = {0, 0}, oracle[2] = {0, 0}, top4[2] = {0, 0}, flat[2] = {0, 0}; long winRankHist[2][16] = {};
     double ratioSum[2] = {0, 0}; long ratioN[2] = {0, 0};
+    long lateAll[3] = {0, 0, 0}, latePruned[3][2] = {};
     double lbHist[2][12] = {}; double costByBest[2][8] = {}; double now2[2] = {0, 0}, lbSum[2] = {0,0}, lb2Sum[2] = {0,0}, finSum[2] = {0,0}; long viol[2] = {0, 0}, violC[2] = {0, 0};
     for (int t = 0; t < n; ++t)
     {
@@ -243,15 +246,34 @@ int main(int argc, char** argv)
                 if (sNow) { const double r = c[i].lb > 0 ? double(c[i].lb) / std::max(1, tabNow) : 0.0; lbHist[m][std::min(11, int(r * 10))] += w; }
                 if (sNow) { int k = 0; for (int v = best; v > 0 && k < 7; v >>= 2) ++k; costByBest[m][k] += w; }
             }
+            if (getenv("DXTEX_STATS_DUMP") && t < atoi(getenv("DXTEX_STATS_DUMP")))
+            {
+                printf("block %d mode %d:", t, m ? 3 : 1);
+                for (int i = 0; i < 16; ++i) printf(" [%d lb %d lb2 %d org %d fin %d]", i, c[i].lb, c[i].lb2, c[i].org, c[i].fin);
+                printf("\n");
+            }
             winRankHist[m][bi]++;
             prevBest = std::min(prevBest, best);
         }
+        // the late modes' tasks (modes 4 / 5: the whole block per rotation): today's universal bound and the along-the-line one against what modes 1 / 3 left
+        for (uint32_t rot = 0; rot < 4; ++rot)
+        {
+            const int colour = subset_lower_bound(b.ldr, 0xFFFFu, rot, 3);
+            const int line4 = std::max(colour, subset_lower_bound_line<4, true>(b.ldr, 0xFFFFu, rot, 3)), line8 = std::max(colour, subset_lower_bound_line<8, false>(b.ldr, 0xFFFFu, rot, 3));
+            const int sc4 = rot ? scalar_kmeans_lower_bound<4>(b.ldr, rot) : 0, sc8 = rot ? scalar_kmeans_lower_bound<8>(b.ldr, rot) : 0;
+            const int oldB[3] = { colour + sc4, colour + sc8, colour + sc4 }, newB[3] = { line4 + sc4, line4 + sc8, line8 + sc4 };
+            for (int k = 0; k < 3; ++k) { ++lateAll[k]; latePruned[k][0] += oldB[k] > prevBest; latePruned[k][1] += newB[k] > prevBest; }
+        }
     }
+    printf("late modes (whole-block tasks against the best of modes 1 / 3): pruned now / with the along-the-line term -");
+    { const char* nm[3] = { "mode 5", "mode 4 im0", "mode 4 im1" }; for (int k = 0; k < 3; ++k) printf(" %s %.1f %% / %.1f %% of %ld;", nm[k], 100.0 * latePruned[k][0] / lateAll[k], 100.0 * latePruned[k][1] / lateAll[k], lateAll[k]); }
+    printf("\n");
     for (int m = 0; m < 2; ++m)
     {
         printf("mode %d: %.0f cost units (texel-evaluations) unpruned; searched now %.1f %%; with the in-mode final table %.1f %%; two-phase (best 4 by org first) %.1f %%; oracle %.1f %%; mean final/LB of the searched %.2f\n",
                m ? 3 : 1, tot[m], 100.0 * now[m] / tot[m], 100.0 * inmode[m] / tot[m], 100.0 * top4[m] / tot[m], 100.0 * oracle[m] / tot[m], ratioSum[m] / std::max(1L, ratioN[m]));
         printf("  EXPERIMENT along-the-line bound: searched %.1f %% (bound above a subset's final error: %ld subsets, %ld candidates); mean bound / final: now %.3f, new %.3f\n", 100.0 * now2[m] / tot[m], viol[m], violC[m], lbSum[m] / finSum[m], lb2Sum[m] / finSum[m]);
+        printf("  sums over all subsets: line residual R1 %.0f, along-the-line term K0 %.0f, G = min over directions %.0f, bound after the rounding slack %.0f, final errors %.0f\n", g_diagSum[m][0], g_diagSum[m][1], g_diagSum[m][2], g_diagSum[m][4], g_diagSum[m][3]);
         printf("  searched if the bound were the plain line residual (no rounding slack; NOT valid, potential only): %.1f %%; cost-weighted final / residual of the searched: %.2f\n", 100.0 * noslack[m] / tot[m], fr[m] / std::max(1.0, frN[m]));
         printf("  cost share by LB / table of the searched (0.0-0.1 ... 1.0+):"); for (int k = 0; k < 12; ++k) printf(" %.1f%%", 100.0 * lbHist[m][k] / now[m]); printf("\n");
         printf("  cost share by the mode's best final error (0, 1-3, 4-15, 16-63, 64-255, 256-1023, 1024-4095, 4096+):"); for (int k = 0; k < 8; ++k) printf(" %.1f%%", 100.0 * costByBest[m][k] / now[m]); printf("\n");
