@@ -118,7 +118,7 @@ static double kconstr1d(std::vector<double> t, int N)
     return best;
 }
 static double g_lb2Diag[4];
-static double g_diagSum[2][5];
+static double g_diagSum[2][6];
 static int subset_lower_bound2(const uint32_t* pix, uint32_t mask, int N)
 {
     double n = 0, m[3] = {0,0,0}; std::vector<std::array<double,3>> P;
@@ -144,12 +144,19 @@ static int subset_lower_bound2(const uint32_t* pix, uint32_t mask, int N)
         if (e > 0 && e < 1) { const double ee = std::min(1.0, e * (1.0 + 1e-9) + 1e-12); G = std::min(R1 + (1.0 - ee) * K0, tr - l2 / ee); G = std::max(G, R1); }
     }
     g_lb2Diag[0] = R1; g_lb2Diag[1] = K0; g_lb2Diag[2] = G;
+    // slack-free: the texels of one entry share ONE rounding vector, so their error is at least their scatter about their own centroid, whatever
+    // the entry is: error >= within-cluster scatter of SOME partition into N clusters >= sum over three orthogonal axes of the 1-D N-means optimum
+    double W3 = 0;
+    for (int ax = 0; ax < 3; ++ax) { std::vector<double> q; for (auto& v : P) q.push_back((v[0] - m[0]) * V[0][ax] + (v[1] - m[1]) * V[1][ax] + (v[2] - m[2]) * V[2][ax]); W3 += kmeans1d(q, N); }
+    g_lb2Diag[3] = W3;
     // and without any rounding slack: whatever the N palette entries are, the error is at least the optimum of N-means in space, which is at
     // least the optimum of N-means of the projections on any one direction (K0)
     const double d = sqrt(G) - 0.5 * sqrt(3.0 * n) - 1e-3;
     double lb = (d > 0) ? d * d * 0.99999 - 1.0 : 0.0;
     static const bool noFree = getenv("DXTEX_STATS_NO_FREE_K") != nullptr;
     if (!noFree) lb = std::max(lb, K0 * 0.99999 - 1.0);
+    static const bool useW3 = getenv("DXTEX_STATS_W3") != nullptr;
+    if (useW3) lb = std::max(lb, W3 * 0.99999 - 1.0);
     return lb > 0 ? int(lb) : 0;
 }
 struct CandStat { int lb, lb2, org, fin, np[2], orgS[2], finS[2], lb2S[2]; double cost, resid; };
@@ -171,7 +178,7 @@ template<int MODE> static CandStat cand(const HB& b, uint32_t shape)
         if (devForm) c.lb2S[r] = (MODE == 1) ? subset_lower_bound_line<8, false>(b.ldr, mask, 0u, 3) : (fixedK ? subset_lower_bound_line<4, true>(b.ldr, mask, 0u, 3) : subset_lower_bound_line<4, false>(b.ldr, mask, 0u, 3));
         else c.lb2S[r] = subset_lower_bound2(b.ldr, mask, (MODE == 1) ? 8 : 4);
         c.lb2 += c.lb2S[r];
-        if (!devForm) { g_diagSum[MODE == 1 ? 0 : 1][0] += g_lb2Diag[0]; g_diagSum[MODE == 1 ? 0 : 1][1] += g_lb2Diag[1]; g_diagSum[MODE == 1 ? 0 : 1][2] += g_lb2Diag[2]; g_diagSum[MODE == 1 ? 0 : 1][3] += res.optErr < res.orgErr ? res.optErr : res.orgErr; g_diagSum[MODE == 1 ? 0 : 1][4] += c.lb2S[r]; }
+        if (!devForm) { g_diagSum[MODE == 1 ? 0 : 1][0] += g_lb2Diag[0]; g_diagSum[MODE == 1 ? 0 : 1][1] += g_lb2Diag[1]; g_diagSum[MODE == 1 ? 0 : 1][2] += g_lb2Diag[2]; g_diagSum[MODE == 1 ? 0 : 1][3] += res.optErr < res.orgErr ? res.optErr : res.orgErr; g_diagSum[MODE == 1 ? 0 : 1][4] += c.lb2S[r]; g_diagSum[MODE == 1 ? 0 : 1][5] += g_lb2Diag[3]; }
     }
     c.fin = std::min(c.org, opt);
     return c;
@@ -273,7 +280,7 @@ int main(int argc, char** argv)
         printf("mode %d: %.0f cost units (texel-evaluations) unpruned; searched now %.1f %%; with the in-mode final table %.1f %%; two-phase (best 4 by org first) %.1f %%; oracle %.1f %%; mean final/LB of the searched %.2f\n",
                m ? 3 : 1, tot[m], 100.0 * now[m] / tot[m], 100.0 * inmode[m] / tot[m], 100.0 * top4[m] / tot[m], 100.0 * oracle[m] / tot[m], ratioSum[m] / std::max(1L, ratioN[m]));
         printf("  EXPERIMENT along-the-line bound: searched %.1f %% (bound above a subset's final error: %ld subsets, %ld candidates); mean bound / final: now %.3f, new %.3f\n", 100.0 * now2[m] / tot[m], viol[m], violC[m], lbSum[m] / finSum[m], lb2Sum[m] / finSum[m]);
-        printf("  sums over all subsets: line residual R1 %.0f, along-the-line term K0 %.0f, G = min over directions %.0f, bound after the rounding slack %.0f, final errors %.0f\n", g_diagSum[m][0], g_diagSum[m][1], g_diagSum[m][2], g_diagSum[m][4], g_diagSum[m][3]);
+        printf("  sums over all subsets: line residual R1 %.0f, along-the-line term K0 %.0f, G = min over directions %.0f, bound after the rounding slack %.0f, final errors %.0f; slack-free sum of per-axis N-means %.0f\n", g_diagSum[m][0], g_diagSum[m][1], g_diagSum[m][2], g_diagSum[m][4], g_diagSum[m][3], g_diagSum[m][5]);
         printf("  searched if the bound were the plain line residual (no rounding slack; NOT valid, potential only): %.1f %%; cost-weighted final / residual of the searched: %.2f\n", 100.0 * noslack[m] / tot[m], fr[m] / std::max(1.0, frN[m]));
         printf("  cost share by LB / table of the searched (0.0-0.1 ... 1.0+):"); for (int k = 0; k < 12; ++k) printf(" %.1f%%", 100.0 * lbHist[m][k] / now[m]); printf("\n");
         printf("  cost share by the mode's best final error (0, 1-3, 4-15, 16-63, 64-255, 256-1023, 1024-4095, 4096+):"); for (int k = 0; k < 8; ++k) printf(" %.1f%%", 100.0 * costByBest[m][k] / now[m]); printf("\n");
