@@ -32,6 +32,7 @@ namespace bc7
 #if defined(DXTEX_COUNT_EVALS)
 static long g_evalCount[8], g_evalTexels[8], g_macroCount[8], g_boundCount[8], g_pendCount[8], g_drainCount[8], g_pfTotal[8], g_pfPass[8], g_pfImprove[8], g_pfStepTotal[8][8], g_pfStepPass[8][8], g_tabWin[8], g_tabWinOut[8], g_tabWinOutPrev[8];
 static int g_statTable = 0x7FFFFFFF, g_statTablePrev = 0x7FFFFFFF, g_statOther = 0;
+static long g_rowCand[8], g_rowWin[8], g_rowTests[8][4], g_rowOut[8][4], g_rowDistN[8][6], g_rowDistOut[8][6], g_peelTests[8][4][3], g_peelOut[8][4][3];
 #endif
 // ---- per-mode constants (BC6HBC7.cpp:1106-1124) ---------------------------------------------------
 template<int MODE> struct ModeInfo;
@@ -85,6 +86,25 @@ DXTEX_HD int mul24(int a, int b)
     return __mul24(a, b);
 #else
     return a * b;
+#endif
+}
+// a * b + c with 24-bit factors (v_mad_i32_i24) and the middle of three (v_med3_i32: a clamp in one instruction)
+DXTEX_HD int mad24(int a, int b, int c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b) + c;
+#else
+    return a * b + c;
+#endif
+}
+DXTEX_HD int med3(int v, int lo, int hi)      // lo <= hi
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+#else
+    return v < lo ? lo : (v > hi ? hi : v);
 #endif
 }
 // One interpolated byte of LDRColorA::Interpolate (:384-416): (ua (64 - w) + ub w + 32) >> 6 = (64 ua + 32 + w (ub - ua)) >> 6.
@@ -923,8 +943,9 @@ struct ExhState
     uint32_t optA, optB;
     int optErr;
     int ch;                 // >= CH1: finished
-    int o, i, oEnd, iEnd, lo;
-    int o0;                 // first value of the outer variable in this window
+    int o, i, oEnd, iEnd, lo;   // lo: lowest value of the inner variable in the window as the reference opens it = origin of the candidate codes
+    int iA;                 // lowest value of the inner variable still to be visited (>= lo: exh_peel may have taken columns off)
+    int o0;                 // first value of the outer variable in the window as opened = origin of the candidate codes (s.o may start above it after exh_peel)
     int aleb;
     int omin, imin, best;
     int bestCode;           // queue code of (omin, imin) in the current window, -1 while the window has not improved on optErr
@@ -946,6 +967,7 @@ DXTEX_HD ExhState exh_window(const ExhState& in, int ch)
     s.o0 = s.o;
     s.oEnd = s.aleb ? ahigh + 1 : bhigh;
     s.lo = s.aleb ? blow : alow;
+    s.iA = s.lo;
     s.iEnd = s.aleb ? bhigh : ahigh + 1;
     s.i = s.o > s.lo ? s.o : s.lo;
     s.omin = 0; s.imin = 0; s.best = in.optErr; s.bestCode = -1;
@@ -955,7 +977,7 @@ DXTEX_HD ExhState exh_window(const ExhState& in, int ch)
 // Skip empty inner ranges; returns false when the window is used up.
 DXTEX_HD bool exh_settle(ExhState& s)
 {
-    while (s.o < s.oEnd && s.i >= s.iEnd) { ++s.o; s.i = s.o > s.lo ? s.o : s.lo; }
+    while (s.o < s.oEnd && s.i >= s.iEnd) { ++s.o; s.i = s.o > s.iA ? s.o : s.iA; }
     return s.o < s.oEnd;
 }
 
@@ -967,7 +989,7 @@ DXTEX_HD void exh_advance(ExhState& s)
     ++s.i;
     const bool wrap = s.i >= s.iEnd;
     s.o += wrap ? 1 : 0;
-    const int first = s.o > s.lo ? s.o : s.lo;
+    const int first = s.o > s.iA ? s.o : s.iA;
     s.i = wrap ? first : s.i;
 }
 
@@ -1004,7 +1026,7 @@ DXTEX_HD bool exh_begin(ExhState& s, VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, ui
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     s.optA = optA; s.optB = optB; s.optErr = optErr;
-    s.ch = 0; s.o = s.i = s.oEnd = s.iEnd = s.lo = 0; s.o0 = 0; s.aleb = 0; s.omin = s.imin = 0; s.best = optErr; s.bestCode = -1;
+    s.ch = 0; s.o = s.i = s.oEnd = s.iEnd = s.lo = 0; s.iA = 0; s.o0 = 0; s.aleb = 0; s.omin = s.imin = 0; s.best = optErr; s.bestCode = -1;
     s = exh_window<MODE, IM, CHSET>(s, C::CH0);
     if (s.ch < C::CH1) varpal_init<MODE, IM, CHSET>(vp, s.optA, s.optB, s.ch);
     return exh_next<MODE, IM, CHSET>(s, vp);
@@ -1048,7 +1070,7 @@ DXTEX_HD int exh_remaining(const ExhState& s)
     int n = 0;
     for (int o = s.o; o < s.oEnd; ++o)
     {
-        const int from = (o == s.o) ? s.i : (o > s.lo ? o : s.lo);
+        const int from = (o == s.o) ? s.i : (o > s.iA ? o : s.iA);
         n += (s.iEnd > from) ? (s.iEnd - from) : 0;
     }
     return n;
@@ -1081,10 +1103,19 @@ DXTEX_HD int exh_exact(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& 
 // One evaluation of about four candidate bounds. (Measured on the benchmark image, unpruned: 78 % of mode 4's windows, 55 % of mode
 // 5's, 20 % / 14 % / 32 % of the windows of modes 1 / 3 / 6 are of that kind - e.g. every window on a channel that is constant.)
 template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD int exh_range_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, const ExhState& s, int base, int oLo, int oHi, int iLo, int iHi);
+
+template<int MODE, int IM, int CHSET, class RG>
 DXTEX_HD int exh_window_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, const ExhState& s, int base)
 {
+    return exh_range_bound<MODE, IM, CHSET>(rg, vp, s, base, s.o, s.oEnd - 1, s.i, s.iEnd - 1);      // at window open: s.o == s.o0, s.i == the first row's first value
+}
+
+// The same bound over any rectangle of (outer, inner) endpoint values of the window `s` describes.
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD int exh_range_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, const ExhState& s, int base, int oLo, int oHi, int iLo, int iHi)
+{
     typedef LoopCfg<MODE, IM, CHSET> C;
-    const int oLo = s.o, oHi = s.oEnd - 1, iLo = s.i, iHi = s.iEnd - 1;      // at window open: s.o == s.o0, s.i == the first row's first value
     const uint32_t uoL = unq1<C::PREC>(uint32_t(oLo)), uoH = unq1<C::PREC>(uint32_t(oHi)), uiL = unq1<C::PREC>(uint32_t(iLo)), uiH = unq1<C::PREC>(uint32_t(iHi));
     const uint32_t aL = s.aleb ? uoL : uiL, bL = s.aleb ? uiL : uoL, aH = s.aleb ? uoH : uiH, bH = s.aleb ? uiH : uoH;
     int lo[C::N], hi[C::N];
@@ -1115,7 +1146,13 @@ DXTEX_HD int exh_window_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET
         });
         return base - sumA;
     }
+    // vp.palO has the searched channel blanked: h = p.q' + floor(-|q'|^2 / 2) is the other channels' share of the score, halved and rounded
+    // down as in eval_var_bound (2 h <= 2 p.q' - |q'|^2 <= 2 h + 1: ONE dot product); the searched channel adds 2 pc v - v^2 = pc^2 - (pc - v)^2
+    // <= pc^2 - d^2 with d the distance of pc to the entry's interval (v_med3). So score <= 2 h - d^2 + pc^2 + 1 per entry.
     const int sh = 8 * s.ch;
+    uint32_t accO[C::N];
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) accO[i] = uint32_t(int(vp.nq2O[i]) >> 1);
     int sum = 0;
     for_texels(rg, [&](int k)
     {
@@ -1126,21 +1163,57 @@ DXTEX_HD int exh_window_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET
 #pragma unroll
         for (int i = 0; i < C::N; ++i)
         {
-            // vp.palO has the searched channel blanked, so the score below is the other channels' 2 p.q - |q|^2
-            const int c = pc < lo[i] ? lo[i] : (pc > hi[i] ? hi[i] : pc);
-            const int dc = pc - c;
-            const int t = score(p, vp.palO[i], vp.nq2O[i]) - mul24(dc, dc);
+            const int h = int(udot4acc(p, vp.palO[i], accO[i]));
+            const int c = med3(pc, lo[i], hi[i]);
+            const int t = mad24(pc - c, c - pc, h + h);
             m = t > m ? t : m;
         }
         sum += m + mul24(pc, pc);
     });
-    return base - sum;
+    return base - sum - rg.count();
 }
 
-template<int MODE, int IM, int CHSET, class RG>
-DXTEX_HD bool exh_window_excluded(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, const ExhState& s, int base)
+// Strips of kPeelRows rows / columns are taken off the four sides of a freshly opened window's rectangle while their interval bound says
+// that nothing in them can beat the error the window starts from (the argument of exh_window_excluded, applied to a part of the window:
+// Exhaustive's strict '<' (:3006) accepts none of the strip's candidates whatever the rest of the window finds, because the best error
+// only goes down). On the benchmark image the four tests remove 30 % / 22 % / 35 % / 26 % of the candidates of the windows of modes
+// 1 / 3 / 4 / 5 that survive the whole-window test, for the price of about seven candidate bounds (tools/bc7_debug.cpp, -DDXTEX_ROW_STATS);
+// single rows anywhere in the window, or wider strips, pay less. The codes of the remaining candidates keep their origin (s.o0, s.lo).
+enum : int { kPeelRows = 2 };
+// The strip on `side` of what is left of the window (0 / 1: the lowest / highest rows = outer values, 2 / 3: the lowest / highest columns =
+// inner values): its rectangle, and whether there is one to test (the side must keep at least one row / column).
+DXTEX_HD bool exh_peel_rect(const ExhState& s, int side, int& ro0, int& ro1, int& ri0, int& ri1)
 {
-    return exh_window_bound<MODE, IM, CHSET>(rg, vp, s, base) >= s.optErr;
+    const int oA = s.o, oB = s.oEnd - 1, iA = s.iA, iB = s.iEnd - 1;      // candidates have inner >= outer
+    const bool rows = side < 2, high = (side & 1) != 0;
+    const int extent = rows ? (oB - oA + 1) : (iB - iA + 1);
+    ro0 = (rows && high) ? oB - kPeelRows + 1 : oA;
+    ro1 = (rows && !high) ? oA + kPeelRows - 1 : oB;
+    ri0 = (!rows && high) ? iB - kPeelRows + 1 : iA;
+    ri1 = (!rows && !high) ? iA + kPeelRows - 1 : iB;
+    ro1 = ro1 < ri1 ? ro1 : ri1;             // outer <= inner
+    ri0 = ri0 > ro0 ? ri0 : ro0;             // inner >= outer
+    return extent > kPeelRows && ro0 <= ro1 && ri0 <= ri1;
+}
+DXTEX_HD void exh_peel_apply(ExhState& s, int side, bool take = true)
+{
+    // (selects, not branches on `side`: indexed through a per-lane side the four bounds would be moved to scratch memory)
+    const int k = take ? int(kPeelRows) : 0;
+    s.o += (side == 0) ? k : 0;
+    s.oEnd -= (side == 1) ? k : 0;
+    s.iA += (side == 2) ? k : 0;
+    s.iEnd -= (side == 3) ? k : 0;
+    s.i = s.o > s.iA ? s.o : s.iA;
+}
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD void exh_peel(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, ExhState& s, int base)
+{
+#pragma unroll 1
+    for (int side = 0; side < 4; ++side)
+    {
+        int ro0, ro1, ri0, ri1;
+        if (exh_peel_rect(s, side, ro0, ro1, ri0, ri1) && exh_range_bound<MODE, IM, CHSET>(rg, vp, s, base, ro0, ro1, ri0, ri1) >= s.optErr) exh_peel_apply(s, side);
+    }
 }
 
 // optimize_one() through the lockstep pieces, one lane's worth (host-side equivalence check, and the
@@ -1197,6 +1270,64 @@ DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& o
         }
     };
     skip_excluded();
+    if (has) exh_peel<MODE, IM, CHSET>(rg, vp, s, base);
+#if defined(DXTEX_ROW_STATS)
+    // development statistics: candidates of the surviving windows that sit in strips of H rows (outer endpoint values) whose interval
+    // bound is not below the error the window starts from
+    auto row_stats = [&]()
+    {
+        if (!has) return;
+        g_rowCand[MODE] += exh_remaining(s); ++g_rowWin[MODE];
+        for (int H = 1; H <= 3; ++H)
+            for (int o = s.o; o < s.oEnd; o += H)
+            {
+                const int oHi = (o + H - 1 < s.oEnd - 1) ? o + H - 1 : s.oEnd - 1;
+                int n = 0;
+                for (int oo = o; oo <= oHi; ++oo) { const int from = oo > s.lo ? oo : s.lo; n += (s.iEnd > from) ? s.iEnd - from : 0; }
+                if (!n) continue;
+                const int from = o > s.lo ? o : s.lo;
+                ++g_rowTests[MODE][H];
+                const bool out = exh_range_bound<MODE, IM, CHSET>(rg, vp, s, base, o, oHi, from, s.iEnd - 1) >= s.optErr;
+                if (out) g_rowOut[MODE][H] += n;
+                if (H == 2)
+                {
+                    // by distance of the strip from the row of the starting endpoints (the outer variable's current value)
+                    const int cur = int(byte_of(s.aleb ? s.optA : s.optB, s.ch));
+                    int dist = (cur < o) ? o - cur : (cur > oHi ? cur - oHi : 0);
+                    dist = dist > 5 ? 5 : dist;
+                    g_rowDistN[MODE][dist] += n; if (out) g_rowDistOut[MODE][dist] += n;
+                }
+            }
+    };
+    row_stats();
+    // peel statistics: strips of H rows / columns taken off the four sides of the window's rectangle while their interval bound is not
+    // below the starting error, L layers deep
+    auto peel_stats = [&]()
+    {
+        if (!has) return;
+        for (int H = 1; H <= 3; ++H)
+            for (int L = 1; L <= 2; ++L)
+            {
+                int oA = s.o, oB = s.oEnd - 1, iA = s.lo, iB = s.iEnd - 1;     // rectangle of (outer, inner), inclusive; cells need inner >= outer
+                auto count = [&](int a, int b, int c, int d) { int n = 0; for (int o = a; o <= b; ++o) { const int f = o > c ? o : c; n += (d >= f) ? d - f + 1 : 0; } return n; };
+                const int before = count(oA, oB, iA, iB);
+                int tests = 0;
+                for (int l = 0; l < L; ++l)
+                {
+                    // low rows, high rows, low columns, high columns
+                    if (oB - oA + 1 > H) { ++tests; const int f = oA > iA ? oA : iA; if (count(oA, oA + H - 1, iA, iB) == 0 || exh_range_bound<MODE, IM, CHSET>(rg, vp, s, base, oA, oA + H - 1, f, iB) >= s.optErr) oA += H; }
+                    if (oB - oA + 1 > H) { ++tests; const int f = (oB - H + 1) > iA ? (oB - H + 1) : iA; if (count(oB - H + 1, oB, iA, iB) == 0 || exh_range_bound<MODE, IM, CHSET>(rg, vp, s, base, oB - H + 1, oB, f, iB) >= s.optErr) oB -= H; }
+                    if (iB - iA + 1 > H) { ++tests; const int hi = (iA + H - 1) < oB ? oB : oB; const int oh = oB < iA + H - 1 ? oB : iA + H - 1; (void)hi;
+                                           if (count(oA, oB, iA, iA + H - 1) == 0 || exh_range_bound<MODE, IM, CHSET>(rg, vp, s, base, oA, oh, iA > oA ? iA : oA, iA + H - 1) >= s.optErr) iA += H; }
+                    if (iB - iA + 1 > H) { ++tests; const int oh = oB < iB ? oB : iB;
+                                           if (count(oA, oB, iB - H + 1, iB) == 0 || exh_range_bound<MODE, IM, CHSET>(rg, vp, s, base, oA, oh, (iB - H + 1) > oA ? (iB - H + 1) : oA, iB) >= s.optErr) iB -= H; }
+                }
+                const int after = count(oA, oB, iA, iB);
+                g_peelTests[MODE][H][L] += tests; g_peelOut[MODE][H][L] += before - after;
+            }
+    };
+    peel_stats();
+#endif
     uint32_t bestKey = has ? exh_start_key(s) : 0u;
     int rem = has ? exh_remaining(s) : 0;
     while (has)
@@ -1229,6 +1360,10 @@ DXTEX_HD void lockstep_exhaustive_loop(const RG& rg, uint32_t& optA, uint32_t& o
             exh_apply_key(s, bestKey);
             has = exh_next<MODE, IM, CHSET>(s, vp);          // the window is used up: commit, open the next one
             skip_excluded();
+            if (has) exh_peel<MODE, IM, CHSET>(rg, vp, s, base);
+#if defined(DXTEX_ROW_STATS)
+            row_stats(); peel_stats();
+#endif
             if (has) { bestKey = exh_start_key(s); rem = exh_remaining(s); }
         }
     }

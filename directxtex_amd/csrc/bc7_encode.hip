@@ -490,6 +490,27 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask)
     return int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
 }
 
+#if defined(DXTEX_BC7_WAVETIMES)
+// Development instrumentation (-DDXTEX_BC7_WAVETIMES, never in the product): per wavefront of every lane-per-task search kernel outside the
+// early phases - start, the moment it first saw the queue drained, end (s_memrealtime, 100 MHz), rounds, busy lanes summed over the rounds,
+// tasks taken - and a histogram of rounds per finished task; summarised on stderr after the submission (bc7_wavetimes_report).
+enum : int { WT_KINDS = 3, WT_KEYS = WT_KINDS * 8 * 2 * 3, WT_FIELDS = 6 };
+__device__ unsigned long long g_wt[WT_KEYS][8192][WT_FIELDS];
+__device__ unsigned int g_wtHist[WT_KEYS][256];
+#define WT_BEGIN(KIND) const int wtKey = (((KIND) * 8 + MODE) * 2 + IM) * 3 + CHSET; const bool wtOn = a.phase != PHASE_EARLY; \
+    const unsigned long long wt0 = wall_clock64(); unsigned long long wtDr = 0, wtRounds = 0, wtLanes = 0, wtTasks = 0; int wtMine = 0
+#define WT_TAKE(IDX) do { wtTasks += (unsigned long long)__popcll(__ballot((IDX) != 0xFFFFFFFFu)); if (!wtDr && q.drained) wtDr = wall_clock64(); } while (0)
+#define WT_ROUND(BUSYL) do { ++wtRounds; wtLanes += (unsigned long long)__popcll(__ballot(BUSYL)); if (BUSYL) ++wtMine; } while (0)
+#define WT_DONE() do { wtMine = 0; } while (0)
+#define WT_END() do { if (wtOn && lane == 0 && wtRounds) { unsigned long long* w_ = g_wt[wtKey][blockIdx.x & 8191]; w_[0] = wt0; w_[1] = wtDr ? wtDr : wall_clock64(); \
+    w_[2] = wall_clock64(); w_[3] = wtRounds; w_[4] = wtLanes; w_[5] = wtTasks; } } while (0)
+#else
+#define WT_BEGIN(KIND) do { } while (0)
+#define WT_TAKE(IDX) do { } while (0)
+#define WT_ROUND(BUSYL) do { } while (0)
+#define WT_DONE() do { } while (0)
+#define WT_END() do { } while (0)
+#endif
 // The PERTURB phase of OptimizeOne (:3060-3105) for the channels of CHSET, over every live task of the mode.
 template<int MODE, int IM, int CHSET>
 __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
@@ -502,6 +523,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
     if (TaskMap<MODE, IM>::NS == 1 && live <= a.perturbWaveMax) return;      // short list of whole-block tasks: bc7_perturb_wave_kernel's turn
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
+    WT_BEGIN(0);
 
     PerturbState st = perturb_begin<MODE, IM, CHSET>(0, 0, 0);
     SlotRegion rg; rg.base = slotCol; rg.np = 0; rg.p2sum = 0;
@@ -514,6 +536,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
         if (idle && !(q.drained && q.lo >= q.hi))
         {
             const uint32_t idx = queue_take(q, head, live, idle, lane);
+            WT_TAKE(idx);
             if (idx != 0xFFFFFFFFu)
             {
                 const uint2 task = a.order[idx];
@@ -531,6 +554,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
             if (q.drained && q.lo >= q.hi) break;
             continue;
         }
+        WT_ROUND(myTask != 0xFFFFFFFFu);
         if (myTask != 0xFFFFFFFFu)
         {
             int e; uint32_t v;
@@ -541,9 +565,11 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
                 TaskRec* r = a.recs + myTask;
                 r->A = st.optA; r->B = st.optB; r->err = st.optErr;
                 myTask = 0xFFFFFFFFu;
+                WT_DONE();
             }
         }
     }
+    WT_END();
 }
 
 // PerturbOne (:2926-2966) for SHORT lists of whole-block tasks, half a wavefront per task: lane (cand, k) of a half scores texel k
@@ -642,6 +668,7 @@ __global__ void __launch_bounds__(64, (MODE == 1) ? 5 : 1) bc7_perturb_filter_ke
     if (TaskMap<MODE, IM>::NS == 1 && live <= a.perturbWaveMax) return;      // short list of whole-block tasks: bc7_perturb_wave_kernel's turn
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
+    WT_BEGIN(1);
 
     PerturbState st = perturb_begin<MODE, IM, CHSET>(0, 0, 0);
     SlotRegion rg; rg.base = slotCol; rg.np = 0; rg.p2sum = 0;
@@ -654,6 +681,7 @@ __global__ void __launch_bounds__(64, (MODE == 1) ? 5 : 1) bc7_perturb_filter_ke
         if (idle && !(q.drained && q.lo >= q.hi))
         {
             const uint32_t idx = queue_take(q, head, live, idle, lane);
+            WT_TAKE(idx);
             if (idx != 0xFFFFFFFFu)
             {
                 const uint2 task = a.order[idx];
@@ -670,6 +698,7 @@ __global__ void __launch_bounds__(64, (MODE == 1) ? 5 : 1) bc7_perturb_filter_ke
             if (q.drained && q.lo >= q.hi) break;
             continue;
         }
+        WT_ROUND(busyL);
         wave_lds_sync();             // the texel columns of tasks just taken are visible to every lane
         // widest subset among the busy lanes (the list is sorted by size: nearly always everybody's)
         int npMax = busyL ? rg.np : 0;
@@ -775,9 +804,11 @@ __global__ void __launch_bounds__(64, (MODE == 1) ? 5 : 1) bc7_perturb_filter_ke
                 TaskRec* r = a.recs + myTask;
                 r->A = st.optA; r->B = st.optB; r->err = st.optErr;
                 myTask = 0xFFFFFFFFu;
+                WT_DONE();
             }
         }
     }
+    WT_END();
 }
 
 // Mode 6's short task lists go to bc7_exhaustive_wave_kernel (below): above this many live tasks the lane-per-task kernel is the
@@ -835,11 +866,11 @@ __device__ __forceinline__ ExhCtx<LoopCfg<MODE, IM, CHSET>::N> exh_fetch_ctx(con
 #if !defined(DXTEX_EXH45_WGS)
 #define DXTEX_EXH45_WGS 3
 #endif
-#if !defined(DXTEX_WIN_TRIES)
-#define DXTEX_WIN_TRIES 3
+#if !defined(DXTEX_RANGE_TESTS)
+#define DXTEX_RANGE_TESTS 5
 #endif
 template<int MODE, int IM, int CHSET>
-__global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS : 1) bc7_exhaustive_kernel(Bc7Args a, int loop, int tailBelow)
+__global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS : 1) bc7_exhaustive_kernel(Bc7Args a, int loop, int tailBelow, int rangeTests)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     __shared__ uint32_t sSlot[16 * 64];             // texel columns, one per lane
@@ -855,9 +886,10 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
     if (TaskMap<MODE, IM>::NS == 1 && live <= a.exhWaveMax) return;      // short list of whole-block tasks: bc7_exhaustive_wave_kernel has done it
     uint32_t* head = a.counters + kQueueBase + loop;
     uint32_t* slotCol = &sSlot[lane];
+    WT_BEGIN(2);
 
     ExhState st; st.ch = C::CH1; st.optA = st.optB = 0; st.optErr = 0;
-    st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.o0 = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = 0; st.bestCode = -1;
+    st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.iA = 0; st.o0 = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = 0; st.bestCode = -1;
     VarPal<C::N> vp;
 #pragma unroll
     for (int i = 0; i < C::N; ++i) { vp.palO[i] = 0; vp.nq2O[i] = 0; }
@@ -900,6 +932,7 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
         if (idle != 0ull && !(q.drained && q.lo >= q.hi))
         {
             const uint32_t idx = queue_take(q, head, live, idle, lane);
+            WT_TAKE(idx);
             DXTEX_STAT(5, __ballot(idx != 0xFFFFFFFFu));
             if (idx != 0xFFFFFFFFu)
             {
@@ -913,24 +946,48 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
             }
         }
         // Many windows cannot hold an improvement - every window on a channel that is constant over the block, as the swapped-in alpha
-        // of an opaque block is, and many others - and one interval bound says so (exh_window_excluded: 78 % / 55 % / 32 % / 20 % / 14 %
-        // of the windows of modes 4 / 5 / 6 / 1 / 3 on the benchmark image, unpruned). Such a window is closed at once and the lane goes
-        // on to its next one, up to DXTEX_WIN_TRIES times (3: 143.9 ms per 4096^2 image; 1 / 2 / 4 tries: 148.6 / 149.0 / 144.8);
-        // lanes that end up without candidates help the others through the pooled phase below.
+        // of an opaque block is, and many others - and one interval bound says so (exh_range_bound over the whole window: 78 % / 55 % / 32 % /
+        // 20 % / 14 % of the windows of modes 4 / 5 / 6 / 1 / 3 on the benchmark image, unpruned). Such a window is closed at once and the lane
+        // goes on to its next one. A window that stays loses the strips along its four sides that cannot hold an improvement either (exh_peel,
+        // bc7_core.h: 30 % / 22 % of the candidates of modes 1 / 3). Both are the same test on a different rectangle, so they share ONE loop: per
+        // trip every lane tests the rectangle its own stage calls for - stage 0: the whole window, stages 1 ... 4: a side - and a lane whose
+        // window was closed starts over on the next one. `rangeTests` trips (DXTEX_RANGE_TESTS = 5: a lane that never closes a window tests all four sides);
+        // whatever has not been tested by then is simply visited. Lanes that end up without candidates help the others through the pooled phase.
         {
+            int stage = 0;
+            const int trips = rangeTests & 0xFF, lastStage = (rangeTests >> 8) ? 1 : 5;       // (development knob: no peeling = only stage 0)
 #pragma unroll 1
-            for (int tries = 0; tries < DXTEX_WIN_TRIES; ++tries)
+            for (int trip = 0; trip < trips; ++trip)
             {
-                const bool excluded = (myTask != 0xFFFFFFFFu) && exh_window_excluded<MODE, IM, CHSET>(rg, vp, st, base);
-                if (__ballot(excluded) == 0ull) break;
-                if (excluded)
+                const bool testing = (myTask != 0xFFFFFFFFu) && stage < lastStage;
+                if (__ballot(testing) == 0ull) break;
+                int ro0 = st.o, ro1 = st.oEnd - 1, ri0 = st.i, ri1 = st.iEnd - 1;      // at window open: st.i == the first row's first value
+                bool valid = true;
+                if (stage > 0) valid = exh_peel_rect(st, stage - 1, ro0, ro1, ri0, ri1);
+                if (!valid) { ro0 = ro1 = st.o; ri0 = ri1 = st.iEnd - 1; }           // (the call is wave-uniform: a harmless rectangle)
+                const int b = exh_range_bound<MODE, IM, CHSET>(rg, vp, st, base, ro0, ro1, ri0, ri1);
+                if (testing)
                 {
-                    st.o = st.oEnd;              // past the last row: exh_next commits "no change" and opens the next window
-                    if (!exh_next<MODE, IM, CHSET>(st, vp))
+                    const bool out = valid && b >= st.optErr;
+                    if (stage == 0)
                     {
-                        TaskRec* r = a.recs + myTask;
-                        r->A = st.optA; r->B = st.optB; r->err = st.optErr;
-                        myTask = 0xFFFFFFFFu;
+                        if (out)
+                        {
+                            st.o = st.oEnd;              // past the last row: exh_next commits "no change" and opens the next window
+                            if (!exh_next<MODE, IM, CHSET>(st, vp))
+                            {
+                                TaskRec* r = a.recs + myTask;
+                                r->A = st.optA; r->B = st.optB; r->err = st.optErr;
+                                myTask = 0xFFFFFFFFu;
+                                WT_DONE();
+                            }
+                        }
+                        else stage = 1;
+                    }
+                    else
+                    {
+                        exh_peel_apply(st, stage - 1, out);
+                        ++stage;
                     }
                 }
             }
@@ -943,6 +1000,7 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
             if (q.drained && q.lo >= q.hi) break;
             continue;
         }
+        WT_ROUND(busyL);
         // what a helper needs of this lane's window: channel, loop orientation, subset size, window origin
         const uint32_t geom = uint32_t(st.ch & 3) | (uint32_t(st.aleb & 1) << 2) | (uint32_t(rg.np) << 3) | (uint32_t(st.o0 & 0xFF) << 8) | (uint32_t(st.lo & 0xFF) << 16);
         uint32_t bestKey = busyL ? exh_start_key(st) : 0u;
@@ -1022,9 +1080,11 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
                 TaskRec* r = a.recs + myTask;
                 r->A = st.optA; r->B = st.optB; r->err = st.optErr;
                 myTask = 0xFFFFFFFFu;
+                WT_DONE();
             }
         }
     }
+    WT_END();
 }
 
 // Exhaustive for SHORT task lists, one task per wavefront: the <= 11 x 11 candidates of a channel's window are evaluated by the
@@ -1054,7 +1114,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_wave_kernel(Bc7Args a)
         const int base = loop_base<MODE, IM, CHSET>(rg, rec.A, rec.B, &other);
         if (loop_is_settled<CHSET>(rec.err, other)) continue;      // scalar slot already exact (wave-uniform: one task per wavefront)
         ExhState st; st.optA = rec.A; st.optB = rec.B; st.optErr = rec.err;
-        st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.o0 = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = rec.err; st.bestCode = -1; st.ch = C::CH0;
+        st.o = st.i = st.oEnd = st.iEnd = st.lo = 0; st.iA = 0; st.o0 = 0; st.aleb = 0; st.omin = st.imin = 0; st.best = rec.err; st.bestCode = -1; st.ch = C::CH0;
         VarPal<C::N> vp;
 #pragma unroll 1
         for (int ch = C::CH0; ch < C::CH1; ++ch)
@@ -1350,6 +1410,8 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
     const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
     static const int tailBelow = dev_env("DXTEX_BC7_TAIL_BELOW") ? atoi(dev_env("DXTEX_BC7_TAIL_BELOW")) : 48;
     static const bool perturbPlain = dev_env("DXTEX_BC7_PERTURB_PLAIN") != nullptr;      // A/B: PerturbOne without the bound filter
+    // Exhaustive's interval tests per round (see the kernel); DXTEX_BC7_NO_PEEL = whole-window tests only (three of them, as before round 5)
+    static const int rangeTests = dev_env("DXTEX_BC7_NO_PEEL") ? (3 | 0x100) : (dev_env("DXTEX_BC7_RANGE_TESTS") ? atoi(dev_env("DXTEX_BC7_RANGE_TESTS")) & 0xFF : DXTEX_RANGE_TESTS);
     if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
         // the filter pays where the exact evaluation is dearest - eight palette entries on subsets of ~8 texels (mode 1: 24.5 -> 21.7 ms
@@ -1365,7 +1427,7 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
         if constexpr (kWhole) { if (maybeShortP) hipLaunchKernelGGL((bc7_perturb_wave_kernel<MODE, IM, CH_ALL>), dim3(wavesP), dim3(64), 0, stream, a); }
         if (marks) marks->mark(names[4]);
         if constexpr (kWhole) { if (maybeShortE) hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_ALL>), dim3(wavesE), dim3(64), 0, stream, a); }
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1, tailBelow);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALL>), dim3(waves), dim3(64), 0, stream, a, 1, tailBelow, rangeTests);
     }
     else
     {
@@ -1376,10 +1438,10 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
         if (maybeShortP) hipLaunchKernelGGL((bc7_perturb_wave_kernel<MODE, IM, CH_ALPHA>), dim3(wavesP), dim3(64), 0, stream, a);
         if (marks) marks->mark(names[4]);
         if (maybeShortE) hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_COLOR>), dim3(wavesE), dim3(64), 0, stream, a);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2, tailBelow);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 2, tailBelow, rangeTests);
         if (marks) marks->mark(names[5]);
         if (maybeShortE) hipLaunchKernelGGL((bc7_exhaustive_wave_kernel<MODE, IM, CH_ALPHA>), dim3(wavesE), dim3(64), 0, stream, a);
-        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3, tailBelow);
+        hipLaunchKernelGGL((bc7_exhaustive_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 3, tailBelow, rangeTests);
     }
     if (marks) marks->mark(names[6]);
     hipLaunchKernelGGL((bc7_post_kernel<MODE, IM>), dim3(gridPP), dim3(256), 0, stream, a);
@@ -1398,6 +1460,71 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
 #endif
 }
 } // namespace
+
+#if defined(DXTEX_BC7_WAVETIMES)
+namespace
+{
+void bc7_wavetimes_report()
+{
+    (void)hipDeviceSynchronize();
+    static int call = 0;
+    static const int wanted = dev_env("DXTEX_BC7_WT_CALL") ? atoi(dev_env("DXTEX_BC7_WT_CALL")) : 2;      // which submission of the process is reported
+    const bool print = call++ == wanted;
+    static std::vector<unsigned long long> h(size_t(WT_KEYS) * 8192 * WT_FIELDS);
+    static std::vector<unsigned int> hist(size_t(WT_KEYS) * 256);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_wt), h.size() * 8);
+    (void)hipMemcpyFromSymbol(hist.data(), HIP_SYMBOL(g_wtHist), hist.size() * 4);
+    unsigned long long tAll = ~0ull;
+    for (size_t i = 0; i < size_t(WT_KEYS) * 8192; ++i) if (h[i * WT_FIELDS + 2]) tAll = std::min(tAll, h[i * WT_FIELDS]);
+    static const char* const kinds[3] = { "perturb", "perturb_filter", "exhaustive" };
+    for (int key = 0; key < WT_KEYS; ++key)
+    {
+        const unsigned long long* w = h.data() + size_t(key) * 8192 * WT_FIELDS;
+        std::vector<unsigned long long> st, dr, en; unsigned long long rounds = 0, lanes = 0, life = 0, maxR = 0, tasks = 0, maxT = 0;
+        for (int i = 0; i < 8192; ++i)
+            if (w[i * WT_FIELDS + 2])
+            {
+                st.push_back(w[i * WT_FIELDS]); dr.push_back(w[i * WT_FIELDS + 1]); en.push_back(w[i * WT_FIELDS + 2]);
+                rounds += w[i * WT_FIELDS + 3]; lanes += w[i * WT_FIELDS + 4]; tasks += w[i * WT_FIELDS + 5];
+                life += w[i * WT_FIELDS + 2] - w[i * WT_FIELDS]; maxR = std::max(maxR, w[i * WT_FIELDS + 3]); maxT = std::max(maxT, w[i * WT_FIELDS + 5]);
+            }
+        if (st.empty() || !print) continue;
+        const unsigned long long t0 = *std::min_element(st.begin(), st.end()), t1 = *std::max_element(en.begin(), en.end());
+        std::sort(st.begin(), st.end()); std::sort(dr.begin(), dr.end()); std::sort(en.begin(), en.end());
+        const double dur = double(t1 - t0); const size_t n = st.size();
+        auto pct = [&](const std::vector<unsigned long long>& v, double p) { return 100.0 * double(v[std::min(n - 1, size_t(p * n))] - t0) / dur; };
+        const unsigned int* hh = hist.data() + size_t(key) * 256;
+        unsigned long long nt = 0, rt = 0; for (int r = 0; r < 256; ++r) { nt += hh[r]; rt += (unsigned long long)hh[r] * r; }
+        auto hp = [&](double p) { unsigned long long c = 0; for (int r = 0; r < 256; ++r) { c += hh[r]; if (double(c) >= p * double(nt)) return r; } return 255; };
+        unsigned long long rLong = 0; for (int r = 2 * hp(0.9) + 1; r < 256; ++r) if (r >= 0) rLong += (unsigned long long)hh[r] * r;
+        const int chset = key % 3, im = (key / 3) % 2, mode = (key / 6) % 8, kind = key / 48;
+        std::fprintf(stderr, "wt %s<%d,%d,%d>: at %.2f ms, span %.3f ms, %zu wavefronts worked; starts p50 %.0f p90 %.0f; saw the queue drained p10 %.0f p50 %.0f p90 %.0f; ends p10 %.0f p50 %.0f p90 %.0f p99 %.0f (%% of span); "
+                     "mean lifetime %.0f %%; rounds / wavefront mean %.1f max %llu, busy lanes / round %.1f; tasks / wavefront mean %.0f max %llu; "
+                     "finished tasks %llu, rounds / task mean %.2f p50 %d p90 %d p99 %d p99.9 %d, share of task-rounds in tasks above 2 x p90: %.1f %%\n",
+                     kinds[kind], mode, im, chset, double(t0 - tAll) / 1e5, dur / 1e5, n, pct(st, 0.5), pct(st, 0.9), pct(dr, 0.1), pct(dr, 0.5), pct(dr, 0.9),
+                     pct(en, 0.1), pct(en, 0.5), pct(en, 0.9), pct(en, 0.99), 100.0 * double(life) / (dur * n), double(rounds) / n, maxR, rounds ? double(lanes) / rounds : 0.0,
+                     double(tasks) / n, maxT, nt, nt ? double(rt) / nt : 0.0, hp(0.5), hp(0.9), hp(0.99), hp(0.999), rt ? 100.0 * double(rLong) / rt : 0.0);
+        std::vector<int> idx; for (int i = 0; i < 8192; ++i) if (w[i * WT_FIELDS + 2]) idx.push_back(i);
+        std::sort(idx.begin(), idx.end(), [&](int x, int y) { return w[x * WT_FIELDS + 2] > w[y * WT_FIELDS + 2]; });
+        for (size_t k = 0; k < std::min<size_t>(4, idx.size()); ++k)
+        {
+            const unsigned long long* e = w + idx[k] * WT_FIELDS;
+            std::fprintf(stderr, "    late wavefront %d: start %.0f drained %.0f end %.0f %% of span, rounds %llu, busy lanes / round %.1f, tasks %llu\n", idx[k],
+                         100.0 * double(e[0] - t0) / dur, 100.0 * double(e[1] - t0) / dur, 100.0 * double(e[2] - t0) / dur, e[3], e[3] ? double(e[4]) / e[3] : 0.0, e[5]);
+        }
+        {
+            // median wavefront by end time, for comparison
+            const unsigned long long* e = w + idx[idx.size() / 2] * WT_FIELDS;
+            std::fprintf(stderr, "    median wavefront %d: start %.0f drained %.0f end %.0f %% of span, rounds %llu, busy lanes / round %.1f, tasks %llu\n", idx[idx.size() / 2],
+                         100.0 * double(e[0] - t0) / dur, 100.0 * double(e[1] - t0) / dur, 100.0 * double(e[2] - t0) / dur, e[3], e[3] ? double(e[4]) / e[3] : 0.0, e[5]);
+        }
+    }
+    std::fill(h.begin(), h.end(), 0ull); std::fill(hist.begin(), hist.end(), 0u);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wt), h.data(), h.size() * 8);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wtHist), hist.data(), hist.size() * 4);
+}
+} // namespace
+#endif
 
 size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags, size_t nimages)
 {
@@ -1617,6 +1744,9 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
     DXTEX_MARK(nullptr);
 #undef DXTEX_MODE
 #undef DXTEX_MARK
+#if defined(DXTEX_BC7_WAVETIMES)
+    bc7_wavetimes_report();
+#endif
     return hipGetLastError();
 }
 } // namespace dxtex

@@ -382,6 +382,22 @@ int main(int argc, char** argv)
         if (g_pfTotal[m]) printf("mode %d perturb: %.1f candidates/tile, %.1f %% pass the bound filter, %.1f %% improve\n", m, double(g_pfTotal[m]) / ntiles, 100.0 * g_pfPass[m] / g_pfTotal[m], 100.0 * g_pfImprove[m] / g_pfTotal[m]);
     }
 #endif
+#if defined(DXTEX_ROW_STATS)
+    for (int m = 0; m < 8; ++m)
+        if (g_rowCand[m])
+            for (int H = 1; H <= 3; ++H)
+                printf("mode %d: %.1f candidates per surviving window; strips of %d rows: %.2f tests per window, %.1f %% of the candidates in excluded strips\n", m,
+                       double(g_rowCand[m]) / g_rowWin[m], H, double(g_rowTests[m][H]) / g_rowWin[m], 100.0 * g_rowOut[m][H] / g_rowCand[m]);
+    for (int m = 0; m < 8; ++m)
+        if (g_rowCand[m])
+        {
+            for (int H = 1; H <= 3; ++H) for (int L = 1; L <= 2; ++L)
+                printf("mode %d peel H=%d L=%d: %.2f tests per window, %.1f %% of the candidates removed\n", m, H, L, double(g_peelTests[m][H][L]) / g_rowWin[m], 100.0 * g_peelOut[m][H][L] / g_rowCand[m]);
+            printf("mode %d, strips of 2 rows by distance from the starting row (share of candidates : excluded):", m);
+            for (int d = 0; d < 6; ++d) printf("  d%d %.1f%% : %.1f%%", d, 100.0 * g_rowDistN[m][d] / g_rowCand[m], g_rowDistN[m][d] ? 100.0 * g_rowDistOut[m][d] / g_rowDistN[m][d] : 0.0);
+            printf("\n");
+        }
+#endif
     printf("%d of %d tiles differ\n", nbad, ntiles);
     return nbad ? 1 : 0;
 }

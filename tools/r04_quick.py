@@ -43,6 +43,7 @@ GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))["
 
 
 def run(name, img, sfmt, dfmt, W, H, gold=None, reps=3):
+    reps = int(os.environ.get("PROBE_REPS", reps))
     src = h2d(img)
     nbytes = dx.compute_pitch(dfmt, W, H)[1]
     dst = dmalloc(nbytes)
