@@ -232,8 +232,15 @@ DXTEX_HD void region_init(Region& r, const uint32_t* pix, uint32_t mask16)
 }
 
 // SlotRegion: the subset's texels copied, in order, to a per-lane column of an LDS array laid out
-// [k][lane] (stride 64 dwords), so that a wavefront's fetch(k) is one conflict-free ds_read_b32. Used by
-// the persistent search loop, where every lane works on a different (block, shape, subset).
+// [k][lane], so that a wavefront's fetch(k) is one conflict-free ds_read_b32. Used by the persistent search
+// loop, where every lane works on a different (block, shape, subset). Rows are kSlotStride = 65 dwords apart:
+// with 64 a column would sit in ONE bank, and the lanes that score the texels of ANOTHER lane's column side by
+// side (the exact-evaluation list of bc7_perturb_filter_kernel: eight lanes, eight texels of one owner) would
+// collide eight ways - 40 % of that kernel's LDS cycles in round 4's counters.
+#if !defined(DXTEX_SLOT_STRIDE)
+#define DXTEX_SLOT_STRIDE 65
+#endif
+enum : int { kSlotStride = DXTEX_SLOT_STRIDE };
 struct SlotRegion
 {
     enum : bool { kStatic = false };
@@ -242,7 +249,7 @@ struct SlotRegion
     int p2sum;
     DXTEX_HD int count() const { return np; }
     DXTEX_HD uint32_t pos(int k) const { return uint32_t(k); }
-    DXTEX_HD uint32_t fetch(int k) const { return base[k * 64]; }
+    DXTEX_HD uint32_t fetch(int k) const { return base[k * kSlotStride]; }
 };
 
 // Block16: all 16 texels of a block held in the lane's registers (already rotated); used by the

@@ -472,14 +472,14 @@ __device__ __forceinline__ void search_pickup(const Bc7Args& a, uint2 task, uint
     if (TM::NS == 1)
     {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) slotCol[i * 64] = rotate_pixel(px[i], rot);
+        for (int i = 0; i < 16; ++i) slotCol[i * kSlotStride] = rotate_pixel(px[i], rot);
         np = 16;
     }
     else
     {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if ((mask >> i) & 1u) { slotCol[np * 64] = px[i]; ++np; }
+            if ((mask >> i) & 1u) { slotCol[np * kSlotStride] = px[i]; ++np; }
     }
     rg.base = slotCol; rg.np = np; rg.p2sum = 0;
 }
@@ -516,7 +516,7 @@ template<int MODE, int IM, int CHSET>
 __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
-    __shared__ uint32_t sSlot[16 * 64];
+    __shared__ uint32_t sSlot[16 * kSlotStride];
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
     if (live == 0) return;           // nothing survived pre (a phase that owns no block, everything pruned): skip the queue atomics
@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_wave_kernel(Bc7Args a)
     typedef LoopCfg<MODE, IM, CHSET> C;
     typedef TaskMap<MODE, IM> TM;
     static_assert(TM::NS == 1, "whole-block tasks only");
-    __shared__ uint32_t sTex[16 * 64];              // column `slot` holds the slot's sixteen texels (SlotRegion's layout)
+    __shared__ uint32_t sTex[16 * kSlotStride];              // column `slot` holds the slot's sixteen texels (SlotRegion's layout)
     const int lane = threadIdx.x, slot = lane >> 5, k = lane & 15, cand = (lane >> 4) & 1;
     const uint32_t live = a.counters[34];
     if (live == 0 || live > a.perturbWaveMax) return;
@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_wave_kernel(Bc7Args a)
         const int base = loop_base<MODE, IM, CHSET>(rg, rec.A, rec.B, &other);
         PerturbState st = perturb_begin<MODE, IM, CHSET>(rec.A, rec.B, rec.err);
         if (loop_is_settled<CHSET>(rec.err, other)) st.ch = C::CH1;       // scalar slot already exact: the record stays as it is
-        SlotRegion one; one.base = &sTex[slot] + k * 64; one.np = 1; one.p2sum = 0;      // this lane's texel
+        SlotRegion one; one.base = &sTex[slot] + k * kSlotStride; one.np = 1; one.p2sum = 0;      // this lane's texel
         // sum over the sixteen texel lanes of a candidate group
         auto group_sum = [](int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; };
         while (__ballot(st.ch < C::CH1) != 0ull)
@@ -652,16 +652,23 @@ __global__ void __launch_bounds__(64) bc7_perturb_wave_kernel(Bc7Args a)
 // sums: any order) and the owner reads its exact error back. Same candidates, same decisions as perturb_macro (bc7_core.h), which the
 // plain kernel above runs and DXTEX_BC7_PERTURB_PLAIN=1 selects.
 // Mode 1 at 5 waves per SIMD (91 registers instead of 105, no spill): the list handling waits on LDS, 21.3 -> 20.9 ms; 6 waves: no gain.
+#if !defined(DXTEX_PF1_WAVES)
+#define DXTEX_PF1_WAVES 5
+#endif
+#if !defined(DXTEX_PF_LCAP)
+#define DXTEX_PF_LCAP 32               // entries of the exact-evaluation list: a step with more passing candidates (rare: 6 of 64 on average) takes two rounds
+#endif
 template<int MODE, int IM, int CHSET>
-__global__ void __launch_bounds__(64, (MODE == 1) ? 5 : 1) bc7_perturb_filter_kernel(Bc7Args a, int loop)
+__global__ void __launch_bounds__(64, (MODE == 1) ? DXTEX_PF1_WAVES : 1) bc7_perturb_filter_kernel(Bc7Args a, int loop)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     static_assert(!C::kAlpha, "colour / combined loops only");
     constexpr int N = C::N;
-    __shared__ uint32_t sSlot[16 * 64];             // texel columns, one per lane
-    __shared__ uint32_t sCand[64 * 2 * N];          // list entry e: pal[N], then -|q|^2 [N]
-    __shared__ uint32_t sOwner[64];                 // list entry -> owner lane | subset size << 8
-    __shared__ uint32_t sSum[64];                   // list entry -> sum over the subset of the first-peak scores
+    constexpr int LCAP = DXTEX_PF_LCAP;
+    __shared__ uint32_t sSlot[16 * kSlotStride];    // texel columns, one per lane
+    __shared__ uint32_t sCand[LCAP * (2 * N)];  // list entry e: pal[N], then -|q|^2 [N] (16-byte aligned: written and read as ds_*_b128; an odd stride measured 0.8 ms slower)
+    __shared__ uint32_t sOwner[LCAP];               // list entry -> owner lane | subset size << 8
+    __shared__ uint32_t sSum[LCAP];                 // list entry -> sum over the subset of the first-peak scores
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
     if (live == 0) return;
@@ -744,35 +751,43 @@ __global__ void __launch_bounds__(64, (MODE == 1) ? 5 : 1) bc7_perturb_filter_ke
             const unsigned long long passMask = __ballot(pass);
             if (passMask == 0ull) return 0x7FFFFFFF;
             const int n = __popcll(passMask), pos = lanes_below(passMask);
-            if (pass)
+            int exact = 0x7FFFFFFF;
+            for (int first = 0; first < n; first += LCAP)
             {
-#pragma unroll
-                for (int i = 0; i < N; ++i) { sCand[pos * 2 * N + i] = pal[i]; sCand[pos * 2 * N + N + i] = nq2[i]; }
-                sOwner[pos] = uint32_t(lane) | (uint32_t(rg.np) << 8);
-                sSum[pos] = 0u;
-            }
-            wave_lds_sync();
-            const int items = n * npMax;
-            for (int g0 = 0; g0 < items; g0 += 64)
-            {
-                const int g = g0 + lane;
-                const int ent = int((uint32_t(g) * npMagic) >> 16), k = g - ent * npMax;
-                if (g < items)
+                const int cnt = min(n - first, LCAP), e = pos - first;
+                const bool mine = pass && uint32_t(e) < uint32_t(cnt);
+                if (mine)
                 {
-                    const uint32_t own = sOwner[ent];
-                    if (k < int(own >> 8))
-                    {
-                        uint32_t p = sSlot[(own & 63u) + uint32_t(k) * 64u];
-                        if (CHSET == CH_COLOR) p &= 0x00FFFFFFu;
-                        int sc[N];
 #pragma unroll
-                        for (int i = 0; i < N; ++i) sc[i] = score(p, sCand[ent * 2 * N + i], sCand[ent * 2 * N + N + i]);
-                        atomicAdd(&sSum[ent], uint32_t(first_peak(sc)));
+                    for (int i = 0; i < N; ++i) { sCand[e * (2 * N) + i] = pal[i]; sCand[e * (2 * N) + N + i] = nq2[i]; }
+                    sOwner[e] = uint32_t(lane) | (uint32_t(rg.np) << 8);
+                    sSum[e] = 0u;
+                }
+                wave_lds_sync();
+                const int items = cnt * npMax;
+                for (int g0 = 0; g0 < items; g0 += 64)
+                {
+                    const int g = g0 + lane;
+                    const int ent = int((uint32_t(g) * npMagic) >> 16), k = g - ent * npMax;
+                    if (g < items)
+                    {
+                        const uint32_t own = sOwner[ent];
+                        if (k < int(own >> 8))
+                        {
+                            uint32_t p = sSlot[(own & 63u) + uint32_t(k) * uint32_t(kSlotStride)];
+                            if (CHSET == CH_COLOR) p &= 0x00FFFFFFu;
+                            int sc[N];
+#pragma unroll
+                            for (int i = 0; i < N; ++i) sc[i] = score(p, sCand[ent * (2 * N) + i], sCand[ent * (2 * N) + N + i]);
+                            atomicAdd(&sSum[ent], uint32_t(first_peak(sc)));
+                        }
                     }
                 }
+                wave_lds_sync();
+                if (mine) exact = base - int(sSum[e]);
+                if (first + LCAP < n) wave_lds_sync();          // the next round rewrites the list
             }
-            wave_lds_sync();
-            return pass ? base - int(sSum[pos]) : 0x7FFFFFFF;
+            return exact;
         };
 
         {
@@ -873,7 +888,7 @@ template<int MODE, int IM, int CHSET>
 __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS : 1) bc7_exhaustive_kernel(Bc7Args a, int loop, int tailBelow, int rangeTests)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
-    __shared__ uint32_t sSlot[16 * 64];             // texel columns, one per lane
+    __shared__ uint32_t sSlot[16 * kSlotStride];             // texel columns, one per lane
     __shared__ uint32_t sWork[kExhWorkMax];         // pooled candidates to bound: (owner << 8) | code
     __shared__ uint32_t sExact[kExhExactMax];       // candidates to evaluate exactly: (owner << 8) | code
     __shared__ uint32_t sBest[64];                  // per lane: best key of its current window
@@ -955,7 +970,7 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
         // whatever has not been tested by then is simply visited. Lanes that end up without candidates help the others through the pooled phase.
         {
             int stage = 0;
-            const int trips = rangeTests & 0xFF, lastStage = (rangeTests >> 8) ? 1 : 5;       // (development knob: no peeling = only stage 0)
+            const int trips = rangeTests & 0xFF, lastStage = 1 + 4 * (rangeTests >> 8);      // (rangeTests >> 8 = layers of strips: 1; development knob: 0 = no peeling, 2 = two layers)
 #pragma unroll 1
             for (int trip = 0; trip < trips; ++trip)
             {
@@ -963,7 +978,7 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
                 if (__ballot(testing) == 0ull) break;
                 int ro0 = st.o, ro1 = st.oEnd - 1, ri0 = st.i, ri1 = st.iEnd - 1;      // at window open: st.i == the first row's first value
                 bool valid = true;
-                if (stage > 0) valid = exh_peel_rect(st, stage - 1, ro0, ro1, ri0, ri1);
+                if (stage > 0) valid = exh_peel_rect(st, (stage - 1) & 3, ro0, ro1, ri0, ri1);
                 if (!valid) { ro0 = ro1 = st.o; ri0 = ri1 = st.iEnd - 1; }           // (the call is wave-uniform: a harmless rectangle)
                 const int b = exh_range_bound<MODE, IM, CHSET>(rg, vp, st, base, ro0, ro1, ri0, ri1);
                 if (testing)
@@ -986,7 +1001,7 @@ __global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS
                     }
                     else
                     {
-                        exh_peel_apply(st, stage - 1, out);
+                        exh_peel_apply(st, (stage - 1) & 3, out);
                         ++stage;
                     }
                 }
@@ -1098,7 +1113,7 @@ __global__ void __launch_bounds__(64) bc7_exhaustive_wave_kernel(Bc7Args a)
     typedef LoopCfg<MODE, IM, CHSET> C;
     typedef TaskMap<MODE, IM> TM;
     static_assert(TM::NS == 1, "whole-block tasks only");
-    __shared__ uint32_t sTex[16 * 64];
+    __shared__ uint32_t sTex[16 * kSlotStride];
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
     if (live == 0 || live > a.exhWaveMax) return;
@@ -1411,7 +1426,8 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
     static const int tailBelow = dev_env("DXTEX_BC7_TAIL_BELOW") ? atoi(dev_env("DXTEX_BC7_TAIL_BELOW")) : 48;
     static const bool perturbPlain = dev_env("DXTEX_BC7_PERTURB_PLAIN") != nullptr;      // A/B: PerturbOne without the bound filter
     // Exhaustive's interval tests per round (see the kernel); DXTEX_BC7_NO_PEEL = whole-window tests only (three of them, as before round 5)
-    static const int rangeTests = dev_env("DXTEX_BC7_NO_PEEL") ? (3 | 0x100) : (dev_env("DXTEX_BC7_RANGE_TESTS") ? atoi(dev_env("DXTEX_BC7_RANGE_TESTS")) & 0xFF : DXTEX_RANGE_TESTS);
+    static const int rangeTests = dev_env("DXTEX_BC7_NO_PEEL") ? 3 : ((dev_env("DXTEX_BC7_RANGE_TESTS") ? atoi(dev_env("DXTEX_BC7_RANGE_TESTS")) & 0xFF : DXTEX_RANGE_TESTS) |
+                                                                       ((dev_env("DXTEX_BC7_PEEL_LAYERS") ? atoi(dev_env("DXTEX_BC7_PEEL_LAYERS")) : 1) << 8));
     if constexpr (PaletteBits<MODE, IM>::AB == 0)
     {
         // the filter pays where the exact evaluation is dearest - eight palette entries on subsets of ~8 texels (mode 1: 24.5 -> 21.7 ms

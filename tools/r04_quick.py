@@ -36,6 +36,15 @@ def d2h(p, n):
     return out
 
 
+def cached(name, make):
+    """synthetic images are a few seconds of numpy each: several probe runs in one gpurun call share them through /tmp"""
+    path = "/tmp/dxtex_probe_%s.npy" % name
+    if os.path.exists(path):
+        return np.load(path)
+    img = make(); np.save(path, img)
+    return img
+
+
 what = set(sys.argv[1:]) or {"bc7"}
 TOP = int(os.environ.get("PROBE_TOP", "16"))
 ctx = dx.Context(0)
@@ -69,11 +78,11 @@ def run(name, img, sfmt, dfmt, W, H, gold=None, reps=3):
 
 
 if "bc7" in what:
-    run("bc7 4096^2 cfg2", synth.survey_rgba8(4096, 4096, 2, "opaque"), 28, 98, 4096, 4096, "cfg2_bc7_4096")
+    run("bc7 4096^2 cfg2", cached("cfg2", lambda: synth.survey_rgba8(4096, 4096, 2, "opaque")), 28, 98, 4096, 4096, "cfg2_bc7_4096")
 if "bc6h" in what:
-    run("bc6h 4096^2 cfg3", synth.survey_rgba16f(4096, 4096, 3), 10, 95, 4096, 4096, "cfg3_bc6h_uf16_4096", reps=2)
+    run("bc6h 4096^2 cfg3", cached("cfg3", lambda: synth.survey_rgba16f(4096, 4096, 3)), 10, 95, 4096, 4096, "cfg3_bc6h_uf16_4096", reps=2)
 if "bc1" in what:
-    img = synth.survey_rgba8(4096, 4096, 2, "opaque")
+    img = cached("cfg2", lambda: synth.survey_rgba8(4096, 4096, 2, "opaque"))
     for fmt, nm in ((71, "bc1"), (74, "bc2"), (77, "bc3"), (80, "bc4"), (83, "bc5")):
         run(nm + " 4096^2", img, 28, fmt, 4096, 4096, None, reps=20)
 if "small" in what:
