@@ -873,7 +873,10 @@ __device__ __forceinline__ void encode_packed(PackedTile& t, uint8_t* out, uint3
 #define DXTEX_BC15_COLOR_WGS 4         // workgroups per CU of the BC1 - BC3 instantiations whose fit reads packed 5:6:5 codes (CodeColors)
 #endif
 #if !defined(DXTEX_BC15_PACKED_WGS)
-#define DXTEX_BC15_PACKED_WGS 3        // workgroups per CU the packed-tile instantiations of BC3 - BC5 are compiled for
+#define DXTEX_BC15_PACKED_WGS 3        // workgroups per CU the other packed-tile instantiations of BC3 (dithered / fit on floats) are compiled for
+#endif
+#if !defined(DXTEX_BC15_BC45_WGS)
+#define DXTEX_BC15_BC45_WGS 4          // BC4 / BC5: no colour fit, 120 registers are enough (at 3 the allocator took 168 and BC5 of a 4096^2 image went 0.077 -> 0.092 ms)
 #endif
 // Occupancy per codec, measured (round 4, 4096^2 cfg2 image / BC3 of the 8192^2 cfg4 chain with random alpha, same box): BC1 and BC2 with the
 // fit on 48 floats at 2 workgroups per CU (no spill; BC2 0.128 ms against 0.144 at 3) - on packed codes at 3 - 4 workgroups they are slower
@@ -881,7 +884,7 @@ __device__ __forceinline__ void encode_packed(PackedTile& t, uint8_t* out, uint3
 // any occupancy). BC3, whose alpha fit shares the registers, spilled 128 bytes per lane at 3 workgroups and was slower still at 2; on codes
 // at 4 workgroups it has no scratch: 0.163 -> 0.147 ms per 4096^2 image, the cfg4 chain 1.16 -> 0.93 ms.
 template<int KIND, bool DITHER, bool PACKED8>
-__global__ void __launch_bounds__(256, PACKED8 ? ((KIND == 3 && !DITHER && DXTEX_BC15_CODES) ? DXTEX_BC15_COLOR_WGS : (KIND <= 2 ? 2 : DXTEX_BC15_PACKED_WGS)) : 1) bc15_encode_kernel(EncodeArgs a)
+__global__ void __launch_bounds__(256, PACKED8 ? ((KIND == 3 && !DITHER && DXTEX_BC15_CODES) ? DXTEX_BC15_COLOR_WGS : (KIND <= 2 ? 2 : (KIND >= 4 ? DXTEX_BC15_BC45_WGS : DXTEX_BC15_PACKED_WGS))) : 1) bc15_encode_kernel(EncodeArgs a)
 {
     // A wavefront takes an 8 x 8 tile of blocks (32 x 32 texels), not 64 blocks of one block row: what the lanes of a wavefront do
     // differs by content - flat blocks leave the fit at once, noisy ones run its eight Newton trips - and content is coherent in two

@@ -1118,6 +1118,13 @@ DXTEX_HD int exh_window_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET
     return exh_range_bound<MODE, IM, CHSET>(rg, vp, s, base, s.o, s.oEnd - 1, s.i, s.iEnd - 1);      // at window open: s.o == s.o0, s.i == the first row's first value
 }
 
+// "nothing in this window can beat the error it starts from": the bound is not below that error
+template<int MODE, int IM, int CHSET, class RG>
+DXTEX_HD bool exh_window_excluded(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, const ExhState& s, int base)
+{
+    return exh_window_bound<MODE, IM, CHSET>(rg, vp, s, base) >= s.optErr;
+}
+
 // The same bound over any rectangle of (outer, inner) endpoint values of the window `s` describes.
 template<int MODE, int IM, int CHSET, class RG>
 DXTEX_HD int exh_range_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>::N>& vp, const ExhState& s, int base, int oLo, int oHi, int iLo, int iHi)
