@@ -63,7 +63,6 @@ struct Bc7Args
     uint32_t gateMin;        // when too few blocks are flagged - is skipped on the device: its kernels return at once when *gate < gateMin (nullptr: always run)
     uint32_t perturbWaveMax; // whole-block modes: lists of at most this many live tasks are searched by bc7_perturb_wave_kernel (0 = never)
     uint32_t exhWaveMax;     // ... and by bc7_exhaustive_wave_kernel
-    uint32_t maxWaves;       // launcher only: persistent wavefronts per search kernel (staggered passes leave room for each other's kernels)
 };
 
 // Whole-block tasks (modes 4, 5, 6: one subset of 16 texels) on SHORT lists - a small image, the late phase of mode 6 - are searched by
@@ -655,6 +654,9 @@ __global__ void __launch_bounds__(64) bc7_perturb_wave_kernel(Bc7Args a)
 // Mode 1 at 5 waves per SIMD (91 registers instead of 105, no spill): the list handling waits on LDS, 21.3 -> 20.9 ms; 6 waves: no gain.
 #if !defined(DXTEX_PF1_WAVES)
 #define DXTEX_PF1_WAVES 5
+#endif
+#if !defined(DXTEX_PF_M4)
+#define DXTEX_PF_M4 1
 #endif
 #if !defined(DXTEX_PF_LCAP)
 #define DXTEX_PF_LCAP 32               // entries of the exact-evaluation list: a step with more passing candidates (rare: 6 of 64 on average) takes two rounds
@@ -1385,41 +1387,6 @@ struct ScratchLayout
     }
 };
 
-// Staggered passes. The search kernels of one pass leave issue slots idle: the late modes' kernels are as long as their longest chains
-// (0.2 - 0.6 of the VALU issue rate, profiles/r04_bc7.md), every persistent kernel ends with a tail of a few busy wavefronts, and between two
-// dependent kernels the machine is empty for some microseconds. A second pass that is at a different point of its pipeline fills them: a
-// submission of more than kStaggerMinBlocks blocks is cut into (at least) kStaggerPasses passes that alternate between two scratch sets and
-// two streams (the context's and its last side stream); pass p + 1 starts when pass p has finished the step kStaggerAfter, and while two
-// passes are in flight each search kernel launches at most kStaggerWaves persistent wavefronts, so the other pass's kernels always find
-// wave slots, registers and LDS (a persistent wavefront holds its slot until the task queue has drained). Passes do not share state: same bytes.
-struct PassPlan { uint64_t perPass; int pipelines; };
-inline int knob_int(const char* name, int dflt) { const char* e = dev_env(name); return e ? atoi(e) : dflt; }
-#if !defined(DXTEX_STAGGER_PASSES)
-#define DXTEX_STAGGER_PASSES 1
-#endif
-#if !defined(DXTEX_STAGGER_WAVES)
-#define DXTEX_STAGGER_WAVES 2048
-#endif
-#if !defined(DXTEX_STAGGER_AFTER)
-#define DXTEX_STAGGER_AFTER 1
-#endif
-const int kStaggerPasses = knob_int("DXTEX_BC7_STAGGER", DXTEX_STAGGER_PASSES);              // 1 = off
-const uint64_t kStaggerMinBlocks = uint64_t(knob_int("DXTEX_BC7_STAGGER_MIN", 524288));
-const int kStaggerWaves = knob_int("DXTEX_BC7_STAGGER_WAVES", DXTEX_STAGGER_WAVES);
-const int kStaggerAfter = knob_int("DXTEX_BC7_STAGGER_AFTER", DXTEX_STAGGER_AFTER);          // step code of `order`; -1 = no offset, 99 = after the whole pass
-const int kStaggerFork = knob_int("DXTEX_BC7_STAGGER_FORK", 1);                              // modes 4 / 5 side by side: 0 never, 1 in the last pass only, 2 in every pass
-inline PassPlan plan_passes(uint64_t total, uint32_t flags)
-{
-    PassPlan p; p.perPass = total < kMaxBlocksPerPass ? total : kMaxBlocksPerPass; p.pipelines = 1;
-    if (kStaggerPasses > 1 && total > kStaggerMinBlocks && !(flags & BCF_BC7_QUICK))
-    {
-        const uint64_t cut = (total + uint64_t(kStaggerPasses) - 1) / uint64_t(kStaggerPasses);
-        p.perPass = std::max<uint64_t>(std::min<uint64_t>(cut, kMaxBlocksPerPass), std::min<uint64_t>(total, kSmallPassBlocks + 1));
-        p.pipelines = 2;
-    }
-    return p;
-}
-
 template<int MODE, int IM>
 void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, const char* const (&names)[7])
 {
@@ -1437,8 +1404,7 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
     static const bool noGroup = dev_env("DXTEX_BC7_NO_GROUP") != nullptr;      // development A/B: every list through the lane-per-task kernels
     const bool maybeShortP = kWhole && !noGroup && (MODE == 6 || ntasks <= 4u * kPerturbWaveMax);
     const bool maybeShortE = kWhole && !noGroup && (MODE == 6 || ntasks <= 4u * kExhMax);
-    const uint32_t maxWaves = a0.maxWaves ? a0.maxWaves : uint32_t(kSearchWaves);
-    const uint32_t wavesP = std::min<uint32_t>(maxWaves, (ntasks + 1) / 2), wavesE = std::min<uint32_t>(maxWaves, ntasks);
+    const uint32_t wavesP = std::min<uint32_t>(kSearchWaves, (ntasks + 1) / 2), wavesE = std::min<uint32_t>(kSearchWaves, ntasks);
     Bc7Args a = a0;
     // device-side skip of launches that own no block (flagged[] is written by bc7_flag_count_kernel; BC7_QUICK has neither flags nor phases)
     a.gate = nullptr; a.gateMin = 0;
@@ -1459,7 +1425,7 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
     hipLaunchKernelGGL(bc7_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a.counters);
     hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order, a.gate, a.gateMin);
     if (marks) marks->mark(names[2]);
-    const uint32_t waves = std::min<uint32_t>(maxWaves, (ntasks + 63) / 64);
+    const uint32_t waves = std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64);
     static const int tailBelow = dev_env("DXTEX_BC7_TAIL_BELOW") ? atoi(dev_env("DXTEX_BC7_TAIL_BELOW")) : 48;
     static const bool perturbPlain = dev_env("DXTEX_BC7_PERTURB_PLAIN") != nullptr;      // A/B: PerturbOne without the bound filter
     // Exhaustive's interval tests per round (see the kernel); DXTEX_BC7_NO_PEEL = whole-window tests only (three of them, as before round 5)
@@ -1484,7 +1450,15 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
     }
     else
     {
-        hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 0);
+        // mode 4's 3-bit colours (index mode 1): eight entries on sixteen texels, the dearest exact evaluation after mode 6's - through the
+        // filter as well (3.98 -> 3.67 ms on the benchmark image)
+        if constexpr (MODE == 4 && IM == 1 && DXTEX_PF_M4 != 0)
+        {
+            if (perturbPlain) hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 0);
+            else hipLaunchKernelGGL((bc7_perturb_filter_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 0);
+        }
+        else
+            hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_COLOR>), dim3(waves), dim3(64), 0, stream, a, 0);
         if (maybeShortP) hipLaunchKernelGGL((bc7_perturb_wave_kernel<MODE, IM, CH_COLOR>), dim3(wavesP), dim3(64), 0, stream, a);
         if (marks) marks->mark(names[3]);
         hipLaunchKernelGGL((bc7_perturb_kernel<MODE, IM, CH_ALPHA>), dim3(waves), dim3(64), 0, stream, a, 1);
@@ -1584,10 +1558,9 @@ size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags, size_t nimages)
     // monotone in the number of blocks (a context prepared for a larger submission never reallocates for a smaller one): the small
     // layout's side pipelines have full-size task arrays, so a lone 2048^2 image needs more than a slightly larger submission would
     const bool three = (flags & BCF_USE_3SUBSETS) != 0;
-    const PassPlan plan = plan_passes(nblocks, flags);
-    size_t need = size_t(plan.pipelines) * ScratchLayout(plan.perPass, three).total;
+    size_t need = ScratchLayout(nblocks < kMaxBlocksPerPass ? nblocks : kMaxBlocksPerPass, three).total;
     if (nblocks > kSmallPassBlocks) need = std::max(need, ScratchLayout(kSmallPassBlocks, three).total);
-    return need + seg_table_bytes(nblocks, plan.perPass, nimages);
+    return need + seg_table_bytes(nblocks, kMaxBlocksPerPass, nimages);
 }
 
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
@@ -1607,34 +1580,18 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
     std::vector<BcSeg> segs;
     std::vector<BcPass> passes;
     uint64_t perPass = 0;
-    uint64_t totalBlocks = 0;
-    for (size_t i = 0; i < count; ++i) totalBlocks += uint64_t((images[i].src.width + 3) / 4) * ((images[i].src.height + 3) / 4);
-    const PassPlan plan = plan_passes(totalBlocks, flags);
-    if (!build_passes(images, count, plan.perPass, segs, passes, &perPass)) return hipSuccess;
+    if (!build_passes(images, count, kMaxBlocksPerPass, segs, passes, &perPass)) return hipSuccess;
     const bool three = (flags & BCF_USE_3SUBSETS) != 0;
     const ScratchLayout L(perPass, three);
-    // staggered passes need the side streams, and per-kernel timing (marks) needs one stream; the scratch was sized for plan.pipelines sets
-    const bool stagger = plan.pipelines > 1 && side && !marks && passes.size() > 1;
-    uint8_t* const base0 = static_cast<uint8_t*>(scratch);
-    BcSeg* dSegs = reinterpret_cast<BcSeg*>(base0 + size_t(plan.pipelines) * L.total);
+    uint8_t* base = static_cast<uint8_t*>(scratch);
+    BcSeg* dSegs = reinterpret_cast<BcSeg*>(base + L.total);
     const hipError_t ce = upload_segments(dSegs, segs, passes, stream);
     if (ce != hipSuccess) return ce;
     const bool quick = (flags & BCF_BC7_QUICK) != 0;
-    hipStream_t const mainStream = stream;
 
-    for (size_t passNo = 0; passNo < passes.size(); ++passNo)
+    for (const BcPass& pass : passes)
     {
-        const BcPass& pass = passes[passNo];
-        const bool lastPass = passNo + 1 == passes.size();
-        // pass p runs on pipeline p % 2: its own scratch set and stream; it starts when the pass before it has passed kStaggerAfter
-        const bool onSide = stagger && (passNo & 1);
-        uint8_t* const base = base0 + (onSide ? L.total : 0);
-        hipStream_t const stream = onSide ? side->side[kSideStreams - 1] : mainStream;
-        if (stagger && passNo > 0) (void)hipStreamWaitEvent(stream, side->passMid, 0);
-        bool midRecorded = false;
         Bc7Args a;
-        static const int searchWaves = knob_int("DXTEX_BC7_SEARCH_WAVES", 0), forkWaves = knob_int("DXTEX_BC7_FORK_WAVES", 0);      // development A/B
-        a.maxWaves = (stagger && kStaggerWaves > 0) ? uint32_t(kStaggerWaves) : uint32_t(searchWaves);
         set_pass(a.seg, dSegs, segs, pass);
         a.nblocks = pass.nblocks;
         a.flags = flags;
@@ -1728,7 +1685,7 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
         // Per-kernel timing (marks) needs one stream and keeps them serial.
         auto family45 = [](int step) { const int m = step % 10; return m == 4 || m == 8 || m == 5; };
         static const bool serial45 = dev_env("DXTEX_BC7_SERIAL") != nullptr;
-        const SideStreams* fork = (marks || serial45 || quick || (stagger && (kStaggerFork == 0 || (kStaggerFork == 1 && !lastPass)))) ? nullptr : side;
+        const SideStreams* fork = (marks || serial45 || quick) ? nullptr : side;
         // the task arrays of side pipeline k (0-based)
         auto side_args = [&](const Bc7Args& a0, size_t k)
         {
@@ -1796,15 +1753,8 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
             size_t run = 1;
             if (fork && family45(step))
                 while (at + run < order.size() && run < 3 && family45(order[at + run]) && order[at + run] / 10 == step / 10) ++run;
-            auto stagger_mark = [&](int done)
-            {
-                if (stagger && !lastPass && !midRecorded && done == kStaggerAfter) { (void)hipEventRecord(side->passMid, stream); midRecorded = true; }
-            };
-            if (at == 0) stagger_mark(-1);
-            if (run == 1) { run_step(step, a, stream, marks); stagger_mark(step); ++at; continue; }
+            if (run == 1) { run_step(step, a, stream, marks); ++at; continue; }
             (void)hipEventRecord(fork->forked, stream);
-            const uint32_t keepWaves = a.maxWaves;
-            if (forkWaves > 0) a.maxWaves = uint32_t(forkWaves);
             for (size_t k = 1; k < run; ++k)
             {
                 const Bc7Args b = side_args(a, k - 1);
@@ -1813,7 +1763,6 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
                 (void)hipEventRecord(fork->joined[k - 1], fork->side[k - 1]);
             }
             run_step(step, a, stream, nullptr);
-            a.maxWaves = keepWaves;
             for (size_t k = 1; k < run; ++k) (void)hipStreamWaitEvent(stream, fork->joined[k - 1], 0);
             at += run;
         }
@@ -1822,13 +1771,6 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
 #endif
         DXTEX_MARK("bc7_pick");
         hipLaunchKernelGGL(bc7_pick_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, stream, a, slotMask);
-        if (stagger && !lastPass && !midRecorded) (void)hipEventRecord(side->passMid, stream);
-    }
-    if (stagger)
-    {
-        // the caller's stream ends up behind every pass: it carried the even ones, the odd ones are joined here
-        (void)hipEventRecord(side->passDone, side->side[kSideStreams - 1]);
-        (void)hipStreamWaitEvent(mainStream, side->passDone, 0);
     }
     DXTEX_MARK(nullptr);
 #undef DXTEX_MODE

@@ -129,9 +129,7 @@ const SideStreams* side_streams(dxtex_ctx* ctx)
     if (!ctx->sideTried)
     {
         ctx->sideTried = true;
-        bool ok = hipEventCreateWithFlags(&ctx->side.forked, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&ctx->side.passMid, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&ctx->side.passDone, hipEventDisableTiming) == hipSuccess;
+        bool ok = hipEventCreateWithFlags(&ctx->side.forked, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < kSideStreams && ok; ++k)
             ok = hipStreamCreateWithFlags(&ctx->side.side[k], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&ctx->side.joined[k], hipEventDisableTiming) == hipSuccess;
@@ -323,8 +321,6 @@ void dxtex_ctx_destroy(dxtex_ctx* ctx)
         if (ctx->side.joined[k]) (void)hipEventDestroy(ctx->side.joined[k]);
     }
     if (ctx->side.forked) (void)hipEventDestroy(ctx->side.forked);
-    if (ctx->side.passMid) (void)hipEventDestroy(ctx->side.passMid);
-    if (ctx->side.passDone) (void)hipEventDestroy(ctx->side.passDone);
     for (hipEvent_t e : ctx->marks.pool) (void)hipEventDestroy(e);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);

@@ -29,8 +29,7 @@ hipError_t launch_bc15_encode_small(const BcImage* images, int count, int dstFor
 // Two extra streams (and the events that fork / join them) for pipelines that are independent of each other until the last kernel:
 // owned by the context (one set per context and device, destroyed with it); nullptr = everything on `stream`.
 constexpr int kSideStreams = 3;
-struct SideStreams { hipStream_t side[kSideStreams]; hipEvent_t forked; hipEvent_t joined[kSideStreams];
-                     hipEvent_t passMid, passDone; };     // staggered passes of the BC7 pipeline (launch_bc7_encode_many): side[kSideStreams - 1] carries every other pass
+struct SideStreams { hipStream_t side[kSideStreams]; hipEvent_t forked; hipEvent_t joined[kSideStreams]; };
 size_t bc7_scratch_bytes(uint64_t nblocks, uint32_t flags, size_t nimages = 1);
 hipError_t launch_bc7_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, uint32_t flags,
                              void* scratch, hipStream_t stream, KernelMarks* marks, const SideStreams* side = nullptr);
