@@ -424,7 +424,8 @@ def live_pmc(dom, budget_s=150.0):
     out = {}
     tmp = tempfile.mkdtemp(prefix="dxtex_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    passes = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]))
+    passes = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]),
+              ("lds", ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]))
     try:
         for tag, counters in passes:
             if time.perf_counter() - t_start > budget_s:
@@ -437,11 +438,15 @@ def live_pmc(dom, budget_s=150.0):
                 return None
             acc = {}; n = {}; dur = []
             for row in csv.DictReader(open(files[0])):
+                if tag in ("fetch", "write") and "bc7_" in row["Kernel_Name"]:      # every launch of the image (one repetition): the whole step's traffic
+                    out["STEP_" + row["Counter_Name"]] = out.get("STEP_" + row["Counter_Name"], 0.0) + float(row["Counter_Value"])
                 if name in row["Kernel_Name"]:
                     c = row["Counter_Name"]
                     acc[c] = acc.get(c, 0.0) + float(row["Counter_Value"]); n[c] = n.get(c, 0) + 1
                     dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
             if not acc:
+                if tag == "lds":
+                    continue                                  # optional pass
                 return None
             for c in acc:
                 out[c] = acc[c] / n[c]
@@ -613,6 +618,8 @@ def main():
             roof["all_kernels_ms"] = {k: round(v, 4) for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])}
             roof["step_kernel_ms"] = round(sum(ms for ms, n in kernels.values()) / nprof, 4)
             roof["step_hbm_frac"] = round(algo_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6)
+            # the late phase (modes 4 / 5 / 6 on the blocks the earlier modes left): its kernels one after the other (the profiling pass is serial)
+            roof["late_phase_kernel_ms"] = round(sum(v for k, v in per_launch.items() if k.endswith("_late")), 3)
         # PMC counters: measured in THIS run by child rocprofv3 passes over the same workload (live_pmc); the committed file only supplies the
         # static issue cost per instruction of the kernel's opcode mix (a property of the code: it needs a disassembly) and is the fallback
         # for everything when rocprofv3 is not available - and then ONLY if it was measured on these kernel sources (stamp) and names this
@@ -649,6 +656,15 @@ def main():
                 if tot:
                     v["wave_cycles_parked_stalled_issuing"] = [round(live.get(k, 0) / tot, 2) for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")]
                 roof["valu"] = v
+                # the same evidence as flat scalars (nested objects do not survive every consumer of this line)
+                if "issue_utilisation" in v:
+                    roof["valu_issue_utilisation"] = v["issue_utilisation"]
+                roof["active_lanes_per_valu_inst"] = v["active_lanes_per_valu_inst"]
+            if live.get("SQ_LDS_IDX_ACTIVE"):
+                roof["lds_bank_conflict_share"] = round(live.get("SQ_LDS_BANK_CONFLICT", 0.0) / live["SQ_LDS_IDX_ACTIVE"], 3)
+            if "STEP_FETCH_SIZE" in live and "STEP_WRITE_SIZE" in live:
+                roof["traffic_whole_step"] = int((live["STEP_FETCH_SIZE"] + live["STEP_WRITE_SIZE"]) * 1024)
+                roof["traffic_whole_step_over_algorithmic"] = round(roof["traffic_whole_step"] / algo_bytes, 1)
             roof["pmc_seconds"] = live.get("seconds")
         elif roof and os.path.exists(pmc):
             try:
@@ -662,6 +678,11 @@ def main():
                     roof["traffic_source"] = t.get("source")
                     if t.get("valu"):
                         roof["valu"] = t["valu"]               # SQ counters of the same kernel (profiles/): what actually bounds it
+                        for k_ in ("issue_utilisation", "active_lanes_per_valu_inst", "lds_bank_conflict_share"):
+                            if k_ in t["valu"]:
+                                roof["valu_issue_utilisation" if k_ == "issue_utilisation" else k_] = t["valu"][k_]
+                    if t.get("traffic_whole_step_over_algorithmic"):
+                        roof["traffic_whole_step_over_algorithmic"] = t["traffic_whole_step_over_algorithmic"]
             except Exception:
                 pass
 
@@ -686,7 +707,7 @@ def main():
                     parity.update(live)
                     # the whole image on the reference: measured by the live parity test on the GPU box (tests/test_zz_fullsize_gpu.py),
                     # committed under profiles/ (3+ minutes - not re-run here; --cpu-full does)
-                    for name in ("r03_fullsize_live.json", "r02_fullsize_live.json"):
+                    for name in ("r05_fullsize_live.json", "r03_fullsize_live.json", "r02_fullsize_live.json"):
                         fp = os.path.join(ROOT, "profiles", name)
                         if cpu and os.path.exists(fp):
                             w = json.load(open(fp)).get("cfg2_bc7_4096")

@@ -56,7 +56,8 @@ struct Bc7Args
     int* bestErr;            // per block: smallest error an already finished mode reached (subset_lower_bound prunes against it)
     int prune;               // 0 = search every candidate like the reference does (DXTEX_BC7_NO_PRUNE, for A/B runs)
     const uint32_t* flagged; // [0] = blocks of this pass flagged for an early mode 6, [1] = blocks with alpha (bc7_flag_count_kernel)
-    uint32_t early6Min;      // an early phase (mode 6; modes 4 / 5) only exists when at least this many blocks would be in it
+    uint32_t early6Min;      // the early phase of mode 6 only exists when at least this many blocks would be in it
+    uint32_t earlyAlphaMin;  // ... and the early phases of modes 4 / 5 (blocks with alpha) when at least this many
     int early6Pct;           // rough kernel: mode 6 goes first where 100 * lower bound <= early6Pct * best 3-bit rough error
     int phase;               // which blocks this launch of a mode owns: PHASE_ALL, or the early / late half of a split mode
     const uint32_t* gate;    // a mode (or the early phase of a split mode) that owns no block of the pass - mode 7 on an opaque image, the early phases
@@ -289,7 +290,7 @@ __device__ __forceinline__ bool phase_owns(const Bc7Args& a, uint32_t nb)
     const uint8_t* lst = a.lists + uint64_t(nb) * LIST_BYTES;
     // A handful of flagged blocks is not worth a phase of its own: the search kernels of a nearly empty phase still take as long
     // as their longest task (milliseconds). Below the threshold the flagged blocks simply stay with the late phase.
-    const bool early = (MODE == 6) ? (lst[37] != 0 && a.flagged[0] >= a.early6Min) : (lst[32] != 0 && a.flagged[1] >= a.early6Min);
+    const bool early = (MODE == 6) ? (lst[37] != 0 && a.flagged[0] >= a.early6Min) : (lst[32] != 0 && a.flagged[1] >= a.earlyAlphaMin);
     return early == (a.phase == PHASE_EARLY);
 }
 
@@ -1411,7 +1412,7 @@ void launch_mode(const Bc7Args& a0, hipStream_t stream, KernelMarks* marks, cons
     if (a0.flagged && !(a0.flags & BCF_BC7_QUICK))
     {
         if (MODE == 7) { a.gate = a0.flagged + 1; a.gateMin = 1; }                                               // blocks with alpha (phase_owns / task_geometry: lst[32])
-        else if (a0.phase == PHASE_EARLY && (MODE == 4 || MODE == 5)) { a.gate = a0.flagged + 1; a.gateMin = std::max<uint32_t>(1u, a0.early6Min); }
+        else if (a0.phase == PHASE_EARLY && (MODE == 4 || MODE == 5)) { a.gate = a0.flagged + 1; a.gateMin = std::max<uint32_t>(1u, a0.earlyAlphaMin); }
         else if (a0.phase == PHASE_EARLY && MODE == 6) { a.gate = a0.flagged; a.gateMin = std::max<uint32_t>(1u, a0.early6Min); }
     }
     a.perturbWaveMax = maybeShortP ? kPerturbWaveMax : 0u;
@@ -1617,8 +1618,12 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
 
         uint32_t* flagCount = reinterpret_cast<uint32_t*>(base + L.flagcnt);
         a.flagged = flagCount;
-        static const int early6MinPct = dev_env("DXTEX_BC7_EARLY6_MIN_PCT") ? atoi(dev_env("DXTEX_BC7_EARLY6_MIN_PCT")) : 25;
+        // Mode 6's early phase costs its own search (5 ms for the 42 % of the benchmark image's blocks it takes) and buys pruning in modes 1 / 3; since
+        // round 5's cheaper Exhaustive it only pays when at least half of the blocks are in it (131.8 -> 130.7 ms without it on the benchmark image)
+        static const int early6MinPct = dev_env("DXTEX_BC7_EARLY6_MIN_PCT") ? atoi(dev_env("DXTEX_BC7_EARLY6_MIN_PCT")) : 50;
+        static const int earlyAlphaMinPct = dev_env("DXTEX_BC7_EARLYA_MIN_PCT") ? atoi(dev_env("DXTEX_BC7_EARLYA_MIN_PCT")) : 25;
         a.early6Min = uint32_t(uint64_t(a.nblocks) * uint32_t(early6MinPct) / 100u);
+        a.earlyAlphaMin = uint32_t(uint64_t(a.nblocks) * uint32_t(earlyAlphaMinPct) / 100u);
         if (!quick)
         {
             DXTEX_MARK("bc7_rough");

@@ -189,6 +189,8 @@ def test_pruning_changes_nothing():
     outs = []
     for env in ({}, {"DXTEX_BC7_NO_PRUNE": "1", "DXTEX_BC6H_NO_PRUNE": "1"}, {"DXTEX_BC7_ORDER": "7,6,5,8,4,3,2,1,0", "DXTEX_BC7_PERTURB_PLAIN": "1", "DXTEX_BC7_NO_GROUP": "1", "DXTEX_BC7_SERIAL": "1", "DXTEX_BC6H_PERTURB_PLAIN": "1"},
                 {"DXTEX_BC7_NO_SMALL_PLAN": "1"}, {"DXTEX_BC7_SMALL_PLAN": "16/1/3,2|7,14,15,18|24,26/28/25,0"},
+                {"DXTEX_BC7_NO_SMALL_PLAN": "1", "DXTEX_BC7_EARLY6_MIN_PCT": "0", "DXTEX_BC7_EARLYA_MIN_PCT": "0"},          # every early phase that has a block
+                {"DXTEX_BC7_NO_SMALL_PLAN": "1", "DXTEX_BC7_EARLY6_MIN_PCT": "101", "DXTEX_BC7_EARLYA_MIN_PCT": "101"},      # no early phase at all
                 {"DXTEX_BC7_ORDER": "26,25,3,1,16,7,15,14,18,24,28,0,2", "DXTEX_BC6H_WAVE_MAX": "0", "DXTEX_BC6H_NO_REUSE": "1", "DXTEX_BC6H_ORDER": "0,1,2,3,4,5,6,7,8,9"}):
         r = subprocess.run([sys.executable, "-c", code] + (["--dev"] if env else []), env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -2,7 +2,7 @@
 # DEVELOPMENT TOOL: builds variants of the library that differ in compile-time definitions of ONE translation unit, for A/B runs on
 # the GPU box in one gpurun call.
 #   build (here):   tools/ab_variants.sh build bc7_encode.hip  v6="-DDXTEX_ROUGH_WGS=6" v7="-DDXTEX_ROUGH_WGS=7" ...
-#   run (GPU box):  tools/ab_variants.sh run "python tools/r03_quick.py --dev bc7" -> runs the command once per variant in build/variants/
+#   run (GPU box):  tools/ab_variants.sh run "python tools/quick_probe.py --dev bc7" -> runs the command once per variant in build/variants/
 # A variant replaces lib/libdxtex_amd_dev.so for its run (the command selects the development build itself: --dev); the product library is not touched.
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$HERE/..

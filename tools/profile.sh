@@ -3,7 +3,7 @@
 # runtime / sys trace): SQ instruction counters; SQ wait / activity split (WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, all in
 # quad-cycles) + GRBM_GUI_ACTIVE for the clock; the LDS pass (bank-conflict cycles against all LDS cycles, LDS issue stalls, VMEM / scalar
 # activity); TCC FETCH_SIZE; TCC WRITE_SIZE (the two TCC counters do not fit one pass). Outputs under gpurun_out/$1.
-# usage: tools/profile_r04.sh <tag> <workload: bc7|others>
+# usage: tools/profile.sh <tag> <workload: bc7|others>
 cd /tmp && export TMPDIR=/tmp
 TAG=$1; WL=$2; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 CMD="python $GRAFT_REPO_ROOT/tools/prof_workloads.py $WL"

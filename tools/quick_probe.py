@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """DEVELOPMENT TOOL: torch-free A/B probe (device buffers through libamdhip64 directly, so a fresh GPU box does not pay for importing
 torch): wall time per image, the context's per-kernel times and the golden check of the full-size BC7 (cfg2) / BC6H (cfg3) encodes.
-usage: [DXTEX_...=...] python tools/r04_quick.py [--dev] [bc7] [bc6h] [bc1] [small] [cfg4]
+usage: [DXTEX_...=...] python tools/quick_probe.py [--dev] [bc7] [bc6h] [bc1] [small] [cfg4]
 (round 4: payload digests for every run, so A/B variants can be compared byte for byte; cfg4 = the 8192^2 mip chains + BC3 of the chain against the golden digests)"""
 import ctypes, hashlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
