@@ -604,6 +604,7 @@ def main():
         except Exception as e:
             if rank == 0:
                 split = {"error": repr(e)}
+            raise            # a rank that stopped here would leave the others waiting in the section's collectives until the backend times out
 
     if rank == 0:
         # ---- roofline of the dominant kernel -----------------------------------------------------------

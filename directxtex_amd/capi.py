@@ -107,8 +107,8 @@ def load(dev=False):
     """Binds this module to the product library (the default, done at import) or - dev=True - to libdxtex_amd_dev.so: the same sources
     compiled with -DDXTEX_DEV, the only build that reads DXTEX_* development knobs from the environment. The choice is this explicit
     call, made by the tests and tools that need knobs before they create a Context; no environment variable selects a library, so
-    nothing in a user's shell changes what `import directxtex_amd` runs. Contexts created earlier keep working on the library that
-    created them only as long as they are not used again: call this first."""
+    nothing in a user's shell changes what `import directxtex_amd` runs. A Context keeps the library that created it (its handle belongs to
+    that library's statics), so contexts of both builds can live side by side; module-level helpers follow the latest load()."""
     global _lib
     lib, path = _open(dev)
     for name, (res, args) in _SIGS.items():
@@ -171,14 +171,15 @@ class Context:
 
     def __init__(self, device=0):
         self._h = _ctx_p()
-        hr = _lib.dxtex_ctx_create(device, ctypes.byref(self._h))
+        self._lib = _lib            # the library that creates the handle serves it for life, whatever load() binds the module to later
+        hr = self._lib.dxtex_ctx_create(device, ctypes.byref(self._h))
         if hr != 0:
             raise DxtexError(hr, "dxtex_ctx_create: no usable gfx950 device (this library has no CPU path)")
         self.device = device
 
     def close(self):
         if self._h:
-            _lib.dxtex_ctx_destroy(self._h)
+            self._lib.dxtex_ctx_destroy(self._h)
             self._h = _ctx_p()
 
     def __del__(self):
@@ -189,23 +190,23 @@ class Context:
 
     def _check(self, hr, what):
         if hr != 0:
-            raise DxtexError(hr, f"{what}: {_lib.dxtex_ctx_last_error(self._h).decode()}")
+            raise DxtexError(hr, f"{what}: {self._lib.dxtex_ctx_last_error(self._h).decode()}")
 
     # -- plumbing ---------------------------------------------------------------------------------
     def set_stream(self, stream_ptr):
-        self._check(_lib.dxtex_ctx_set_stream(self._h, stream_ptr), "set_stream")
+        self._check(self._lib.dxtex_ctx_set_stream(self._h, stream_ptr), "set_stream")
 
     def stream(self):
-        return _lib.dxtex_ctx_get_stream(self._h)
+        return self._lib.dxtex_ctx_get_stream(self._h)
 
     def synchronize(self):
-        self._check(_lib.dxtex_ctx_synchronize(self._h), "synchronize")
+        self._check(self._lib.dxtex_ctx_synchronize(self._h), "synchronize")
 
     def last_kernel_ms(self):
-        return float(_lib.dxtex_ctx_last_kernel_ms(self._h))
+        return float(self._lib.dxtex_ctx_last_kernel_ms(self._h))
 
     def profile_begin(self):
-        self._check(_lib.dxtex_ctx_profile_begin(self._h), "profile_begin")
+        self._check(self._lib.dxtex_ctx_profile_begin(self._h), "profile_begin")
 
     def profile_end(self):
         """-> {kernel name: (total ms, launches)} since profile_begin (synchronises the stream)."""
@@ -214,54 +215,54 @@ class Context:
         ms = (ctypes.c_float * cap)()
         n = (ctypes.c_uint32 * cap)()
         cnt = ctypes.c_size_t()
-        self._check(_lib.dxtex_ctx_profile_end(self._h, names, 16384, ms, n, cap, ctypes.byref(cnt)), "profile_end")
+        self._check(self._lib.dxtex_ctx_profile_end(self._h, names, 16384, ms, n, cap, ctypes.byref(cnt)), "profile_end")
         keys = names.value.decode().split("\n")[:cnt.value]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(keys)}
 
     # -- device-resident pipeline helpers -----------------------------------------------------------
     def device_alloc(self, nbytes, zero=False):
         p = ctypes.c_void_p()
-        self._check(_lib.dxtex_device_alloc(self._h, nbytes, ctypes.byref(p)), "device_alloc")
+        self._check(self._lib.dxtex_device_alloc(self._h, nbytes, ctypes.byref(p)), "device_alloc")
         if zero:
-            self._check(_lib.dxtex_device_memset(self._h, p, 0, nbytes), "device_memset")
+            self._check(self._lib.dxtex_device_memset(self._h, p, 0, nbytes), "device_memset")
         return p.value
 
     def device_free(self, ptr):
-        self._check(_lib.dxtex_device_free(self._h, ptr), "device_free")
+        self._check(self._lib.dxtex_device_free(self._h, ptr), "device_free")
 
     def host_alloc(self, nbytes):
         """Page-locked host memory as a numpy uint8 array (free with host_free(arr.ctypes.data) after the last use)."""
         p = ctypes.c_void_p()
-        self._check(_lib.dxtex_host_alloc(self._h, nbytes, ctypes.byref(p)), "host_alloc")
+        self._check(self._lib.dxtex_host_alloc(self._h, nbytes, ctypes.byref(p)), "host_alloc")
         return np.ctypeslib.as_array(ctypes.cast(p, _P(ctypes.c_uint8)), shape=(nbytes,))
 
     def host_free(self, ptr):
-        self._check(_lib.dxtex_host_free(self._h, ptr), "host_free")
+        self._check(self._lib.dxtex_host_free(self._h, ptr), "host_free")
 
     def upload(self, dst_ptr, arr, nbytes=None, sync=False):
         """Stream-ordered host -> device copy of a C-contiguous numpy buffer (keep it alive until synchronize())."""
         n = arr.nbytes if nbytes is None else nbytes
-        fn = _lib.dxtex_memcpy_h2d if sync else _lib.dxtex_memcpy_h2d_async
+        fn = self._lib.dxtex_memcpy_h2d if sync else self._lib.dxtex_memcpy_h2d_async
         self._check(fn(self._h, dst_ptr, arr.ctypes.data, n), "upload")
 
     def download(self, arr, src_ptr, nbytes=None, sync=False):
         n = arr.nbytes if nbytes is None else nbytes
-        fn = _lib.dxtex_memcpy_d2h if sync else _lib.dxtex_memcpy_d2h_async
+        fn = self._lib.dxtex_memcpy_d2h if sync else self._lib.dxtex_memcpy_d2h_async
         self._check(fn(self._h, arr.ctypes.data, src_ptr, n), "download")
 
     def copy_rows_device(self, dst_ptr, dst_pitch, src_ptr, src_pitch, row_bytes, rows):
-        self._check(_lib.dxtex_copy_rows_device(self._h, dst_ptr, dst_pitch, src_ptr, src_pitch, row_bytes, rows), "copy_rows_device")
+        self._check(self._lib.dxtex_copy_rows_device(self._h, dst_ptr, dst_pitch, src_ptr, src_pitch, row_bytes, rows), "copy_rows_device")
 
     def alpha_all_opaque_device(self, images):
         arr = (Image * len(images))(*images)
         out = ctypes.c_int(0)
-        self._check(_lib.dxtex_alpha_all_opaque_device(self._h, arr, len(images), ctypes.byref(out)), "alpha_all_opaque_device")
+        self._check(self._lib.dxtex_alpha_all_opaque_device(self._h, arr, len(images), ctypes.byref(out)), "alpha_all_opaque_device")
         return bool(out.value)
 
     def transfer_bytes(self, reset=False):
         """(host -> device bytes, device -> host bytes) this context has moved since creation / the last reset."""
         up, down = ctypes.c_uint64(0), ctypes.c_uint64(0)
-        self._check(_lib.dxtex_ctx_transfer_bytes(self._h, ctypes.byref(up), ctypes.byref(down), 1 if reset else 0), "transfer_bytes")
+        self._check(self._lib.dxtex_ctx_transfer_bytes(self._h, ctypes.byref(up), ctypes.byref(down), 1 if reset else 0), "transfer_bytes")
         return int(up.value), int(down.value)
 
     # -- Compress -----------------------------------------------------------------------------------
@@ -269,7 +270,7 @@ class Context:
         """GPUCompressBC::Prepare's role: allocate the search scratch and staging for `count` images of this shape now.
         Returns the bytes of device memory the context holds afterwards."""
         held = ctypes.c_size_t(0)
-        self._check(_lib.dxtex_ctx_prepare(self._h, width, height, src_format, dst_format, flags, count, ctypes.byref(held)), "prepare")
+        self._check(self._lib.dxtex_ctx_prepare(self._h, width, height, src_format, dst_format, flags, count, ctypes.byref(held)), "prepare")
         return held.value
 
     def compress(self, pixels, width, height, src_format, dst_format, flags=0, threshold=0.5, src_row_pitch=None):
@@ -279,7 +280,7 @@ class Context:
         rp, sp = compute_pitch(dst_format, width, height)
         out = np.zeros(sp, np.uint8)
         dst = Image(width, height, dst_format, rp, sp, out.ctypes.data)
-        self._check(_lib.dxtex_compress(self._h, ctypes.byref(src), ctypes.byref(dst), flags, threshold), "compress")
+        self._check(self._lib.dxtex_compress(self._h, ctypes.byref(src), ctypes.byref(dst), flags, threshold), "compress")
         return out
 
     def compress_into(self, pixels, width, height, src_format, out, dst_format, flags=0, threshold=0.5):
@@ -288,18 +289,18 @@ class Context:
         rp, sp = compute_pitch(dst_format, width, height)
         assert out.flags["C_CONTIGUOUS"] and out.nbytes >= sp
         dst = Image(width, height, dst_format, rp, sp, out.ctypes.data)
-        self._check(_lib.dxtex_compress(self._h, ctypes.byref(src), ctypes.byref(dst), flags, threshold), "compress")
+        self._check(self._lib.dxtex_compress(self._h, ctypes.byref(src), ctypes.byref(dst), flags, threshold), "compress")
 
     def compress_device(self, src_ptr, width, height, src_format, dst_ptr, dst_format, flags=0, threshold=0.5, src_row_pitch=None):
         src = device_image(src_ptr, width, height, src_format, src_row_pitch)
         dst = device_image(dst_ptr, width, height, dst_format)
-        self._check(_lib.dxtex_compress_device(self._h, ctypes.byref(src), ctypes.byref(dst), flags, threshold), "compress_device")
+        self._check(self._lib.dxtex_compress_device(self._h, ctypes.byref(src), ctypes.byref(dst), flags, threshold), "compress_device")
 
     def compress_many_device(self, srcs, dsts, flags=0, threshold=0.5):
         n = len(srcs)
         a = (Image * n)(*srcs)
         b = (Image * n)(*dsts)
-        self._check(_lib.dxtex_compress_many_device(self._h, a, b, n, flags, threshold), "compress_many_device")
+        self._check(self._lib.dxtex_compress_many_device(self._h, a, b, n, flags, threshold), "compress_many_device")
 
     def compress_many(self, images, width, height, src_format, dst_format, flags=0, threshold=0.5):
         """Array of same-sized host images -> list of BC payloads, through dxtex_compress_many (the cfg5 entry point: chunks of the
@@ -310,7 +311,7 @@ class Context:
         outs = [np.zeros(sp, np.uint8) for _ in range(n)]
         srcs = (Image * n)(*[_host_image(im, width, height, src_format) for im in images])
         dsts = (Image * n)(*[Image(width, height, dst_format, rp, sp, o.ctypes.data) for o in outs])
-        self._check(_lib.dxtex_compress_many(self._h, srcs, dsts, n, flags, threshold), "compress_many")
+        self._check(self._lib.dxtex_compress_many(self._h, srcs, dsts, n, flags, threshold), "compress_many")
         return outs
 
     def compress_array(self, items, dst_format, flags=0, threshold=0.5):
@@ -325,21 +326,21 @@ class Context:
             o = np.zeros(sp, np.uint8); outs.append(o)
             dsts.append(Image(w, h, dst_format, rp, sp, o.ctypes.data))
         a = (Image * n)(*srcs); b = (Image * n)(*dsts)
-        self._check(_lib.dxtex_compress_many(self._h, a, b, n, flags, threshold), "compress_many")
+        self._check(self._lib.dxtex_compress_many(self._h, a, b, n, flags, threshold), "compress_many")
         return outs
 
     def encode_blocks(self, bc_format, rgba, flags=0, threshold=0.5):
         rgba = np.ascontiguousarray(rgba, np.float32).reshape(-1, 16, 4)
         n = rgba.shape[0]
         out = np.zeros((n, F.BC_BLOCK_BYTES[bc_format]), np.uint8)
-        self._check(_lib.dxtex_encode_blocks(self._h, bc_format, flags, threshold, rgba.ctypes.data, n, out.ctypes.data), "encode_blocks")
+        self._check(self._lib.dxtex_encode_blocks(self._h, bc_format, flags, threshold, rgba.ctypes.data, n, out.ctypes.data), "encode_blocks")
         return out
 
     def decode_blocks(self, bc_format, blocks):
         blocks = np.ascontiguousarray(blocks, np.uint8).reshape(-1, F.BC_BLOCK_BYTES[bc_format])
         n = blocks.shape[0]
         out = np.zeros((n, 16, 4), np.float32)
-        self._check(_lib.dxtex_decode_blocks(self._h, bc_format, blocks.ctypes.data, n, out.ctypes.data), "decode_blocks")
+        self._check(self._lib.dxtex_decode_blocks(self._h, bc_format, blocks.ctypes.data, n, out.ctypes.data), "decode_blocks")
         return out
 
     def decompress(self, payload, width, height, bc_format, dst_format):
@@ -348,20 +349,20 @@ class Context:
         rp, sp = compute_pitch(dst_format, width, height)
         out = np.zeros(sp, np.uint8)
         dst = Image(width, height, dst_format, rp, sp, out.ctypes.data)
-        self._check(_lib.dxtex_decompress(self._h, ctypes.byref(src), ctypes.byref(dst)), "decompress")
+        self._check(self._lib.dxtex_decompress(self._h, ctypes.byref(src), ctypes.byref(dst)), "decompress")
         return out
 
     def decompress_device(self, src_ptr, width, height, bc_format, dst_ptr, dst_format):
         src = device_image(src_ptr, width, height, bc_format)
         dst = device_image(dst_ptr, width, height, dst_format)
-        self._check(_lib.dxtex_decompress_device(self._h, ctypes.byref(src), ctypes.byref(dst)), "decompress_device")
+        self._check(self._lib.dxtex_decompress_device(self._h, ctypes.byref(src), ctypes.byref(dst)), "decompress_device")
 
     def compute_mse_device(self, a_ptr, a_format, b_ptr, b_format, width, height):
         """Per-channel MSE (4 doubles) of two device images of the same size."""
         a = device_image(a_ptr, width, height, a_format)
         b = device_image(b_ptr, width, height, b_format)
         out = (ctypes.c_double * 4)()
-        self._check(_lib.dxtex_compute_mse_device(self._h, ctypes.byref(a), ctypes.byref(b), out), "compute_mse_device")
+        self._check(self._lib.dxtex_compute_mse_device(self._h, ctypes.byref(a), ctypes.byref(b), out), "compute_mse_device")
         return np.array(list(out), np.float64)
 
     # -- GenerateMipMaps / Convert / Resize ---------------------------------------------------------
@@ -379,13 +380,13 @@ class Context:
             levels.append(Image(w, h, fmt, rp, sp, buf.ctypes.data))
             w, h = max(1, w >> 1), max(1, h >> 1)
         arr = (Image * nlevels)(*levels)
-        self._check(_lib.dxtex_generate_mips(self._h, arr, nlevels, filter_flags), "generate_mips")
+        self._check(self._lib.dxtex_generate_mips(self._h, arr, nlevels, filter_flags), "generate_mips")
         return bufs
 
     def generate_mips_device(self, levels, filter_flags):
         """levels: list of device Images (capi.device_image) forming a mip chain; fills levels[1:] from levels[0]."""
         arr = (Image * len(levels))(*levels)
-        self._check(_lib.dxtex_generate_mips_device(self._h, arr, len(levels), filter_flags), "generate_mips_device")
+        self._check(self._lib.dxtex_generate_mips_device(self._h, arr, len(levels), filter_flags), "generate_mips_device")
 
     def convert(self, pixels, width, height, src_format, dst_format, filter_flags=0, threshold=0.5):
         pixels = np.ascontiguousarray(pixels)
@@ -393,7 +394,7 @@ class Context:
         rp, sp = compute_pitch(dst_format, width, height)
         out = np.zeros(sp, np.uint8)
         dst = Image(width, height, dst_format, rp, sp, out.ctypes.data)
-        self._check(_lib.dxtex_convert(self._h, ctypes.byref(src), ctypes.byref(dst), filter_flags, threshold), "convert")
+        self._check(self._lib.dxtex_convert(self._h, ctypes.byref(src), ctypes.byref(dst), filter_flags, threshold), "convert")
         return out
 
     def generate_mips3d(self, volume, width, height, depth, fmt, nlevels, filter_flags):
@@ -409,7 +410,7 @@ class Context:
             vols.append(Volume(w, h, d, fmt, rp, sp, buf.ctypes.data))
             w, h, d = max(1, w >> 1), max(1, h >> 1), max(1, d >> 1)
         arr = (Volume * nlevels)(*vols)
-        self._check(_lib.dxtex_generate_mips3d(self._h, arr, nlevels, filter_flags), "generate_mips3d")
+        self._check(self._lib.dxtex_generate_mips3d(self._h, arr, nlevels, filter_flags), "generate_mips3d")
         return bufs
 
     def premultiply_alpha(self, pixels, width, height, fmt, flags=0):
@@ -419,7 +420,7 @@ class Context:
         rp, sp = compute_pitch(fmt, width, height)
         out = np.zeros(sp, np.uint8)
         dst = Image(width, height, fmt, rp, sp, out.ctypes.data)
-        self._check(_lib.dxtex_premultiply_alpha(self._h, ctypes.byref(src), ctypes.byref(dst), flags), "premultiply_alpha")
+        self._check(self._lib.dxtex_premultiply_alpha(self._h, ctypes.byref(src), ctypes.byref(dst), flags), "premultiply_alpha")
         return out
 
     def scale_mips_alpha_for_coverage(self, levels, width, height, fmt, alpha_reference):
@@ -435,7 +436,7 @@ class Context:
             dsts.append(Image(w, h, fmt, rp, sp, o.ctypes.data))
             w, h = max(1, w >> 1), max(1, h >> 1)
         a = (Image * n)(*srcs); b = (Image * n)(*dsts)
-        self._check(_lib.dxtex_scale_mips_alpha_for_coverage(self._h, a, b, n, alpha_reference), "scale_mips_alpha_for_coverage")
+        self._check(self._lib.dxtex_scale_mips_alpha_for_coverage(self._h, a, b, n, alpha_reference), "scale_mips_alpha_for_coverage")
         return outs
 
     def resize(self, pixels, width, height, fmt, new_width, new_height, filter_flags=0):
@@ -444,5 +445,5 @@ class Context:
         rp, sp = compute_pitch(fmt, new_width, new_height)
         out = np.zeros(sp, np.uint8)
         dst = Image(new_width, new_height, fmt, rp, sp, out.ctypes.data)
-        self._check(_lib.dxtex_resize(self._h, ctypes.byref(src), ctypes.byref(dst), filter_flags), "resize")
+        self._check(self._lib.dxtex_resize(self._h, ctypes.byref(src), ctypes.byref(dst), filter_flags), "resize")
         return out

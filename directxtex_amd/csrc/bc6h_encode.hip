@@ -32,8 +32,12 @@ namespace
 {
 using namespace bc6h;
 
-// A task's quantised endpoints as six 16-bit fields: every mode's endpoint precision is at most 16 bits (ms_aInfo, :1051-1067), unsigned
-// formats hold 0 ... 2^prec - 1 and signed ones -(2^(prec-1)) ... 2^(prec-1) - 1, so the extension on the way back is the format's.
+// A task's quantised endpoints as six 16-bit fields: every mode's endpoint precision is at most 16 bits (ms_aInfo, :1051-1067); Quantize leaves
+// unsigned formats in 0 ... 2^prec - 1 and signed ones in -(2^(prec-1) - 1) ... 2^(prec-1) - 1, so the extension on the way back is the format's.
+// One exception: PerturbOne tries every value in [0, 2^prec) whatever the signedness (:2112-2118), so with SF16 and the 16-bit one-region mode
+// a search can END on a component above 32767. The reference keeps such endpoints and drops them at EndPointsFit (NBits = 17 > 16, :2408); here
+// the field would wrap, so the search kernels mark the record instead (ep16_overflows -> Rec6::err = -1, an error is never negative) and
+// bc6h_post_kernel treats the marked result as not fitting: the unoptimised endpoints stand, as in the reference.
 // (Round 3 kept them as six ints: 72 bytes of records per task, 1.2 GB written by every mode's pre and read by its post.)
 struct Ep16 { uint32_t a01, a2b0, b12; };
 __device__ __forceinline__ Ep16 pack_ep16(const int (&A)[3], const int (&B)[3])
@@ -49,6 +53,10 @@ __device__ __forceinline__ void unpack_ep16(const Ep16& e, bool sg, int (&A)[3],
     const auto lo = [sg](uint32_t w) { return sg ? int(int16_t(w & 0xFFFFu)) : int(w & 0xFFFFu); };
     const auto hi = [sg](uint32_t w) { return sg ? (int(w) >> 16) : int(w >> 16); };
     A[0] = lo(e.a01); A[1] = hi(e.a01); A[2] = lo(e.a2b0); B[0] = hi(e.a2b0); B[1] = lo(e.b12); B[2] = hi(e.b12);
+}
+__device__ __forceinline__ bool ep16_overflows(bool sg, const int (&A)[3], const int (&B)[3])
+{
+    return sg && (A[0] > 32767 || A[1] > 32767 || A[2] > 32767 || B[0] > 32767 || B[1] > 32767 || B[2] > 32767);
 }
 struct Rec6 { Ep16 ep; float err; };                               // 16 bytes per task: the search's start, then its result
 struct Best6 { float err; uint32_t mode; uint64_t lo, hi; };       // 24 bytes per block; mode = position of the winner's mode in the encoder's order
@@ -513,10 +521,12 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     const uint32_t ti = a.tinfo[t];
     const bool ownSearched = (ti >> 24) != 0u || (ti & kDoneBit6) != 0u;
     EndPts opt = o.ep;
+    bool optOverflow = false;            // the search ended outside the signed 16-bit range (see Ep16): EndPointsFit fails in the reference
     if (ownSearched)
     {
         const Rec6 rec = a.recs[t];
         unpack_ep16(rec.ep, sg, opt.A, opt.B);
+        optOverflow = rec.err < 0.0f;
     }
     // A candidate the search never ran for either region (pruned, does not fit, error already 0: subset size 0 in the task list)
     // still has its unoptimised endpoints: it either cannot win (its lower bound exceeds an error on the table, or it is not
@@ -547,7 +557,7 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
 #pragma unroll
     for (int c = 0; c < 3; ++c) b0[c] = REGIONS2 ? __shfl(opt.A[c], lane & ~1) : opt.A[c];
     const EndPts optT = a.mode.transformed ? transform_forward(opt, int(region), b0) : opt;
-    bool fitOpt = endpoints_fit(optT, int(region), a.mode, sg);
+    bool fitOpt = endpoints_fit(optT, int(region), a.mode, sg) && !optOverflow;
     if (REGIONS2) { const int partner = __shfl_xor(int(fitOpt), 1); fitOpt = fitOpt && (partner != 0); }
     const bool useOpt = fitOpt && (optTot < orgTot);
     const float err = useOpt ? optTot : orgTot;
@@ -651,6 +661,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a, uint32_t w
             if (st.ch >= 3)
             {
                 a.recs[myTask].ep = pack_ep16(st.ep.A, st.ep.B);
+                if (ep16_overflows(sg, st.ep.A, st.ep.B)) a.recs[myTask].err = -1.0f;
                 myTask = 0xFFFFFFFFu;
             }
         }
@@ -885,6 +896,7 @@ __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel
             if (st.ch >= 3)
             {
                 a.recs[myTask].ep = pack_ep16(st.ep.A, st.ep.B);
+                if (ep16_overflows(SG, st.ep.A, st.ep.B)) a.recs[myTask].err = -1.0f;
                 myTask = 0xFFFFFFFFu;
             }
         }
@@ -968,6 +980,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_wave_kernel(Bc6hArgs a, uint3
         if (lane == 0)
         {
             a.recs[myTask].ep = pack_ep16(st.ep.A, st.ep.B);
+            if (ep16_overflows(sg, st.ep.A, st.ep.B)) a.recs[myTask].err = -1.0f;
         }
     }
 }

@@ -1056,7 +1056,19 @@ hipError_t launch_resize_tail(const MipLevel* levels, int nlevels, int format, u
                               const MipLevel* twoHigh, hipStream_t stream)
 {
     if (nlevels < 2) return hipSuccess;
-    if (filterMode == 0x300000u || (filterMode == 0x400000u && resize_half_tail_applies(levels, nlevels, format, filterFlags)))
+    const bool halving = (filterMode == 0x300000u || filterMode == 0x400000u) && resize_half_tail_applies(levels, nlevels, format, filterFlags);
+    if (filterMode == 0x300000u && !halving)
+    {
+        // a cubic chain the one-workgroup form does not cover (not an exact-halving RGBA8 clamp chain): one launch per level, as GenerateMipMaps does above the tail
+        for (int k = 1; k < nlevels; ++k)
+        {
+            const hipError_t e = launch_resize(levels[k - 1].pixels, levels[k - 1].pitch, levels[k - 1].width, levels[k - 1].height, levels[k].pixels, levels[k].pitch,
+                                               levels[k].width, levels[k].height, format, filterMode, filterFlags, true, nullptr, stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    if (halving)
     {
         // the LDS tail: RGBA8, no sRGB, every level an exact halving (cubic: clamp addressing; admitted by the caller, checked again here)
         CubicTailArgs c;

@@ -13,7 +13,7 @@
 #include <cstring>
 #include "../../directxtex_amd/csrc/bc67_tables.h"
 #include "../../directxtex_amd/csrc/bc7_core.h"
-#include "../../directxtex_amd/csrc/bc7_bound2.h"
+#include "../../tools/bc7_bound2.h"
 
 using namespace dxtex;
 using namespace dxtex::bc7;

@@ -1,5 +1,7 @@
-// A tighter exact pruning bound for BC7 (round 4: derived, checked on the host, NOT yet called by the kernels - bc7_encode.hip does not
-// include this file; tests/cpp/bc7_bound_check.cpp and tools/bc7_prune_stats.cpp do).
+// A tighter exact pruning bound for BC7 - DEVELOPMENT MATERIAL, not part of the product (round 4: derived and checked on the host; round 5:
+// moved out of directxtex_amd/csrc because no kernel uses it - its free 4-means term would remove 3 - 4 ms of mode 3's search for about 2 ms
+// of fp64 sorting and dynamic programming per image in `pre`). tests/cpp/bc7_bound_check.cpp keeps it under the
+// property test (never above the error of any palette), tools/bc7_prune_stats.cpp measures what it would prune.
 //
 // subset_lower_bound (bc7_core.h) is the residual of the best-fit line minus the rounding slack: it ignores that a palette has only N
 // points on its line. For a palette on a line of direction u the texels' squared distances to the REAL line points split exactly into
@@ -18,7 +20,7 @@
 // Host statistics (tools/bc7_prune_stats.cpp, 1 500 blocks of the benchmark image, against the final error of every candidate of the lockstep
 // search): 0 bounds above a final error; mode 3's searched share of its unpruned cost 77.7 % -> 69.1 % (free term), 63.1 % (fixed weights).
 #pragma once
-#include "bc7_core.h"
+#include "../directxtex_amd/csrc/bc7_core.h"
 
 namespace dxtex
 {

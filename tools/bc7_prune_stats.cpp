@@ -17,7 +17,7 @@
 #include <cmath>
 #include "../directxtex_amd/csrc/bc67_tables.h"
 #include "../directxtex_amd/csrc/bc7_core.h"
-#include "../directxtex_amd/csrc/bc7_bound2.h"
+#include "bc7_bound2.h"
 using namespace dxtex; using namespace dxtex::bc7;
 
 struct HB { float f[64]; uint32_t ldr[16]; };
