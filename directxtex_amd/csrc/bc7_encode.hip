@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(256, DXTEX_ROUGH_WGS) bc7_rough_kernel(Bc7Args
 //   post    (lane = task, natural order): FixEndpointPBits + AssignIndices of the optimised endpoints, org-vs-opt
 //           decision over the subsets of a candidate (lane shuffles), first minimum over the block's candidates
 //           (butterfly), EmitBlock by the winning lane -> per-mode candidate slot.
-struct TaskRec { uint32_t A, B; int err; uint32_t np; };     // 16 bytes
+struct TaskRec { uint32_t A, B; int err; int orgErr; };      // 16 bytes: the search's start and then its result; orgErr = error of the unoptimised endpoints
+                                                             // (pre -> post, the search kernels leave it alone)
 
 template<int MODE, int IM> struct TaskMap
 {
@@ -331,7 +332,9 @@ __device__ __forceinline__ bool task_geometry(const Bc7Args& a, uint32_t nb, uin
 }
 
 // Refine's first half for one task, from the block's float + 8-bit texels (LDS or registers).
-template<int MODE, int IM>
+// ASSIGN = false: the unoptimised endpoints only (Quantize + FixEndpointPBits), without AssignIndices - post takes their error from the task
+// record and only the block's winner, if it stands with them, needs their indices (org_indices).
+template<int MODE, int IM, bool ASSIGN = true>
 __device__ __forceinline__ void task_org(const float* fpx, const uint32_t* pix, uint32_t mask, uint32_t anchor, uint32_t rot,
                                          SubsetResult& res, int& np, bool wantRegion, Region& rgOut, Block16& b16Out, const uint2* seed = nullptr)
 {
@@ -352,7 +355,8 @@ __device__ __forceinline__ void task_org(const float* fpx, const uint32_t* pix, 
             A = (A & 0x00FFFFFFu) | (mn << 24);
             B = (B & 0x00FFFFFFu) | (mx << 24);
         }
-        refine_pre<MODE, IM>(b16Out, A, B, 0u, res);
+        if (ASSIGN) refine_pre<MODE, IM>(b16Out, A, B, 0u, res);
+        else fix_pbits<MODE>(quantize_endpoint<MODE>(A), quantize_endpoint<MODE>(B), res.orgA, res.orgB);
         np = 16;
     }
     else
@@ -363,7 +367,8 @@ __device__ __forceinline__ void task_org(const float* fpx, const uint32_t* pix, 
         else if (rgOut.np == 1) { A = pix[rgOut.pos(0)]; B = A; }
         else if (rgOut.np == 2) { A = pix[rgOut.pos(0)]; B = pix[rgOut.pos(1)]; }
         else seed_endpoints<true>(fpx, mask, A, B);
-        refine_pre<MODE, IM>(rgOut, A, B, anchor, res);
+        if (ASSIGN) refine_pre<MODE, IM>(rgOut, A, B, anchor, res);
+        else fix_pbits<MODE>(quantize_endpoint<MODE>(A), quantize_endpoint<MODE>(B), res.orgA, res.orgB);
         np = rgOut.np;
     }
 }
@@ -398,7 +403,8 @@ __global__ void __launch_bounds__(256, (MODE == 4 || MODE == 5) ? DXTEX_PP45_WGS
     const uint32_t nb = nbFirst + blk;
     uint32_t shape, mask, anchor, rot;
     const bool active = (blk < uint32_t(BPW)) && task_geometry<MODE, IM>(a, nb, r, shape, mask, anchor, rot);
-    TaskRec rec; rec.A = 0; rec.B = 0; rec.err = 0; rec.np = 0;
+    TaskRec rec; rec.A = 0; rec.B = 0; rec.err = 0; rec.orgErr = 0;
+    uint32_t npLive = 0;               // subset size if the task is to be searched, else 0
     if (!__any(active))
     {
         // nothing to do for these blocks (another phase owns them, mode 7 on opaque blocks, Encode already returned): the task
@@ -418,9 +424,9 @@ __global__ void __launch_bounds__(256, (MODE == 4 || MODE == 5) ? DXTEX_PP45_WGS
         task_org<MODE, IM>(nullptr, &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
                            (TM::NS == 2) ? a.seeds + uint64_t(nb) * 64 + (TM::LIST ? 32 : 0) + r
                                          : (TM::NS == 1) ? a.seeds1 + uint64_t(nb) * 2 : a.seeds3 + uint64_t(nb) * 192 + shape * 3 + (r % TM::G));
-        rec.A = res.orgA; rec.B = res.orgB; rec.err = res.orgErr;
-        rec.np = (res.orgErr != 0) ? uint32_t(np) : 0u;        // error 0: OptimizeOne cannot move the endpoints
-        if (a.prune && rec.np)
+        rec.A = res.orgA; rec.B = res.orgB; rec.err = res.orgErr; rec.orgErr = res.orgErr;
+        npLive = (res.orgErr != 0) ? uint32_t(np) : 0u;        // error 0: OptimizeOne cannot move the endpoints
+        if (a.prune && npLive)
         {
             lb = subset_lower_bound(&sL[wave][blk * 16], mask, rot, (MODE >= 6) ? 4 : 3);
             if (MODE == 4 || MODE == 5)
@@ -450,12 +456,12 @@ __global__ void __launch_bounds__(256, (MODE == 4 || MODE == 5) ? DXTEX_PP45_WGS
 #pragma unroll
         for (int d = TM::G; d < TM::TPB && d < 64; d <<= 1) table = min(table, __shfl_xor(table, d));
         if (nb < a.nblocks && blk < uint32_t(BPW)) table = min(table, a.bestErr[nb]);
-        if (candLb > table) rec.np = 0;
+        if (candLb > table) npLive = 0;
     }
     if (nb < a.nblocks && blk < uint32_t(BPW))
     {
         a.recs[uint64_t(nb) * TM::TPB + r] = rec;
-        a.tinfo[uint64_t(nb) * TM::TPB + r] = (mask & 0xFFFFu) | (rot << 16) | (rec.np << 24);
+        a.tinfo[uint64_t(nb) * TM::TPB + r] = (mask & 0xFFFFu) | (rot << 16) | (npLive << 24);
     }
 }
 
@@ -1214,13 +1220,17 @@ __global__ void __launch_bounds__(256, (MODE == 4 || MODE == 5) ? DXTEX_PP45_WGS
     SubsetResult res;
     res.orgErr = 0; res.optErr = 0; res.orgA = res.orgB = res.optA = res.optB = 0;
     res.orgIdx1 = res.orgIdx2 = res.optIdx1 = res.optIdx2 = 0;
+    // The unoptimised half of Refine was evaluated by pre (its error is in the task record); here only its endpoints are re-derived, and
+    // AssignIndices runs once per task - for the optimised endpoints - instead of twice. The indices of the unoptimised endpoints are needed
+    // only where the block's winning candidate stands with them (below).
+    int np = 0; Region rg; Block16 b16;
     if (active)
     {
-        int np; Region rg; Block16 b16;
-        task_org<MODE, IM>(nullptr, &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
-                           (TM::NS == 2) ? a.seeds + uint64_t(nb) * 64 + (TM::LIST ? 32 : 0) + r
-                                         : (TM::NS == 1) ? a.seeds1 + uint64_t(nb) * 2 : a.seeds3 + uint64_t(nb) * 192 + shape * 3 + (r % TM::G));
+        task_org<MODE, IM, false>(nullptr, &sL[wave][blk * 16], mask, anchor, rot, res, np, true, rg, b16,
+                                  (TM::NS == 2) ? a.seeds + uint64_t(nb) * 64 + (TM::LIST ? 32 : 0) + r
+                                                : (TM::NS == 1) ? a.seeds1 + uint64_t(nb) * 2 : a.seeds3 + uint64_t(nb) * 192 + shape * 3 + (r % TM::G));
         const TaskRec rec = a.recs[uint64_t(nb) * TM::TPB + r];
+        res.orgErr = rec.orgErr;
         if (TM::NS == 1) refine_post<MODE, IM>(b16, rec.A, rec.B, 0u, res);
         else refine_post<MODE, IM>(rg, rec.A, rec.B, anchor, res);
     }
@@ -1230,6 +1240,22 @@ __global__ void __launch_bounds__(256, (MODE == 4 || MODE == 5) ? DXTEX_PP45_WGS
     for (int d = 1; d < TM::G; d <<= 1) { orgTot += __shfl_xor(orgTot, d); optTot += __shfl_xor(optTot, d); }
     const bool useOpt = optTot < orgTot;
     const int err = useOpt ? optTot : orgTot;
+    // evaluation order inside D3DX_BC7::Encode: modes ascending, then rotation, index mode, shape rank
+    const uint32_t sub = candidate_sub<MODE, IM>(rank);
+    const uint32_t key = active ? ((uint32_t(err) << 7) | sub) : 0xFFFFFFFFu;
+    uint32_t best = key;
+#pragma unroll
+    for (int d = 1; d < TM::TPB && d < 64; d <<= 1) best = min(best, uint32_t(__shfl_xor(int(best), d)));
+    // the winner keeps its unoptimised endpoints: their indices (and the anchor fix-up of the endpoints) now
+    const bool needOrg = active && key == best && !useOpt;
+    if (__any(needOrg))
+    {
+        if (needOrg)
+        {
+            if (TM::NS == 1) (void)assign_indices<MODE, IM>(b16, res.orgA, res.orgB, 0u, res.orgIdx1, res.orgIdx2);
+            else (void)assign_indices<MODE, IM>(rg, res.orgA, res.orgB, anchor, res.orgIdx1, res.orgIdx2);
+        }
+    }
     const uint32_t myA = useOpt ? res.optA : res.orgA, myB = useOpt ? res.optB : res.orgB;
     const uint64_t myIdx1 = useOpt ? res.optIdx1 : res.orgIdx1, myIdx2 = useOpt ? res.optIdx2 : res.orgIdx2;
     // gather the candidate's endpoints and indices into its subset-0 lane
@@ -1244,12 +1270,6 @@ __global__ void __launch_bounds__(256, (MODE == 4 || MODE == 5) ? DXTEX_PP45_WGS
                             (uint64_t(uint32_t(__shfl_down(int(uint32_t(myIdx1 >> 32)), s))) << 32);
         idx1 |= oi;
     }
-    // evaluation order inside D3DX_BC7::Encode: modes ascending, then rotation, index mode, shape rank
-    const uint32_t sub = candidate_sub<MODE, IM>(rank);
-    const uint32_t key = active ? ((uint32_t(err) << 7) | sub) : 0xFFFFFFFFu;
-    uint32_t best = key;
-#pragma unroll
-    for (int d = 1; d < TM::TPB && d < 64; d <<= 1) best = min(best, uint32_t(__shfl_xor(int(best), d)));
 
     if (blk < uint32_t(BPW) && nb < a.nblocks && region == 0)
     {
