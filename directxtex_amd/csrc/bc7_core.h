@@ -1758,24 +1758,29 @@ struct Bits128
 // candidate or mode of the block has already reached can never win D3DX_BC7::Encode's "first minimum" (:2835-2848), so
 // its OptimizeOne search (:3045-3110) is skipped - the output does not change, only work that cannot matter is dropped.
 // Returned rounded down (and shaved) so that float rounding can only weaken the bound.
-DXTEX_HD int subset_lower_bound(const uint32_t* pix, uint32_t mask16, uint32_t rot, int C)
+template<int C>
+DXTEX_HD int subset_lower_bound_c(const uint32_t* pix, uint32_t mask16, uint32_t rot)
 {
+    // C == 3: the fourth channel does not take part; every term it would contribute is an exact zero (0 * finite, x + 0), so the
+    // three-channel form below is the same number with 18 instead of 40 products per squaring
+    constexpr bool Q = (C == 4);
     uint32_t n = 0, s[4] = { 0, 0, 0, 0 }, ss[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };    // ss: (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
     for (uint32_t i = 0; i < 16; ++i)
         if ((mask16 >> i) & 1u)
         {
             const uint32_t p = rotate_pixel(pix[i], rot);
-            const uint32_t c0 = p & 0xFFu, c1 = (p >> 8) & 0xFFu, c2 = (p >> 16) & 0xFFu, c3 = (C == 4) ? (p >> 24) : 0u;
-            ++n; s[0] += c0; s[1] += c1; s[2] += c2; s[3] += c3;
-            ss[0] += c0 * c0; ss[1] += c0 * c1; ss[2] += c0 * c2; ss[3] += c0 * c3;
-            ss[4] += c1 * c1; ss[5] += c1 * c2; ss[6] += c1 * c3;
-            ss[7] += c2 * c2; ss[8] += c2 * c3; ss[9] += c3 * c3;
+            const uint32_t c0 = p & 0xFFu, c1 = (p >> 8) & 0xFFu, c2 = (p >> 16) & 0xFFu, c3 = Q ? (p >> 24) : 0u;
+            ++n; s[0] += c0; s[1] += c1; s[2] += c2;
+            ss[0] += c0 * c0; ss[1] += c0 * c1; ss[2] += c0 * c2;
+            ss[4] += c1 * c1; ss[5] += c1 * c2;
+            ss[7] += c2 * c2;
+            if (Q) { s[3] += c3; ss[3] += c0 * c3; ss[6] += c1 * c3; ss[8] += c2 * c3; ss[9] += c3 * c3; }
         }
     if (n < 2) return 0;
     // M = n * S, exact integers (|entries| <= 16 * 16 * 255^2)
-    const int M00 = int(n * ss[0]) - int(s[0] * s[0]), M01 = int(n * ss[1]) - int(s[0] * s[1]), M02 = int(n * ss[2]) - int(s[0] * s[2]), M03 = int(n * ss[3]) - int(s[0] * s[3]);
-    const int M11 = int(n * ss[4]) - int(s[1] * s[1]), M12 = int(n * ss[5]) - int(s[1] * s[2]), M13 = int(n * ss[6]) - int(s[1] * s[3]);
-    const int M22 = int(n * ss[7]) - int(s[2] * s[2]), M23 = int(n * ss[8]) - int(s[2] * s[3]), M33 = int(n * ss[9]) - int(s[3] * s[3]);
+    const int M00 = int(n * ss[0]) - int(s[0] * s[0]), M01 = int(n * ss[1]) - int(s[0] * s[1]), M02 = int(n * ss[2]) - int(s[0] * s[2]), M03 = Q ? int(n * ss[3]) - int(s[0] * s[3]) : 0;
+    const int M11 = int(n * ss[4]) - int(s[1] * s[1]), M12 = int(n * ss[5]) - int(s[1] * s[2]), M13 = Q ? int(n * ss[6]) - int(s[1] * s[3]) : 0;
+    const int M22 = int(n * ss[7]) - int(s[2] * s[2]), M23 = Q ? int(n * ss[8]) - int(s[2] * s[3]) : 0, M33 = Q ? int(n * ss[9]) - int(s[3] * s[3]) : 0;
     const int T = M00 + M11 + M22 + M33;
     if (T <= 0) return 0;
     const double inv = 1.0 / double(T);
@@ -1783,19 +1788,30 @@ DXTEX_HD int subset_lower_bound(const uint32_t* pix, uint32_t mask16, uint32_t r
            a22 = M22 * inv, a23 = M23 * inv, a33 = M33 * inv;
     for (int k = 0; k < 4; ++k)
     {
-        const double b00 = a00 * a00 + a01 * a01 + a02 * a02 + a03 * a03;
-        const double b01 = a00 * a01 + a01 * a11 + a02 * a12 + a03 * a13;
-        const double b02 = a00 * a02 + a01 * a12 + a02 * a22 + a03 * a23;
-        const double b03 = a00 * a03 + a01 * a13 + a02 * a23 + a03 * a33;
-        const double b11 = a01 * a01 + a11 * a11 + a12 * a12 + a13 * a13;
-        const double b12 = a01 * a02 + a11 * a12 + a12 * a22 + a13 * a23;
-        const double b13 = a01 * a03 + a11 * a13 + a12 * a23 + a13 * a33;
-        const double b22 = a02 * a02 + a12 * a12 + a22 * a22 + a23 * a23;
-        const double b23 = a02 * a03 + a12 * a13 + a22 * a23 + a23 * a33;
-        const double b33 = a03 * a03 + a13 * a13 + a23 * a23 + a33 * a33;
+        double b00 = a00 * a00 + a01 * a01 + a02 * a02;
+        double b01 = a00 * a01 + a01 * a11 + a02 * a12;
+        double b02 = a00 * a02 + a01 * a12 + a02 * a22;
+        double b11 = a01 * a01 + a11 * a11 + a12 * a12;
+        double b12 = a01 * a02 + a11 * a12 + a12 * a22;
+        double b22 = a02 * a02 + a12 * a12 + a22 * a22;
+        double b03 = 0.0, b13 = 0.0, b23 = 0.0, b33 = 0.0;
+        if (Q)
+        {
+            b00 += a03 * a03; b01 += a03 * a13; b02 += a03 * a23; b11 += a13 * a13; b12 += a13 * a23; b22 += a23 * a23;
+            b03 = a00 * a03 + a01 * a13 + a02 * a23 + a03 * a33;
+            b13 = a01 * a03 + a11 * a13 + a12 * a23 + a13 * a33;
+            b23 = a02 * a03 + a12 * a13 + a22 * a23 + a23 * a33;
+            b33 = a03 * a03 + a13 * a13 + a23 * a23 + a33 * a33;
+        }
         a00 = b00; a01 = b01; a02 = b02; a03 = b03; a11 = b11; a12 = b12; a13 = b13; a22 = b22; a23 = b23; a33 = b33;
     }
-    const double f2 = a00 * a00 + a11 * a11 + a22 * a22 + a33 * a33 + 2.0 * (a01 * a01 + a02 * a02 + a03 * a03 + a12 * a12 + a13 * a13 + a23 * a23);
+    double f2 = a00 * a00 + a11 * a11 + a22 * a22;
+    if (Q) f2 += a33 * a33;
+    double off = a01 * a01 + a02 * a02;
+    if (Q) off += a03 * a03;
+    off += a12 * a12;
+    if (Q) { off += a13 * a13; off += a23 * a23; }
+    f2 = f2 + 2.0 * off;
     double lam = sqrt(sqrt(sqrt(sqrt(sqrt(f2)))));          // ||N^16||_F ^ (1/16)
     lam = lam * (1.0 + 1e-9);
     if (lam >= 1.0) return 0;
@@ -1804,6 +1820,10 @@ DXTEX_HD int subset_lower_bound(const uint32_t* pix, uint32_t mask16, uint32_t r
     if (d <= 0.0) return 0;
     const double lb = d * d * 0.99999 - 1.0;
     return (lb > 0.0) ? int(lb) : 0;
+}
+DXTEX_HD int subset_lower_bound(const uint32_t* pix, uint32_t mask16, uint32_t rot, int C)
+{
+    return (C == 4) ? subset_lower_bound_c<4>(pix, mask16, rot) : subset_lower_bound_c<3>(pix, mask16, rot);
 }
 
 // The separate-alpha modes (4, 5) give the fourth slot of the (rotated) texel a scalar palette of K = 2^bits entries of its own.

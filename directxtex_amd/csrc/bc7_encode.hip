@@ -31,7 +31,8 @@ using namespace bc7;
 struct Cand { uint32_t err; uint32_t ord; uint64_t lo, hi; };   // ord = evaluation order inside D3DX_BC7::Encode
 
 enum : int { SLOT_M0 = 0, SLOT_M1, SLOT_M2, SLOT_M3, SLOT_M4A, SLOT_M4B, SLOT_M5, SLOT_M6, SLOT_M7, NUM_SLOTS };
-enum : int { LIST_BYTES = 64 };   // per block: [0..15] 3-bit list, [16..31] 2-bit list, [32] hasAlpha, [33..36] mode-0 list, [37] mode 6 first, [40..55] mode-2 list
+enum : int { LIST_BYTES = 64 };   // per block: [0..15] 3-bit list, [16..31] 2-bit list, [32] hasAlpha, [33..36] mode-0 list, [37] mode 6 first, [40..55] mode-2 list,
+                                  // [56..59] best 3-bit rough error (int; rough -> flag_count)
 
 enum : int { PHASE_ALL = 0, PHASE_EARLY = 1, PHASE_LATE = 2 };
 
@@ -204,7 +205,9 @@ __global__ void __launch_bounds__(256, DXTEX_ROUGH_WGS) bc7_rough_kernel(Bc7Args
             // Scheduling hint, not a result: mode 6 (one subset, RGBA on one line) runs BEFORE the two-subset modes for blocks
             // where it has a chance against them - its lower bound does not exceed the best 3-bit rough error - so that its
             // result can prune their candidates; elsewhere it runs last and is mostly pruned itself. See launch order below.
-            lst[37] = (hasAlpha || int64_t(subset_lower_bound(pix, 0xFFFFu, 0u, 4)) * 100 <= int64_t(ea) * a.early6Pct) ? 1 : 0;
+            // (decided by bc7_flag_count_kernel, a lane per block: on one lane of this wavefront the bound's fp64 arithmetic cost 1.2 of the
+            // kernel's 11.8 ms per 4096^2 image; what it needs from here is the best 3-bit rough error)
+            *reinterpret_cast<int*>(lst + 56) = ea;
         }
     }
 
@@ -1315,11 +1318,25 @@ __global__ void __launch_bounds__(256) bc7_block_seeds_kernel(Bc7Args a)
 // out[0] = number of blocks flagged for the early mode-6 phase (lists[37]), out[1] = number of blocks that have alpha (lists[32]).
 __global__ void __launch_bounds__(256) bc7_flag_count_kernel(Bc7Args a, uint32_t* out)
 {
+    // ... and decides lists[37] first: mode 6 goes early where its lower bound does not exceed early6Pct % of the best 3-bit rough error (or
+    // the block has alpha). A scheduling hint, not a result - see the rough kernel.
     uint32_t n = 0, m = 0;
     for (uint32_t nb = blockIdx.x * 256u + threadIdx.x; nb < a.nblocks; nb += gridDim.x * 256u)
     {
-        n += a.lists[uint64_t(nb) * LIST_BYTES + 37] ? 1u : 0u;
-        m += a.lists[uint64_t(nb) * LIST_BYTES + 32] ? 1u : 0u;
+        uint8_t* lst = a.lists + uint64_t(nb) * LIST_BYTES;
+        const bool hasAlpha = lst[32] != 0;
+        bool first = hasAlpha;
+        if (!first)
+        {
+            const uint4* px4 = reinterpret_cast<const uint4*>(a.px + uint64_t(nb) * 16);
+            const uint4 q0 = px4[0], q1 = px4[1], q2 = px4[2], q3 = px4[3];
+            const uint32_t px[16] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
+            const int ea = *reinterpret_cast<const int*>(lst + 56);
+            first = int64_t(subset_lower_bound(px, 0xFFFFu, 0u, 4)) * 100 <= int64_t(ea) * a.early6Pct;
+        }
+        lst[37] = first ? 1 : 0;
+        n += first ? 1u : 0u;
+        m += hasAlpha ? 1u : 0u;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { n += __shfl_xor(n, o); m += __shfl_xor(m, o); }
@@ -1649,7 +1666,7 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
             DXTEX_MARK("bc7_rough");
             hipLaunchKernelGGL(bc7_rough_kernel, dim3((a.nblocks + 3) / 4), dim3(256), 0, stream, a);
             (void)hipMemsetAsync(flagCount, 0, 256, stream);
-            hipLaunchKernelGGL(bc7_flag_count_kernel, dim3(std::min<uint32_t>(1024u, (a.nblocks + 255) / 256)), dim3(256), 0, stream, a, flagCount);
+            hipLaunchKernelGGL(bc7_flag_count_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, stream, a, flagCount);
         }
         else
         {
