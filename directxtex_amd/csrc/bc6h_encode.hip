@@ -678,6 +678,13 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a, uint32_t w
 // sixteen lanes take one list entry, lane k scores texel k (norm3 + scan_min, the functions of the plain kernel), and the per-texel errors
 // are summed in texel order along the sixteen lanes (a DPP row_shr:1 chain: the reference's fTotErr += fBestErr, :2074).
 constexpr int kFilterSlots = 32;          // list entries per round (a step with more passing candidates takes several rounds)
+// Texel k of the lane's region sits kColStride6 16-bit words after texel k - 1: 66 (33 dwords), not 64, so that the sixteen lanes of an exact
+// round - same owner column, texels 0 ... 15 - read sixteen different banks (at 64 they all hit one; the bound's loops, where a lane reads
+// its own column, are conflict-free either way)
+#if !defined(DXTEX_F6_STRIDE)
+#define DXTEX_F6_STRIDE 66
+#endif
+constexpr int kColStride6 = DXTEX_F6_STRIDE;
 struct FilterLds
 {
     float4 pal[kFilterSlots][6];          // r[8], g[8], b[8] of a passing candidate
@@ -704,6 +711,17 @@ __device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L,
     const uint32_t n0 = uint32_t(__popcll(b0)), total = n0 + uint32_t(__popcll(b1));
     const uint32_t s0 = uint32_t(__popcll(b0 & below)), s1 = n0 + uint32_t(__popcll(b1 & below));
     const int grp = lane >> 4, k = lane & 15;
+    // Regions of at most eight texels (the smaller region of most shapes; the task list is sorted by size, so a wavefront's regions are nearly
+    // all of one size) take HALF a row of sixteen lanes each: eight list entries per round instead of four, and a sum chain of seven steps
+    // instead of fifteen. Wave-uniform per call; the arithmetic per texel and the order of the sum are the same.
+#if defined(DXTEX_F6_NO_PACK)
+    const bool packed = false;
+#else
+    const bool packed = __ballot((pass0 || pass1) && np > 8) == 0ull;
+#endif
+    const int kk = packed ? (k & 7) : k;
+    const uint32_t perRound = packed ? 8u : 4u;
+    const uint32_t slotInRound = packed ? uint32_t(grp * 2 + (k >> 3)) : uint32_t(grp);
     for (uint32_t first = 0; first < total; first += kFilterSlots)
     {
         const uint32_t cnt = min(total - first, uint32_t(kFilterSlots));
@@ -711,19 +729,19 @@ __device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L,
         if (in0) { writePal(0, reinterpret_cast<float*>(L.pal[s0 - first])); L.meta[s0 - first] = uint32_t(lane) | (uint32_t(np) << 8); }
         if (in1) { writePal(1, reinterpret_cast<float*>(L.pal[s1 - first])); L.meta[s1 - first] = uint32_t(lane) | (uint32_t(np) << 8); }
         __syncthreads();                  // one wavefront per workgroup: orders the LDS traffic, costs no barrier
-        for (uint32_t g = 0; g < cnt; g += 4)
+        for (uint32_t g = 0; g < cnt; g += perRound)
         {
 #if defined(DXTEX_DEV)
             if (stats && lane == 0) atomicAdd(stats + 3, 1u);
 #endif
-            const uint32_t sl = g + uint32_t(grp);
+            const uint32_t sl = g + slotInRound;
             const uint32_t meta = (sl < cnt) ? L.meta[sl] : 0u;
             const int owner = int(meta & 63u), onp = int(meta >> 8);
             float err = 0.0f;
-            if (k < onp)
+            if (kk < onp)
             {
-                const int16_t* t = cols + owner + k * 64;
-                const float tr = float(t[0]), tg = float(t[16 * 64]), tb = float(t[32 * 64]);
+                const int16_t* t = cols + owner + kk * kColStride6;
+                const float tr = float(t[0]), tg = float(t[16 * kColStride6]), tb = float(t[32 * kColStride6]);
                 const float4 r0 = L.pal[sl][0], r1 = L.pal[sl][1], g0 = L.pal[sl][2], g1 = L.pal[sl][3], c0 = L.pal[sl][4], c1 = L.pal[sl][5];
                 const float pr[8] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w }, pg[8] = { g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w },
                             pb[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
@@ -734,10 +752,16 @@ __device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L,
             }
             // fTotErr += fBestErr, texel by texel (:2074): lane j of the group takes lane j - 1's partial sum and adds its texel's error -
             // the reference's order; texels past the region's end add +0.0f, which changes nothing, so lane 15 ends with the total
+            // (half rows: lane 8 of a row has kk == 0 and never takes lane 7's sum, so the two halves' chains do not meet)
             float S = err;
 #pragma unroll
-            for (int j = 1; j < 16; ++j) { const float t = row_shr1(S); S = (k == j) ? t + err : S; }
-            if (k == 15 && sl < cnt) L.tot[sl] = S;
+            for (int j = 1; j < 8; ++j) { const float t = row_shr1(S); S = (kk == j) ? t + err : S; }
+            if (!packed)
+            {
+#pragma unroll
+                for (int j = 8; j < 16; ++j) { const float t = row_shr1(S); S = (kk == j) ? t + err : S; }
+            }
+            if (kk == (packed ? 7 : 15) && sl < cnt) L.tot[sl] = S;
         }
         __syncthreads();
         if (in0) e0 = L.tot[s0 - first];
@@ -830,7 +854,7 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
 template<bool SG>
 __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel(Bc6hArgs a)
 {
-    __shared__ int16_t sCols[48 * 64];        // 6 KiB + the list: sixteen wavefronts per CU
+    __shared__ int16_t sCols[48 * kColStride6];        // 6.2 KiB + the list: sixteen wavefronts per CU
     __shared__ FilterLds sList;
     const int lane = threadIdx.x;
     const uint32_t live = a.counters[34];
@@ -839,7 +863,7 @@ __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel
     int16_t* slot = &sCols[lane];
     EndPts zero; for (int c = 0; c < 3; ++c) { zero.A[c] = 0; zero.B[c] = 0; }
     Perturb6 st = perturb6_begin(zero, 0.0f);
-    Texels16 tx; tx.r = slot; tx.g = slot + 16 * 64; tx.b = slot + 32 * 64; tx.stride = 64; tx.np = 0;
+    Texels16 tx; tx.r = slot; tx.g = slot + 16 * kColStride6; tx.b = slot + 32 * kColStride6; tx.stride = kColStride6; tx.np = 0;
     Bound6 bd; bd.o[0] = bd.o[1] = bd.o[2] = 0.0f; bd.pp = 0.0f; bd.pre[0] = bd.pre[1] = bd.pre[2] = 0.0f;
     uint32_t myTask = 0xFFFFFFFFu;
     const int prec = a.mode.prec;
@@ -871,7 +895,7 @@ __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel
                 {
                     const int i = __ffs(int(mask)) - 1;
                     mask &= mask - 1u;
-                    slot[np * 64] = int16_t(int(gp[i])); slot[(16 + np) * 64] = int16_t(int(gp[16 + i])); slot[(32 + np) * 64] = int16_t(int(gp[32 + i]));
+                    slot[np * kColStride6] = int16_t(int(gp[i])); slot[(16 + np) * kColStride6] = int16_t(int(gp[16 + i])); slot[(32 + np) * kColStride6] = int16_t(int(gp[32 + i]));
                     ++np;
                 }
                 tx.np = np;
