@@ -482,6 +482,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads (cfg3 / cfg4 / cfg5 shard / BC1-5 / decode) reported next to the headline")
     ap.add_argument("--cfg5-images", type=int, default=128, help="images of the cfg5 shard every rank compresses after the timed region (0 = skip); "
                     "128 = a rank's whole share of the 1024 images at 8 GPUs, sixteen chunks of dxtex_compress_many's double-buffered pipeline")
+    ap.add_argument("--inprocess-contexts", type=int, default=0, help="contexts of the in-process split leg (dxtex_compress_multi); 0 = one per visible GPU, "
+                    "reported when there are at least two")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo lets several "
                     "ranks share one GPU in the tests)")
     args = ap.parse_args()
@@ -606,6 +608,43 @@ def main():
                 split = {"error": repr(e)}
             raise            # a rank that stopped here would leave the others waiting in the section's collectives until the backend times out
 
+    # The same split inside ONE process (dxtex_compress_multi: a context per visible GPU, a thread per context, stripes of block rows of a host
+    # image): what a caller of the host layer's Compress(devices, n, ...) gets. Rank 0 drives every GPU while the other ranks wait, so it is
+    # reported next to the rank-per-GPU split, not instead of it. Host memory in and out: PCIe-inclusive.
+    inproc = None
+    ngpu = torch.cuda.device_count()
+    ndev = args.inprocess_contexts if args.inprocess_contexts > 0 else ngpu       # (--inprocess-contexts N: N contexts dealt over the visible GPUs, for boxes with one GPU)
+    if ndev > 1 and not args.no_extra:
+        barrier()
+        if rank == 0:
+            try:
+                img0 = make_image(0)
+                extra_ctxs = [dx.Context((local_rank + i) % ngpu) for i in range(1, ndev)]
+                all_ctxs = [ctx] + extra_ctxs
+                out = np.zeros(sp, np.uint8)
+                times = {}
+                for n in sorted({1, 2, ndev}):
+                    dx.capi.compress_multi(all_ctxs[:n], img0, WIDTH, HEIGHT, dx.DXGI_FORMAT_R8G8B8A8_UNORM, dx.DXGI_FORMAT_BC7_UNORM, 0, 0.5, out=out)     # warm-up: scratch and staging of the stripe's size
+                    best = 1e9
+                    for _ in range(2):
+                        t1 = time.perf_counter()
+                        dx.capi.compress_multi(all_ctxs[:n], img0, WIDTH, HEIGHT, dx.DXGI_FORMAT_R8G8B8A8_UNORM, dx.DXGI_FORMAT_BC7_UNORM, 0, 0.5, out=out)
+                        best = min(best, time.perf_counter() - t1)
+                    times[n] = best
+                gold = golden_case("cfg2_bc7_4096")
+                ok = None
+                if gold and hashlib.sha256(img0.tobytes()).hexdigest() == gold["input_sha256"]:
+                    ok = band_sha(out, WIDTH, HEIGHT) == gold["bands"]
+                inproc = {"ms": round(times[ndev] * 1e3, 3), "Mtexels_s": round(WIDTH * HEIGHT / times[ndev] / 1e6, 2), "n_contexts": ndev, "n_gpus_visible": ngpu, "scaling": "strong",
+                          "ms_by_contexts": {str(k): round(v * 1e3, 3) for k, v in times.items()}, "identical_to_reference_golden": ok,
+                          "workload": "ONE 4096^2 RGBA8 image in host memory -> BC7 through dxtex_compress_multi: a context per GPU in this process, a thread per context, "
+                                      "stripes of block rows; upload, encode and download inside the time"}
+                for c in extra_ctxs:
+                    c.close()
+            except Exception as e:
+                inproc = {"error": repr(e)}
+        barrier()
+
     if rank == 0:
         # ---- roofline of the dominant kernel -----------------------------------------------------------
         per_launch = {k: (ms / max(1, n)) for k, (ms, n) in kernels.items()}
@@ -728,6 +767,8 @@ def main():
                 extra["other_workloads_error"] = repr(e)
         if split:
             extra.setdefault("other_workloads", {})["bc7_4096_split"] = split
+        if inproc:
+            extra.setdefault("other_workloads", {})["bc7_4096_inprocess_split"] = inproc
         if cfg5:
             if n_gpus == 1 and not args.no_cpu_baseline and "error" not in cfg5:
                 try:

@@ -77,6 +77,8 @@ _SIGS = {
     "dxtex_encode_blocks": (ctypes.c_int32, [_ctx_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dxtex_decode_blocks": (ctypes.c_int32, [_ctx_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "dxtex_generate_mips": (ctypes.c_int32, [_ctx_p, _P(Image), ctypes.c_size_t, ctypes.c_uint32]),
+    "dxtex_compress_multi": (ctypes.c_int32, [_P(_ctx_p), ctypes.c_size_t, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
+    "dxtex_generate_mips_multi": (ctypes.c_int32, [_P(_ctx_p), ctypes.c_size_t, _P(Image), ctypes.c_size_t, ctypes.c_uint32]),
     "dxtex_generate_mips_device": (ctypes.c_int32, [_ctx_p, _P(Image), ctypes.c_size_t, ctypes.c_uint32]),
     "dxtex_compress_many": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_size_t, ctypes.c_uint32, ctypes.c_float]),
     "dxtex_convert": (ctypes.c_int32, [_ctx_p, _P(Image), _P(Image), ctypes.c_uint32, ctypes.c_float]),
@@ -164,6 +166,45 @@ def device_image(ptr, width, height, fmt, row_pitch=None):
         rows = sp // rp
         rp, sp = row_pitch, row_pitch * rows
     return Image(width, height, fmt, rp, sp, ptr)
+
+
+def _ctx_array(contexts):
+    libs = {id(c._lib) for c in contexts}
+    assert len(libs) == 1, "the contexts of one call must come from one library"
+    return (_ctx_p * len(contexts))(*[c._h for c in contexts])
+
+
+def compress_multi(contexts, pixels, width, height, src_format, dst_format, flags=0, threshold=0.5, out=None):
+    """ONE host image over several contexts (dxtex_compress_multi: stripes of block rows, a thread per context) -> the BC payload,
+    byte for byte what contexts[0].compress returns."""
+    pixels = np.ascontiguousarray(pixels)
+    src = _host_image(pixels, width, height, src_format)
+    rp, sp = compute_pitch(dst_format, width, height)
+    if out is None:
+        out = np.zeros(sp, np.uint8)
+    dst = Image(width, height, dst_format, rp, sp, out.ctypes.data)
+    c0 = contexts[0]
+    c0._check(c0._lib.dxtex_compress_multi(_ctx_array(contexts), len(contexts), ctypes.byref(src), ctypes.byref(dst), flags, threshold), "compress_multi")
+    return out
+
+
+def generate_mips_multi(contexts, level0, width, height, fmt, nlevels, filter_flags=0):
+    """dxtex_generate_mips_multi: the chain of a host image with its large levels cut into stripes of rows over the contexts; returns the
+    levels as uint8 arrays (tight pitch), identical to contexts[0].generate_mips."""
+    bufs, levels = [], []
+    w, h = width, height
+    for i in range(nlevels):
+        rp, sp = compute_pitch(fmt, w, h)
+        buf = np.zeros(sp, np.uint8)
+        if i == 0:
+            buf[:] = np.ascontiguousarray(level0).view(np.uint8).reshape(-1)[:sp]
+        bufs.append(buf)
+        levels.append(Image(w, h, fmt, rp, sp, buf.ctypes.data))
+        w, h = max(1, w >> 1), max(1, h >> 1)
+    arr = (Image * nlevels)(*levels)
+    c0 = contexts[0]
+    c0._check(c0._lib.dxtex_generate_mips_multi(_ctx_array(contexts), len(contexts), arr, nlevels, filter_flags), "generate_mips_multi")
+    return bufs
 
 
 class Context:

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace dxtex;
@@ -1619,5 +1620,92 @@ dxtex_hresult dxtex_ctx_transfer_bytes(dxtex_ctx* ctx, uint64_t* h2d_bytes, uint
     if (d2h_bytes) *d2h_bytes = ctx->d2hBytes;
     if (reset) ctx->h2dBytes = ctx->d2hBytes = 0;
     return DXTEX_S_OK;
+}
+} // extern "C"
+
+// ---- ONE image over several contexts (one process, N GPUs - or N contexts of one GPU) -------------------------------------------------
+// Blocks are independent (DirectXTexCompress.cpp:257-281 is the reference's own split of an image's block rows over OpenMP threads), and a
+// destination row of a 2:1 filter needs a bounded window of source rows (cubic: one source row above the pair it covers and one below,
+// filters.h:176-179). So an image in host memory is cut into stripes of (block) rows, one per context, each stripe goes through the
+// single-context entry point on a thread of its own, and the stripes land in the caller's destination: the bytes of the one-context call.
+namespace
+{
+template<class F>
+dxtex_hresult run_stripes(size_t n, F&& stripe)
+{
+    std::vector<dxtex_hresult> hr(n, DXTEX_S_OK);
+    std::vector<std::thread> workers;
+    for (size_t i = 1; i < n; ++i) workers.emplace_back([&, i] { hr[i] = stripe(i); });
+    hr[0] = stripe(0);
+    for (std::thread& t : workers) t.join();
+    for (dxtex_hresult h : hr) if (h != DXTEX_S_OK) return h;
+    return DXTEX_S_OK;
+}
+} // namespace
+
+extern "C" {
+dxtex_hresult dxtex_compress_multi(dxtex_ctx* const* ctxs, size_t nctx, const dxtex_image* src, const dxtex_image* dst, uint32_t flags, float threshold)
+{
+    if (!ctxs || !nctx || !ctxs[0]) return DXTEX_E_POINTER;
+    for (size_t i = 0; i < nctx; ++i) if (!ctxs[i]) return DXTEX_E_POINTER;
+    if (!src || !dst) return fail(ctxs[0], DXTEX_E_INVALIDARG, "null image");
+    const size_t nbh = (src->height + 3) / 4;
+    const size_t n = std::max<size_t>(1, std::min(nctx, nbh));
+    if (n == 1 || src->width != dst->width || src->height != dst->height) return dxtex_compress(ctxs[0], src, dst, flags, threshold);      // (a mismatch is the single call's error to report)
+    return run_stripes(n, [&](size_t i) -> dxtex_hresult
+    {
+        const size_t b0 = nbh * i / n, b1 = nbh * (i + 1) / n;            // block rows [b0, b1)
+        if (b1 <= b0) return DXTEX_S_OK;
+        const size_t y0 = b0 * 4, rows = std::min(src->height, b1 * 4) - y0;
+        dxtex_image s = *src, d = *dst;
+        s.pixels = src->pixels + y0 * src->rowPitch; s.height = rows; s.slicePitch = src->rowPitch * rows;
+        d.pixels = dst->pixels + b0 * dst->rowPitch; d.height = rows; d.slicePitch = dst->rowPitch * (b1 - b0);
+        return dxtex_compress(ctxs[i], &s, &d, flags, threshold);
+    });
+}
+
+dxtex_hresult dxtex_generate_mips_multi(dxtex_ctx* const* ctxs, size_t nctx, const dxtex_image* levels, size_t nlevels, uint32_t filter)
+{
+    if (!ctxs || !nctx) return DXTEX_E_POINTER;
+    for (size_t i = 0; i < nctx; ++i) if (!ctxs[i]) return DXTEX_E_POINTER;
+    uint32_t mode = 0;
+    const dxtex_hresult hc = check_mips(ctxs[0], levels, nlevels, filter, &mode);
+    if (hc != DXTEX_S_OK) return hc;
+    const uint32_t explicitFilter = (filter & ~kFilterModeMask) | mode;      // the sub-chains below must not choose again (a stripe is not a power of two high)
+    // A level is split while it is an exact halving, large enough to be worth a transfer per context, and filtered by a kernel whose taps
+    // are a fixed window around the destination row: point / box (the 2 x 2 source texels), linear and cubic with clamp addressing in V
+    // (u = (y + 0.5) * 2 - 0.5 is exact in fp32, so a stripe's rows get the weights the whole image's rows get). Destination rows
+    // [d0, d1) come from source rows [2 d0 - 2, 2 d1 + 2): the stripe is resized with one extra destination row on either inner side, whose
+    // own taps run into the stripe's clamped edge and which is thrown away. The triangle filter (a gather over the whole axis) and V wrap /
+    // mirror go to the first context whole, as does the chain below kSplitMinRows.
+    constexpr size_t kSplitMinRows = 256;
+    const bool splittable = nctx > 1 && (mode == DXTEX_FILTER_POINT || mode == DXTEX_FILTER_BOX || mode == DXTEX_FILTER_LINEAR || mode == DXTEX_FILTER_CUBIC) &&
+                            !(filter & (DXTEX_FILTER_WRAP_V | DXTEX_FILTER_MIRROR_V));
+    size_t lv = 1;
+    for (; splittable && lv < nlevels; ++lv)
+    {
+        const dxtex_image& S = levels[lv - 1];
+        const dxtex_image& D = levels[lv];
+        if (S.width != 2 * D.width || S.height != 2 * D.height || D.height < kSplitMinRows || D.height < 4 * nctx) break;
+        const dxtex_hresult hr = run_stripes(nctx, [&](size_t i) -> dxtex_hresult
+        {
+            const size_t d0 = D.height * i / nctx, d1 = D.height * (i + 1) / nctx;
+            if (d1 <= d0) return DXTEX_S_OK;
+            const size_t e0 = d0 ? d0 - 1 : 0, e1 = std::min(D.height, d1 + 1);           // with the throw-away rows
+            dxtex_image s = S, d = D;
+            s.pixels = S.pixels + 2 * e0 * S.rowPitch; s.height = 2 * (e1 - e0); s.slicePitch = S.rowPitch * s.height;
+            d.height = e1 - e0; d.slicePitch = D.rowPitch * d.height;
+            if (e0 == d0 && e1 == d1) { d.pixels = D.pixels + d0 * D.rowPitch; return dxtex_resize(ctxs[i], &s, &d, explicitFilter); }
+            std::vector<uint8_t> tmp(d.slicePitch);
+            d.pixels = tmp.data();
+            const dxtex_hresult h = dxtex_resize(ctxs[i], &s, &d, explicitFilter);
+            if (h != DXTEX_S_OK) return h;
+            std::memcpy(D.pixels + d0 * D.rowPitch, tmp.data() + (d0 - e0) * D.rowPitch, (d1 - d0) * D.rowPitch);
+            return DXTEX_S_OK;
+        });
+        if (hr != DXTEX_S_OK) return hr;
+    }
+    if (lv >= nlevels) return DXTEX_S_OK;
+    return dxtex_generate_mips(ctxs[0], levels + (lv - 1), nlevels - (lv - 1), explicitFilter);       // the rest of the chain from the last level filled
 }
 } // extern "C"

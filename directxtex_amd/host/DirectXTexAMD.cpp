@@ -882,6 +882,66 @@ HRESULT GenerateMipMaps(Device& device, const Image& baseImage, TEX_FILTER_FLAGS
     return hr;
 }
 
+// ---- one image over several devices (in-process strong scaling; dxtex_compress_multi / dxtex_generate_mips_multi) -------------------------
+namespace
+{
+bool Contexts(Device* const* devices, size_t ndevices, std::vector<dxtex_ctx*>& out)
+{
+    if (!devices || !ndevices) return false;
+    for (size_t i = 0; i < ndevices; ++i)
+    {
+        if (!devices[i] || !*devices[i]) return false;
+        out.push_back(devices[i]->Get());
+    }
+    return true;
+}
+}
+
+HRESULT Compress(Device* const* devices, size_t ndevices, const Image& srcImage, DXGI_FORMAT format, TEX_COMPRESS_FLAGS compress, float threshold, ScratchImage& image) noexcept
+{
+    try
+    {
+        std::vector<dxtex_ctx*> ctxs;
+        if (!Contexts(devices, ndevices, ctxs)) return E_POINTER;
+        if (IsCompressed(srcImage.format) || !IsCompressed(format) || srcImage.format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
+        if (!IsKnown(srcImage.format) || !IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
+        HRESULT hr = image.Initialize2D(format, srcImage.width, srcImage.height, 1, 1);
+        if (FAILED(hr)) return hr;
+        const Image* img = image.GetImage(0, 0, 0);
+        if (!img) { image.Release(); return E_POINTER; }
+        const dxtex_image s = View(srcImage), d = View(*img);
+        hr = dxtex_compress_multi(ctxs.data(), ctxs.size(), &s, &d, uint32_t(compress), threshold);
+        if (FAILED(hr)) image.Release();
+        return hr;
+    }
+    catch (...) { image.Release(); return E_OUTOFMEMORY; }
+}
+
+HRESULT GenerateMipMaps(Device* const* devices, size_t ndevices, const Image& baseImage, TEX_FILTER_FLAGS filter, size_t levels, ScratchImage& mipChain) noexcept
+{
+    try
+    {
+        std::vector<dxtex_ctx*> ctxs;
+        if (!Contexts(devices, ndevices, ctxs)) return E_POINTER;
+        if (baseImage.format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
+        if (!baseImage.pixels) return E_POINTER;
+        if (!CalculateMipLevels(baseImage.width, baseImage.height, levels)) return E_INVALIDARG;
+        if (levels <= 1) return E_INVALIDARG;
+        if (IsCompressed(baseImage.format) || !IsKnown(baseImage.format)) return HRESULT_E_NOT_SUPPORTED;
+        HRESULT hr = mipChain.Initialize2D(baseImage.format, baseImage.width, baseImage.height, 1, levels);
+        if (FAILED(hr)) return hr;
+        const Image* top = mipChain.GetImage(0, 0, 0);
+        for (size_t y = 0; y < baseImage.height; ++y)
+            std::memcpy(top->pixels + y * top->rowPitch, baseImage.pixels + y * baseImage.rowPitch, std::min(top->rowPitch, baseImage.rowPitch));
+        std::vector<dxtex_image> views(levels);
+        for (size_t l = 0; l < levels; ++l) views[l] = View(*mipChain.GetImage(l, 0, 0));
+        hr = dxtex_generate_mips_multi(ctxs.data(), ctxs.size(), views.data(), levels, uint32_t(filter));
+        if (FAILED(hr)) mipChain.Release();
+        return hr;
+    }
+    catch (...) { mipChain.Release(); return E_OUTOFMEMORY; }
+}
+
 namespace
 {
 template <class Space>

@@ -243,6 +243,13 @@ HRESULT CompressEx(Device& device, const Image& srcImage, DXGI_FORMAT format, co
                    StatusCallback statusCallBack = nullptr);
 HRESULT CompressEx(Device& device, const Image* srcImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format,
                    const CompressOptions& options, ScratchImage& cImages, StatusCallback statusCallBack = nullptr);
+// ONE image over several devices (normally one Device per GPU of the node): the image's block rows - for GenerateMipMaps the destination
+// rows of its large levels, with the filter's halo of source rows - are dealt out over the devices, each stripe on a thread of its own
+// (dxtex_compress_multi / dxtex_generate_mips_multi). The role of CompressBC_Parallel's split over OpenMP threads
+// (DirectXTexCompress.cpp:257-281); the result is byte for byte that of the single-device overload.
+HRESULT Compress(Device* const* devices, size_t ndevices, const Image& srcImage, DXGI_FORMAT format, TEX_COMPRESS_FLAGS compress, float threshold,
+                 ScratchImage& cImage) noexcept;
+HRESULT GenerateMipMaps(Device* const* devices, size_t ndevices, const Image& baseImage, TEX_FILTER_FLAGS filter, size_t levels, ScratchImage& mipChain) noexcept;
 // format == DXGI_FORMAT_UNKNOWN picks the default target (DefaultDecompress, DirectXTexCompress.cpp:377-421)
 HRESULT Decompress(Device& device, const Image& cImage, DXGI_FORMAT format, ScratchImage& image) noexcept;
 HRESULT Decompress(Device& device, const Image* cImages, size_t nimages, const TexMetadata& metadata, DXGI_FORMAT format, ScratchImage& images) noexcept;

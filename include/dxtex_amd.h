@@ -191,6 +191,17 @@ dxtex_hresult dxtex_convert_device(dxtex_ctx* ctx, const dxtex_image* src, const
 dxtex_hresult dxtex_resize(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter);
 dxtex_hresult dxtex_resize_device(dxtex_ctx* ctx, const dxtex_image* src, const dxtex_image* dst, uint32_t filter);
 
+/* ---- one image over several contexts (in-process strong scaling) --------------------------------
+ * The role of the reference's own split of one image over its workers (CompressBC_Parallel hands block rows to OpenMP threads,
+ * DirectXTexCompress.cpp:257-281): `ctxs` are nctx contexts - normally one per GPU of the node, several on one GPU work too - and the
+ * image in HOST memory is cut into stripes of block rows (Compress) or destination rows with the filter's halo of source rows
+ * (GenerateMipMaps: exact-halving levels of at least 256 rows, point / box / linear / cubic, no V wrap / mirror; everything else runs on
+ * ctxs[0]). Each stripe goes through the single-context entry point on its own thread; the result is byte for byte that of
+ * dxtex_compress / dxtex_generate_mips on one context. Errors: the first failing stripe's code (its text in that context's last_error). */
+dxtex_hresult dxtex_compress_multi(dxtex_ctx* const* ctxs, size_t nctx, const dxtex_image* src, const dxtex_image* dst,
+                                   uint32_t flags, float threshold);
+dxtex_hresult dxtex_generate_mips_multi(dxtex_ctx* const* ctxs, size_t nctx, const dxtex_image* levels, size_t nlevels, uint32_t filter);
+
 /* ComputeMSE (DirectXTexMisc.cpp:27-176) for two same-size images on the device: per-channel MSE in
  * mse[4] over [0,1] floats. Used for PSNR reporting without a D2H round trip. */
 dxtex_hresult dxtex_compute_mse_device(dxtex_ctx* ctx, const dxtex_image* a, const dxtex_image* b, double mse[4]);

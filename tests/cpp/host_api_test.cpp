@@ -193,6 +193,29 @@ static int gpu_run(const std::string& outdir)
     CHECK(resizedAll.GetImageCount() == 1 && resizedAll.GetMetadata().mipLevels == 1 && resizedAll.GetMetadata().width == 40);
     dump(outdir + "/resized_linear_array.bin", resizedAll.GetPixels(), resizedAll.GetPixelsSize());
 
+    // one image over three devices (three contexts of this GPU): the single-device bytes (dxtex_compress_multi / dxtex_generate_mips_multi)
+    {
+        Device d1, d2;
+        CHECK(SUCCEEDED(d1.Create(0)) && SUCCEEDED(d2.Create(0)));
+        Device* const devs[3] = { &dev, &d1, &d2 };
+        ScratchImage multi;
+        CHECK(Compress(devs, 3, src, DXGI_FORMAT_BC7_UNORM, TEX_COMPRESS_DEFAULT, TEX_THRESHOLD_DEFAULT, multi) == S_OK);
+        CHECK(multi.GetPixelsSize() == bc7.GetPixelsSize() && !std::memcmp(multi.GetPixels(), bc7.GetPixels(), bc7.GetPixelsSize()));
+        const size_t BW = 512, BH = 1024;
+        std::vector<uint8_t> big(BW * BH * 4);
+        for (size_t i = 0; i < big.size(); ++i) { s = s * 1664525u + 1013904223u; big[i] = uint8_t((i >> 7) + ((s >> 24) & 31)); }
+        Image bsrc; bsrc.width = BW; bsrc.height = BH; bsrc.format = DXGI_FORMAT_R8G8B8A8_UNORM; bsrc.rowPitch = BW * 4; bsrc.slicePitch = big.size(); bsrc.pixels = big.data();
+        for (TEX_FILTER_FLAGS f : { TEX_FILTER_CUBIC, TEX_FILTER_BOX })
+        {
+            ScratchImage one, three;
+            CHECK(GenerateMipMaps(dev, bsrc, f, 0, one) == S_OK);
+            CHECK(GenerateMipMaps(devs, 3, bsrc, f, 0, three) == S_OK);
+            CHECK(one.GetPixelsSize() == three.GetPixelsSize() && !std::memcmp(one.GetPixels(), three.GetPixels(), one.GetPixelsSize()));
+        }
+        CHECK(Compress(devs, 0, src, DXGI_FORMAT_BC7_UNORM, TEX_COMPRESS_DEFAULT, TEX_THRESHOLD_DEFAULT, multi) == E_POINTER);
+        std::printf("multi-device OK\n");
+    }
+
     // premultiplied alpha and alpha-to-coverage preserving mips
     ScratchImage pm, cov;
     CHECK(PremultiplyAlpha(dev, src, TEX_PMALPHA_DEFAULT, pm) == S_OK);

@@ -26,6 +26,7 @@ def test_host_layer_cpu_rules():
 def test_host_layer_on_gpu(tmp_path, oracle):
     r = subprocess.run([_exe(), "gpu", str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "multi-device OK" in r.stdout               # one image over three Devices == the single-device bytes
     assert "resident pipeline OK" in r.stdout          # DeviceScratchImage steps == the host-memory steps checked below, one upload / one download
     W, H = 96, 64
     rd = lambda n: np.fromfile(os.path.join(tmp_path, n), np.uint8)
