@@ -521,6 +521,16 @@ __device__ unsigned int g_wtHist[WT_KEYS][256];
 #define WT_DONE() do { } while (0)
 #define WT_END() do { } while (0)
 #endif
+// Which search kernels look for PerturbOne calls that cannot change anything (bc7_core.h, flat_call): mode 6, whose alpha channel is such a
+// channel in every opaque block (2.49 -> 2.30 ms on the benchmark image). Measured and left out: modes 4 / 5 - their colour endpoints start from
+// the fit of the UNROTATED texels (:3552-3568), so the swapped-in constant of rotations 1 - 3 is not exact when its calls come, and the test
+// costs what the few later calls save; two- and three-subset regions seldom have a constant channel at all.
+#if !defined(DXTEX_FLAT_SKIP)
+#define DXTEX_FLAT_SKIP 1
+#endif
+template<int MODE, int IM, int CHSET>
+constexpr bool kFlatSkip = DXTEX_FLAT_SKIP != 0 && MODE == 6 && CHSET == CH_ALL;
+
 // The PERTURB phase of OptimizeOne (:3060-3105) for the channels of CHSET, over every live task of the mode.
 template<int MODE, int IM, int CHSET>
 __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
@@ -539,6 +549,7 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
     SlotRegion rg; rg.base = slotCol; rg.np = 0; rg.p2sum = 0;
     int base = 0;
     uint32_t myTask = 0xFFFFFFFFu;
+    uint32_t flatMask = 0, flatVals = 0;            // whole-block modes: the texel channels that are constant over the block (flat_channels)
     WaveQueue q; q.lo = q.hi = 0; q.drained = false;
     for (;;)
     {
@@ -557,6 +568,29 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
                 int other;
                 base = loop_base<MODE, IM, CHSET>(rg, st.optA, st.optB, &other);
                 if (loop_is_settled<CHSET>(r.err, other)) myTask = 0xFFFFFFFFu;     // scalar slot already exact: the record stays as it is
+                if constexpr (kFlatSkip<MODE, IM, CHSET>) flatMask = flat_channels(rg, flatVals);
+            }
+        }
+        // PerturbOne calls on a channel that is constant over the block and already exact cannot change anything (bc7_core.h, flat_call): the
+        // lane's state moves past them without the 2 PREC - 1 evaluations - every call on alpha of an opaque block in mode 6, every call on the
+        // swapped-in constant of rotations 1 - 3 in modes 4 / 5. One nearest-entry evaluation (for all lanes of the wavefront) decides.
+        if constexpr (kFlatSkip<MODE, IM, CHSET>)
+        {
+            const bool fc = myTask != 0xFFFFFFFFu && flat_call<MODE, IM, CHSET>(st, flatMask, flatVals);
+            if (__any(fc))
+            {
+                const int nearest = eval_nearest<MODE, IM, CHSET>(rg, st, base);
+                if (fc && nearest == st.optErr)
+                {
+                    st = skip_flat_calls<MODE, IM, CHSET>(st);
+                    if (st.ch >= C::CH1)
+                    {
+                        TaskRec* r = a.recs + myTask;
+                        r->A = st.optA; r->B = st.optB; r->err = st.optErr;
+                        myTask = 0xFFFFFFFFu;
+                        WT_DONE();
+                    }
+                }
             }
         }
         if (__ballot(myTask != 0xFFFFFFFFu) == 0ull)
@@ -694,6 +728,7 @@ __global__ void __launch_bounds__(64, (MODE == 1) ? DXTEX_PF1_WAVES : 1) bc7_per
     SlotRegion rg; rg.base = slotCol; rg.np = 0; rg.p2sum = 0;
     int base = 0;
     uint32_t myTask = 0xFFFFFFFFu;
+    uint32_t flatMask = 0, flatVals = 0;
     WaveQueue q; q.lo = q.hi = 0; q.drained = false;
     for (;;)
     {
@@ -710,6 +745,26 @@ __global__ void __launch_bounds__(64, (MODE == 1) ? DXTEX_PF1_WAVES : 1) bc7_per
                 search_pickup<MODE, IM>(a, task, slotCol, rg);
                 st = perturb_begin<MODE, IM, CHSET>(r.A, r.B, r.err);
                 base = loop_base<MODE, IM, CHSET>(rg, st.optA, st.optB);
+                if constexpr (kFlatSkip<MODE, IM, CHSET>) flatMask = flat_channels(rg, flatVals);
+            }
+        }
+        if constexpr (kFlatSkip<MODE, IM, CHSET>)         // see bc7_perturb_kernel
+        {
+            const bool fc = myTask != 0xFFFFFFFFu && flat_call<MODE, IM, CHSET>(st, flatMask, flatVals);
+            if (__any(fc))
+            {
+                const int nearest = eval_nearest<MODE, IM, CHSET>(rg, st, base);
+                if (fc && nearest == st.optErr)
+                {
+                    st = skip_flat_calls<MODE, IM, CHSET>(st);
+                    if (st.ch >= C::CH1)
+                    {
+                        TaskRec* r = a.recs + myTask;
+                        r->A = st.optA; r->B = st.optB; r->err = st.optErr;
+                        myTask = 0xFFFFFFFFu;
+                        WT_DONE();
+                    }
+                }
             }
         }
         const bool busyL = myTask != 0xFFFFFFFFu;
