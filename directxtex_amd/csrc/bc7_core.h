@@ -1893,7 +1893,13 @@ DXTEX_HD int subset_lower_bound_c(const uint32_t* pix, uint32_t mask16, uint32_t
     lam = lam * (1.0 + 1e-9);
     if (lam >= 1.0) return 0;
     const double resid = double(T) * (1.0 - lam) / double(n);       // tr(S) - lambda_max(S), S = M / n
-    const double d = sqrt(resid) - 0.5 * sqrt(double(C) * double(n)) - 1e-3;
+    // The rounding slack is per channel that takes part. A channel that is CONSTANT over the subset has no variance and no covariance: the
+    // scatter matrix, its largest eigenvalue and the residual are those of the other channels alone, and the error on those channels alone
+    // (the constant channel's share is >= 0) is bounded by the same argument one dimension lower - the projection of the palette's line is a
+    // line there, its entries within 0.5 per channel of it. So only the channels that vary pay slack: alpha of an opaque block in mode 6, the
+    // swapped-in constant of rotations 1 - 3 in modes 4 / 5, grey or single-hue subsets anywhere (round 5).
+    const int varying = (M00 > 0 ? 1 : 0) + (M11 > 0 ? 1 : 0) + (M22 > 0 ? 1 : 0) + ((Q && M33 > 0) ? 1 : 0);
+    const double d = sqrt(resid) - 0.5 * sqrt(double(varying) * double(n)) - 1e-3;
     if (d <= 0.0) return 0;
     const double lb = d * d * 0.99999 - 1.0;
     return (lb > 0.0) ? int(lb) : 0;

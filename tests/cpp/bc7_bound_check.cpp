@@ -74,6 +74,18 @@ int main(int argc, char** argv)
             }
             px[i] = p;
         }
+        // a third of the blocks get one or two CONSTANT channels (alpha of an opaque block, grey ramps): the bound charges rounding slack
+        // only to the channels that vary, and palettes that move off the constant must not get below it
+        if (rnd() % 3 == 0)
+        {
+            const int c0 = rnd() % 4, c1 = (rnd() & 1) ? int(rnd() % 4) : c0;
+            const uint32_t v0 = (rnd() & 1) ? 255u : rnd() % 256, v1 = rnd() % 256;
+            for (int i = 0; i < 16; ++i)
+            {
+                px[i] = (px[i] & ~(0xFFu << (8 * c0))) | (v0 << (8 * c0));
+                if (c1 != c0) px[i] = (px[i] & ~(0xFFu << (8 * c1))) | (v1 << (8 * c1));
+            }
+        }
         const uint32_t mask = (rnd() % 3 == 0) ? 0xFFFFu : (kPart2Mask[rnd() % 64] ^ ((rnd() & 1) ? 0xFFFFu : 0u)) & 0xFFFFu;
         if (!mask) continue;
         const int C = (rnd() & 1) ? 3 : 4;

@@ -163,7 +163,8 @@ DXTEX_HD int subset_lower_bound_line(const uint32_t* pix, uint32_t mask16, uint3
             }
         }
     }
-    const double d = sqrt(G > 0.0 ? G : 0.0) - 0.5 * sqrt(double(C) * double(n)) - 1e-3;
+    const int varying = (M00 > 0 ? 1 : 0) + (M11 > 0 ? 1 : 0) + (M22 > 0 ? 1 : 0) + (M33 > 0 ? 1 : 0);      // as subset_lower_bound: only channels that vary pay rounding slack
+    const double d = sqrt(G > 0.0 ? G : 0.0) - 0.5 * sqrt(double(varying) * double(n)) - 1e-3;
     if (d <= 0.0) return 0;
     const double lb = d * d * 0.99999 - 1.0;
     return (lb > 0.0) ? int(lb) : 0;
