@@ -11,6 +11,9 @@
 #undef protected
 
 #include <cstdio>
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -212,8 +215,172 @@ static void encode_host(const float* fpx, bool isSigned, uint64_t& lo, uint64_t&
     }
 }
 
+#if defined(DXTEX_PRUNE_STATS6)
+// DEVELOPMENT STATISTICS (round 5): what would a tighter pruning bound be worth for BC6H? The kernels prune a candidate (mode, shape) when the sum of its
+// regions' lower bounds exceeds an error already on the table (bc6h_pre_kernel). The bound in use is the residual of the best-fit line minus the rounding
+// slack (region_lower_bound6); `line` adds the error ALONG the line - eight palette points against the texels' projections (free 8-means, exact dynamic
+// programme), minimised over the line's direction as tools/bc7_bound2.h derives it. Search cost = texels scored x (2 prec - 1), region 0 against all
+// sixteen texels (the reference's quirk); the second and third mode of a trio reuse the first one's search.
+static double g_costAll, g_costCur, g_costNew, g_lbCur, g_lbNew, g_errSum; static unsigned long long g_nCand, g_newBelow, g_violCur, g_violNew;
+static void scatter3(const Region6& rg, double& n, double (&mean)[3], double (&S)[3][3])
+{
+    n = rg.np; mean[0] = mean[1] = mean[2] = 0;
+    for (int k = 0; k < rg.np; ++k) { mean[0] += rg.r[k]; mean[1] += rg.g[k]; mean[2] += rg.b[k]; }
+    for (int c = 0; c < 3; ++c) mean[c] /= n;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) S[i][j] = 0;
+    for (int k = 0; k < rg.np; ++k)
+    {
+        const double d[3] = { rg.r[k] - mean[0], rg.g[k] - mean[1], rg.b[k] - mean[2] };
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) S[i][j] += d[i] * d[j];
+    }
+}
+static double kmeans8(double* t, int n)
+{
+    if (n <= 8) return 0.0;
+    std::sort(t, t + n);
+    double s1[17] = { 0 }, s2[17] = { 0 };
+    for (int i = 0; i < n; ++i) { s1[i + 1] = s1[i] + t[i]; s2[i + 1] = s2[i] + t[i] * t[i]; }
+    auto sse = [&](int i, int j) { const double m = s1[j + 1] - s1[i]; const double c = (s2[j + 1] - s2[i]) - m * m / double(j - i + 1); return c > 0 ? c : 0.0; };
+    double d[16], e[16];
+    for (int j = 0; j < n; ++j) d[j] = sse(0, j);
+    for (int k = 2; k <= 8; ++k)
+    {
+        for (int j = 0; j < n; ++j) { double best = (j < k) ? 0.0 : 1e300; for (int i = k - 1; i <= j; ++i) best = std::min(best, d[i - 1] + sse(i, j)); e[j] = best; }
+        for (int j = 0; j < n; ++j) d[j] = e[j];
+    }
+    return d[n - 1];
+}
+// returns (cur, line) lower bounds of one region
+static void region_bounds(const Region6& rg, double& cur, double& line)
+{
+    cur = line = 0.0;
+    if (rg.np < 2) return;
+    double n, mean[3], S[3][3]; scatter3(rg, n, mean, S);
+    const double trS = S[0][0] + S[1][1] + S[2][2];
+    if (!(trS > 0)) return;
+    double A[3][3], B[3][3], Q[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { A[i][j] = S[i][j] / trS; B[i][j] = A[i][j]; }
+    for (int k = 0; k < 4; ++k)
+    {
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double v = 0; for (int l = 0; l < 3; ++l) v += B[i][l] * B[l][j]; Q[i][j] = v; }
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[i][j] = Q[i][j];
+    }
+    double f2 = 0; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) f2 += B[i][j] * B[i][j];
+    const double lam = std::sqrt(std::sqrt(std::sqrt(std::sqrt(std::sqrt(f2))))) * (1.0 + 1e-9);
+    const double rPlain = lam < 1.0 ? trS * (1.0 - lam) : 0.0;
+    auto finish = [&](double G) { const double d = std::sqrt(G > 0 ? G : 0.0) - 3.0 * std::sqrt(n) - 1e-3; return d > 0 ? d * d * 0.9999 : 0.0; };
+    cur = finish(rPlain);
+    int jc = 0; for (int j = 1; j < 3; ++j) if (B[j][j] > B[jc][jc]) jc = j;
+    double u0[3] = { B[0][jc], B[1][jc], B[2][jc] };
+    const double nu = std::sqrt(u0[0] * u0[0] + u0[1] * u0[1] + u0[2] * u0[2]);
+    double G = rPlain;
+    if (nu > 1e-150)
+    {
+        for (int i = 0; i < 3; ++i) u0[i] /= nu;
+        double Su[3]; for (int i = 0; i < 3; ++i) Su[i] = S[i][0] * u0[0] + S[i][1] * u0[1] + S[i][2] * u0[2];
+        const double a = u0[0] * Su[0] + u0[1] * Su[1] + u0[2] * Su[2];
+        double g2 = 0; for (int i = 0; i < 3; ++i) { const double r = Su[i] - a * u0[i]; g2 += r * r; }
+        const double g = std::sqrt(g2) * (1.0 + 1e-9) + 1e-9 * trS, mu = (trS - a) * (1.0 + 1e-9) + 1e-9 * trS;
+        double t[16];
+        for (int k = 0; k < rg.np; ++k) t[k] = (rg.r[k] - mean[0]) * u0[0] + (rg.g[k] - mean[1]) * u0[1] + (rg.b[k] - mean[2]) * u0[2];
+        const double K0 = kmeans8(t, rg.np) * (1.0 - 1e-9);
+        if (K0 > 0)
+        {
+            const double bq = a - K0, e = (-bq + std::sqrt(bq * bq + 4.0 * K0 * mu)) / (2.0 * K0);
+            if (e > 0 && e < 1) { const double x1 = (trS - a) + (1.0 - e) * K0, x2 = trS - mu / e; const double Gn = std::min(x1, x2) * (1.0 - 1e-9) - g; G = std::max(G, Gn); }
+        }
+    }
+    line = finish(G);
+}
+static void prune_stats_host(const float* fpx, bool isSigned)
+{
+    int ipx[16][3];
+    for (int i = 0; i < 16; ++i) for (int c = 0; c < 3; ++c) ipx[i][c] = float_to_int16f(fpx[i * 4 + c], isSigned);
+    EndPts seeds2[32][2]; float rough[32]; uint32_t shp[32]; Region6 rg;
+    for (uint32_t s = 0; s < 32; ++s)
+    {
+        const uint32_t m1 = kPart2Mask[s]; const uint32_t masks[2] = { (~m1) & 0xFFFFu, m1 };
+        rough[s] = 0.0f; shp[s] = s;
+        for (int r = 0; r < 2; ++r) { int np; seeds2[s][r] = seed_region(fpx, ipx, masks[r], isSigned, np); if (np > 2) { gather(ipx, masks[r], rg); rough[s] += rough_error6<8>(tex(rg), seeds2[s][r]); } }
+    }
+    for (int i = 0; i < 8; ++i) for (int j = i + 1; j < 32; ++j) if (rough[i] > rough[j]) { std::swap(rough[i], rough[j]); std::swap(shp[i], shp[j]); }
+    double lbCur[8], lbNew[8]; int np1[8];
+    for (int i = 0; i < 8; ++i)
+    {
+        const uint32_t m1 = kPart2Mask[shp[i]]; const uint32_t masks[2] = { (~m1) & 0xFFFFu, m1 };
+        lbCur[i] = lbNew[i] = 0;
+        for (int r = 0; r < 2; ++r) { gather(ipx, masks[r], rg); double c, l; region_bounds(rg, c, l); lbCur[i] += c; lbNew[i] += l; if (r == 1) np1[i] = rg.np; if (l < c - 1e-6) ++g_newBelow; }
+    }
+    static const int order[10] = { 5, 6, 7, 8, 0, 2, 3, 4, 1, 9 };
+    float best = FLT_MAX; int prevPrec = -1;
+    bool searchedCur[8] = {}, searchedNew[8] = {};
+    for (int oi = 0; oi < 10; ++oi)
+    {
+        const ModeRt m = mode_rt(order[oi]);
+        const bool same = m.prec == prevPrec; prevPrec = m.prec;
+        if (!same) for (int i = 0; i < 8; ++i) searchedCur[i] = searchedNew[i] = false;
+        // pre: unoptimised errors of the candidates that fit -> the table
+        float orgTot[8]; bool fit[8]; float table = best;
+        for (int i = 0; i < 8; ++i)
+        {
+            const uint32_t shape = shp[i]; const uint32_t m1 = kPart2Mask[shape]; const uint32_t masks[2] = { (~m1) & 0xFFFFu, m1 };
+            const uint32_t anchors[2] = { 0u, uint32_t(kAnchor2[shape]) };
+            EndPts org[2]; float e[2]; uint64_t idx[2]; Region6 r2[2];
+            for (int r = 0; r < 2; ++r)
+            {
+                gather(ipx, masks[r], r2[r]);
+                for (int c = 0; c < 3; ++c) { org[r].A[c] = quantize(seeds2[shape][r].A[c], m.prec, isSigned); org[r].B[c] = quantize(seeds2[shape][r].B[c], m.prec, isSigned); }
+                e[r] = assign_indices6<8>(tex(r2[r]), r2[r].pos, org[r], m.prec, isSigned, anchors[r], idx[r]);
+            }
+            int a0[3] = { org[0].A[0], org[0].A[1], org[0].A[2] };
+            fit[i] = true;
+            for (int r = 0; r < 2; ++r) { const EndPts t = m.transformed ? transform_forward(org[r], r, a0) : org[r]; fit[i] = fit[i] && endpoints_fit(t, r, m, isSigned); }
+            orgTot[i] = e[0] + e[1];
+            if (fit[i]) table = std::min(table, orgTot[i] * 1.00001f);
+        }
+        const double w = double(2 * m.prec - 1);
+        for (int i = 0; i < 8; ++i)
+        {
+            if (!fit[i] || !(orgTot[i] > 0.0f)) continue;
+            const double cost = w * double(16 + np1[i]);
+            const bool liveCur = !(lbCur[i] > table), liveNew = !(lbNew[i] > table);
+            g_costAll += same ? 0.0 : cost;
+            if (liveCur && !searchedCur[i]) { g_costCur += cost; searchedCur[i] = true; }
+            if (liveNew && !searchedNew[i]) { g_costNew += cost; searchedNew[i] = true; }
+        }
+        // the mode's results fold into the running best (whatever was pruned could not have lowered it)
+        uint64_t lo, hi;
+        for (int i = 0; i < 8 && best > 0; ++i)
+        {
+            float b2 = FLT_MAX; uint64_t l2, h2;
+            if (refine_host<8>(m, isSigned, shp[i], seeds2[shp[i]], ipx, b2, l2, h2) && b2 < FLT_MAX)
+            {
+                ++g_nCand; g_lbCur += lbCur[i]; g_lbNew += lbNew[i]; g_errSum += b2;
+                if (lbCur[i] > b2 * 1.0001) ++g_violCur;
+                if (lbNew[i] > b2 * 1.0001) ++g_violNew;
+                if (b2 < best) best = b2;
+            }
+        }
+        (void)lo; (void)hi;
+    }
+}
+#endif
+
 int main(int argc, char** argv)
 {
+#if defined(DXTEX_PRUNE_STATS6)
+    if (argc >= 4 && !strcmp(argv[1], "prune"))
+    {
+        FILE* f = fopen(argv[2], "rb"); const bool sg = atoi(argv[3]) != 0;
+        alignas(16) float px[64]; int t = 0;
+        while (fread(px, sizeof(px), 1, f) == 1) { prune_stats_host(px, sg); ++t; }
+        printf("%d blocks: search cost of the two-region modes, all candidates that fit = 100 %%: bound in use %.1f %%, with the along-the-line term %.1f %%\n", t,
+               100.0 * g_costCur / g_costAll, 100.0 * g_costNew / g_costAll);
+        printf("  mean bound / final error over %llu refined candidates: %.3f in use, %.3f with the term; term below the plain bound in %llu regions; bounds above a final error: %llu / %llu\n",
+               g_nCand, g_lbCur / g_errSum, g_lbNew / g_errSum, g_newBelow, g_violCur, g_violNew);
+        return 0;
+    }
+#endif
     if (argc >= 4 && !strcmp(argv[1], "file"))
     {
         FILE* f = fopen(argv[2], "rb"); const bool sg = atoi(argv[3]) != 0;
