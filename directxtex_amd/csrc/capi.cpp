@@ -1635,8 +1635,11 @@ dxtex_hresult run_stripes(size_t n, F&& stripe)
 {
     std::vector<dxtex_hresult> hr(n, DXTEX_S_OK);
     std::vector<std::thread> workers;
-    for (size_t i = 1; i < n; ++i) workers.emplace_back([&, i] { hr[i] = stripe(i); });
-    hr[0] = stripe(0);
+    // (a stripe that runs out of host memory reports it like any other failure: nothing may leave a worker thread as an exception)
+    auto guarded = [&](size_t i) { try { hr[i] = stripe(i); } catch (...) { hr[i] = DXTEX_E_OUTOFMEMORY; } };
+    try { for (size_t i = 1; i < n; ++i) workers.emplace_back(guarded, i); }
+    catch (...) { for (std::thread& t : workers) t.join(); return DXTEX_E_OUTOFMEMORY; }
+    guarded(0);
     for (std::thread& t : workers) t.join();
     for (dxtex_hresult h : hr) if (h != DXTEX_S_OK) return h;
     return DXTEX_S_OK;
