@@ -54,6 +54,21 @@ def test_bc7_3subsets_bit_exact(ctx, oracle, alpha):
     _compare(oracle, got, ref, img, w, h, "3subsets-" + alpha)
 
 
+@pytest.mark.parametrize("flags", [0, dx.TEX_COMPRESS_BC7_QUICK])
+@pytest.mark.parametrize("const", [{3: 255}, {1: 128}, {0: 255, 3: 255}, {2: 0, 3: 37}, {0: 9, 1: 200}])
+def test_bc7_constant_channels(ctx, oracle, const, flags):
+    """Channels that are constant over whole blocks: mode 6 skips the PerturbOne calls that provably find nothing there (bc7_core.h flat_call /
+    eval_nearest), and the pruning bound charges rounding slack only to the channels that vary - every byte must stay the reference's. The
+    constants include values that the endpoint precision represents exactly and ones it does not; half of the image keeps noise in the channel."""
+    w, h = 64, 64
+    img = synth.rgba8(w, h, seed=9, alpha="random").copy()
+    for ch, v in const.items():
+        img[:, : w // 2, ch] = v            # left half: constant; right half: as generated (blocks on the seam are constant too - 4-aligned)
+    got = ctx.compress(img, w, h, RGBA8, BC7, flags, 0.5)
+    ref = oracle.compress_image(img, w, h, RGBA8, BC7, flags, 0.5)
+    _compare(oracle, got, ref, img, w, h, f"const {const} flags {flags}")
+
+
 @pytest.mark.parametrize("size", [(1, 1), (3, 5), (7, 2), (13, 9)])
 def test_bc7_partial_blocks(ctx, oracle, size):
     w, h = size
