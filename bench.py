@@ -16,13 +16,18 @@ Extra objects on the line:
                  a separate, untimed profiling pass through dxtex_ctx_profile_*), against 8 TB/s HBM. BC7 at the reference's
                  search depth is VALU-bound, so the HBM fraction is small by design; `valu` gives the kernel's VALU issue
                  utilisation against the measured gfx950 issue rates (profiles/r02_valu_rates.md), `all_kernels_ms` every kernel.
+                 The same evidence as flat scalars (for consumers that keep scalars only): valu_issue_utilisation,
+                 active_lanes_per_valu_inst, lds_bank_conflict_share, traffic_whole_step[_over_algorithmic] (every launch of one
+                 image), late_phase_kernel_ms.
   parity       - the payload of the timed run against the committed digests of the reference's output for the same image
                  (tests/golden/fullsize.json: whole 4096^2 image, 1 048 576 blocks) and, live, against the reference run on
                  this box's host cores on a bounded sample of block rows; PSNR of the whole image (decoded on the GPU).
   cpu_baseline - the reference's own encoder (oracle/_ref: DirectX::Compress with TEX_COMPRESS_PARALLEL = CompressBC_Parallel,
                  OpenMP over blocks) timed on this box's host cores on that bounded sample (rank 0, N = 1 only; --cpu-full runs
                  the whole image, ~3.5 min on 128 threads). Reported, not a target.
-  other_workloads - cfg3, cfg4, a cfg5 shard and the other codecs, each with its own roofline object.
+  other_workloads - cfg3, cfg4, a cfg5 shard and the other codecs, each with its own roofline object; for N > 1 one image split over
+                 the ranks (bc7_4096_split) and, where one process sees several GPUs, over contexts of this process
+                 (bc7_4096_inprocess_split: dxtex_compress_multi). tools/perf_guard.py compares their times with the last committed line.
 """
 import argparse
 import hashlib
