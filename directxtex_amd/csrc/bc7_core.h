@@ -188,17 +188,15 @@ DXTEX_HD int first_peak(const int (&sc)[N])
 template<int N>
 DXTEX_HD int first_peak_idx(const int (&sc)[N], uint32_t& idx)
 {
-    // the scan keeps the FIRST entry of a plateau (strict '<' on errors to replace the best)
-    int best = sc[0];
-    bool done = false;
-    idx = 0;
+    // the scan keeps the FIRST entry of a plateau (strict '<' on errors to replace the best). The scores do not fall before the scan stops, so
+    // its result v = first_peak(sc) is the largest score of that stretch, the entries equal to v inside it are its last ones, and every entry
+    // before them is smaller: the scan's index is the SMALLEST index whose score equals v (a later entry that climbs back to v has a larger
+    // index). Two chains of independent compare / selects instead of one serial scan with a "done" flag.
+    const int v = first_peak(sc);
+    idx = uint32_t(N - 1);
 #pragma unroll
-    for (int i = 1; i < N; ++i)
-    {
-        done = done || (sc[i] < best);
-        if (!done && sc[i] > best) { best = sc[i]; idx = uint32_t(i); }
-    }
-    return best;
+    for (int i = N - 2; i >= 0; --i) idx = (sc[i] == v) ? uint32_t(i) : idx;
+    return v;
 }
 
 // ---- the pixels one task sees ------------------------------------------------------------------------
@@ -216,6 +214,7 @@ struct Region
     DXTEX_HD int count() const { return np; }
     DXTEX_HD uint32_t pos(int k) const { return uint32_t(order >> (4 * k)) & 15u; }
     DXTEX_HD uint32_t fetch(int k) const { return pix[pos(k)]; }
+    DXTEX_HD uint32_t fetch_pos(uint32_t p) const { return pix[p]; }        // the texel at block position p (a member of the region)
 };
 
 DXTEX_HD void region_init(Region& r, const uint32_t* pix, uint32_t mask16)
@@ -262,6 +261,7 @@ struct Block16
     DXTEX_HD int count() const { return 16; }
     DXTEX_HD uint32_t pos(int k) const { return uint32_t(k); }
     DXTEX_HD uint32_t fetch(int k) const { return px[k]; }
+    DXTEX_HD uint32_t fetch_pos(uint32_t p) const { return px[p]; }
 };
 
 template<class PIX>
@@ -433,6 +433,87 @@ DXTEX_HD int assign_indices(const RG& rg, uint32_t& epA, uint32_t& epB, uint32_t
             epA = (a & 0x00FFFFFFu) | (b & 0xFF000000u);
             epB = (b & 0x00FFFFFFu) | (a & 0xFF000000u);
             idx2 ^= uint64_t(PB::NA - 1) * 0x1111111111111111ull;
+        }
+    }
+    return total;
+}
+
+// AssignIndices for a caller that needs the region's ERROR and the anchor fix-up of the endpoints but not the indices (pre: the unoptimised
+// half of Refine, whose indices are only ever wanted for a block's winner, and post derives those itself): the texel loop takes the
+// first-peak VALUE (first_peak: independent compares) instead of tracking the index (first_peak_idx: a serial scan plus the 64-bit index
+// word) - the same sum - and only the anchor texel is scanned for its index. Same error, same endpoints as assign_indices.
+template<int MODE, int IM, class RG>
+DXTEX_HD int assign_error(const RG& rg, uint32_t& epA, uint32_t& epB, uint32_t anchorPos)
+{
+    typedef PaletteBits<MODE, IM> PB;
+    const uint32_t ua = unquantize<MODE>(epA), ub = unquantize<MODE>(epB);
+    int total = rg.p2sum;
+    uint32_t pal[PB::NC], nq2[PB::NC];
+#pragma unroll
+    for (int i = 0; i < PB::NC; ++i)
+    {
+        pal[i] = lerp_bytes(ua, ub, weight(PB::CB, i));
+        if (PB::AB != 0) pal[i] &= 0x00FFFFFFu;
+        nq2[i] = 0u - udot4(pal[i], pal[i]);
+    }
+    int pa[PB::NA];
+    if (PB::AB != 0)
+    {
+        const int a0 = int(ua >> 24), a1 = int(ub >> 24);
+#pragma unroll
+        for (int i = 0; i < PB::NA; ++i)
+            pa[i] = int(lerp1(lerp_base(uint32_t(a0)), a1 - a0, weight(PB::AB, i)));
+    }
+    for_texels(rg, [&](int k)
+    {
+        const uint32_t p = rg.fetch(k);
+        const uint32_t pc = (PB::AB != 0) ? (p & 0x00FFFFFFu) : p;
+        int sc[PB::NC];
+#pragma unroll
+        for (int i = 0; i < PB::NC; ++i) sc[i] = score(pc, pal[i], nq2[i]);
+        total -= first_peak(sc);
+        if (PB::AB != 0)
+        {
+            const int al = int(p >> 24);
+            int su[PB::NA];
+#pragma unroll
+            for (int i = 0; i < PB::NA; ++i) su[i] = 2 * al * pa[i] - pa[i] * pa[i];
+            total -= first_peak(su);
+        }
+    });
+    // the anchor texel's index decides the swap (:3195-3215)
+    {
+        const uint32_t p = rg.fetch_pos(anchorPos);
+        const uint32_t pc = (PB::AB != 0) ? (p & 0x00FFFFFFu) : p;
+        int sc[PB::NC];
+#pragma unroll
+        for (int i = 0; i < PB::NC; ++i) sc[i] = score(pc, pal[i], nq2[i]);
+        uint32_t i1;
+        (void)first_peak_idx(sc, i1);
+        if (i1 & uint32_t(PB::NC >> 1))
+        {
+            if (PB::AB == 0) { const uint32_t t = epA; epA = epB; epB = t; }
+            else
+            {
+                const uint32_t a = epA, b = epB;
+                epA = (b & 0x00FFFFFFu) | (a & 0xFF000000u);
+                epB = (a & 0x00FFFFFFu) | (b & 0xFF000000u);
+            }
+        }
+    }
+    if (PB::AB != 0)
+    {
+        const int al = int(rg.fetch_pos(0u) >> 24);      // aIndices2[0]: separate-alpha modes have one region, anchor texel 0
+        int su[PB::NA];
+#pragma unroll
+        for (int i = 0; i < PB::NA; ++i) su[i] = 2 * al * pa[i] - pa[i] * pa[i];
+        uint32_t i2;
+        (void)first_peak_idx(su, i2);
+        if (i2 & uint32_t(PB::NA >> 1))
+        {
+            const uint32_t a = epA, b = epB;
+            epA = (a & 0x00FFFFFFu) | (b & 0xFF000000u);
+            epB = (b & 0x00FFFFFFu) | (a & 0xFF000000u);
         }
     }
     return total;
@@ -1496,6 +1577,15 @@ DXTEX_HD void refine_pre(const RG& rg, uint32_t seedA, uint32_t seedB, uint32_t 
     const uint32_t qa = quantize_endpoint<MODE>(seedA), qb = quantize_endpoint<MODE>(seedB);
     fix_pbits<MODE>(qa, qb, out.orgA, out.orgB);
     out.orgErr = assign_indices<MODE, IM>(rg, out.orgA, out.orgB, anchorPos, out.orgIdx1, out.orgIdx2);
+}
+
+// ... the same without the indices (what bc7_pre_kernel needs: endpoints after the anchor fix-up, and the error)
+template<int MODE, int IM, class RG>
+DXTEX_HD void refine_pre_err(const RG& rg, uint32_t seedA, uint32_t seedB, uint32_t anchorPos, SubsetResult& out)
+{
+    const uint32_t qa = quantize_endpoint<MODE>(seedA), qb = quantize_endpoint<MODE>(seedB);
+    fix_pbits<MODE>(qa, qb, out.orgA, out.orgB);
+    out.orgErr = assign_error<MODE, IM>(rg, out.orgA, out.orgB, anchorPos);
 }
 
 // Refine, second half: the optimised endpoints (from OptimizeOne) get their p-bits and indices (opt candidate).

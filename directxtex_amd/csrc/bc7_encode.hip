@@ -335,8 +335,9 @@ __device__ __forceinline__ bool task_geometry(const Bc7Args& a, uint32_t nb, uin
 }
 
 // Refine's first half for one task, from the block's float + 8-bit texels (LDS or registers).
-// ASSIGN = false: the unoptimised endpoints only (Quantize + FixEndpointPBits), without AssignIndices - post takes their error from the task
-// record and only the block's winner, if it stands with them, needs their indices (org_indices).
+// ASSIGN = true (pre): the unoptimised endpoints with their anchor fix-up and their error, no indices (assign_error). ASSIGN = false (post): the
+// endpoints before AssignIndices only (Quantize + FixEndpointPBits) - post takes their error from the task record and only the block's winner,
+// if it stands with them, runs AssignIndices for their indices.
 template<int MODE, int IM, bool ASSIGN = true>
 __device__ __forceinline__ void task_org(const float* fpx, const uint32_t* pix, uint32_t mask, uint32_t anchor, uint32_t rot,
                                          SubsetResult& res, int& np, bool wantRegion, Region& rgOut, Block16& b16Out, const uint2* seed = nullptr)
@@ -358,7 +359,7 @@ __device__ __forceinline__ void task_org(const float* fpx, const uint32_t* pix, 
             A = (A & 0x00FFFFFFu) | (mn << 24);
             B = (B & 0x00FFFFFFu) | (mx << 24);
         }
-        if (ASSIGN) refine_pre<MODE, IM>(b16Out, A, B, 0u, res);
+        if (ASSIGN) refine_pre_err<MODE, IM>(b16Out, A, B, 0u, res);
         else fix_pbits<MODE>(quantize_endpoint<MODE>(A), quantize_endpoint<MODE>(B), res.orgA, res.orgB);
         np = 16;
     }
@@ -370,7 +371,7 @@ __device__ __forceinline__ void task_org(const float* fpx, const uint32_t* pix, 
         else if (rgOut.np == 1) { A = pix[rgOut.pos(0)]; B = A; }
         else if (rgOut.np == 2) { A = pix[rgOut.pos(0)]; B = pix[rgOut.pos(1)]; }
         else seed_endpoints<true>(fpx, mask, A, B);
-        if (ASSIGN) refine_pre<MODE, IM>(rgOut, A, B, anchor, res);
+        if (ASSIGN) refine_pre_err<MODE, IM>(rgOut, A, B, anchor, res);
         else fix_pbits<MODE>(quantize_endpoint<MODE>(A), quantize_endpoint<MODE>(B), res.orgA, res.orgB);
         np = rgOut.np;
     }
