@@ -487,10 +487,11 @@ __device__ __forceinline__ float pow_rn(float x, float y) { return float(pow(dou
 
 __device__ __forceinline__ float srgb_to_linear1(float v)
 {
-    // V = saturate(srgb); V <= 0.04045 ? V / 12.92 : pow((V + 0.055) / 1.055, 2.4)
+    // V = saturate(srgb); V > 0.04045 ? pow((V + 0.055) * (1 / 1.055), 2.4) : V * (1 / 12.92) - DirectXMath multiplies by the reciprocal
+    // CONSTANTS (ILinear, Scale), it does not divide (oracle/shim/DirectXMath.h, XMColorSRGBToRGB)
     float s = (v > 0.0f) ? v : 0.0f; s = (s < 1.0f) ? s : 1.0f;
-    const float lo = s / 12.92f;
-    const float hi = pow_rn((s + 0.055f) / 1.055f, 2.4f);
+    const float lo = s * (1.0f / 12.92f);
+    const float hi = pow_rn((s + 0.055f) * (1.0f / 1.055f), 2.4f);
     return (s > 0.04045f) ? hi : lo;
 }
 
@@ -500,7 +501,7 @@ __device__ __forceinline__ float linear_to_srgb1(float v)
     float s = (v > 0.0f) ? v : 0.0f; s = (s < 1.0f) ? s : 1.0f;
     const float lo = s * 12.92f;
     const float hi = 1.055f * pow_rn(s, 1.0f / 2.4f) - 0.055f;
-    return (s > 0.0031308f) ? hi : lo;
+    return (s < 0.0031308f) ? lo : hi;
 }
 
 enum : int { TCV_SRGB_TO_LINEAR = 0x100, TCV_LINEAR_TO_SRGB = 0x200 };   // or-ed into SrcView::tcv by the compress path

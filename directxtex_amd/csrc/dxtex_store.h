@@ -149,7 +149,9 @@ __device__ __forceinline__ uint32_t store_float11(float v, int MB)
     return ((I + ((1u << (shift - 1)) - 1u) + ((I >> shift) & 1u)) >> shift) & all;
 }
 
-// XMStoreFloat3SE (DirectXMath >= 3.10; the reference carries the same code for older versions, DirectXTexConvert.cpp:158-191)
+// XMStoreFloat3SE (DirectXMath >= 3.10, which is what the reference calls: DirectXTexConvert.cpp:155-156). The mantissas are rounded
+// to nearest EVEN (DirectXMath's Internal::round_to_nearest); the reference's private copy for DirectXMath < 3.10 (:158-191) uses lroundf
+// (half away from zero) and is not compiled against a current DirectXMath.
 __device__ __forceinline__ uint32_t store_float3se(const Texel& t)
 {
     const float maxf9 = float(0x1FF << 7), minf9 = 1.0f / float(1 << 16);
@@ -162,9 +164,8 @@ __device__ __forceinline__ uint32_t store_float3se(const Texel& t)
     const uint32_t fi = __float_as_uint(maxColor) + 0x00004000u;      // round up leaving 9 bits in the fraction (including the assumed 1)
     const uint32_t e = fi >> 23;
     const float scaleR = __uint_as_float(0x83000000u - (e << 23));
-    // lroundf: round half away from zero
-    return (uint32_t(int32_t(roundf(x * scaleR))) & 0x1FFu) | ((uint32_t(int32_t(roundf(y * scaleR))) & 0x1FFu) << 9) |
-           ((uint32_t(int32_t(roundf(z * scaleR))) & 0x1FFu) << 18) | (((e - 0x6Fu) & 0x1Fu) << 27);
+    return (uint32_t(int32_t(rintf(x * scaleR))) & 0x1FFu) | ((uint32_t(int32_t(rintf(y * scaleR))) & 0x1FFu) << 9) |
+           ((uint32_t(int32_t(rintf(z * scaleR))) & 0x1FFu) << 18) | (((e - 0x6Fu) & 0x1Fu) << 27);
 }
 
 // XMStoreU565 / XMStoreU555 / XMStoreUNibble4 after the reference's scaling (v * 31 | 63 | 15, no bias on x64): clamp to [0, max], round
@@ -179,16 +180,14 @@ __device__ __forceinline__ uint32_t store_scaled_rne(float v, float scale)
 
 // ---- integer stores --------------------------------------------------------------------------------------------------------
 // XMStoreUInt4/3/2 and XMConvertVectorFloatToUInt(v, 0), SSE2 path: max(v, 0) (a NaN becomes 0: maxps returns its second operand),
-// values above 4294967295.0f (which is 2^32 in fp32) give 0xFFFFFFFF, everything else is TRUNCATED (cvttps2dq, with the usual
-// subtract-2^31 detour above 2^31, which is exact).
+// values above g_XMMaxUInt = 65536 * 65536 - 256 = 4294967040.0f (the largest fp32 below 2^32) give 0xFFFFFFFF, everything else is
+// TRUNCATED (cvttps2dq, with the usual subtract-2^31 detour above 2^31, which is exact).
 __device__ __forceinline__ uint32_t store_u32(float v)
 {
     const float s = (v > 0.0f) ? v : 0.0f;
-    if (s > 4294967295.0f) return 0xFFFFFFFFu;             // (the constant IS 2^32 in fp32, so exactly 2^32 is not an overflow there ...)
+    if (s > 4294967040.0f) return 0xFFFFFFFFu;
     if (s < 2147483648.0f) return uint32_t(int32_t(s));
-    const float t = s - 2147483648.0f;
-    // ... and its detour value 2^31 converts to cvttps2dq's 0x80000000, which the final XOR turns into 0: reproduced
-    return ((t >= 2147483648.0f) ? 0x80000000u : uint32_t(int32_t(t))) ^ 0x80000000u;
+    return uint32_t(int32_t(s - 2147483648.0f)) ^ 0x80000000u;
 }
 // XMStoreSInt4/3/2 and XMConvertVectorFloatToInt(v, 0): truncation; above 2147483520.0f (65536 * 32768 - 128) the result is
 // 0x7FFFFFFF; below -2^31 and for NaN cvttps2dq's "integer indefinite" 0x80000000.

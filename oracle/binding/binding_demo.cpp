@@ -116,23 +116,11 @@ int main()
             report("Resize 44 x 28 -> 61 x 17 cubic", h1, h2, SUCCEEDED(h1) && SUCCEEDED(h2) && SameScratch(cpu, gpu));
         }
         {
-            // DirectX::Convert lives in DirectXTexConvert.cpp, which cannot be compiled here (DirectXMath is absent): the CPU side is the loop of
-            // ConvertCustom's plain branch (:4887-4909) over the scanline layer libdxtex_ref.so carries (oracle/restate/scanline.cpp, restated)
+            // DirectX::Convert itself (DirectXTexConvert.cpp compiled in place into libdxtex_ref.so since round 6)
             ScratchImage cpu, gpu;
-            HRESULT h1 = cpu.Initialize2D(DXGI_FORMAT_R16G16B16A16_FLOAT, base.width, base.height, 1, 1);
-            if (SUCCEEDED(h1))
-            {
-                std::vector<XMVECTOR> row(base.width);
-                const Image& d = *cpu.GetImage(0, 0, 0);
-                for (size_t y = 0; y < base.height && SUCCEEDED(h1); ++y)
-                {
-                    if (!Internal::LoadScanline(row.data(), base.width, base.pixels + y * base.rowPitch, base.rowPitch, base.format)) h1 = E_FAIL;
-                    Internal::ConvertScanline(row.data(), base.width, d.format, base.format, TEX_FILTER_DEFAULT);
-                    if (!Internal::StoreScanline(d.pixels + y * d.rowPitch, d.rowPitch, d.format, row.data(), base.width, TEX_THRESHOLD_DEFAULT)) h1 = E_FAIL;
-                }
-            }
+            const HRESULT h1 = Convert(base, DXGI_FORMAT_R16G16B16A16_FLOAT, TEX_FILTER_DEFAULT, TEX_THRESHOLD_DEFAULT, cpu);
             const HRESULT h2 = ConvertMI355X(0, base, DXGI_FORMAT_R16G16B16A16_FLOAT, TEX_FILTER_DEFAULT, TEX_THRESHOLD_DEFAULT, gpu);
-            report("Convert RGBA8 -> RGBA16F (CPU side: restated scanline layer)", h1, h2, SUCCEEDED(h1) && SUCCEEDED(h2) && SameScratch(cpu, gpu));
+            report("Convert RGBA8 -> RGBA16F", h1, h2, SUCCEEDED(h1) && SUCCEEDED(h2) && SameScratch(cpu, gpu));
             ScratchImage bad;
             if (ConvertMI355X(0, base, DXGI_FORMAT_R8G8B8A8_UNORM, TEX_FILTER_DEFAULT, 0.5f, bad) != E_INVALIDARG) { std::puts("expected E_INVALIDARG for Convert to the same format"); ++failures; }
         }

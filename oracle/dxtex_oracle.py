@@ -1,9 +1,10 @@
 """TEST INFRASTRUCTURE ONLY. CPU oracle for Compress / Decompress (see oracle/__init__.py).
 
-Parity status: the block codecs are the reference itself (oracle/_ref). The scanline conventions that
-live in DirectXMath (XMLoadUByteN4 = float(b) * (1/255.f), XMLoadHalf4 exact, ...) are restated from
-its published behaviour - DirectXMath is not vendored in /root/reference and no reference test pins
-them: PARITY UNPINNED at that boundary.
+Parity status: the block codecs, the image drivers and the scanline layer are the reference itself
+(oracle/_ref). The packed-vector conventions that live in DirectXMath (XMLoadUByteN4 = float(b) * (1/255.f),
+XMLoadHalf4 exact, ...) are stated leaf by leaf in oracle/shim from its published SSE2 behaviour -
+DirectXMath is not vendored in /root/reference and no reference test pins them: PARITY UNPINNED at that
+leaf boundary; the numpy functions below repeat the same conventions.
 """
 import ctypes
 import os
@@ -381,7 +382,7 @@ def ref_resize(pixels, width, height, fmt, new_width, new_height, filter_flags):
 
 
 def ref_convert(pixels, width, height, src_fmt, dst_fmt, filter_flags=0, threshold=0.5):
-    """ConvertCustom's plain branch (DirectXTexConvert.cpp:4887-4909) over oracle/restate/scanline.cpp."""
+    """The reference's own Convert (DirectXTexConvert.cpp:5091-5180 -> ConvertCustom :4804-4913), compiled in place."""
     px = np.ascontiguousarray(pixels).view(np.uint8).reshape(-1)
     return _run(_load_ref().dxtex_ref_convert, image_bytes(dst_fmt, width, height), px.ctypes.data, width, height, src_fmt, 0, dst_fmt, filter_flags, threshold)
 

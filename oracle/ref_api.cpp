@@ -97,7 +97,8 @@ extern "C"
 
     // ---- image-level drivers: the reference's own Compress / Decompress / GenerateMipMaps / Resize / ComputeMSE
     // (DirectXTexCompress.cpp, DirectXTexMipmaps.cpp, DirectXTexResize.cpp, DirectXTexMisc.cpp compiled in place) on top
-    // of oracle/restate/scanline.cpp. Results are copied out level by level with tight pitch.
+    // of the reference's own scanline layer (DirectXTexConvert.cpp, compiled in place: ref_convert.cpp). Results are copied out level by
+    // level with tight pitch.
     static Image make_image(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t rowPitch)
     {
         Image img;
@@ -163,23 +164,30 @@ extern "C"
         return FAILED(hr) ? -1 : copy_out(si, out, capacity);
     }
 
-    // ConvertCustom's no-dither branch (DirectXTexConvert.cpp:4887-4909), restated: DirectXTexConvert.cpp is not compiled
+    // The reference's own Convert (DirectXTexConvert.cpp:5091-5180 -> ConvertCustom :4804-4913), compiled in place (ref_convert.cpp)
     int64_t dxtex_ref_convert(const uint8_t* pixels, size_t w, size_t h, int fmt, size_t rowPitch, int dstFmt, uint32_t filter, float threshold,
                               uint8_t* out, size_t capacity, int32_t* hrOut)
     {
-        const Image src = make_image(pixels, w, h, fmt, rowPitch);
-        size_t rp = 0, sp = 0;
-        ComputePitch(DXGI_FORMAT(dstFmt), w, h, rp, sp);
-        if (hrOut) *hrOut = 0;
-        if (sp > capacity) return -2;
-        std::vector<XMVECTOR> row(w);
-        for (size_t y = 0; y < h; ++y)
-        {
-            if (!Internal::LoadScanline(row.data(), w, src.pixels + y * src.rowPitch, src.rowPitch, src.format)) { if (hrOut) *hrOut = int32_t(E_FAIL); return -1; }
-            Internal::ConvertScanline(row.data(), w, DXGI_FORMAT(dstFmt), src.format, TEX_FILTER_FLAGS(filter));
-            if (!Internal::StoreScanline(out + y * rp, rp, DXGI_FORMAT(dstFmt), row.data(), w, threshold)) { if (hrOut) *hrOut = int32_t(E_FAIL); return -1; }
-        }
-        return int64_t(sp);
+        ScratchImage si;
+        const HRESULT hr = Convert(make_image(pixels, w, h, fmt, rowPitch), DXGI_FORMAT(dstFmt), TEX_FILTER_FLAGS(filter), threshold, si);
+        if (hrOut) *hrOut = int32_t(hr);
+        return FAILED(hr) ? -1 : copy_out(si, out, capacity);
+    }
+
+    // One row through the reference's LoadScanline / StoreScanline (DirectXTexConvert.cpp:779-1619, :1643-2533) with fp32 RGBA on the
+    // other side: the leaves of oracle/shim/DirectXPackedVector.h under the reference's own case analysis, for the leaf tests.
+    int dxtex_ref_load_scanline(const uint8_t* src, size_t size, int fmt, float* rgba, size_t count)
+    {
+        std::vector<XMVECTOR> row(count);
+        if (!Internal::LoadScanline(row.data(), count, src, size, DXGI_FORMAT(fmt))) return -1;
+        memcpy(rgba, row.data(), count * sizeof(XMVECTOR));
+        return 0;
+    }
+    int dxtex_ref_store_scanline(uint8_t* dst, size_t size, int fmt, const float* rgba, size_t count, float threshold)
+    {
+        std::vector<XMVECTOR> row(count);
+        memcpy(row.data(), rgba, count * sizeof(XMVECTOR));
+        return Internal::StoreScanline(dst, size, DXGI_FORMAT(fmt), row.data(), count, threshold) ? 0 : -1;
     }
 
     // GenerateMipMaps3D (DirectXTexMipmaps.cpp:3254-3361). `pixels`: the `depth` base slices, tight pitch, consecutive.

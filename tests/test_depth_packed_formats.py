@@ -1,7 +1,7 @@
 """Depth / stencil formats (D32_FLOAT_S8X24_UINT, D32_FLOAT, D24_UNORM_S8_UINT, D16_UNORM) of LoadScanline / StoreScanline
 (DirectXTexConvert.cpp:844-860, :937, :982-997, :1053 and :1725-1744, :1810, :1852-1869, :1897) and ConvertScanline's depth branch
-(:3186-3451): the HIP kernels against the restated scanline layer under the reference's drivers (oracle/restate/scanline.cpp), and - on
-the CPU - that layer against a third statement in numpy (below). These cases are the reference's own scalar code (no DirectXMath packed
+(:3186-3451): the HIP kernels against the reference's own scanline layer (DirectXTexConvert.cpp compiled in place into oracle/_ref), and - on
+the CPU - that layer against an independent statement in numpy (below). These cases are the reference's own scalar code (no DirectXMath packed
 type), except the XMVectorClamp / XMVectorSaturate / XMVectorMultiplyAdd steps (maxps / minps, unfused multiply-add)."""
 import numpy as np
 import pytest
@@ -82,7 +82,7 @@ def _values(rng, n):
 
 
 @pytest.mark.parametrize("fmt", DEPTH)
-def test_numpy_statement_agrees_with_the_restated_layer(oracle, fmt):
+def test_numpy_statement_agrees_with_the_reference_layer(oracle, fmt):
     w, h = 97, 3
     rng = np.random.default_rng(fmt)
     raw = rng.integers(0, 256, oracle.image_bytes(fmt, w, h), dtype=np.uint8)
@@ -260,7 +260,7 @@ def _group_values(rng, w, h):
 
 @pytest.mark.parametrize("fmt", GROUPED)
 @pytest.mark.parametrize("w", [97, 32, 1])
-def test_numpy_statement_agrees_with_the_restated_layer_grouped(oracle, fmt, w):
+def test_numpy_statement_agrees_with_the_reference_layer_grouped(oracle, fmt, w):
     h = 3
     rng = np.random.default_rng(fmt * 7 + w)
     raw = rng.integers(0, 256, oracle.image_bytes(fmt, w, h), dtype=np.uint8)

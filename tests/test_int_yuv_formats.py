@@ -1,8 +1,8 @@
 """The integer (UINT / SINT), extended-range (R10G10B10_XR_BIAS_A2_UNORM) and 4:4:4 video (AYUV, Y410, Y416) formats of LoadScanline /
 StoreScanline (DirectXTexConvert.cpp:805-842, :900-904, :913-981, :1031-1156, :1291-1394 and :1674-1850, :1873-2016, :2173-2272):
-the HIP kernels against the restated scanline layer under the reference's drivers (oracle/restate/scanline.cpp), and - on the CPU - that
-layer against a third, vectorised statement in numpy (below). DirectXMath's integer loads / stores are restated from its SSE2 paths
-("assumed"); the single-channel 8- / 16-bit integer formats and the video formats are the reference's own scalar code."""
+the HIP kernels against the reference's own scanline layer (DirectXTexConvert.cpp compiled in place into oracle/_ref over the DirectXMath
+leaf shim, oracle/shim), and - on the CPU - that layer against an independent, vectorised statement in numpy (below). DirectXMath's integer
+loads / stores are stated from its SSE2 paths in the shim (and checked against the x86 instructions by oracle/checks/shim_sse_check.cpp); the single-channel 8- / 16-bit integer formats and the video formats are the reference's own scalar code."""
 import numpy as np
 import pytest
 
@@ -76,8 +76,8 @@ def np_store(v, fmt):
                 s = _sse_clamp(x, 0.0, np.inf)
                 big = s >= F(2147483648.0)
                 t = np.where(big, (s - F(2147483648.0)).astype(F), s)
-                q = np.trunc(np.where(s > F(4294967295.0), 0, t)).astype(np.int64).astype(np.uint32) ^ np.where(big, np.uint32(0x80000000), np.uint32(0))
-                q = np.where(s > F(4294967295.0), np.uint32(0xFFFFFFFF), q)
+                q = np.trunc(np.where(s > F(4294967040.0), 0, t)).astype(np.int64).astype(np.uint32) ^ np.where(big, np.uint32(0x80000000), np.uint32(0))
+                q = np.where(s > F(4294967040.0), np.uint32(0xFFFFFFFF), q)
                 return q.astype(np.uint32).reshape(-1).view(np.uint8)
             if bits == 32:
                 ok = (x >= F(-2147483648.0)) & ~(x > F(2147483520.0))
@@ -131,8 +131,8 @@ def _values(rng, n):
 
 
 @pytest.mark.parametrize("fmt", NEW)
-def test_numpy_statement_agrees_with_the_restated_layer(oracle, fmt):
-    """CPU: load every bit pattern (random) and store boundary values through oracle/restate/scanline.cpp (ConvertCustom's loop with fp32 on
+def test_numpy_statement_agrees_with_the_reference_layer(oracle, fmt):
+    """CPU: load every bit pattern (random) and store boundary values through the reference's Convert (ConvertCustom's loop with fp32 on
     the other side, so ConvertScanline has nothing to do to the values except the UNORM saturation the float -> UNORM branch applies) and
     through the numpy statement above."""
     w, h = 97, 3

@@ -1,10 +1,10 @@
 """CPU-only checks of the test oracle itself (no GPU, no product code):
   * the reference has no golden vectors for this path, so the oracle is pinned the other way
     round: it IS the reference - BC.cpp / BC4BC5.cpp / BC6HBC7.cpp / DirectXTexCompress / Mipmaps / Resize / Misc.cpp
-    compiled in place into oracle/_ref - and these tests pin the thin restated layers around it against each other
-    and against format-level invariants;
+    and (round 6) DirectXTexConvert.cpp compiled in place into oracle/_ref - and these tests pin the thin layers around it (the numpy
+    driver, the DirectXMath leaf shim) against each other and against format-level invariants;
   * the numpy restatement of the Compress driver (LoadScanline, tile gather, ConvertScanline) must agree byte for byte
-    with the reference's real CompressBC driver running over the C++ restatement of the scanline layer."""
+    with the reference's real CompressBC driver running over the reference's own scanline layer."""
 import numpy as np
 import pytest
 

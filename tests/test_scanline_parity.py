@@ -1,5 +1,5 @@
 """GenerateMipMaps / Resize / Convert / ComputeMSE on the GPU against the reference's own drivers (DirectXTexMipmaps.cpp,
-DirectXTexResize.cpp, DirectXTexMisc.cpp compiled in place into oracle/_ref, on top of the restated scanline layer).
+DirectXTexResize.cpp, DirectXTexMisc.cpp, DirectXTexConvert.cpp compiled in place into oracle/_ref over the DirectXMath leaf shim).
 Bar: byte-identical output for every non-sRGB format (the filters are fp32 expression-for-expression restatements);
 sRGB formats go through powf on both sides, so they are allowed to differ by one 8-bit step."""
 import numpy as np
