@@ -82,14 +82,15 @@ def cpu_baseline(img, payload, full, budget_s=20.0):
     nbands = HEIGHT // rows
     got = np.ascontiguousarray(payload, np.uint8).reshape(HEIGHT // 4, (WIDTH // 4) * 16)
     texels = 0; secs = 0.0; same = 0; blocks = 0
-    done = []
+    done = []; band_secs = {}
 
     def run_band(b):
         nonlocal texels, secs, same, blocks
         crop = np.ascontiguousarray(img[b * rows:(b + 1) * rows])
         t0 = time.perf_counter()
         ref = oracle.ref_compress_image(crop, WIDTH, crop.shape[0], 28, 98, TEX_COMPRESS_PARALLEL, 0.5)
-        secs += time.perf_counter() - t0
+        band_secs[b] = time.perf_counter() - t0
+        secs += band_secs[b]
         texels += crop.shape[0] * WIDTH
         g = got[b * BAND_ROWS:(b + 1) * BAND_ROWS].reshape(-1, 16)
         same += int((g == ref.reshape(-1, 16)).all(axis=1).sum()); blocks += g.shape[0]
@@ -108,9 +109,33 @@ def cpu_baseline(img, payload, full, budget_s=20.0):
                 run_band(b)
     picks = done
     sample = "the whole 4096x4096 image" if full else f"{len(picks)} bands of {rows} rows x {WIDTH} ({texels} texels) spread over the benchmark image"
-    cpu = {"value": round(texels / secs / 1e6, 5), "unit": "Mtexels/s", "cores": threads, "kind": "reference",
+    raw = texels / secs / 1e6
+    cpu = {"value": round(raw, 5), "unit": "Mtexels/s", "cores": threads, "kind": "reference",
            "sample": f"{sample}; DirectX::Compress -> CompressBC_Parallel (OpenMP over blocks), D3DXEncodeBC7 flags=0, {secs:.1f} s"}
+    if full:
+        cpu["band_seconds"] = [round(band_secs[b], 4) for b in range(nbands)]
+    else:
+        # The bands are not equally expensive (flat blocks end at mode 6, noisy ones search every mode): weight the sample with the
+        # per-band cost of a whole-image run of the reference on this image (profiles/r06_cpu_bands.json, from `bench.py --cpu-full`
+        # on the GPU box), so that `value` estimates the WHOLE image's rate: seconds(whole) ~ seconds(sample) * cost(all) / cost(sample).
+        table = band_cost_table(nbands)
+        if table:
+            frac = sum(table[b] for b in picks) / sum(table)
+            est = WIDTH * HEIGHT / (secs / frac) / 1e6
+            cpu["value"] = round(est, 5)
+            cpu["raw_sample_value"] = round(raw, 5)
+            cpu["weighting"] = (f"sample seconds scaled by the sample's share of the whole image's reference time ({frac:.4f} of it in "
+                                f"{len(picks)}/{nbands} of the bands; profiles/r06_cpu_bands.json): an estimate of the whole-image rate")
     return cpu, {"live_reference_blocks_compared": blocks, "live_reference_blocks_identical": same}
+
+
+def band_cost_table(nbands):
+    """Per-band seconds of the reference over the whole benchmark image (one `--cpu-full` run on the GPU box, committed)."""
+    fp = os.path.join(ROOT, "profiles", "r06_cpu_bands.json")
+    if not os.path.exists(fp):
+        return None
+    t = json.load(open(fp)).get("band_seconds")
+    return t if t and len(t) == nbands and min(t) > 0 else None
 
 
 def gpu_psnr(ctx, dev, src, dst, fmt_src, fmt_bc, width, height):
@@ -752,13 +777,16 @@ def main():
                     parity.update(live)
                     # the whole image on the reference: measured by the live parity test on the GPU box (tests/test_zz_fullsize_gpu.py),
                     # committed under profiles/ (3+ minutes - not re-run here; --cpu-full does)
-                    for name in ("r05_fullsize_live.json", "r03_fullsize_live.json", "r02_fullsize_live.json"):
+                    for name in ("r06_fullsize_live.json", "r05_fullsize_live.json", "r03_fullsize_live.json", "r02_fullsize_live.json"):
                         fp = os.path.join(ROOT, "profiles", name)
                         if cpu and os.path.exists(fp):
                             w = json.load(open(fp)).get("cfg2_bc7_4096")
                             if w:
                                 cpu["whole_image"] = {"seconds": w["ref_seconds"], "cores": w["ref_threads"], "Mtexels_s": w["Mtexels_s"],
                                                       "identical_to_gpu": w["identical"], "source": f"profiles/{name} (live parity run, same image)"}
+                                # flat scalars (nested objects do not survive every parser of this line)
+                                extra["cpu_baseline_whole_image_Mtexels_s"] = w["Mtexels_s"]
+                                extra["cpu_baseline_sample_over_whole_image"] = round(cpu["value"] / w["Mtexels_s"], 4)
                                 break
                 if not args.no_extra:
                     extra["end_to_end"] = end_to_end(ctx, img, gold["sha256"] if gold else None)

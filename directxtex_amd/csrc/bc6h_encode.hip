@@ -35,9 +35,12 @@ using namespace bc6h;
 // A task's quantised endpoints as six 16-bit fields: every mode's endpoint precision is at most 16 bits (ms_aInfo, :1051-1067); Quantize leaves
 // unsigned formats in 0 ... 2^prec - 1 and signed ones in -(2^(prec-1) - 1) ... 2^(prec-1) - 1, so the extension on the way back is the format's.
 // One exception: PerturbOne tries every value in [0, 2^prec) whatever the signedness (:2112-2118), so with SF16 and the 16-bit one-region mode
-// a search can END on a component above 32767. The reference keeps such endpoints and drops them at EndPointsFit (NBits = 17 > 16, :2408); here
-// the field would wrap, so the search kernels mark the record instead (ep16_overflows -> Rec6::err = -1, an error is never negative) and
-// bc6h_post_kernel treats the marked result as not fitting: the unoptimised endpoints stand, as in the reference.
+// a search can END on a component above 32767. The only 16-bit mode is 16:4 TRANSFORMED (ms_aInfo, :1066): EndPointsFit (:1962-1968) tests A
+// against 16 signed bits - A > 32767 never fits (NBits = 17) and the reference drops the optimised endpoints - but B as the DELTA B - A
+// against 4 bits, so A <= 32767 with B in 32768 ... A + 7 does fit there. The fields would wrap, so the search kernels mark the record
+// instead (ep16_mark -> Rec6::err, which nobody reads as an error after the search: post recomputes it): -1 = A overflowed, the result does
+// not fit, the unoptimised endpoints stand; -(2 + m) = only components of B did, m = their bit mask - bc6h_post_kernel adds the 65536 back
+// to those components and runs TransformForward / EndPointsFit / AssignIndices on the true values, as the reference does.
 // (Round 3 kept them as six ints: 72 bytes of records per task, 1.2 GB written by every mode's pre and read by its post.)
 struct Ep16 { uint32_t a01, a2b0, b12; };
 __device__ __forceinline__ Ep16 pack_ep16(const int (&A)[3], const int (&B)[3])
@@ -54,9 +57,12 @@ __device__ __forceinline__ void unpack_ep16(const Ep16& e, bool sg, int (&A)[3],
     const auto hi = [sg](uint32_t w) { return sg ? (int(w) >> 16) : int(w >> 16); };
     A[0] = lo(e.a01); A[1] = hi(e.a01); A[2] = lo(e.a2b0); B[0] = hi(e.a2b0); B[1] = lo(e.b12); B[2] = hi(e.b12);
 }
-__device__ __forceinline__ bool ep16_overflows(bool sg, const int (&A)[3], const int (&B)[3])
+__device__ __forceinline__ float ep16_mark(bool sg, const int (&A)[3], const int (&B)[3])
 {
-    return sg && (A[0] > 32767 || A[1] > 32767 || A[2] > 32767 || B[0] > 32767 || B[1] > 32767 || B[2] > 32767);
+    if (!sg) return 0.0f;
+    if (A[0] > 32767 || A[1] > 32767 || A[2] > 32767) return -1.0f;
+    const int m = int(B[0] > 32767) | (int(B[1] > 32767) << 1) | (int(B[2] > 32767) << 2);
+    return m ? -float(2 + m) : 0.0f;
 }
 struct Rec6 { Ep16 ep; float err; };                               // 16 bytes per task: the search's start, then its result
 struct Best6 { float err; uint32_t mode; uint64_t lo, hi; };       // 24 bytes per block; mode = position of the winner's mode in the encoder's order
@@ -521,12 +527,18 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     const uint32_t ti = a.tinfo[t];
     const bool ownSearched = (ti >> 24) != 0u || (ti & kDoneBit6) != 0u;
     EndPts opt = o.ep;
-    bool optOverflow = false;            // the search ended outside the signed 16-bit range (see Ep16): EndPointsFit fails in the reference
+    bool optOverflow = false;            // the search ended with A outside the signed 16-bit range (see Ep16): EndPointsFit fails in the reference
     if (ownSearched)
     {
         const Rec6 rec = a.recs[t];
         unpack_ep16(rec.ep, sg, opt.A, opt.B);
-        optOverflow = rec.err < 0.0f;
+        optOverflow = rec.err == -1.0f;
+        if (rec.err <= -2.0f)            // components of B above 32767 wrapped in their fields: the true values (ep16_mark)
+        {
+            const int m = int(-rec.err) - 2;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) if ((m >> c) & 1) opt.B[c] += 65536;
+        }
     }
     // A candidate the search never ran for either region (pruned, does not fit, error already 0: subset size 0 in the task list)
     // still has its unoptimised endpoints: it either cannot win (its lower bound exceeds an error on the table, or it is not
@@ -661,7 +673,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a, uint32_t w
             if (st.ch >= 3)
             {
                 a.recs[myTask].ep = pack_ep16(st.ep.A, st.ep.B);
-                if (ep16_overflows(sg, st.ep.A, st.ep.B)) a.recs[myTask].err = -1.0f;
+                { const float mk = ep16_mark(sg, st.ep.A, st.ep.B); if (mk < 0.0f) a.recs[myTask].err = mk; }
                 myTask = 0xFFFFFFFFu;
             }
         }
@@ -920,7 +932,7 @@ __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel
             if (st.ch >= 3)
             {
                 a.recs[myTask].ep = pack_ep16(st.ep.A, st.ep.B);
-                if (ep16_overflows(SG, st.ep.A, st.ep.B)) a.recs[myTask].err = -1.0f;
+                { const float mk = ep16_mark(SG, st.ep.A, st.ep.B); if (mk < 0.0f) a.recs[myTask].err = mk; }
                 myTask = 0xFFFFFFFFu;
             }
         }
@@ -1004,7 +1016,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_wave_kernel(Bc6hArgs a, uint3
         if (lane == 0)
         {
             a.recs[myTask].ep = pack_ep16(st.ep.A, st.ep.B);
-            if (ep16_overflows(sg, st.ep.A, st.ep.B)) a.recs[myTask].err = -1.0f;
+            { const float mk = ep16_mark(sg, st.ep.A, st.ep.B); if (mk < 0.0f) a.recs[myTask].err = mk; }
         }
     }
 }

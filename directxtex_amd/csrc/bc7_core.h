@@ -29,6 +29,12 @@ namespace dxtex
 {
 namespace bc7
 {
+#if defined(DXTEX_HOST_DEBUG)
+// host mirror only: lockstep_perturb_loop takes the flat-call shortcut in EVERY mode (so that the CPU suite checks the argument on two- and
+// three-subset regions as well) unless this is false - then only where the kernels take it (kFlatSkip in bc7_encode.hip: mode 6's combined
+// loop), which makes the mirror run the path the kernels run for modes 0 - 5. tools/bc7_debug.cpp sets it from DXTEX_HOST_FLAT_SKIP=kernel.
+static bool g_hostFlatSkipEveryMode = true;
+#endif
 #if defined(DXTEX_COUNT_EVALS)
 static long g_evalCount[8], g_evalTexels[8], g_macroCount[8], g_boundCount[8], g_pendCount[8], g_drainCount[8], g_pfTotal[8], g_pfPass[8], g_pfImprove[8], g_pfStepTotal[8][8], g_pfStepPass[8][8], g_tabWin[8], g_tabWinOut[8], g_tabWinOutPrev[8];
 static int g_statTable = 0x7FFFFFFF, g_statTablePrev = 0x7FFFFFFF, g_statOther = 0;
@@ -1312,7 +1318,7 @@ DXTEX_HD int exh_range_bound(const RG& rg, const VarPal<LoopCfg<MODE, IM, CHSET>
     // vp.palO has the searched channel blanked: h = p.q' + floor(-|q'|^2 / 2) is the other channels' share of the score, halved and rounded
     // down as in eval_var_bound (2 h <= 2 p.q' - |q'|^2 <= 2 h + 1: ONE dot product); the searched channel adds 2 pc v - v^2 = pc^2 - (pc - v)^2
     // <= pc^2 - d^2 with d the distance of pc to the entry's interval (v_med3). So score <= 2 h - d^2 + pc^2 + 1 per entry.
-    const int sh = 8 * s.ch;
+    const int sh = 8 * (s.ch & 3);           // (idle lanes of the kernels call this with s.ch == CH1 and discard the result: no shift by 32)
     uint32_t accO[C::N];
 #pragma unroll
     for (int i = 0; i < C::N; ++i) accO[i] = uint32_t(int(vp.nq2O[i]) >> 1);
@@ -1394,9 +1400,13 @@ DXTEX_HD void lockstep_perturb_loop(const RG& rg, uint32_t& optA, uint32_t& optB
     const uint32_t flatMask = flat_channels(rg, flatVals);
     while (s.ch < C::CH1)
     {
-        // (the kernels apply this to the whole-block modes 4 / 5 / 6 only; here every mode takes it, so the CPU suite checks the argument against
-        // the reference on two- and three-subset regions as well)
-        if (flat_call<MODE, IM, CHSET>(s, flatMask, flatVals) && eval_nearest<MODE, IM, CHSET>(rg, s, base) == s.optErr)
+        // (the kernels apply this to mode 6's combined loop only - kFlatSkip, bc7_encode.hip; here every mode takes it by default, so the CPU
+        // suite checks the argument against the reference on two- and three-subset regions as well, and once more the way the kernels run)
+        bool take = MODE == 6 && CHSET == CH_ALL;
+#if defined(DXTEX_HOST_DEBUG)
+        take = take || g_hostFlatSkipEveryMode;
+#endif
+        if (take && flat_call<MODE, IM, CHSET>(s, flatMask, flatVals) && eval_nearest<MODE, IM, CHSET>(rg, s, base) == s.optErr)
         {
             s = skip_flat_calls<MODE, IM, CHSET>(s);
             continue;

@@ -573,8 +573,8 @@ __global__ void __launch_bounds__(64) bc7_perturb_kernel(Bc7Args a, int loop)
             }
         }
         // PerturbOne calls on a channel that is constant over the block and already exact cannot change anything (bc7_core.h, flat_call): the
-        // lane's state moves past them without the 2 PREC - 1 evaluations - every call on alpha of an opaque block in mode 6, every call on the
-        // swapped-in constant of rotations 1 - 3 in modes 4 / 5. One nearest-entry evaluation (for all lanes of the wavefront) decides.
+        // lane's state moves past them without the 2 PREC - 1 evaluations - every call on alpha of an opaque block in mode 6 (kFlatSkip: modes
+        // 4 / 5 were measured and left out, see above). One nearest-entry evaluation (for all lanes of the wavefront) decides.
         if constexpr (kFlatSkip<MODE, IM, CHSET>)
         {
             const bool fc = myTask != 0xFFFFFFFFu && flat_call<MODE, IM, CHSET>(st, flatMask, flatVals);

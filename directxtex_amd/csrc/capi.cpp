@@ -1630,8 +1630,9 @@ dxtex_hresult dxtex_ctx_transfer_bytes(dxtex_ctx* ctx, uint64_t* h2d_bytes, uint
 // single-context entry point on a thread of its own, and the stripes land in the caller's destination: the bytes of the one-context call.
 namespace
 {
+// Returns the first failing stripe's result and, through *failed, its index (so that the caller can surface that context's error text).
 template<class F>
-dxtex_hresult run_stripes(size_t n, F&& stripe)
+dxtex_hresult run_stripes(size_t n, F&& stripe, size_t* failed = nullptr)
 {
     std::vector<dxtex_hresult> hr(n, DXTEX_S_OK);
     std::vector<std::thread> workers;
@@ -1641,8 +1642,26 @@ dxtex_hresult run_stripes(size_t n, F&& stripe)
     catch (...) { for (std::thread& t : workers) t.join(); return DXTEX_E_OUTOFMEMORY; }
     guarded(0);
     for (std::thread& t : workers) t.join();
-    for (dxtex_hresult h : hr) if (h != DXTEX_S_OK) return h;
+    for (size_t i = 0; i < n; ++i) if (hr[i] != DXTEX_S_OK) { if (failed) *failed = i; return hr[i]; }
     return DXTEX_S_OK;
+}
+
+// Every stripe runs on a context of its own (a context's staging buffers and stream serve one call at a time): the same context twice is
+// the caller's error. A failing stripe's text is copied to the first context, where the caller of a multi-context call looks for it.
+dxtex_hresult check_distinct(dxtex_ctx* const* ctxs, size_t nctx)
+{
+    for (size_t i = 0; i < nctx; ++i)
+        for (size_t j = i + 1; j < nctx; ++j)
+            if (ctxs[i] == ctxs[j]) return fail(ctxs[0], DXTEX_E_INVALIDARG, "the same context listed twice");
+    return DXTEX_S_OK;
+}
+dxtex_hresult surface_stripe_error(dxtex_ctx* const* ctxs, dxtex_hresult hr, size_t failed)
+{
+    if (hr != DXTEX_S_OK && failed != 0)
+    {
+        try { ctxs[0]->lastError = "stripe " + std::to_string(failed) + ": " + ctxs[failed]->lastError; } catch (...) { }
+    }
+    return hr;
 }
 } // namespace
 
@@ -1655,7 +1674,14 @@ dxtex_hresult dxtex_compress_multi(dxtex_ctx* const* ctxs, size_t nctx, const dx
     const size_t nbh = (src->height + 3) / 4;
     const size_t n = std::max<size_t>(1, std::min(nctx, nbh));
     if (n == 1 || src->width != dst->width || src->height != dst->height) return dxtex_compress(ctxs[0], src, dst, flags, threshold);      // (a mismatch is the single call's error to report)
-    return run_stripes(n, [&](size_t i) -> dxtex_hresult
+    // the whole image is validated ONCE, before any stripe pointer is formed from it (a stripe's `pixels + y0 * rowPitch` of a null image
+    // would pass the stripes' own null test): the checks of the single-context call, on the first context
+    dxtex_hresult hr = check_pair(ctxs[0], src, dst);
+    if (hr != DXTEX_S_OK) return hr;
+    { size_t sb = 0, db = 0; hr = check_host_pitches(ctxs[0], src, dst, &sb, &db); if (hr != DXTEX_S_OK) return hr; }
+    hr = check_distinct(ctxs, n); if (hr != DXTEX_S_OK) return hr;
+    size_t failed = 0;
+    hr = run_stripes(n, [&](size_t i) -> dxtex_hresult
     {
         const size_t b0 = nbh * i / n, b1 = nbh * (i + 1) / n;            // block rows [b0, b1)
         if (b1 <= b0) return DXTEX_S_OK;
@@ -1664,7 +1690,8 @@ dxtex_hresult dxtex_compress_multi(dxtex_ctx* const* ctxs, size_t nctx, const dx
         s.pixels = src->pixels + y0 * src->rowPitch; s.height = rows; s.slicePitch = src->rowPitch * rows;
         d.pixels = dst->pixels + b0 * dst->rowPitch; d.height = rows; d.slicePitch = dst->rowPitch * (b1 - b0);
         return dxtex_compress(ctxs[i], &s, &d, flags, threshold);
-    });
+    }, &failed);
+    return surface_stripe_error(ctxs, hr, failed);
 }
 
 dxtex_hresult dxtex_generate_mips_multi(dxtex_ctx* const* ctxs, size_t nctx, const dxtex_image* levels, size_t nlevels, uint32_t filter)
@@ -1674,6 +1701,7 @@ dxtex_hresult dxtex_generate_mips_multi(dxtex_ctx* const* ctxs, size_t nctx, con
     uint32_t mode = 0;
     const dxtex_hresult hc = check_mips(ctxs[0], levels, nlevels, filter, &mode);
     if (hc != DXTEX_S_OK) return hc;
+    { const dxtex_hresult hd = check_distinct(ctxs, nctx); if (hd != DXTEX_S_OK) return hd; }
     const uint32_t explicitFilter = (filter & ~kFilterModeMask) | mode;      // the sub-chains below must not choose again (a stripe is not a power of two high)
     // A level is split while it is an exact halving, large enough to be worth a transfer per context, and filtered by a kernel whose taps
     // are a fixed window around the destination row: point / box (the 2 x 2 source texels), linear and cubic with clamp addressing in V
@@ -1690,6 +1718,7 @@ dxtex_hresult dxtex_generate_mips_multi(dxtex_ctx* const* ctxs, size_t nctx, con
         const dxtex_image& S = levels[lv - 1];
         const dxtex_image& D = levels[lv];
         if (S.width != 2 * D.width || S.height != 2 * D.height || D.height < kSplitMinRows || D.height < 4 * nctx) break;
+        size_t failed = 0;
         const dxtex_hresult hr = run_stripes(nctx, [&](size_t i) -> dxtex_hresult
         {
             const size_t d0 = D.height * i / nctx, d1 = D.height * (i + 1) / nctx;
@@ -1705,8 +1734,8 @@ dxtex_hresult dxtex_generate_mips_multi(dxtex_ctx* const* ctxs, size_t nctx, con
             if (h != DXTEX_S_OK) return h;
             std::memcpy(D.pixels + d0 * D.rowPitch, tmp.data() + (d0 - e0) * D.rowPitch, (d1 - d0) * D.rowPitch);
             return DXTEX_S_OK;
-        });
-        if (hr != DXTEX_S_OK) return hr;
+        }, &failed);
+        if (hr != DXTEX_S_OK) return surface_stripe_error(ctxs, hr, failed);
     }
     if (lv >= nlevels) return DXTEX_S_OK;
     return dxtex_generate_mips(ctxs[0], levels + (lv - 1), nlevels - (lv - 1), explicitFilter);       // the rest of the chain from the last level filled

@@ -904,6 +904,7 @@ HRESULT Compress(Device* const* devices, size_t ndevices, const Image& srcImage,
         std::vector<dxtex_ctx*> ctxs;
         if (!Contexts(devices, ndevices, ctxs)) return E_POINTER;
         if (IsCompressed(srcImage.format) || !IsCompressed(format) || srcImage.format == DXGI_FORMAT_UNKNOWN) return E_INVALIDARG;
+        if (!srcImage.pixels) return E_POINTER;                      // as the single-device overload (DirectXTexCompress.cpp:613-614)
         if (!IsKnown(srcImage.format) || !IsKnown(format)) return HRESULT_E_NOT_SUPPORTED;
         HRESULT hr = image.Initialize2D(format, srcImage.width, srcImage.height, 1, 1);
         if (FAILED(hr)) return hr;

@@ -23,14 +23,16 @@ def test_bc7_core_on_the_host_matches_the_reference(seed, flags):
 LOCKSTEP_EXE = os.path.join(ROOT, "oracle", "_ref", "bc7_lockstep_check")
 
 
-@pytest.mark.parametrize("seed,flags", [(31, 0), (32, 0), (33, 0x80000), (34, 0x100000)])
-def test_bc7_lockstep_pieces_match_the_reference(seed, flags):
+@pytest.mark.parametrize("seed,flags,flat", [(31, 0, "every"), (32, 0, "every"), (33, 0x80000, "every"), (34, 0x100000, "every"), (35, 0, "kernel"), (36, 0x80000, "kernel")])
+def test_bc7_lockstep_pieces_match_the_reference(seed, flags, flat):
     """The same comparison with OptimizeOne taken through the pieces the search kernels run per lane (bc7_core.h: perturb_macro with
     the merged first step, Exhaustive as bound filter + minimum key + exh_advance, the settled-scalar-slot shortcut) instead of the
-    straight restatement: what bc7_perturb_kernel / bc7_perturb_filter_kernel / bc7_exhaustive_kernel compute, without a GPU."""
+    straight restatement: what bc7_perturb_kernel / bc7_perturb_filter_kernel / bc7_exhaustive_kernel compute, without a GPU.
+    flat = "every": the flat-call shortcut in every mode (checks its argument on all region shapes); "kernel": only where the kernels take it
+    (mode 6), so modes 0 - 5 run the kernels' path."""
     if not os.path.exists(LOCKSTEP_EXE):
         pytest.fail(f"{LOCKSTEP_EXE} missing: run __graft_entry__.build() where /root/reference exists")
-    r = subprocess.run([LOCKSTEP_EXE, "200", str(seed), hex(flags)], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([LOCKSTEP_EXE, "200", str(seed), hex(flags)], capture_output=True, text=True, timeout=900, env=dict(os.environ, DXTEX_HOST_FLAT_SKIP=flat))
     assert r.returncode == 0 and "0 of 200 tiles differ" in r.stdout, r.stdout[-3000:]
 
 

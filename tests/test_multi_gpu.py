@@ -40,6 +40,30 @@ def test_compress_multi_against_the_reference(ctxs, oracle):
     assert np.array_equal(got, oracle.ref_compress_image(img.reshape(-1), w, h, 28, 98, 0, 0.5))
 
 
+def test_compress_multi_rejects_bad_calls_before_touching_memory(ctxs):
+    """The whole image is validated once, before any stripe pointer is formed (a null image's `pixels + y0 * rowPitch` would pass a stripe's own
+    null test and reach the copy); the same context twice is refused; a stripe's failure text reaches the first context."""
+    import ctypes
+    import directxtex_amd as dx
+    from directxtex_amd import capi
+    w, h = 64, 64
+    rp, sp = capi.compute_pitch(98, w, h)
+    out = np.zeros(sp, np.uint8)
+    src = capi.Image(w, h, 28, w * 4, w * 4 * h, 0)                       # null pixels
+    dst = capi.Image(w, h, 98, rp, sp, out.ctypes.data)
+    lib = ctxs[0]._lib
+    hr = lib.dxtex_compress_multi(capi._ctx_array(ctxs), 3, ctypes.byref(src), ctypes.byref(dst), 0, ctypes.c_float(0.5))
+    assert hr & 0xFFFFFFFF == 0x80004003, hex(hr & 0xFFFFFFFF)         # E_POINTER, not a crash
+    assert b"null pixels" in lib.dxtex_ctx_last_error(ctxs[0]._h)
+    img = np.zeros((h, w, 4), np.uint8)
+    with pytest.raises(dx.DxtexError) as e:
+        capi.compress_multi([ctxs[0], ctxs[1], ctxs[0]], img, w, h, 28, 98, 0, 0.5)
+    assert e.value.hresult & 0xFFFFFFFF == 0x80070057 and "listed twice" in str(e.value)
+    with pytest.raises(dx.DxtexError) as e:
+        capi.generate_mips_multi([ctxs[0], ctxs[0]], np.zeros((1024, 64, 4), np.uint8), 64, 1024, 28, 3, 0x400000)
+    assert e.value.hresult & 0xFFFFFFFF == 0x80070057
+
+
 @pytest.mark.parametrize("filt", [0x100000, 0x200000, 0x300000, 0x400000, 0x500000, 0x300000 | 0x2, 0])
 @pytest.mark.parametrize("fmt,w,h", [(28, 512, 2048), (28, 1200, 1000), (10, 256, 1024), (2, 64, 1024)])
 def test_generate_mips_multi_is_the_single_context_chain(ctxs, filt, fmt, w, h):

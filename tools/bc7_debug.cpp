@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string>
 #include "../directxtex_amd/csrc/bc67_tables.h"
 #include "../directxtex_amd/csrc/bc7_core.h"
 
@@ -230,6 +231,7 @@ static void ref_setup(D3DX_BC7::EncodeParams& EP, const HDRColorA* pIn, int mode
 
 int main(int argc, char** argv)
 {
+    if (const char* fs = getenv("DXTEX_HOST_FLAT_SKIP")) dxtex::bc7::g_hostFlatSkipEveryMode = std::string(fs) != "kernel";
     const int ntiles = argc > 1 ? atoi(argv[1]) : 200;
     g_rng = argc > 2 ? uint32_t(atoi(argv[2])) : 12345u;
     // optional third argument: BC_FLAGS (0x80000 BC7_USE_3SUBSETS, 0x100000 BC7_QUICK)
