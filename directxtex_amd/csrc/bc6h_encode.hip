@@ -688,7 +688,7 @@ __global__ void __launch_bounds__(64) bc6h_perturb_kernel(Bc6hArgs a, uint32_t w
 // 1; DXTEX_BC6H_STATS in the development build, tools/bc6h_debug.cpp -DDXTEX_COUNT_EVALS6 on the host). Those are evaluated exactly -
 // operation for operation as MapColorsQuantized does - by the WHOLE wavefront: the owners put the candidates' palettes on a list in LDS,
 // sixteen lanes take one list entry, lane k scores texel k (norm3 + scan_min, the functions of the plain kernel), and the per-texel errors
-// are summed in texel order along the sixteen lanes (a DPP row_shr:1 chain: the reference's fTotErr += fBestErr, :2074).
+// are summed in texel order for the group's last lane (adds with DPP row_shr sources: the reference's fTotErr += fBestErr, :2074).
 constexpr int kFilterSlots = 32;          // list entries per round (a step with more passing candidates takes several rounds)
 // Texel k of the lane's region sits kColStride6 16-bit words after texel k - 1: 66 (33 dwords), not 64, so that the sixteen lanes of an exact
 // round - same owner column, texels 0 ... 15 - read sixteen different banks (at 64 they all hit one; the bound's loops, where a lane reads
@@ -704,10 +704,35 @@ struct FilterLds
     uint32_t meta[kFilterSlots];          // owner lane | np << 8
 };
 
-// lane k of a row of sixteen gets lane k - 1's value (v_mov_b32_dpp row_shr:1; lane 0 of the row gets 0)
-__device__ __forceinline__ float row_shr1(float v)
+// lane l of a row of sixteen gets lane l - D's value, 0.0f where that lane is outside the row (v_mov_b32_dpp row_shr:D, bound_ctrl:0; the
+// compiler folds it into the v_add_f32 that consumes it)
+template<int D>
+__device__ __forceinline__ float row_shr(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xF, 0xF, true));
+}
+// fTotErr += fBestErr, texel by texel (:2074), for the LAST lane of a group of W lanes (W = 8: half rows, 16: rows): ((e_0 + e_1) + e_2) + ...
+// with e_j pulled from W - 1 - j lanes below - one add with a DPP source per texel, the reference's order. The other lanes compute sums of
+// shifted windows nobody reads. (Round 4 passed the partial sum along the row: a move, an add and a select per texel.)
+template<int W>
+__device__ __forceinline__ float row_ordered_sum(float err)
+{
+    float S = row_shr<W - 1>(err);
+    if constexpr (W > 2) S = S + row_shr<W - 2>(err);
+    if constexpr (W > 3) S = S + row_shr<W - 3>(err);
+    if constexpr (W > 4) S = S + row_shr<W - 4>(err);
+    if constexpr (W > 5) S = S + row_shr<W - 5>(err);
+    if constexpr (W > 6) S = S + row_shr<W - 6>(err);
+    if constexpr (W > 7) S = S + row_shr<W - 7>(err);
+    if constexpr (W > 8) S = S + row_shr<W - 8>(err);
+    if constexpr (W > 9) S = S + row_shr<W - 9>(err);
+    if constexpr (W > 10) S = S + row_shr<W - 10>(err);
+    if constexpr (W > 11) S = S + row_shr<W - 11>(err);
+    if constexpr (W > 12) S = S + row_shr<W - 12>(err);
+    if constexpr (W > 13) S = S + row_shr<W - 13>(err);
+    if constexpr (W > 14) S = S + row_shr<W - 14>(err);
+    if constexpr (W > 15) S = S + row_shr<W - 15>(err);
+    return S + err;
 }
 
 template<class WRITE>
@@ -762,17 +787,9 @@ __device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L,
                 for (int i = 0; i < 8; ++i) e[i] = norm3(tr, tg, tb, pr[i], pg[i], pb[i]);
                 err = scan_min(e);
             }
-            // fTotErr += fBestErr, texel by texel (:2074): lane j of the group takes lane j - 1's partial sum and adds its texel's error -
-            // the reference's order; texels past the region's end add +0.0f, which changes nothing, so lane 15 ends with the total
-            // (half rows: lane 8 of a row has kk == 0 and never takes lane 7's sum, so the two halves' chains do not meet)
-            float S = err;
-#pragma unroll
-            for (int j = 1; j < 8; ++j) { const float t = row_shr1(S); S = (kk == j) ? t + err : S; }
-            if (!packed)
-            {
-#pragma unroll
-                for (int j = 8; j < 16; ++j) { const float t = row_shr1(S); S = (kk == j) ? t + err : S; }
-            }
+            // fTotErr += fBestErr, texel by texel (:2074), in the reference's order; texels past the region's end add +0.0f, which changes
+            // nothing, so the group's last lane ends with the total (row_ordered_sum; half rows: lane 7 / 15 of a row pull from their own half)
+            const float S = packed ? row_ordered_sum<8>(err) : row_ordered_sum<16>(err);
             if (kk == (packed ? 7 : 15) && sl < cnt) L.tot[sl] = S;
         }
         __syncthreads();

@@ -6,7 +6,7 @@
 # A variant replaces lib/libdxtex_amd_dev.so for its run (the command selects the development build itself: --dev); the product library is not touched.
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$HERE/..
-CS=$ROOT/directxtex_amd/csrc; OBJ=$ROOT/build/obj; VAR=$ROOT/build/variants
+CS=$ROOT/directxtex_amd/csrc; OBJ=$ROOT/build/obj; VAR=${VARDIR:-$ROOT/build/variants}      # VARDIR: several sets of variants side by side
 if [ "$1" = build ]; then
   TU=$2; shift 2
   rm -rf $VAR; mkdir -p $VAR
