@@ -64,6 +64,24 @@ __device__ __forceinline__ float ep16_mark(bool sg, const int (&A)[3], const int
     const int m = int(B[0] > 32767) | (int(B[1] > 32767) << 1) | (int(B[2] > 32767) << 2);
     return m ? -float(2 + m) : 0.0f;
 }
+// The filter kernel's per-lane task state (bc6h_core.h: Perturb6, twelve dwords) in SIX: the endpoints as Ep16, err, err0, and new0 / ch / sub /
+// do_b in one word. As twelve dwords the compiler kept the struct in SCRATCH (the kernel is compiled for four waves per SIMD) and read it back
+// at every PerturbOne call and - three dependent round trips to memory - for every step whose candidates reach the exact list: by the kernel's own
+// clock (DXTEX_BC6H_STATS, profiles/r06_bc6h.md) the "list write" that contains those loads was 35 - 44 % of a wavefront's time. The
+// two-region modes' endpoints have at most eleven bits (ms_aInfo, :1051-1060), new0 is an endpoint value: sixteen-bit fields hold them.
+struct PkState { Ep16 ep; float err, err0; uint32_t misc; };       // misc = new0 (low 16 bits, sign-extended back) | ch << 16 | sub << 18 | do_b << 20
+__device__ __forceinline__ PkState pk_pack(const Perturb6& s)
+{
+    PkState p; p.ep = pack_ep16(s.ep.A, s.ep.B); p.err = s.err; p.err0 = s.err0;
+    p.misc = (uint32_t(s.new0) & 0xFFFFu) | (uint32_t(s.ch) << 16) | (uint32_t(s.sub) << 18) | (uint32_t(s.do_b) << 20);
+    return p;
+}
+__device__ __forceinline__ Perturb6 pk_unpack(const PkState& p, bool sg)
+{
+    Perturb6 s; unpack_ep16(p.ep, sg, s.ep.A, s.ep.B); s.err = p.err; s.err0 = p.err0;
+    s.new0 = int(int16_t(p.misc & 0xFFFFu)); s.ch = int((p.misc >> 16) & 3u); s.sub = int((p.misc >> 18) & 3u); s.do_b = int((p.misc >> 20) & 1u);
+    return s;
+}
 struct Rec6 { Ep16 ep; float err; };                               // 16 bytes per task: the search's start, then its result
 struct Best6 { float err; uint32_t mode; uint64_t lo, hi; };       // 24 bytes per block; mode = position of the winner's mode in the encoder's order
 struct OrgSave { Ep16 ep; float err; uint64_t idx; };              // 24 bytes per task: Refine's unoptimised half, pre -> post
@@ -743,6 +761,7 @@ __device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L,
 #if defined(DXTEX_DEV)
     if (stats && lane == 0) { atomicAdd(stats + 1, 1u); atomicAdd(stats + 2, uint32_t(__popcll(b0) + __popcll(b1))); }
     const long long t0 = stats ? clock64() : 0;
+    long long tList = 0, tRounds = 0;
 #endif
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t n0 = uint32_t(__popcll(b0)), total = n0 + uint32_t(__popcll(b1));
@@ -763,9 +782,26 @@ __device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L,
     {
         const uint32_t cnt = min(total - first, uint32_t(kFilterSlots));
         const bool in0 = pass0 && (s0 - first) < cnt, in1 = pass1 && (s1 - first) < cnt;          // unsigned: s < first wraps above cnt
-        if (in0) { writePal(0, reinterpret_cast<float*>(L.pal[s0 - first])); L.meta[s0 - first] = uint32_t(lane) | (uint32_t(np) << 8); }
-        if (in1) { writePal(1, reinterpret_cast<float*>(L.pal[s1 - first])); L.meta[s1 - first] = uint32_t(lane) | (uint32_t(np) << 8); }
+        // ONE pass of the palette derivation (~250 instructions, run by the few owners) serves both candidates of a step: a lane writes the one it
+        // has; the second pass runs only when some lane has both on the list (the kernel is bound by instruction issue: what counts is how
+        // often the derivation is issued, not how many lanes take part)
+        {
+            const bool one = in0 || in1, both = in0 && in1;
+            const uint32_t sl = (in0 ? s0 : s1) - first;
+            if (one) { writePal(in0 ? 0 : 1, reinterpret_cast<float*>(L.pal[sl])); L.meta[sl] = uint32_t(lane) | (uint32_t(np) << 8); }
+            if (__ballot(both) != 0ull)
+            {
+                if (both) { writePal(1, reinterpret_cast<float*>(L.pal[s1 - first])); L.meta[s1 - first] = uint32_t(lane) | (uint32_t(np) << 8); }
+            }
+        }
+#if defined(DXTEX_DEV)
+        const long long tw0 = stats ? clock64() : 0;
+#endif
         __syncthreads();                  // one wavefront per workgroup: orders the LDS traffic, costs no barrier
+#if defined(DXTEX_DEV)
+        const long long tw1 = stats ? clock64() : 0;
+        tList += tw1 - (first ? tw0 : t0);
+#endif
         for (uint32_t g = 0; g < cnt; g += perRound)
         {
 #if defined(DXTEX_DEV)
@@ -775,6 +811,9 @@ __device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L,
             const uint32_t meta = (sl < cnt) ? L.meta[sl] : 0u;
             const int owner = int(meta & 63u), onp = int(meta >> 8);
             float err = 0.0f;
+#if defined(DXTEX_DEV)
+            if (stats) { const unsigned long long used = __ballot(kk < onp); if (lane == 0) atomicAdd(stats + 6, uint32_t(__popcll(used))); }
+#endif
             if (kk < onp)
             {
                 const int16_t* t = cols + owner + kk * kColStride6;
@@ -792,13 +831,21 @@ __device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L,
             const float S = packed ? row_ordered_sum<8>(err) : row_ordered_sum<16>(err);
             if (kk == (packed ? 7 : 15) && sl < cnt) L.tot[sl] = S;
         }
+#if defined(DXTEX_DEV)
+        if (stats) tRounds += clock64() - tw1;
+#endif
         __syncthreads();
         if (in0) e0 = L.tot[s0 - first];
         if (in1) e1 = L.tot[s1 - first];
         __syncthreads();
     }
 #if defined(DXTEX_DEV)
-    if (stats && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(stats + 8), (unsigned long long)(clock64() - t0));
+    if (stats && lane == 0)
+    {
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats + 8), (unsigned long long)(clock64() - t0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats + 14), (unsigned long long)tList);
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats + 16), (unsigned long long)tRounds);
+    }
 #endif
 }
 
@@ -807,12 +854,15 @@ __device__ __forceinline__ void exact_by_wave(const int16_t* cols, FilterLds& L,
 // the best so far and `<` would refuse it; the +step candidate is bounded against the best error before the -step candidate's result (a
 // superset passes) and accepted against the one after it, as in the reference's loop.
 template<bool SG>
-__device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, FilterLds& L, int lane, bool active, const Texels16& tx, const Bound6& bd, const Perturb6& s,
+__device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, FilterLds& L, int lane, bool active, const Texels16& tx, const Bound6& bd, const PkState& pk,
                                                       int prec, float& outErr, int& outVal, uint32_t* stats)
 {
     constexpr int N = 8;
+    const Perturb6 s = pk_unpack(pk, SG);          // short-lived: only ch / do_b (and what is derived below) live across the step loop
 #if defined(DXTEX_DEV)
     if (stats) { const unsigned long long act = __ballot(active); if (lane == 0) { atomicAdd(stats + 4, 1u); atomicAdd(stats + 5, uint32_t(__popcll(act))); } }
+    const long long tm0 = stats ? clock64() : 0;
+    long long tBound = 0;
 #endif
     const int fixedQ = (s.ch == 0) ? (s.do_b ? s.ep.A[0] : s.ep.B[0]) : (s.ch == 1) ? (s.do_b ? s.ep.A[1] : s.ep.B[1]) : (s.do_b ? s.ep.A[2] : s.ep.B[2]);
     int cur = (s.ch == 0) ? (s.do_b ? s.ep.B[0] : s.ep.A[0]) : (s.ch == 1) ? (s.do_b ? s.ep.B[1] : s.ep.A[1]) : (s.do_b ? s.ep.B[2] : s.ep.A[2]);
@@ -832,10 +882,15 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
     };
     auto write_pal = [&](int tmp, float* dst)        // the rare path: all three channels' palettes are derived again rather than kept across the bound's loop
     {
+        // the endpoints from the packed words, opaque to the optimiser: it must not keep the six unpacked values alive from the top of the call
+        Ep16 e = pk.ep;
+        asm volatile("" : "+v"(e.a01), "+v"(e.a2b0), "+v"(e.b12));
+        int A[3], B[3];
+        unpack_ep16(e, SG, A, B);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
         {
-            const int qa = (c == s.ch && !s.do_b) ? tmp : s.ep.A[c], qb = (c == s.ch && s.do_b) ? tmp : s.ep.B[c];
+            const int qa = (c == s.ch && !s.do_b) ? tmp : A[c], qb = (c == s.ch && s.do_b) ? tmp : B[c];
             float pal[N];
             palette_channel<N>(qa, qb, prec, SG, pal);
 #pragma unroll
@@ -857,11 +912,26 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
     for (int step = 1 << (prec - 1) >> 1; step; step >>= 1)
     {
         const int tM = cur - step, tP = cur + step;
+#if defined(DXTEX_DEV)
+        const long long tb0 = stats ? clock64() : 0;
+#endif
         float varM[N], varP[N];
         var_of(tM, varM);
         var_of(tP, varP);
         float lbM, lbP;
         perturb6_bound_pair<N>(tx, bd, mb, varM, varP, minErr, lbM, lbP);
+#if defined(DXTEX_DEV)
+        if (stats)
+        {
+            // lanes that still walk texels when the pair's loop ends are not known here: count the lanes with a task, weighted by their share of the longest region
+            int npMax = tx.np;
+            for (int d = 32; d; d >>= 1) npMax = max(npMax, __shfl_xor(npMax, d));
+            int share = npMax ? (tx.np * 64) / npMax : 0;          // 64ths of the wave's loop this lane is busy
+            for (int d = 32; d; d >>= 1) share += __shfl_xor(share, d);
+            if (lane == 0) atomicAdd(stats + 7, uint32_t(share >> 6));
+            tBound += clock64() - tb0;
+        }
+#endif
         const bool passM = active && (tM >= 0) && (tM < (1 << prec)) && lbM < minErr;
         const bool passP = active && (tP >= 0) && (tP < (1 << prec)) && lbP < minErr;
         float eM = 0.0f, eP = 0.0f;
@@ -875,11 +945,22 @@ __device__ __forceinline__ void perturb6_macro_filter(const int16_t* cols, Filte
         cur += beststep;
     }
     outErr = minErr; outVal = cur;
+#if defined(DXTEX_DEV)
+    if (stats && lane == 0)
+    {
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats + 12), (unsigned long long)tBound);
+        atomicAdd(reinterpret_cast<unsigned long long*>(stats + 20), (unsigned long long)(clock64() - tm0));
+    }
+#endif
 }
 
 #if !defined(DXTEX_F6_WAVES)
 #define DXTEX_F6_WAVES 4
 #endif
+#if !defined(DXTEX_F6_PICKUP_MIN)
+#define DXTEX_F6_PICKUP_MIN 1
+#endif
+constexpr int kPickupMin6 = DXTEX_F6_PICKUP_MIN;
 template<bool SG>
 __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel(Bc6hArgs a)
 {
@@ -891,13 +972,13 @@ __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel
     uint32_t* head = a.counters + kQueueBase;
     int16_t* slot = &sCols[lane];
     EndPts zero; for (int c = 0; c < 3; ++c) { zero.A[c] = 0; zero.B[c] = 0; }
-    Perturb6 st = perturb6_begin(zero, 0.0f);
+    PkState st = pk_pack(perturb6_begin(zero, 0.0f));
     Texels16 tx; tx.r = slot; tx.g = slot + 16 * kColStride6; tx.b = slot + 32 * kColStride6; tx.stride = kColStride6; tx.np = 0;
     Bound6 bd; bd.o[0] = bd.o[1] = bd.o[2] = 0.0f; bd.pp = 0.0f; bd.pre[0] = bd.pre[1] = bd.pre[2] = 0.0f;
     uint32_t myTask = 0xFFFFFFFFu;
     const int prec = a.mode.prec;
 #if defined(DXTEX_DEV)
-    uint32_t* stats = a.filterStats ? a.counters + 48 : nullptr;      // [0] pair steps, [1] steps with passing candidates, [2] passing candidates, [3] rounds of four, [4] macros, [5] active lanes in them
+    uint32_t* stats = a.filterStats ? a.counters + 64 : nullptr;      // see the table printed by the launcher (DXTEX_BC6H_STATS)
 #else
     uint32_t* stats = nullptr;
 #endif
@@ -908,7 +989,13 @@ __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel
     for (;;)
     {
         const unsigned long long idle = __ballot(myTask == 0xFFFFFFFFu);
-        if (idle && !(q.drained && q.lo >= q.hi))
+#if defined(DXTEX_DEV)
+        const long long tp0 = stats ? clock64() : 0;
+#endif
+        // (kPickupMin6 > 1 would let idle lanes wait until several can take tasks together, as the BC7 kernels do; measured 1 / 4 / 8 / 16 / 32:
+        // 56.0 / 56.0 / 56.2 / 56.8 / 59.7 ms - the kernel is bound by instruction issue, a pick-up's latency is hidden by the other waves, and
+        // waiting lanes are lost work: 1 stays)
+        if (idle && !(q.drained && q.lo >= q.hi) && (__popcll(idle) >= kPickupMin6 || idle == ~0ull))
         {
             const uint32_t idx = queue_take(q, head, live, idle, lane);
             if (idx != 0xFFFFFFFFu)
@@ -916,24 +1003,38 @@ __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel
                 const uint2 task = a.order[idx];
                 myTask = task.x;
                 const Rec6 rec = a.recs[myTask];
-                const float* gp = a.fpix + uint64_t(myTask / 16u) * 48;
-                // the region's texels into the lane's columns (floats holding integers of at most 16 bits)
-                uint32_t mask = task.y & 0xFFFFu;
+                // the block's 48 texel values (r[16], g[16], b[16], floats holding 16-bit integers): twelve loads in flight at once, then the region's
+                // texels into the lane's columns with static register indices (before: a load per texel and channel inside the loop over the mask,
+                // i.e. np dependent trips to memory)
+                const float4* gp = reinterpret_cast<const float4*>(a.fpix + uint64_t(myTask / 16u) * 48);
+                float4 v[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) v[i] = gp[i];
+                const uint32_t mask = task.y & 0xFFFFu;
                 int np = 0;
-                while (mask)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
                 {
-                    const int i = __ffs(int(mask)) - 1;
-                    mask &= mask - 1u;
-                    slot[np * kColStride6] = int16_t(int(gp[i])); slot[(16 + np) * kColStride6] = int16_t(int(gp[16 + i])); slot[(32 + np) * kColStride6] = int16_t(int(gp[32 + i]));
-                    ++np;
+                    if (mask & (1u << i))
+                    {
+                        const float4 r4 = v[i >> 2], g4 = v[4 + (i >> 2)], b4 = v[8 + (i >> 2)];
+                        const float fr = (i & 3) == 0 ? r4.x : (i & 3) == 1 ? r4.y : (i & 3) == 2 ? r4.z : r4.w;
+                        const float fg = (i & 3) == 0 ? g4.x : (i & 3) == 1 ? g4.y : (i & 3) == 2 ? g4.z : g4.w;
+                        const float fb = (i & 3) == 0 ? b4.x : (i & 3) == 1 ? b4.y : (i & 3) == 2 ? b4.z : b4.w;
+                        slot[np * kColStride6] = int16_t(int(fr)); slot[(16 + np) * kColStride6] = int16_t(int(fg)); slot[(32 + np) * kColStride6] = int16_t(int(fb));
+                        ++np;
+                    }
                 }
                 tx.np = np;
                 bd = bound6_begin(tx);
                 EndPts e;
                 unpack_ep16(rec.ep, SG, e.A, e.B);
-                st = perturb6_begin(e, rec.err);
+                st = pk_pack(perturb6_begin(e, rec.err));
             }
         }
+#if defined(DXTEX_DEV)
+        if (stats && lane == 0 && idle) atomicAdd(reinterpret_cast<unsigned long long*>(stats + 18), (unsigned long long)(clock64() - tp0));
+#endif
         const bool active = myTask != 0xFFFFFFFFu;
         if (__ballot(active) == 0ull)
         {
@@ -945,11 +1046,12 @@ __global__ void __launch_bounds__(64, DXTEX_F6_WAVES) bc6h_perturb_filter_kernel
         perturb6_macro_filter<SG>(sCols, sList, lane, active, tx, bd, st, prec, e, v, stats);
         if (active)
         {
-            st = perturb6_transition(st, e, v);
-            if (st.ch >= 3)
+            const Perturb6 nx = perturb6_transition(pk_unpack(st, SG), e, v);
+            st = pk_pack(nx);
+            if (nx.ch >= 3)
             {
-                a.recs[myTask].ep = pack_ep16(st.ep.A, st.ep.B);
-                { const float mk = ep16_mark(SG, st.ep.A, st.ep.B); if (mk < 0.0f) a.recs[myTask].err = mk; }
+                a.recs[myTask].ep = st.ep;
+                { const float mk = ep16_mark(SG, nx.ep.A, nx.ep.B); if (mk < 0.0f) a.recs[myTask].err = mk; }
                 myTask = 0xFFFFFFFFu;
             }
         }
@@ -1065,7 +1167,7 @@ struct Scratch6
         orgs = o; o = up(o + nb * 16 * sizeof(OrgSave));
         order = o; o = up(o + nb * 16 * sizeof(uint2));
         tinfo = o; o = up(o + nb * 16 * sizeof(uint32_t));
-        counters = o; o = up(o + 64 * sizeof(uint32_t));
+        counters = o; o = up(o + 128 * sizeof(uint32_t));       // [0, 64): bins, live count, queue heads; [64, 128): the development build's statistics
         best = o; o = up(o + nb * sizeof(Best6));
         bounds = o; o = up(o + nb * 17 * sizeof(float));
         total = o;
@@ -1156,7 +1258,7 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         auto sort_tasks = [&](uint32_t ntasks)
         {
             const uint32_t binGroups = std::min<uint32_t>(kBinGroups, (ntasks + 255) / 256);
-            (void)hipMemsetAsync(a.counters, 0, 64 * sizeof(uint32_t), stream);
+            (void)hipMemsetAsync(a.counters, 0, 128 * sizeof(uint32_t), stream);
             hipLaunchKernelGGL(bc7_bin_count_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters);
             hipLaunchKernelGGL(bc7_bin_scan_kernel, dim3(1), dim3(1), 0, stream, a.counters);
             hipLaunchKernelGGL(bc7_bin_scatter_kernel, dim3(binGroups), dim3(256), 0, stream, a.tinfo, ntasks, a.counters, a.order);
@@ -1217,13 +1319,22 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
 #if defined(DXTEX_DEV)
             if (stats6 && !plainPerturb)
             {
-                uint32_t c[12] = {};
+                uint32_t c[24] = {};
                 (void)hipStreamSynchronize(stream);
-                (void)hipMemcpy(c, a.counters + 48, sizeof(c), hipMemcpyDeviceToHost);
-                unsigned long long tx = 0, tk = 0; memcpy(&tx, c + 8, 8); memcpy(&tk, c + 10, 8);
-                std::fprintf(stderr, "bc6h filter mode %d: %u macros (%.1f lanes active), %u pair steps, %u with passing candidates (%.2f per such step), %u rounds of four; "
-                             "exact evaluation %.1f %% of the waves' time\n", mi, c[4],
-                             c[4] ? double(c[5]) / c[4] : 0.0, c[0], c[1], c[1] ? double(c[2]) / c[1] : 0.0, c[3], tk ? 100.0 * double(tx) / double(tk) : 0.0);
+                (void)hipMemcpy(c, a.counters + 64, sizeof(c), hipMemcpyDeviceToHost);
+                auto u64 = [&](int i) { unsigned long long v = 0; memcpy(&v, c + i, 8); return double(v); };
+                const double tk = u64(10), tx = u64(8), tb = u64(12), tl = u64(14), tr = u64(16), tp = u64(18), tm = u64(20);
+                const double lanesMacro = c[4] ? double(c[5]) / c[4] : 0.0, lanesBound = c[0] ? double(c[7]) / c[0] : 0.0, lanesRounds = c[3] ? double(c[6]) / c[3] : 0.0,
+                             lanesList = c[1] ? double(c[2]) / c[1] : 0.0;
+                std::fprintf(stderr, "bc6h filter mode %d: %u macros (%.1f lanes active), %u pair steps, %u with passing candidates (%.2f per such step), %u list rounds; "
+                             "exact evaluation %.1f %% of the waves' time\n", mi, c[4], lanesMacro, c[0], c[1], lanesList, c[3], tk ? 100.0 * tx / tk : 0.0);
+                // where the wave time goes and how many lanes work there (time-weighted lanes = what "active lanes per VALU instruction" approximates)
+                const double tOtherMacro = tm - tb - tx, tRest = tk - tm - tp, tBack = tx - tl - tr;
+                const double weighted = (tb * lanesBound + tl * lanesList + tr * lanesRounds + tBack * lanesList + tOtherMacro * lanesMacro + tp * 32.0 + tRest * lanesMacro) / (tk ? tk : 1.0);
+                std::fprintf(stderr, "bc6h filter sections mode %d | share of wave time, lanes busy: bound loops %.1f %% at %.1f | list write %.1f %% at %.1f | exact rounds %.1f %% at %.1f | "
+                             "read-back + syncs %.1f %% at %.1f | rest of PerturbOne (fixed palettes, bound setup, transitions) %.1f %% at %.1f | task pickup %.1f %% | outside %.1f %% | "
+                             "time-weighted lanes %.1f of 64\n", mi, 100 * tb / tk, lanesBound, 100 * tl / tk, lanesList, 100 * tr / tk, lanesRounds, 100 * tBack / tk, lanesList,
+                             100 * tOtherMacro / tk, lanesMacro, 100 * tp / tk, 100 * tRest / tk, weighted);
             }
 #endif
             DXTEX_MARK(kPost[mi]);
