@@ -669,6 +669,26 @@ def main():
                           "ms_by_contexts": {str(k): round(v * 1e3, 3) for k, v in times.items()}, "identical_to_reference_golden": ok,
                           "workload": "ONE 4096^2 RGBA8 image in host memory -> BC7 through dxtex_compress_multi: a context per GPU in this process, a thread per context, "
                                       "stripes of block rows; upload, encode and download inside the time"}
+                # the mip chain of the same image split the same way (dxtex_generate_mips_multi: resident stripes - one upload and one download per
+                # context and chain, nothing between the contexts), with what every context moved over the host link
+                try:
+                    chain = {}
+                    for n in sorted({1, ndev}):
+                        use = all_ctxs[:n]
+                        dx.capi.generate_mips_multi(use, img0, WIDTH, HEIGHT, dx.DXGI_FORMAT_R8G8B8A8_UNORM, 13, 0x300000)
+                        for c in use:
+                            c.transfer_bytes(reset=True)
+                        t1 = time.perf_counter()
+                        lv = dx.capi.generate_mips_multi(use, img0, WIDTH, HEIGHT, dx.DXGI_FORMAT_R8G8B8A8_UNORM, 13, 0x300000)
+                        dt = time.perf_counter() - t1
+                        moved = [c.transfer_bytes() for c in use]
+                        chain[str(n)] = {"ms": round(dt * 1e3, 3), "h2d_bytes_per_context": [m[0] for m in moved], "d2h_bytes_per_context": [m[1] for m in moved],
+                                         "levels_sha256_16": hashlib.sha256(b"".join(x.tobytes() for x in lv)).hexdigest()[:16]}
+                    inproc["mip_chain_cubic_4096"] = {"by_contexts": chain, "identical_across_context_counts": len({v["levels_sha256_16"] for v in chain.values()}) == 1,
+                                                      "source_bytes": WIDTH * HEIGHT * 4,
+                                                      "workload": "4096^2 RGBA8 host image -> 13-level cubic chain in host memory through dxtex_generate_mips_multi"}
+                except Exception as e:
+                    inproc["mip_chain_cubic_4096"] = {"error": repr(e)}
                 for c in extra_ctxs:
                     c.close()
             except Exception as e:

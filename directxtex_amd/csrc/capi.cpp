@@ -1703,36 +1703,87 @@ dxtex_hresult dxtex_generate_mips_multi(dxtex_ctx* const* ctxs, size_t nctx, con
     if (hc != DXTEX_S_OK) return hc;
     { const dxtex_hresult hd = check_distinct(ctxs, nctx); if (hd != DXTEX_S_OK) return hd; }
     const uint32_t explicitFilter = (filter & ~kFilterModeMask) | mode;      // the sub-chains below must not choose again (a stripe is not a power of two high)
-    // A level is split while it is an exact halving, large enough to be worth a transfer per context, and filtered by a kernel whose taps
+    // A level is split while it is an exact halving, large enough to be worth a context of its own, and filtered by a kernel whose taps
     // are a fixed window around the destination row: point / box (the 2 x 2 source texels), linear and cubic with clamp addressing in V
-    // (u = (y + 0.5) * 2 - 0.5 is exact in fp32, so a stripe's rows get the weights the whole image's rows get). Destination rows
-    // [d0, d1) come from source rows [2 d0 - 2, 2 d1 + 2): the stripe is resized with one extra destination row on either inner side, whose
-    // own taps run into the stripe's clamped edge and which is thrown away. The triangle filter (a gather over the whole axis) and V wrap /
-    // mirror go to the first context whole, as does the chain below kSplitMinRows.
+    // (u = (y + 0.5) * 2 - 0.5 is exact in fp32, so a stripe's rows get the weights the whole image's rows get). The triangle filter (a
+    // gather over the whole axis) and V wrap / mirror go to the first context whole, as does the chain below kSplitMinRows.
+    //
+    // Round 6: the stripes stay RESIDENT. A context computes rows of every split level from its own copy of the level above and never
+    // exchanges anything: destination rows [a, b) of a level come from source rows [2 a - 2, 2 b + 2) of the level above (cubic reads one
+    // row above the pair it covers and one below, filters.h:176-179; a sub-image is resized with one throw-away destination row on either
+    // inner side, whose taps run into the sub-image's clamped edge), so working back from the stripe a context owns at the LAST split level
+    // gives the rows it needs of every level above - its own stripe plus a halo that doubles per level (3 * 2^k rows k levels up: 48 rows
+    // of level 0 for four split levels, against stripes of hundreds). One upload per context (its rows of level 0), the levels chained on
+    // the device, one download per context (its stripes of levels 1 ... L): every byte crosses the host link once, and on N GPUs no byte
+    // crosses between them. (Round 5 went host -> device -> host once per level and stripe.)
     constexpr size_t kSplitMinRows = 256;
     const bool splittable = nctx > 1 && (mode == DXTEX_FILTER_POINT || mode == DXTEX_FILTER_BOX || mode == DXTEX_FILTER_LINEAR || mode == DXTEX_FILTER_CUBIC) &&
                             !(filter & (DXTEX_FILTER_WRAP_V | DXTEX_FILTER_MIRROR_V));
-    size_t lv = 1;
+    size_t lv = 1;      // levels [1, lv) are split
     for (; splittable && lv < nlevels; ++lv)
     {
         const dxtex_image& S = levels[lv - 1];
         const dxtex_image& D = levels[lv];
         if (S.width != 2 * D.width || S.height != 2 * D.height || D.height < kSplitMinRows || D.height < 4 * nctx) break;
+    }
+    const size_t L = lv - 1;                          // the last split level (0: nothing to split)
+    if (L >= 1)
+    {
+        struct Rows { size_t a, b; };
         size_t failed = 0;
         const dxtex_hresult hr = run_stripes(nctx, [&](size_t i) -> dxtex_hresult
         {
-            const size_t d0 = D.height * i / nctx, d1 = D.height * (i + 1) / nctx;
-            if (d1 <= d0) return DXTEX_S_OK;
-            const size_t e0 = d0 ? d0 - 1 : 0, e1 = std::min(D.height, d1 + 1);           // with the throw-away rows
-            dxtex_image s = S, d = D;
-            s.pixels = S.pixels + 2 * e0 * S.rowPitch; s.height = 2 * (e1 - e0); s.slicePitch = S.rowPitch * s.height;
-            d.height = e1 - e0; d.slicePitch = D.rowPitch * d.height;
-            if (e0 == d0 && e1 == d1) { d.pixels = D.pixels + d0 * D.rowPitch; return dxtex_resize(ctxs[i], &s, &d, explicitFilter); }
-            std::vector<uint8_t> tmp(d.slicePitch);
-            d.pixels = tmp.data();
-            const dxtex_hresult h = dxtex_resize(ctxs[i], &s, &d, explicitFilter);
-            if (h != DXTEX_S_OK) return h;
-            std::memcpy(D.pixels + d0 * D.rowPitch, tmp.data() + (d0 - e0) * D.rowPitch, (d1 - d0) * D.rowPitch);
+            dxtex_ctx* ctx = ctxs[i];
+            auto owned = [&](size_t l) { const size_t H = levels[l].height; return Rows{ H * i / nctx, H * (i + 1) / nctx }; };
+            // C[l]: rows of level l this context must hold CORRECT; E[l]: rows it computes (C[l] plus the throw-away rows); S[l - 1] = [2 E[l].a, 2 E[l].b):
+            // the sub-image of level l - 1 they are computed from
+            std::vector<Rows> C(L + 1), E(L + 1);
+            C[L] = owned(L);
+            for (size_t l = L; l >= 1; --l)
+            {
+                const size_t H = levels[l].height;
+                E[l] = Rows{ C[l].a ? C[l].a - 1 : 0, std::min(C[l].b + 1, H) };
+                C[l - 1] = Rows{ 2 * E[l].a, 2 * E[l].b };
+                if (l - 1 >= 1)                       // the level above is an output too: its own stripe must be inside what is held (it is: the halo grows faster than the stripes' rounding)
+                {
+                    const Rows o = owned(l - 1);
+                    C[l - 1].a = std::min(C[l - 1].a, o.a); C[l - 1].b = std::max(C[l - 1].b, o.b);
+                }
+            }
+            E[0] = C[0];
+            if (C[L].b <= C[L].a) return DXTEX_S_OK;
+            // one arena for the context's rows of every level (the staging buffer of the single-image calls, reused across calls)
+            std::vector<size_t> at(L + 1);
+            size_t bytes = 0;
+            for (size_t l = 0; l <= L; ++l) { at[l] = bytes; bytes += ((E[l].b - E[l].a) * levels[l].rowPitch + 255) & ~size_t(255); }
+            ScopedDevice sd(ctx->device);
+            dxtex_hresult h = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, bytes); if (h != DXTEX_S_OK) return h;
+            uint8_t* arena = static_cast<uint8_t*>(ctx->stageIn);
+            // rows [a, b) of level l as one copy: whole pitches, the last row only as far as its texels go (a host image may end there)
+            auto span = [&](size_t l, const Rows& r) -> size_t
+            {
+                size_t minRow = 0, minSlice = 0;
+                (void)dxtex_compute_pitch(levels[l].format, levels[l].width, 1, &minRow, &minSlice);
+                return (r.b - r.a - 1) * levels[l].rowPitch + minRow;
+            };
+            HIP_TRY(ctx, counted_copy(ctx, arena + at[0], levels[0].pixels + E[0].a * levels[0].rowPitch, span(0, E[0]), hipMemcpyHostToDevice, ctx->stream));
+            time_begin(ctx);
+            for (size_t l = 1; l <= L; ++l)
+            {
+                const size_t s0 = 2 * E[l].a;         // first row of the source sub-image, inside [E[l - 1].a, E[l - 1].b)
+                std::vector<LevelPair> pairs{ { arena + at[l - 1] + (s0 - E[l - 1].a) * levels[l - 1].rowPitch, levels[l - 1].rowPitch, levels[l - 1].width, 2 * (E[l].b - E[l].a),
+                                                arena + at[l], levels[l].rowPitch, levels[l].width, E[l].b - E[l].a } };
+                h = submit_resizes(ctx, pairs, levels[0].format, mode, explicitFilter, false);
+                if (h != DXTEX_S_OK) { time_end(ctx); return h; }
+            }
+            time_end(ctx);
+            for (size_t l = 1; l <= L; ++l)
+            {
+                const Rows o = owned(l);
+                if (o.b <= o.a) continue;
+                HIP_TRY(ctx, counted_copy(ctx, levels[l].pixels + o.a * levels[l].rowPitch, arena + at[l] + (o.a - E[l].a) * levels[l].rowPitch, span(l, o), hipMemcpyDeviceToHost, ctx->stream));
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             return DXTEX_S_OK;
         }, &failed);
         if (hr != DXTEX_S_OK) return surface_stripe_error(ctxs, hr, failed);

@@ -86,3 +86,35 @@ def test_generate_mips_multi_is_the_single_context_chain(ctxs, filt, fmt, w, h):
     assert len(one) == len(many)
     for lvl, (a, b) in enumerate(zip(one, many)):
         assert np.array_equal(a, b), (hex(filt), fmt, w, h, lvl)
+
+
+@pytest.mark.parametrize("filt", [0x300000, 0x400000])
+def test_generate_mips_multi_keeps_stripes_resident(ctxs, filt):
+    """Round 6: every byte crosses the host link once. A context uploads its rows of level 0 (its stripe plus the halo the split levels
+    below need: 3 * 2^k rows k levels up), chains the split levels on the device and downloads its stripes of the levels; nothing is
+    re-uploaded per level. Checked through the contexts' own transfer counters."""
+    import directxtex_amd as dx
+    from directxtex_amd import synth
+    w, h, fmt = 1024, 4096, 28
+    img = synth.survey_rgba8(w, h, 9, "random")
+    nlev = 13
+    one = ctxs[0].generate_mips(img, w, h, fmt, nlev, filt)
+    for c in ctxs:
+        c.transfer_bytes(reset=True)
+    many = dx.capi.generate_mips_multi(ctxs, img, w, h, fmt, nlev, filt)
+    for lvl, (a, b) in enumerate(zip(one, many)):
+        assert np.array_equal(a, b), (hex(filt), lvl)
+    moved = [c.transfer_bytes() for c in ctxs]
+    n = len(ctxs)
+    level0 = w * h * 4
+    # split levels: 2048, 1024, 512, 256 rows (>= kSplitMinRows); the tail (128 rows and below) runs on the first context
+    split = sum((w >> l) * (h >> l) * 4 for l in range(1, 5))
+    tail_up = (w >> 4) * (h >> 4) * 4
+    tail_down = sum(max(1, w >> l) * max(1, h >> l) * 4 for l in range(5, nlev))
+    halo = 2 * 3 * 16 * w * 4                         # at most 3 * 2^4 rows of level 0 on either side of a stripe
+    for i, (up, down) in enumerate(moved):
+        extra_up = tail_up if i == 0 else 0
+        assert level0 // n <= up - extra_up <= level0 // n + halo + w * 4 * 2, (i, up, level0 // n, halo)
+    ups, downs = sum(u for u, _ in moved), sum(d for _, d in moved)
+    assert ups <= level0 + n * halo + tail_up + n * w * 8
+    assert downs == split + tail_down, (downs, split, tail_down)
