@@ -130,8 +130,11 @@ for (k, g), v in rows:
     m = meta[(k, g)]
     L.append(f"| `{k}` | {g} | {len(v)} | {sum(v)/len(v):.4f} | {min(v):.4f} | {sum(v):.3f} | {100*sum(v)/total:.2f} | " + " | ".join(m) + " |")
 L.append("\n## VALU issue utilisation (method: header of tools/profile_report.py, issue costs of profiles/r02_valu_rates.md)\n")
-L.append("| kernel | grid | avg ms | waves | VALU insts / wave | active lanes per VALU inst | mean issue cyc / inst (static mix) | VALU issue utilisation | if every inst were 2 cyc / 4 cyc |")
-L.append("|---|---|---|---|---|---|---|---|---|")
+L.append("Round 6: the last column is MEASURED - `SQ_ACTIVE_INST_VALU` (quad-cycles in which a wave had a VALU instruction executing, summed over the waves) x 4 /")
+L.append("(1024 SIMDs x kernel cycles at 2.4 GHz): the VALU pipes' busy share, independent of any opcode price list. The static-mix estimate left of it weighs the")
+L.append("kernel's disassembly and under-prices kernels whose hot loops are `v_dot4` / `v_max` (4 cycles) next to much cold 2-cycle straight-line code.\n")
+L.append("| kernel | grid | avg ms | waves | VALU insts / wave | active lanes per VALU inst | mean issue cyc / inst (static mix) | VALU issue utilisation | if every inst were 2 cyc / 4 cyc | VALU busy, measured |")
+L.append("|---|---|---|---|---|---|---|---|---|---|")
 for (k, g), v in rows:
     c = cnt.get((k, g))
     if not c or not c.get('SQ_INSTS_VALU'):
@@ -144,8 +147,9 @@ for (k, g), v in rows:
     lanes = c['SQ_THREAD_CYCLES_VALU'] / max(1, c['SQ_ACTIVE_INST_VALU'])
     cyc = mix.get(k, (4.15, 0))[0]
     ps = insts / SIMDS
-    L.append("| `%s` | %d | %.4f | %d | %.0f | %.1f | %.2f | **%.2f** | %.2f / %.2f |" % (
-        k, g, secs * 1e3, c['SQ_WAVES'] / n, insts / max(1, c['SQ_WAVES'] / n), lanes, cyc, min(1.0, ps * cyc / (secs * HZ)), ps * 2.15 / (secs * HZ), ps * 4.15 / (secs * HZ)))
+    busy = (c['SQ_ACTIVE_INST_VALU'] / n) * 4.0 / (SIMDS * secs * HZ)
+    L.append("| `%s` | %d | %.4f | %d | %.0f | %.1f | %.2f | **%.2f** | %.2f / %.2f | **%.2f** |" % (
+        k, g, secs * 1e3, c['SQ_WAVES'] / n, insts / max(1, c['SQ_WAVES'] / n), lanes, cyc, min(1.0, ps * cyc / (secs * HZ)), ps * 2.15 / (secs * HZ), ps * 4.15 / (secs * HZ), busy))
 # ---- where the wave cycles go (pass 2) and what the LDS does (pass 3) -------------------------------------------------------------
 L.append("\n## Where the wave cycles go, and the LDS (SQ wait / activity counters, quad-cycles; `tools/profile.sh` passes 2 and 3)\n")
 L.append("`SQ_WAIT_ANY` = wave parked on `s_waitcnt` / a barrier (memory or LDS latency not hidden); `SQ_WAIT_INST_ANY` = a ready instruction could not issue")
