@@ -1778,11 +1778,14 @@ DXTEX_HD bool fit_iterate(const float* fpx, uint32_t mask16, float (&X)[4], floa
             if (RGBA && !A1) fDot = fDot + (p[3] - X[3]) * Dir[3];
 
             // fDot <= 0 -> step 0, fDot >= fSteps -> step 3, else uint32(fDot + 0.5f) (:1300-1306): the clamp maps the outer cases
-            // onto the same conversion; float compares keep the table lookups (pC4 / pD4) as selects - an integer equality
-            // chain is turned into a switch, i.e. divergent branches, by the compiler
-            const float kStep = float(uint32_t(fminf(fmaxf(fDot, 0.0f), fSteps) + 0.5f));
-            const float pc = (kStep < 0.5f) ? 1.0f : (kStep < 1.5f) ? (2.0f / 3.0f) : (kStep < 2.5f) ? (1.0f / 3.0f) : 0.0f;
-            const float pd = (kStep < 0.5f) ? 0.0f : (kStep < 1.5f) ? (1.0f / 3.0f) : (kStep < 2.5f) ? (2.0f / 3.0f) : 1.0f;
+            // onto the same conversion (the sum is in [0.5, 3.5]: truncation = floor, one instruction instead of two conversions).
+            // The table lookups pC4 = {1, 2/3, 1/3, 0}, pD4 = {0, 1/3, 2/3, 1} (BC.cpp:26-31) are ONE multiplication each, as in
+            // bc15_encode.hip's StepCoef: with r = float(1/3) = 0x3EAAAAAB, 0 r = 0, 1 r = r, 2 r = 0x3F2AAAAB = float(2/3) (a
+            // power-of-two scaling) and 3 r = 1.00000003 rounds to 1.0f - every entry exact. (Until round 6 three float
+            // compare-selects per coefficient: 9 of the loop's ~40 instructions per texel, all at the 4-cycle rate.)
+            const float kStep = floorf(fminf(fmaxf(fDot, 0.0f), fSteps) + 0.5f);
+            const float pc = (fSteps - kStep) * (1.0f / 3.0f);
+            const float pd = kStep * (1.0f / 3.0f);
             const float fC = pc * (1.0f / 8.0f);
             const float fD = pd * (1.0f / 8.0f);
             d2X += fC * pc;
@@ -1900,6 +1903,31 @@ DXTEX_HD int rough_error(const RG& rg, uint32_t epA, uint32_t epB)
         }
     });
     return total;
+}
+
+// RoughMSE for the 3-bit and the 2-bit palette of the same endpoints in ONE pass over the texels (what bc7_rough_kernel needs of every
+// two-subset fit: mode 1 ranks the shapes by the first, modes 3 / 7 by the second). Both palettes start at A and end at B (weights 0 and 64),
+// so the scores of those two entries are shared: ten scores per texel instead of twelve, one texel fetch instead of two.
+template<class RG>
+DXTEX_HD void rough_error_3_2(const RG& rg, uint32_t epA, uint32_t epB, int& e3, int& e2)
+{
+    uint32_t pal3[8], nq3[8], pal2[2], nq2[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { pal3[i] = lerp_bytes(epA, epB, weight(3, i)); nq3[i] = 0u - udot4(pal3[i], pal3[i]); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { pal2[i] = lerp_bytes(epA, epB, weight(2, i + 1)); nq2[i] = 0u - udot4(pal2[i], pal2[i]); }
+    int t3 = rg.p2sum, t2 = rg.p2sum;
+    for_texels(rg, [&](int k)
+    {
+        const uint32_t p = rg.fetch(k);
+        int sc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sc[i] = score(p, pal3[i], nq3[i]);
+        const int sd[4] = { sc[0], score(p, pal2[0], nq2[0]), score(p, pal2[1], nq2[1]), sc[7] };
+        t3 -= first_peak(sc);
+        t2 -= first_peak(sd);
+    });
+    e3 = t3; e2 = t2;
 }
 
 // ---- bit packing (EmitBlock, :3221-3308) ------------------------------------------------------------------

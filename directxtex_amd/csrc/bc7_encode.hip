@@ -161,7 +161,13 @@ __global__ void __launch_bounds__(256, DXTEX_ROUGH_WGS) bc7_rough_kernel(Bc7Args
                 else if (opaque) seed_endpoints<true, false, true>(fpxk, m, A, B);
                 else seed_endpoints<true>(fpxk, m, A, B);
                 sSeed[blk][code] = make_uint2(A, B);                              // Refine starts from the same fit (:3411-3417)
+#if defined(DXTEX_ROUGH_SPLIT_ERR)
                 sErr[blk][code] = make_int2(rough_error<3, 0>(rg, A, B), rough_error<2, 0>(rg, A, B));
+#else
+                int e3, e2;
+                rough_error_3_2(rg, A, B, e3, e2);
+                sErr[blk][code] = make_int2(e3, e2);
+#endif
             }
         }
     }
