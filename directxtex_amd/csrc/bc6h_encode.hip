@@ -1155,7 +1155,7 @@ __global__ void __launch_bounds__(256) bc6h_store_kernel(Bc6hArgs a)
 const uint64_t kMaxBlocksPerPass6 = dev_env("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(dev_env("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 22);
 struct Scratch6
 {
-    size_t fpix, lists, seeds, recs, orgs, order, tinfo, counters, best, bounds, total;
+    size_t fpix, lists, seeds, recs, orgs, order, tinfo, counters, best, bounds, recs1, orgs1, order1, tinfo1, counters1, total;
     explicit Scratch6(uint64_t nb)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -1170,6 +1170,12 @@ struct Scratch6
         counters = o; o = up(o + 128 * sizeof(uint32_t));       // [0, 64): bins, live count, queue heads; [64, 128): the development build's statistics
         best = o; o = up(o + nb * sizeof(Best6));
         bounds = o; o = up(o + nb * 17 * sizeof(float));
+        // the one-region section's own task arrays (four mode slots of nb tasks): it runs on a side stream next to the last two-region mode
+        recs1 = o; o = up(o + nb * 4 * sizeof(Rec6));
+        orgs1 = o; o = up(o + nb * 4 * sizeof(OrgSave));
+        order1 = o; o = up(o + nb * 4 * sizeof(uint2));
+        tinfo1 = o; o = up(o + nb * 4 * sizeof(uint32_t));
+        counters1 = o; o = up(o + 128 * sizeof(uint32_t));
         total = o;
     }
 };
@@ -1181,13 +1187,14 @@ size_t bc6h_scratch_bytes(uint64_t nblocks, size_t nimages)
 }
 
 hipError_t launch_bc6h_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, bool isSigned, void* scratch,
-                              hipStream_t stream, KernelMarks* marks)
+                              hipStream_t stream, KernelMarks* marks, const SideStreams* side)
 {
     BcImage one; one.src = src; one.dst = dst; one.dstRowPitch = dstRowPitch;
-    return launch_bc6h_encode_many(&one, 1, isSigned, scratch, stream, marks);
+    return launch_bc6h_encode_many(&one, 1, isSigned, scratch, stream, marks, side);
 }
 
-hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isSigned, void* scratch, hipStream_t stream, KernelMarks* marks)
+hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isSigned, void* scratch, hipStream_t stream, KernelMarks* marks,
+                                   const SideStreams* side)
 {
 #define DXTEX_MARK(NAME) do { if (marks) marks->mark(NAME); } while (0)
     std::vector<BcSeg> segs;
@@ -1249,13 +1256,14 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
             { 0x12, 1, 1, 3, { 8, 8, 8 }, { 6, 5, 5 } }, { 0x16, 1, 1, 3, { 8, 8, 8 }, { 5, 6, 5 } }, { 0x1a, 1, 1, 3, { 8, 8, 8 }, { 5, 5, 6 } },
             { 0x1e, 1, 0, 3, { 6, 6, 6 }, { 6, 6, 6 } }, { 0x03, 0, 0, 4, { 10, 10, 10 }, { 10, 10, 10 } }, { 0x07, 0, 1, 4, { 11, 11, 11 }, { 9, 9, 9 } },
             { 0x0b, 0, 1, 4, { 12, 12, 12 }, { 8, 8, 8 } }, { 0x0f, 0, 1, 4, { 16, 16, 16 }, { 4, 4, 4 } } };     // == kBc6hModes (device table), host copy
-        auto set_mode = [&](int mi)
+        auto set_mode_on = [&](Bc6hArgs& a, int mi)
         {
             const Bc6hMode& k = kModes[mi];
             a.mode.index = mi; a.mode.code = k.code; a.mode.regions2 = k.regions2; a.mode.transformed = k.transformed; a.mode.prec = k.prec[0];
             for (int c = 0; c < 3; ++c) a.mode.delta[c] = k.delta[c];
         };
-        auto sort_tasks = [&](uint32_t ntasks)
+        auto set_mode = [&](int mi) { set_mode_on(a, mi); };
+        auto sort_tasks = [&](const Bc6hArgs& a, uint32_t ntasks, hipStream_t stream)
         {
             const uint32_t binGroups = std::min<uint32_t>(kBinGroups, (ntasks + 255) / 256);
             (void)hipMemsetAsync(a.counters, 0, 128 * sizeof(uint32_t), stream);
@@ -1278,10 +1286,60 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         }();
         int prevPrec = -1;
         a.samePrec = 0;
-        for (int mi : order6)
+        std::vector<int> run2;
+        for (int mi : order6) if (mi >= 0 && mi <= 9 && (onlyMode < 0 || mi == onlyMode)) run2.push_back(mi);
+        // The one-region section (below) is two milliseconds of latency-bound kernels - a few thousand long tasks - that used to run alone after
+        // the last two-region mode. Its search now runs on a side stream NEXT TO the last two-region modes (own task arrays; it prunes against the
+        // best of the modes before that one - a looser table, never a wrong one: the bound is exact whatever it is compared with - and reads
+        // best[].err while that mode's post may be writing it: a 32-bit word, old or new, both upper bounds of the final error; a zero in it
+        // comes from a two-region mode either way, which is all org_candidate asks). Its posts fold into best[] after the join, in order.
+        static const int forkBack = dev_env("DXTEX_BC6H_FORK_BACK") ? atoi(dev_env("DXTEX_BC6H_FORK_BACK")) : 2;      // 0 = serial, k = next to the last k two-region modes (cfg3 on one box: 54.90 / 54.97 / 54.10 / 54.21 ms for 0 / 1 / 2 / 3 - a persistent search kernel leaves the side stream little room, the gaps between two modes more)
+        const SideStreams* fork = (marks || forkBack <= 0 || run2.size() < size_t(forkBack) + 1 || onlyMode >= 0) ? nullptr : side;
+        Bc6hArgs a1 = a;
+        a1.recs = reinterpret_cast<Rec6*>(base + L.recs1);
+        a1.orgs = reinterpret_cast<OrgSave*>(base + L.orgs1);
+        a1.order = reinterpret_cast<uint2*>(base + L.order1);
+        a1.tinfo = reinterpret_cast<uint32_t*>(base + L.tinfo1);
+        a1.counters = reinterpret_cast<uint32_t*>(base + L.counters1);
+        a1.samePrec = 0;
+        auto one_region_search = [&](hipStream_t stream, KernelMarks* marks)
         {
-            if (mi < 0 || mi > 9) continue;
-            if (onlyMode >= 0 && mi != onlyMode) continue;
+            const uint32_t gridPP = (a1.nblocks + 255) / 256;
+            DXTEX_MARK("bc6h_pre_1region");
+            a1.boundsReady = 0;
+            for (int m = 0; m < 4; ++m)
+            {
+                if (onlyMode >= 0 && 10 + m != onlyMode) continue;
+                set_mode_on(a1, 10 + m); a1.taskBase = uint32_t(m) * a1.nblocks;
+                hipLaunchKernelGGL(bc6h_pre_kernel<0>, dim3(gridPP), dim3(256), 0, stream, a1);
+                a1.boundsReady = 1;
+            }
+            const uint32_t ntasks = a1.nblocks * 4u;
+            if (onlyMode >= 0)        // development aid: the slots of the modes that did not run hold no tasks
+                for (int m = 0; m < 4; ++m) if (10 + m != onlyMode) (void)hipMemsetAsync(a1.tinfo + uint64_t(m) * a1.nblocks, 0, uint64_t(a1.nblocks) * 4, stream);
+            DXTEX_MARK("bc6h_bin_1region");
+            sort_tasks(a1, ntasks, stream);
+            DXTEX_MARK("bc6h_perturb_1region");
+            // both are launched; the live count (known on the device only) decides which one works
+            static const uint32_t waveMax = dev_env("DXTEX_BC6H_WAVE_MAX") ? uint32_t(strtoul(dev_env("DXTEX_BC6H_WAVE_MAX"), nullptr, 0)) : kWaveTaskMax6;
+            if (!noSearch)
+            {
+                hipLaunchKernelGGL(bc6h_perturb_kernel<16>, dim3(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64)), dim3(64), 0, stream, a1, waveMax);
+                hipLaunchKernelGGL(bc6h_perturb_wave_kernel, dim3(std::min<uint32_t>(kSearchWaves, ntasks)), dim3(64), 0, stream, a1, waveMax);
+            }
+        };
+        bool forked = false;
+        for (size_t at = 0; at < run2.size(); ++at)
+        {
+            const int mi = run2[at];
+            if (fork && at + size_t(forkBack) == run2.size())
+            {
+                (void)hipEventRecord(fork->forked, stream);
+                (void)hipStreamWaitEvent(fork->side[0], fork->forked, 0);
+                one_region_search(fork->side[0], nullptr);
+                (void)hipEventRecord(fork->joined[0], fork->side[0]);
+                forked = true;
+            }
             set_mode(mi);
             static const bool noReuse = dev_env("DXTEX_BC6H_NO_REUSE") != nullptr;      // development A/B: search every mode from scratch
             a.samePrec = (!noReuse && prevPrec == kModes[mi].prec[0]) ? 1 : 0;
@@ -1295,7 +1353,7 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
             hipLaunchKernelGGL(bc6h_pre_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
             a.boundsReady = 1;
             DXTEX_MARK("bc6h_bin_2region");
-            sort_tasks(ntasks);
+            sort_tasks(a, ntasks, stream);
 #if defined(DXTEX_DEV)
             static const bool stats6 = dev_env("DXTEX_BC6H_STATS") != nullptr;       // development statistics: tasks that survive pre, per mode
             a.filterStats = stats6 ? 1 : 0;
@@ -1341,39 +1399,19 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
             hipLaunchKernelGGL(bc6h_post_kernel<1>, dim3(gridPP), dim3(256), 0, stream, a);
         }
         // The four one-region modes have ONE task per block each - a long serial chain on one lane - so a search kernel per mode would
-        // only be as fast as its slowest lane. Their pre kernels run first (each prunes against the best of the two-region modes),
-        // the four task lists are searched as one list (4x the tasks per lane, sorted by mode), then the posts fold the modes into
+        // only be as fast as its slowest lane. Their pre kernels run first (each prunes against the best of the two-region modes that have
+        // finished), the four task lists are searched as one list (4x the tasks per lane, sorted by mode), then the posts fold the modes into
         // the running best in the reference's order.
+        if (forked) (void)hipStreamWaitEvent(stream, fork->joined[0], 0);
+        else one_region_search(stream, marks);
         {
-            const uint32_t gridPP = (a.nblocks + 255) / 256;
-            DXTEX_MARK("bc6h_pre_1region");
-            a.boundsReady = 0;
-            for (int m = 0; m < 4; ++m)
-            {
-                if (onlyMode >= 0 && 10 + m != onlyMode) continue;
-                set_mode(10 + m); a.taskBase = uint32_t(m) * a.nblocks;
-                hipLaunchKernelGGL(bc6h_pre_kernel<0>, dim3(gridPP), dim3(256), 0, stream, a);
-                a.boundsReady = 1;
-            }
-            const uint32_t ntasks = a.nblocks * 4u;
-            if (onlyMode >= 0)        // development aid: the slots of the modes that did not run hold no tasks
-                for (int m = 0; m < 4; ++m) if (10 + m != onlyMode) (void)hipMemsetAsync(a.tinfo + uint64_t(m) * a.nblocks, 0, uint64_t(a.nblocks) * 4, stream);
-            DXTEX_MARK("bc6h_bin_1region");
-            sort_tasks(ntasks);
-            DXTEX_MARK("bc6h_perturb_1region");
-            // both are launched; the live count (known on the device only) decides which one works
-            static const uint32_t waveMax = dev_env("DXTEX_BC6H_WAVE_MAX") ? uint32_t(strtoul(dev_env("DXTEX_BC6H_WAVE_MAX"), nullptr, 0)) : kWaveTaskMax6;
-            if (!noSearch)
-            {
-                hipLaunchKernelGGL(bc6h_perturb_kernel<16>, dim3(std::min<uint32_t>(kSearchWaves, (ntasks + 63) / 64)), dim3(64), 0, stream, a, waveMax);
-                hipLaunchKernelGGL(bc6h_perturb_wave_kernel, dim3(std::min<uint32_t>(kSearchWaves, ntasks)), dim3(64), 0, stream, a, waveMax);
-            }
+            const uint32_t gridPP = (a1.nblocks + 255) / 256;
             DXTEX_MARK("bc6h_post_1region");
             for (int m = 0; m < 4; ++m)
             {
                 if (onlyMode >= 0 && 10 + m != onlyMode) continue;
-                set_mode(10 + m); a.taskBase = uint32_t(m) * a.nblocks;
-                hipLaunchKernelGGL(bc6h_post_kernel<0>, dim3(gridPP), dim3(256), 0, stream, a);
+                set_mode_on(a1, 10 + m); a1.taskBase = uint32_t(m) * a1.nblocks;
+                hipLaunchKernelGGL(bc6h_post_kernel<0>, dim3(gridPP), dim3(256), 0, stream, a1);
             }
         }
         DXTEX_MARK("bc6h_store");

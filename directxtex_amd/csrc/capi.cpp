@@ -239,7 +239,7 @@ dxtex_hresult submit_compress(dxtex_ctx* ctx, const uint8_t* dSrc, size_t width,
         const uint64_t nblocks = uint64_t((width + 3) / 4) * uint64_t((height + 3) / 4);
         hr = ensure(ctx, &ctx->scratch, &ctx->scratchBytes, bc6h_scratch_bytes(nblocks));
         if (hr != DXTEX_S_OK) return hr;
-        e = launch_bc6h_encode(v, dDst, dstRowPitch, dstFormat == FMT_BC6H_SF16, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
+        e = launch_bc6h_encode(v, dDst, dstRowPitch, dstFormat == FMT_BC6H_SF16, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr, side_streams(ctx));
         break;
     }
     default:
@@ -499,7 +499,7 @@ dxtex_hresult dxtex_compress_many_device(dxtex_ctx* ctx, const dxtex_image* srcs
         if (hr != DXTEX_S_OK) return hr;
         time_begin(ctx);
         const hipError_t e = allBc7 ? launch_bc7_encode_many(batch.data(), count, flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr, side_streams(ctx))
-                                    : launch_bc6h_encode_many(batch.data(), count, dsts[0].format == FMT_BC6H_SF16, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
+                                    : launch_bc6h_encode_many(batch.data(), count, dsts[0].format == FMT_BC6H_SF16, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr, side_streams(ctx));
         time_end(ctx);
         if (e != hipSuccess) return fail(ctx, DXTEX_E_FAIL, "kernel launch failed", e);
         return DXTEX_S_OK;
@@ -780,7 +780,7 @@ dxtex_hresult dxtex_encode_blocks(dxtex_ctx* ctx, int32_t bc_format, uint32_t bc
     switch (bc_format)
     {
     case FMT_BC6H_UF16: case FMT_BC6H_SF16:
-        e = launch_bc6h_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_format == FMT_BC6H_SF16, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr);
+        e = launch_bc6h_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_format == FMT_BC6H_SF16, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr, side_streams(ctx));
         break;
     case FMT_BC7_UNORM: case FMT_BC7_UNORM_SRGB:
         e = launch_bc7_encode(v, static_cast<uint8_t*>(ctx->stageOut), bb, bc_flags, ctx->scratch, ctx->stream, ctx->profiling ? &ctx->marks : nullptr, side_streams(ctx));

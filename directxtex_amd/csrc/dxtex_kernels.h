@@ -39,8 +39,9 @@ hipError_t launch_bc7_encode_many(const BcImage* images, size_t count, uint32_t 
 // BC6H (UF16 / SF16): `scratch` must hold bc6h_scratch_bytes(number of 4x4 blocks) bytes of device memory.
 size_t bc6h_scratch_bytes(uint64_t nblocks, size_t nimages = 1);
 hipError_t launch_bc6h_encode(const SrcView& src, uint8_t* dst, uint64_t dstRowPitch, bool isSigned, void* scratch,
-                              hipStream_t stream, KernelMarks* marks);
-hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isSigned, void* scratch, hipStream_t stream, KernelMarks* marks);
+                              hipStream_t stream, KernelMarks* marks, const SideStreams* side = nullptr);
+hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isSigned, void* scratch, hipStream_t stream, KernelMarks* marks,
+                                   const SideStreams* side = nullptr);
 
 // BC -> uncompressed (DecompressBC). `plan` = resolve_convert_plan(bc format, target format, TEX_FILTER_DEFAULT).
 struct ConvertPlan;
