@@ -85,6 +85,7 @@ __device__ __forceinline__ Perturb6 pk_unpack(const PkState& p, bool sg)
 struct Rec6 { Ep16 ep; float err; };                               // 16 bytes per task: the search's start, then its result
 struct Best6 { float err; uint32_t mode; uint64_t lo, hi; };       // 24 bytes per block; mode = position of the winner's mode in the encoder's order
 struct OrgSave { Ep16 ep; float err; uint64_t idx; };              // 24 bytes per task: Refine's unoptimised half, pre -> post
+struct OptSave { uint64_t idx; float err; uint32_t swapped; };         // 16 bytes per task: Refine's optimised half of a precision trio's first member, post -> post
 
 enum : int { SEED_INTS = 17 * 6 + 2 };      // 8 shapes x 2 regions + the one-region seed, 6 ints each (+ pad)
 
@@ -107,6 +108,8 @@ struct Bc6hArgs
     int boundsReady;        // 0: this launch computes and stores them, 1: it reads them
     int filterStats;        // development build: bc6h_perturb_filter_kernel counts its steps and exact rounds in counters[48..]
     int samePrec;           // two-region modes: the previous mode had the same endpoint precision and its task arrays are still in place
+    struct OptSave* opts;   // two-region modes of one precision: post's AssignIndices of the optimised endpoints, first member -> the others (saveOpt)
+    int saveOpt;            // 1: the next mode has the same precision - post stores what it assigned
     ModeRt mode;
 };
 
@@ -566,14 +569,36 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     if (REGIONS2) searched = searched || (__shfl_xor(int(searched), 1) != 0);      // the candidate's other region: Refine scores both (:2401-2410)
     uint64_t optIdx = o.idx;
     float optErr = o.err;
-    if (__any(searched))
+    // AssignIndices (+ SwapIndices) of the optimised endpoints depends on the endpoint PRECISION, not on the mode's delta bits (as pre's does,
+    // reuseOrg): the second and third mode of an 8-bit / 11-bit trio inherit 98 % of their searches from the first (kDoneBit6), and a
+    // candidate neither of whose regions was searched anew in THIS mode has the endpoints the previous member's post scored - it reads back
+    // what that post assigned (error, indices, whether the endpoints were swapped) instead of assigning again.
+    const bool newly = (ti >> 24) != 0u;
+    bool candNewly = newly;
+    if (REGIONS2) candNewly = candNewly || (__shfl_xor(int(newly), 1) != 0);
+    const bool inherited = REGIONS2 && a.samePrec != 0 && searched && !candNewly;
+    bool swapped = false;
+    if (inherited)
+    {
+        const OptSave sv = a.opts[t];
+        optErr = sv.err; optIdx = sv.idx; swapped = sv.swapped != 0u;
+        if (swapped) { for (int c = 0; c < 3; ++c) { const int tmp = opt.A[c]; opt.A[c] = opt.B[c]; opt.B[c] = tmp; } }
+    }
+    const bool assign = searched && !inherited;
+    if (__any(assign))
     {
         uint64_t ix;
         float e;
-        if constexpr (REGIONS2) { const TileTexels tx = { planes, o.np }; e = assign_indices6<L::N>(tx, o.pos, opt, a.mode.prec, sg, o.anchor, ix); }
-        else e = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, opt, a.mode.prec, sg, o.anchor, ix);
-        if (searched) { optErr = e; optIdx = ix; }
+        EndPts tmpEp = opt;
+        if constexpr (REGIONS2) { const TileTexels tx = { planes, o.np }; e = assign_indices6<L::N>(tx, o.pos, tmpEp, a.mode.prec, sg, o.anchor, ix); }
+        else e = assign_indices6<L::N>(slot_texels(slot, o.np), o.pos, tmpEp, a.mode.prec, sg, o.anchor, ix);
+        if (assign)
+        {
+            swapped = (tmpEp.A[0] != opt.A[0]) || (tmpEp.A[1] != opt.A[1]) || (tmpEp.A[2] != opt.A[2]);      // (A == B: a swap changes nothing)
+            optErr = e; optIdx = ix; opt = tmpEp;
+        }
     }
+    if (REGIONS2 && a.saveOpt != 0 && searched && inRange) { OptSave sv; sv.idx = optIdx; sv.err = optErr; sv.swapped = swapped ? 1u : 0u; a.opts[t] = sv; }
     if (!searched) opt = o.ep;
     float orgTot = 0.0f + o.err, optTot = 0.0f + optErr;
     if (REGIONS2)
@@ -1155,7 +1180,7 @@ __global__ void __launch_bounds__(256) bc6h_store_kernel(Bc6hArgs a)
 const uint64_t kMaxBlocksPerPass6 = dev_env("DXTEX_MAX_BLOCKS_PER_PASS") ? std::max<uint64_t>(1, strtoull(dev_env("DXTEX_MAX_BLOCKS_PER_PASS"), nullptr, 10)) : (1u << 22);
 struct Scratch6
 {
-    size_t fpix, lists, seeds, recs, orgs, order, tinfo, counters, best, bounds, recs1, orgs1, order1, tinfo1, counters1, total;
+    size_t fpix, lists, seeds, recs, orgs, order, tinfo, counters, best, bounds, recs1, orgs1, order1, tinfo1, counters1, opts, total;
     explicit Scratch6(uint64_t nb)
     {
         auto up = [](size_t v) { return (v + 255) & ~size_t(255); };
@@ -1176,6 +1201,7 @@ struct Scratch6
         order1 = o; o = up(o + nb * 4 * sizeof(uint2));
         tinfo1 = o; o = up(o + nb * 4 * sizeof(uint32_t));
         counters1 = o; o = up(o + 128 * sizeof(uint32_t));
+        opts = o; o = up(o + nb * 16 * sizeof(OptSave));
         total = o;
     }
 };
@@ -1224,6 +1250,8 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
         a.counters = reinterpret_cast<uint32_t*>(base + L.counters);
         a.best = reinterpret_cast<Best6*>(base + L.best);
         a.bounds = reinterpret_cast<float*>(base + L.bounds);
+        a.opts = reinterpret_cast<OptSave*>(base + L.opts);
+        a.saveOpt = 0;
         a.boundsReady = 0;
         a.filterStats = 0;
         a.mode = ModeRt();
@@ -1344,6 +1372,7 @@ hipError_t launch_bc6h_encode_many(const BcImage* images, size_t count, bool isS
             static const bool noReuse = dev_env("DXTEX_BC6H_NO_REUSE") != nullptr;      // development A/B: search every mode from scratch
             a.samePrec = (!noReuse && prevPrec == kModes[mi].prec[0]) ? 1 : 0;
             prevPrec = kModes[mi].prec[0];
+            a.saveOpt = (!noReuse && at + 1 < run2.size() && kModes[run2[at + 1]].prec[0] == kModes[mi].prec[0]) ? 1 : 0;
             const uint32_t ntasks = a.nblocks * 16u;
             const uint32_t gridPP = (a.nblocks + 15) / 16;
             static const char* const kPre[10] = { "bc6h_pre_m0", "bc6h_pre_m1", "bc6h_pre_m2", "bc6h_pre_m3", "bc6h_pre_m4", "bc6h_pre_m5", "bc6h_pre_m6", "bc6h_pre_m7", "bc6h_pre_m8", "bc6h_pre_m9" };
