@@ -371,7 +371,8 @@ struct Org6
 
 // Refine's first half (:2386-2393) for this lane's region; needs the partner lane of the candidate for the transform.
 template<int REGIONS2>
-__device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, uint32_t r, const float* planes, float* slot, Org6& o, const OrgSave* saved = nullptr)
+__device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, uint32_t r, const float* planes, float* slot, Org6& o, const OrgSave* saved = nullptr,
+                                              const OrgSave* loaded = nullptr, const Best6* bestLoaded = nullptr)
 {
     typedef Lay6<REGIONS2> L;
     const bool sg = a.isSigned != 0;
@@ -386,7 +387,7 @@ __device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, ui
     if (saved)
     {
         // post: the pre kernel of this mode already quantised the seeds and assigned the indices
-        const OrgSave sv = *saved;
+        const OrgSave sv = loaded ? *loaded : *saved;
         unpack_ep16(sv.ep, sg, o.ep.A, o.ep.B);
         o.err = sv.err; o.idx = sv.idx;
     }
@@ -410,7 +411,7 @@ __device__ __forceinline__ void org_candidate(const Bc6hArgs& a, uint32_t nb, ui
     // Encode() stops at the first candidate that reaches error 0 (:1823, :1851): nothing later can be strictly better
     // ... from an EARLIER mode of the encoder's order that is: the modes may run in another order here (see launch_bc6h_encode_many), and a
     // zero reached by a later mode does not stop an earlier one, which could reach zero too and would then come first
-    const Best6 cur = a.best[nb];
+    const Best6 cur = bestLoaded ? *bestLoaded : a.best[nb];
     o.fit = fit && (cur.err > 0.0f || cur.mode > uint32_t(a.mode.index));
 }
 
@@ -528,6 +529,13 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
     float regs[REGIONS2 ? 1 : 48];
     const float* planes = regs;
     float* slot = &sSlot[wave][REGIONS2 ? 0 : lane];
+    // everything this lane reads of its task, requested before the texels are staged: the kernel spent more than half of its time parked on
+    // these loads one after the other (orgs -> best -> tinfo -> recs; profiles/r05_kernels.md)
+    const uint64_t t = REGIONS2 ? uint64_t(nb) * L::TPB + r : uint64_t(a.taskBase) + nb;
+    const uint32_t ti = a.tinfo[t];
+    const OrgSave orgLoaded = a.orgs[t];
+    const Rec6 recLoaded = a.recs[t];            // (read for every task: the array is there whether or not a search wrote the slot)
+    const Best6 bestLoaded = a.best[nb];
     if constexpr (REGIONS2)
     {
         stage_planes<L::BPW>(a, nbFirst, lane, sSlot[wave]);
@@ -540,18 +548,16 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
         for (int i = 0; i < 12; ++i) { const float4 v = gp[i]; regs[4 * i] = v.x; regs[4 * i + 1] = v.y; regs[4 * i + 2] = v.z; regs[4 * i + 3] = v.w; }
     }
     Org6 o;
-    const uint64_t t = REGIONS2 ? uint64_t(nb) * L::TPB + r : uint64_t(a.taskBase) + nb;
-    org_candidate<REGIONS2>(a, nb, r, planes, slot, o, a.orgs + t);
+    org_candidate<REGIONS2>(a, nb, r, planes, slot, o, a.orgs + t, &orgLoaded, &bestLoaded);
 
     // the optimised endpoints: in recs[] where a search ran for this task (this mode's, or an earlier one's of the same precision), the
     // unoptimised ones everywhere else
-    const uint32_t ti = a.tinfo[t];
     const bool ownSearched = (ti >> 24) != 0u || (ti & kDoneBit6) != 0u;
     EndPts opt = o.ep;
     bool optOverflow = false;            // the search ended with A outside the signed 16-bit range (see Ep16): EndPointsFit fails in the reference
     if (ownSearched)
     {
-        const Rec6 rec = a.recs[t];
+        const Rec6 rec = recLoaded;
         unpack_ep16(rec.ep, sg, opt.A, opt.B);
         optOverflow = rec.err == -1.0f;
         if (rec.err <= -2.0f)            // components of B above 32767 wrapped in their fields: the true values (ep16_mark)
@@ -650,7 +656,7 @@ __global__ void __launch_bounds__(256) bc6h_post_kernel(Bc6hArgs a)
         Best6* b = a.best + nb;
         // Refine only emits when it beats fBestErr (:2412-2424): the block ends up with the FIRST minimum in the encoder's mode order. The modes
         // of a pass run one after the other on one stream, in any order: ties go to the mode that comes first in the encoder's order.
-        if (err < b->err || (err == b->err && uint32_t(a.mode.index) < b->mode))
+        if (err < bestLoaded.err || (err == bestLoaded.err && uint32_t(a.mode.index) < bestLoaded.mode))      // (only this lane writes the block's slot in this launch)
         {
             Best6 n; n.err = err; n.mode = uint32_t(a.mode.index);
             emit_block6(a.mode, o.shape, ep, idx, REGIONS2 ? uint32_t(kAnchor2[o.shape]) : 0u, n.lo, n.hi);
