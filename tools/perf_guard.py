@@ -4,8 +4,10 @@ ms_per_step) of a fresh bench line with the last committed full line (profiles/r
 slower by more than the tolerance. Run by tools/gpu_round_end.sh after the default bench run, so a round that speeds one codec up cannot
 silently slow its neighbour down (round 4 did: BC5 +19 %, BC3 +21 %, found only by the next review).
 
-usage: tools/perf_guard.py <fresh bench line .json> [--baseline profiles/rNN_bench_default.json] [--tolerance 0.05] [--floor-ms 0.02]
-Times below --floor-ms are compared with an absolute slack of 2 us instead (launch-latency noise). Exit code 1 = regression."""
+usage: tools/perf_guard.py <fresh bench line .json> [--baseline profiles/rNN_bench_default.json] [--tolerance 0.05] [--floor-ms 0.1]
+Times below --floor-ms are compared with an absolute slack of 5 us instead: a 50 us kernel timed over 20 calls moves by that much between
+boxes and runs with unchanged code (bc_decode_kernel<2>, same 1 235 instructions per wave: 0.0528 / 0.0480 ms in the kernel traces of
+profiles/r05_kernels.md / r06_kernels.md, 0.048 / 0.052 ms in the bench lines of the same two rounds). Exit code 1 = regression."""
 import glob, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,7 +49,7 @@ def main():
         if not cands:
             print("perf_guard: no committed baseline under profiles/"); return 0
         base_path = cands[-1]
-    tol = float(opt("--tolerance", "0.05")); floor = float(opt("--floor-ms", "0.02"))
+    tol = float(opt("--tolerance", "0.05")); floor = float(opt("--floor-ms", "0.1"))
     fresh, base = times(load_line(fresh_path)), times(load_line(base_path))
     bad = []
     print("perf_guard: %s against %s (tolerance %.0f %%)" % (fresh_path, os.path.relpath(base_path, ROOT), tol * 100))
@@ -55,7 +57,7 @@ def main():
         if k not in fresh:
             print("  %-40s missing in the fresh line" % k); continue
         b, f = base[k], fresh[k]
-        slow = (f > b + 0.002) if (k.endswith(".ms") and b < floor) else (f > b * (1 + tol))
+        slow = (f > b + 0.005) if (k.endswith(".ms") and b < floor) else (f > b * (1 + tol))
         print("  %-40s %10.3f -> %10.3f  %+6.1f %%%s" % (k, b, f, 100.0 * (f - b) / b if b else 0.0, "   <-- SLOWER" if slow else ""))
         if slow:
             bad.append(k)
