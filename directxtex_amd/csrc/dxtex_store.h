@@ -2,7 +2,8 @@
 // ConvertScanline plan (DirectXTexConvert.cpp:3080-3854) resolved once per call on the host.
 //
 // The packed stores live in DirectXMath (not vendored by the reference). What is restated
-// here is its SSE2 behaviour, the one every x64 build of the reference gets:
+// here is its SSE2 behaviour, the one every x64 build of the reference gets (since round 6 the checker is the reference's own
+// StoreScanline compiled over oracle/shim's leaf stand-ins of these same stores):
 //   XMStoreUByteN4  : clamp to [0,1], multiply by 255 (lanes pre-shifted by powers of two, which does not change the
 //                     rounding), TRUNCATE (_mm_cvttps_epi32). The reference adds g_8BitBias = 0.5/255 beforehand
 //                     (:1767) precisely because of that truncation.
