@@ -66,6 +66,7 @@ struct dxtex_ctx
     // side streams of the BC7 pipeline (modes 4 / 5 run next to each other): created on first use, destroyed with the context
     SideStreams side = {};
     bool sideTried = false, sideOk = false;
+    uint64_t warmedFormats = 0;        // dxtex_ctx_prepare: destination BC formats (bit = format - 64) whose pipeline has run once on this context
     std::string lastError;
     bool profiling = false;
     Marks marks;
@@ -566,6 +567,25 @@ dxtex_hresult dxtex_ctx_prepare(dxtex_ctx* ctx, size_t width, size_t height, int
     hr = ensure(ctx, &ctx->stageIn, &ctx->stageInBytes, ((srcSlice + 255) & ~size_t(255)) * count); if (hr != DXTEX_S_OK) return hr;
     hr = ensure(ctx, &ctx->stageOut, &ctx->stageOutBytes, ((dstSlice + 255) & ~size_t(255)) * count); if (hr != DXTEX_S_OK) return hr;
     if (device_bytes) *device_bytes = ctx->scratchBytes + ctx->stageInBytes + ctx->stageOutBytes;
+    // GPUCompressBC::Prepare also binds the shaders the size needs (BCDirectCompute.cpp:203-369). The counterpart here: the HIP runtime loads a
+    // kernel's code object on its first launch, and the BC7 / BC6H pipelines are some forty kernels plus three side streams - 19 ms on the first
+    // call of a fresh process against 1.2 ms on the second (tools/cold_probe.py: a 64 x 64 image). One block of zeros goes through the same
+    // pipeline now, once per destination format and context, so the first real call finds everything loaded. Nothing is returned from it.
+    const uint64_t bit = (dst_format >= 64 && dst_format < 128) ? (uint64_t(1) << (dst_format - 64)) : 0;
+    if (bit && !(ctx->warmedFormats & bit))
+    {
+        const size_t ww = std::min<size_t>(width, 4), wh = std::min<size_t>(height, 4);
+        size_t wRow = 0, wSlice = 0, oRow = 0, oSlice = 0;
+        if (dxtex_compute_pitch(src_format, ww, wh, &wRow, &wSlice) == DXTEX_S_OK && dxtex_compute_pitch(dst_format, ww, wh, &oRow, &oSlice) == DXTEX_S_OK &&
+            wSlice <= ctx->stageInBytes && oSlice <= ctx->stageOutBytes)
+        {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->stageIn, 0, wSlice, ctx->stream));
+            hr = submit_compress(ctx, static_cast<const uint8_t*>(ctx->stageIn), ww, wh, src_format, wRow, static_cast<uint8_t*>(ctx->stageOut), dst_format, oRow, flags, 0.5f);
+            if (hr != DXTEX_S_OK) return hr;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->warmedFormats |= bit;
+        }
+    }
     return DXTEX_S_OK;
 }
 

@@ -180,7 +180,9 @@ def test_pruning_changes_nothing():
     two-region modes in the encoder's order (DXTEX_BC6H_ORDER) instead of the default running order, and BC7's
     whole-block tasks (modes 4 / 5 / 6) searched by groups of lanes (default on lists this short) or a lane each (DXTEX_BC7_NO_GROUP), and the
     late modes 4 / 5 on the context's side streams (default) or one after the other on its stream (DXTEX_BC7_SERIAL), and a small submission's
-    modes side by side as the default plan has them, in the large-pass order (DXTEX_BC7_NO_SMALL_PLAN) or in another plan (DXTEX_BC7_SMALL_PLAN)."""
+    modes side by side as the default plan has them, in the large-pass order (DXTEX_BC7_NO_SMALL_PLAN) or in another plan (DXTEX_BC7_SMALL_PLAN), and
+    (round 6) BC6H's one-region search after the two-region modes (DXTEX_BC6H_FORK_BACK=0) or on a side stream next to the last one / two (default) / three
+    of them, and a large pass's modes through a plan (DXTEX_BC7_LARGE_PLAN: late mode 6 beside mode 3)."""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
@@ -206,7 +208,9 @@ def test_pruning_changes_nothing():
                 {"DXTEX_BC7_NO_SMALL_PLAN": "1"}, {"DXTEX_BC7_SMALL_PLAN": "16/1/3,2|7,14,15,18|24,26/28/25,0"},
                 {"DXTEX_BC7_NO_SMALL_PLAN": "1", "DXTEX_BC7_EARLY6_MIN_PCT": "0", "DXTEX_BC7_EARLYA_MIN_PCT": "0"},          # every early phase that has a block
                 {"DXTEX_BC7_NO_SMALL_PLAN": "1", "DXTEX_BC7_EARLY6_MIN_PCT": "101", "DXTEX_BC7_EARLYA_MIN_PCT": "101"},      # no early phase at all
-                {"DXTEX_BC7_ORDER": "26,25,3,1,16,7,15,14,18,24,28,0,2", "DXTEX_BC6H_WAVE_MAX": "0", "DXTEX_BC6H_NO_REUSE": "1", "DXTEX_BC6H_ORDER": "0,1,2,3,4,5,6,7,8,9"}):
+                {"DXTEX_BC7_ORDER": "26,25,3,1,16,7,15,14,18,24,28,0,2", "DXTEX_BC6H_WAVE_MAX": "0", "DXTEX_BC6H_NO_REUSE": "1", "DXTEX_BC6H_ORDER": "0,1,2,3,4,5,6,7,8,9"},
+                {"DXTEX_BC6H_FORK_BACK": "0", "DXTEX_BC7_NO_SMALL_PLAN": "1", "DXTEX_BC7_LARGE_PLAN": "16,7|14/18/15|0,1|3,2/26|24/28/25"},
+                {"DXTEX_BC6H_FORK_BACK": "1"}, {"DXTEX_BC6H_FORK_BACK": "3", "DXTEX_BC6H_ORDER": "9,1,5,6,7,8,0,2,3,4"}):
         r = subprocess.run([sys.executable, "-c", code] + (["--dev"] if env else []), env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.split())
