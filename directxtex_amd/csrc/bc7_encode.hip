@@ -930,7 +930,43 @@ __global__ void bc7_stats_print_kernel(unsigned long long* stats)
 #define DXTEX_STAT(SLOT, MASK) do { } while (0)
 #endif
 
-enum : int { kExhWorkMax = 1024, kExhExactMax = 512 };
+// Mode 4 with 2-bit colour indices would take 217 registers (2 waves per SIMD): capped at 3 waves (168 registers + 168 B of spill), 4.6 -> 3.9 ms.
+#if !defined(DXTEX_EXH45_WGS)
+#define DXTEX_EXH45_WGS 3
+#endif
+// LDS lists of bc7_exhaustive_kernel, per mode: sWork = the pooled candidates of a round (the lanes' shares), sExact = candidates waiting for their exact
+// evaluation (drained when fewer than 64 slots are left). Together with the texel columns (4160 B) and the best keys (256 B) they decide how many
+// wavefronts a CU holds: 10 752 B (1024 + 512 entries, rounds 2 - 5) were 15, one SIMD of four a wavefront short. Round 6, one box, byte-identical:
+// 896 + 512 (10 240 B: 16 per CU) exhaustive<1> 31.5 -> 30.6 ms, <3> 21.2 -> 20.1, the image 126.0 -> 123.8 ms; mode 3 with 512 + 256 (shorter
+// pooled shares, earlier drains) 20.1 -> 19.5, the image 122.9; mode 1 prefers 896 (768 / 640 / 512: + 0.1 ... 0.3 ms), the late modes do not care;
+// five wavefronts per SIMD (launch bound 5, 640 + 304 entries) change nothing for either.
+#if !defined(DXTEX_EXH_WORK1)
+#define DXTEX_EXH_WORK1 896
+#endif
+#if !defined(DXTEX_EXH_EXACT1)
+#define DXTEX_EXH_EXACT1 512
+#endif
+#if !defined(DXTEX_EXH_WORK3)
+#define DXTEX_EXH_WORK3 512
+#endif
+#if !defined(DXTEX_EXH_EXACT3)
+#define DXTEX_EXH_EXACT3 256
+#endif
+#if !defined(DXTEX_EXH_WORK)
+#define DXTEX_EXH_WORK 896
+#endif
+#if !defined(DXTEX_EXH_EXACT)
+#define DXTEX_EXH_EXACT 512
+#endif
+#if !defined(DXTEX_EXH1_WAVES)
+#define DXTEX_EXH1_WAVES 1
+#endif
+#if !defined(DXTEX_EXH3_WAVES)
+#define DXTEX_EXH3_WAVES 1
+#endif
+template<int MODE> struct ExhLists { enum : int { kWork = (MODE == 1) ? DXTEX_EXH_WORK1 : (MODE == 3) ? DXTEX_EXH_WORK3 : DXTEX_EXH_WORK,
+                                                  kExact = (MODE == 1) ? DXTEX_EXH_EXACT1 : (MODE == 3) ? DXTEX_EXH_EXACT3 : DXTEX_EXH_EXACT,
+                                                  kWaves = (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS : (MODE == 1) ? DXTEX_EXH1_WAVES : (MODE == 3) ? DXTEX_EXH3_WAVES : 1 }; };
 
 
 // What a helper needs of another lane's window.
@@ -952,18 +988,15 @@ __device__ __forceinline__ ExhCtx<LoopCfg<MODE, IM, CHSET>::N> exh_fetch_ctx(con
     return c;
 }
 
-// Mode 4 with 2-bit colour indices would take 217 registers (2 waves per SIMD): capped at 3 waves (168 registers + 168 B of spill), 4.6 -> 3.9 ms.
-#if !defined(DXTEX_EXH45_WGS)
-#define DXTEX_EXH45_WGS 3
-#endif
 #if !defined(DXTEX_RANGE_TESTS)
 #define DXTEX_RANGE_TESTS 5
 #endif
 template<int MODE, int IM, int CHSET>
-__global__ void __launch_bounds__(64, (MODE == 4 || MODE == 5) ? DXTEX_EXH45_WGS : 1) bc7_exhaustive_kernel(Bc7Args a, int loop, int tailBelow, int rangeTests)
+__global__ void __launch_bounds__(64, ExhLists<MODE>::kWaves) bc7_exhaustive_kernel(Bc7Args a, int loop, int tailBelow, int rangeTests)
 {
     typedef LoopCfg<MODE, IM, CHSET> C;
     __shared__ uint32_t sSlot[16 * kSlotStride];             // texel columns, one per lane
+    constexpr int kExhWorkMax = ExhLists<MODE>::kWork, kExhExactMax = ExhLists<MODE>::kExact;
     __shared__ uint32_t sWork[kExhWorkMax];         // pooled candidates to bound: (owner << 8) | code
     __shared__ uint32_t sExact[kExhExactMax];       // candidates to evaluate exactly: (owner << 8) | code
     __shared__ uint32_t sBest[64];                  // per lane: best key of its current window
